@@ -1,0 +1,144 @@
+"""Seeded synthetic LiDAR sweeps shaped like the reference's per-frame dict.
+
+There is no dataset (and no network) in this environment, so every test and
+the benchmark run on frames generated here.  The layout follows the dict that
+the reference reads from ``HDF5Dataset(dir, vis_name=<res>, eval=True)[i]``
+(keys consumed at /root/reference/save_zip.py:113-123 and eval.py:282-310; on-disk
+dtypes at dataprocess/extract_sca.py:78-93 and tools/test/repack_h5_scania.py:23-36)
+and the distributions of SURVEY.md section 8(d).
+
+Pure numpy; no GPU work happens in this module.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# Category indices: "NONE" = 0, then 1-based position in the Argoverse-2 annotation
+# list (reference copy at tools/test/score.py:29-65).
+REGULAR_VEHICLE = 19
+BOX_TRUCK = 6
+BUS = 7
+TRUCK = 25
+PEDESTRIAN = 17
+_VEHICLE_CLASSES = (REGULAR_VEHICLE, REGULAR_VEHICLE, REGULAR_VEHICLE, TRUCK, BUS, BOX_TRUCK)
+
+# network range used by the SeFlow++ launchers (assets/slurm/ssl-train-av2.sh:32)
+POINT_CLOUD_RANGE = (-51.2, -51.2, -3.0, 51.2, 51.2, 3.0)
+
+
+def _yaw_pose(yaw: float, tx: float, ty: float) -> np.ndarray:
+    pose = np.eye(4, dtype=np.float64)
+    c, s = np.cos(yaw), np.sin(yaw)
+    pose[:3, :3] = [[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]]
+    pose[0, 3], pose[1, 3] = tx, ty
+    return pose
+
+
+def make_frame(
+    frame_idx: int,
+    n_points: int = 120_000,
+    n_instances: int = 30,
+    res_name: str = "seflowpp_best",
+    scene_id: str | None = None,
+    est_noise: float = 0.05,
+    data_name: str = "av2",
+) -> dict:
+    """One synthetic sweep as a reference-style frame dict.
+
+    ``flow`` includes ego-motion (the reference subtracts ``pose_flow`` from it,
+    save_zip.py:117); ``<res_name>`` is an "estimated" flow = GT + N(0, est_noise).
+    """
+    rng = np.random.default_rng(frame_idx)
+    n = int(n_points)
+    lo = np.array(POINT_CLOUD_RANGE[:3], dtype=np.float64)
+    hi = np.array(POINT_CLOUD_RANGE[3:], dtype=np.float64)
+
+    xyz = rng.uniform(lo, hi, size=(n, 3))
+    category = np.zeros(n, dtype=np.uint8)
+    instance = np.zeros(n, dtype=np.uint32)
+    obj_flow = np.zeros((n, 3), dtype=np.float64)
+
+    # carve a share of the points into box-shaped moving instances
+    n_instances = int(min(n_instances, max(n // 40, 0)))
+    if n_instances > 0:
+        per_inst = rng.integers(12, max(13, min(5000, n // (2 * n_instances))), size=n_instances)
+        start = 0
+        for k in range(n_instances):
+            cnt = int(per_inst[k])
+            if start + cnt > n:
+                break
+            cls = _VEHICLE_CLASSES[k % len(_VEHICLE_CLASSES)]
+            dims = np.array([4.5, 1.9, 1.6]) if cls == REGULAR_VEHICLE else np.array([10.0, 2.5, 3.2])
+            rad = rng.uniform(4.0, 48.0)
+            ang = rng.uniform(-np.pi, np.pi)
+            centre = np.array([rad * np.cos(ang), rad * np.sin(ang), rng.uniform(-1.6, -0.4)])
+            heading = rng.uniform(-np.pi, np.pi)
+            c, s = np.cos(heading), np.sin(heading)
+            rot = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+            local = rng.uniform(-0.5, 0.5, size=(cnt, 3)) * dims
+            xyz[start:start + cnt] = local @ rot.T + centre
+            speed = rng.uniform(0.0, 35.0)  # m/s, spans the buckets of eval.py:101-108
+            obj_flow[start:start + cnt] = speed * 0.1 * np.array([c, s, 0.0])
+            category[start:start + cnt] = cls
+            instance[start:start + cnt] = k + 1
+            start += cnt
+
+    pc0 = np.empty((n, 4), dtype=np.float32)
+    pc0[:, :3] = xyz.astype(np.float32)
+    pc0[:, 3] = rng.uniform(0.0, 1.0, size=n).astype(np.float32)
+
+    lidar_dt = rng.uniform(0.0, 0.1, size=n).astype(np.float32)
+    lidar_id = rng.integers(1, 7, size=n).astype(np.uint8)
+
+    pose0 = np.eye(4, dtype=np.float64)
+    pose1 = _yaw_pose(np.deg2rad(rng.uniform(-2.0, 2.0)), rng.uniform(-3.0, 3.0), rng.uniform(-0.5, 0.5))
+
+    ego = np.linalg.inv(pose1) @ pose0
+    pose_flow = pc0[:, :3].astype(np.float64) @ ego[:3, :3].T + ego[:3, 3] - pc0[:, :3]
+    flow = (pose_flow + obj_flow + rng.normal(0.0, 0.02, size=(n, 3)) * (instance[:, None] > 0)).astype(np.float32)
+    est = (flow + rng.normal(0.0, est_noise, size=(n, 3)) * (instance[:, None] > 0)).astype(np.float32)
+
+    gm0 = (pc0[:, 2] < -2.6) & (instance == 0)
+    flow_is_valid = rng.uniform(size=n) > 0.01
+
+    return {
+        "scene_id": scene_id if scene_id is not None else f"synthetic-{data_name}-{frame_idx // 8:04d}",
+        "timestamp": 315_965_785_000_000_000 + int(frame_idx) * 100_000_000,
+        "pc0": pc0,
+        "pose0": pose0,
+        "pose1": pose1,
+        "lidar_dt": lidar_dt,
+        "lidar_id": lidar_id,
+        "gm0": gm0,
+        "flow": flow,
+        "flow_is_valid": flow_is_valid,
+        "flow_category_indices": category,
+        "flow_instance_id": instance,
+        res_name: est,
+    }
+
+
+def make_frames(n_frames: int, n_points: int = 120_000, first: int = 0, **kw) -> list[dict]:
+    return [make_frame(first + i, n_points=n_points, **kw) for i in range(n_frames)]
+
+
+class SyntheticDataset:
+    """Sequence of frame dicts with the ``len`` / ``[i]`` protocol of the reference's
+    ``HDF5Dataset`` (constructed at save_zip.py:111, eval.py:279)."""
+
+    def __init__(self, n_frames: int, n_points: int = 120_000, ragged: bool = False, **kw):
+        self.n_frames = int(n_frames)
+        self.n_points = int(n_points)
+        self.ragged = ragged
+        self.kw = kw
+
+    def __len__(self) -> int:
+        return self.n_frames
+
+    def __getitem__(self, i: int) -> dict:
+        if not 0 <= i < self.n_frames:
+            raise IndexError(i)
+        n = self.n_points
+        if self.ragged:  # sweeps differ in point count, as real sweeps do
+            n = max(1, int(n * (0.6 + 0.4 * ((i * 2654435761) % 1000) / 999.0)))
+        return make_frame(i, n_points=n, **self.kw)
