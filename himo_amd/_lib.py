@@ -1,0 +1,138 @@
+"""ctypes binding of libhimo_amd.so (declared in include/himo_amd.h).
+
+There is deliberately NO fallback: if the shared library is missing or a symbol cannot be
+resolved, importing callers get an ImportError that says how to build it; if no GPU is
+visible, the operators raise instead of computing on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint, c_void_p
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("HIMO_AMD_LIB", _PKG / "libhimo_amd.so"))
+
+# name -> (restype, argtypes); mirrors include/himo_amd.h one to one
+SIGNATURES = {
+    "himo_abi_version": (c_int, []),
+    "himo_status_string": (c_char_p, [c_int]),
+    "himo_last_hip_error": (c_char_p, []),
+    "himo_prof_enable": (None, [c_int]),
+    "himo_prof_reset": (None, []),
+    "himo_prof_summary": (c_size_t, [ctypes.c_char_p, c_size_t]),
+    "himo_compdis_workspace_bytes": (c_size_t, [c_int]),
+    "himo_compdis_batch": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                   c_double, c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   ctypes.POINTER(c_float), c_float, c_void_p, c_size_t, c_void_p]),
+    "himo_compdis_frame": (c_int, [c_int64, ctypes.POINTER(c_double), ctypes.POINTER(c_double), c_void_p, c_int,
+                                   c_void_p, c_void_p, c_double, c_uint, c_void_p, c_void_p, c_void_p, c_size_t,
+                                   c_void_p]),
+    "himo_flow2compdis": (c_int, [c_int64, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p]),
+    "himo_refine_pts": (c_int, [c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "himo_ego_pts_mask": (c_int, [c_int64, c_void_p, c_int, ctypes.POINTER(c_float), c_void_p, c_void_p]),
+    "himo_dt0": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+FLAG_F32_CHAIN = 0x1
+FLAG_RAW = 0x2
+FLAG_SCANIA = 0x4
+
+OK, ERR_INVALID_ARGUMENT, ERR_EMPTY_FRAME, ERR_WORKSPACE, ERR_SINGULAR_POSE, ERR_HIP, ERR_UNSUPPORTED = range(7)
+
+_lib = None
+
+
+def register(signatures: dict) -> None:
+    """Let sibling modules declare the entry points of further translation units."""
+    SIGNATURES.update(signatures)
+    if _lib is not None:
+        _bind(_lib, signatures)
+
+
+def _bind(lib, signatures):
+    for name, (restype, argtypes) in signatures.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover - build/ABI mismatch
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild with "
+                              f"`make -C {_PKG / 'csrc'}` (or python -c 'import __graft_entry__ as g; g.build()')") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+
+
+def load():
+    """Load libhimo_amd.so once; raises ImportError (never falls back) if it is absent."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(f"HIP extension {LIB_PATH} is missing -- build it with `make -C {_PKG / 'csrc'}` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = ctypes.CDLL(str(LIB_PATH))
+        _bind(lib, SIGNATURES)
+        if lib.himo_abi_version() != 1:
+            raise ImportError(f"{LIB_PATH}: ABI version {lib.himo_abi_version()} != 1")
+        _lib = lib
+    return _lib
+
+
+class HimoError(RuntimeError):
+    pass
+
+
+def check(status: int, what: str = "") -> None:
+    """Map a himo_status to the exception the reference would raise at the same point."""
+    if status == OK:
+        return
+    lib = load()
+    msg = lib.himo_status_string(status).decode()
+    if status == ERR_EMPTY_FRAME:
+        raise ValueError("max() arg is an empty sequence")          # save_zip.py:120 on an empty sweep
+    if status == ERR_SINGULAR_POSE:
+        import numpy as np
+        raise np.linalg.LinAlgError("Singular matrix")               # save_zip.py:115
+    if status == ERR_HIP:
+        raise HimoError(f"{what}: {msg}: {lib.himo_last_hip_error().decode()}")
+    if status == ERR_INVALID_ARGUMENT:
+        raise ValueError(f"{what}: {msg}")
+    raise HimoError(f"{what}: {msg}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("himo_amd needs a HIP device (MI355X / gfx950); none is visible and there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_handle() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def prof_start():
+    lib = load()
+    lib.himo_prof_reset()
+    lib.himo_prof_enable(1)
+
+
+def prof_stop() -> dict:
+    """{kernel name: {"count", "total_ms", "avg_ms", "min_ms", "max_ms"}} for launches since prof_start()."""
+    lib = load()
+    lib.himo_prof_enable(0)
+    need = lib.himo_prof_summary(None, 0)
+    buf = ctypes.create_string_buffer(int(need) + 16)
+    lib.himo_prof_summary(buf, len(buf))
+    lib.himo_prof_reset()
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, n, tot, mn, mx = line.split()
+        out[name] = {"count": int(n), "total_ms": float(tot), "avg_ms": float(tot) / max(int(n), 1),
+                     "min_ms": float(mn), "max_ms": float(mx)}
+    return out

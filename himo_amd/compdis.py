@@ -1,0 +1,201 @@
+"""Host side of the fused flow -> comp_dis path (stages a1-a6 of SURVEY.md section 8).
+
+Mirrors the body of the reference's per-frame loops (save_zip.py:112-121, eval.py:281-299) but
+works on a ragged BATCH of sweeps resident in HBM, because one 120k-point sweep is ~5 MB --
+less than a microsecond of HBM time on an MI355X.  The arithmetic is in
+himo_amd/csrc/compdis.hip behind the C ABI of include/himo_amd.h.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# `CLOSE_DISTANCE_THRESHOLD` comes from the reference's absent OpenSceneFlow submodule
+# (eval.py:21); 35 m is the Argoverse-2 convention, recorded as unverified in SURVEY.md 0.1.
+CLOSE_DISTANCE_THRESHOLD = 35.0
+# ego boxes: utils/__init__.py:26 (Scania default) and eval.py:296 (everything else)
+EGO_BOX = {
+    "scania": ([-9.5, -3 / 2, 0], [5, 2.760004 / 2, 5]),
+    "av2": ([-1.5, -1.5, -2.0], [1.5, 1.5, 2.0]),
+}
+
+
+@dataclass
+class FrameBatch:
+    """Ragged batch of sweeps laid end to end in HBM (frame f owns rows offsets[f]:offsets[f+1])."""
+    offsets_host: np.ndarray                 # int64 [F+1]
+    offsets: torch.Tensor                    # int64 [F+1]  (device)
+    pose0: torch.Tensor                      # float64 [F,4,4]
+    pose1: torch.Tensor                      # float64 [F,4,4]
+    pc0: torch.Tensor                        # float32 [T,S]
+    lidar_dt: torch.Tensor                   # float32 [T]
+    flow: torch.Tensor | None = None         # float32 [T,3]  (None => "raw")
+    gm0: torch.Tensor | None = None          # uint8 [T]
+    flow_is_valid: torch.Tensor | None = None
+    f32_chain: bool = False                  # numpy would have computed in float32 (float32 poses)
+    meta: list = field(default_factory=list)  # (scene_id, timestamp) per frame
+
+    @property
+    def n_frames(self) -> int:
+        return len(self.offsets_host) - 1
+
+    @property
+    def total_points(self) -> int:
+        return int(self.offsets_host[-1])
+
+    def split(self, t: torch.Tensor) -> list[torch.Tensor]:
+        """Per-frame views of a per-point tensor."""
+        o = self.offsets_host
+        return [t[int(o[i]):int(o[i + 1])] for i in range(self.n_frames)]
+
+    @classmethod
+    def from_frames(cls, frames, res_name: str | None = "seflowpp_best", device=None, with_masks: bool = False):
+        """Pack reference-style frame dicts.  ``res_name`` "raw"/None => no flow (save_zip.py:117).
+        A missing result key raises ``KeyError`` exactly where the reference's ``data[res_name]`` does."""
+        dev = device if device is not None else _lib.require_gpu()
+        frames = list(frames)
+        if not frames:
+            raise ValueError("empty batch")
+        raw = res_name in (None, "raw")
+        counts = [int(np.asarray(f["pc0"]).shape[0]) for f in frames]
+        offsets = np.zeros(len(frames) + 1, dtype=np.int64)
+        np.cumsum(counts, out=offsets[1:])
+        stride = int(np.asarray(frames[0]["pc0"]).shape[1])
+
+        def cat(key, dtype, width=None):
+            parts = []
+            for f, n in zip(frames, counts):
+                a = np.asarray(f[key])
+                if a.shape[0] != n:
+                    raise ValueError(f"{key}: {a.shape[0]} rows for a sweep of {n} points")
+                parts.append(a.astype(dtype, copy=False))
+            host = np.concatenate(parts, axis=0) if parts else np.empty((0,) if width is None else (0, width), dtype)
+            return torch.from_numpy(np.ascontiguousarray(host)).to(dev, non_blocking=False)
+
+        pose_dtypes = {np.asarray(f[k]).dtype for f in frames for k in ("pose0", "pose1")}
+        f32_chain = all(dt == np.float32 for dt in pose_dtypes)
+        pose0 = torch.from_numpy(np.stack([np.asarray(f["pose0"], dtype=np.float64) for f in frames])).to(dev)
+        pose1 = torch.from_numpy(np.stack([np.asarray(f["pose1"], dtype=np.float64) for f in frames])).to(dev)
+        b = cls(
+            offsets_host=offsets,
+            offsets=torch.from_numpy(offsets).to(dev),
+            pose0=pose0, pose1=pose1,
+            pc0=cat("pc0", np.float32, stride),
+            lidar_dt=cat("lidar_dt", np.float32),
+            flow=None if raw else cat(res_name, np.float32, 3),
+            f32_chain=f32_chain,
+            meta=[(f.get("scene_id"), f.get("timestamp")) for f in frames],
+        )
+        if with_masks:
+            b.gm0 = cat("gm0", np.uint8)
+            if all("flow_is_valid" in f for f in frames):
+                b.flow_is_valid = cat("flow_is_valid", np.uint8)
+        return b
+
+
+class CompDisEngine:
+    """Owns the (tiny) workspace and launches the two kernels of the fused path."""
+
+    def __init__(self, device=None, max_frames: int = 1):
+        self.lib = _lib.load()
+        self.device = device if device is not None else _lib.require_gpu()
+        self._ws = None
+        self._reserve(max_frames)
+
+    def _reserve(self, n_frames: int):
+        need = int(self.lib.himo_compdis_workspace_bytes(n_frames))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need + 64, dtype=torch.uint8, device=self.device)
+        return need
+
+    def run(self, batch: FrameBatch, sensor_dt: float = 0.1, refined: bool = False, data_name: str | None = None,
+            out: dict | None = None) -> dict:
+        """comp_dis (T,3) f32 [+ refined (T,3) f32] [+ eval_mask (T,) uint8 when ``data_name`` is given].
+        Asynchronous on the current stream; ``out`` may carry preallocated tensors to reuse."""
+        b = batch
+        self._reserve(b.n_frames)
+        T = b.total_points
+        out = {} if out is None else out
+        cd = out.get("comp_dis")
+        if cd is None:
+            cd = out["comp_dis"] = torch.empty((T, 3), dtype=torch.float32, device=self.device)
+        rf = None
+        if refined:
+            rf = out.get("refined")
+            if rf is None:
+                rf = out["refined"] = torch.empty((T, 3), dtype=torch.float32, device=self.device)
+        flags = (_lib.FLAG_F32_CHAIN if b.f32_chain else 0) | (_lib.FLAG_RAW if b.flow is None else 0)
+        mask = valid = bounds = None
+        if data_name is not None:
+            if b.gm0 is None:
+                raise KeyError("gm0")                                  # eval.py:290 reads data['gm0']
+            mask = out.get("eval_mask")
+            if mask is None:
+                mask = out["eval_mask"] = torch.empty(T, dtype=torch.uint8, device=self.device)
+            lo, hi = EGO_BOX["scania" if data_name == "scania" else "av2"]
+            bounds = (ctypes.c_float * 6)(*[float(v) for v in lo + hi])
+            if data_name == "scania":
+                if b.flow_is_valid is None:
+                    raise KeyError("flow_is_valid")                    # eval.py:294
+                flags |= _lib.FLAG_SCANIA
+                valid = b.flow_is_valid
+        st = self.lib.himo_compdis_batch(
+            b.n_frames, T, _lib.ptr(b.offsets), _lib.ptr(b.pose0), _lib.ptr(b.pose1), _lib.ptr(b.pc0), b.pc0.shape[1],
+            _lib.ptr(b.flow), _lib.ptr(b.lidar_dt), float(sensor_dt), flags, _lib.ptr(cd), _lib.ptr(rf), _lib.ptr(mask),
+            _lib.ptr(b.gm0), _lib.ptr(valid), bounds, float(CLOSE_DISTANCE_THRESHOLD), _lib.ptr(self._ws),
+            self._ws.numel(), _lib.stream_handle())
+        _lib.check(st, "himo_compdis_batch")
+        return out
+
+    def run_frame(self, pc0: torch.Tensor, flow: torch.Tensor | None, lidar_dt: torch.Tensor, pose0, pose1,
+                  sensor_dt: float = 0.1, refined: bool = False):
+        """One sweep with host poses -- the loop body of save_zip.py:113-121."""
+        self._reserve(1)
+        n = pc0.shape[0]
+        p0 = np.ascontiguousarray(pose0)
+        p1 = np.ascontiguousarray(pose1)
+        f32_chain = p0.dtype == np.float32 and p1.dtype == np.float32
+        p0 = p0.astype(np.float64).ravel()
+        p1 = p1.astype(np.float64).ravel()
+        cd = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        rf = torch.empty((n, 3), dtype=torch.float32, device=self.device) if refined else None
+        flags = (_lib.FLAG_F32_CHAIN if f32_chain else 0) | (_lib.FLAG_RAW if flow is None else 0)
+        dptr = ctypes.POINTER(ctypes.c_double)
+        st = self.lib.himo_compdis_frame(n, p0.ctypes.data_as(dptr), p1.ctypes.data_as(dptr), _lib.ptr(pc0), pc0.shape[1],
+                                         _lib.ptr(flow), _lib.ptr(lidar_dt), float(sensor_dt), flags, _lib.ptr(cd),
+                                         _lib.ptr(rf), _lib.ptr(self._ws), self._ws.numel(), _lib.stream_handle())
+        _lib.check(st, "himo_compdis_frame")
+        return (cd, rf) if refined else cd
+
+
+_default_engine: CompDisEngine | None = None
+
+
+def default_engine() -> CompDisEngine:
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = CompDisEngine()
+    return _default_engine
+
+
+def comp_dis_frame(data: dict, res_name: str, sensor_dt: float = 0.1) -> np.ndarray:
+    """Drop-in for the body of the loop at save_zip.py:113-121: frame dict -> (N,3) float32
+    ``comp_dis`` as a numpy array (what the reference hands to ``write_output_file``)."""
+    eng = default_engine()
+    dev = eng.device
+    pc0 = torch.from_numpy(np.ascontiguousarray(data["pc0"], dtype=np.float32)).to(dev)
+    dt = torch.from_numpy(np.ascontiguousarray(data["lidar_dt"], dtype=np.float32)).to(dev)
+    flow = None
+    if res_name != "raw":
+        flow = torch.from_numpy(np.ascontiguousarray(data[res_name], dtype=np.float32)).to(dev)   # KeyError as the reference
+        if flow.shape != (pc0.shape[0], 3):
+            raise ValueError(f"operands could not be broadcast together with shapes {tuple(flow.shape)} {(pc0.shape[0], 3)}")
+    if dt.shape[0] != pc0.shape[0]:
+        raise ValueError(f"operands could not be broadcast together with shapes {(pc0.shape[0], 3)} {tuple(dt.shape)}")
+    cd = eng.run_frame(pc0, flow, dt, data["pose0"], data["pose1"], sensor_dt=sensor_dt)
+    return cd.cpu().numpy()

@@ -1,0 +1,132 @@
+/*
+ * himo_amd.h -- C ABI of libhimo_amd.so: the MI355X (gfx950) motion-compensation hot path
+ * of KTH-RPL/HiMo.
+ *
+ * The reference has no native layer: its per-frame path is numpy code
+ * inside two Python loops.  This ABI is what a maintainer of the reference would bind with
+ * ctypes to replace that arithmetic (binding shown in INTEGRATION.md).  Each entry point
+ * cites the reference lines it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - plain C types only; every `d_*` pointer is DEVICE memory (HBM), every `h_*` pointer is
+ *     HOST memory; the caller owns all buffers, the library never allocates or frees;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); every call is
+ *     asynchronous on that stream unless stated, re-entrant per stream, and holds no global
+ *     state;
+ *   - row-major arrays; point rows are `pc_stride` floats apart (3 = xyz, 4 = xyzi as the
+ *     reference's `pc0`); 16-byte aligned base pointers take the vectorised path;
+ *   - every function returns a himo_status; HIMO_OK == 0.  The Python host layer turns a
+ *     non-zero status into the exception the reference would raise (ValueError / KeyError).
+ */
+#ifndef HIMO_AMD_H
+#define HIMO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIMO_ABI_VERSION 1
+
+typedef enum himo_status {
+    HIMO_OK = 0,
+    HIMO_ERR_INVALID_ARGUMENT = 1, /* NULL where data is required, negative sizes, bad stride */
+    HIMO_ERR_EMPTY_FRAME = 2,      /* reference: `max()` of an empty lidar_dt raises ValueError (save_zip.py:120) */
+    HIMO_ERR_WORKSPACE = 3,        /* workspace smaller than himo_*_workspace_bytes() */
+    HIMO_ERR_SINGULAR_POSE = 4,    /* reference: np.linalg.inv raises LinAlgError (save_zip.py:115) */
+    HIMO_ERR_HIP = 5,              /* a HIP runtime call failed; see himo_last_hip_error() */
+    HIMO_ERR_UNSUPPORTED = 6
+} himo_status;
+
+/* flags for the comp_dis entry points */
+#define HIMO_FLAG_F32_CHAIN 0x1u /* do the arithmetic in float32: what numpy does when the poses are
+                                    float32 (dataprocess/extract_sca.py:232); default is the float64
+                                    chain numpy runs for float64 poses, rounded to f32 at the end
+                                    exactly where save_zip.py:70-72 casts */
+#define HIMO_FLAG_RAW 0x2u       /* res_name == "raw": est_flow = zeros (save_zip.py:117) */
+#define HIMO_FLAG_SCANIA 0x4u    /* eval mask also requires flow_is_valid (eval.py:293-294) */
+
+int himo_abi_version(void);
+const char* himo_status_string(int status);
+/* text of the last HIP error seen by this thread (empty string if none) */
+const char* himo_last_hip_error(void);
+
+/* Optional per-kernel timing (used by bench.py for the roofline figure): while enabled, every
+ * kernel launch of this library is bracketed by two HIP events on its own stream.
+ * himo_prof_summary waits for the recorded launches and writes one line per kernel name:
+ * "<name> <count> <total_ms> <min_ms> <max_ms>\n"; returns the bytes needed (incl. NUL). */
+void himo_prof_enable(int on);
+void himo_prof_reset(void);
+size_t himo_prof_summary(char* buf, size_t cap);
+
+/* ---------------------------------------------------------------------------------------------
+ * a1-a4 (+a5/a6): flow -> per-point de-distortion offsets, batched over ragged frames.
+ *
+ * Replaces, per frame f with rows [offsets[f], offsets[f+1]):
+ *     ego_pose  = inv(pose1) @ pose0                                   save_zip.py:115  eval.py:284
+ *     pose_flow = pc0[:, :3] @ ego_pose[:3,:3].T + ego_pose[:3,3] - pc0[:, :3]    save_zip.py:116
+ *     est_flow  = flow - pose_flow            (zeros when RAW)          save_zip.py:117
+ *     dt0       = max(lidar_dt) - lidar_dt                             save_zip.py:120
+ *     comp_dis  = est_flow / sensor_dt * dt0[:, None]    utils/__init__.py:43, save_zip.py:121
+ *     refined   = pc0[:, :3] + comp_dis                  utils/__init__.py:46     (optional)
+ *     eval_mask = |pc0.xy| <= close_distance & ~gm0 & ego_pts_mask(pc0) [& flow_is_valid]
+ *                                                         eval.py:288-296         (optional)
+ *
+ * d_offsets   int64[n_frames+1], non-decreasing, offsets[0] == 0, offsets[n_frames] == total_points
+ * d_pose0/1   double[n_frames][16], row-major 4x4 (`pose0`, `pose1` of the frame dict)
+ * d_pc0       float[total_points][pc_stride]; d_flow float[total_points][3] (ignored when RAW);
+ * d_lidar_dt  float[total_points]
+ * d_comp_dis  float[total_points][3]  (out)
+ * d_refined   float[total_points][3]  (out, may be NULL)
+ * d_eval_mask uint8[total_points]     (out, may be NULL; then the four arguments below are unused)
+ * d_gm0, d_flow_is_valid  uint8/bool[total_points]  (d_flow_is_valid may be NULL unless SCANIA)
+ * mask_bounds float[6] HOST: ego box min xyz, max xyz (utils/__init__.py:26; eval.py:296)
+ * d_workspace at least himo_compdis_workspace_bytes(n_frames) bytes, 16-byte aligned.
+ *
+ * Frames with zero points are skipped (the single-frame wrapper reports HIMO_ERR_EMPTY_FRAME).
+ * NaN entries of lidar_dt are ignored by the max.  A singular pose1 yields NaN outputs for that
+ * frame (the single-frame wrapper reports HIMO_ERR_SINGULAR_POSE instead).
+ */
+size_t himo_compdis_workspace_bytes(int n_frames);
+
+int himo_compdis_batch(int n_frames, int64_t total_points,
+                       const int64_t* d_offsets, const double* d_pose0, const double* d_pose1,
+                       const float* d_pc0, int pc_stride, const float* d_flow, const float* d_lidar_dt,
+                       double sensor_dt, unsigned flags,
+                       float* d_comp_dis, float* d_refined,
+                       uint8_t* d_eval_mask, const uint8_t* d_gm0, const uint8_t* d_flow_is_valid,
+                       const float* h_mask_bounds, float close_distance,
+                       void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* One frame with host-side scalars: the body of the loop at save_zip.py:112-121.  Uploads the two
+ * poses into the workspace (a small blocking copy), then runs the batch path with n_frames = 1. */
+int himo_compdis_frame(int64_t n_points, const double* h_pose0, const double* h_pose1,
+                       const float* d_pc0, int pc_stride, const float* d_flow, const float* d_lidar_dt,
+                       double sensor_dt, unsigned flags,
+                       float* d_comp_dis, float* d_refined,
+                       void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The three functions of utils/__init__.py as stand-alone element-wise operators.
+ * `dtype_is_f64` selects float64 flow/out arrays (numpy's result for float64 poses).
+ */
+/* utils/__init__.py:36-43  out = flow / sensor_dt * dt0[:, None];  flow,out: [n][3]; dt0: [n]
+ * dtype_flags bit 0: flow and out are float64 (else float32); bit 1: dt0 is float64 (needs bit 0,
+ * numpy's promotion rule) */
+int himo_flow2compdis(int64_t n, const void* d_flow, const void* d_dt0, double sensor_dt,
+                      int dtype_flags, void* d_out, void* stream);
+/* utils/__init__.py:45-47  out = pc[:, :3] + ds;  pc float[n][pc_stride]; ds,out [n][3] */
+int himo_refine_pts(int64_t n, const float* d_pc, int pc_stride, const void* d_ds,
+                    int dtype_is_f64, void* d_out, void* stream);
+/* utils/__init__.py:26-34  out[i] = 1 when point i is OUTSIDE the open box (min,max) */
+int himo_ego_pts_mask(int64_t n, const float* d_pts, int pc_stride, const float* h_bounds,
+                      uint8_t* d_out, void* stream);
+/* save_zip.py:120 / eval.py:299  dt0 = max(lidar_dt) - lidar_dt  (one frame; d_workspace >= 32 bytes, 16-byte aligned) */
+int himo_dt0(int64_t n, const float* d_lidar_dt, float* d_dt0, void* d_workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIMO_AMD_H */

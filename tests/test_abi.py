@@ -1,0 +1,70 @@
+"""The C-ABI library loads and exports every symbol include/*.h declares (CPU only, no compute)."""
+import ctypes
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def declared_symbols():
+    names = []
+    for h in sorted((REPO / "include").glob("*.h")):
+        text = re.sub(r"/\*.*?\*/", "", h.read_text(), flags=re.S)
+        names += re.findall(r"\b(himo_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_header_declares_entry_points():
+    syms = declared_symbols()
+    assert "himo_compdis_batch" in syms and "himo_compdis_frame" in syms and len(syms) >= 10
+
+
+def test_library_exports_every_declared_symbol():
+    from himo_amd import _lib
+    lib = _lib.load()
+    raw = ctypes.CDLL(str(_lib.LIB_PATH))
+    for name in declared_symbols():
+        assert hasattr(raw, name), f"{name} declared in include/ but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in himo_amd/_lib.py"
+    assert lib.himo_abi_version() == 1
+    assert lib.himo_status_string(0) == b"ok"
+    assert b"empty" in lib.himo_status_string(2)
+    assert lib.himo_compdis_workspace_bytes(1) >= 4 + 96
+    assert lib.himo_compdis_workspace_bytes(256) >= 256 * 100
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from himo_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_no_gpu_means_error_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import numpy as np
+    from himo_amd import utils
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        utils.flow2compDis(np.zeros((4, 3), np.float32), np.zeros(4, np.float32), 0.1)
+
+
+def test_status_to_exception_mapping():
+    import numpy as np
+    from himo_amd import _lib
+    with pytest.raises(ValueError, match="empty sequence"):
+        _lib.check(_lib.ERR_EMPTY_FRAME)
+    with pytest.raises(np.linalg.LinAlgError):
+        _lib.check(_lib.ERR_SINGULAR_POSE)
+    with pytest.raises(ValueError):
+        _lib.check(_lib.ERR_INVALID_ARGUMENT, "x")
+    _lib.check(_lib.OK)
+
+
+def test_product_never_imports_the_oracle():
+    for p in (REPO / "himo_amd").rglob("*.py"):
+        src = p.read_text()
+        assert "himo_oracle" not in src and "seflow_oracle" not in src and "from oracle" not in src, p

@@ -1,0 +1,81 @@
+"""Host-side logic that needs no GPU: dataset sniffing, batch packing, synthetic frames, datasets."""
+import numpy as np
+import pytest
+import torch
+
+from himo_amd import utils
+from himo_amd.compdis import FrameBatch
+from himo_amd.dataset import ListDataset, NpzDataset
+from himo_amd.synthetic import SyntheticDataset, make_frame
+
+
+def test_check_valid_quirks(tmp_path, capsys):
+    assert utils.check_valid("/data/scania/val", "x") == ("scania", 2)
+    assert utils.check_valid("/data/Scania/val", "x") == ("scania", 2)
+    assert utils.check_valid("/data/av2/h5", "x")[0] == "av2"
+    assert utils.check_valid("/data/AV2/h5", "x")[0] == "av2"
+    with pytest.raises(ValueError):
+        utils.check_valid("/data/nuscenes", "x")
+    with pytest.raises(ValueError):                     # name at position 0 does not count (find() > 0)
+        utils.check_valid("av2/h5", "x")
+    z = tmp_path / "a.zip"
+    z.write_bytes(b"")
+    assert utils.check_valid("/data/av2", "x", str(z)) == ("av2", 1)
+    assert utils.check_valid("/data/av2", "x", str(tmp_path / "missing.zip")) == ("av2", 2)
+    assert "comp_dis_zip" in capsys.readouterr().out
+
+
+def test_synthetic_frame_contract():
+    f = make_frame(3, n_points=5000)
+    assert f["pc0"].shape == (5000, 4) and f["pc0"].dtype == np.float32
+    assert f["pose0"].dtype == np.float64 and f["pose1"].shape == (4, 4)
+    assert f["lidar_dt"].dtype == np.float32 and 0 <= f["lidar_dt"].min() and f["lidar_dt"].max() <= 0.1
+    assert f["flow"].dtype == np.float32 and f["seflowpp_best"].shape == (5000, 3)
+    assert f["flow_category_indices"].dtype == np.uint8 and f["flow_instance_id"].dtype == np.uint32
+    assert f["gm0"].dtype == bool and f["flow_is_valid"].dtype == bool
+    g = make_frame(3, n_points=5000)
+    assert all(np.array_equal(f[k], g[k]) for k in f if isinstance(f[k], np.ndarray))   # seeded
+    assert len(np.unique(f["flow_instance_id"])) > 5
+
+
+def test_frame_batch_packing_ragged():
+    frames = [make_frame(i, n_points=n) for i, n in enumerate([100, 1, 257, 64])]
+    b = FrameBatch.from_frames(frames, "seflowpp_best", device=torch.device("cpu"), with_masks=True)
+    assert b.n_frames == 4 and b.total_points == 422
+    assert b.offsets_host.tolist() == [0, 100, 101, 358, 422]
+    assert b.pc0.shape == (422, 4) and b.flow.shape == (422, 3) and b.gm0.dtype == torch.uint8
+    assert not b.f32_chain
+    parts = b.split(b.lidar_dt)
+    assert [len(p) for p in parts] == [100, 1, 257, 64]
+    assert np.array_equal(parts[2].numpy(), frames[2]["lidar_dt"])
+    raw = FrameBatch.from_frames(frames, "raw", device=torch.device("cpu"))
+    assert raw.flow is None
+    with pytest.raises(KeyError):
+        FrameBatch.from_frames(frames, "no_such_result", device=torch.device("cpu"))
+    f32 = [dict(f, pose0=f["pose0"].astype(np.float32), pose1=f["pose1"].astype(np.float32)) for f in frames]
+    assert FrameBatch.from_frames(f32, "raw", device=torch.device("cpu")).f32_chain
+
+
+def test_datasets_roundtrip(tmp_path):
+    frames = [make_frame(i, n_points=300) for i in range(5)]
+    NpzDataset.write(tmp_path, frames, eval_subset=[1, 3])
+    full = NpzDataset(tmp_path)
+    ev = NpzDataset(tmp_path, eval=True)
+    assert len(full) == 5 and len(ev) == 2
+    assert ev[1]["timestamp"] == frames[3]["timestamp"] and ev[1]["scene_id"] == frames[3]["scene_id"]
+    assert np.array_equal(full[2]["pc0"], frames[2]["pc0"])
+    assert len(ListDataset(frames)) == 5
+    ds = SyntheticDataset(4, n_points=1000, ragged=True)
+    assert len(ds) == 4 and len({len(ds[i]["pc0"]) for i in range(4)}) > 1
+    with pytest.raises(IndexError):
+        ds[4]
+
+
+def test_hdf5_dataset_says_what_is_missing(tmp_path):
+    from himo_amd.dataset import HDF5Dataset
+    try:
+        import h5py  # noqa: F401
+        pytest.skip("h5py present")
+    except ImportError:
+        with pytest.raises(ImportError, match="h5py"):
+            HDF5Dataset(tmp_path)
