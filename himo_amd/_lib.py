@@ -38,6 +38,7 @@ SIGNATURES = {
 FLAG_F32_CHAIN = 0x1
 FLAG_RAW = 0x2
 FLAG_SCANIA = 0x4
+FLAG_POSE_IS_EGO = 0x8
 
 OK, ERR_INVALID_ARGUMENT, ERR_EMPTY_FRAME, ERR_WORKSPACE, ERR_SINGULAR_POSE, ERR_HIP, ERR_UNSUPPORTED = range(7)
 
@@ -69,6 +70,9 @@ def load():
         if not LIB_PATH.exists():
             raise ImportError(f"HIP extension {LIB_PATH} is missing -- build it with `make -C {_PKG / 'csrc'}` "
                               "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # torch first: libhimo_amd.so must bind to the HIP runtime torch ships (one runtime per process);
+        # loading it before torch would pull in /opt/rocm's libamdhip64 as a second, device-less runtime
+        import torch  # noqa: F401
         lib = ctypes.CDLL(str(LIB_PATH))
         _bind(lib, SIGNATURES)
         if lib.himo_abi_version() != 1:

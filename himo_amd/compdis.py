@@ -153,20 +153,33 @@ class CompDisEngine:
         return out
 
     def run_frame(self, pc0: torch.Tensor, flow: torch.Tensor | None, lidar_dt: torch.Tensor, pose0, pose1,
-                  sensor_dt: float = 0.1, refined: bool = False):
-        """One sweep with host poses -- the loop body of save_zip.py:113-121."""
+                  sensor_dt: float = 0.1, refined: bool = False, host_ego: bool = True):
+        """One sweep with host poses -- the loop body of save_zip.py:113-121.
+
+        ``host_ego=True`` computes ``ego_pose = inv(pose1) @ pose0`` with numpy in the poses' own dtype, the
+        very expression of save_zip.py:115 (so a singular pose raises numpy's own ``LinAlgError`` and the
+        4x4 bits are the reference's); ``False`` leaves the inverse to the library (float64 LU)."""
         self._reserve(1)
         n = pc0.shape[0]
-        p0 = np.ascontiguousarray(pose0)
-        p1 = np.ascontiguousarray(pose1)
-        f32_chain = p0.dtype == np.float32 and p1.dtype == np.float32
-        p0 = p0.astype(np.float64).ravel()
-        p1 = p1.astype(np.float64).ravel()
+        p0 = np.asarray(pose0)
+        p1 = np.asarray(pose1)
+        flags = _lib.FLAG_RAW if flow is None else 0
+        dptr = ctypes.POINTER(ctypes.c_double)
+        if host_ego:
+            ego = np.linalg.inv(p1) @ p0                                  # save_zip.py:115
+            f32_chain = ego.dtype == np.float32
+            a = np.ascontiguousarray(ego, dtype=np.float64).ravel()
+            b_ptr = None
+            flags |= _lib.FLAG_POSE_IS_EGO
+        else:
+            f32_chain = p0.dtype == np.float32 and p1.dtype == np.float32
+            a = np.ascontiguousarray(p0, dtype=np.float64).ravel()
+            b = np.ascontiguousarray(p1, dtype=np.float64).ravel()
+            b_ptr = b.ctypes.data_as(dptr)
+        flags |= _lib.FLAG_F32_CHAIN if f32_chain else 0
         cd = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         rf = torch.empty((n, 3), dtype=torch.float32, device=self.device) if refined else None
-        flags = (_lib.FLAG_F32_CHAIN if f32_chain else 0) | (_lib.FLAG_RAW if flow is None else 0)
-        dptr = ctypes.POINTER(ctypes.c_double)
-        st = self.lib.himo_compdis_frame(n, p0.ctypes.data_as(dptr), p1.ctypes.data_as(dptr), _lib.ptr(pc0), pc0.shape[1],
+        st = self.lib.himo_compdis_frame(n, a.ctypes.data_as(dptr), b_ptr, _lib.ptr(pc0), pc0.shape[1],
                                          _lib.ptr(flow), _lib.ptr(lidar_dt), float(sensor_dt), flags, _lib.ptr(cd),
                                          _lib.ptr(rf), _lib.ptr(self._ws), self._ws.numel(), _lib.stream_handle())
         _lib.check(st, "himo_compdis_frame")
@@ -183,7 +196,7 @@ def default_engine() -> CompDisEngine:
     return _default_engine
 
 
-def comp_dis_frame(data: dict, res_name: str, sensor_dt: float = 0.1) -> np.ndarray:
+def comp_dis_frame(data: dict, res_name: str, sensor_dt: float = 0.1, host_ego: bool = True) -> np.ndarray:
     """Drop-in for the body of the loop at save_zip.py:113-121: frame dict -> (N,3) float32
     ``comp_dis`` as a numpy array (what the reference hands to ``write_output_file``)."""
     eng = default_engine()
@@ -197,5 +210,5 @@ def comp_dis_frame(data: dict, res_name: str, sensor_dt: float = 0.1) -> np.ndar
             raise ValueError(f"operands could not be broadcast together with shapes {tuple(flow.shape)} {(pc0.shape[0], 3)}")
     if dt.shape[0] != pc0.shape[0]:
         raise ValueError(f"operands could not be broadcast together with shapes {(pc0.shape[0], 3)} {tuple(dt.shape)}")
-    cd = eng.run_frame(pc0, flow, dt, data["pose0"], data["pose1"], sensor_dt=sensor_dt)
+    cd = eng.run_frame(pc0, flow, dt, data["pose0"], data["pose1"], sensor_dt=sensor_dt, host_ego=host_ego)
     return cd.cpu().numpy()

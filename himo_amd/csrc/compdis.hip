@@ -60,53 +60,75 @@ __device__ inline int find_frame(const int64_t* __restrict__ offsets, int n_fram
     return lo;
 }
 
-// ego = inv(pose1) @ pose0 in float64 (save_zip.py:115): LU with partial pivoting, explicit
-// inverse, then a k-ordered 4x4 product -- the same sequence numpy's inv + matmul perform.
+// ego = inv(pose1) @ pose0 in float64 (save_zip.py:115): LU with partial pivoting (first maximal
+// pivot, as LAPACK's idamax), explicit inverse by forward/back substitution on the identity, then
+// a k-ordered 4x4 product -- the sequence numpy's inv + matmul perform.  Everything is unrolled with
+// compile-time indices (row swaps are predicated selects) so it lives in registers.
+__device__ inline void swap_if(bool c, double& x, double& y) { const double tx = c ? y : x, ty = c ? x : y; x = tx; y = ty; }
+
 __device__ inline void compute_ego(const double* __restrict__ p0, const double* __restrict__ p1, FrameXf* out) {
-    double a[4][4], inv[4][4];
-    int piv[4];
+    double a[4][4], b[4][4];   // b starts as the identity and ends as inv(pose1)
+#pragma unroll
     for (int r = 0; r < 4; ++r)
-        for (int c = 0; c < 4; ++c) a[r][c] = p1[r * 4 + c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { a[r][c] = p1[r * 4 + c]; b[r][c] = r == c ? 1.0 : 0.0; }
     bool singular = false;
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
         int p = k;
         double best = fabs(a[k][k]);
+#pragma unroll
         for (int r = k + 1; r < 4; ++r)
             if (fabs(a[r][k]) > best) { best = fabs(a[r][k]); p = r; }
-        piv[k] = p;
-        if (!(best > 0.0)) { singular = true; break; }
-        if (p != k)
-            for (int c = 0; c < 4; ++c) { double tmp = a[k][c]; a[k][c] = a[p][c]; a[p][c] = tmp; }
-        double rp = 1.0 / a[k][k];
+        singular = singular || !(best > 0.0);
+#pragma unroll
+        for (int r = k + 1; r < 4; ++r) {
+            const bool sw = p == r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { swap_if(sw, a[k][c], a[r][c]); swap_if(sw, b[k][c], b[r][c]); }
+        }
+        const double rp = 1.0 / a[k][k];
+#pragma unroll
         for (int r = k + 1; r < 4; ++r) {
             a[r][k] *= rp;
+#pragma unroll
             for (int c = k + 1; c < 4; ++c) a[r][c] -= a[r][k] * a[k][c];
         }
     }
-    if (singular) {
-        for (int i = 0; i < 9; ++i) out->R[i] = NAN;
-        for (int i = 0; i < 3; ++i) out->t[i] = NAN;
-        return;
-    }
+    // L y = P I (unit lower), then U x = y, column by column
+#pragma unroll
     for (int col = 0; col < 4; ++col) {
-        double b[4] = {0, 0, 0, 0};
-        b[col] = 1.0;
-        for (int k = 0; k < 4; ++k)
-            if (piv[k] != k) { double tmp = b[k]; b[k] = b[piv[k]]; b[piv[k]] = tmp; }
+#pragma unroll
         for (int r = 1; r < 4; ++r)
-            for (int c = 0; c < r; ++c) b[r] -= a[r][c] * b[c];
+#pragma unroll
+            for (int c = 0; c < r; ++c) b[r][col] -= a[r][c] * b[c][col];
+#pragma unroll
         for (int r = 3; r >= 0; --r) {
-            for (int c = r + 1; c < 4; ++c) b[r] -= a[r][c] * b[c];
-            b[r] /= a[r][r];
+#pragma unroll
+            for (int c = r + 1; c < 4; ++c) b[r][col] -= a[r][c] * b[c][col];
+            b[r][col] /= a[r][r];
         }
-        for (int r = 0; r < 4; ++r) inv[r][col] = b[r];
     }
+#pragma unroll
     for (int r = 0; r < 3; ++r)
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
-            double s = inv[r][0] * p0[c];
-            for (int k = 1; k < 4; ++k) s = fma(inv[r][k], p0[k * 4 + c], s);
+            double s = b[r][0] * p0[c];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) s = fma(b[r][k], p0[k * 4 + c], s);
+            if (singular) s = NAN;
             if (c < 3) out->R[r * 3 + c] = s; else out->t[r] = s;
         }
+}
+
+// the caller already holds ego = inv(pose1) @ pose0 (HIMO_FLAG_POSE_IS_EGO): copy it through
+__device__ inline void copy_ego(const double* __restrict__ e, FrameXf* out) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out->R[r * 3 + c] = e[r * 4 + c];
+        out->t[r] = e[r * 4 + 3];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -117,48 +139,69 @@ __device__ inline float wave_max(float v) {
     return v;
 }
 
+__device__ inline void block_max_to_key(float m, unsigned* key) {
+    __shared__ float wmax[kPrepThreads / 64];
+    m = wave_max(m);
+    __syncthreads();   // wmax may still be read by the previous round
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = wmax[0];
+#pragma unroll
+        for (int w = 1; w < kPrepThreads / 64; ++w) r = fmaxf(r, wmax[w]);
+        if (r > -INFINITY) atomicMax(key, float_to_key(r));
+    }
+}
+
+// ego_mode: 0 = no poses (himo_dt0), 1 = pose0/pose1 given, 2 = pose0 holds the ego transform
 __global__ __launch_bounds__(kPrepThreads) void frame_prep_kernel(
-    int n_frames, int64_t total, int n_chunks, const int64_t* __restrict__ offsets,
+    int n_frames, int64_t total, int n_chunks, int ego_mode, const int64_t* __restrict__ offsets,
     const double* __restrict__ pose0, const double* __restrict__ pose1,
     const float* __restrict__ lidar_dt, unsigned* __restrict__ keys, FrameXf* __restrict__ xf) {
     const int b = blockIdx.x;
-    if (b < n_frames && threadIdx.x == 0 && pose0 != nullptr) compute_ego(pose0 + 16 * (size_t)b, pose1 + 16 * (size_t)b, &xf[b]);
-    if (b >= n_chunks) return;
-
+    if (b >= n_chunks) {   // surplus blocks: one thread per frame does the 4x4 work
+        const int f = (b - n_chunks) * kPrepThreads + threadIdx.x;
+        if (f < n_frames) {
+            if (ego_mode == 1) compute_ego(pose0 + 16 * (size_t)f, pose1 + 16 * (size_t)f, &xf[f]);
+            else if (ego_mode == 2) copy_ego(pose0 + 16 * (size_t)f, &xf[f]);
+        }
+        return;
+    }
     const int64_t start = (int64_t)b * kPrepChunk;
     const int64_t end = start + kPrepChunk < total ? start + kPrepChunk : total;
-    const int f0 = find_frame(offsets, n_frames, start);
-    const bool one_frame = offsets[f0 + 1] >= end;   // block-uniform
+    const int f0 = __builtin_amdgcn_readfirstlane(find_frame(offsets, n_frames, start));
+    const bool vec = (reinterpret_cast<uintptr_t>(lidar_dt) & 15u) == 0;
 
-    if (one_frame) {
+    float v[kPrepChunk / kPrepThreads];   // this thread's 16 elements; -inf where out of range
+#pragma unroll
+    for (int j = 0; j < kPrepChunk / (kPrepThreads * 4); ++j) {
+        const int64_t i = start + ((int64_t)j * kPrepThreads + threadIdx.x) * 4;
+        if (vec && i + 3 < end) {
+            const float4 q = *reinterpret_cast<const float4*>(lidar_dt + i);
+            v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[4 * j + k] = i + k < end ? lidar_dt[i + k] : -INFINITY;
+        }
+    }
+    // one round per frame present in the chunk (one round unless a frame boundary falls inside it)
+    int f = f0;
+    int64_t fend = offsets[f + 1];
+    int64_t fbeg = start;
+    while (true) {
+        const int64_t hi = fend < end ? fend : end;
         float m = -INFINITY;   // fmaxf drops NaN operands
-        const bool vec = (reinterpret_cast<uintptr_t>(lidar_dt) & 15u) == 0;
 #pragma unroll
         for (int j = 0; j < kPrepChunk / (kPrepThreads * 4); ++j) {
             const int64_t i = start + ((int64_t)j * kPrepThreads + threadIdx.x) * 4;
-            if (vec && i + 3 < end) {
-                const float4 v = *reinterpret_cast<const float4*>(lidar_dt + i);
-                m = fmaxf(fmaxf(m, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
-            } else {
-                for (int64_t k = i; k < i + 4 && k < end; ++k) m = fmaxf(m, lidar_dt[k]);
-            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i + k >= fbeg && i + k < hi) m = fmaxf(m, v[4 * j + k]);
         }
-        m = wave_max(m);
-        __shared__ float wmax[kPrepThreads / 64];
-        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float r = wmax[0];
-            for (int w = 1; w < kPrepThreads / 64; ++w) r = fmaxf(r, wmax[w]);
-            if (r > -INFINITY) atomicMax(&keys[f0], float_to_key(r));
-        }
-    } else {   // chunk straddles a frame boundary (rare): one atomic per element
-        for (int64_t i = start + threadIdx.x; i < end; i += kPrepThreads) {
-            int f = f0;
-            while (i >= offsets[f + 1]) ++f;
-            const float v = lidar_dt[i];
-            if (v == v) atomicMax(&keys[f], float_to_key(v));
-        }
+        block_max_to_key(m, &keys[f]);
+        if (hi >= end) break;
+        fbeg = hi;
+        do { ++f; fend = offsets[f + 1]; } while (fend <= fbeg);   // skip empty frames
     }
 }
 
@@ -391,11 +434,11 @@ static int launch_compdis(int n_frames, int64_t total, const int64_t* d_offsets,
     HIMO_HIP(hipMemsetAsync(w.keys, 0, keys_bytes(n_frames), s));
 
     const int n_chunks = (int)((total + kPrepChunk - 1) / kPrepChunk);
-    const int grid1 = n_chunks > n_frames ? n_chunks : n_frames;
+    const int grid1 = n_chunks + (n_frames + kPrepThreads - 1) / kPrepThreads;
     {
         ProfScope ps("frame_prep_kernel", s);
-        hipLaunchKernelGGL(frame_prep_kernel, dim3(grid1), dim3(kPrepThreads), 0, s, n_frames, total, n_chunks, d_offsets,
-                           d_pose0, d_pose1, d_lidar_dt, w.keys, w.xf);
+        hipLaunchKernelGGL(frame_prep_kernel, dim3(grid1), dim3(kPrepThreads), 0, s, n_frames, total, n_chunks,
+                           (flags & HIMO_FLAG_POSE_IS_EGO) ? 2 : 1, d_offsets, d_pose0, d_pose1, d_lidar_dt, w.keys, w.xf);
     }
     HIMO_LAUNCH_CHECK("frame_prep_kernel");
     if (total == 0) return HIMO_OK;
@@ -436,7 +479,8 @@ extern "C" int himo_compdis_batch(int n_frames, int64_t total_points, const int6
                                   const uint8_t* d_flow_is_valid, const float* h_mask_bounds, float close_distance,
                                   void* d_workspace, size_t workspace_bytes, void* stream) {
     if (n_frames < 1 || total_points < 0 || pc_stride < 3) return HIMO_ERR_INVALID_ARGUMENT;
-    if (!d_offsets || !d_pose0 || !d_pose1 || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
+    if (!d_offsets || !d_pose0 || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
+    if (!d_pose1 && !(flags & HIMO_FLAG_POSE_IS_EGO)) return HIMO_ERR_INVALID_ARGUMENT;
     if (total_points > 0 && (!d_pc0 || !d_lidar_dt || !d_comp_dis)) return HIMO_ERR_INVALID_ARGUMENT;
     if (total_points > 0 && !(flags & HIMO_FLAG_RAW) && !d_flow) return HIMO_ERR_INVALID_ARGUMENT;
     if (d_eval_mask && (!d_gm0 || !h_mask_bounds)) return HIMO_ERR_INVALID_ARGUMENT;
@@ -453,14 +497,15 @@ extern "C" int himo_compdis_frame(int64_t n_points, const double* h_pose0, const
                                   int pc_stride, const float* d_flow, const float* d_lidar_dt, double sensor_dt,
                                   unsigned flags, float* d_comp_dis, float* d_refined, void* d_workspace,
                                   size_t workspace_bytes, void* stream) {
-    if (n_points < 0 || pc_stride < 3 || !h_pose0 || !h_pose1 || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
+    if (n_points < 0 || pc_stride < 3 || !h_pose0 || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
+    if (!h_pose1 && !(flags & HIMO_FLAG_POSE_IS_EGO)) return HIMO_ERR_INVALID_ARGUMENT;
     if (n_points == 0) return HIMO_ERR_EMPTY_FRAME;                       // max() of an empty sequence
     if (!d_pc0 || !d_lidar_dt || !d_comp_dis) return HIMO_ERR_INVALID_ARGUMENT;
     if (!(flags & HIMO_FLAG_RAW) && !d_flow) return HIMO_ERR_INVALID_ARGUMENT;
     if (!(sensor_dt != 0.0)) return HIMO_ERR_INVALID_ARGUMENT;
     if (workspace_bytes < himo_compdis_workspace_bytes(1) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
     // singular pose1 -> the error numpy raises at save_zip.py:115; 4x4 determinant by cofactors
-    {
+    if (!(flags & HIMO_FLAG_POSE_IS_EGO)) {
         const double* m = h_pose1;
         auto det3 = [](double a, double b, double c, double d, double e, double f, double g, double h, double i) {
             return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
@@ -475,7 +520,7 @@ extern "C" int himo_compdis_frame(int64_t n_points, const double* h_pose0, const
     char* tail = reinterpret_cast<char*>(d_workspace) + keys_bytes(1) + sizeof(FrameXf);
     int64_t h_off[2] = {0, n_points};
     double h_poses[32];
-    for (int i = 0; i < 16; ++i) { h_poses[i] = h_pose0[i]; h_poses[16 + i] = h_pose1[i]; }
+    for (int i = 0; i < 16; ++i) { h_poses[i] = h_pose0[i]; h_poses[16 + i] = h_pose1 ? h_pose1[i] : 0.0; }
     int64_t* d_off = reinterpret_cast<int64_t*>(tail);
     double* d_poses = reinterpret_cast<double*>(tail + 2 * sizeof(int64_t));
     HIMO_HIP(hipMemcpyAsync(d_off, h_off, sizeof(h_off), hipMemcpyHostToDevice, s));
@@ -543,9 +588,13 @@ extern "C" int himo_dt0(int64_t n, const float* d_lidar_dt, float* d_dt0, void* 
     int64_t* d_off = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(d_workspace) + 16);
     HIMO_HIP(hipMemcpyAsync(d_off, h_off, sizeof(h_off), hipMemcpyHostToDevice, s));
     const int n_chunks = (int)((n + kPrepChunk - 1) / kPrepChunk);
-    hipLaunchKernelGGL(frame_prep_kernel, dim3(n_chunks), dim3(kPrepThreads), 0, s, 1, n, n_chunks, d_off,
-                       (const double*)nullptr, (const double*)nullptr, d_lidar_dt, key, (FrameXf*)nullptr);
+    {
+        ProfScope ps("frame_prep_kernel_dt0", s);
+        hipLaunchKernelGGL(frame_prep_kernel, dim3(n_chunks), dim3(kPrepThreads), 0, s, 1, n, n_chunks, 0, d_off,
+                           (const double*)nullptr, (const double*)nullptr, d_lidar_dt, key, (FrameXf*)nullptr);
+    }
     HIMO_LAUNCH_CHECK("frame_prep_kernel");
+    ProfScope ps("dt0_kernel", s);
     hipLaunchKernelGGL(dt0_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, d_lidar_dt, key, d_dt0);
     HIMO_LAUNCH_CHECK("dt0_kernel");
     return HIMO_OK;

@@ -47,6 +47,8 @@ typedef enum himo_status {
                                     exactly where save_zip.py:70-72 casts */
 #define HIMO_FLAG_RAW 0x2u       /* res_name == "raw": est_flow = zeros (save_zip.py:117) */
 #define HIMO_FLAG_SCANIA 0x4u    /* eval mask also requires flow_is_valid (eval.py:293-294) */
+#define HIMO_FLAG_POSE_IS_EGO 0x8u /* `pose0` already holds ego_pose = inv(pose1) @ pose0 (save_zip.py:115,
+                                    computed by the caller, e.g. with numpy); `pose1` is ignored / may be NULL */
 
 int himo_abi_version(void);
 const char* himo_status_string(int status);

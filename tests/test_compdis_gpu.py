@@ -12,8 +12,10 @@ from conftest import RES, golden_frames
 
 pytestmark = pytest.mark.gpu
 
-ABS_TOL = 1e-6          # north_star allows 1e-4; this path holds 1e-6
-MIN_EXACT = 0.9999      # fraction of elements that must be bit-identical to the reference
+ABS_TOL = 1e-9          # north_star allows 1e-4 abs; the float64 chain holds 1e-9
+MIN_EXACT = 0.9999      # fraction of significant elements that must be bit-identical to the reference
+SIGNIFICANT = 1e-5      # |value| below this is cancellation residue of flow - pose_flow (~1e-8): the
+                        # last bits of inv(pose1) decide its float32 rounding, so it is held to ABS_TOL only
 
 
 def _engine():
@@ -30,19 +32,24 @@ def _close(got, ref, tol=ABS_TOL):
 
 
 def _exact_fraction(got, ref):
-    return float((np.asarray(got) == np.asarray(ref)).mean()) if np.asarray(ref).size else 1.0
+    got, ref = np.asarray(got), np.asarray(ref)
+    sig = np.abs(ref) >= SIGNIFICANT
+    return float((got[sig] == ref[sig]).mean()) if sig.any() else 1.0
 
 
 @pytest.mark.parametrize("data_name", ["av2", "scania"])
 def test_single_frame_matches_reference_feather_payload(gpu, gold, data_name):
     from himo_amd.compdis import comp_dis_frame
     for i, f in enumerate(golden_frames(gold, data_name)):
-        cd = comp_dis_frame(f, RES)
         ref = gold[f"{data_name}/{i}/ref_comp_dis"]
+        cd = comp_dis_frame(f, RES)                      # ego_pose from numpy, as save_zip.py:115 computes it
         assert cd.dtype == np.float32 and cd.shape == ref.shape
-        _close(cd, ref)
-        assert _exact_fraction(cd, ref) >= MIN_EXACT
-        ulp = np.abs(cd.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64)).max()
+        assert np.array_equal(cd, ref), f"{(cd != ref).sum()} of {ref.size} elements differ from the reference"
+        cd2 = comp_dis_frame(f, RES, host_ego=False)     # 4x4 inverse inside the library
+        _close(cd2, ref)
+        assert _exact_fraction(cd2, ref) >= MIN_EXACT
+        sig = np.abs(ref) >= SIGNIFICANT
+        ulp = np.abs(cd2.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))[sig].max()
         assert ulp <= 1
 
 
@@ -141,6 +148,8 @@ def test_error_behaviour_matches_reference(gpu, frames_av2):
     sing = dict(f, pose1=np.zeros((4, 4)))
     with pytest.raises(np.linalg.LinAlgError):
         comp_dis_frame(sing, RES)                        # np.linalg.inv(pose1)
+    with pytest.raises(np.linalg.LinAlgError):
+        comp_dis_frame(sing, RES, host_ego=False)        # the library's own singularity check
 
 
 def test_full_size_frames_against_oracle_and_invariants(gpu, oracle):
@@ -158,7 +167,7 @@ def test_full_size_frames_against_oracle_and_invariants(gpu, oracle):
         g = got.cpu().numpy()
         worst = max(worst, float(np.abs(g.astype(np.float64) - ref).max()))
         exact.append(_exact_fraction(g, ref))
-    assert worst <= ABS_TOL and min(exact) >= MIN_EXACT
+    assert worst <= ABS_TOL and min(exact) >= MIN_EXACT, (worst, exact)
     # (1) the latest point of each sweep is not moved: dt0 == 0 there
     for f, got in zip(frames, b.split(cd)):
         assert not got[int(np.argmax(f["lidar_dt"]))].any().item()
