@@ -33,6 +33,12 @@ SIGNATURES = {
     "himo_refine_pts": (c_int, [c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "himo_ego_pts_mask": (c_int, [c_int64, c_void_p, c_int, ctypes.POINTER(c_float), c_void_p, c_void_p]),
     "himo_dt0": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "himo_nn_search": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p,
+                               c_void_p, c_void_p]),
+    "himo_eval_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64]),
+    "himo_eval_instances": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ctypes.c_uint8), c_double,
+                                    c_int, c_uint, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 FLAG_F32_CHAIN = 0x1

@@ -22,43 +22,9 @@
 // float32 where save_zip.py:70-72 casts, which is what makes the result bit-comparable with the
 // reference for float64 poses.  HIMO_FLAG_F32_CHAIN runs the float32 chain numpy runs for float32
 // poses.  This file is compiled with -ffp-contract=off; every fused multiply-add is explicit.
-#include "himo_common.h"
-#include <math.h>
+#include "compdis_math.h"
 
 namespace himo {
-
-struct FrameXf {   // ego transform of one frame: p' = R p + t
-    double R[9];
-    double t[3];
-};
-
-constexpr int kPrepThreads = 256;
-constexpr int kPrepChunk = 4096;      // points per block in the max pre-pass
-constexpr int kThreads = 256;
-constexpr int kPtsPerThread = 4;
-constexpr int kBlockPts = kThreads * kPtsPerThread;
-
-struct WorkspaceLayout {
-    unsigned* keys;   // [n_frames] order-preserving keys of max(lidar_dt)
-    FrameXf* xf;      // [n_frames]
-};
-
-__host__ __device__ inline size_t keys_bytes(int n_frames) {
-    return ((size_t)n_frames * sizeof(unsigned) + 15) / 16 * 16;
-}
-
-// ------------------------------------------------------------------------------------------
-// per-frame helpers
-// ------------------------------------------------------------------------------------------
-// largest f in [0, n_frames) with offsets[f] <= i   (i < offsets[n_frames])
-__device__ inline int find_frame(const int64_t* __restrict__ offsets, int n_frames, int64_t i) {
-    int lo = 0, hi = n_frames;   // invariant: offsets[lo] <= i < offsets[hi]
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (offsets[mid] <= i) lo = mid; else hi = mid;
-    }
-    return lo;
-}
 
 // ego = inv(pose1) @ pose0 in float64 (save_zip.py:115): LU with partial pivoting (first maximal
 // pivot, as LAPACK's idamax), explicit inverse by forward/back substitution on the identity, then
@@ -228,53 +194,6 @@ struct CompdisArgs {
     float close_distance;
 };
 
-struct XfRegs {   // one frame's transform + max, held in registers (SGPRs on the uniform path)
-    double R[9];
-    double t[3];
-    float fmax;
-};
-
-__device__ inline XfRegs load_xf(const CompdisArgs& a, int f) {
-    XfRegs x;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) x.R[i] = a.xf[f].R[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) x.t[i] = a.xf[f].t[i];
-    x.fmax = key_to_float(a.keys[f]);
-    return x;
-}
-
-template <bool F32>
-__device__ inline void point_math(const XfRegs& x, float px, float py, float pz, float fx, float fy, float fz,
-                                  float dt, double sensor_dt, bool raw, float* cd, float* rf) {
-    const float dt0 = x.fmax - dt;                                   // save_zip.py:120 (float32)
-    if (F32) {
-        const float r[9] = {(float)x.R[0], (float)x.R[1], (float)x.R[2], (float)x.R[3], (float)x.R[4],
-                            (float)x.R[5], (float)x.R[6], (float)x.R[7], (float)x.R[8]};
-        const float sdt = (float)sensor_dt;
-        const float p[3] = {px, py, pz}, fl[3] = {fx, fy, fz};
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float pf = (fmaf(pz, r[c * 3 + 2], fmaf(py, r[c * 3 + 1], px * r[c * 3])) + (float)x.t[c]) - p[c];
-            const float est = raw ? 0.0f : fl[c] - pf;
-            const float v = est / sdt * dt0;                         // utils/__init__.py:43
-            cd[c] = v;
-            rf[c] = p[c] + v;                                        // utils/__init__.py:46
-        }
-    } else {
-        const double p[3] = {(double)px, (double)py, (double)pz}, fl[3] = {(double)fx, (double)fy, (double)fz};
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            // save_zip.py:116 -- dgemm accumulates k-ordered fused multiply-adds
-            const double pf = (fma(p[2], x.R[c * 3 + 2], fma(p[1], x.R[c * 3 + 1], p[0] * x.R[c * 3])) + x.t[c]) - p[c];
-            const double est = raw ? 0.0 : fl[c] - pf;               // save_zip.py:117
-            const double v = est / sensor_dt * (double)dt0;          // utils/__init__.py:43
-            cd[c] = (float)v;                                        // save_zip.py:70-72
-            rf[c] = (float)(p[c] + v);                               // utils/__init__.py:46
-        }
-    }
-}
-
 __device__ inline uint8_t mask_math(const CompdisArgs& a, float px, float py, float pz, uint8_t gm, uint8_t valid) {
     const float d = sqrtf(px * px + py * py);                        // eval.py:288 (float32 norm)
     const bool inside = (px > a.bmin[0]) & (px < a.bmax[0]) & (py > a.bmin[1]) & (py < a.bmax[1]) &
@@ -309,13 +228,13 @@ __global__ __launch_bounds__(kThreads) void compdis_kernel(CompdisArgs a) {
         int f = f0;
         for (int64_t i = g; i < g + kPtsPerThread && i < bend; ++i) {
             while (i >= a.offsets[f + 1]) ++f;
-            const XfRegs x = load_xf(a, f);
+            const XfRegs x = load_xf(a.xf, a.keys, f);
             scalar_point<F32>(a, x, i);
         }
         return;
     }
 
-    const XfRegs x = load_xf(a, f0);
+    const XfRegs x = load_xf(a.xf, a.keys, f0);
     const bool raw = a.flow == nullptr;
 
     float px[4], py[4], pz[4];
@@ -408,13 +327,6 @@ __global__ __launch_bounds__(256) void dt0_kernel(int64_t n, const float* __rest
     out[i] = key_to_float(*key) - dt[i];
 }
 
-static WorkspaceLayout carve(void* ws, int n_frames) {
-    WorkspaceLayout w;
-    w.keys = reinterpret_cast<unsigned*>(ws);
-    w.xf = reinterpret_cast<FrameXf*>(reinterpret_cast<char*>(ws) + keys_bytes(n_frames));
-    return w;
-}
-
 }  // namespace himo
 
 using namespace himo;
@@ -425,11 +337,8 @@ extern "C" size_t himo_compdis_workspace_bytes(int n_frames) {
     return keys_bytes(n_frames) + (size_t)n_frames * sizeof(FrameXf) + 2 * sizeof(int64_t) + 32 * sizeof(double);
 }
 
-static int launch_compdis(int n_frames, int64_t total, const int64_t* d_offsets, const double* d_pose0,
-                          const double* d_pose1, const float* d_pc0, int pc_stride, const float* d_flow,
-                          const float* d_lidar_dt, double sensor_dt, unsigned flags, float* d_comp_dis, float* d_refined,
-                          uint8_t* d_eval_mask, const uint8_t* d_gm0, const uint8_t* d_valid, const float* h_bounds,
-                          float close_distance, void* d_workspace, hipStream_t s) {
+int himo::launch_frame_prep(int n_frames, int64_t total, const int64_t* d_offsets, const double* d_pose0,
+                            const double* d_pose1, unsigned flags, const float* d_lidar_dt, void* d_workspace, hipStream_t s) {
     WorkspaceLayout w = carve(d_workspace, n_frames);
     HIMO_HIP(hipMemsetAsync(w.keys, 0, keys_bytes(n_frames), s));
 
@@ -441,6 +350,19 @@ static int launch_compdis(int n_frames, int64_t total, const int64_t* d_offsets,
                            (flags & HIMO_FLAG_POSE_IS_EGO) ? 2 : 1, d_offsets, d_pose0, d_pose1, d_lidar_dt, w.keys, w.xf);
     }
     HIMO_LAUNCH_CHECK("frame_prep_kernel");
+    return HIMO_OK;
+}
+
+static int launch_compdis(int n_frames, int64_t total, const int64_t* d_offsets, const double* d_pose0,
+                          const double* d_pose1, const float* d_pc0, int pc_stride, const float* d_flow,
+                          const float* d_lidar_dt, double sensor_dt, unsigned flags, float* d_comp_dis, float* d_refined,
+                          uint8_t* d_eval_mask, const uint8_t* d_gm0, const uint8_t* d_valid, const float* h_bounds,
+                          float close_distance, void* d_workspace, hipStream_t s) {
+    WorkspaceLayout w = carve(d_workspace, n_frames);
+    {
+        int st = launch_frame_prep(n_frames, total, d_offsets, d_pose0, d_pose1, flags, d_lidar_dt, d_workspace, s);
+        if (st != HIMO_OK) return st;
+    }
     if (total == 0) return HIMO_OK;
 
     CompdisArgs a;

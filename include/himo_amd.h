@@ -128,6 +128,65 @@ int himo_ego_pts_mask(int64_t n, const float* d_pts, int pc_stride, const float*
 /* save_zip.py:120 / eval.py:299  dt0 = max(lidar_dt) - lidar_dt  (one frame; d_workspace >= 32 bytes, 16-byte aligned) */
 int himo_dt0(int64_t n, const float* d_lidar_dt, float* d_dt0, void* d_workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * a8: exact k = 1 nearest neighbour (both halves of the Chamfer distance), brute force through LDS.
+ * Replaces the cKDTree build + query pairs of eval.py:56-59 / tools/test/score.py:186-189 and is the
+ * correspondence search of the self-supervised Chamfer loss.
+ * Queries in rows [q_offsets[s], q_offsets[s+1]) search the references in rows
+ * [r_offsets[s], r_offsets[s+1]) (segments = sweeps of a batch, or instances).  d_q, d_r: [n][3]
+ * float32, or float64 when dtype_is_f64.  d_dist2: [nq] SQUARED distance in the same dtype (+inf for
+ * an empty reference range); d_idx: [nq] int32 global reference row or -1 (may be NULL).
+ * float64 mode is bit-comparable with cKDTree ((dx*dx + dy*dy) + dz*dz, then sqrt by the caller). */
+int himo_nn_search(int n_segments, const int64_t* d_q_offsets, const int64_t* d_r_offsets,
+                   int64_t nq, int64_t nr, const void* d_q, const void* d_r, int dtype_is_f64,
+                   void* d_dist2, int32_t* d_idx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a7 + a8: per-instance refinement metrics for a ragged batch of sweeps.
+ * Replaces the per-category / per-instance loops of InstanceMetrics.step_eval (eval.py:64-114) and
+ * ScoreMetrics.step (tools/test/score.py:223-321) up to, but not including, the bucket bookkeeping
+ * (eval.py:99-147), which needs a few dozen records per sweep and stays on the host.
+ * One record per (frame, class group, instance id) among the points with eval_mask != 0 and
+ * class_lut[category] != 0, in no particular order (sort on the host). */
+typedef struct himo_instance_record {
+    int32_t frame;     /* index of the sweep in the batch */
+    int32_t group;     /* class_lut value: 1 = CAR, 2 = OTHER_VEHICLES */
+    int64_t instance;  /* flow_instance_id */
+    int64_t num_pts;   /* eval.py:90 */
+    double vel;        /* mean |gt_flow| / sensor_dt                         eval.py:91 */
+    double dis;        /* mean |pc0 row| (all columns, float32 norm)         eval.py:94 */
+    double mpe;        /* mean |gt_refined - est_refined|                    eval.py:95 */
+    double cham;       /* (mean NN(gt->est) + mean NN(est->gt)) / 2          eval.py:50-62, :96 */
+} himo_instance_record;
+
+#define HIMO_EVAL_FLOW 0     /* d_est = estimated flow incl. ego motion (EVAL_FLAG 2, eval.py:301-305) */
+#define HIMO_EVAL_COMPDIS 1  /* d_est = float32 comp_dis read from a zip (EVAL_FLAG 1, eval.py:306-310) */
+#define HIMO_EVAL_RAW 2      /* est_flow = zeros (res_name == "raw") */
+#define HIMO_EVAL_SCORE 3    /* leaderboard scorer: d_gt = GT comp_dis, d_est = predicted comp_dis (both float32),
+                                d_pc0 = pc0 xyz or NULL, d_lidar_dt = gt_flow_norm or NULL; poses unused
+                                (tools/test/score.py:299-306) */
+
+#define HIMO_EVAL_DIRECT 4   /* step_eval's own arguments (eval.py:64): d_pc0 = masked points, d_gt = float64 [T][3]
+                                ego-motion-free GT flow, d_lidar_dt = dt0 (already max - dt), d_est = float64 [T][3]
+                                ego-motion-free estimated flow, or float32 comp_dis with HIMO_EVAL_DIRECT_EST_IS_DIS;
+                                poses unused */
+#define HIMO_EVAL_DIRECT_EST_IS_DIS 0x100u
+
+size_t himo_eval_workspace_bytes(int n_frames, int64_t total_points, int64_t max_records);
+
+/* d_gt: GT flow incl. ego motion [T][3] (data['flow']); d_category uint8[T]; d_instance int64[T] (ids must fit
+ * 32 bits); d_eval_mask uint8[T] (e.g. from himo_compdis_batch); h_class_lut: HOST uint8[256].
+ * d_records: himo_instance_record[max_records]; d_counts: int64[2] = {selected points, records found}.
+ * flags: HIMO_FLAG_POSE_IS_EGO.  Always the float64 chain.  Synchronises the stream once internally. */
+int himo_eval_instances(int n_frames, int64_t total_points,
+                        const int64_t* d_offsets, const double* d_pose0, const double* d_pose1,
+                        const float* d_pc0, int pc_stride, const void* d_gt, const void* d_est,
+                        const float* d_lidar_dt, const uint8_t* d_category, const int64_t* d_instance,
+                        const uint8_t* d_eval_mask, const uint8_t* h_class_lut,
+                        double sensor_dt, int mode, unsigned flags,
+                        himo_instance_record* d_records, int64_t max_records, int64_t* d_counts,
+                        void* d_workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
