@@ -1,0 +1,299 @@
+// conv.hip -- stage a10, backbone + head arithmetic: NHWC float32 convolution / row-GEMM on the
+// gfx950 matrix cores with fused epilogues, and bilinear x2 upsampling.
+//
+// No reference source exists for this stage (OpenSceneFlow submodule absent).
+// Specification: himo_amd/seflow/spec.py steps 3-5; oracle: oracle/seflow_oracle.py (PyTorch CPU fp32).
+//
+// Why float32 MFMA: north_star asks for per-point flow within 1e-4 of a float32 CPU path.  bf16
+// inputs lose that after ~20 conv layers, so the matrix cores run v_mfma_f32_32x32x2_f32 -- exact
+// float32 products and accumulation (a k-ordered fma chain) at the float32 vector peak (157 TF) but
+// issued from 64-cycle matrix instructions that leave the VALU free for staging and epilogues.
+//
+// Kernel: implicit GEMM.  M = output pixels (or point rows), N = output channels, K = taps x Cin.
+//   * block = 256 threads = 4 waves (2 along M x 2 along N); block tile 128 pixels x BN channels;
+//     for 3x3 convs the 128 pixels are an 8 x 16 spatial tile so that the input halo patch
+//     ((8-1)s+3) x ((16-1)s+3) pixels is loaded ONCE per 16-channel slab and reused by all 9 taps;
+//   * LDS holds the patch k-major ([16][patch pixels], so an A fragment is one conflict-free
+//     ds_read_b32 per lane) and the [16][BN] weight slab of the current tap;
+//   * the fragment loop issues 2 A reads + BN/64 B reads per 2*BN/64 MFMAs -- the LDS is ~12% busy;
+//   * epilogues are fused: bias, BatchNorm(eval) scale/shift, exact-erf GELU, the GRU gate math.
+// Channel concatenation never copies: every tensor is addressed as base + n*batch_stride +
+// pixel*pitch + channel, so frames live as channel groups of one wider buffer.
+#include "himo_common.h"
+#include <math.h>
+
+namespace himo {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+enum Epilogue {
+    kEpiBias = 0,         // y = acc + bias
+    kEpiBiasBnGelu = 1,   // y = gelu((acc + bias) * scale + shift)
+    kEpiBiasGelu = 2,     // y = gelu(acc + bias)
+    kEpiGruZR = 3,        // cols [0,C/2): z = sigmoid(.) -> out ; cols [C/2,C): r = sigmoid(.), aux_out = r * h
+    kEpiGruQ = 4          // q = tanh(.) ; h = (1 - z) * h + z * q  (in place in aux_out)
+};
+
+struct ConvArgs {
+    const float* x; int64_t x_batch_stride; int x_pitch;      // input  [n][H][W] pixels, `x_pitch` floats apart
+    const float* w;                                           // [KS][KS][Cin][Cout]
+    const float* bias; const float* scale; const float* shift;
+    float* y; int64_t y_batch_stride; int y_pitch;            // output
+    int N, H, W, Cin, Cout;                                   // input spatial size (KS=1 rows: H = 1, W = rows)
+    int Ho, Wo;
+    // GRU epilogues
+    const float* aux_in; int aux_in_pitch;                    // z (kEpiGruQ) / h (kEpiGruZR), [rows][pitch]
+    float* aux_out; int aux_out_pitch;                        // r*h (kEpiGruZR) / h in place (kEpiGruQ)
+};
+
+__device__ inline float gelu_exact(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ inline float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+template <int KS, int S, int BN, int EPI>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+    constexpr int BM = 128, BK = 16, TH = 8, TW = 16;
+    constexpr int PH = KS == 1 ? 1 : (TH - 1) * S + KS;
+    constexpr int PW = KS == 1 ? BM : (TW - 1) * S + KS;
+    constexpr int PP = PH * PW + 1;                 // +1: break the power-of-two plane stride
+    constexpr int WN = BN / 2, NI = WN / 32;
+    __shared__ float patchT[BK * PP];
+    __shared__ float wt[BK * BN];
+
+    // ---- block -> (image, spatial tile, channel tile) ----
+    const int n_tiles_n = (a.Cout + BN - 1) / BN;
+    int bid = blockIdx.x;
+    const int tn = bid % n_tiles_n; bid /= n_tiles_n;
+    int oy0, ox0, img;
+    int64_t row0 = 0;                               // KS == 1: first linear pixel of the tile
+    if (KS == 1) {
+        const int64_t rows = (int64_t)a.Ho * a.Wo;
+        const int tiles = (int)((rows + BM - 1) / BM);
+        img = bid / tiles;
+        row0 = (int64_t)(bid % tiles) * BM;
+        oy0 = ox0 = 0;
+    } else {
+        const int tx = (a.Wo + TW - 1) / TW, ty = (a.Ho + TH - 1) / TH;
+        ox0 = (bid % tx) * TW; bid /= tx;
+        oy0 = (bid % ty) * TH; img = bid / ty;
+    }
+    const int n0 = tn * BN;
+    const float* __restrict__ xin = a.x + (int64_t)img * a.x_batch_stride;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // A-fragment pixel offsets inside the patch for this lane's two 32-row MFMA tiles
+    int ppA[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int m = wm * 64 + mi * 32 + li;
+        ppA[mi] = KS == 1 ? m : ((m / TW) * S) * PW + (m % TW) * S;
+    }
+
+    floatx16 acc[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int iy0 = oy0 * S - (KS / 2), ix0 = ox0 * S - (KS / 2);
+    const int64_t in_rows = (int64_t)a.H * a.W;
+
+    for (int ci0 = 0; ci0 < a.Cin; ci0 += BK) {
+        __syncthreads();                            // everyone is done reading the previous patch
+        // ---- stage the input patch slab, transposed to k-major ----
+        for (int item = threadIdx.x; item < PH * PW * (BK / 4); item += 256) {
+            const int pp = item / (BK / 4), q = item % (BK / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int64_t pix;
+            bool ok;
+            if (KS == 1) { pix = row0 + pp; ok = pix < in_rows; }
+            else {
+                const int iy = iy0 + pp / PW, ix = ix0 + pp % PW;
+                ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                pix = (int64_t)iy * a.W + ix;
+            }
+            const int ci = ci0 + q * 4;
+            if (ok && ci < a.Cin) v = *reinterpret_cast<const float4*>(xin + pix * a.x_pitch + ci);
+            patchT[(q * 4 + 0) * PP + pp] = v.x;
+            patchT[(q * 4 + 1) * PP + pp] = v.y;
+            patchT[(q * 4 + 2) * PP + pp] = v.z;
+            patchT[(q * 4 + 3) * PP + pp] = v.w;
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            __syncthreads();                        // previous tap's weight slab fully consumed
+            // ---- stage the [BK][BN] weight slab of this tap ----
+            for (int item = threadIdx.x; item < BK * (BN / 4); item += 256) {
+                const int k = item / (BN / 4), q = item % (BN / 4);
+                const int ci = ci0 + k, co = n0 + q * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci < a.Cin && co < a.Cout)
+                    v = *reinterpret_cast<const float4*>(a.w + ((int64_t)tap * a.Cin + ci) * a.Cout + co);
+                *reinterpret_cast<float4*>(&wt[k * BN + q * 4]) = v;
+            }
+            __syncthreads();
+            const int tapoff = KS == 1 ? 0 : (tap / KS) * PW + (tap % KS);
+#pragma unroll
+            for (int t = 0; t < BK / 2; ++t) {
+                const int k = 2 * t + lh;
+                float af[2], bf[NI];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) af[mi] = patchT[k * PP + ppA[mi] + tapoff];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bf[ni] = wt[k * BN + wn * WN + ni * 32 + li];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] ----
+    float* __restrict__ yout = a.y + (int64_t)img * a.y_batch_stride;
+    const int64_t out_rows = (int64_t)a.Ho * a.Wo;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int co = n0 + wn * WN + ni * 32 + li;
+        if (co >= a.Cout) continue;
+        const float b = a.bias ? a.bias[co] : 0.f;
+        float sc = 1.f, sh = 0.f;
+        if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                int64_t pix;
+                bool ok;
+                if (KS == 1) { pix = row0 + m; ok = pix < out_rows; }
+                else {
+                    const int oy = oy0 + m / TW, ox = ox0 + m % TW;
+                    ok = oy < a.Ho && ox < a.Wo;
+                    pix = (int64_t)oy * a.Wo + ox;
+                }
+                if (!ok) continue;
+                float v = acc[mi][ni][r] + b;
+                if (EPI == kEpiBias) {
+                    yout[pix * a.y_pitch + co] = v;
+                } else if (EPI == kEpiBiasBnGelu) {
+                    v = v * sc + sh;
+                    yout[pix * a.y_pitch + co] = gelu_exact(v);
+                } else if (EPI == kEpiBiasGelu) {
+                    yout[pix * a.y_pitch + co] = gelu_exact(v);
+                } else if (EPI == kEpiGruZR) {
+                    const int half = a.Cout / 2;
+                    const float g = sigmoid_f(v);
+                    if (co < half) yout[pix * a.y_pitch + co] = g;                               // z
+                    else a.aux_out[pix * a.aux_out_pitch + (co - half)] = g * a.aux_in[pix * a.aux_in_pitch + (co - half)];   // r * h
+                } else if (EPI == kEpiGruQ) {
+                    const float q = tanhf(v);
+                    const float z = a.aux_in[pix * a.aux_in_pitch + co];
+                    const float h = a.aux_out[pix * a.aux_out_pitch + co];
+                    a.aux_out[pix * a.aux_out_pitch + co] = (1.0f - z) * h + z * q;
+                }
+            }
+        }
+    }
+}
+
+// bilinear x2, align_corners=True (torch's area_pixel_compute_source_index / lambda formulation)
+struct UpArgs {
+    const float* x; int x_pitch; int H, W, C;
+    float* y; int y_pitch;
+    float ry, rx;   // (H-1)/(2H-1), (W-1)/(2W-1)
+};
+
+__global__ __launch_bounds__(256) void upsample2x_kernel(UpArgs a) {
+    const int c4 = a.C / 4;
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)(2 * a.H) * (2 * a.W) * c4;
+    if (item >= total) return;
+    const int q = (int)(item % c4);
+    const int64_t pix = item / c4;
+    const int ox = (int)(pix % (2 * a.W)), oy = (int)(pix / (2 * a.W));
+    const float sy = a.ry * (float)oy, sx = a.rx * (float)ox;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < a.H - 1 ? 1 : 0), x1 = x0 + (x0 < a.W - 1 ? 1 : 0);
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    auto ld = [&](int yy, int xx) { return *reinterpret_cast<const float4*>(a.x + ((int64_t)yy * a.W + xx) * a.x_pitch + q * 4); };
+    const float4 v00 = ld(y0, x0), v01 = ld(y0, x1), v10 = ld(y1, x0), v11 = ld(y1, x1);
+    float4 o;
+    o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+    o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+    o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+    o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+    *reinterpret_cast<float4*>(a.y + pix * a.y_pitch + q * 4) = o;
+}
+
+template <int KS, int S, int BN>
+static void launch_epi(const ConvArgs& a, int epi, dim3 grid, hipStream_t s) {
+    switch (epi) {
+        case kEpiBias: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBias>), grid, dim3(256), 0, s, a); break;
+        case kEpiBiasBnGelu: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBiasBnGelu>), grid, dim3(256), 0, s, a); break;
+        case kEpiBiasGelu: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBiasGelu>), grid, dim3(256), 0, s, a); break;
+        case kEpiGruZR: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiGruZR>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiGruQ>), grid, dim3(256), 0, s, a); break;
+    }
+}
+
+}  // namespace himo
+
+using namespace himo;
+
+extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
+    if (!d || !d->x || !d->w || !d->y) return HIMO_ERR_INVALID_ARGUMENT;
+    if (d->n < 1 || d->h < 1 || d->w_in < 1 || d->cin < 1 || d->cout < 1) return HIMO_ERR_INVALID_ARGUMENT;
+    if (!(d->ksize == 1 || d->ksize == 3) || !(d->stride == 1 || d->stride == 2)) return HIMO_ERR_UNSUPPORTED;
+    if (d->ksize == 1 && d->stride != 1) return HIMO_ERR_UNSUPPORTED;
+    if (d->epilogue < 0 || d->epilogue > kEpiGruQ) return HIMO_ERR_INVALID_ARGUMENT;
+    if (d->epilogue == kEpiBiasBnGelu && (!d->scale || !d->shift)) return HIMO_ERR_INVALID_ARGUMENT;
+    if ((d->epilogue == kEpiGruZR || d->epilogue == kEpiGruQ) && (!d->aux_in || !d->aux_out)) return HIMO_ERR_INVALID_ARGUMENT;
+    // 16-byte vector loads: channel counts / pitches / bases must be multiples of 4 floats
+    if ((d->cin & 3) || (d->cout & 3) || (d->x_pitch & 3) || (d->x_batch_stride & 3) || !aligned16(d->x) || !aligned16(d->w))
+        return HIMO_ERR_UNSUPPORTED;
+    ConvArgs a{};
+    a.x = d->x; a.x_batch_stride = d->x_batch_stride; a.x_pitch = d->x_pitch;
+    a.w = d->w; a.bias = d->bias; a.scale = d->scale; a.shift = d->shift;
+    a.y = d->y; a.y_batch_stride = d->y_batch_stride; a.y_pitch = d->y_pitch;
+    a.N = d->n; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Cout = d->cout;
+    a.Ho = d->stride == 2 ? (d->h + 1) / 2 : d->h;      // 3x3, pad 1: ceil(H / stride)
+    a.Wo = d->stride == 2 ? (d->w_in + 1) / 2 : d->w_in;
+    a.aux_in = d->aux_in; a.aux_in_pitch = d->aux_in_pitch; a.aux_out = d->aux_out; a.aux_out_pitch = d->aux_out_pitch;
+    hipStream_t s = (hipStream_t)stream;
+    const bool wide = d->cout >= 128 && (d->cout % 128) == 0;
+    const int bn = wide ? 128 : 64;
+    const int tiles_n = (d->cout + bn - 1) / bn;
+    int64_t tiles_m;
+    if (d->ksize == 1) tiles_m = (int64_t)d->n * (((int64_t)a.Ho * a.Wo + 127) / 128);
+    else tiles_m = (int64_t)d->n * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
+    const dim3 grid((unsigned)(tiles_m * tiles_n));
+    const char* name = d->ksize == 1 ? "conv1x1_mfma_kernel" : (d->stride == 2 ? "conv3x3s2_mfma_kernel" : "conv3x3_mfma_kernel");
+    {
+        ProfScope ps(name, s);
+        if (d->ksize == 1) { if (wide) launch_epi<1, 1, 128>(a, d->epilogue, grid, s); else launch_epi<1, 1, 64>(a, d->epilogue, grid, s); }
+        else if (d->stride == 1) { if (wide) launch_epi<3, 1, 128>(a, d->epilogue, grid, s); else launch_epi<3, 1, 64>(a, d->epilogue, grid, s); }
+        else { if (wide) launch_epi<3, 2, 128>(a, d->epilogue, grid, s); else launch_epi<3, 2, 64>(a, d->epilogue, grid, s); }
+    }
+    HIMO_LAUNCH_CHECK("conv_mfma_kernel");
+    return HIMO_OK;
+}
+
+extern "C" int himo_upsample2x(const float* d_x, int x_pitch, int h, int w, int c, float* d_y, int y_pitch, void* stream) {
+    if (!d_x || !d_y || h < 1 || w < 1 || c < 4 || (c & 3) || (x_pitch & 3) || (y_pitch & 3)) return HIMO_ERR_INVALID_ARGUMENT;
+    UpArgs a{};
+    a.x = d_x; a.x_pitch = x_pitch; a.H = h; a.W = w; a.C = c; a.y = d_y; a.y_pitch = y_pitch;
+    a.ry = h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
+    a.rx = w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+    const int64_t total = (int64_t)(2 * h) * (2 * w) * (c / 4);
+    ProfScope ps("upsample2x_kernel", (hipStream_t)stream);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    HIMO_LAUNCH_CHECK("upsample2x_kernel");
+    return HIMO_OK;
+}

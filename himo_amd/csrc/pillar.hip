@@ -1,0 +1,242 @@
+// pillar.hip -- stage a10, front end: ego transform + dynamic pillarisation + pillar feature net,
+// N x 3 LiDAR points -> 32-channel BEV pseudo-image (NHWC float32) for gfx950.
+//
+// No reference source exists for this stage (OpenSceneFlow submodule absent);
+// the specification is himo_amd/seflow/spec.py (steps 0-2) and the oracle is
+// oracle/seflow_oracle.py::pillar_image.  In-tree facts honoured: voxel_size = [0.2, 0.2, 6],
+// point_cloud_range = [-51.2, -51.2, -3, 51.2, 51.2, 3] -> 512 x 512 x 1 pillars
+// (assets/slurm/ssl-train-av2.sh:32).
+//
+// Kernels (one sweep per call, all on one stream):
+//   pillar_assign_kernel    coalesced read of the raw point rows, float32 rigid transform into the
+//                           target frame, cell index, integer histogram of points per cell
+//   cell_scan_kernel        exclusive scan of the 262,144 cell counts (one 1024-thread block)
+//   pillar_fill_kernel      counting-sort scatter of point indices into per-cell lists
+//   pillar_feature_kernel   half a wavefront (32 lanes = 32 channels) per cell: the cell's point
+//                           list is staged in LDS (through global memory for the rare cell with more
+//                           than 128 points) and put in ascending point order (so sums are
+//                           order-deterministic and match a sequential CPU scatter), then
+//                           mean -> 9 features -> Linear(9,32) -> BN -> ReLU -> mean over the cell,
+//                           one 128-byte NHWC store per cell; empty cells are written as zeros
+//                           (so no separate memset of the 32 MB image).
+// Only integer atomics are used; the output is bit-deterministic.
+#include "himo_common.h"
+#include <math.h>
+
+namespace himo {
+
+struct GridSpec {
+    float xmin, ymin, zmin;
+    float vx, vy, vz;
+    float cx0, cy0, cz0;   // cell-centre offsets: v/2 + min, rounded to float32
+    int W, H;
+};
+
+struct PillarArgs {
+    int64_t n;
+    const float* pts; int stride;
+    float R[9], t[3];
+    GridSpec g;
+    const float* pfn_w;       // [9][32]
+    const float* pfn_scale;   // [32] gamma / sqrt(var + eps)
+    const float* pfn_shift;   // [32] beta - mean * scale
+    float* xyz_t;             // [n][3]
+    int* pid;                 // [n]  cell id (iy * W + ix) or -1
+    float* offsets;           // [n][3] point - cell centre (zeros for dropped points)
+    float* image; int image_pitch;   // [H*W][pitch], 32 channels written per cell
+    int* cell_count;          // [H*W + 1] -> exclusive offsets after the scan
+    int* cell_cursor;         // [H*W]
+    int* order;               // [n] point indices grouped by cell (scatter order)
+    int* order2;              // [n] ascending order for cells too crowded for the LDS stage
+};
+
+__global__ __launch_bounds__(256) void pillar_assign_kernel(PillarArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const float* p = a.pts + i * a.stride;
+    const float x = p[0], y = p[1], z = p[2];
+    // p' = R p + t with every product and sum rounded separately (this file is built with
+    // -ffp-contract=off): the cell a point falls into is a discrete decision, so the transform is
+    // specified down to the rounding (spec.py step 0) and the oracle evaluates the identical sequence
+    const float tx = ((x * a.R[0] + y * a.R[1]) + z * a.R[2]) + a.t[0];
+    const float ty = ((x * a.R[3] + y * a.R[4]) + z * a.R[5]) + a.t[1];
+    const float tz = ((x * a.R[6] + y * a.R[7]) + z * a.R[8]) + a.t[2];
+    a.xyz_t[i * 3] = tx; a.xyz_t[i * 3 + 1] = ty; a.xyz_t[i * 3 + 2] = tz;
+    const float fx = floorf((tx - a.g.xmin) / a.g.vx);
+    const float fy = floorf((ty - a.g.ymin) / a.g.vy);
+    const float fz = floorf((tz - a.g.zmin) / a.g.vz);
+    const bool ok = fx >= 0.f && fx < (float)a.g.W && fy >= 0.f && fy < (float)a.g.H && fz >= 0.f && fz < 1.f;
+    int cell = -1;
+    if (ok) {
+        cell = (int)fy * a.g.W + (int)fx;
+        atomicAdd(&a.cell_count[cell], 1);
+    } else {
+        a.offsets[i * 3] = 0.f; a.offsets[i * 3 + 1] = 0.f; a.offsets[i * 3 + 2] = 0.f;
+    }
+    a.pid[i] = cell;
+}
+
+// exclusive scan of `n` ints in place (v[n] = total); one block of 1024 threads
+__global__ __launch_bounds__(1024) void cell_scan_kernel(int* v, int n) {
+    __shared__ int part[1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(lo + per, n);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += v[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int y = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += y;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - s;
+    for (int i = lo; i < hi; ++i) { const int c = v[i]; v[i] = run; run += c; }
+    if (threadIdx.x == 1023) v[n] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void pillar_fill_kernel(PillarArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const int cell = a.pid[i];
+    if (cell < 0) return;
+    const int slot = atomicAdd(&a.cell_cursor[cell], 1);
+    a.order[a.cell_count[cell] + slot] = (int)i;
+}
+
+constexpr int kCellsPerBlock = 8;     // 8 cells x 32 lanes = 256 threads
+constexpr int kMaxStage = 128;        // points of one cell staged (and sorted) in LDS at a time
+
+__global__ __launch_bounds__(256) void pillar_feature_kernel(PillarArgs a) {
+    __shared__ int s_idx[kCellsPerBlock][kMaxStage];
+    __shared__ int s_sorted[kCellsPerBlock][kMaxStage];
+    const int sub = threadIdx.x >> 5, c = threadIdx.x & 31;
+    const int cell = blockIdx.x * kCellsPerBlock + sub;
+    const int n_cells = a.g.W * a.g.H;
+    const bool live = cell < n_cells;
+    const int beg = live ? a.cell_count[cell] : 0;
+    const int cnt = live ? a.cell_count[cell + 1] - beg : 0;
+    const bool staged = cnt <= kMaxStage;
+
+    // ascending point order: rank every index among the cell's (short) list
+    if (staged)
+        for (int j = c; j < cnt; j += 32) s_idx[sub][j] = a.order[beg + j];
+    __syncthreads();
+    if (staged)
+        for (int j = c; j < cnt; j += 32) {
+            const int v = s_idx[sub][j];
+            int rank = 0;
+            for (int k = 0; k < cnt; ++k) rank += s_idx[sub][k] < v;
+            s_sorted[sub][rank] = v;
+        }
+    if (!staged) {
+        // crowded cell (rare: > kMaxStage returns in one 0.2 m pillar): same ranking, through global memory
+        for (int j = c; j < cnt; j += 32) {
+            const int v = a.order[beg + j];
+            int rank = 0;
+            for (int k = 0; k < cnt; ++k) rank += a.order[beg + k] < v;
+            a.order2[beg + rank] = v;
+        }
+        __threadfence_block();
+    }
+    __syncthreads();
+    if (!live) return;
+    float* out = a.image + (int64_t)cell * a.image_pitch;
+    if (cnt == 0) { out[c] = 0.f; return; }
+    auto pt = [&](int j) { return staged ? s_sorted[sub][j] : a.order2[beg + j]; };
+
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int j = 0; j < cnt; ++j) {
+        const float* p = a.xyz_t + (int64_t)pt(j) * 3;
+        sx += p[0]; sy += p[1]; sz += p[2];
+    }
+    const float fc = (float)cnt;
+    const float mx = sx / fc, my = sy / fc, mz = sz / fc;
+    const int iy = cell / a.g.W, ix = cell - iy * a.g.W;
+    const float ccx = (float)ix * a.g.vx + a.g.cx0, ccy = (float)iy * a.g.vy + a.g.cy0, ccz = 0.f * a.g.vz + a.g.cz0;
+
+    float w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = a.pfn_w[k * 32 + c];
+    const float scale = a.pfn_scale[c], shift = a.pfn_shift[c];
+    float acc = 0.f;
+    for (int j = 0; j < cnt; ++j) {
+        const int idx = pt(j);
+        const float* p = a.xyz_t + (int64_t)idx * 3;
+        const float x = p[0], y = p[1], z = p[2];
+        const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
+        float v = f[0] * w[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) v = fmaf(f[k], w[k], v);
+        v = v * scale + shift;
+        acc += fmaxf(v, 0.f);
+        if (c < 3) a.offsets[(int64_t)idx * 3 + c] = f[6 + c];
+    }
+    out[c] = acc / fc;
+}
+
+}  // namespace himo
+
+using namespace himo;
+
+static size_t pillar_ws(int64_t n, int cells) {
+    return round_up(((size_t)cells + 1) * 4, 16) + round_up((size_t)cells * 4, 16) + 2 * round_up((size_t)(n > 0 ? n : 1) * 4, 16);
+}
+
+extern "C" size_t himo_pillar_workspace_bytes(int64_t max_points, int grid_w, int grid_h) {
+    return pillar_ws(max_points, grid_w * grid_h) + 64;
+}
+
+extern "C" int himo_pillarize(int64_t n, const float* d_pts, int pc_stride, const float* h_transform,
+                              const float* h_range, const float* h_voxel, const float* h_centre_offset,
+                              int grid_w, int grid_h,
+                              const float* d_pfn_weight, const float* d_pfn_scale, const float* d_pfn_shift,
+                              float* d_xyz_t, int32_t* d_pid, float* d_offsets, float* d_image, int image_pitch,
+                              void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || pc_stride < 3 || grid_w < 1 || grid_h < 1 || !h_transform || !h_range || !h_voxel || !h_centre_offset)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    if (!d_pfn_weight || !d_pfn_scale || !d_pfn_shift || !d_image || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
+    if (n > 0 && (!d_pts || !d_xyz_t || !d_pid || !d_offsets)) return HIMO_ERR_INVALID_ARGUMENT;
+    if (n > 0x7fffffff || image_pitch < 32) return HIMO_ERR_UNSUPPORTED;
+    const int cells = grid_w * grid_h;
+    if (workspace_bytes < pillar_ws(n, cells) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+
+    PillarArgs a{};
+    a.n = n; a.pts = d_pts; a.stride = pc_stride;
+    for (int i = 0; i < 9; ++i) a.R[i] = h_transform[(i / 3) * 4 + (i % 3)];
+    for (int i = 0; i < 3; ++i) a.t[i] = h_transform[i * 4 + 3];
+    a.g.xmin = h_range[0]; a.g.ymin = h_range[1]; a.g.zmin = h_range[2];
+    a.g.vx = h_voxel[0]; a.g.vy = h_voxel[1]; a.g.vz = h_voxel[2];
+    a.g.cx0 = h_centre_offset[0]; a.g.cy0 = h_centre_offset[1]; a.g.cz0 = h_centre_offset[2];
+    a.g.W = grid_w; a.g.H = grid_h;
+    a.pfn_w = d_pfn_weight; a.pfn_scale = d_pfn_scale; a.pfn_shift = d_pfn_shift;
+    a.xyz_t = d_xyz_t; a.pid = d_pid; a.offsets = d_offsets; a.image = d_image; a.image_pitch = image_pitch;
+    char* ws = reinterpret_cast<char*>(d_workspace);
+    a.cell_count = reinterpret_cast<int*>(ws);
+    a.cell_cursor = reinterpret_cast<int*>(ws + round_up(((size_t)cells + 1) * 4, 16));
+    a.order = reinterpret_cast<int*>(ws + round_up(((size_t)cells + 1) * 4, 16) + round_up((size_t)cells * 4, 16));
+    a.order2 = a.order + round_up((size_t)(n > 0 ? n : 1) * 4, 16) / 4;
+
+    HIMO_HIP(hipMemsetAsync(a.cell_count, 0, round_up(((size_t)cells + 1) * 4, 16) + round_up((size_t)cells * 4, 16), s));
+    const unsigned pblocks = (unsigned)((n + 255) / 256);
+    if (n > 0) {
+        ProfScope ps("pillar_assign_kernel", s);
+        hipLaunchKernelGGL(pillar_assign_kernel, dim3(pblocks), dim3(256), 0, s, a);
+    }
+    HIMO_LAUNCH_CHECK("pillar_assign_kernel");
+    { ProfScope ps("cell_scan_kernel", s); hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, s, a.cell_count, cells); }
+    HIMO_LAUNCH_CHECK("cell_scan_kernel");
+    if (n > 0) {
+        ProfScope ps("pillar_fill_kernel", s);
+        hipLaunchKernelGGL(pillar_fill_kernel, dim3(pblocks), dim3(256), 0, s, a);
+    }
+    HIMO_LAUNCH_CHECK("pillar_fill_kernel");
+    {
+        ProfScope ps("pillar_feature_kernel", s);
+        hipLaunchKernelGGL(pillar_feature_kernel, dim3((cells + kCellsPerBlock - 1) / kCellsPerBlock), dim3(256), 0, s, a);
+    }
+    HIMO_LAUNCH_CHECK("pillar_feature_kernel");
+    return HIMO_OK;
+}

@@ -1,0 +1,263 @@
+"""Host orchestration of the scene-flow network (stage a10) on one MI355X.
+
+Python only sequences C-ABI kernel launches (include/himo_amd.h) on torch-owned HBM buffers; there
+is no torch arithmetic on the forward path.  Architecture and parameter names: seflow/spec.py
+(self-specified -- the reference's network source is absent).
+
+Memory plan (NHWC float32, one sample = 3 sweeps): all feature maps are preallocated once; channel
+concatenation is done by writing producers straight into channel groups of the wider consumer
+buffer (``pitch`` / ``batch_stride`` addressing), so the decoder never copies.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from . import spec
+
+EPI_BIAS, EPI_BIAS_BN_GELU, EPI_BIAS_GELU, EPI_GRU_ZR, EPI_GRU_Q = range(5)
+
+
+class ConvDesc(ctypes.Structure):
+    """include/himo_amd.h: himo_conv_desc."""
+    _fields_ = [("x", ctypes.c_void_p), ("x_batch_stride", ctypes.c_int64), ("x_pitch", ctypes.c_int),
+                ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
+                ("y", ctypes.c_void_p), ("y_batch_stride", ctypes.c_int64), ("y_pitch", ctypes.c_int),
+                ("n", ctypes.c_int), ("h", ctypes.c_int), ("w_in", ctypes.c_int), ("cin", ctypes.c_int),
+                ("cout", ctypes.c_int), ("ksize", ctypes.c_int), ("stride", ctypes.c_int), ("epilogue", ctypes.c_int),
+                ("aux_in", ctypes.c_void_p), ("aux_in_pitch", ctypes.c_int),
+                ("aux_out", ctypes.c_void_p), ("aux_out_pitch", ctypes.c_int)]
+
+
+_lib.register({
+    "himo_pillar_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "himo_pillarize": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
+                                      ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                      ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,                    # pfn weight/scale/shift
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,   # xyz_t, pid, offsets, image
+                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "himo_conv2d": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
+    "himo_upsample2x": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "himo_head_gather": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "himo_head_final": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.c_void_p]),
+})
+
+
+def _f32x(values):
+    return (ctypes.c_float * len(values))(*[float(v) for v in values])
+
+
+class SeFlowNet:
+    """``forward(pch1, pc0, pc1, pose_h1, pose0, pose1)`` -> (N0,3) float32 device tensor: the flow of every
+    pc0 row INCLUDING ego motion (the h5 ``<res_name>`` dataset that save_zip.py:117 reads)."""
+
+    def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, seed: int = 0):
+        self.lib = _lib.load()
+        self.device = device if device is not None else _lib.require_gpu()
+        params = spec.init_params(seed) if params is None else params
+        shapes = spec.param_shapes()
+        for k, shp in shapes.items():
+            if k not in params or tuple(params[k].shape) != tuple(shp):
+                raise KeyError(f"parameter {k} missing or of wrong shape (want {shp})")
+        cpu = {k: torch.from_numpy(np.ascontiguousarray(params[k], dtype=np.float32)) for k in shapes}
+        # BatchNorm(eval) folded to scale / shift in float32, formed exactly as the oracle forms them
+        def fold(prefix, eps):
+            scale = cpu[f"{prefix}.gamma"] / torch.sqrt(cpu[f"{prefix}.var"] + eps)
+            return scale, cpu[f"{prefix}.beta"] - cpu[f"{prefix}.mean"] * scale
+        derived = {}
+        derived["pfn.scale"], derived["pfn.shift"] = fold("pfn.bn", spec.BN_EPS_PFN)
+        for name, *_ in spec.ENCODER:
+            derived[f"{name}.scale"], derived[f"{name}.shift"] = fold(f"{name}.bn", spec.BN_EPS)
+        derived["head.gru.zr.weight"] = torch.cat([cpu["head.gru.z.weight"], cpu["head.gru.r.weight"]], dim=1).contiguous()
+        derived["head.gru.zr.bias"] = torch.cat([cpu["head.gru.z.bias"], cpu["head.gru.r.bias"]]).contiguous()
+        self.p = {k: v.to(self.device) for k, v in {**cpu, **derived}.items()}
+
+        H, W = spec.GRID
+        F = spec.NUM_FRAMES
+        self.H, self.W, self.F = H, W, F
+        dev = self.device
+        buf = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        self.B0 = buf(H * W, 32 * F)                                   # 3 pillar images as channel groups
+        self.E1 = [buf(F, (H // 2) * (W // 2), 64) for _ in range(2)]
+        self.F1 = buf((H // 2) * (W // 2), 64 * F)
+        self.E2 = [buf(F, (H // 4) * (W // 4), 128) for _ in range(2)]
+        self.F2 = buf((H // 4) * (W // 4), 128 * F)
+        self.E3 = [buf(F, (H // 8) * (W // 8), 256) for _ in range(2)]
+        self.F3 = buf((H // 8) * (W // 8), 256 * F)
+        self.T1 = buf((H // 8) * (W // 8), 256)
+        self.CAT1 = buf((H // 4) * (W // 4), 512)
+        self.S = [buf((H // 4) * (W // 4), 256) for _ in range(2)]
+        self.T2 = buf((H // 4) * (W // 4), 128)
+        self.CAT2 = buf((H // 2) * (W // 2), 256)
+        self.T = [buf((H // 2) * (W // 2), 128) for _ in range(2)]
+        self.T3 = buf((H // 2) * (W // 2), 64)
+        self.CAT3 = buf(H * W, 128)
+        self.U = [buf(H * W, 64) for _ in range(2)]
+        self.DEC = buf(H * W, 64)
+        self.max_points = 0
+        self._reserve_points(max_points)
+        self._range = _f32x(spec.POINT_CLOUD_RANGE[:3])
+        self._voxel = _f32x(spec.VOXEL_SIZE)
+        r, v = spec.POINT_CLOUD_RANGE, spec.VOXEL_SIZE
+        self._centre = _f32x([v[0] / 2 + r[0], v[1] / 2 + r[1], v[2] / 2 + r[2]])
+
+    def _reserve_points(self, n: int):
+        if n <= self.max_points:
+            return
+        dev = self.device
+        self.max_points = n
+        need = int(self.lib.himo_pillar_workspace_bytes(n, self.W, self.H))
+        self.ws = torch.empty(need + 64, dtype=torch.uint8, device=dev)
+        self.xyz_t = torch.empty((self.F, n, 3), dtype=torch.float32, device=dev)
+        self.pid = torch.empty((self.F, n), dtype=torch.int32, device=dev)
+        self.offsets = torch.empty((self.F, n, 3), dtype=torch.float32, device=dev)
+        self.hx = torch.empty((n, 192), dtype=torch.float32, device=dev)
+        self.rhx = torch.empty((n, 192), dtype=torch.float32, device=dev)
+        self.zbuf = torch.empty((n, 128), dtype=torch.float32, device=dev)
+        self.y1 = torch.empty((n, 32), dtype=torch.float32, device=dev)
+
+    # ---- launch helpers ---------------------------------------------------------------------------
+    def _conv(self, x, x_bs, x_pitch, wname, y, y_bs, y_pitch, n, h, w, cin, cout, ks, stride, epi, x_off=0, y_off=0,
+              scale=None, shift=None, aux_in=None, aux_in_pitch=0, aux_out=None, aux_out_pitch=0, bias=None):
+        d = ConvDesc()
+        d.x = x.data_ptr() + 4 * x_off; d.x_batch_stride = x_bs; d.x_pitch = x_pitch
+        d.w = self.p[f"{wname}.weight"].data_ptr()
+        d.bias = (self.p[f"{wname}.bias"] if bias is None else bias).data_ptr()
+        d.scale = None if scale is None else scale.data_ptr()
+        d.shift = None if shift is None else shift.data_ptr()
+        d.y = y.data_ptr() + 4 * y_off; d.y_batch_stride = y_bs; d.y_pitch = y_pitch
+        d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = n, h, w, cin, cout, ks, stride, epi
+        d.aux_in = None if aux_in is None else aux_in.data_ptr(); d.aux_in_pitch = aux_in_pitch
+        d.aux_out = None if aux_out is None else aux_out.data_ptr(); d.aux_out_pitch = aux_out_pitch
+        _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), f"himo_conv2d({wname})")
+
+    def _up(self, x, x_pitch, h, w, c, y, y_pitch):
+        _lib.check(self.lib.himo_upsample2x(x.data_ptr(), x_pitch, h, w, c, y.data_ptr(), y_pitch, _lib.stream_handle()),
+                   "himo_upsample2x")
+
+    # ---- stages ---------------------------------------------------------------------------------------
+    def backbone(self):
+        """B0 (3 pillar images) -> DEC (64 x H x W)."""
+        H, W, F = self.H, self.W, self.F
+        p = self.p
+        # encoder: frames are the batch; the last conv of a stage writes into the concat buffer
+        stages = [("enc1", 4, 32, 64, H, W, self.E1, self.F1), ("enc2", 6, 64, 128, H // 2, W // 2, self.E2, self.F2),
+                  ("enc3", 6, 128, 256, H // 4, W // 4, self.E3, self.F3)]
+        src, src_bs, src_pitch = self.B0, 32, 32 * F
+        for stage, n_conv, cin, cout, h, w, pingpong, catbuf in stages:
+            ho, wo = h // 2, w // 2
+            for i in range(n_conv):
+                name = f"{stage}.{i}"
+                last = i == n_conv - 1
+                dst = catbuf if last else pingpong[i % 2]
+                dst_bs, dst_pitch = (cout, cout * F) if last else (ho * wo * cout, cout)
+                if i == 0:
+                    self._conv(src, src_bs, src_pitch, name, dst, dst_bs, dst_pitch, F, h, w, cin, cout, 3, 2,
+                               EPI_BIAS_BN_GELU, scale=p[f"{name}.scale"], shift=p[f"{name}.shift"])
+                else:
+                    self._conv(src, src_bs, src_pitch, name, dst, dst_bs, dst_pitch, F, ho, wo, cout, cout, 3, 1,
+                               EPI_BIAS_BN_GELU, scale=p[f"{name}.scale"], shift=p[f"{name}.shift"])
+                src, src_bs, src_pitch = dst, dst_bs, dst_pitch
+        # decoder
+        def block(name, coarse, c_in, ch, cw, tmp, cat, skip, skip_c, lat, out, work):
+            self._conv(coarse, 0, c_in, f"{name}.u1", tmp, 0, lat, 1, 1, ch * cw, c_in, lat, 1, 1, EPI_BIAS)
+            self._up(tmp, lat, ch, cw, lat, cat, 2 * lat)
+            self._conv(skip, 0, skip_c, f"{name}.u3", cat, 0, 2 * lat, 1, 1, 4 * ch * cw, skip_c, lat, 1, 1, EPI_BIAS, y_off=lat)
+            self._conv(cat, 0, 2 * lat, f"{name}.u4", work[0], 0, out, 1, 2 * ch, 2 * cw, 2 * lat, out, 3, 1, EPI_BIAS)
+            self._conv(work[0], 0, out, f"{name}.u5", work[1], 0, out, 1, 2 * ch, 2 * cw, out, out, 3, 1, EPI_BIAS)
+            return work[1]
+        s = block("dec1", self.F3, 256 * F, H // 8, W // 8, self.T1, self.CAT1, self.F2, 128 * F, 256, 256, self.S)
+        t = block("dec2", s, 256, H // 4, W // 4, self.T2, self.CAT2, self.F1, 64 * F, 128, 128, self.T)
+        u = block("dec3", t, 128, H // 2, W // 2, self.T3, self.CAT3, self.B0, 32 * F, 64, 64, self.U)
+        self._conv(u, 0, 64, "dec4", self.DEC, 0, 64, 1, H, W, 64, 64, 3, 1, EPI_BIAS)
+        return self.DEC
+
+    def head(self, pc0: torch.Tensor, slot0: int = 1, slot1: int = 2) -> torch.Tensor:
+        n = pc0.shape[0]
+        p = self.p
+        F = self.F
+        st = self.lib.himo_head_gather(n, self.pid[slot0].data_ptr(), self.offsets[slot0].data_ptr(),
+                                       self.B0.data_ptr() + 4 * 32 * slot0, self.B0.data_ptr() + 4 * 32 * slot1, 32 * F,
+                                       self.DEC.data_ptr(), 64, p["head.offset.weight"].data_ptr(),
+                                       p["head.offset.bias"].data_ptr(), self.hx.data_ptr(), self.rhx.data_ptr(), 192,
+                                       _lib.stream_handle())
+        _lib.check(st, "himo_head_gather")
+        for _ in range(spec.GRU_ITERS):
+            self._conv(self.hx, 0, 192, "head.gru.zr", self.zbuf, 0, 128, 1, 1, n, 192, 256, 1, 1, EPI_GRU_ZR,
+                       aux_in=self.hx, aux_in_pitch=192, aux_out=self.rhx, aux_out_pitch=192)
+            self._conv(self.rhx, 0, 192, "head.gru.q", self.zbuf, 0, 128, 1, 1, n, 192, 128, 1, 1, EPI_GRU_Q,
+                       aux_in=self.zbuf, aux_in_pitch=128, aux_out=self.hx, aux_out_pitch=192)
+        self._conv(self.hx, 0, 192, "head.dec1", self.y1, 0, 32, 1, 1, n, 192, 32, 1, 1, EPI_BIAS_GELU)
+        flow = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        st = self.lib.himo_head_final(n, self.y1.data_ptr(), 32, p["head.dec2.weight"].data_ptr(),
+                                      p["head.dec2.bias"].data_ptr(), self.pid[slot0].data_ptr(),
+                                      self.xyz_t[slot0].data_ptr(), pc0.data_ptr(), pc0.shape[1], flow.data_ptr(),
+                                      _lib.stream_handle())
+        _lib.check(st, "himo_head_final")
+        return flow
+
+    def forward(self, pch1, pc0, pc1, pose_h1, pose0, pose1) -> torch.Tensor:
+        dev = self.device
+        to_dev = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(dev, torch.float32).contiguous()
+        pch1, pc0, pc1 = to_dev(pch1), to_dev(pc0), to_dev(pc1)
+        inv1 = np.linalg.inv(np.asarray(pose1, np.float64))
+        T0 = inv1 @ np.asarray(pose0, np.float64)
+        Th = inv1 @ np.asarray(pose_h1, np.float64)
+        self.pillarize_into(0, pch1, Th)
+        self.pillarize_into(1, pc0, T0)
+        self.pillarize_into(2, pc1, np.eye(4))
+        self.backbone()
+        return self.head(pc0)
+
+    def pillarize_into(self, slot: int, pts: torch.Tensor, transform):
+        """Sweep -> channel group ``slot`` of B0 (pitch 96)."""
+        n = pts.shape[0]
+        self._reserve_points(n)
+        T = _f32x(np.asarray(transform, dtype=np.float32).reshape(-1))
+        st = self.lib.himo_pillarize(n, pts.data_ptr(), pts.shape[1], T, self._range, self._voxel, self._centre,
+                                     self.W, self.H, self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
+                                     self.p["pfn.shift"].data_ptr(), self.xyz_t[slot].data_ptr(), self.pid[slot].data_ptr(),
+                                     self.offsets[slot].data_ptr(), self.B0.data_ptr() + 4 * 32 * slot, 32 * self.F,
+                                     self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle())
+        _lib.check(st, "himo_pillarize")
+
+
+# ---- stand-alone operators (tests / experiments): the same kernels on caller-provided tensors -------------------
+def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: int = 1, epilogue: int = EPI_BIAS,
+                scale: torch.Tensor | None = None, shift: torch.Tensor | None = None) -> torch.Tensor:
+    """x [N,H,W,Cin] float32 (contiguous, device), weight [k,k,Cin,Cout] -> y [N,Ho,Wo,Cout]."""
+    lib = _lib.load()
+    n, h, w, cin = x.shape
+    k, _, _, cout = weight.shape
+    ho, wo = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    d = ConvDesc()
+    d.x = x.data_ptr(); d.x_batch_stride = h * w * cin; d.x_pitch = cin
+    d.w = weight.data_ptr(); d.bias = bias.data_ptr()
+    d.scale = None if scale is None else scale.data_ptr(); d.shift = None if shift is None else shift.data_ptr()
+    d.y = y.data_ptr(); d.y_batch_stride = ho * wo * cout; d.y_pitch = cout
+    if k == 1:
+        d.n, d.h, d.w_in = n, 1, h * w
+    else:
+        d.n, d.h, d.w_in = n, h, w
+    d.cin, d.cout, d.ksize, d.stride, d.epilogue = cin, cout, k, stride, epilogue
+    _lib.check(lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), "himo_conv2d")
+    return y
+
+
+def upsample2x_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """x [H,W,C] -> [2H,2W,C], bilinear, align_corners=True."""
+    lib = _lib.load()
+    h, w, c = x.shape
+    y = torch.empty((2 * h, 2 * w, c), dtype=torch.float32, device=x.device)
+    _lib.check(lib.himo_upsample2x(x.data_ptr(), c, h, w, c, y.data_ptr(), c, _lib.stream_handle()), "himo_upsample2x")
+    return y

@@ -187,6 +187,58 @@ int himo_eval_instances(int n_frames, int64_t total_points,
                         himo_instance_record* d_records, int64_t max_records, int64_t* d_counts,
                         void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * a10: scene-flow network (voxelise -> encoder/decoder -> per-point flow).
+ * The reference's implementation is in the absent OpenSceneFlow submodule: these
+ * entry points have NO reference lines to cite beyond the call sites README.md:50 (`save.py`) and the
+ * hyper-parameters at assets/slurm/ssl-train-av2.sh:32-33; the specification is himo_amd/seflow/spec.py.
+ * All feature maps are NHWC float32 addressed as base + n*batch_stride + pixel*pitch + channel.
+ */
+/* One sweep: rigid transform (h_transform: row-major 4x4 float32), dynamic pillarisation on a
+ * grid_w x grid_h grid (h_range = min xyz, h_voxel = cell size, h_centre_offset = voxel/2 + min as
+ * float32), pillar feature net Linear(9,32)+BN+ReLU+mean -> 32 floats at d_image[cell * image_pitch] (every cell written).
+ * Also returns the transformed points, each point's cell (-1 = out of range) and its offset to the cell
+ * centre. */
+size_t himo_pillar_workspace_bytes(int64_t max_points, int grid_w, int grid_h);
+int himo_pillarize(int64_t n, const float* d_pts, int pc_stride, const float* h_transform,
+                   const float* h_range, const float* h_voxel, const float* h_centre_offset,
+                   int grid_w, int grid_h,
+                   const float* d_pfn_weight, const float* d_pfn_scale, const float* d_pfn_shift,
+                   float* d_xyz_t, int32_t* d_pid, float* d_offsets, float* d_image, int image_pitch,
+                   void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* NHWC float32 convolution (ksize 3 pad 1 stride 1|2, or ksize 1) / row GEMM on v_mfma_f32_32x32x2_f32
+ * with a fused epilogue. */
+#define HIMO_EPI_BIAS 0          /* y = acc + bias */
+#define HIMO_EPI_BIAS_BN_GELU 1  /* y = gelu((acc + bias) * scale + shift) */
+#define HIMO_EPI_BIAS_GELU 2     /* y = gelu(acc + bias) */
+#define HIMO_EPI_GRU_ZR 3        /* cols [0,C/2): y = sigmoid(.) (z); cols [C/2,C): aux_out = sigmoid(.) * aux_in (r*h) */
+#define HIMO_EPI_GRU_Q 4         /* aux_out = (1 - aux_in) * aux_out + aux_in * tanh(acc + bias)   (aux_in = z, aux_out = h) */
+typedef struct himo_conv_desc {
+    const float* x; int64_t x_batch_stride; int x_pitch;   /* input  (device) */
+    const float* w;                                        /* [ksize][ksize][cin][cout] (device) */
+    const float* bias; const float* scale; const float* shift;   /* [cout] (device; scale/shift for BN) */
+    float* y; int64_t y_batch_stride; int y_pitch;         /* output (device) */
+    int n, h, w_in, cin, cout, ksize, stride, epilogue;
+    const float* aux_in; int aux_in_pitch;                 /* GRU epilogues, [rows][pitch] */
+    float* aux_out; int aux_out_pitch;
+} himo_conv_desc;
+int himo_conv2d(const himo_conv_desc* h_desc, void* stream);
+
+/* bilinear x2 upsampling, align_corners = true; c channels of every pixel, NHWC with pitches */
+int himo_upsample2x(const float* d_x, int x_pitch, int h, int w, int c, float* d_y, int y_pitch, void* stream);
+
+/* per-point head glue: hx[i] = [img0[cell], img1[cell], dec[cell], Linear(3,64)(offset)] (192 floats; zeros for
+ * dropped points), rhx[i][128:192] = the same Linear output */
+int himo_head_gather(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0,
+                     const float* d_img1, int img_pitch, const float* d_dec, int dec_pitch,
+                     const float* d_w_off, const float* d_b_off, float* d_hx, float* d_rhx, int pitch, void* stream);
+/* flow[i] = (xyz_t[i] - pts[i]) + (cell >= 0 ? y1[i] @ w2 + b2 : 0): the (N,3) flow INCLUDING ego motion that
+ * save_zip.py:117 consumes */
+int himo_head_final(int64_t n, const float* d_y1, int y1_pitch, const float* d_w2, const float* d_b2,
+                    const int32_t* d_pid, const float* d_xyz_t, const float* d_pts, int pc_stride,
+                    float* d_flow, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

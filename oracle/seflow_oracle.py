@@ -1,0 +1,164 @@
+"""CPU ORACLE for the scene-flow network (stage a10) -- test infrastructure, NOT product code.
+
+PARITY UNPINNED: the reference's network source (OpenSceneFlow submodule) is absent from
+/root/reference, there is no checkpoint and no golden flow (SURVEY.md sections 0 and 8c), so this
+file restates THIS BUILD'S OWN specification (himo_amd/seflow/spec.py) with plain PyTorch float32
+ops on the CPU.  It pins the HIP kernels against an independent implementation of the same spec,
+not against the reference.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import it.
+
+All functions are functional: they take the parameter dict produced by
+``himo_amd.seflow.spec.init_params`` (numpy float32 arrays) and numpy / torch inputs.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+VOXEL_SIZE = (0.2, 0.2, 6.0)
+PC_RANGE = (-51.2, -51.2, -3.0, 51.2, 51.2, 3.0)
+GRID_H, GRID_W = 512, 512
+BN_EPS_PFN, BN_EPS = 1e-3, 1e-5
+GRU_ITERS = 4
+
+
+def _t(x):
+    return x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+
+
+def ego_transform(pose_from, pose_to) -> np.ndarray:
+    """4x4 float64 taking points of sweep `from` into sweep `to`'s frame: inv(pose_to) @ pose_from."""
+    return np.linalg.inv(np.asarray(pose_to, np.float64)) @ np.asarray(pose_from, np.float64)
+
+
+def transform_points(xyz, T) -> torch.Tensor:
+    """float32 p' = R p + t as ((x*R0 + y*R1) + z*R2) + t with every product / sum rounded separately
+    (spec.py step 0: the pillar a point lands in is a discrete decision, so the rounding is specified)."""
+    p = _t(xyz)[:, :3].float()
+    R = np.asarray(T[:3, :3], np.float32)
+    t = np.asarray(T[:3, 3], np.float32)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    cols = [((x * float(R[r, 0]) + y * float(R[r, 1])) + z * float(R[r, 2])) + float(t[r]) for r in range(3)]
+    return torch.stack(cols, dim=1)
+
+
+def voxelize(xyz: torch.Tensor):
+    """valid (N,) bool, iy (N,), ix (N,) int64 -- float32 arithmetic: floor((p - min) / size)."""
+    mn = torch.tensor(PC_RANGE[:3], dtype=torch.float32)
+    vs = torch.tensor(VOXEL_SIZE, dtype=torch.float32)
+    c = torch.floor((xyz - mn) / vs)
+    valid = (c[:, 0] >= 0) & (c[:, 0] < GRID_W) & (c[:, 1] >= 0) & (c[:, 1] < GRID_H) & (c[:, 2] >= 0) & (c[:, 2] < 1)
+    return valid, c[:, 1].long(), c[:, 0].long()
+
+
+def pillar_image(params, xyz: torch.Tensor):
+    """(32, H, W) pseudo-image + per-point (valid, pillar id, offset-to-centre)."""
+    valid, iy, ix = voxelize(xyz)
+    pid = iy * GRID_W + ix
+    pts = xyz[valid]
+    pv = pid[valid]
+    n_cells = GRID_H * GRID_W
+    cnt = torch.zeros(n_cells, dtype=torch.float32).index_add_(0, pv, torch.ones(len(pv)))
+    sums = torch.zeros(n_cells, 3, dtype=torch.float32).index_add_(0, pv, pts)       # sequential, in point order
+    mean = sums[pv] / cnt[pv, None]
+    vs = torch.tensor(VOXEL_SIZE, dtype=torch.float32)
+    off = torch.tensor([VOXEL_SIZE[0] / 2 + PC_RANGE[0], VOXEL_SIZE[1] / 2 + PC_RANGE[1], VOXEL_SIZE[2] / 2 + PC_RANGE[2]],
+                       dtype=torch.float32)
+    cell = torch.stack([ix[valid].float(), iy[valid].float(), torch.zeros(len(pv))], dim=1)
+    centre = cell * vs + off
+    feats = torch.cat([pts, pts - mean, pts - centre], dim=1)                        # (n, 9)
+    y = feats @ _t(params["pfn.weight"])
+    scale = _t(params["pfn.bn.gamma"]) / torch.sqrt(_t(params["pfn.bn.var"]) + BN_EPS_PFN)
+    shift = _t(params["pfn.bn.beta"]) - _t(params["pfn.bn.mean"]) * scale
+    y = torch.relu(y * scale + shift)
+    acc = torch.zeros(n_cells, y.shape[1], dtype=torch.float32).index_add_(0, pv, y)
+    img = acc / cnt.clamp(min=1.0)[:, None]
+    img = img.T.reshape(-1, GRID_H, GRID_W).contiguous()
+    offsets = torch.zeros_like(xyz)
+    offsets[valid] = pts - centre
+    return img, valid, pid, offsets
+
+
+def _conv(params, name, x, stride=1, pad=1):
+    w = _t(params[f"{name}.weight"]).permute(3, 2, 0, 1).contiguous()                 # [kh,kw,ci,co] -> [co,ci,kh,kw]
+    return F.conv2d(x, w, _t(params[f"{name}.bias"]), stride=stride, padding=pad)
+
+
+def conv_bn_gelu(params, name, x, stride):
+    y = _conv(params, name, x, stride=stride)
+    scale = _t(params[f"{name}.bn.gamma"]) / torch.sqrt(_t(params[f"{name}.bn.var"]) + BN_EPS)
+    shift = _t(params[f"{name}.bn.beta"]) - _t(params[f"{name}.bn.mean"]) * scale
+    return F.gelu(y * scale[None, :, None, None] + shift[None, :, None, None])
+
+
+ENC_STAGES = (("enc1", 4), ("enc2", 6), ("enc3", 6))
+
+
+def encoder(params, imgs: torch.Tensor):
+    """imgs (F,32,H,W) -> [(F,64,H/2,..), (F,128,H/4,..), (F,256,H/8,..)]"""
+    outs, x = [], imgs
+    for stage, n in ENC_STAGES:
+        for i in range(n):
+            x = conv_bn_gelu(params, f"{stage}.{i}", x, stride=2 if i == 0 else 1)
+        outs.append(x)
+    return outs
+
+
+def upsample_skip(params, name, coarse, skip):
+    a = _conv(params, f"{name}.u1", coarse, pad=0)
+    a = F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=True)
+    b = _conv(params, f"{name}.u3", skip, pad=0)
+    y = _conv(params, f"{name}.u4", torch.cat([a, b], dim=1))
+    return _conv(params, f"{name}.u5", y)
+
+
+def backbone(params, imgs: torch.Tensor):
+    """imgs (F,32,H,W) -> (64,H,W) decoder map."""
+    f1, f2, f3 = encoder(params, imgs)
+    cat = lambda t: t.reshape(1, -1, t.shape[2], t.shape[3])                          # frames stacked on channels
+    s = upsample_skip(params, "dec1", cat(f3), cat(f2))
+    t = upsample_skip(params, "dec2", s, cat(f1))
+    u = upsample_skip(params, "dec3", t, cat(imgs))
+    return _conv(params, "dec4", u)[0]
+
+
+def head(params, img0, img1, dec, pid, offsets):
+    """per-point GRU head for the valid pc0 points; pid / offsets already restricted to them."""
+    gather = lambda im: im.reshape(im.shape[0], -1)[:, pid].T                          # (n, C)
+    h = torch.cat([gather(img0), gather(img1), gather(dec)], dim=1)                    # (n, 128)
+    x = offsets @ _t(params["head.offset.weight"]) + _t(params["head.offset.bias"])    # (n, 64)
+    W = lambda g: _t(params[f"head.gru.{g}.weight"])
+    B = lambda g: _t(params[f"head.gru.{g}.bias"])
+    for _ in range(GRU_ITERS):
+        hx = torch.cat([h, x], dim=1)
+        z = torch.sigmoid(hx @ W("z") + B("z"))
+        r = torch.sigmoid(hx @ W("r") + B("r"))
+        q = torch.tanh(torch.cat([r * h, x], dim=1) @ W("q") + B("q"))
+        h = (1 - z) * h + z * q
+    y = F.gelu(torch.cat([h, x], dim=1) @ _t(params["head.dec1.weight"]) + _t(params["head.dec1.bias"]))
+    return y @ _t(params["head.dec2.weight"]) + _t(params["head.dec2.bias"])
+
+
+@torch.no_grad()
+def forward(params, pch1, pc0, pc1, pose_h1, pose0, pose1, return_intermediates: bool = False):
+    """One sample -> (N0,3) float32 flow INCLUDING ego motion, aligned with pc0 rows."""
+    p0 = _t(pc0)[:, :3].float()
+    T0, Th = ego_transform(pose0, pose1), ego_transform(pose_h1, pose1)
+    p0t = transform_points(p0, T0)
+    pht = transform_points(pch1, Th)
+    p1 = _t(pc1)[:, :3].float()
+    pose_flow = p0t - p0
+    img_h, *_ = pillar_image(params, pht)
+    img0, valid0, pid0, off0 = pillar_image(params, p0t)
+    img1, *_ = pillar_image(params, p1)
+    imgs = torch.stack([img_h, img0, img1])
+    dec = backbone(params, imgs)
+    res = head(params, img0, img1, dec, pid0[valid0], off0[valid0])
+    flow = pose_flow.clone()
+    flow[valid0] = flow[valid0] + res
+    out = flow.numpy()
+    if return_intermediates:
+        return out, {"imgs": imgs.numpy(), "dec": dec.numpy(), "valid0": valid0.numpy(), "pose_flow": pose_flow.numpy(),
+                     "res": res.numpy()}
+    return out
