@@ -56,8 +56,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     constexpr int PW = KS == 1 ? BM : (TW - 1) * S + KS;
     constexpr int PP = PH * PW + 1;                 // +1: break the power-of-two plane stride
     constexpr int WN = BN / 2, NI = WN / 32;
-    __shared__ float patchT[BK * PP];
-    __shared__ float wt[BK * BN];
+    constexpr int T = KS * KS;
+    constexpr bool kPatchDouble = S == 1;           // stride-2 patches (561 px) stay single-buffered
+    constexpr int kPatchBufs = kPatchDouble ? 2 : 1;
+    constexpr int kPatchItems = PH * PW * (BK / 4);
+    constexpr int kPatchPerThread = (kPatchItems + 255) / 256;
+    constexpr int kWPerThread = BK * (BN / 4) / 256;
+    __shared__ float patchT[kPatchBufs][BK * PP];
+    __shared__ float wt[2][BK * BN];
 
     // ---- block -> (image, spatial tile, channel tile) ----
     const int n_tiles_n = (a.Cout + BN - 1) / BN;
@@ -102,54 +108,124 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int iy0 = oy0 * S - (KS / 2), ix0 = ox0 * S - (KS / 2);
     const int64_t in_rows = (int64_t)a.H * a.W;
 
-    for (int ci0 = 0; ci0 < a.Cin; ci0 += BK) {
-        __syncthreads();                            // everyone is done reading the previous patch
-        // ---- stage the input patch slab, transposed to k-major ----
-        for (int item = threadIdx.x; item < PH * PW * (BK / 4); item += 256) {
-            const int pp = item / (BK / 4), q = item % (BK / 4);
+    // global -> registers (issued early, consumed after the MFMAs of the current step)
+    auto load_patch = [&](int ci0, float4 (&r)[kPatchDouble ? kPatchPerThread : 1]) {
+        if constexpr (!kPatchDouble) return;
+#pragma unroll
+        for (int it = 0; it < kPatchPerThread; ++it) {
+            const int item = it * 256 + threadIdx.x;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            int64_t pix;
-            bool ok;
-            if (KS == 1) { pix = row0 + pp; ok = pix < in_rows; }
-            else {
-                const int iy = iy0 + pp / PW, ix = ix0 + pp % PW;
-                ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                pix = (int64_t)iy * a.W + ix;
+            if (item < kPatchItems) {
+                const int pp = item / (BK / 4), q = item % (BK / 4);
+                int64_t pix;
+                bool ok;
+                if (KS == 1) { pix = row0 + pp; ok = pix < in_rows; }
+                else {
+                    const int iy = iy0 + pp / PW, ix = ix0 + pp % PW;
+                    ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                    pix = (int64_t)iy * a.W + ix;
+                }
+                const int ci = ci0 + q * 4;
+                if (ok && ci < a.Cin) v = *reinterpret_cast<const float4*>(xin + pix * a.x_pitch + ci);
             }
-            const int ci = ci0 + q * 4;
-            if (ok && ci < a.Cin) v = *reinterpret_cast<const float4*>(xin + pix * a.x_pitch + ci);
-            patchT[(q * 4 + 0) * PP + pp] = v.x;
-            patchT[(q * 4 + 1) * PP + pp] = v.y;
-            patchT[(q * 4 + 2) * PP + pp] = v.z;
-            patchT[(q * 4 + 3) * PP + pp] = v.w;
+            r[it] = v;
         }
-#pragma unroll 1
-        for (int tap = 0; tap < KS * KS; ++tap) {
-            __syncthreads();                        // previous tap's weight slab fully consumed
-            // ---- stage the [BK][BN] weight slab of this tap ----
-            for (int item = threadIdx.x; item < BK * (BN / 4); item += 256) {
-                const int k = item / (BN / 4), q = item % (BN / 4);
-                const int ci = ci0 + k, co = n0 + q * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ci < a.Cin && co < a.Cout)
-                    v = *reinterpret_cast<const float4*>(a.w + ((int64_t)tap * a.Cin + ci) * a.Cout + co);
-                *reinterpret_cast<float4*>(&wt[k * BN + q * 4]) = v;
+    };
+    // registers -> LDS, transposed to k-major so that an A fragment is one conflict-free ds_read_b32
+    auto store_patch = [&](int buf, const float4 (&r)[kPatchDouble ? kPatchPerThread : 1]) {
+        if constexpr (!kPatchDouble) return;
+#pragma unroll
+        for (int it = 0; it < kPatchPerThread; ++it) {
+            const int item = it * 256 + threadIdx.x;
+            if (item < kPatchItems) {
+                const int pp = item / (BK / 4), q = item % (BK / 4);
+                float* dst = &patchT[buf][(q * 4) * PP + pp];
+                dst[0] = r[it].x; dst[PP] = r[it].y; dst[2 * PP] = r[it].z; dst[3 * PP] = r[it].w;
             }
-            __syncthreads();
+        }
+    };
+    auto load_w = [&](int tap, int ci0, float4 (&r)[kWPerThread]) {
+#pragma unroll
+        for (int it = 0; it < kWPerThread; ++it) {
+            const int item = it * 256 + threadIdx.x;
+            const int k = item / (BN / 4), q = item % (BN / 4);
+            const int ci = ci0 + k, co = n0 + q * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < a.Cin && co < a.Cout)
+                v = *reinterpret_cast<const float4*>(a.w + ((int64_t)tap * a.Cin + ci) * a.Cout + co);
+            r[it] = v;
+        }
+    };
+    auto store_w = [&](int buf, const float4 (&r)[kWPerThread]) {
+#pragma unroll
+        for (int it = 0; it < kWPerThread; ++it) {
+            const int item = it * 256 + threadIdx.x;
+            *reinterpret_cast<float4*>(&wt[buf][(item / (BN / 4)) * BN + (item % (BN / 4)) * 4]) = r[it];
+        }
+    };
+
+    // direct (unpipelined) patch staging, one float4 in flight per thread: used for the prologue-free
+    // stride-2 variant whose 561-pixel patch would need 36 prefetch registers per lane
+    auto stage_patch_direct = [&](int ci0) {
+        for (int item = threadIdx.x; item < kPatchItems; item += 256) {
+            const int pp = item / (BK / 4), q = item % (BK / 4);
+            const int iy = iy0 + pp / PW, ix = ix0 + pp % PW;
+            const bool ok = KS == 1 ? (row0 + pp < in_rows) : (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W);
+            const int64_t pix = KS == 1 ? row0 + pp : (int64_t)iy * a.W + ix;
+            const int ci = ci0 + q * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && ci < a.Cin) v = *reinterpret_cast<const float4*>(xin + pix * a.x_pitch + ci);
+            float* dst = &patchT[0][(q * 4) * PP + pp];
+            dst[0] = v.x; dst[PP] = v.y; dst[2 * PP] = v.z; dst[3 * PP] = v.w;
+        }
+    };
+
+    float4 pr[kPatchDouble ? kPatchPerThread : 1], wr[kWPerThread];
+    load_w(0, 0, wr);
+    if constexpr (kPatchDouble) { load_patch(0, pr); store_patch(0, pr); }
+    else stage_patch_direct(0);
+    store_w(0, wr);
+    __syncthreads();
+
+    int pbuf = 0, wbuf = 0;
+#pragma unroll 1
+    for (int ci0 = 0; ci0 < a.Cin; ci0 += BK) {
+#pragma unroll 1
+        for (int tap = 0; tap < T; ++tap) {
+            const bool last_tap = tap == T - 1;
+            const bool has_next = !(last_tap && ci0 + BK >= a.Cin);
+            const int ntap = last_tap ? 0 : tap + 1, nci0 = last_tap ? ci0 + BK : ci0;
+            if (has_next) {                                  // software pipeline: next slab's loads fly under the MFMAs
+                load_w(ntap, nci0, wr);
+                if (last_tap && kPatchDouble) load_patch(nci0, pr);
+            }
             const int tapoff = KS == 1 ? 0 : (tap / KS) * PW + (tap % KS);
+            const float* __restrict__ pa = patchT[kPatchDouble ? pbuf : 0];
+            const float* __restrict__ pw = wt[wbuf];
 #pragma unroll
             for (int t = 0; t < BK / 2; ++t) {
                 const int k = 2 * t + lh;
                 float af[2], bf[NI];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) af[mi] = patchT[k * PP + ppA[mi] + tapoff];
+                for (int mi = 0; mi < 2; ++mi) af[mi] = pa[k * PP + ppA[mi] + tapoff];
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bf[ni] = wt[k * BN + wn * WN + ni * 32 + li];
+                for (int ni = 0; ni < NI; ++ni) bf[ni] = pw[k * BN + wn * WN + ni * 32 + li];
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (has_next) {
+                store_w(wbuf ^ 1, wr);
+                if (last_tap && kPatchDouble) store_patch(pbuf ^ 1, pr);
+            }
+            __syncthreads();
+            wbuf ^= 1;
+            if (last_tap && kPatchDouble) pbuf ^= 1;
+            if (last_tap && !kPatchDouble && has_next) {     // single-buffered patch: refill after everyone is done with it
+                stage_patch_direct(nci0);
+                __syncthreads();
             }
         }
     }

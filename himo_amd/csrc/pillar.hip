@@ -10,7 +10,7 @@
 // Kernels (one sweep per call, all on one stream):
 //   pillar_assign_kernel    coalesced read of the raw point rows, float32 rigid transform into the
 //                           target frame, cell index, integer histogram of points per cell
-//   cell_scan_kernel        exclusive scan of the 262,144 cell counts (one 1024-thread block)
+//   cell_scan_*_kernel      two-level exclusive scan of the 262,144 cell counts
 //   pillar_fill_kernel      counting-sort scatter of point indices into per-cell lists
 //   pillar_feature_kernel   half a wavefront (32 lanes = 32 channels) per cell: the cell's point
 //                           list is staged in LDS (through global memory for the rare cell with more
@@ -44,7 +44,8 @@ struct PillarArgs {
     int* pid;                 // [n]  cell id (iy * W + ix) or -1
     float* offsets;           // [n][3] point - cell centre (zeros for dropped points)
     float* image; int image_pitch;   // [H*W][pitch], 32 channels written per cell
-    int* cell_count;          // [H*W + 1] -> exclusive offsets after the scan
+    int* cell_count;          // [H*W] -> block-local exclusive offsets after the scan
+    int* block_sum;           // [H*W/1024 + 1] exclusive offsets of the 1024-cell blocks
     int* cell_cursor;         // [H*W]
     int* order;               // [n] point indices grouped by cell (scatter order)
     int* order2;              // [n] ascending order for cells too crowded for the LDS stage
@@ -76,14 +77,37 @@ __global__ __launch_bounds__(256) void pillar_assign_kernel(PillarArgs a) {
     a.pid[i] = cell;
 }
 
-// exclusive scan of `n` ints in place (v[n] = total); one block of 1024 threads
-__global__ __launch_bounds__(1024) void cell_scan_kernel(int* v, int n) {
+// exclusive scan of the cell counts in two levels: every 1024-cell block scans itself in place and
+// leaves its total in block_sum; a single small block then scans the (<= 1024) block totals.
+// Consumers read cell_offset(cell) = v[cell] + block_sum[cell / 1024].
+constexpr int kScanBlock = 1024;
+
+__global__ __launch_bounds__(256) void cell_scan_local_kernel(int* v, int n, int* block_sum) {
+    __shared__ int wsum[4];
+    const int base = blockIdx.x * kScanBlock + threadIdx.x * 4;
+    int x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = base + k < n ? v[base + k] : 0;
+    const int mine = x[0] + x[1] + x[2] + x[3];
+    int incl = mine;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += y;
+    }
+    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int run = incl - mine;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wsum[w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (base + k < n) v[base + k] = run; run += x[k]; }
+    if (threadIdx.x == 255) block_sum[blockIdx.x] = run;
+}
+
+__global__ __launch_bounds__(1024) void cell_scan_top_kernel(int* block_sum, int nblk) {
     __shared__ int part[1024];
-    const int per = (n + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = min(lo + per, n);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += v[i];
-    part[threadIdx.x] = s;
+    const int x = (int)threadIdx.x < nblk ? block_sum[threadIdx.x] : 0;
+    part[threadIdx.x] = x;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
         const int y = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
@@ -91,9 +115,16 @@ __global__ __launch_bounds__(1024) void cell_scan_kernel(int* v, int n) {
         part[threadIdx.x] += y;
         __syncthreads();
     }
-    int run = part[threadIdx.x] - s;
-    for (int i = lo; i < hi; ++i) { const int c = v[i]; v[i] = run; run += c; }
-    if (threadIdx.x == 1023) v[n] = part[1023];
+    if ((int)threadIdx.x < nblk) block_sum[threadIdx.x] = part[threadIdx.x] - x;
+    if (threadIdx.x == 1023) block_sum[nblk] = part[1023];
+}
+
+__device__ inline int cell_offset(const PillarArgs& a, int cell);
+
+__device__ inline int cell_offset(const PillarArgs& a, int cell) {
+    const int n_cells = a.g.W * a.g.H;
+    return cell >= n_cells ? a.block_sum[(n_cells + kScanBlock - 1) / kScanBlock]
+                           : a.cell_count[cell] + a.block_sum[cell / kScanBlock];
 }
 
 __global__ __launch_bounds__(256) void pillar_fill_kernel(PillarArgs a) {
@@ -102,7 +133,7 @@ __global__ __launch_bounds__(256) void pillar_fill_kernel(PillarArgs a) {
     const int cell = a.pid[i];
     if (cell < 0) return;
     const int slot = atomicAdd(&a.cell_cursor[cell], 1);
-    a.order[a.cell_count[cell] + slot] = (int)i;
+    a.order[cell_offset(a, cell) + slot] = (int)i;
 }
 
 constexpr int kCellsPerBlock = 8;     // 8 cells x 32 lanes = 256 threads
@@ -115,8 +146,8 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarArgs a) {
     const int cell = blockIdx.x * kCellsPerBlock + sub;
     const int n_cells = a.g.W * a.g.H;
     const bool live = cell < n_cells;
-    const int beg = live ? a.cell_count[cell] : 0;
-    const int cnt = live ? a.cell_count[cell + 1] - beg : 0;
+    const int beg = live ? cell_offset(a, cell) : 0;
+    const int cnt = live ? cell_offset(a, cell + 1) - beg : 0;
     const bool staged = cnt <= kMaxStage;
 
     // ascending point order: rank every index among the cell's (short) list
@@ -180,9 +211,10 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarArgs a) {
 
 using namespace himo;
 
-static size_t pillar_ws(int64_t n, int cells) {
-    return round_up(((size_t)cells + 1) * 4, 16) + round_up((size_t)cells * 4, 16) + 2 * round_up((size_t)(n > 0 ? n : 1) * 4, 16);
-}
+static size_t ws_cells(int cells) { return round_up((size_t)cells * 4, 16); }
+static size_t ws_blocks(int cells) { return round_up(((size_t)(cells + kScanBlock - 1) / kScanBlock + 1) * 4, 16); }
+static size_t ws_points(int64_t n) { return round_up((size_t)(n > 0 ? n : 1) * 4, 16); }
+static size_t pillar_ws(int64_t n, int cells) { return 2 * ws_cells(cells) + ws_blocks(cells) + 2 * ws_points(n); }
 
 extern "C" size_t himo_pillar_workspace_bytes(int64_t max_points, int grid_w, int grid_h) {
     return pillar_ws(max_points, grid_w * grid_h) + 64;
@@ -215,19 +247,26 @@ extern "C" int himo_pillarize(int64_t n, const float* d_pts, int pc_stride, cons
     a.xyz_t = d_xyz_t; a.pid = d_pid; a.offsets = d_offsets; a.image = d_image; a.image_pitch = image_pitch;
     char* ws = reinterpret_cast<char*>(d_workspace);
     a.cell_count = reinterpret_cast<int*>(ws);
-    a.cell_cursor = reinterpret_cast<int*>(ws + round_up(((size_t)cells + 1) * 4, 16));
-    a.order = reinterpret_cast<int*>(ws + round_up(((size_t)cells + 1) * 4, 16) + round_up((size_t)cells * 4, 16));
-    a.order2 = a.order + round_up((size_t)(n > 0 ? n : 1) * 4, 16) / 4;
+    a.cell_cursor = reinterpret_cast<int*>(ws + ws_cells(cells));
+    a.block_sum = reinterpret_cast<int*>(ws + 2 * ws_cells(cells));
+    a.order = reinterpret_cast<int*>(ws + 2 * ws_cells(cells) + ws_blocks(cells));
+    a.order2 = a.order + ws_points(n) / 4;
+    const int nblk = (cells + kScanBlock - 1) / kScanBlock;
+    if (nblk > 1024) return HIMO_ERR_UNSUPPORTED;   // grids beyond 1M cells need a third scan level
 
-    HIMO_HIP(hipMemsetAsync(a.cell_count, 0, round_up(((size_t)cells + 1) * 4, 16) + round_up((size_t)cells * 4, 16), s));
+    HIMO_HIP(hipMemsetAsync(a.cell_count, 0, 2 * ws_cells(cells), s));
     const unsigned pblocks = (unsigned)((n + 255) / 256);
     if (n > 0) {
         ProfScope ps("pillar_assign_kernel", s);
         hipLaunchKernelGGL(pillar_assign_kernel, dim3(pblocks), dim3(256), 0, s, a);
     }
     HIMO_LAUNCH_CHECK("pillar_assign_kernel");
-    { ProfScope ps("cell_scan_kernel", s); hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, s, a.cell_count, cells); }
-    HIMO_LAUNCH_CHECK("cell_scan_kernel");
+    {
+        ProfScope ps("cell_scan_kernels", s);
+        hipLaunchKernelGGL(cell_scan_local_kernel, dim3(nblk), dim3(256), 0, s, a.cell_count, cells, a.block_sum);
+        hipLaunchKernelGGL(cell_scan_top_kernel, dim3(1), dim3(1024), 0, s, a.block_sum, nblk);
+    }
+    HIMO_LAUNCH_CHECK("cell_scan_kernels");
     if (n > 0) {
         ProfScope ps("pillar_fill_kernel", s);
         hipLaunchKernelGGL(pillar_fill_kernel, dim3(pblocks), dim3(256), 0, s, a);

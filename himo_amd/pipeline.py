@@ -1,0 +1,87 @@
+"""The per-frame motion-compensation pipeline of north_star on one MI355X:
+
+    3 sweeps (pch1, pc0, pc1) --voxelise + SeFlow++-style network (a10)--> per-point flow incl. ego motion
+                              --ego-motion removal, dt0, flow2compDis (a1-a4)--> comp_dis (N,3) float32
+
+i.e. what the reference does in two programs: ``OpenSceneFlow/save.py`` (README.md:50; absent
+submodule) writing ``<res_name>`` into the scene h5, then ``save_zip.py`` (save_zip.py:102-125)
+turning it into compensation distances.  Here the flow never leaves HBM: the network head writes
+each frame's flow into its rows of one ragged batch buffer and a single fused comp_dis launch
+finishes the whole batch.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from .compdis import CompDisEngine, FrameBatch
+from .seflow.model import SeFlowNet
+
+
+@dataclass
+class Sample:
+    """One network input resident in HBM.  Sweeps are (N,>=3) float32 rows; poses are host 4x4 float64."""
+    pch1: torch.Tensor
+    pc0: torch.Tensor
+    pc1: torch.Tensor
+    pose_h1: np.ndarray
+    pose0: np.ndarray
+    pose1: np.ndarray
+    lidar_dt: torch.Tensor            # (N0,) float32 of pc0
+    scene_id: str = ""
+    timestamp: int = 0
+
+    @classmethod
+    def from_frames(cls, fh: dict, f0: dict, f1: dict | None = None, device=None):
+        """Frame dicts (reference layout) -> Sample.  ``f1`` defaults to the ``pc1`` / ``pose1`` stored in ``f0``."""
+        dev = device if device is not None else _lib.require_gpu()
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        pc1 = f1["pc0"] if f1 is not None else f0["pc1"]
+        return cls(up(fh["pc0"]), up(f0["pc0"]), up(pc1), np.asarray(fh["pose0"], np.float64), np.asarray(f0["pose0"], np.float64),
+                   np.asarray(f0["pose1"], np.float64), up(f0["lidar_dt"]), f0.get("scene_id", ""), int(f0.get("timestamp", 0)))
+
+
+class HiMoPipeline:
+    def __init__(self, net: SeFlowNet | None = None, device=None, max_points: int = 140_000):
+        self.device = device if device is not None else _lib.require_gpu()
+        self.net = net if net is not None else SeFlowNet(device=self.device, max_points=max_points)
+        self.compdis = CompDisEngine(device=self.device)
+        self._batch = None
+        self._key = None
+
+    def _batch_for(self, samples) -> FrameBatch:
+        """Ragged batch container over the pc0 sweeps of ``samples`` (rebuilt only when the batch changes)."""
+        key = tuple(id(s) for s in samples)
+        if self._key != key:
+            counts = [int(s.pc0.shape[0]) for s in samples]
+            offsets = np.zeros(len(samples) + 1, dtype=np.int64)
+            np.cumsum(counts, out=offsets[1:])
+            dev = self.device
+            self._batch = FrameBatch(
+                offsets_host=offsets, offsets=torch.from_numpy(offsets).to(dev),
+                pose0=torch.from_numpy(np.stack([s.pose0 for s in samples])).to(dev),
+                pose1=torch.from_numpy(np.stack([s.pose1 for s in samples])).to(dev),
+                pc0=torch.cat([s.pc0 for s in samples], dim=0).contiguous(),
+                lidar_dt=torch.cat([s.lidar_dt for s in samples], dim=0).contiguous(),
+                flow=torch.empty((int(offsets[-1]), 3), dtype=torch.float32, device=dev),
+                meta=[(s.scene_id, s.timestamp) for s in samples])
+            self._out = {}
+            self._key = key
+        return self._batch
+
+    def flow(self, s: Sample, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Network only: (N0,3) flow including ego motion (the h5 ``<res_name>`` payload)."""
+        return self.net.forward_device(s.pch1, s.pc0, s.pc1, s.pose_h1, s.pose0, s.pose1, out=out)
+
+    def run(self, samples, sensor_dt: float = 0.1, refined: bool = False) -> dict:
+        """flow + comp_dis for a list of samples; asynchronous on the current stream.
+        Returns {"flow", "comp_dis"[, "refined"]} as (T,3) tensors plus "batch" for splitting per frame."""
+        batch = self._batch_for(samples)
+        o = batch.offsets_host
+        for k, s in enumerate(samples):
+            self.flow(s, out=batch.flow[int(o[k]):int(o[k + 1])])
+        res = self.compdis.run(batch, sensor_dt=sensor_dt, refined=refined, out=self._out)
+        return {"flow": batch.flow, "comp_dis": res["comp_dis"], "refined": res.get("refined"), "batch": batch}

@@ -181,7 +181,7 @@ class SeFlowNet:
         self._conv(u, 0, 64, "dec4", self.DEC, 0, 64, 1, H, W, 64, 64, 3, 1, EPI_BIAS)
         return self.DEC
 
-    def head(self, pc0: torch.Tensor, slot0: int = 1, slot1: int = 2) -> torch.Tensor:
+    def head(self, pc0: torch.Tensor, slot0: int = 1, slot1: int = 2, out: torch.Tensor | None = None) -> torch.Tensor:
         n = pc0.shape[0]
         p = self.p
         F = self.F
@@ -197,7 +197,9 @@ class SeFlowNet:
             self._conv(self.rhx, 0, 192, "head.gru.q", self.zbuf, 0, 128, 1, 1, n, 192, 128, 1, 1, EPI_GRU_Q,
                        aux_in=self.zbuf, aux_in_pitch=128, aux_out=self.hx, aux_out_pitch=192)
         self._conv(self.hx, 0, 192, "head.dec1", self.y1, 0, 32, 1, 1, n, 192, 32, 1, 1, EPI_BIAS_GELU)
-        flow = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        flow = out if out is not None else torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        if flow.shape != (n, 3) or flow.dtype != torch.float32 or not flow.is_contiguous():
+            raise ValueError("out must be a contiguous (N0,3) float32 tensor")
         st = self.lib.himo_head_final(n, self.y1.data_ptr(), 32, p["head.dec2.weight"].data_ptr(),
                                       p["head.dec2.bias"].data_ptr(), self.pid[slot0].data_ptr(),
                                       self.xyz_t[slot0].data_ptr(), pc0.data_ptr(), pc0.shape[1], flow.data_ptr(),
@@ -208,7 +210,10 @@ class SeFlowNet:
     def forward(self, pch1, pc0, pc1, pose_h1, pose0, pose1) -> torch.Tensor:
         dev = self.device
         to_dev = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(dev, torch.float32).contiguous()
-        pch1, pc0, pc1 = to_dev(pch1), to_dev(pc0), to_dev(pc1)
+        return self.forward_device(to_dev(pch1), to_dev(pc0), to_dev(pc1), pose_h1, pose0, pose1)
+
+    def forward_device(self, pch1, pc0, pc1, pose_h1, pose0, pose1, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Sweeps already in HBM as contiguous float32 (N,>=3) tensors; ``out`` may be a slice of a batch buffer."""
         inv1 = np.linalg.inv(np.asarray(pose1, np.float64))
         T0 = inv1 @ np.asarray(pose0, np.float64)
         Th = inv1 @ np.asarray(pose_h1, np.float64)
@@ -216,7 +221,7 @@ class SeFlowNet:
         self.pillarize_into(1, pc0, T0)
         self.pillarize_into(2, pc1, np.eye(4))
         self.backbone()
-        return self.head(pc0)
+        return self.head(pc0, out=out)
 
     def pillarize_into(self, slot: int, pts: torch.Tensor, transform):
         """Sweep -> channel group ``slot`` of B0 (pitch 96)."""
