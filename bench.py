@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- LiDAR frames/s of the HiMo motion-compensation hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames-per-step B] [--points P]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload pipeline|compdis]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one ragged batch of B synthetic 120k-point sweeps that
-is already resident in HBM.  Every rank owns its own B sweeps (frames shard embarrassingly; weak
-scaling); the only collective is the final gather of per-rank counts/checksums after the timed
-region.  Rank 0 prints ONE JSON line (contract in the task statement) that also carries
-  "roofline":     the dominant kernel's algorithmic bytes / its HIP-event-timed duration vs HBM peak,
-  "cpu_baseline": the numpy oracle (a port of the reference's CPU path) timed on this host.
+Workloads (synthetic 120k-point sweeps already resident in HBM when the clock starts):
+  pipeline (default)  north_star's per-frame path: voxelise 3 sweeps -> SeFlow++-style network forward (random-init,
+                      float32 on the matrix cores) -> per-point flow -> ego-motion removal, dt0, flow2compDis ->
+                      comp_dis.  A step = one batch of B frames (B network forwards + one fused comp_dis launch).
+  compdis             only stages a1-a4 (the part of the path the reference tree contains) over a ragged batch of
+                      B sweeps: the HBM-bound kernel on its own.
+Every rank owns its own frames (frames shard embarrassingly; weak scaling); the only collective is the final
+gather of per-rank counts after the timed region.  Rank 0 prints ONE JSON line that also carries
+  "roofline":     dominant kernel: algorithmic flops|bytes per launch / HIP-event-timed launch duration vs peak,
+  "cpu_baseline": the CPU restatement (oracle) timed on this host on a bounded sample.
 """
 from __future__ import annotations
 
@@ -27,49 +31,87 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+MFMA_F32_PEAK_TF = 157.3         # dense float32-input MFMA peak (MI355X_MICROARCH.md)
 POINTS_PER_FRAME = 120_000       # BASELINE.json metric
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames-per-step", type=int, default=256, help="sweeps per rank per step")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "compdis"])
+    ap.add_argument("--frames-per-step", type=int, default=None, help="frames per rank per step")
     ap.add_argument("--points", type=int, default=POINTS_PER_FRAME)
-    ap.add_argument("--workload", default="compdis", choices=["compdis"])
     ap.add_argument("--refined", action="store_true", help="also write refined points (+12 B/pt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work budget for the baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget for the baseline leg")
     ap.add_argument("--traffic-json", default=str(REPO / "profiles" / "traffic_latest.json"))
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.workload == "pipeline":
+        a.steps = 10 if a.steps is None else a.steps
+        a.warmup = 2 if a.warmup is None else a.warmup
+        a.frames_per_step = 8 if a.frames_per_step is None else a.frames_per_step
+    else:
+        a.steps = 50 if a.steps is None else a.steps
+        a.warmup = 5 if a.warmup is None else a.warmup
+        a.frames_per_step = 256 if a.frames_per_step is None else a.frames_per_step
+    return a
+
+
+# ------------------------------------------------------------------------------------------------------
+# synthetic inputs, generated on the device with the distributions of SURVEY.md 8(d)
+# ------------------------------------------------------------------------------------------------------
+def _poses(n, rng):
+    pose0 = np.tile(np.eye(4), (n, 1, 1))
+    pose1 = np.tile(np.eye(4), (n, 1, 1))
+    yaw = np.deg2rad(rng.uniform(-2, 2, n))
+    pose1[:, 0, 0], pose1[:, 0, 1], pose1[:, 1, 0], pose1[:, 1, 1] = np.cos(yaw), -np.sin(yaw), np.sin(yaw), np.cos(yaw)
+    pose1[:, 0, 3], pose1[:, 1, 3] = rng.uniform(-3, 3, n), rng.uniform(-0.5, 0.5, n)
+    return pose0, pose1
+
+
+def _sweep(n, g, device):
+    import torch
+    lo = torch.tensor([-51.2, -51.2, -3.0, 0.0], device=device)
+    hi = torch.tensor([51.2, 51.2, 3.0, 1.0], device=device)
+    return torch.rand((n, 4), generator=g, device=device, dtype=torch.float32) * (hi - lo) + lo
 
 
 def synthetic_batch(n_frames: int, n_points: int, device, seed: int):
-    """Ragged-batch container filled ON the device with the distributions of SURVEY.md 8(d)
-    (uniform xyz in the network range, intensity U[0,1], lidar_dt U[0,0.1], yaw <= 2 deg +
-    translation <= 3 m ego motion, flow = N(0, 1) m per sweep)."""
+    """Ragged-batch container for the comp_dis workload (uniform xyz in the network range, intensity U[0,1],
+    lidar_dt U[0,0.1], yaw <= 2 deg + translation <= 3 m ego motion, flow ~ N(0,1) m per sweep)."""
     import torch
     from himo_amd.compdis import FrameBatch
-
     g = torch.Generator(device=device)
     g.manual_seed(1234 + seed)
     T = n_frames * n_points
-    lo = torch.tensor([-51.2, -51.2, -3.0, 0.0], device=device)
-    hi = torch.tensor([51.2, 51.2, 3.0, 1.0], device=device)
-    pc0 = torch.rand((T, 4), generator=g, device=device, dtype=torch.float32) * (hi - lo) + lo
+    pc0 = _sweep(T, g, device)
     flow = torch.randn((T, 3), generator=g, device=device, dtype=torch.float32)
     lidar_dt = torch.rand(T, generator=g, device=device, dtype=torch.float32) * 0.1
-    rng = np.random.default_rng(seed)
-    pose0 = np.tile(np.eye(4), (n_frames, 1, 1))
-    pose1 = np.tile(np.eye(4), (n_frames, 1, 1))
-    yaw = np.deg2rad(rng.uniform(-2, 2, n_frames))
-    pose1[:, 0, 0], pose1[:, 0, 1], pose1[:, 1, 0], pose1[:, 1, 1] = np.cos(yaw), -np.sin(yaw), np.sin(yaw), np.cos(yaw)
-    pose1[:, 0, 3], pose1[:, 1, 3] = rng.uniform(-3, 3, n_frames), rng.uniform(-0.5, 0.5, n_frames)
+    pose0, pose1 = _poses(n_frames, np.random.default_rng(seed))
     offsets = np.arange(n_frames + 1, dtype=np.int64) * n_points
     return FrameBatch(offsets_host=offsets, offsets=torch.from_numpy(offsets).to(device),
                       pose0=torch.from_numpy(pose0).to(device), pose1=torch.from_numpy(pose1).to(device),
                       pc0=pc0, lidar_dt=lidar_dt, flow=flow)
+
+
+def synthetic_samples(n_frames: int, n_points: int, device, seed: int):
+    """B network inputs: history sweep, pc0, pc1 (each n_points x 4), poses, lidar_dt."""
+    import torch
+    from himo_amd.pipeline import Sample
+    g = torch.Generator(device=device)
+    g.manual_seed(4321 + seed)
+    rng = np.random.default_rng(seed)
+    pose0, pose1 = _poses(n_frames, rng)
+    _, pose_h = _poses(n_frames, rng)
+    out = []
+    for k in range(n_frames):
+        out.append(Sample(_sweep(n_points, g, device), _sweep(n_points, g, device), _sweep(n_points, g, device),
+                          np.linalg.inv(pose_h[k]), pose0[k], pose1[k],
+                          torch.rand(n_points, generator=g, device=device, dtype=torch.float32) * 0.1,
+                          scene_id=f"bench-{seed}", timestamp=k))
+    return out
 
 
 def frame_to_host(batch, k: int) -> dict:
@@ -80,15 +122,18 @@ def frame_to_host(batch, k: int) -> dict:
             "pose1": batch.pose1[k].cpu().numpy()}
 
 
-def cpu_baseline(frames: list[dict], budget_s: float) -> dict:
-    """The oracle (numpy port of save_zip.py:113-121 incl. the f32 cast) on this host, single thread."""
+# ------------------------------------------------------------------------------------------------------
+# CPU baselines (the oracle is the thing timed here, never the thing shipped)
+# ------------------------------------------------------------------------------------------------------
+def cpu_baseline_compdis(frames: list[dict], budget_s: float) -> dict:
+    """numpy port of save_zip.py:113-121 incl. the f32 cast, single thread."""
     sys.path.insert(0, str(REPO / "oracle"))
     import himo_oracle as oracle
     try:
         from threadpoolctl import threadpool_limits
-        limiter = threadpool_limits(limits=1)
+        threadpool_limits(limits=1)
     except Exception:                                   # pragma: no cover
-        limiter = None
+        pass
     for f in frames[:2]:
         oracle.comp_dis_frame_f32(f, "seflowpp_best")   # warm-up
     n, t0 = 0, time.perf_counter()
@@ -98,11 +143,33 @@ def cpu_baseline(frames: list[dict], budget_s: float) -> dict:
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 20000:
             break
-    if limiter is not None:
-        limiter.unregister() if hasattr(limiter, "unregister") else None
     return {"value": n / el, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{n} x {len(frames[0]['pc0'])}-pt frames in {el:.1f}s, numpy oracle/himo_oracle.py "
                       f"comp_dis_frame_f32 (host has {os.cpu_count()} cores, 1 used)"}
+
+
+def cpu_baseline_pipeline(samples, params, budget_s: float) -> dict:
+    """PyTorch-CPU float32 restatement of the network (oracle/seflow_oracle.py) + numpy comp_dis, all host cores
+    torch wants.  PARITY UNPINNED: this is the build's own restatement, not the reference's code (absent)."""
+    import torch
+    sys.path.insert(0, str(REPO / "oracle"))
+    import himo_oracle as oracle
+    import seflow_oracle as so
+    threads = torch.get_num_threads()
+    n, t0, el = 0, time.perf_counter(), 0.0
+    while True:
+        s = samples[n % len(samples)]
+        flow = so.forward(params, s.pch1.cpu().numpy(), s.pc0.cpu().numpy(), s.pc1.cpu().numpy(), s.pose_h1, s.pose0, s.pose1)
+        frame = {"pc0": s.pc0.cpu().numpy(), "seflowpp_best": flow, "lidar_dt": s.lidar_dt.cpu().numpy(),
+                 "pose0": s.pose0, "pose1": s.pose1}
+        oracle.comp_dis_frame_f32(frame, "seflowpp_best")
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 64:
+            break
+    return {"value": n / el, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} frame(s) of 3 x {len(samples[0].pc0)} pts in {el:.1f}s: PyTorch-CPU fp32 restatement "
+                      f"(oracle/seflow_oracle.py) + numpy comp_dis; torch threads={threads}, host cores={os.cpu_count()}"}
 
 
 def main():
@@ -122,33 +189,59 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from himo_amd import _lib
-    from himo_amd.compdis import CompDisEngine
-
     B, P = args.frames_per_step, args.points
-    batch = synthetic_batch(B, P, device, seed=rank)
-    eng = CompDisEngine(device=device, max_frames=B)
-    out = {}
+    sys.path.insert(0, str(REPO / "oracle"))
 
-    def step():
-        eng.run(batch, sensor_dt=0.1, refined=args.refined, out=out)
+    if args.workload == "compdis":
+        from himo_amd.compdis import CompDisEngine
+        batch = synthetic_batch(B, P, device, seed=rank)
+        eng = CompDisEngine(device=device, max_frames=B)
+        out = {}
+
+        def step():
+            eng.run(batch, sensor_dt=0.1, refined=args.refined, out=out)
+    else:
+        from himo_amd.pipeline import HiMoPipeline
+        from himo_amd.seflow import spec
+        from himo_amd.seflow.model import SeFlowNet
+        params = spec.init_params(0)
+        pipe = HiMoPipeline(SeFlowNet(params, device=device, max_points=P), device=device)
+        samples = synthetic_samples(B, P, device, seed=rank)
+        result = {}
+
+        def step():
+            result.update(pipe.run(samples, sensor_dt=0.1, refined=args.refined))
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
 
-    # parity spot-check on rank 0 (not timed): mean EPE / max abs of comp_dis vs the oracle
+    # parity spot-check on rank 0 (not timed): EPE / max abs vs the CPU oracle on one frame
     parity = None
     if rank == 0:
-        sys.path.insert(0, str(REPO / "oracle"))
         import himo_oracle as oracle
         step()
         torch.cuda.synchronize()
-        f = frame_to_host(batch, 0)
-        ref = oracle.comp_dis_frame_f32(f, "seflowpp_best")
-        got = out["comp_dis"][:P].cpu().numpy()
-        d = got.astype(np.float64) - ref
-        parity = {"mean_epe_vs_ref": float(np.linalg.norm(d, axis=1).mean()), "max_abs_vs_ref": float(np.abs(d).max()),
-                  "bit_exact_fraction": float((got == ref).mean())}
+        if args.workload == "compdis":
+            f = frame_to_host(batch, 0)
+            ref = oracle.comp_dis_frame_f32(f, "seflowpp_best")
+            got = out["comp_dis"][:P].cpu().numpy()
+            d = got.astype(np.float64) - ref
+            parity = {"comp_dis_mean_epe_vs_ref": float(np.linalg.norm(d, axis=1).mean()),
+                      "comp_dis_max_abs_vs_ref": float(np.abs(d).max()), "bit_exact_fraction": float((got == ref).mean())}
+        elif not args.no_cpu_baseline:
+            import seflow_oracle as so
+            s = samples[0]
+            ref_flow = so.forward(params, s.pch1.cpu().numpy(), s.pc0.cpu().numpy(), s.pc1.cpu().numpy(), s.pose_h1, s.pose0, s.pose1)
+            got_flow = result["flow"][:P].cpu().numpy()
+            frame = {"pc0": s.pc0.cpu().numpy(), "seflowpp_best": ref_flow, "lidar_dt": s.lidar_dt.cpu().numpy(),
+                     "pose0": s.pose0, "pose1": s.pose1}
+            ref_cd = oracle.comp_dis_frame_f32(frame, "seflowpp_best")
+            got_cd = result["comp_dis"][:P].cpu().numpy()
+            parity = {"flow_mean_epe_vs_cpu_restatement": float(np.linalg.norm(got_flow - ref_flow, axis=1).mean()),
+                      "flow_max_abs_vs_cpu_restatement": float(np.abs(got_flow - ref_flow).max()),
+                      "comp_dis_max_abs_vs_cpu_restatement": float(np.abs(got_cd.astype(np.float64) - ref_cd).max()),
+                      "note": "network parity is against this build's own CPU restatement (reference source absent)"}
 
     if world > 1:
         dist.barrier()
@@ -167,43 +260,66 @@ def main():
     frames_done = torch.tensor([B * args.steps], device=device, dtype=torch.int64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        # the path's only exchange: the final gather of per-rank results metadata
         gathered = [torch.zeros_like(frames_done) for _ in range(world)] if rank == 0 else None
-        dist.gather(frames_done, gathered, dst=0)
+        dist.gather(frames_done, gathered, dst=0)          # the path's only exchange: final gather of per-rank results
         total_frames = int(sum(int(g.item()) for g in gathered)) if rank == 0 else 0
     else:
         total_frames = int(frames_done.item())
     elapsed = float(el.item())
 
     if rank == 0:
-        bytes_per_pt = 44 + (12 if args.refined else 0)     # xyzi 16 + flow 12 + dt 4 + comp_dis 12 [+ refined 12]
-        k = prof.get("compdis_kernel", {"avg_ms": float("nan"), "count": 0})
-        achieved = bytes_per_pt * B * P / (k["avg_ms"] * 1e-3) / 1e9 if k["count"] else float("nan")
         traffic = None
         try:
-            tj = json.loads(Path(args.traffic_json).read_text())
-            traffic = tj.get("compdis_kernel", {}).get("hbm_bytes_per_launch")
+            traffic = json.loads(Path(args.traffic_json).read_text())
         except Exception:
-            pass
+            traffic = {}
+        per_kernel = {n: {"avg_ms": v["avg_ms"], "launches": v["count"], "total_ms": v["total_ms"]} for n, v in prof.items()}
+        if args.workload == "compdis":
+            bytes_per_pt = 44 + (12 if args.refined else 0)     # xyzi 16 + flow 12 + dt 4 + comp_dis 12 [+ refined 12]
+            k = prof.get("compdis_kernel", {"avg_ms": float("nan"), "count": 0})
+            achieved = bytes_per_pt * B * P / (k["avg_ms"] * 1e-3) / 1e9 if k["count"] else float("nan")
+            roofline = {"bound": "hbm", "kernel": "compdis_kernel<4,f64>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": traffic.get("compdis_kernel", {}).get("hbm_bytes_per_launch"),
+                        "algorithmic_bytes_per_launch": bytes_per_pt * B * P, "avg_launch_ms": k["avg_ms"],
+                        "launches_timed": k["count"]}
+            workload = ("flow->comp_dis fused path only (a1-a4: ego-motion removal, dt0, flow2compDis; f64 chain, f32 I/O) "
+                        "over a ragged HBM-resident batch; network forward NOT included")
+            dtype = "f64"
+        else:
+            from himo_amd.seflow import spec
+            k = prof.get("conv3x3_mfma_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
+            n_fwd = B * args.steps
+            # algorithmic flops of the 20 stride-1 3x3 convolutions of one forward (2*M*N*K each), see DESIGN.md
+            flops3 = spec.conv3x3_flops()
+            launches_per_fwd = k["count"] / max(n_fwd, 1)
+            achieved = flops3 * n_fwd / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
+            roofline = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
+                        "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TF,
+                        "traffic": traffic.get("conv3x3_mfma_kernel", {}).get("hbm_bytes_per_launch"),
+                        "algorithmic_flops_per_launch": flops3 / max(launches_per_fwd, 1e-9), "avg_launch_ms": k["avg_ms"],
+                        "launches_timed": k["count"], "launches_per_forward": launches_per_fwd,
+                        "share_of_step_time": k["total_ms"] / (elapsed * 1e3)}
+            workload = ("per-frame pipeline: pillarise 3 sweeps (512x512 grid) -> SeFlow++-style encoder/decoder + GRU head "
+                        "(random-init, self-specified: reference network source absent) -> per-point flow -> ego-motion "
+                        "removal + dt0 + flow2compDis -> comp_dis")
+            dtype = "f32"
         line = {
             "metric": "lidar_frames_per_sec_120k", "value": total_frames / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "flow->comp_dis fused path (a1-a4: ego-motion removal, dt0, flow2compDis; f64 chain, "
-                                   "f32 I/O) over a ragged HBM-resident batch; SeFlow++ forward NOT included yet",
-                       "frames_per_step_per_gpu": B, "points_per_frame": P, "parallelism": f"frames sharded x{world}",
-                       "refined_output": bool(args.refined)},
-            "roofline": {"bound": "hbm", "kernel": "compdis_kernel<4,f64>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_per_pt * B * P, "avg_launch_ms": k["avg_ms"],
-                         "launches_timed": k["count"],
-                         "other_kernels_avg_ms": {n: v["avg_ms"] for n, v in prof.items() if n != "compdis_kernel"}},
-            "parity": parity,
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": workload, "frames_per_step_per_gpu": B, "points_per_frame": P,
+                       "sweeps_per_frame": 3 if args.workload == "pipeline" else 1,
+                       "parallelism": f"frames sharded x{world}", "refined_output": bool(args.refined)},
+            "roofline": roofline, "kernels": per_kernel, "parity": parity,
         }
         if not args.no_cpu_baseline:
-            frames = [frame_to_host(batch, i) for i in range(min(8, B))]
-            line["cpu_baseline"] = cpu_baseline(frames, args.cpu_seconds)
+            if args.workload == "compdis":
+                frames = [frame_to_host(batch, i) for i in range(min(8, B))]
+                line["cpu_baseline"] = cpu_baseline_compdis(frames, args.cpu_seconds)
+            else:
+                line["cpu_baseline"] = cpu_baseline_pipeline(samples, params, args.cpu_seconds)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:

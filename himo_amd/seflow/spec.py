@@ -129,6 +129,25 @@ def conv_flops() -> float:
     return total
 
 
+def conv3x3_flops() -> float:
+    """Flops (2*M*N*K) of the 20 stride-1 3x3 convolutions of one forward: 13 encoder layers x 3 frames, the two
+    3x3 convs of each decoder block and the final 3x3 conv -- the launches named conv3x3_mfma_kernel."""
+    H, W = GRID
+    total = 0.0
+    h, w = H, W
+    for name, cin, cout, stride in ENCODER:
+        if stride == 2:
+            h, w = h // 2, w // 2
+        else:
+            total += NUM_FRAMES * 2.0 * h * w * cin * cout * 9
+    size = {"dec1": (H // 4, W // 4), "dec2": (H // 2, W // 2), "dec3": (H, W)}
+    for name, cin, skip, lat, out in DECODER:
+        oh, ow = size[name]
+        total += 2.0 * oh * ow * (2 * lat) * out * 9 + 2.0 * oh * ow * out * out * 9
+    total += 2.0 * H * W * DEC_OUT * DEC_OUT * 9
+    return total
+
+
 def head_flops_per_point() -> float:
     per_iter = 3 * 2.0 * (HIDDEN + XDIM) * HIDDEN
     return GRU_ITERS * per_iter + 2.0 * 3 * XDIM + 2.0 * (HIDDEN + XDIM) * 32 + 2.0 * 32 * 3
