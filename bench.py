@@ -172,6 +172,23 @@ def cpu_baseline_pipeline(samples, params, budget_s: float) -> dict:
                       f"(oracle/seflow_oracle.py) + numpy comp_dis; torch threads={threads}, host cores={os.cpu_count()}"}
 
 
+def reduce_job(elapsed: float, frames_done: int, device, world: int, rank: int):
+    """Max-over-ranks wall time and the whole-job frame count.  The frame counts travel through the path's only
+    exchange, the final gather to rank 0 (RCCL on GPUs; gloo in the CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    done = torch.tensor([frames_done], device=device, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(done) for _ in range(world)] if rank == 0 else None
+        dist.gather(done, gathered, dst=0)
+        total = int(sum(int(g.item()) for g in gathered)) if rank == 0 else 0
+    else:
+        total = int(done.item())
+    return float(el.item()), total
+
+
 def main():
     args = parse_args()
     import torch
@@ -256,16 +273,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = _lib.prof_stop()
 
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    frames_done = torch.tensor([B * args.steps], device=device, dtype=torch.int64)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        gathered = [torch.zeros_like(frames_done) for _ in range(world)] if rank == 0 else None
-        dist.gather(frames_done, gathered, dst=0)          # the path's only exchange: final gather of per-rank results
-        total_frames = int(sum(int(g.item()) for g in gathered)) if rank == 0 else 0
-    else:
-        total_frames = int(frames_done.item())
-    elapsed = float(el.item())
+    elapsed, total_frames = reduce_job(elapsed, B * args.steps, device, world, rank)
 
     if rank == 0:
         traffic = None
