@@ -47,11 +47,19 @@ struct ConvArgs {
 };
 
 __device__ inline float gelu_exact(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
-__device__ inline float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
+// GRU gates: hardware exp2 / rcp (~1 ulp each); the gate outputs are O(1) and feed a 1e-4 abs budget
+__device__ inline float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ inline float tanh_f(float v) {
+    const float e = __expf(-2.0f * fabsf(v));            // in (0, 1]: no overflow
+    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    return copysignf(t, v);
+}
 
-template <int KS, int S, int BN, int EPI>
+// MI = 32-row MFMA tiles per wave along M: 2 -> 128-pixel block tile (8 x 16), 1 -> 64-pixel tile (4 x 16) for the
+// low-resolution layers whose 128-pixel tiling would leave most of the 256 CUs idle
+template <int KS, int S, int BN, int EPI, int MI>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
-    constexpr int BM = 128, BK = 16, TH = 8, TW = 16;
+    constexpr int BM = 64 * MI, BK = 16, TH = 4 * MI, TW = 16;
     constexpr int PH = KS == 1 ? 1 : (TH - 1) * S + KS;
     constexpr int PW = KS == 1 ? BM : (TW - 1) * S + KS;
     constexpr int PP = PH * PW + 1;                 // +1: break the power-of-two plane stride
@@ -90,16 +98,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int li = lane & 31, lh = lane >> 5;
 
     // A-fragment pixel offsets inside the patch for this lane's two 32-row MFMA tiles
-    int ppA[2];
+    int ppA[MI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const int m = wm * 64 + mi * 32 + li;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = wm * (32 * MI) + mi * 32 + li;
         ppA[mi] = KS == 1 ? m : ((m / TW) * S) * PW + (m % TW) * S;
     }
 
-    floatx16 acc[2][NI];
+    floatx16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -205,13 +213,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int t = 0; t < BK / 2; ++t) {
                 const int k = 2 * t + lh;
-                float af[2], bf[NI];
+                float af[MI], bf[NI];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) af[mi] = pa[k * PP + ppA[mi] + tapoff];
+                for (int mi = 0; mi < MI; ++mi) af[mi] = pa[k * PP + ppA[mi] + tapoff];
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) bf[ni] = pw[k * BN + wn * WN + ni * 32 + li];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
@@ -241,10 +249,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         float sc = 1.f, sh = 0.f;
         if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 int64_t pix;
                 bool ok;
                 if (KS == 1) { pix = row0 + m; ok = pix < out_rows; }
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                     if (co < half) yout[pix * a.y_pitch + co] = g;                               // z
                     else a.aux_out[pix * a.aux_out_pitch + (co - half)] = g * a.aux_in[pix * a.aux_in_pitch + (co - half)];   // r * h
                 } else if (EPI == kEpiGruQ) {
-                    const float q = tanhf(v);
+                    const float q = tanh_f(v);
                     const float z = a.aux_in[pix * a.aux_in_pitch + co];
                     const float h = a.aux_out[pix * a.aux_out_pitch + co];
                     a.aux_out[pix * a.aux_out_pitch + co] = (1.0f - z) * h + z * q;
@@ -308,15 +316,21 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(UpArgs a) {
     *reinterpret_cast<float4*>(a.y + pix * a.y_pitch + q * 4) = o;
 }
 
-template <int KS, int S, int BN>
+template <int KS, int S, int BN, int MI>
 static void launch_epi(const ConvArgs& a, int epi, dim3 grid, hipStream_t s) {
     switch (epi) {
-        case kEpiBias: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBias>), grid, dim3(256), 0, s, a); break;
-        case kEpiBiasBnGelu: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBiasBnGelu>), grid, dim3(256), 0, s, a); break;
-        case kEpiBiasGelu: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBiasGelu>), grid, dim3(256), 0, s, a); break;
-        case kEpiGruZR: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiGruZR>), grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiGruQ>), grid, dim3(256), 0, s, a); break;
+        case kEpiBias: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBias, MI>), grid, dim3(256), 0, s, a); break;
+        case kEpiBiasBnGelu: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBiasBnGelu, MI>), grid, dim3(256), 0, s, a); break;
+        case kEpiBiasGelu: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBiasGelu, MI>), grid, dim3(256), 0, s, a); break;
+        case kEpiGruZR: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiGruZR, MI>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiGruQ, MI>), grid, dim3(256), 0, s, a); break;
     }
+}
+
+template <int KS, int S>
+static void launch_tile(const ConvArgs& a, int epi, int bn, int mi, dim3 grid, hipStream_t s) {
+    if (bn == 128) { if (mi == 2) launch_epi<KS, S, 128, 2>(a, epi, grid, s); else launch_epi<KS, S, 128, 1>(a, epi, grid, s); }
+    else { if (mi == 2) launch_epi<KS, S, 64, 2>(a, epi, grid, s); else launch_epi<KS, S, 64, 1>(a, epi, grid, s); }
 }
 
 }  // namespace himo
@@ -343,19 +357,26 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
     a.Wo = d->stride == 2 ? (d->w_in + 1) / 2 : d->w_in;
     a.aux_in = d->aux_in; a.aux_in_pitch = d->aux_in_pitch; a.aux_out = d->aux_out; a.aux_out_pitch = d->aux_out_pitch;
     hipStream_t s = (hipStream_t)stream;
-    const bool wide = d->cout >= 128 && (d->cout % 128) == 0;
-    const int bn = wide ? 128 : 64;
-    const int tiles_n = (d->cout + bn - 1) / bn;
-    int64_t tiles_m;
-    if (d->ksize == 1) tiles_m = (int64_t)d->n * (((int64_t)a.Ho * a.Wo + 127) / 128);
-    else tiles_m = (int64_t)d->n * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
-    const dim3 grid((unsigned)(tiles_m * tiles_n));
+    // tile choice: 128 x 128 when that still gives >= 2 blocks per CU, else shrink M then N so the chip is filled
+    auto blocks_for = [&](int bn, int mi) -> int64_t {
+        const int bm = 64 * mi, th = 4 * mi;
+        const int64_t tm = d->ksize == 1 ? (int64_t)d->n * (((int64_t)a.Ho * a.Wo + bm - 1) / bm)
+                                         : (int64_t)d->n * ((a.Ho + th - 1) / th) * ((a.Wo + 15) / 16);
+        return tm * ((d->cout + bn - 1) / bn);
+    };
+    const bool can128 = d->cout >= 128 && (d->cout % 128) == 0;
+    const bool gru = d->epilogue == kEpiGruZR;          // the z|r split needs the 128-wide channel tile
+    int bn = can128 ? 128 : 64, mi = 2;
+    const int64_t want = 512;
+    if (blocks_for(bn, mi) < want) mi = 1;
+    if (blocks_for(bn, mi) < want && bn == 128 && !gru) bn = 64;
+    const dim3 grid((unsigned)blocks_for(bn, mi));
     const char* name = d->ksize == 1 ? "conv1x1_mfma_kernel" : (d->stride == 2 ? "conv3x3s2_mfma_kernel" : "conv3x3_mfma_kernel");
     {
         ProfScope ps(name, s);
-        if (d->ksize == 1) { if (wide) launch_epi<1, 1, 128>(a, d->epilogue, grid, s); else launch_epi<1, 1, 64>(a, d->epilogue, grid, s); }
-        else if (d->stride == 1) { if (wide) launch_epi<3, 1, 128>(a, d->epilogue, grid, s); else launch_epi<3, 1, 64>(a, d->epilogue, grid, s); }
-        else { if (wide) launch_epi<3, 2, 128>(a, d->epilogue, grid, s); else launch_epi<3, 2, 64>(a, d->epilogue, grid, s); }
+        if (d->ksize == 1) launch_tile<1, 1>(a, d->epilogue, bn, mi, grid, s);
+        else if (d->stride == 1) launch_tile<3, 1>(a, d->epilogue, bn, mi, grid, s);
+        else launch_tile<3, 2>(a, d->epilogue, bn, mi, grid, s);
     }
     HIMO_LAUNCH_CHECK("conv_mfma_kernel");
     return HIMO_OK;
