@@ -1,0 +1,352 @@
+// sslloss.hip -- stage a11: the four self-supervised loss terms named at
+// assets/slurm/ssl-train-av2.sh:33 (`chamfer_dis`, `static_flow_loss`, `dynamic_chamfer_dis`,
+// `cluster_based_pc0pc1`, unit weights) and their gradient with respect to the estimated flow.
+//
+// PARITY UNPINNED: `seflowppLoss` lives in the absent OpenSceneFlow submodule.  The
+// definitions below are this build's own specification (written from the published SeFlow formulation);
+// the oracle is oracle/sslloss_oracle.py (PyTorch CPU with autograd + cKDTree correspondences).
+//
+//   moved_i = pc0_i + flow_i
+//   chamfer_dis          = mean_i |moved_i - NN_pc1(moved_i)|^2 + mean_j |pc1_j - NN_moved(pc1_j)|^2
+//   dynamic_chamfer_dis  = the same over {i : label0_i > 0} and {j : label1_j > 0}   (0 when either set is empty)
+//   static_flow_loss     = mean_{i : label0_i == 0} |flow_i|                          (0 when empty)
+//   cluster_based_pc0pc1 = mean over points i of "anchored" dynamic clusters c of |flow_i - t_c|, where for
+//                          cluster c the anchor a_c is the member with the LARGEST raw nearest-neighbour distance
+//                          to pc1 among members whose raw neighbour is itself dynamic (label1 > 0; ties: lowest
+//                          index) and t_c = pc1[NN_raw(a_c)] - pc0[a_c]; clusters without such a member are skipped
+//   total = sum of the four.  Correspondences are treated as constants in the gradient.
+//
+// All nearest-neighbour searches run through nngrid.hip (exact).  Loss sums are fixed two-level trees
+// (deterministic); the pc1 -> moved direction scatters its gradient with float atomics (order-dependent in the
+// last bits, like every scatter-add Chamfer backward).
+#include "himo_common.h"
+#include <math.h>
+
+extern "C" int himo_nn_grid(int64_t nq, const float* d_q, int64_t nr, const float* d_r, float x0, float y0, float cell,
+                            int grid_w, int grid_h, float* d_dist2, int32_t* d_idx, void* d_workspace,
+                            size_t workspace_bytes, void* stream);
+extern "C" size_t himo_nn_grid_workspace_bytes(int64_t n_ref, int grid_w, int grid_h);
+
+namespace himo {
+
+struct LossArgs {
+    int n0, n1, n_labels;
+    const float* pc0; const float* pc1; const float* flow;
+    const int* lab0; const int* lab1;
+    float* moved;                    // [n0][3]
+    float* grad;                     // [n0][3]
+    // correspondences
+    float* d_a; int* i_a;            // moved -> pc1
+    float* d_b; int* i_b;            // pc1 -> moved
+    float* d_r; int* i_r;            // pc0 (raw) -> pc1
+    // dynamic subsets (ordered compaction)
+    int* dyn0; int* dyn1;            // indices of dynamic points
+    int* pos0;                       // [n0] position in dyn0 or -1
+    float* mdyn; float* qdyn;        // moved[dyn0], pc1[dyn1]
+    float* d_c; int* i_c;            // mdyn -> qdyn
+    float* d_d; int* i_d;            // qdyn -> mdyn
+    int* counts;                     // [8]: 0 nd0, 1 nd1, 2 n_static, 3 n_cluster_pts
+    unsigned long long* anchor;      // [n_labels] packed (dist bits << 32 | ~index); 0 = none
+    double* partial;                 // [blocks][4]
+    double* loss;                    // [5] four terms + total
+};
+
+__global__ __launch_bounds__(256) void loss_prepare_kernel(LossArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n0) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a.moved[i * 3 + c] = a.pc0[i * 3 + c] + a.flow[i * 3 + c];
+        a.grad[i * 3 + c] = 0.f;
+    }
+}
+
+// ordered compaction of {i : lab[i] > 0}: block counts -> scan (one block) -> write
+__global__ __launch_bounds__(256) void dyn_count_kernel(int n, const int* __restrict__ lab, int* __restrict__ block_cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int c = (i < n && lab[i] > 0) ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    __shared__ int w[4];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+
+__global__ __launch_bounds__(1024) void dyn_scan_kernel(int* v, int n, int* total) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int x = i < n ? v[i] : 0;
+        part[threadIdx.x] = x;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int y = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += y;
+            __syncthreads();
+        }
+        const int incl = part[threadIdx.x], c = carry;
+        if (i < n) v[i] = c + incl - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void dyn_write_kernel(int n, const int* __restrict__ lab, const int* __restrict__ block_off,
+                                                        const float* __restrict__ pts, int* __restrict__ idx_out,
+                                                        int* __restrict__ pos_out, float* __restrict__ pts_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool sel = i < n && lab[i] > 0;
+    int incl = sel ? 1 : 0;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += y;
+    }
+    __shared__ int wt[4];
+    if (lane == 63) wt[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int pos = block_off[blockIdx.x] + incl - (sel ? 1 : 0);
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) pos += wt[w];
+    if (i < n && pos_out) pos_out[i] = sel ? pos : -1;
+    if (sel) {
+        idx_out[pos] = i;
+        pts_out[pos * 3] = pts[i * 3]; pts_out[pos * 3 + 1] = pts[i * 3 + 1]; pts_out[pos * 3 + 2] = pts[i * 3 + 2];
+    }
+}
+
+// cluster anchors + the two remaining counts
+__global__ __launch_bounds__(256) void cluster_anchor_kernel(LossArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n0) return;
+    const int l = a.lab0[i];
+    if (l == 0) { atomicAdd(&a.counts[2], 1); return; }
+    if (l < 0 || l >= a.n_labels || a.n1 == 0) return;
+    const int j = a.i_r[i];
+    if (j >= 0 && a.lab1[j] > 0) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(a.d_r[i]) << 32) | (unsigned)(~(unsigned)i);
+        atomicMax(&a.anchor[l], key);
+    }
+}
+
+__global__ __launch_bounds__(256) void cluster_count_kernel(LossArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n0) return;
+    const int l = a.lab0[i];
+    if (l > 0 && l < a.n_labels && a.anchor[l] != 0ull) atomicAdd(&a.counts[3], 1);
+}
+
+__device__ inline void block_sum4(double (&v)[4], double* out) {
+    __shared__ double red[4][256];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = v[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = red[k][0];
+}
+
+// per pc0 point: the terms it owns and their gradient
+__global__ __launch_bounds__(256) void loss_pc0_kernel(LossArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double t[4] = {0, 0, 0, 0};
+    if (i < a.n0) {
+        const float inv_n0 = 1.0f / (float)a.n0;
+        float g[3] = {0.f, 0.f, 0.f};
+        const float m[3] = {a.moved[i * 3], a.moved[i * 3 + 1], a.moved[i * 3 + 2]};
+        const float f[3] = {a.flow[i * 3], a.flow[i * 3 + 1], a.flow[i * 3 + 2]};
+        // chamfer, moved -> pc1
+        if (a.n1 > 0) {
+            t[0] += (double)a.d_a[i] * inv_n0;
+            const int j = a.i_a[i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[c] += 2.0f * inv_n0 * (m[c] - a.pc1[j * 3 + c]);
+        }
+        const int l = a.lab0[i];
+        const int nd0 = a.counts[0], nd1 = a.counts[1], ns = a.counts[2], nc = a.counts[3];
+        if (l == 0) {                                           // static_flow_loss
+            const float nrm = sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+            t[1] += (double)nrm / (double)ns;
+            if (nrm > 0.f)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[c] += f[c] / (nrm * (float)ns);
+        } else if (l > 0) {
+            if (nd0 > 0 && nd1 > 0) {                           // dynamic chamfer, moved_dyn -> pc1_dyn
+                const int k = a.pos0[i];
+                t[2] += (double)a.d_c[k] / (double)nd0;
+                const int j = a.i_c[k];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[c] += 2.0f / (float)nd0 * (m[c] - a.qdyn[j * 3 + c]);
+            }
+            if (l < a.n_labels && a.anchor[l] != 0ull) {        // cluster_based_pc0pc1
+                const int w = (int)(~(unsigned)(a.anchor[l] & 0xffffffffull));
+                const int j = a.i_r[w];
+                float e[3], s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { e[c] = f[c] - (a.pc1[j * 3 + c] - a.pc0[w * 3 + c]); s += e[c] * e[c]; }
+                const float nrm = sqrtf(s);
+                t[3] += (double)nrm / (double)nc;
+                if (nrm > 0.f)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) g[c] += e[c] / (nrm * (float)nc);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.grad[i * 3 + c] = g[c];      // this kernel runs before the scattering one
+    }
+    block_sum4(t, a.partial + (size_t)blockIdx.x * 4);
+}
+
+// per pc1 point: the pc1 -> moved halves (scatter their gradient onto the matched pc0 point)
+__global__ __launch_bounds__(256) void loss_pc1_kernel(LossArgs a, int blocks0) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    double t[4] = {0, 0, 0, 0};
+    if (j < a.n1 && a.n0 > 0) {
+        const float inv_n1 = 1.0f / (float)a.n1;
+        t[0] += (double)a.d_b[j] * inv_n1;
+        const int i = a.i_b[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomicAdd(&a.grad[i * 3 + c], 2.0f * inv_n1 * (a.moved[i * 3 + c] - a.pc1[j * 3 + c]));
+    }
+    const int nd0 = a.counts[0], nd1 = a.counts[1];
+    if (j < nd1 && nd0 > 0) {                                   // j indexes the dynamic pc1 subset here
+        t[2] += (double)a.d_d[j] / (double)nd1;
+        const int k = a.i_d[j];
+        const int i = a.dyn0[k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomicAdd(&a.grad[i * 3 + c], 2.0f / (float)nd1 * (a.mdyn[k * 3 + c] - a.qdyn[j * 3 + c]));
+    }
+    block_sum4(t, a.partial + ((size_t)blocks0 + blockIdx.x) * 4);
+}
+
+__global__ __launch_bounds__(256) void loss_final_kernel(const double* __restrict__ partial, int n_blocks, double* __restrict__ loss) {
+    double t[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < n_blocks; b += 256)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] += partial[(size_t)b * 4 + k];
+    __shared__ double out[4];
+    block_sum4(t, out);
+    if (threadIdx.x == 0) {
+        loss[0] = out[0]; loss[1] = out[1]; loss[2] = out[2]; loss[3] = out[3];
+        loss[4] = ((out[0] + out[1]) + out[2]) + out[3];
+    }
+}
+
+struct LossLayout { size_t moved, da, ia, db, ib, dr, ir, dyn0, dyn1, pos0, mdyn, qdyn, dc, ic, dd, id, bc0, bc1, counts, anchor, partial, nn, end; };
+
+static LossLayout loss_layout(int n0, int n1, int n_labels, int gw, int gh) {
+    LossLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += round_up(bytes > 0 ? bytes : 16, 16); return at; };
+    const size_t N0 = (size_t)(n0 > 0 ? n0 : 1), N1 = (size_t)(n1 > 0 ? n1 : 1);
+    L.moved = take(N0 * 12);
+    L.da = take(N0 * 4); L.ia = take(N0 * 4); L.db = take(N1 * 4); L.ib = take(N1 * 4); L.dr = take(N0 * 4); L.ir = take(N0 * 4);
+    L.dyn0 = take(N0 * 4); L.dyn1 = take(N1 * 4); L.pos0 = take(N0 * 4); L.mdyn = take(N0 * 12); L.qdyn = take(N1 * 12);
+    L.dc = take(N0 * 4); L.ic = take(N0 * 4); L.dd = take(N1 * 4); L.id = take(N1 * 4);
+    L.bc0 = take(((N0 + 255) / 256 + 1) * 4); L.bc1 = take(((N1 + 255) / 256 + 1) * 4);
+    L.counts = take(8 * 4);
+    L.anchor = take((size_t)(n_labels > 0 ? n_labels : 1) * 8);
+    L.partial = take(((N0 + 255) / 256 + (N1 + 255) / 256 + 2) * 4 * 8);
+    L.nn = take(himo_nn_grid_workspace_bytes((int64_t)(N0 > N1 ? N0 : N1), gw, gh));
+    L.end = o;
+    return L;
+}
+
+}  // namespace himo
+
+using namespace himo;
+
+extern "C" size_t himo_ssl_loss_workspace_bytes(int n0, int n1, int n_labels, int grid_w, int grid_h) {
+    return loss_layout(n0, n1, n_labels, grid_w, grid_h).end + 64;
+}
+
+extern "C" int himo_ssl_loss(int n0, int n1, const float* d_pc0, const float* d_pc1, const float* d_flow,
+                             const int32_t* d_label0, const int32_t* d_label1, int n_labels,
+                             float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
+                             double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (n0 < 0 || n1 < 0 || n_labels < 1 || grid_w < 1 || grid_h < 1) return HIMO_ERR_INVALID_ARGUMENT;
+    if (!d_loss || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
+    if (n0 > 0 && (!d_pc0 || !d_flow || !d_label0 || !d_grad_flow)) return HIMO_ERR_INVALID_ARGUMENT;
+    if (n1 > 0 && (!d_pc1 || !d_label1)) return HIMO_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < himo_ssl_loss_workspace_bytes(n0, n1, n_labels, grid_w, grid_h) || !aligned16(d_workspace))
+        return HIMO_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const LossLayout L = loss_layout(n0, n1, n_labels, grid_w, grid_h);
+    char* ws = reinterpret_cast<char*>(d_workspace);
+    LossArgs a{};
+    a.n0 = n0; a.n1 = n1; a.n_labels = n_labels;
+    a.pc0 = d_pc0; a.pc1 = d_pc1; a.flow = d_flow; a.lab0 = d_label0; a.lab1 = d_label1;
+    a.moved = (float*)(ws + L.moved); a.grad = d_grad_flow;
+    a.d_a = (float*)(ws + L.da); a.i_a = (int*)(ws + L.ia); a.d_b = (float*)(ws + L.db); a.i_b = (int*)(ws + L.ib);
+    a.d_r = (float*)(ws + L.dr); a.i_r = (int*)(ws + L.ir);
+    a.dyn0 = (int*)(ws + L.dyn0); a.dyn1 = (int*)(ws + L.dyn1); a.pos0 = (int*)(ws + L.pos0);
+    a.mdyn = (float*)(ws + L.mdyn); a.qdyn = (float*)(ws + L.qdyn);
+    a.d_c = (float*)(ws + L.dc); a.i_c = (int*)(ws + L.ic); a.d_d = (float*)(ws + L.dd); a.i_d = (int*)(ws + L.id);
+    a.counts = (int*)(ws + L.counts); a.anchor = (unsigned long long*)(ws + L.anchor);
+    a.partial = (double*)(ws + L.partial); a.loss = d_loss;
+    int* bc0 = (int*)(ws + L.bc0); int* bc1 = (int*)(ws + L.bc1);
+    void* nnws = ws + L.nn;
+    const size_t nnbytes = himo_nn_grid_workspace_bytes((int64_t)(n0 > n1 ? n0 : n1), grid_w, grid_h);
+    const int blocks0 = (n0 + 255) / 256, blocks1 = (n1 + 255) / 256;
+
+    HIMO_HIP(hipMemsetAsync(a.counts, 0, 32, s));
+    HIMO_HIP(hipMemsetAsync(a.anchor, 0, (size_t)n_labels * 8, s));
+    HIMO_HIP(hipMemsetAsync(a.partial, 0, ((size_t)blocks0 + blocks1 + 2) * 32, s));
+    if (n0 > 0) hipLaunchKernelGGL(loss_prepare_kernel, dim3(blocks0), dim3(256), 0, s, a);
+    HIMO_LAUNCH_CHECK("loss_prepare_kernel");
+    int st;
+#define NNG(nq, q, nr, r, d, i) \
+    st = himo_nn_grid(nq, q, nr, r, grid_x0, grid_y0, grid_cell, grid_w, grid_h, d, i, nnws, nnbytes, s); if (st != HIMO_OK) return st;
+    if (n0 > 0 && n1 > 0) {
+        NNG(n0, a.moved, n1, d_pc1, a.d_a, a.i_a);
+        NNG(n1, d_pc1, n0, a.moved, a.d_b, a.i_b);
+        NNG(n0, d_pc0, n1, d_pc1, a.d_r, a.i_r);
+    }
+    // dynamic subsets
+    if (n0 > 0) {
+        hipLaunchKernelGGL(dyn_count_kernel, dim3(blocks0), dim3(256), 0, s, n0, d_label0, bc0);
+        hipLaunchKernelGGL(dyn_scan_kernel, dim3(1), dim3(1024), 0, s, bc0, blocks0, a.counts + 0);
+        hipLaunchKernelGGL(dyn_write_kernel, dim3(blocks0), dim3(256), 0, s, n0, d_label0, bc0, a.moved, a.dyn0, a.pos0, a.mdyn);
+    }
+    if (n1 > 0) {
+        hipLaunchKernelGGL(dyn_count_kernel, dim3(blocks1), dim3(256), 0, s, n1, d_label1, bc1);
+        hipLaunchKernelGGL(dyn_scan_kernel, dim3(1), dim3(1024), 0, s, bc1, blocks1, a.counts + 1);
+        hipLaunchKernelGGL(dyn_write_kernel, dim3(blocks1), dim3(256), 0, s, n1, d_label1, bc1, d_pc1, a.dyn1, (int*)nullptr, a.qdyn);
+    }
+    HIMO_LAUNCH_CHECK("dyn_compaction");
+    int h_counts[2] = {0, 0};                    // subset sizes size the two dynamic searches (one small blocking copy)
+    HIMO_HIP(hipMemcpyAsync(h_counts, a.counts, 8, hipMemcpyDeviceToHost, s));
+    HIMO_HIP(hipStreamSynchronize(s));
+    const int nd0 = h_counts[0], nd1 = h_counts[1];
+    if (nd0 > 0 && nd1 > 0) {
+        NNG(nd0, a.mdyn, nd1, a.qdyn, a.d_c, a.i_c);
+        NNG(nd1, a.qdyn, nd0, a.mdyn, a.d_d, a.i_d);
+    }
+#undef NNG
+    if (n0 > 0 && n1 > 0) {
+        hipLaunchKernelGGL(cluster_anchor_kernel, dim3(blocks0), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(cluster_count_kernel, dim3(blocks0), dim3(256), 0, s, a);
+    } else if (n0 > 0) {
+        hipLaunchKernelGGL(cluster_anchor_kernel, dim3(blocks0), dim3(256), 0, s, a);   // still counts static points
+    }
+    HIMO_LAUNCH_CHECK("cluster_kernels");
+    {
+        ProfScope ps("ssl_loss_point_kernels", s);
+        if (n0 > 0) hipLaunchKernelGGL(loss_pc0_kernel, dim3(blocks0), dim3(256), 0, s, a);
+        if (n1 > 0) hipLaunchKernelGGL(loss_pc1_kernel, dim3(blocks1), dim3(256), 0, s, a, blocks0);
+        hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, a.partial, blocks0 + blocks1, d_loss);
+    }
+    HIMO_LAUNCH_CHECK("ssl_loss_point_kernels");
+    return HIMO_OK;
+}

@@ -239,6 +239,27 @@ int himo_head_final(int64_t n, const float* d_y1, int y1_pitch, const float* d_w
                     const int32_t* d_pid, const float* d_xyz_t, const float* d_pts, int pc_stride,
                     float* d_flow, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * a11: KNN/Chamfer correspondence + the self-supervised loss terms.  The reference's `seflowppLoss` is in the
+ * absent OpenSceneFlow submodule; the only in-tree facts are the four term names and unit weights at
+ * assets/slurm/ssl-train-av2.sh:33.  Definitions: himo_amd/csrc/sslloss.hip header (this build's own spec).
+ */
+/* exact k=1 NN between two sweeps through a uniform BEV grid (cell metres, grid_w x grid_h cells from
+ * (x0, y0); points outside are binned into border cells).  float32 [n][3] in, squared distances + int32
+ * reference rows out (idx may be NULL; -1 / +inf when nr == 0).  Ties keep the lowest reference row. */
+size_t himo_nn_grid_workspace_bytes(int64_t n_ref, int grid_w, int grid_h);
+int himo_nn_grid(int64_t nq, const float* d_q, int64_t nr, const float* d_r, float x0, float y0, float cell,
+                 int grid_w, int grid_h, float* d_dist2, int32_t* d_idx, void* d_workspace,
+                 size_t workspace_bytes, void* stream);
+/* loss[0..3] = chamfer_dis, static_flow_loss, dynamic_chamfer_dis, cluster_based_pc0pc1; loss[4] = their sum
+ * (float64, device); d_grad_flow [n0][3] = d loss[4] / d flow.  pc0 must already be in pc1's frame; labels:
+ * 0 = static, > 0 = dynamic cluster id (< n_labels).  Synchronises the stream once internally. */
+size_t himo_ssl_loss_workspace_bytes(int n0, int n1, int n_labels, int grid_w, int grid_h);
+int himo_ssl_loss(int n0, int n1, const float* d_pc0, const float* d_pc1, const float* d_flow,
+                  const int32_t* d_label0, const int32_t* d_label1, int n_labels,
+                  float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
+                  double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

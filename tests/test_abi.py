@@ -23,6 +23,7 @@ def test_header_declares_entry_points():
 def test_library_exports_every_declared_symbol():
     from himo_amd import _lib
     import himo_amd.seflow.model  # noqa: F401  (registers the network entry points' signatures)
+    import himo_amd.ssl_loss  # noqa: F401
     lib = _lib.load()
     raw = ctypes.CDLL(str(_lib.LIB_PATH))
     for name in declared_symbols():

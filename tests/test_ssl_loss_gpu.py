@@ -1,0 +1,90 @@
+"""GPU parity of a11 (KNN/Chamfer correspondences + self-supervised loss terms and gradient) against the
+CPU restatement (PARITY UNPINNED: own spec, see csrc/sslloss.hip)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(seed, n0, n1, n_clusters=12):
+    from himo_amd.synthetic import make_frame
+    a, b = make_frame(seed, n_points=n0, n_instances=n_clusters), make_frame(seed + 1, n_points=n1, n_instances=n_clusters)
+    rng = np.random.default_rng(seed)
+    lab0 = a["flow_instance_id"].astype(np.int32)          # 0 = background, k > 0 = instance k
+    lab1 = (b["flow_instance_id"] > 0).astype(np.int32) * 7
+    flow = (a["flow"] + rng.normal(0, 0.05, a["flow"].shape)).astype(np.float32)
+    # make pc1 contain the moved instances so that dynamic correspondences exist
+    pc1 = b["pc0"][:, :3].copy()
+    k = min(len(pc1), len(a["pc0"])) // 4
+    pc1[:k] = a["pc0"][:k, :3] + a["flow"][:k]
+    lab1[:k] = (lab0[:k] > 0) * 7
+    return a["pc0"][:, :3].copy(), pc1, flow, lab0, lab1
+
+
+@pytest.mark.parametrize("nq,nr", [(1, 1), (100, 3), (5000, 7000), (120_000, 120_000)])
+def test_nn_grid_is_exact(gpu, nq, nr):
+    from himo_amd.ssl_loss import nn_grid
+    import sslloss_oracle as so
+    rng = np.random.default_rng(nq + nr)
+    q = rng.uniform([-60, -60, -3], [60, 60, 3], (nq, 3)).astype(np.float32)     # some points outside the 104 m grid
+    r = rng.uniform([-60, -60, -3], [60, 60, 3], (nr, 3)).astype(np.float32)
+    d2, idx = nn_grid(torch.from_numpy(q).to(gpu), torch.from_numpy(r).to(gpu))
+    ref_d2, ref_i = so.nearest(q, r)
+    got_d2 = d2.cpu().numpy()
+    assert np.abs(got_d2 - ref_d2).max() <= 1e-4 * max(1.0, ref_d2.max())
+    diff = q - r[idx.cpu().numpy().astype(np.int64)]
+    assert np.allclose((diff * diff).sum(1), got_d2, rtol=1e-5, atol=1e-6)       # the index really is that neighbour
+    exact = (idx.cpu().numpy() == ref_i).mean()
+    assert exact >= 0.999
+
+
+def test_nn_grid_matches_brute_force_kernel_including_ties(gpu):
+    from himo_amd.eval import nearest_neighbor
+    from himo_amd.ssl_loss import nn_grid
+    rng = np.random.default_rng(3)
+    r = rng.uniform(-50, 50, (3000, 3)).astype(np.float32)
+    r = np.concatenate([r, r])                               # every reference point twice: ties everywhere
+    q = rng.uniform(-50, 50, (4000, 3)).astype(np.float32)
+    d2, idx = nn_grid(torch.from_numpy(q).to(gpu), torch.from_numpy(r).to(gpu))
+    bd, bi = nearest_neighbor(torch.from_numpy(q).to(gpu), torch.from_numpy(r).to(gpu))
+    assert torch.equal(idx, bi) and (idx < 3000).all()       # lowest index wins in both kernels
+
+
+@pytest.mark.parametrize("n0,n1", [(4000, 3500), (30_000, 32_000)])
+def test_loss_terms_and_gradient(gpu, n0, n1):
+    import sslloss_oracle as so
+    from himo_amd.ssl_loss import SeFlowLoss
+    pc0, pc1, flow, lab0, lab1 = _scene(5, n0, n1)
+    terms, total, grad = SeFlowLoss()(torch.from_numpy(pc0), torch.from_numpy(pc1), torch.from_numpy(flow),
+                                      torch.from_numpy(lab0), torch.from_numpy(lab1))
+    ref_terms, ref_total, ref_grad = so.ssl_loss(pc0, pc1, flow, lab0, lab1)
+    for k, v in ref_terms.items():
+        assert float(terms[k]) == pytest.approx(v, rel=2e-5, abs=1e-7), k
+        assert v > 0, k                                      # every term is exercised
+    assert float(total) == pytest.approx(ref_total, rel=2e-5)
+    g = grad.cpu().numpy()
+    assert np.abs(g - ref_grad).max() <= 1e-6 + 1e-4 * np.abs(ref_grad).max()
+
+
+def test_loss_edge_cases(gpu):
+    from himo_amd.ssl_loss import SeFlowLoss
+    eng = SeFlowLoss()
+    pc0, pc1, flow, lab0, lab1 = _scene(9, 2000, 1800)
+    z0, z1 = np.zeros_like(lab0), np.zeros_like(lab1)
+    terms, total, grad = eng(torch.from_numpy(pc0), torch.from_numpy(pc1), torch.from_numpy(flow), torch.from_numpy(z0), torch.from_numpy(z1))
+    assert float(terms["dynamic_chamfer_dis"]) == 0 and float(terms["cluster_based_pc0pc1"]) == 0   # no dynamic points
+    assert float(terms["static_flow_loss"]) > 0 and torch.isfinite(grad).all()
+    zero = torch.zeros_like(torch.from_numpy(flow))
+    terms, total, grad = eng(torch.from_numpy(pc0), torch.from_numpy(pc1), zero, torch.from_numpy(lab0), torch.from_numpy(lab1))
+    assert float(terms["static_flow_loss"]) == 0 and torch.isfinite(grad).all()                       # |0| has zero sub-gradient
+
+
+def test_autograd_wrapper(gpu):
+    from himo_amd.ssl_loss import SeFlowLoss, seflow_loss
+    pc0, pc1, flow, lab0, lab1 = (torch.from_numpy(x).to(gpu) for x in _scene(11, 3000, 3000))
+    f = flow.clone().requires_grad_(True)
+    loss = seflow_loss(f, pc0, pc1, lab0, lab1)
+    (loss * 2).backward()
+    _, total, grad = SeFlowLoss()(pc0, pc1, flow, lab0, lab1)
+    assert torch.allclose(f.grad, 2 * grad, rtol=1e-5, atol=1e-7)
