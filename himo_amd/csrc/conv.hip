@@ -19,41 +19,9 @@
 //   * epilogues are fused: bias, BatchNorm(eval) scale/shift, exact-erf GELU, the GRU gate math.
 // Channel concatenation never copies: every tensor is addressed as base + n*batch_stride +
 // pixel*pitch + channel, so frames live as channel groups of one wider buffer.
-#include "himo_common.h"
-#include <math.h>
+#include "conv_common.h"
 
 namespace himo {
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-enum Epilogue {
-    kEpiBias = 0,         // y = acc + bias
-    kEpiBiasBnGelu = 1,   // y = gelu((acc + bias) * scale + shift)
-    kEpiBiasGelu = 2,     // y = gelu(acc + bias)
-    kEpiGruZR = 3,        // cols [0,C/2): z = sigmoid(.) -> out ; cols [C/2,C): r = sigmoid(.), aux_out = r * h
-    kEpiGruQ = 4          // q = tanh(.) ; h = (1 - z) * h + z * q  (in place in aux_out)
-};
-
-struct ConvArgs {
-    const float* x; int64_t x_batch_stride; int x_pitch;      // input  [n][H][W] pixels, `x_pitch` floats apart
-    const float* w;                                           // [KS][KS][Cin][Cout]
-    const float* bias; const float* scale; const float* shift;
-    float* y; int64_t y_batch_stride; int y_pitch;            // output
-    int N, H, W, Cin, Cout;                                   // input spatial size (KS=1 rows: H = 1, W = rows)
-    int Ho, Wo;
-    // GRU epilogues
-    const float* aux_in; int aux_in_pitch;                    // z (kEpiGruQ) / h (kEpiGruZR), [rows][pitch]
-    float* aux_out; int aux_out_pitch;                        // r*h (kEpiGruZR) / h in place (kEpiGruQ)
-};
-
-__device__ inline float gelu_exact(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
-// GRU gates: hardware exp2 / rcp (~1 ulp each); the gate outputs are O(1) and feed a 1e-4 abs budget
-__device__ inline float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-__device__ inline float tanh_f(float v) {
-    const float e = __expf(-2.0f * fabsf(v));            // in (0, 1]: no overflow
-    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
-    return copysignf(t, v);
-}
 
 // MI = 32-row MFMA tiles per wave along M: 2 -> 128-pixel block tile (8 x 16), 1 -> 64-pixel tile (4 x 16) for the
 // low-resolution layers whose 128-pixel tiling would leave most of the 256 CUs idle
@@ -262,25 +230,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                     pix = (int64_t)oy * a.Wo + ox;
                 }
                 if (!ok) continue;
-                float v = acc[mi][ni][r] + b;
-                if (EPI == kEpiBias) {
-                    yout[pix * a.y_pitch + co] = v;
-                } else if (EPI == kEpiBiasBnGelu) {
-                    v = v * sc + sh;
-                    yout[pix * a.y_pitch + co] = gelu_exact(v);
-                } else if (EPI == kEpiBiasGelu) {
-                    yout[pix * a.y_pitch + co] = gelu_exact(v);
-                } else if (EPI == kEpiGruZR) {
-                    const int half = a.Cout / 2;
-                    const float g = sigmoid_f(v);
-                    if (co < half) yout[pix * a.y_pitch + co] = g;                               // z
-                    else a.aux_out[pix * a.aux_out_pitch + (co - half)] = g * a.aux_in[pix * a.aux_in_pitch + (co - half)];   // r * h
-                } else if (EPI == kEpiGruQ) {
-                    const float q = tanh_f(v);
-                    const float z = a.aux_in[pix * a.aux_in_pitch + co];
-                    const float h = a.aux_out[pix * a.aux_out_pitch + co];
-                    a.aux_out[pix * a.aux_out_pitch + co] = (1.0f - z) * h + z * q;
-                }
+                epilogue_store<EPI>(a, yout, pix, co, acc[mi][ni][r] + b, sc, sh);
             }
         }
     }
@@ -357,6 +307,7 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
     a.Wo = d->stride == 2 ? (d->w_in + 1) / 2 : d->w_in;
     a.aux_in = d->aux_in; a.aux_in_pitch = d->aux_in_pitch; a.aux_out = d->aux_out; a.aux_out_pitch = d->aux_out_pitch;
     hipStream_t s = (hipStream_t)stream;
+    if (d->w_packed && d->stride == 1) return launch_conv_bf16x3(a, d->ksize, d->epilogue, d->w_packed, s);
     // tile choice: 128 x 128 when that still gives >= 2 blocks per CU, else shrink M then N so the chip is filled
     auto blocks_for = [&](int bn, int mi) -> int64_t {
         const int bm = 64 * mi, th = 4 * mi;

@@ -1,0 +1,67 @@
+// conv_common.h -- argument block, epilogue kinds and the per-element fused epilogue shared by the float32-MFMA
+// convolution (conv.hip) and the split-bf16 convolution (convbf.hip).
+#pragma once
+#include "himo_common.h"
+#include <math.h>
+
+namespace himo {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+enum Epilogue {
+    kEpiBias = 0,         // y = acc + bias
+    kEpiBiasBnGelu = 1,   // y = gelu((acc + bias) * scale + shift)
+    kEpiBiasGelu = 2,     // y = gelu(acc + bias)
+    kEpiGruZR = 3,        // cols [0,C/2): z = sigmoid(.) -> out ; cols [C/2,C): r = sigmoid(.), aux_out = r * h
+    kEpiGruQ = 4          // q = tanh(.) ; h = (1 - z) * h + z * q  (in place in aux_out)
+};
+
+struct ConvArgs {
+    const float* x; int64_t x_batch_stride; int x_pitch;      // input  [n][H][W] pixels, `x_pitch` floats apart
+    const float* w;                                           // [KS][KS][Cin][Cout]
+    const float* bias; const float* scale; const float* shift;
+    float* y; int64_t y_batch_stride; int y_pitch;            // output
+    int N, H, W, Cin, Cout;                                   // input spatial size (KS=1 rows: H = 1, W = rows)
+    int Ho, Wo;
+    // GRU epilogues
+    const float* aux_in; int aux_in_pitch;                    // z (kEpiGruQ) / h (kEpiGruZR), [rows][pitch]
+    float* aux_out; int aux_out_pitch;                        // r*h (kEpiGruZR) / h in place (kEpiGruQ)
+};
+
+__device__ inline float gelu_exact(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
+// GRU gates: hardware exp2 / rcp (~1 ulp each); the gate outputs are O(1) and feed a 1e-4 abs budget
+__device__ inline float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ inline float tanh_f(float v) {
+    const float e = __expf(-2.0f * fabsf(v));            // in (0, 1]: no overflow
+    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    return copysignf(t, v);
+}
+
+
+// one output element: bias -> (BatchNorm scale/shift) -> activation / GRU gate math -> store
+template <int EPI>
+__device__ inline void epilogue_store(const ConvArgs& a, float* __restrict__ yout, int64_t pix, int co, float v, float sc, float sh) {
+    if (EPI == kEpiBias) {
+        yout[pix * a.y_pitch + co] = v;
+    } else if (EPI == kEpiBiasBnGelu) {
+        v = v * sc + sh;
+        yout[pix * a.y_pitch + co] = gelu_exact(v);
+    } else if (EPI == kEpiBiasGelu) {
+        yout[pix * a.y_pitch + co] = gelu_exact(v);
+    } else if (EPI == kEpiGruZR) {
+        const int half = a.Cout / 2;
+        const float g = sigmoid_f(v);
+        if (co < half) yout[pix * a.y_pitch + co] = g;                               // z
+        else a.aux_out[pix * a.aux_out_pitch + (co - half)] = g * a.aux_in[pix * a.aux_in_pitch + (co - half)];   // r * h
+    } else if (EPI == kEpiGruQ) {
+        const float q = tanh_f(v);
+        const float z = a.aux_in[pix * a.aux_in_pitch + co];
+        const float h = a.aux_out[pix * a.aux_out_pitch + co];
+        a.aux_out[pix * a.aux_out_pitch + co] = (1.0f - z) * h + z * q;
+    }
+}
+
+// implemented in convbf.hip: stride-1 convolutions / row GEMMs on split-bf16 matrix instructions
+int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w_packed, hipStream_t s);
+
+}  // namespace himo

@@ -1,0 +1,311 @@
+// convbf.hip -- stride-1 NHWC convolution / row GEMM with float32-class accuracy on the bf16 matrix
+// instructions of gfx950: every float32 operand is split into three bf16 terms (x = h + m + l, 8 + 8 + 8
+// mantissa bits) and the product is formed from the six significant cross terms
+//     h*h + h*m + m*h + m*m + h*l + l*h            (dropped: m*l, l*m, l*l  <= 2^-24 relative)
+// accumulated in float32 by v_mfma_f32_32x32x16_bf16.  Six 32-cycle bf16 MFMAs replace eight 64-cycle
+// float32 MFMAs per 32x32x16 block: 2.67x the float32-MFMA rate at the same 1e-4 parity budget
+// (north_star's bar against a float32 CPU path rules out plain bf16).
+//
+// Specification and oracle: as conv.hip (himo_amd/seflow/spec.py, oracle/seflow_oracle.py; reference source absent).
+//
+// Structure (block = 4 waves, 64*MI pixels x BN channels; the pixel tile is 2*MI rows x 32 columns so that one
+// MFMA tile is 32 consecutive pixels of one image row):
+//   * activations are split while they are staged: the input halo patch of a 16-channel slab is held in LDS as
+//     three bf16 planes [pixel][16 + 8 pad] -- the 48-byte pixel pitch makes every ds_read_b128 fragment read
+//     conflict-free -- and reused by all nine taps;
+//   * weights are split ONCE at load time (himo_conv_pack_weights) into [tap][slab][term][cout][16] so a tap's
+//     slab is three contiguous runs that are copied, double-buffered, into [cout][16 + 8 pad] LDS planes;
+//   * per tap a wave reads 3*MI A fragments + 3*NI B fragments (16 bytes per lane each) and issues 6*MI*NI MFMAs,
+//     rotating over the MI*NI accumulators so that consecutive MFMAs never share one;
+//   * the next tap's weights (and the next slab's patch) are prefetched into registers under the MFMAs.
+#include "conv_common.h"
+
+namespace himo {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline unsigned bf16_rne_bits(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;        // round to nearest even (inputs are finite)
+}
+__device__ inline float bf16_bits_to_float(unsigned b) { return __builtin_bit_cast(float, b << 16); }
+
+// x -> (h, m, l) with x == h + m + l up to 2^-24 |x|
+__device__ inline void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = bf16_rne_bits(x);
+    const float r1 = x - bf16_bits_to_float(h);
+    m = bf16_rne_bits(r1);
+    const float r2 = r1 - bf16_bits_to_float(m);
+    l = bf16_rne_bits(r2);
+}
+
+constexpr int kRowBytes = 48;      // LDS pitch of one pixel / one output channel: 16 bf16 + 8 bf16 of padding
+
+// weights [T][Cin][Cout] float32 -> [T][slabs][3][Cout][16] bf16
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int T, int Cin, int Cout,
+                                                           unsigned short* __restrict__ out) {
+    const int slabs = (Cin + 15) / 16;
+    const int64_t total = (int64_t)T * slabs * Cout * 16;
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (item >= total) return;
+    const int k = (int)(item % 16);
+    const int co = (int)((item / 16) % Cout);
+    const int slab = (int)((item / (16 * (int64_t)Cout)) % slabs);
+    const int tap = (int)(item / (16 * (int64_t)Cout * slabs));
+    const int ci = slab * 16 + k;
+    const float x = ci < Cin ? w[((int64_t)tap * Cin + ci) * Cout + co] : 0.f;
+    unsigned h, m, l;
+    split3(x, h, m, l);
+    const int64_t base = (((int64_t)tap * slabs + slab) * 3) * Cout * 16 + (int64_t)co * 16 + k;
+    out[base] = (unsigned short)h;
+    out[base + (int64_t)Cout * 16] = (unsigned short)m;
+    out[base + 2 * (int64_t)Cout * 16] = (unsigned short)l;
+}
+
+template <int KS, int BN, int EPI, int MI>
+__global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
+    constexpr int TW = 32, TH = 2 * MI, BM = 64 * MI;
+    constexpr int PH = KS == 1 ? 1 : TH + 2;
+    constexpr int PW = KS == 1 ? BM : TW + 2;
+    constexpr int NPIX = PH * PW;
+    constexpr int T = KS * KS;
+    constexpr int WN = BN / 2, NI = WN / 32;
+    constexpr int kPatchItems = NPIX * 4;                       // float4 (4 channels) per item
+    constexpr int kPatchPerThread = (kPatchItems + 255) / 256;
+    constexpr int kWItems = 3 * BN * 2;                         // 16-byte half rows
+    constexpr int kWPerThread = (kWItems + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char patch[3][NPIX * kRowBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char wts[2][3][BN * kRowBytes];
+
+    const int n_tiles_n = (a.Cout + BN - 1) / BN;
+    int bid = blockIdx.x;
+    const int tn = bid % n_tiles_n; bid /= n_tiles_n;
+    int oy0 = 0, ox0 = 0, img;
+    int64_t row0 = 0;
+    if (KS == 1) {
+        const int64_t rows = (int64_t)a.Ho * a.Wo;
+        const int tiles = (int)((rows + BM - 1) / BM);
+        img = bid / tiles;
+        row0 = (int64_t)(bid % tiles) * BM;
+    } else {
+        const int tx = (a.Wo + TW - 1) / TW, ty = (a.Ho + TH - 1) / TH;
+        ox0 = (bid % tx) * TW; bid /= tx;
+        oy0 = (bid % ty) * TH; img = bid / ty;
+    }
+    const int n0 = tn * BN;
+    const float* __restrict__ xin = a.x + (int64_t)img * a.x_batch_stride;
+    const int slabs = (a.Cin + 15) / 16;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int ppA[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) ppA[mi] = KS == 1 ? (wm * MI + mi) * 32 + li : (wm * MI + mi) * PW + li;
+
+    floatx16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int iy0 = oy0 - (KS / 2), ix0 = ox0 - (KS / 2);
+    const int64_t in_rows = (int64_t)a.H * a.W;
+
+    auto load_patch = [&](int slab, float4 (&r)[kPatchPerThread]) {
+#pragma unroll
+        for (int it = 0; it < kPatchPerThread; ++it) {
+            const int item = it * 256 + threadIdx.x;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (item < kPatchItems) {
+                const int pp = item >> 2, q = item & 3;
+                int64_t pix;
+                bool ok;
+                if (KS == 1) { pix = row0 + pp; ok = pix < in_rows; }
+                else {
+                    const int iy = iy0 + pp / PW, ix = ix0 + pp % PW;
+                    ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                    pix = (int64_t)iy * a.W + ix;
+                }
+                const int ci = slab * 16 + q * 4;
+                if (ok && ci < a.Cin) v = *reinterpret_cast<const float4*>(xin + pix * a.x_pitch + ci);
+            }
+            r[it] = v;
+        }
+    };
+    auto store_patch = [&](const float4 (&r)[kPatchPerThread]) {       // split into the three bf16 planes
+#pragma unroll
+        for (int it = 0; it < kPatchPerThread; ++it) {
+            const int item = it * 256 + threadIdx.x;
+            if (item < kPatchItems) {
+                const int pp = item >> 2, q = item & 3;
+                unsigned h[4], m[4], l[4];
+                split3(r[it].x, h[0], m[0], l[0]); split3(r[it].y, h[1], m[1], l[1]);
+                split3(r[it].z, h[2], m[2], l[2]); split3(r[it].w, h[3], m[3], l[3]);
+                const int off = pp * kRowBytes + q * 8;
+                *reinterpret_cast<uint2*>(&patch[0][off]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                *reinterpret_cast<uint2*>(&patch[1][off]) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+                *reinterpret_cast<uint2*>(&patch[2][off]) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+            }
+        }
+    };
+    auto load_w = [&](int tap, int slab, uint4 (&r)[kWPerThread]) {
+        const unsigned short* base = wpk + (((int64_t)tap * slabs + slab) * 3) * a.Cout * 16;
+#pragma unroll
+        for (int it = 0; it < kWPerThread; ++it) {
+            const int item = it * 256 + threadIdx.x;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (item < kWItems) {
+                const int s = item / (BN * 2), rem = item % (BN * 2);
+                const int co = n0 + (rem >> 1), half = rem & 1;
+                if (co < a.Cout) v = *reinterpret_cast<const uint4*>(base + ((int64_t)s * a.Cout + co) * 16 + half * 8);
+            }
+            r[it] = v;
+        }
+    };
+    auto store_w = [&](int buf, const uint4 (&r)[kWPerThread]) {
+#pragma unroll
+        for (int it = 0; it < kWPerThread; ++it) {
+            const int item = it * 256 + threadIdx.x;
+            if (item < kWItems) {
+                const int s = item / (BN * 2), rem = item % (BN * 2);
+                *reinterpret_cast<uint4*>(&wts[buf][s][(rem >> 1) * kRowBytes + (rem & 1) * 16]) = r[it];
+            }
+        }
+    };
+
+    float4 pr[kPatchPerThread];
+    uint4 wr[kWPerThread];
+    load_patch(0, pr);
+    load_w(0, 0, wr);
+    store_patch(pr);
+    store_w(0, wr);
+    __syncthreads();
+
+    int wbuf = 0;
+#pragma unroll 1
+    for (int slab = 0; slab < slabs; ++slab) {
+#pragma unroll 1
+        for (int tap = 0; tap < T; ++tap) {
+            const bool last_tap = tap == T - 1;
+            const bool has_next = !(last_tap && slab + 1 >= slabs);
+            const int ntap = last_tap ? 0 : tap + 1, nslab = last_tap ? slab + 1 : slab;
+            if (has_next) {
+                load_w(ntap, nslab, wr);
+                if (last_tap) load_patch(nslab, pr);
+            }
+            const int tapoff = KS == 1 ? 0 : (tap / KS) * PW + (tap % KS);
+            bf16x8 af[MI][3], bf[NI][3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[s][(ppA[mi] + tapoff) * kRowBytes + lh * 16]);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    bf[ni][s] = *reinterpret_cast<const bf16x8*>(&wts[wbuf][s][(wn * WN + ni * 32 + li) * kRowBytes + lh * 16]);
+            }
+            // six cross terms, smallest first; accumulators rotate so consecutive MFMAs are independent
+#define HIMO_TERM(SA, SB)                                                                                         \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)            \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][SA], bf[ni][SB], acc[mi][ni], 0, 0, 0);
+            HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
+#undef HIMO_TERM
+            if (has_next) store_w(wbuf ^ 1, wr);
+            if (last_tap && has_next) {
+                __syncthreads();                                // every wave is done with this slab's patch
+                store_patch(pr);
+            }
+            __syncthreads();
+            wbuf ^= 1;
+        }
+    }
+
+    float* __restrict__ yout = a.y + (int64_t)img * a.y_batch_stride;
+    const int64_t out_rows = (int64_t)a.Ho * a.Wo;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int co = n0 + wn * WN + ni * 32 + li;
+        if (co >= a.Cout) continue;
+        const float b = a.bias ? a.bias[co] : 0.f;
+        float sc = 1.f, sh = 0.f;
+        if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = (r & 3) + 8 * (r >> 2) + 4 * lh;           // pixel within the 32-pixel MFMA tile
+                int64_t pix;
+                bool ok;
+                if (KS == 1) { pix = row0 + (wm * MI + mi) * 32 + col; ok = pix < out_rows; }
+                else {
+                    const int oy = oy0 + wm * MI + mi, ox = ox0 + col;
+                    ok = oy < a.Ho && ox < a.Wo;
+                    pix = (int64_t)oy * a.Wo + ox;
+                }
+                if (ok) epilogue_store<EPI>(a, yout, pix, co, acc[mi][ni][r] + b, sc, sh);
+            }
+        }
+    }
+}
+
+template <int KS, int BN, int MI>
+static void launch_bf_epi(const ConvArgs& a, int epi, const unsigned short* w, dim3 grid, hipStream_t s) {
+    switch (epi) {
+        case kEpiBias: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBias, MI>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBiasBnGelu: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBiasBnGelu, MI>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBiasGelu: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBiasGelu, MI>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiGruZR: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiGruZR, MI>), grid, dim3(256), 0, s, a, w); break;
+        default: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiGruQ, MI>), grid, dim3(256), 0, s, a, w); break;
+    }
+}
+
+template <int KS>
+static void launch_bf_tile(const ConvArgs& a, int epi, int bn, int mi, const unsigned short* w, dim3 grid, hipStream_t s) {
+    if (bn == 128) { if (mi == 2) launch_bf_epi<KS, 128, 2>(a, epi, w, grid, s); else launch_bf_epi<KS, 128, 1>(a, epi, w, grid, s); }
+    else { if (mi == 2) launch_bf_epi<KS, 64, 2>(a, epi, w, grid, s); else launch_bf_epi<KS, 64, 1>(a, epi, w, grid, s); }
+}
+
+int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w_packed, hipStream_t s) {
+    auto blocks_for = [&](int bn, int mi) -> int64_t {
+        const int bm = 64 * mi, th = 2 * mi;
+        const int64_t tm = ksize == 1 ? (int64_t)a.N * (((int64_t)a.Ho * a.Wo + bm - 1) / bm)
+                                      : (int64_t)a.N * ((a.Ho + th - 1) / th) * ((a.Wo + 31) / 32);
+        return tm * ((a.Cout + bn - 1) / bn);
+    };
+    const bool can128 = a.Cout >= 128 && (a.Cout % 128) == 0;
+    int bn = can128 ? 128 : 64, mi = 2;
+    const int64_t want = 512;
+    if (blocks_for(bn, mi) < want) mi = 1;
+    if (blocks_for(bn, mi) < want && bn == 128) bn = 64;
+    const dim3 grid((unsigned)blocks_for(bn, mi));
+    const char* name = ksize == 1 ? "conv1x1_bf16x3_kernel" : "conv3x3_bf16x3_kernel";
+    {
+        ProfScope ps(name, s);
+        if (ksize == 1) launch_bf_tile<1>(a, epilogue, bn, mi, (const unsigned short*)w_packed, grid, s);
+        else launch_bf_tile<3>(a, epilogue, bn, mi, (const unsigned short*)w_packed, grid, s);
+    }
+    HIMO_LAUNCH_CHECK("conv_bf16x3_kernel");
+    return HIMO_OK;
+}
+
+}  // namespace himo
+
+using namespace himo;
+
+extern "C" size_t himo_conv_packed_weight_bytes(int ksize, int cin, int cout) {
+    return (size_t)ksize * ksize * ((cin + 15) / 16) * 3 * (size_t)cout * 16 * 2;
+}
+
+extern "C" int himo_conv_pack_weights(const float* d_w, int ksize, int cin, int cout, void* d_packed, void* stream) {
+    if (!d_w || !d_packed || cin < 1 || cout < 1 || !(ksize == 1 || ksize == 3)) return HIMO_ERR_INVALID_ARGUMENT;
+    const int T = ksize * ksize;
+    const int64_t total = (int64_t)T * ((cin + 15) / 16) * cout * 16;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_w, T, cin,
+                       cout, (unsigned short*)d_packed);
+    HIMO_LAUNCH_CHECK("pack_weights_kernel");
+    return HIMO_OK;
+}

@@ -29,7 +29,7 @@ class ConvDesc(ctypes.Structure):
                 ("n", ctypes.c_int), ("h", ctypes.c_int), ("w_in", ctypes.c_int), ("cin", ctypes.c_int),
                 ("cout", ctypes.c_int), ("ksize", ctypes.c_int), ("stride", ctypes.c_int), ("epilogue", ctypes.c_int),
                 ("aux_in", ctypes.c_void_p), ("aux_in_pitch", ctypes.c_int),
-                ("aux_out", ctypes.c_void_p), ("aux_out_pitch", ctypes.c_int)]
+                ("aux_out", ctypes.c_void_p), ("aux_out_pitch", ctypes.c_int), ("w_packed", ctypes.c_void_p)]
 
 
 _lib.register({
@@ -41,6 +41,9 @@ _lib.register({
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,   # xyz_t, pid, offsets, image
                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "himo_conv2d": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
+    "himo_conv_packed_weight_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "himo_conv_pack_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                              ctypes.c_void_p]),
     "himo_upsample2x": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "himo_head_gather": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -60,7 +63,13 @@ class SeFlowNet:
     """``forward(pch1, pc0, pc1, pose_h1, pose0, pose1)`` -> (N0,3) float32 device tensor: the flow of every
     pc0 row INCLUDING ego motion (the h5 ``<res_name>`` dataset that save_zip.py:117 reads)."""
 
-    def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, seed: int = 0):
+    def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, seed: int = 0,
+                 precision: str = "bf16x3"):
+        """``precision``: "bf16x3" = split-bf16 matrix instructions for every stride-1 convolution / GEMM (float32-class
+        accuracy, see csrc/convbf.hip); "f32" = float32 MFMA everywhere."""
+        if precision not in ("bf16x3", "f32"):
+            raise ValueError(precision)
+        self.precision = precision
         self.lib = _lib.load()
         self.device = device if device is not None else _lib.require_gpu()
         params = spec.init_params(seed) if params is None else params
@@ -80,6 +89,16 @@ class SeFlowNet:
         derived["head.gru.zr.weight"] = torch.cat([cpu["head.gru.z.weight"], cpu["head.gru.r.weight"]], dim=1).contiguous()
         derived["head.gru.zr.bias"] = torch.cat([cpu["head.gru.z.bias"], cpu["head.gru.r.bias"]]).contiguous()
         self.p = {k: v.to(self.device) for k, v in {**cpu, **derived}.items()}
+        self.packed = {}
+        if precision == "bf16x3":
+            for k, v in self.p.items():
+                if k.endswith(".weight") and k != "pfn.weight" and not k.startswith("head.offset") and k != "head.dec2.weight":
+                    w = v if v.dim() == 4 else v.reshape(1, 1, *v.shape)          # linears are 1x1 convolutions
+                    ks, _, cin, cout = w.shape
+                    buf = torch.empty(int(self.lib.himo_conv_packed_weight_bytes(ks, cin, cout)), dtype=torch.uint8, device=self.device)
+                    _lib.check(self.lib.himo_conv_pack_weights(w.contiguous().data_ptr(), ks, cin, cout, buf.data_ptr(),
+                                                               _lib.stream_handle()), "himo_conv_pack_weights")
+                    self.packed[k] = buf
 
         H, W = spec.GRID
         F = spec.NUM_FRAMES
@@ -138,6 +157,8 @@ class SeFlowNet:
         d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = n, h, w, cin, cout, ks, stride, epi
         d.aux_in = None if aux_in is None else aux_in.data_ptr(); d.aux_in_pitch = aux_in_pitch
         d.aux_out = None if aux_out is None else aux_out.data_ptr(); d.aux_out_pitch = aux_out_pitch
+        pk = self.packed.get(f"{wname}.weight")
+        d.w_packed = None if pk is None else pk.data_ptr()
         _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), f"himo_conv2d({wname})")
 
     def _up(self, x, x_pitch, h, w, c, y, y_pitch):
@@ -238,7 +259,7 @@ class SeFlowNet:
 
 # ---- stand-alone operators (tests / experiments): the same kernels on caller-provided tensors -------------------
 def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: int = 1, epilogue: int = EPI_BIAS,
-                scale: torch.Tensor | None = None, shift: torch.Tensor | None = None) -> torch.Tensor:
+                scale: torch.Tensor | None = None, shift: torch.Tensor | None = None, precision: str = "f32") -> torch.Tensor:
     """x [N,H,W,Cin] float32 (contiguous, device), weight [k,k,Cin,Cout] -> y [N,Ho,Wo,Cout]."""
     lib = _lib.load()
     n, h, w, cin = x.shape
@@ -255,6 +276,11 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, strid
     else:
         d.n, d.h, d.w_in = n, h, w
     d.cin, d.cout, d.ksize, d.stride, d.epilogue = cin, cout, k, stride, epilogue
+    if precision == "bf16x3" and stride == 1:
+        pk = torch.empty(int(lib.himo_conv_packed_weight_bytes(k, cin, cout)), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.himo_conv_pack_weights(weight.contiguous().data_ptr(), k, cin, cout, pk.data_ptr(), _lib.stream_handle()),
+                   "himo_conv_pack_weights")
+        d.w_packed = pk.data_ptr()
     _lib.check(lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), "himo_conv2d")
     return y
 

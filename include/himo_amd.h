@@ -222,8 +222,14 @@ typedef struct himo_conv_desc {
     int n, h, w_in, cin, cout, ksize, stride, epilogue;
     const float* aux_in; int aux_in_pitch;                 /* GRU epilogues, [rows][pitch] */
     float* aux_out; int aux_out_pitch;
+    const void* w_packed;                                  /* optional: himo_conv_pack_weights output; when set and
+                                                              stride == 1 the split-bf16 kernel runs (same accuracy
+                                                              class, 2.67x the float32-MFMA rate) */
 } himo_conv_desc;
 int himo_conv2d(const himo_conv_desc* h_desc, void* stream);
+/* one-time weight preparation for the split-bf16 path: [k][k][cin][cout] float32 -> three bf16 planes */
+size_t himo_conv_packed_weight_bytes(int ksize, int cin, int cout);
+int himo_conv_pack_weights(const float* d_w, int ksize, int cin, int cout, void* d_packed, void* stream);
 
 /* bilinear x2 upsampling, align_corners = true; c channels of every pixel, NHWC with pitches */
 int himo_upsample2x(const float* d_x, int x_pitch, int h, int w, int c, float* d_y, int y_pitch, void* stream);

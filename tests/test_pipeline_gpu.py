@@ -36,3 +36,37 @@ def test_pipeline_matches_cpu_restatement(gpu, oracle):
     first = out["comp_dis"].clone()
     again = pipe.run(samples, refined=True)
     assert torch.equal(first, again["comp_dis"])
+
+
+def test_save_then_save_zip_then_eval_round_trip(gpu, oracle, tmp_path):
+    """The reference's three-program flow (save.py -> save_zip.py / eval.py) on an on-disk dataset, GPU end to end.
+    Feather I/O needs pyarrow, absent on the GPU box: the zip step is exercised only where pyarrow exists."""
+    from himo_amd import save
+    from himo_amd.dataset import NpzDataset
+    from himo_amd.eval import InstanceMetrics
+    from himo_amd.synthetic import make_frame
+    frames = [make_frame(70 + i, n_points=12_000, scene_id="sceneA", res_name="unused") for i in range(3)]
+    for f in frames:
+        f.pop("unused")
+    NpzDataset.write(tmp_path, frames)
+    ds = NpzDataset(tmp_path)
+    done = save.run(ds, "seflowpp_best", sink=save.NpzResultSink(tmp_path, "seflowpp_best"))
+    assert done == 2                                          # the last sweep of the scene has no successor
+    ds = NpzDataset(tmp_path)
+    f0 = ds[0]
+    assert f0["seflowpp_best"].shape == (12_000, 3) and f0["seflowpp_best"].dtype == np.float32
+    # evaluate the stored flow exactly like eval.py does (frames that carry a result)
+    m, ref = InstanceMetrics("av2"), oracle.InstanceMetrics("av2")
+    scored = [dict(ds[i], pose1=frames[i + 1]["pose0"] if False else ds[i]["pose1"]) for i in range(2)]
+    m.step_frames(scored, res_name="seflowpp_best")
+    for f in scored:
+        oracle.eval_frame(ref, f, res_name="seflowpp_best")
+    assert m.frame_cnt == ref.frame_cnt == 2
+    import json
+    a, b = json.loads(json.dumps(m.summary(), default=float)), json.loads(json.dumps(ref.summary(), default=float))
+    assert a.keys() == b.keys()
+    for cat in b:
+        for k in ("mpe", "cd"):
+            va = a[cat]["overall"][k] if "overall" in a[cat] else a[cat][k]
+            vb = b[cat]["overall"][k] if "overall" in b[cat] else b[cat][k]
+            assert va == pytest.approx(vb, rel=1e-9, abs=1e-12)

@@ -34,7 +34,8 @@ def net(gpu, params):
     (16, 32, 32, 64, 3, 1, 1), (24, 48, 64, 128, 3, 1, 0), (32, 32, 32, 64, 3, 2, 1), (16, 16, 128, 256, 3, 2, 1),
     (8, 16, 768, 256, 1, 1, 0), (40, 40, 96, 64, 1, 1, 0), (8, 16, 512, 256, 3, 1, 0), (19, 37, 16, 64, 3, 1, 2),
 ])
-def test_conv_layer_matches_torch(gpu, cfg):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_conv_layer_matches_torch(gpu, cfg, precision):
     from himo_amd.seflow.model import conv2d_nhwc
     H, W, ci, co, k, s, epi = cfg
     g = torch.Generator().manual_seed(H * 1000 + ci)
@@ -48,7 +49,7 @@ def test_conv_layer_matches_torch(gpu, cfg):
     elif epi == 2:
         ref = F.gelu(ref)
     y = conv2d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(gpu), w.to(gpu), b.to(gpu), stride=s, epilogue=epi,
-                    scale=scale.to(gpu), shift=shift.to(gpu))
+                    scale=scale.to(gpu), shift=shift.to(gpu), precision=precision)
     got = y.permute(0, 3, 1, 2).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() <= 2e-5
@@ -98,8 +99,11 @@ def test_pillar_front_end_is_deterministic_and_handles_out_of_range(gpu, net):
     assert torch.equal(a, net.B0)                              # every cell rewritten: no stale data
 
 
-def test_full_forward_matches_cpu_restatement(gpu, so, params, net):
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+def test_full_forward_matches_cpu_restatement(gpu, so, params, precision):
+    from himo_amd.seflow.model import SeFlowNet
     from himo_amd.synthetic import make_frame
+    net = SeFlowNet(params, device=gpu, max_points=50_000, precision=precision)
     fh, f0, f1 = make_frame(10, n_points=30_000), make_frame(11, n_points=40_000), make_frame(12, n_points=35_000)
     flow = net.forward(fh["pc0"], f0["pc0"], f1["pc0"], fh["pose0"], f0["pose0"], f0["pose1"])
     torch.cuda.synchronize()
