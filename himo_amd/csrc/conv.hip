@@ -307,7 +307,7 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
     a.Wo = d->stride == 2 ? (d->w_in + 1) / 2 : d->w_in;
     a.aux_in = d->aux_in; a.aux_in_pitch = d->aux_in_pitch; a.aux_out = d->aux_out; a.aux_out_pitch = d->aux_out_pitch;
     hipStream_t s = (hipStream_t)stream;
-    if (d->w_packed && d->stride == 1) return launch_conv_bf16x3(a, d->ksize, d->epilogue, d->w_packed, s);
+    if (d->w_packed && d->stride == 1) return launch_conv_bf16x3(a, d->ksize, d->epilogue, d->w_packed, d->tile_hint, s);
     // tile choice: 128 x 128 when that still gives >= 2 blocks per CU, else shrink M then N so the chip is filled
     auto blocks_for = [&](int bn, int mi) -> int64_t {
         const int bm = 64 * mi, th = 4 * mi;
@@ -321,6 +321,10 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
     const int64_t want = 512;
     if (blocks_for(bn, mi) < want) mi = 1;
     if (blocks_for(bn, mi) < want && bn == 128 && !gru) bn = 64;
+    if (d->tile_hint) {
+        const int hb = d->tile_hint >> 4, hm = d->tile_hint & 15;
+        if ((hb == 64 || (hb == 128 && can128)) && (hm == 1 || hm == 2)) { bn = hb; mi = hm; }
+    }
     const dim3 grid((unsigned)blocks_for(bn, mi));
     const char* name = d->ksize == 1 ? "conv1x1_mfma_kernel" : (d->stride == 2 ? "conv3x3s2_mfma_kernel" : "conv3x3_mfma_kernel");
     {

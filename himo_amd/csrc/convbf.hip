@@ -269,7 +269,7 @@ static void launch_bf_tile(const ConvArgs& a, int epi, int bn, int mi, const uns
     else { if (mi == 2) launch_bf_epi<KS, 64, 2>(a, epi, w, grid, s); else launch_bf_epi<KS, 64, 1>(a, epi, w, grid, s); }
 }
 
-int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w_packed, hipStream_t s) {
+int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w_packed, int tile_hint, hipStream_t s) {
     auto blocks_for = [&](int bn, int mi) -> int64_t {
         const int bm = 64 * mi, th = 2 * mi;
         const int64_t tm = ksize == 1 ? (int64_t)a.N * (((int64_t)a.Ho * a.Wo + bm - 1) / bm)
@@ -281,6 +281,10 @@ int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w
     const int64_t want = 512;
     if (blocks_for(bn, mi) < want) mi = 1;
     if (blocks_for(bn, mi) < want && bn == 128) bn = 64;
+    if (tile_hint) {                                            // caller-tuned tile: (bn << 4) | mi
+        const int hb = tile_hint >> 4, hm = tile_hint & 15;
+        if ((hb == 64 || (hb == 128 && can128)) && (hm == 1 || hm == 2)) { bn = hb; mi = hm; }
+    }
     const dim3 grid((unsigned)blocks_for(bn, mi));
     const char* name = ksize == 1 ? "conv1x1_bf16x3_kernel" : "conv3x3_bf16x3_kernel";
     {

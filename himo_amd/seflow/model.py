@@ -29,7 +29,8 @@ class ConvDesc(ctypes.Structure):
                 ("n", ctypes.c_int), ("h", ctypes.c_int), ("w_in", ctypes.c_int), ("cin", ctypes.c_int),
                 ("cout", ctypes.c_int), ("ksize", ctypes.c_int), ("stride", ctypes.c_int), ("epilogue", ctypes.c_int),
                 ("aux_in", ctypes.c_void_p), ("aux_in_pitch", ctypes.c_int),
-                ("aux_out", ctypes.c_void_p), ("aux_out_pitch", ctypes.c_int), ("w_packed", ctypes.c_void_p)]
+                ("aux_out", ctypes.c_void_p), ("aux_out_pitch", ctypes.c_int), ("w_packed", ctypes.c_void_p),
+                ("tile_hint", ctypes.c_int)]
 
 
 _lib.register({
@@ -64,12 +65,14 @@ class SeFlowNet:
     pc0 row INCLUDING ego motion (the h5 ``<res_name>`` dataset that save_zip.py:117 reads)."""
 
     def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, seed: int = 0,
-                 precision: str = "bf16x3"):
+                 precision: str = "bf16x3", autotune: bool = True):
         """``precision``: "bf16x3" = split-bf16 matrix instructions for every stride-1 convolution / GEMM (float32-class
         accuracy, see csrc/convbf.hip); "f32" = float32 MFMA everywhere."""
         if precision not in ("bf16x3", "f32"):
             raise ValueError(precision)
         self.precision = precision
+        self.autotune = autotune
+        self.tiles = {}
         self.lib = _lib.load()
         self.device = device if device is not None else _lib.require_gpu()
         params = spec.init_params(seed) if params is None else params
@@ -159,7 +162,36 @@ class SeFlowNet:
         d.aux_out = None if aux_out is None else aux_out.data_ptr(); d.aux_out_pitch = aux_out_pitch
         pk = self.packed.get(f"{wname}.weight")
         d.w_packed = None if pk is None else pk.data_ptr()
+        key = (n, h, w, cin, cout, ks, stride, epi, pk is not None)
+        if self.autotune and key not in self.tiles:
+            self.tiles[key] = self._tune(d)
+        d.tile_hint = self.tiles.get(key, 0)
         _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), f"himo_conv2d({wname})")
+
+    def _tune(self, d: "ConvDesc") -> int:
+        """Time the tile variants of one layer shape once (the kernels are idempotent for the non-GRU epilogues; the
+        GRU ones update state in place, so they keep the library heuristic) and remember the fastest."""
+        if d.epilogue in (EPI_GRU_ZR, EPI_GRU_Q):
+            return 0
+        best, best_t = 0, float("inf")
+        stream = _lib.stream_handle()
+        for bn in (128, 64):
+            if bn == 128 and d.cout % 128:
+                continue
+            for mi in (2, 1):
+                d.tile_hint = (bn << 4) | mi
+                for _ in range(2):
+                    self.lib.himo_conv2d(ctypes.byref(d), stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    self.lib.himo_conv2d(ctypes.byref(d), stream)
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+                if t < best_t:
+                    best, best_t = d.tile_hint, t
+        return best
 
     def _up(self, x, x_pitch, h, w, c, y, y_pitch):
         _lib.check(self.lib.himo_upsample2x(x.data_ptr(), x_pitch, h, w, c, y.data_ptr(), y_pitch, _lib.stream_handle()),

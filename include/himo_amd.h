@@ -225,6 +225,8 @@ typedef struct himo_conv_desc {
     const void* w_packed;                                  /* optional: himo_conv_pack_weights output; when set and
                                                               stride == 1 the split-bf16 kernel runs (same accuracy
                                                               class, 2.67x the float32-MFMA rate) */
+    int tile_hint;                                         /* 0 = library heuristic; else (channel tile 64|128) << 4 | (1|2):
+                                                              pixel tile 64|128 -- for callers that time the variants */
 } himo_conv_desc;
 int himo_conv2d(const himo_conv_desc* h_desc, void* stream);
 /* one-time weight preparation for the split-bf16 path: [k][k][cin][cout] float32 -> three bf16 planes */
