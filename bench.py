@@ -32,6 +32,7 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 MFMA_F32_PEAK_TF = 157.3         # dense float32-input MFMA peak (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TF = 2500.0       # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
 POINTS_PER_FRAME = 120_000       # BASELINE.json metric
 
 
@@ -43,6 +44,8 @@ def parse_args():
     ap.add_argument("--workload", default="pipeline", choices=["pipeline", "compdis"])
     ap.add_argument("--frames-per-step", type=int, default=None, help="frames per rank per step")
     ap.add_argument("--points", type=int, default=POINTS_PER_FRAME)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"],
+                    help="network matrix arithmetic: split-bf16 (float32-class accuracy) or float32 MFMA")
     ap.add_argument("--refined", action="store_true", help="also write refined points (+12 B/pt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget for the baseline leg")
@@ -222,7 +225,7 @@ def main():
         from himo_amd.seflow import spec
         from himo_amd.seflow.model import SeFlowNet
         params = spec.init_params(0)
-        pipe = HiMoPipeline(SeFlowNet(params, device=device, max_points=P), device=device)
+        pipe = HiMoPipeline(SeFlowNet(params, device=device, max_points=P, precision=args.precision), device=device)
         samples = synthetic_samples(B, P, device, seed=rank)
         result = {}
 
@@ -296,22 +299,30 @@ def main():
             dtype = "f64"
         else:
             from himo_amd.seflow import spec
-            k = prof.get("conv3x3_mfma_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
+            bf = args.precision == "bf16x3"
+            kname = "conv3x3_bf16x3_kernel" if bf else "conv3x3_mfma_kernel"
+            k = prof.get(kname, {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
             n_fwd = B * args.steps
             # algorithmic flops of the 20 stride-1 3x3 convolutions of one forward (2*M*N*K each), see DESIGN.md
             flops3 = spec.conv3x3_flops()
             launches_per_fwd = k["count"] / max(n_fwd, 1)
-            achieved = flops3 * n_fwd / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
-            roofline = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
-                        "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TF,
-                        "traffic": traffic.get("conv3x3_mfma_kernel", {}).get("hbm_bytes_per_launch"),
+            alg_tf = flops3 * n_fwd / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
+            if bf:
+                # split-bf16: every float32 multiply-add is SIX bf16 matrix multiply-adds (h*h, h*m, m*h, m*m, h*l, l*h);
+                # `achieved` is the bf16 MFMA work actually issued, priced against the dense bf16 peak
+                achieved, peak, note = 6.0 * alg_tf, MFMA_BF16_PEAK_TF, "v_mfma_f32_32x32x16_bf16, 6 per float32 product block"
+            else:
+                achieved, peak, note = alg_tf, MFMA_F32_PEAK_TF, "v_mfma_f32_32x32x2_f32"
+            roofline = {"bound": "mfma", "kernel": f"{kname} ({note})", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                        "frac": achieved / peak, "traffic": traffic.get("conv3x3_mfma_kernel", {}).get("hbm_bytes_per_launch"),
+                        "algorithmic_f32_equivalent_tflops": alg_tf, "vs_f32_mfma_peak_157_3": alg_tf / MFMA_F32_PEAK_TF,
                         "algorithmic_flops_per_launch": flops3 / max(launches_per_fwd, 1e-9), "avg_launch_ms": k["avg_ms"],
                         "launches_timed": k["count"], "launches_per_forward": launches_per_fwd,
                         "share_of_step_time": k["total_ms"] / (elapsed * 1e3)}
             workload = ("per-frame pipeline: pillarise 3 sweeps (512x512 grid) -> SeFlow++-style encoder/decoder + GRU head "
                         "(random-init, self-specified: reference network source absent) -> per-point flow -> ego-motion "
                         "removal + dt0 + flow2compDis -> comp_dis")
-            dtype = "f32"
+            dtype = "bf16x3 (three-term split bf16 on the matrix cores, float32 accumulate; float32-class accuracy)" if bf else "f32"
         line = {
             "metric": "lidar_frames_per_sec_120k", "value": total_frames / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
