@@ -33,6 +33,7 @@ SIGNATURES = {
     "himo_refine_pts": (c_int, [c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "himo_ego_pts_mask": (c_int, [c_int64, c_void_p, c_int, ctypes.POINTER(c_float), c_void_p, c_void_p]),
     "himo_dt0": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "himo_lz4_frame_decompress": (c_int64, [c_void_p, c_int64, c_void_p, c_int64]),
     "himo_nn_search": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_void_p]),
     "himo_eval_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64]),

@@ -17,13 +17,13 @@ from __future__ import annotations
 import os
 import shutil
 import time
-from io import BytesIO
 from pathlib import Path
 from typing import Tuple
 from zipfile import ZipFile
 
 import numpy as np
-import pandas as pd
+
+from . import feather
 
 COLUMNS = ("comp_dis_x_m", "comp_dis_y_m", "comp_dis_z_m")
 
@@ -33,20 +33,22 @@ def read_output_zip(zip_path: str, sweep_uuid: Tuple[str, int]) -> np.ndarray:
     like ``ZipFile.open`` does in the reference."""
     with ZipFile(zip_path, "r") as myzip:
         with myzip.open(f"{sweep_uuid[0]}/{sweep_uuid[1]}.feather") as f:
-            df = pd.read_feather(BytesIO(f.read()))
-    return np.stack([df[c].values.astype(np.float32) for c in COLUMNS], axis=1)
+            table = feather.read_table(f.read())
+    return np.stack([table[c].astype(np.float32) for c in COLUMNS], axis=1)
 
 
-def _frame_table(compensation_dis) -> pd.DataFrame:
+def _frame_table(compensation_dis) -> bytes:
+    """Feather V2 bytes with the three float32 columns of save_zip.py:74-80 (own writer: himo_amd/feather.py; the
+    reference goes through pandas -> pyarrow, which the GPU box image does not have)."""
     cd = np.asarray(compensation_dis)
-    return pd.DataFrame({c: cd[:, i].astype(np.float32) for i, c in enumerate(COLUMNS)})
+    return feather.write_table({c: np.ascontiguousarray(cd[:, i], dtype=np.float32) for i, c in enumerate(COLUMNS)})
 
 
 def write_output_file(compensation_dis, sweep_uuid: Tuple[str, int], output_dir: Path) -> None:
     """``<output_dir>/<scene_id>/<timestamp>.feather`` with three float32 columns."""
     output_log_dir = Path(output_dir) / sweep_uuid[0]
     output_log_dir.mkdir(exist_ok=True, parents=True)
-    _frame_table(compensation_dis).to_feather(output_log_dir / f"{sweep_uuid[1]}.feather")
+    (output_log_dir / f"{sweep_uuid[1]}.feather").write_bytes(_frame_table(compensation_dis))
 
 
 def zip_res(res_folder, output_file="submit.zip"):
@@ -75,9 +77,7 @@ class ZipSink:
         self._zip = ZipFile(self.path, "w")
 
     def add(self, compensation_dis, sweep_uuid: Tuple[str, int]) -> None:
-        buf = BytesIO()
-        _frame_table(compensation_dis).to_feather(buf)
-        self._zip.writestr(f"{sweep_uuid[0]}/{sweep_uuid[1]}.feather", buf.getvalue())
+        self._zip.writestr(f"{sweep_uuid[0]}/{sweep_uuid[1]}.feather", _frame_table(compensation_dis))
 
     def close(self):
         self._zip.close()

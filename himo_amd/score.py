@@ -14,13 +14,13 @@ bookkeeping stays on the host in the reference's order.
 from __future__ import annotations
 
 import json
-from io import BytesIO
 from pathlib import Path
 from zipfile import ZipFile
 
 import numpy as np
-import pandas as pd
 import torch
+
+from . import feather
 
 from .eval import (BUCKETED_METACATAGORIES, CATEGORY_TO_INDEX, EVAL_GROUPS, MODE_SCORE, RANGES,  # noqa: F401
                    InstanceEvaluator, chamfer_distance, range_name_of)
@@ -32,18 +32,18 @@ def read_data_file(data_path: str, sweep_uuid: tuple) -> tuple:
     member = f"{sweep_uuid[0]}/{sweep_uuid[1]}.feather"
     data_path = Path(data_path)
     if data_path.is_dir():
-        df = pd.read_feather(data_path / member)
+        df = feather.read_table((data_path / member).read_bytes())
     else:
         with ZipFile(data_path, "r") as z:
-            df = pd.read_feather(BytesIO(z.read(member)))
-    col = lambda name, dt: df[name].values.astype(dt) if name in df.columns else None
-    comp_dis = np.stack([df[f"comp_dis_{a}_m"].values.astype(np.float32) for a in "xyz"], axis=1)
+            df = feather.read_table(z.read(member))
+    col = lambda name, dt: df[name].astype(dt) if name in df else None
+    comp_dis = np.stack([df[f"comp_dis_{a}_m"].astype(np.float32) for a in "xyz"], axis=1)
     eval_mask = col("eval_mask", bool)
     if eval_mask is None:
         eval_mask = np.ones(len(comp_dis), dtype=bool)
     pc0 = None
-    if all(f"pc0_{a}" in df.columns for a in "xyz"):
-        pc0 = np.stack([df[f"pc0_{a}"].values.astype(np.float32) for a in "xyz"], axis=1)
+    if all(f"pc0_{a}" in df for a in "xyz"):
+        pc0 = np.stack([df[f"pc0_{a}"].astype(np.float32) for a in "xyz"], axis=1)
     return (comp_dis, eval_mask, col("flow_category_indices", np.uint8), col("flow_instance_id", np.uint32),
             col("gt_flow_norm", np.float32), pc0)
 

@@ -268,6 +268,11 @@ int himo_ssl_loss(int n0, int n1, const float* d_pc0, const float* d_pc1, const 
                   float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
                   double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * a9 helper (host memory, no GPU): LZ4-frame decoder for the compressed buffers of Feather V2 files as pandas /
+ * pyarrow write them (save_zip.py:81 `to_feather`).  Returns the decompressed size, or -1. */
+int64_t himo_lz4_frame_decompress(const void* h_src, int64_t n, void* h_dst, int64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,3 +57,62 @@ def test_empty_sweep_roundtrip(tmp_path):
     save_zip.write_output_file(np.zeros((0, 3)), ("s", "1"), tmp_path)
     save_zip.zip_res(tmp_path, str(tmp_path / "e.zip"))
     assert save_zip.read_output_zip(str(tmp_path / "e.zip"), ("s", "1")).shape == (0, 3)
+
+
+# ---- the package's own Feather V2 codec (himo_amd/feather.py) against pandas/pyarrow -------------------------------
+def test_own_reader_matches_pandas_on_reference_written_members():
+    """The golden zips were written by the reference (pandas -> pyarrow, LZ4-frame compressed buffers)."""
+    from himo_amd import feather
+    for name in ("av2_gt.zip", "av2_pred.zip", "scania_gt.zip", "scania_pred.zip"):
+        with ZipFile(GOLDEN / name) as z:
+            for member in z.namelist():
+                raw = z.read(member)
+                mine, ref = feather.read_table(raw), pd.read_feather(BytesIO(raw))
+                assert list(mine) == list(ref.columns)
+                for c in ref.columns:
+                    assert mine[c].dtype == ref[c].values.dtype and np.array_equal(mine[c], ref[c].values), (member, c)
+
+
+def test_own_writer_is_read_by_pandas_and_pyarrow():
+    import pyarrow.ipc as ipc
+    from himo_amd import feather
+    rng = np.random.default_rng(0)
+    cols = {"comp_dis_x_m": rng.normal(size=4097).astype(np.float32), "eval_mask": (rng.random(4097) > 0.5).astype(np.uint8),
+            "flow_instance_id": rng.integers(0, 2**32, 4097, dtype=np.uint32), "b": rng.random(4097) > 0.5,
+            "f64": rng.normal(size=4097), "i16": rng.integers(-300, 300, 4097).astype(np.int16)}
+    raw = feather.write_table(cols)
+    df = pd.read_feather(BytesIO(raw))
+    tab = ipc.open_file(BytesIO(raw)).read_all()
+    assert tab.num_rows == 4097 and tab.column_names == list(cols)
+    for c, v in cols.items():
+        assert df[c].values.dtype == v.dtype and np.array_equal(df[c].values, v), c
+        assert np.array_equal(feather.read_table(raw)[c], v)
+    for n in (0, 1, 7):
+        raw = feather.write_table({"comp_dis_x_m": np.arange(n, dtype=np.float32)})
+        assert len(pd.read_feather(BytesIO(raw))) == n
+
+
+def test_own_reader_handles_uncompressed_and_multi_batch_files():
+    import pyarrow as pa
+    import pyarrow.ipc as ipc
+    from himo_amd import feather
+    a = np.arange(10, dtype=np.float32)
+    sink = BytesIO()
+    with ipc.new_file(sink, pa.schema([("a", pa.float32()), ("m", pa.uint8())])) as w:
+        for lo in (0, 4, 7):
+            hi = {0: 4, 4: 7, 7: 10}[lo]
+            w.write_batch(pa.record_batch([pa.array(a[lo:hi]), pa.array((a[lo:hi] % 2).astype(np.uint8))], names=["a", "m"]))
+    t = feather.read_table(sink.getvalue())
+    assert np.array_equal(t["a"], a) and np.array_equal(t["m"], (a % 2).astype(np.uint8))
+    with pytest.raises(ValueError):
+        feather.read_table(b"FEA1" + b"\\0" * 64)
+
+
+def test_lz4_decoder_rejects_garbage():
+    import ctypes
+    from himo_amd import _lib
+    lib = _lib.load()
+    dst = ctypes.create_string_buffer(64)
+    assert lib.himo_lz4_frame_decompress(b"\\x00" * 32, 32, dst, 64) == -1
+    bad = b"\\x04\\x22\\x4d\\x18\\x60\\x40\\x82" + b"\\xff\\xff\\xff\\x7f" + b"\\x00" * 8     # block larger than the input
+    assert lib.himo_lz4_frame_decompress(bad, len(bad), dst, 64) == -1

@@ -53,3 +53,38 @@ def test_without_pc0_and_flow_norm(gpu, gold, oracle):
     a, b = mine.compute_scores(), ref.compute_scores()
     for k, v in b.items():
         assert a[k] == pytest.approx(v, rel=2e-6), k
+
+
+@pytest.mark.parametrize("data_name", ["av2", "scania"])
+def test_score_program_on_the_reference_written_zips(gpu, eval_gold, data_name, tmp_path, capsys):
+    """tools/test/score.py's whole program: GT zip + prediction zip (both written by the reference, LZ4 Feather)
+    -> scores.json.  Runs on the GPU box without pyarrow thanks to himo_amd/feather.py."""
+    import json
+    from conftest import GOLDEN
+    from himo_amd.score import score
+    ref = eval_gold[f"{data_name}/scores"]
+    got = score(str(GOLDEN / f"{data_name}_gt.zip"), str(GOLDEN / f"{data_name}_pred.zip"), output_dir=str(tmp_path))
+    for k, v in ref.items():
+        if isinstance(v, float):
+            assert got[k] == pytest.approx(v, rel=2e-6), k
+        else:
+            assert got[k] == v, k
+    saved = json.loads((tmp_path / "scores.json").read_text())
+    assert saved["num_frames"] == ref["num_frames"] and (tmp_path / f"res-{data_name}.json").exists()
+    assert "HiMo refinement metrics" in capsys.readouterr().out
+
+
+def test_save_zip_program_round_trip_on_gpu_box(gpu, gold, tmp_path):
+    """save_zip.run_dataset -> zip_res -> read_output_zip with the package's own Feather writer/reader."""
+    from conftest import golden_frames
+    from himo_amd import save_zip
+    from himo_amd.dataset import ListDataset
+    frames = golden_frames(gold, "av2")
+    out = tmp_path / "results"
+    out.mkdir()
+    assert save_zip.run_dataset(ListDataset(frames), "seflowpp_best", out, batch_frames=2) == len(frames)
+    z = save_zip.zip_res(out, output_file=str(out / "seflowpp_best-submit.zip"))
+    for i, f in enumerate(frames):
+        cd = save_zip.read_output_zip(z, (f["scene_id"], str(f["timestamp"])))
+        ref = gold[f"av2/{i}/ref_comp_dis"]
+        assert cd.dtype == np.float32 and np.abs(cd.astype(np.float64) - ref).max() <= 1e-9
