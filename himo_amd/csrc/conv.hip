@@ -273,6 +273,8 @@ static void launch_epi(const ConvArgs& a, int epi, dim3 grid, hipStream_t s) {
         case kEpiBiasBnGelu: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBiasBnGelu, MI>), grid, dim3(256), 0, s, a); break;
         case kEpiBiasGelu: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBiasGelu, MI>), grid, dim3(256), 0, s, a); break;
         case kEpiGruZR: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiGruZR, MI>), grid, dim3(256), 0, s, a); break;
+        case kEpiBiasRelu: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBiasRelu, MI>), grid, dim3(256), 0, s, a); break;
+        case kEpiReluMask: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiReluMask, MI>), grid, dim3(256), 0, s, a); break;
         default: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiGruQ, MI>), grid, dim3(256), 0, s, a); break;
     }
 }
@@ -292,9 +294,10 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
     if (d->n < 1 || d->h < 1 || d->w_in < 1 || d->cin < 1 || d->cout < 1) return HIMO_ERR_INVALID_ARGUMENT;
     if (!(d->ksize == 1 || d->ksize == 3) || !(d->stride == 1 || d->stride == 2)) return HIMO_ERR_UNSUPPORTED;
     if (d->ksize == 1 && d->stride != 1) return HIMO_ERR_UNSUPPORTED;
-    if (d->epilogue < 0 || d->epilogue > kEpiGruQ) return HIMO_ERR_INVALID_ARGUMENT;
+    if (d->epilogue < 0 || d->epilogue > kEpiReluMask) return HIMO_ERR_INVALID_ARGUMENT;
     if (d->epilogue == kEpiBiasBnGelu && (!d->scale || !d->shift)) return HIMO_ERR_INVALID_ARGUMENT;
     if ((d->epilogue == kEpiGruZR || d->epilogue == kEpiGruQ) && (!d->aux_in || !d->aux_out)) return HIMO_ERR_INVALID_ARGUMENT;
+    if (d->epilogue == kEpiReluMask && !d->aux_in) return HIMO_ERR_INVALID_ARGUMENT;
     // 16-byte vector loads: channel counts / pitches / bases must be multiples of 4 floats
     if ((d->cin & 3) || (d->cout & 3) || (d->x_pitch & 3) || (d->x_batch_stride & 3) || !aligned16(d->x) || !aligned16(d->w))
         return HIMO_ERR_UNSUPPORTED;

@@ -13,7 +13,9 @@ enum Epilogue {
     kEpiBiasBnGelu = 1,   // y = gelu((acc + bias) * scale + shift)
     kEpiBiasGelu = 2,     // y = gelu(acc + bias)
     kEpiGruZR = 3,        // cols [0,C/2): z = sigmoid(.) -> out ; cols [C/2,C): r = sigmoid(.), aux_out = r * h
-    kEpiGruQ = 4          // q = tanh(.) ; h = (1 - z) * h + z * q  (in place in aux_out)
+    kEpiGruQ = 4,         // q = tanh(.) ; h = (1 - z) * h + z * q  (in place in aux_out)
+    kEpiBiasRelu = 5,     // y = max(acc + bias, 0)                      (coordinate-MLP forward, FastNSF)
+    kEpiReluMask = 6      // y = aux_in > 0 ? acc : 0                    (its backward: dX = (dZ W^T) * relu'(X))
 };
 
 struct ConvArgs {
@@ -53,6 +55,10 @@ __device__ inline void epilogue_store(const ConvArgs& a, float* __restrict__ you
         const float g = sigmoid_f(v);
         if (co < half) yout[pix * a.y_pitch + co] = g;                               // z
         else a.aux_out[pix * a.aux_out_pitch + (co - half)] = g * a.aux_in[pix * a.aux_in_pitch + (co - half)];   // r * h
+    } else if (EPI == kEpiBiasRelu) {
+        yout[pix * a.y_pitch + co] = fmaxf(v, 0.f);
+    } else if (EPI == kEpiReluMask) {
+        yout[pix * a.y_pitch + co] = a.aux_in[pix * a.aux_in_pitch + co] > 0.f ? v : 0.f;
     } else if (EPI == kEpiGruQ) {
         const float q = tanh_f(v);
         const float z = a.aux_in[pix * a.aux_in_pitch + co];

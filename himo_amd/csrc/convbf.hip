@@ -259,6 +259,8 @@ static void launch_bf_epi(const ConvArgs& a, int epi, const unsigned short* w, d
         case kEpiBiasBnGelu: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBiasBnGelu, MI>), grid, dim3(256), 0, s, a, w); break;
         case kEpiBiasGelu: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBiasGelu, MI>), grid, dim3(256), 0, s, a, w); break;
         case kEpiGruZR: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiGruZR, MI>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBiasRelu: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBiasRelu, MI>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiReluMask: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiReluMask, MI>), grid, dim3(256), 0, s, a, w); break;
         default: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiGruQ, MI>), grid, dim3(256), 0, s, a, w); break;
     }
 }

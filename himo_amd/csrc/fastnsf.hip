@@ -1,0 +1,309 @@
+// fastnsf.hip -- stage a12: device pieces of the optimisation-based scene flow ("fastnsf": a per-scene
+// coordinate MLP fitted by gradient descent on a truncated Chamfer objective).
+//
+// PARITY UNPINNED: the reference only names the method (`python save.py model=fastnsf`, README.md:53; result keys
+// `fastnsf10` / `nsfp`, tools/view_instance.py:155); the implementation is in the absent OpenSceneFlow submodule.
+// Specification: himo_amd/fastnsf.py (this build's own, after the published Neural Scene Flow Prior family);
+// oracle: oracle/fastnsf_oracle.py (PyTorch CPU autograd + Adam).
+//
+// The MLP forward / input-gradient GEMMs run on conv.hip's row GEMM (epilogues BIAS_RELU / RELU_MASK); this file
+// holds what is specific to fitting:
+//   wgrad_partial_kernel   dW = X^T dZ as a split-K matrix product on the float32 matrix cores: every block owns
+//                          256 point rows and accumulates a full Cin x Cout (<= 128 x 128) partial; MFMA A/B
+//                          fragments are read STRAIGHT from global memory -- a fragment is 32 consecutive floats of
+//                          one row, i.e. one coalesced 128-byte access -- so no LDS staging is needed;
+//   wgrad_reduce_kernel    fixed-order sum of the partials (+ the bias gradient = column sums of dZ);
+//   transpose_kernel       W -> W^T for the input-gradient GEMM;
+//   adam_kernel            the optimiser step;
+//   chamfer_trunc_*        the objective and its gradient with respect to the moved points.
+#include "himo_common.h"
+#include <math.h>
+
+namespace himo {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWgRows = 256;     // point rows per block
+
+// partial[b][ci][co] for ci < 128, co < 128 (row-major 128 x 128 per block)
+__global__ __launch_bounds__(256) void wgrad_partial_kernel(int64_t n, const float* __restrict__ X, int x_pitch, int cin,
+                                                           const float* __restrict__ dZ, int z_pitch, int cout,
+                                                           float* __restrict__ partial) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave & 1, wn = wave >> 1;            // wave tile: ci in [64 wm, +64), co in [64 wn, +64)
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t r0 = (int64_t)blockIdx.x * kWgRows;
+    const int64_t r1 = r0 + kWgRows < n ? r0 + kWgRows : n;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    int ci[2], co[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { ci[t] = wm * 64 + t * 32 + li; co[t] = wn * 64 + t * 32 + li; }
+    const bool any_ci = wm * 64 < cin, any_co = wn * 64 < cout;
+    if (any_ci && any_co) {
+#pragma unroll 4
+        for (int64_t r = r0; r < r1; r += 2) {
+            const int64_t row = r + lh;                    // k index of this half-wave
+            const bool ok = row < r1;
+            float af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = (ok && ci[t] < cin) ? X[row * x_pitch + ci[t]] : 0.f;      // A[i = ci][k = row]
+                bf[t] = (ok && co[t] < cout) ? dZ[row * z_pitch + co[t]] : 0.f;    // B[k = row][j = co]
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    float* out = partial + (int64_t)blockIdx.x * 128 * 128;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // ci
+                const int col = wn * 64 + b * 32 + li;                                  // co
+                out[row * 128 + col] = acc[a][b][r];
+            }
+}
+
+// dW[ci][co] = sum_b partial[b][ci][co] in block order (deterministic); one thread per output element
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int n_blocks, int cin, int cout,
+                                                           float* __restrict__ dW) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= cin * cout) return;
+    const int ci = e / cout, co = e % cout;
+    float s = 0.f;
+    for (int b = 0; b < n_blocks; ++b) s += partial[(int64_t)b * 128 * 128 + ci * 128 + co];
+    dW[e] = s;
+}
+
+// bias gradient: column sums of dZ, two stages with fixed order
+__global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t n, const float* __restrict__ dZ, int z_pitch, int cout,
+                                                            float* __restrict__ partial) {
+    // block = 256 rows x (up to 128) columns: thread t sums column (t % 128) over rows of parity (t / 128)
+    const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const int64_t r0 = (int64_t)blockIdx.x * kWgRows;
+    const int64_t r1 = r0 + kWgRows < n ? r0 + kWgRows : n;
+    float s = 0.f;
+    if (col < cout)
+        for (int64_t r = r0 + half; r < r1; r += 2) s += dZ[r * z_pitch + col];
+    __shared__ float sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (half == 0) partial[(int64_t)blockIdx.x * 128 + col] = sh[col] + sh[col + 128];
+}
+
+__global__ __launch_bounds__(128) void colsum_reduce_kernel(const float* __restrict__ partial, int n_blocks, int cout,
+                                                           float* __restrict__ db) {
+    const int col = threadIdx.x;
+    if (col >= cout) return;
+    float s = 0.f;
+    for (int b = 0; b < n_blocks; ++b) s += partial[(int64_t)b * 128 + col];
+    db[col] = s;
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ wt) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows * cols) return;
+    const int r = e / cols, c = e % cols;
+    wt[c * rows + r] = w[e];
+}
+
+// Adam (no weight decay, bias-corrected), torch.optim.Adam's update order
+__global__ __launch_bounds__(256) void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, float lr, float b1, float b2,
+                                                   float eps, float bc1, float bc2_sqrt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+// truncated Chamfer: terms with squared distance above trunc2 are dropped (contribute neither loss nor gradient)
+struct ChamferArgs {
+    int n0, n1;
+    const float* moved; const float* pc1;
+    const float* d_a; const int* i_a;      // moved -> pc1
+    const float* d_b; const int* i_b;      // pc1 -> moved
+    float trunc2;
+    float* grad;                           // [n0][3] d loss / d moved
+    double* partial;                       // [blocks0 + blocks1]
+};
+
+__device__ inline void block_sum1(double v, double* out) {
+    __shared__ double red[256];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
+__global__ __launch_bounds__(256) void chamfer_trunc_a_kernel(ChamferArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double t = 0.0;
+    if (i < a.n0) {
+        float g[3] = {0.f, 0.f, 0.f};
+        if (a.n1 > 0 && a.d_a[i] <= a.trunc2) {
+            t = (double)a.d_a[i] / (double)a.n0;
+            const int j = a.i_a[i];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[c] = 2.0f / (float)a.n0 * (a.moved[i * 3 + c] - a.pc1[j * 3 + c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.grad[i * 3 + c] = g[c];
+    }
+    block_sum1(t, a.partial + blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void chamfer_trunc_b_kernel(ChamferArgs a, int blocks0) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    double t = 0.0;
+    if (j < a.n1 && a.n0 > 0 && a.d_b[j] <= a.trunc2) {
+        t = (double)a.d_b[j] / (double)a.n1;
+        const int i = a.i_b[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomicAdd(&a.grad[i * 3 + c], 2.0f / (float)a.n1 * (a.moved[i * 3 + c] - a.pc1[j * 3 + c]));
+    }
+    block_sum1(t, a.partial + blocks0 + blockIdx.x);
+}
+
+// p' = R p + t with separately rounded products and sums (the rule of seflow/spec.py step 0); out pitch >= 3, tail zeroed
+__global__ __launch_bounds__(256) void rigid_kernel(int64_t n, const float* __restrict__ p, int stride, const float* __restrict__ T,
+                                                    float* __restrict__ y, int y_pitch) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = p[i * stride], yy = p[i * stride + 1], z = p[i * stride + 2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) y[i * y_pitch + r] = ((x * T[r * 4] + yy * T[r * 4 + 1]) + z * T[r * 4 + 2]) + T[r * 4 + 3];
+    for (int c = 3; c < y_pitch; ++c) y[i * y_pitch + c] = 0.f;
+}
+
+// y[i][c] = a[i][c] + b_scale * b[i][c] for c < cols (b may be null); columns cols..y_pitch-1 are zeroed when zero_tail
+__global__ __launch_bounds__(256) void rows_add_kernel(int64_t n, int cols, const float* __restrict__ a, int a_pitch,
+                                                       const float* __restrict__ b, int b_pitch, float b_scale,
+                                                       float* __restrict__ y, int y_pitch, int zero_tail) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < cols; ++c) y[i * y_pitch + c] = a[i * a_pitch + c] + (b ? b_scale * b[i * b_pitch + c] : 0.f);
+    if (zero_tail)
+        for (int c = cols; c < y_pitch; ++c) y[i * y_pitch + c] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
+    double t = 0.0;
+    for (int b = threadIdx.x; b < n; b += 256) t += partial[b];
+    __shared__ double res;
+    block_sum1(t, &res);
+    if (threadIdx.x == 0) *out = res;
+}
+
+}  // namespace himo
+
+using namespace himo;
+
+extern "C" size_t himo_wgrad_workspace_bytes(int64_t n_rows) {
+    const size_t nb = (size_t)((n_rows + kWgRows - 1) / kWgRows) + 1;
+    return nb * 128 * 128 * 4 + nb * 128 * 4 + 64;
+}
+
+extern "C" int himo_linear_wgrad(int64_t n, const float* d_x, int x_pitch, int cin, const float* d_dz, int z_pitch, int cout,
+                                 float* d_dw, float* d_db, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (n < 1 || cin < 1 || cin > 128 || cout < 1 || cout > 128 || !d_x || !d_dz || !d_dw || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < himo_wgrad_workspace_bytes(n) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)((n + kWgRows - 1) / kWgRows);
+    float* partial = reinterpret_cast<float*>(d_workspace);
+    float* colpart = partial + (size_t)(nb + 1) * 128 * 128;
+    {
+        ProfScope ps("wgrad_partial_kernel", s);
+        hipLaunchKernelGGL(wgrad_partial_kernel, dim3(nb), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch, cout, partial);
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cin * cout + 255) / 256), dim3(256), 0, s, partial, nb, cin, cout, d_dw);
+    if (d_db) {
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, s, n, d_dz, z_pitch, cout, colpart);
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3(1), dim3(128), 0, s, colpart, nb, cout, d_db);
+    }
+    HIMO_LAUNCH_CHECK("wgrad kernels");
+    return HIMO_OK;
+}
+
+extern "C" int himo_transpose(const float* d_w, int rows, int cols, float* d_wt, void* stream) {
+    if (!d_w || !d_wt || rows < 1 || cols < 1) return HIMO_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(transpose_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_w, rows, cols, d_wt);
+    HIMO_LAUNCH_CHECK("transpose_kernel");
+    return HIMO_OK;
+}
+
+extern "C" int himo_adam_step(int64_t n, float* d_param, const float* d_grad, float* d_m, float* d_v, float lr, float beta1,
+                              float beta2, float eps, int step, void* stream) {
+    if (n < 0 || step < 1) return HIMO_ERR_INVALID_ARGUMENT;
+    if (n == 0) return HIMO_OK;
+    if (!d_param || !d_grad || !d_m || !d_v) return HIMO_ERR_INVALID_ARGUMENT;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, d_param, d_grad, d_m,
+                       d_v, lr, beta1, beta2, eps, bc1, sqrtf(bc2));
+    HIMO_LAUNCH_CHECK("adam_kernel");
+    return HIMO_OK;
+}
+
+extern "C" size_t himo_chamfer_trunc_workspace_bytes(int n0, int n1) {
+    return ((size_t)(n0 + 255) / 256 + (size_t)(n1 + 255) / 256 + 2) * 8 + 64;
+}
+
+extern "C" int himo_chamfer_trunc(int n0, int n1, const float* d_moved, const float* d_pc1, const float* d_dist_a,
+                                  const int32_t* d_idx_a, const float* d_dist_b, const int32_t* d_idx_b, float trunc_dist,
+                                  double* d_loss, float* d_grad_moved, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (n0 < 0 || n1 < 0 || !d_loss || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
+    if (n0 > 0 && (!d_moved || !d_grad_moved)) return HIMO_ERR_INVALID_ARGUMENT;
+    if (n0 > 0 && n1 > 0 && (!d_pc1 || !d_dist_a || !d_idx_a || !d_dist_b || !d_idx_b)) return HIMO_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < himo_chamfer_trunc_workspace_bytes(n0, n1)) return HIMO_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    ChamferArgs a{n0, n1, d_moved, d_pc1, d_dist_a, d_idx_a, d_dist_b, d_idx_b, trunc_dist * trunc_dist, d_grad_moved,
+                  reinterpret_cast<double*>(d_workspace)};
+    const int b0 = (n0 + 255) / 256, b1 = (n1 + 255) / 256;
+    if (b0) hipLaunchKernelGGL(chamfer_trunc_a_kernel, dim3(b0), dim3(256), 0, s, a);
+    if (b1) hipLaunchKernelGGL(chamfer_trunc_b_kernel, dim3(b1), dim3(256), 0, s, a, b0);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, a.partial, b0 + b1, d_loss);
+    HIMO_LAUNCH_CHECK("chamfer_trunc kernels");
+    return HIMO_OK;
+}
+
+extern "C" int himo_rigid_transform(int64_t n, const float* d_pts, int pc_stride, const float* d_transform, float* d_out,
+                                    int out_pitch, void* stream) {
+    if (n < 0 || pc_stride < 3 || out_pitch < 3) return HIMO_ERR_INVALID_ARGUMENT;
+    if (n == 0) return HIMO_OK;
+    if (!d_pts || !d_transform || !d_out) return HIMO_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(rigid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, d_pts, pc_stride,
+                       d_transform, d_out, out_pitch);
+    HIMO_LAUNCH_CHECK("rigid_kernel");
+    return HIMO_OK;
+}
+
+extern "C" int himo_rows_add(int64_t n, int cols, const float* d_a, int a_pitch, const float* d_b, int b_pitch, float b_scale,
+                             float* d_y, int y_pitch, int zero_tail, void* stream) {
+    if (n < 0 || cols < 1 || a_pitch < cols || y_pitch < cols || (d_b && b_pitch < cols)) return HIMO_ERR_INVALID_ARGUMENT;
+    if (n == 0) return HIMO_OK;
+    if (!d_a || !d_y) return HIMO_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(rows_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, cols, d_a, a_pitch,
+                       d_b, b_pitch, b_scale, d_y, y_pitch, zero_tail);
+    HIMO_LAUNCH_CHECK("rows_add_kernel");
+    return HIMO_OK;
+}

@@ -1,0 +1,180 @@
+"""Stage a12: optimisation-based scene flow ("fastnsf"): a per-scene coordinate MLP fitted at run time.
+
+PARITY UNPINNED.  The reference only names the method (``python save.py model=fastnsf``, README.md:53; result keys
+``fastnsf10`` / ``nsfp`` at tools/view_instance.py:155); its implementation is in the absent OpenSceneFlow submodule.
+This build's own specification, after the published Neural Scene Flow Prior family:
+
+  * flow field  f_theta: R^3 -> R^3, an MLP 3 -> 128 (x8 hidden layers, ReLU) -> 3, weights U(-1/sqrt(fan_in), ..);
+  * pc0 is first brought into pc1's frame (p' = R p + t with inv(pose1) @ pose0, float32 -- as seflow/spec.py step 0);
+  * objective   L = mean_i [d_i <= tau^2] d_i + mean_j [e_j <= tau^2] e_j, with d_i the squared distance from
+                p'_i + f(p'_i) to its nearest pc1 point, e_j the squared distance from pc1_j to its nearest moved
+                point, tau = 2 m; correspondences are exact (csrc/nngrid.hip) and constant within an iteration;
+  * optimiser   Adam(lr 1e-3, betas (0.9, 0.999), eps 1e-8), ``iters`` steps, optional early stop on the loss;
+  * output      (N,3) float32 flow INCLUDING ego motion, row-aligned with pc0 -- the h5 ``<res_name>`` payload.
+
+Everything that touches point data runs in HIP: the forward / input-gradient products on the matrix cores
+(csrc/conv.hip row GEMM with BIAS_RELU / RELU_MASK epilogues), the weight gradients as a split-K MFMA product
+(csrc/fastnsf.hip), the objective, Adam.  Python sequences launches and owns no arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .seflow.model import ConvDesc
+from .ssl_loss import GRID_CELL, GRID_H, GRID_W, GRID_X0, GRID_Y0
+
+EPI_BIAS, EPI_BIAS_RELU, EPI_RELU_MASK = 0, 5, 6
+HIDDEN, N_HIDDEN, TRUNC = 128, 8, 2.0
+
+_lib.register({
+    "himo_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64]),
+    "himo_linear_wgrad": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "himo_transpose": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "himo_adam_step": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
+                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]),
+    "himo_chamfer_trunc_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "himo_chamfer_trunc": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "himo_rows_add": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                     ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "himo_rigid_transform": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_int, ctypes.c_void_p]),
+})
+
+
+def init_mlp(seed: int = 0) -> list:
+    """[(W [in,out], b [out])] float32 numpy, torch.nn.Linear's default init; in/out of the first/last layer are 3."""
+    rng = np.random.default_rng(seed)
+    dims = [3] + [HIDDEN] * N_HIDDEN + [3]
+    out = []
+    for cin, cout in zip(dims[:-1], dims[1:]):
+        bound = 1.0 / math.sqrt(cin)
+        out.append((rng.uniform(-bound, bound, (cin, cout)).astype(np.float32), rng.uniform(-bound, bound, cout).astype(np.float32)))
+    return out
+
+
+class FastNSF:
+    def __init__(self, device=None, lr: float = 1e-3, iters: int = 100, seed: int = 0, trunc: float = TRUNC,
+                 early_patience: int = 0, early_min_delta: float = 1e-4):
+        self.lib = _lib.load()
+        self.device = device if device is not None else _lib.require_gpu()
+        self.lr, self.iters, self.seed, self.trunc = lr, iters, seed, trunc
+        self.early_patience, self.early_min_delta = early_patience, early_min_delta
+        self.loss_history = []
+
+    # ---- parameters: stored padded to multiples of 4 channels (3 -> 4) -----------------------------------------------
+    def _load(self, layers):
+        dev = self.device
+        self.W, self.b, self.Wt = [], [], []
+        for k, (w, b) in enumerate(layers):
+            cin, cout = w.shape
+            pin, pout = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
+            wp = np.zeros((pin, pout), np.float32); wp[:cin, :cout] = w
+            bp = np.zeros(pout, np.float32); bp[:cout] = b
+            self.W.append(torch.from_numpy(wp).to(dev)); self.b.append(torch.from_numpy(bp).to(dev))
+            self.Wt.append(torch.empty((pout, pin), dtype=torch.float32, device=dev))
+        z = lambda t: torch.zeros_like(t)
+        self.gW, self.gb = [z(w) for w in self.W], [z(b) for b in self.b]
+        self.mW, self.vW = [z(w) for w in self.W], [z(w) for w in self.W]
+        self.mb, self.vb = [z(b) for b in self.b], [z(b) for b in self.b]
+
+    def _gemm(self, x, w, bias, y, n, cin, cout, epi, aux=None):
+        d = ConvDesc()
+        d.x = x.data_ptr(); d.x_batch_stride = 0; d.x_pitch = x.shape[1]
+        d.w = w.data_ptr(); d.bias = None if bias is None else bias.data_ptr()
+        d.y = y.data_ptr(); d.y_batch_stride = 0; d.y_pitch = y.shape[1]
+        d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = 1, 1, n, cin, cout, 1, 1, epi
+        if aux is not None:
+            d.aux_in = aux.data_ptr(); d.aux_in_pitch = aux.shape[1]
+        _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), "himo_conv2d(mlp)")
+
+    def _forward(self, n):
+        L = len(self.W)
+        for k in range(L):
+            x = self.X0 if k == 0 else self.H[k - 1]
+            y = self.OUT if k == L - 1 else self.H[k]
+            self._gemm(x, self.W[k], self.b[k], y, n, self.W[k].shape[0], self.W[k].shape[1], EPI_BIAS if k == L - 1 else EPI_BIAS_RELU)
+
+    def fit(self, pc0, pc1, pose0=None, pose1=None, layers=None) -> torch.Tensor:
+        """-> (N0,3) float32 device tensor: flow of every pc0 row including ego motion."""
+        lib, dev, s = self.lib, self.device, _lib.stream_handle
+        up = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(dev, torch.float32)
+        p0_raw, p1 = up(pc0)[:, :3].contiguous(), up(pc1)[:, :3].contiguous()
+        n, n1 = p0_raw.shape[0], p1.shape[0]
+        # ego transform (host 4x4, float32 like seflow/spec.py step 0), applied by the pillar front end's rule
+        T = np.eye(4) if pose0 is None else np.linalg.inv(np.asarray(pose1, np.float64)) @ np.asarray(pose0, np.float64)
+        T32 = torch.from_numpy(np.ascontiguousarray(T, dtype=np.float32)).to(dev)
+        self.X0 = torch.empty((n, 4), dtype=torch.float32, device=dev)                          # [x', y', z', 0]
+        _lib.check(lib.himo_rigid_transform(n, p0_raw.data_ptr(), 3, T32.data_ptr(), self.X0.data_ptr(), 4, s()), "rigid")
+        self._load(init_mlp(self.seed) if layers is None else layers)
+        buf = lambda c: torch.empty((n, c), dtype=torch.float32, device=dev)
+        self.H = [buf(HIDDEN) for _ in range(N_HIDDEN)]
+        self.dH = [buf(HIDDEN) for _ in range(2)]
+        self.OUT, self.dOUT = buf(4), buf(4)
+        moved, gmoved = torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty((n, 3), dtype=torch.float32, device=dev)
+        d_a, i_a = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
+        d_b, i_b = torch.empty(n1, dtype=torch.float32, device=dev), torch.empty(n1, dtype=torch.int32, device=dev)
+        nn_ws = torch.empty(int(lib.himo_nn_grid_workspace_bytes(max(n, n1), GRID_W, GRID_H)), dtype=torch.uint8, device=dev)
+        ch_ws = torch.empty(int(lib.himo_chamfer_trunc_workspace_bytes(n, n1)), dtype=torch.uint8, device=dev)
+        wg_ws = torch.empty(int(lib.himo_wgrad_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.loss_history, best, stale = [], float("inf"), 0
+        L = len(self.W)
+
+        def nn(q, nq, r, nr, d, i):
+            _lib.check(lib.himo_nn_grid(nq, q.data_ptr(), nr, r.data_ptr(), GRID_X0, GRID_Y0, GRID_CELL, GRID_W, GRID_H, d.data_ptr(),
+                                        i.data_ptr(), nn_ws.data_ptr(), nn_ws.numel(), s()), "himo_nn_grid")
+
+        for it in range(1, self.iters + 1):
+            self._forward(n)
+            _lib.check(lib.himo_rows_add(n, 3, self.X0.data_ptr(), 4, self.OUT.data_ptr(), 4, 1.0, moved.data_ptr(), 3, 0, s()), "rows_add")
+            nn(moved, n, p1, n1, d_a, i_a)
+            nn(p1, n1, moved, n, d_b, i_b)
+            _lib.check(lib.himo_chamfer_trunc(n, n1, moved.data_ptr(), p1.data_ptr(), d_a.data_ptr(), i_a.data_ptr(), d_b.data_ptr(),
+                                              i_b.data_ptr(), self.trunc, loss.data_ptr(), gmoved.data_ptr(), ch_ws.data_ptr(),
+                                              ch_ws.numel(), s()), "himo_chamfer_trunc")
+            _lib.check(lib.himo_rows_add(n, 3, gmoved.data_ptr(), 3, None, 0, 0.0, self.dOUT.data_ptr(), 4, 1, s()), "rows_add")
+            # backward: dZ_k is the gradient at layer k's output (post-mask for hidden layers)
+            dz = self.dOUT
+            for k in range(L - 1, -1, -1):
+                xk = self.X0 if k == 0 else self.H[k - 1]
+                cin, cout = self.W[k].shape
+                _lib.check(lib.himo_linear_wgrad(n, xk.data_ptr(), xk.shape[1], cin, dz.data_ptr(), dz.shape[1], cout,
+                                                 self.gW[k].data_ptr(), self.gb[k].data_ptr(), wg_ws.data_ptr(), wg_ws.numel(), s()), "wgrad")
+                if k > 0:
+                    _lib.check(lib.himo_transpose(self.W[k].data_ptr(), cin, cout, self.Wt[k].data_ptr(), s()), "transpose")
+                    nxt = self.dH[k % 2]
+                    self._gemm(dz, self.Wt[k], None, nxt, n, cout, cin, EPI_RELU_MASK, aux=self.H[k - 1])
+                    dz = nxt
+            for k in range(L):
+                for p, g, m, v in ((self.W[k], self.gW[k], self.mW[k], self.vW[k]), (self.b[k], self.gb[k], self.mb[k], self.vb[k])):
+                    _lib.check(lib.himo_adam_step(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), self.lr, 0.9, 0.999,
+                                                  1e-8, it, s()), "adam")
+            if self.early_patience > 0 or it == self.iters or it <= 3:
+                lv = float(loss.item())
+                self.loss_history.append((it, lv))
+                if self.early_patience > 0:
+                    if lv < best - self.early_min_delta:
+                        best, stale = lv, 0
+                    else:
+                        stale += 1
+                        if stale >= self.early_patience:
+                            break
+        self._forward(n)
+        flow = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        # flow incl. ego motion = (p' + f(p')) - p
+        _lib.check(lib.himo_rows_add(n, 3, self.X0.data_ptr(), 4, self.OUT.data_ptr(), 4, 1.0, moved.data_ptr(), 3, 0, s()), "rows_add")
+        _lib.check(lib.himo_rows_add(n, 3, moved.data_ptr(), 3, p0_raw.data_ptr(), 3, -1.0, flow.data_ptr(), 3, 0, s()), "rows_add")
+        return flow
+
+    def layers(self) -> list:
+        """Current parameters as [(W [in,out], b [out])] numpy with the padding removed."""
+        dims = [3] + [HIDDEN] * N_HIDDEN + [3]
+        return [(w.cpu().numpy()[:ci, :co].copy(), b.cpu().numpy()[:co].copy()) for w, b, ci, co in zip(self.W, self.b, dims[:-1], dims[1:])]

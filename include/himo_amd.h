@@ -214,6 +214,8 @@ int himo_pillarize(int64_t n, const float* d_pts, int pc_stride, const float* h_
 #define HIMO_EPI_BIAS_GELU 2     /* y = gelu(acc + bias) */
 #define HIMO_EPI_GRU_ZR 3        /* cols [0,C/2): y = sigmoid(.) (z); cols [C/2,C): aux_out = sigmoid(.) * aux_in (r*h) */
 #define HIMO_EPI_GRU_Q 4         /* aux_out = (1 - aux_in) * aux_out + aux_in * tanh(acc + bias)   (aux_in = z, aux_out = h) */
+#define HIMO_EPI_BIAS_RELU 5     /* y = max(acc + bias, 0) */
+#define HIMO_EPI_RELU_MASK 6     /* y = aux_in > 0 ? acc : 0   (bias ignored: pass NULL) */
 typedef struct himo_conv_desc {
     const float* x; int64_t x_batch_stride; int x_pitch;   /* input  (device) */
     const float* w;                                        /* [ksize][ksize][cin][cout] (device) */
@@ -267,6 +269,33 @@ int himo_ssl_loss(int n0, int n1, const float* d_pc0, const float* d_pc1, const 
                   const int32_t* d_label0, const int32_t* d_label1, int n_labels,
                   float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
                   double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a12: optimisation-based scene flow ("fastnsf", README.md:53).  Reference implementation absent (OpenSceneFlow
+ * submodule); specification in himo_amd/fastnsf.py.  The MLP forward / input-gradient products use himo_conv2d
+ * (ksize 1) with HIMO_EPI_BIAS_RELU / HIMO_EPI_RELU_MASK; these are the fitting-specific pieces.
+ */
+/* dW[cin][cout] = X^T dZ and (optionally) db[cout] = column sums of dZ over n rows; cin, cout <= 128 */
+size_t himo_wgrad_workspace_bytes(int64_t n_rows);
+int himo_linear_wgrad(int64_t n, const float* d_x, int x_pitch, int cin, const float* d_dz, int z_pitch, int cout,
+                      float* d_dw, float* d_db, void* d_workspace, size_t workspace_bytes, void* stream);
+int himo_transpose(const float* d_w, int rows, int cols, float* d_wt, void* stream);
+/* torch.optim.Adam semantics (no weight decay, no amsgrad); step counts from 1 */
+int himo_adam_step(int64_t n, float* d_param, const float* d_grad, float* d_m, float* d_v, float lr, float beta1,
+                   float beta2, float eps, int step, void* stream);
+/* loss = mean_i [d_a_i <= trunc^2] d_a_i + mean_j [d_b_j <= trunc^2] d_b_j on squared NN distances (from himo_nn_grid),
+ * and d loss / d moved (correspondences constant) */
+size_t himo_chamfer_trunc_workspace_bytes(int n0, int n1);
+int himo_chamfer_trunc(int n0, int n1, const float* d_moved, const float* d_pc1, const float* d_dist_a,
+                       const int32_t* d_idx_a, const float* d_dist_b, const int32_t* d_idx_b, float trunc_dist,
+                       double* d_loss, float* d_grad_moved, void* d_workspace, size_t workspace_bytes, void* stream);
+/* y[i][c] = a[i][c] + b_scale * b[i][c] for c < cols (b may be NULL); zero_tail clears y's columns cols..y_pitch-1 */
+int himo_rows_add(int64_t n, int cols, const float* d_a, int a_pitch, const float* d_b, int b_pitch, float b_scale,
+                  float* d_y, int y_pitch, int zero_tail, void* stream);
+/* out[i][0:3] = R p_i + t with d_transform a DEVICE row-major 4x4 float32 (rounding as seflow/spec.py step 0); the rest
+ * of each out row (out_pitch floats) is zeroed */
+int himo_rigid_transform(int64_t n, const float* d_pts, int pc_stride, const float* d_transform, float* d_out,
+                         int out_pitch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a9 helper (host memory, no GPU): LZ4-frame decoder for the compressed buffers of Feather V2 files as pandas /

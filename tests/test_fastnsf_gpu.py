@@ -1,0 +1,96 @@
+"""GPU parity of a12 (per-scene coordinate-MLP fit) against the CPU restatement.  PARITY UNPINNED (own spec)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(seed, n0, n1):
+    rng = np.random.default_rng(seed)
+    pc1 = rng.uniform([-40, -40, -2], [40, 40, 2], (n1, 3)).astype(np.float32)
+    k = min(n0, n1)
+    pc0 = np.empty((n0, 3), np.float32)
+    pc0[:k] = pc1[:k] - np.array([0.6, 0.2, 0.0], np.float32) + rng.normal(0, 0.02, (k, 3)).astype(np.float32)
+    if n0 > k:
+        pc0[k:] = rng.uniform([-40, -40, -2], [40, 40, 2], (n0 - k, 3)).astype(np.float32)
+    return pc0, pc1
+
+
+def test_wgrad_and_masked_dgrad_kernels(gpu):
+    """The two backward products against torch on the same device-independent data."""
+    import ctypes
+    from himo_amd import _lib
+    from himo_amd.fastnsf import FastNSF
+    lib = _lib.load()
+    eng = FastNSF(device=gpu)
+    rng = np.random.default_rng(0)
+    n = 5000
+    for cin, cout in [(128, 128), (4, 128), (128, 4)]:
+        x = torch.from_numpy(rng.normal(size=(n, cin)).astype(np.float32)).to(gpu)
+        dz = torch.from_numpy(rng.normal(size=(n, cout)).astype(np.float32)).to(gpu)
+        dw = torch.empty((cin, cout), dtype=torch.float32, device=gpu)
+        db = torch.empty(cout, dtype=torch.float32, device=gpu)
+        ws = torch.empty(int(lib.himo_wgrad_workspace_bytes(n)), dtype=torch.uint8, device=gpu)
+        _lib.check(lib.himo_linear_wgrad(n, x.data_ptr(), cin, cin, dz.data_ptr(), cout, cout, dw.data_ptr(), db.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _lib.stream_handle()))
+        ref_dw = (x.double().T @ dz.double()).float()
+        assert (dw - ref_dw).abs().max().item() <= 2e-3 * ref_dw.abs().max().item()
+        assert (db - dz.double().sum(0).float()).abs().max().item() <= 1e-3 * n ** 0.5
+    w = torch.from_numpy(rng.normal(size=(128, 128)).astype(np.float32) * 0.1).to(gpu)
+    act = torch.relu(torch.from_numpy(rng.normal(size=(n, 128)).astype(np.float32)).to(gpu))
+    dz = torch.from_numpy(rng.normal(size=(n, 128)).astype(np.float32)).to(gpu)
+    wt, out = torch.empty_like(w), torch.empty_like(act)
+    _lib.check(lib.himo_transpose(w.data_ptr(), 128, 128, wt.data_ptr(), _lib.stream_handle()))
+    assert torch.equal(wt, w.T.contiguous())
+    eng._gemm(dz, wt, None, out, n, 128, 128, 6, aux=act)
+    ref = (dz @ w.T) * (act > 0)
+    assert (out - ref).abs().max().item() <= 1e-4
+
+
+def test_single_step_gradients_match_autograd(gpu):
+    import fastnsf_oracle as fo
+    from himo_amd.fastnsf import FastNSF, init_mlp
+    pc0, pc1 = _scene(1, 6000, 5500)
+    layers = init_mlp(3)
+    eng = FastNSF(device=gpu, iters=1, lr=0.0, seed=3)
+    eng.fit(pc0, pc1, layers=layers)
+    ref_loss, ref_grads, _ = fo.loss_and_grads(layers, pc0, pc1)
+    assert eng.loss_history[0][1] == pytest.approx(ref_loss, rel=1e-5)
+    for k, (gw, gb) in enumerate(ref_grads):
+        cin, cout = gw.shape
+        got_w, got_b = eng.gW[k].cpu().numpy()[:cin, :cout], eng.gb[k].cpu().numpy()[:cout]
+        scale = max(np.abs(gw).max(), 1e-8)
+        assert np.abs(got_w - gw).max() <= 2e-4 * scale, k
+        assert np.abs(got_b - gb).max() <= 2e-4 * max(np.abs(gb).max(), 1e-8), k
+
+
+def test_fit_follows_the_cpu_restatement_and_recovers_the_motion(gpu):
+    import fastnsf_oracle as fo
+    from himo_amd.fastnsf import FastNSF, init_mlp
+    pc0, pc1 = _scene(2, 8000, 8000)
+    layers = init_mlp(5)
+    iters = 25
+    eng = FastNSF(device=gpu, iters=iters, lr=1e-3, early_patience=10_000)     # patience on => loss logged every step
+    flow = eng.fit(pc0, pc1, layers=layers).cpu().numpy()
+    hist, ref_flow = fo.fit(layers, pc0, pc1, iters)
+    got_hist = [v for _, v in eng.loss_history]
+    assert len(got_hist) == iters
+    for a, b in zip(got_hist[:10], hist[:10]):
+        assert a == pytest.approx(b, rel=2e-3)                 # trajectories diverge slowly (different rounding), so early steps
+    assert got_hist[-1] < 0.5 * got_hist[0] and hist[-1] < 0.5 * hist[0]
+    assert got_hist[-1] == pytest.approx(hist[-1], rel=0.1)
+    # identity poses: flow == network output; it should already point along the true translation (0.6, 0.2, 0)
+    assert np.abs(np.median(flow, axis=0) - np.median(ref_flow, axis=0)).max() < 0.05
+
+
+def test_flow_includes_ego_motion(gpu):
+    from himo_amd.fastnsf import FastNSF
+    pc0, pc1 = _scene(4, 3000, 3000)
+    pose0, pose1 = np.eye(4), np.eye(4)
+    pose1[0, 3] = 1.5                                          # ego moved 1.5 m forward between the sweeps
+    eng = FastNSF(device=gpu, iters=0)
+    flow = eng.fit(pc0, pc1, pose0, pose1).cpu().numpy()
+    # with 0 iterations the MLP output is small but non-zero; flow - f(p') must be the pose flow (-1.5, 0, 0)
+    f = eng.OUT[:, :3].cpu().numpy()
+    assert np.abs((flow - f) - np.array([-1.5, 0, 0], np.float32)).max() < 1e-5
