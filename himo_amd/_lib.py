@@ -36,6 +36,7 @@ SIGNATURES = {
     "himo_lz4_frame_decompress": (c_int64, [c_void_p, c_int64, c_void_p, c_int64]),
     "himo_nn_search": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p,
                                c_void_p, c_void_p]),
+    "himo_sqrt_inplace": (c_int, [c_int64, c_void_p, c_int, c_void_p]),
     "himo_eval_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64]),
     "himo_eval_instances": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(ctypes.c_uint8), c_double,

@@ -179,9 +179,26 @@ int nn_search_ranges(int64_t nq, int64_t nr, const void* q, const void* r, const
     return f64 ? launch_nn<double>(a, s) : launch_nn<float>(a, s);
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void sqrt_kernel(int64_t n, T* __restrict__ v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = sqrt(v[i]);          // correctly rounded in both precisions (cKDTree returns sqrt of the minimum)
+}
+
 }  // namespace himo
 
 using namespace himo;
+
+extern "C" int himo_sqrt_inplace(int64_t n, void* d_values, int dtype_is_f64, void* stream) {
+    if (n < 0) return HIMO_ERR_INVALID_ARGUMENT;
+    if (n == 0) return HIMO_OK;
+    if (!d_values) return HIMO_ERR_INVALID_ARGUMENT;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (dtype_is_f64) hipLaunchKernelGGL(sqrt_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, n, (double*)d_values);
+    else hipLaunchKernelGGL(sqrt_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, n, (float*)d_values);
+    HIMO_LAUNCH_CHECK("sqrt_kernel");
+    return HIMO_OK;
+}
 
 extern "C" int himo_nn_search(int n_segments, const int64_t* d_q_offsets, const int64_t* d_r_offsets, int64_t nq,
                               int64_t nr, const void* d_q, const void* d_r, int dtype_is_f64, void* d_dist2,

@@ -349,7 +349,8 @@ def nearest_neighbor(query, ref, return_index: bool = True):
     ro = torch.tensor([0, nr], dtype=torch.int64, device=dev)
     _lib.check(lib.himo_nn_search(1, _lib.ptr(qo), _lib.ptr(ro), nq, nr, _lib.ptr(q), _lib.ptr(r), 1 if f64 else 0,
                                   _lib.ptr(d2), _lib.ptr(idx), _lib.stream_handle()), "himo_nn_search")
-    d = torch.sqrt(d2)
+    _lib.check(lib.himo_sqrt_inplace(nq, _lib.ptr(d2), 1 if f64 else 0, _lib.stream_handle()), "himo_sqrt_inplace")
+    d = d2
     if isinstance(query, torch.Tensor):
         return (d, idx) if return_index else d
     return (d.cpu().numpy(), idx.cpu().numpy()) if return_index else d.cpu().numpy()

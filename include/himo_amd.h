@@ -140,6 +140,8 @@ int himo_dt0(int64_t n, const float* d_lidar_dt, float* d_dt0, void* d_workspace
 int himo_nn_search(int n_segments, const int64_t* d_q_offsets, const int64_t* d_r_offsets,
                    int64_t nq, int64_t nr, const void* d_q, const void* d_r, int dtype_is_f64,
                    void* d_dist2, int32_t* d_idx, void* stream);
+/* squared distances -> distances, in place (the sqrt cKDTree applies to the winning squared distance) */
+int himo_sqrt_inplace(int64_t n, void* d_values, int dtype_is_f64, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a7 + a8: per-instance refinement metrics for a ragged batch of sweeps.
