@@ -184,8 +184,8 @@ def reduce_job(elapsed: float, frames_done: int, device, world: int, rank: int):
     done = torch.tensor([frames_done], device=device, dtype=torch.int64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        gathered = [torch.zeros_like(done) for _ in range(world)] if rank == 0 else None
-        dist.gather(done, gathered, dst=0)
+        gathered = [torch.zeros_like(done) for _ in range(world)]
+        dist.all_gather(gathered, done)                 # every backend implements all_gather; rank 0 reports
         total = int(sum(int(g.item()) for g in gathered)) if rank == 0 else 0
     else:
         total = int(done.item())
@@ -206,6 +206,7 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver
         dist.init_process_group("nccl", device_id=device)
 
     from himo_amd import _lib
