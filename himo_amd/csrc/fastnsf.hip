@@ -25,13 +25,16 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWgRows = 256;     // point rows per block
 
-// partial[b][ci][co] for ci < 128, co < 128 (row-major 128 x 128 per block)
+// partial[tile][b][128][128]: tile = (ci tile, co tile) = blockIdx.y, b = row chunk = blockIdx.x
 __global__ __launch_bounds__(256) void wgrad_partial_kernel(int64_t n, const float* __restrict__ X, int x_pitch, int cin,
                                                            const float* __restrict__ dZ, int z_pitch, int cout,
                                                            float* __restrict__ partial) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = wave & 1, wn = wave >> 1;            // wave tile: ci in [64 wm, +64), co in [64 wn, +64)
     const int li = lane & 31, lh = lane >> 5;
+    const int co_tiles = (cout + 127) / 128;
+    const int ci0 = ((int)blockIdx.y / co_tiles) * 128, co0 = ((int)blockIdx.y % co_tiles) * 128;
+    X += ci0; dZ += co0; cin -= ci0; cout -= co0;       // this block's 128 x 128 window
     const int64_t r0 = (int64_t)blockIdx.x * kWgRows;
     const int64_t r1 = r0 + kWgRows < n ? r0 + kWgRows : n;
     floatx16 acc[2][2];
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(int64_t n, const flo
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
         }
     }
-    float* out = partial + (int64_t)blockIdx.x * 128 * 128;
+    float* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 * 128;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -76,22 +79,24 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(int64_t n, const flo
             }
 }
 
-// dW[ci][co] = sum_b partial[b][ci][co] in block order (deterministic); one thread per output element
+// dW[ci][co] (+)= sum_b partial[tile][b][ci % 128][co % 128] in chunk order (deterministic); one thread per element
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int n_blocks, int cin, int cout,
-                                                           float* __restrict__ dW) {
+                                                           float* __restrict__ dW, int accumulate) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= cin * cout) return;
     const int ci = e / cout, co = e % cout;
+    const int tile = (ci / 128) * ((cout + 127) / 128) + co / 128;
+    const float* p = partial + (int64_t)tile * n_blocks * 128 * 128 + (ci % 128) * 128 + (co % 128);
     float s = 0.f;
-    for (int b = 0; b < n_blocks; ++b) s += partial[(int64_t)b * 128 * 128 + ci * 128 + co];
-    dW[e] = s;
+    for (int b = 0; b < n_blocks; ++b) s += p[(int64_t)b * 128 * 128];
+    dW[e] = accumulate ? dW[e] + s : s;
 }
 
 // bias gradient: column sums of dZ, two stages with fixed order
 __global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t n, const float* __restrict__ dZ, int z_pitch, int cout,
                                                             float* __restrict__ partial) {
-    // block = 256 rows x (up to 128) columns: thread t sums column (t % 128) over rows of parity (t / 128)
-    const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
+    // block = 256 rows x 128 columns (column tile blockIdx.y): thread t sums column (t % 128) over rows of parity (t / 128)
+    const int col = (int)blockIdx.y * 128 + (threadIdx.x & 127), half = threadIdx.x >> 7;
     const int64_t r0 = (int64_t)blockIdx.x * kWgRows;
     const int64_t r1 = r0 + kWgRows < n ? r0 + kWgRows : n;
     float s = 0.f;
@@ -100,16 +105,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t n, const fl
     __shared__ float sh[256];
     sh[threadIdx.x] = s;
     __syncthreads();
-    if (half == 0) partial[(int64_t)blockIdx.x * 128 + col] = sh[col] + sh[col + 128];
+    const int lc = threadIdx.x & 127;
+    if (half == 0) partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 + lc] = sh[lc] + sh[lc + 128];
 }
 
 __global__ __launch_bounds__(128) void colsum_reduce_kernel(const float* __restrict__ partial, int n_blocks, int cout,
-                                                           float* __restrict__ db) {
-    const int col = threadIdx.x;
+                                                           float* __restrict__ db, int accumulate) {
+    const int col = (int)blockIdx.x * 128 + threadIdx.x;
     if (col >= cout) return;
     float s = 0.f;
-    for (int b = 0; b < n_blocks; ++b) s += partial[(int64_t)b * 128 + col];
-    db[col] = s;
+    for (int b = 0; b < n_blocks; ++b) s += partial[((int64_t)blockIdx.x * n_blocks + b) * 128 + threadIdx.x];
+    db[col] = accumulate ? db[col] + s : s;
 }
 
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ wt) {
@@ -218,30 +224,43 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 
 using namespace himo;
 
-extern "C" size_t himo_wgrad_workspace_bytes(int64_t n_rows) {
+static size_t wgrad_ws(int64_t n_rows, int cin, int cout) {
     const size_t nb = (size_t)((n_rows + kWgRows - 1) / kWgRows) + 1;
-    return nb * 128 * 128 * 4 + nb * 128 * 4 + 64;
+    const size_t tiles = (size_t)((cin + 127) / 128) * ((cout + 127) / 128), ctiles = (size_t)(cout + 127) / 128;
+    return tiles * nb * 128 * 128 * 4 + ctiles * nb * 128 * 4 + 64;
+}
+
+extern "C" size_t himo_wgrad_workspace_bytes(int64_t n_rows) { return wgrad_ws(n_rows, 128, 128); }
+extern "C" size_t himo_wgrad_workspace_bytes_ex(int64_t n_rows, int cin, int cout) { return wgrad_ws(n_rows, cin, cout); }
+
+// flags bit 0: accumulate into dW / db instead of overwriting
+extern "C" int himo_linear_wgrad_ex(int64_t n, const float* d_x, int x_pitch, int cin, const float* d_dz, int z_pitch, int cout,
+                                    float* d_dw, float* d_db, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (n < 1 || cin < 1 || cout < 1 || !d_x || !d_dz || !d_dw || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < wgrad_ws(n, cin, cout) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)((n + kWgRows - 1) / kWgRows);
+    const int ci_tiles = (cin + 127) / 128, co_tiles = (cout + 127) / 128;
+    float* partial = reinterpret_cast<float*>(d_workspace);
+    float* colpart = partial + (size_t)ci_tiles * co_tiles * (nb + 1) * 128 * 128;
+    const int acc = (flags & 1u) ? 1 : 0;
+    {
+        ProfScope ps("wgrad_partial_kernel", s);
+        hipLaunchKernelGGL(wgrad_partial_kernel, dim3(nb, ci_tiles * co_tiles), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch, cout, partial);
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cin * cout + 255) / 256), dim3(256), 0, s, partial, nb, cin, cout, d_dw, acc);
+    if (d_db) {
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, co_tiles), dim3(256), 0, s, n, d_dz, z_pitch, cout, colpart);
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3(co_tiles), dim3(128), 0, s, colpart, nb, cout, d_db, acc);
+    }
+    HIMO_LAUNCH_CHECK("wgrad kernels");
+    return HIMO_OK;
 }
 
 extern "C" int himo_linear_wgrad(int64_t n, const float* d_x, int x_pitch, int cin, const float* d_dz, int z_pitch, int cout,
                                  float* d_dw, float* d_db, void* d_workspace, size_t workspace_bytes, void* stream) {
-    if (n < 1 || cin < 1 || cin > 128 || cout < 1 || cout > 128 || !d_x || !d_dz || !d_dw || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
-    if (workspace_bytes < himo_wgrad_workspace_bytes(n) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    const int nb = (int)((n + kWgRows - 1) / kWgRows);
-    float* partial = reinterpret_cast<float*>(d_workspace);
-    float* colpart = partial + (size_t)(nb + 1) * 128 * 128;
-    {
-        ProfScope ps("wgrad_partial_kernel", s);
-        hipLaunchKernelGGL(wgrad_partial_kernel, dim3(nb), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch, cout, partial);
-    }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cin * cout + 255) / 256), dim3(256), 0, s, partial, nb, cin, cout, d_dw);
-    if (d_db) {
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, s, n, d_dz, z_pitch, cout, colpart);
-        hipLaunchKernelGGL(colsum_reduce_kernel, dim3(1), dim3(128), 0, s, colpart, nb, cout, d_db);
-    }
-    HIMO_LAUNCH_CHECK("wgrad kernels");
-    return HIMO_OK;
+    if (cin > 128 || cout > 128) return HIMO_ERR_INVALID_ARGUMENT;
+    return himo_linear_wgrad_ex(n, d_x, x_pitch, cin, d_dz, z_pitch, cout, d_dw, d_db, 0u, d_workspace, workspace_bytes, stream);
 }
 
 extern "C" int himo_transpose(const float* d_w, int rows, int cols, float* d_wt, void* stream) {

@@ -281,6 +281,10 @@ int himo_ssl_loss(int n0, int n1, const float* d_pc0, const float* d_pc1, const 
 size_t himo_wgrad_workspace_bytes(int64_t n_rows);
 int himo_linear_wgrad(int64_t n, const float* d_x, int x_pitch, int cin, const float* d_dz, int z_pitch, int cout,
                       float* d_dw, float* d_db, void* d_workspace, size_t workspace_bytes, void* stream);
+/* the same for any cin / cout (tiled 128 x 128); flags bit 0: accumulate into d_dw / d_db (BPTT over GRU iterations) */
+size_t himo_wgrad_workspace_bytes_ex(int64_t n_rows, int cin, int cout);
+int himo_linear_wgrad_ex(int64_t n, const float* d_x, int x_pitch, int cin, const float* d_dz, int z_pitch, int cout,
+                         float* d_dw, float* d_db, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);
 int himo_transpose(const float* d_w, int rows, int cols, float* d_wt, void* stream);
 /* torch.optim.Adam semantics (no weight decay, no amsgrad); step counts from 1 */
 int himo_adam_step(int64_t n, float* d_param, const float* d_grad, float* d_m, float* d_v, float lr, float beta1,
@@ -298,6 +302,29 @@ int himo_rows_add(int64_t n, int cols, const float* d_a, int a_pitch, const floa
  * of each out row (out_pitch floats) is zeroed */
 int himo_rigid_transform(int64_t n, const float* d_pts, int pc_stride, const float* d_transform, float* d_out,
                          int out_pitch, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a11, training side: element-wise pieces of the network's backward pass (csrc/train.hip).  The reference trains through
+ * the absent OpenSceneFlow/train.py (assets/slurm/ssl-train-av2.sh:31); conventions in himo_amd/seflow/train.py.
+ * Matrix products use himo_conv2d (row GEMM) and himo_linear_wgrad_ex.
+ */
+/* GRU cell, training forward.  which = 1: pre = [az | ar] (n x 256), hx = [h | x] (n x 192) -> z, r (n x 128),
+ * out = [r * h | x].  which = 2: pre = aq (n x 128), z_in, hx -> q (n x 128), out = [(1 - z) h + z q | x]. */
+int himo_gru_gates_fwd(int64_t n, int which, const float* d_pre, const float* d_z_in, const float* d_hx,
+                       float* d_z, float* d_r, float* d_q, float* d_out, void* stream);
+/* GRU cell, backward (three element-wise stages around the two transposed GEMMs; see csrc/train.hip) */
+int himo_gru_bwd1(int64_t n, const float* d_dh_next, const float* d_z, const float* d_q, const float* d_hx,
+                  float* d_daq, float* d_dz, float* d_dhp, void* stream);
+int himo_gru_bwd2(int64_t n, const float* d_d_rhx, const float* d_hx, const float* d_z, const float* d_r,
+                  const float* d_dz, float* d_dhp, float* d_dazr, float* d_dx, void* stream);
+int himo_gru_bwd3(int64_t n, const float* d_d_hx, const float* d_dhp, float* d_dh, float* d_dx, void* stream);
+/* pre = x * scale[c] + shift[c] (scale/shift NULL: identity), y = gelu(pre); and dx = dy * gelu'(pre) * scale[c] */
+int himo_affine_gelu_fwd(int64_t rows, int ch, const float* d_x, int x_pitch, const float* d_scale, const float* d_shift,
+                         float* d_pre, int pre_pitch, float* d_y, int y_pitch, void* stream);
+int himo_affine_gelu_bwd(int64_t rows, int ch, const float* d_dy, int dy_pitch, const float* d_pre, int pre_pitch,
+                         const float* d_scale, float* d_dx, int dx_pitch, void* stream);
+/* zero the rows of v whose cell id is negative */
+int himo_mask_rows(int64_t n, int cols, const int32_t* d_pid, float* d_v, int pitch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a9 helper (host memory, no GPU): LZ4-frame decoder for the compressed buffers of Feather V2 files as pandas /

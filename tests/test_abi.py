@@ -25,6 +25,7 @@ def test_library_exports_every_declared_symbol():
     import himo_amd.seflow.model  # noqa: F401  (registers the network entry points' signatures)
     import himo_amd.ssl_loss  # noqa: F401
     import himo_amd.fastnsf  # noqa: F401
+    import himo_amd.seflow.train  # noqa: F401
     lib = _lib.load()
     raw = ctypes.CDLL(str(_lib.LIB_PATH))
     for name in declared_symbols():
