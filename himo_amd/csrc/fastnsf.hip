@@ -263,6 +263,20 @@ extern "C" int himo_linear_wgrad(int64_t n, const float* d_x, int x_pitch, int c
     return himo_linear_wgrad_ex(n, d_x, x_pitch, cin, d_dz, z_pitch, cout, d_dw, d_db, 0u, d_workspace, workspace_bytes, stream);
 }
 
+// column sums of a pitched [n][cout] matrix (bias gradients); workspace as for himo_linear_wgrad_ex(n, 1, cout)
+extern "C" int himo_colsum(int64_t n, const float* d_z, int z_pitch, int cout, float* d_out, unsigned flags, void* d_workspace,
+                           size_t workspace_bytes, void* stream) {
+    if (n < 1 || cout < 1 || z_pitch < cout || !d_z || !d_out || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
+    const int nb = (int)((n + kWgRows - 1) / kWgRows), co_tiles = (cout + 127) / 128;
+    if (workspace_bytes < (size_t)co_tiles * nb * 128 * 4) return HIMO_ERR_WORKSPACE;
+    float* colpart = reinterpret_cast<float*>(d_workspace);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, co_tiles), dim3(256), 0, s, n, d_z, z_pitch, cout, colpart);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(co_tiles), dim3(128), 0, s, colpart, nb, cout, d_out, (flags & 1u) ? 1 : 0);
+    HIMO_LAUNCH_CHECK("colsum kernels");
+    return HIMO_OK;
+}
+
 extern "C" int himo_transpose(const float* d_w, int rows, int cols, float* d_wt, void* stream) {
     if (!d_w || !d_wt || rows < 1 || cols < 1) return HIMO_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(transpose_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_w, rows, cols, d_wt);

@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarArgs a) {
             int rank = 0;
             for (int k = 0; k < cnt; ++k) rank += s_idx[sub][k] < v;
             s_sorted[sub][rank] = v;
+            a.order2[beg + rank] = v;        // kept for the training backward pass (pfn_backward / scatter kernels)
         }
     if (!staged) {
         // crowded cell (rare: > kMaxStage returns in one 0.2 m pillar): same ranking, through global memory
@@ -205,6 +206,102 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarArgs a) {
         if (c < 3) a.offsets[(int64_t)idx * 3 + c] = f[6 + c];
     }
     out[c] = acc / fc;
+}
+
+// ---- training backward (stage a11) ------------------------------------------------------------------------------
+// Both kernels walk the per-cell point lists the forward pass left in the workspace (cell offsets + order2, the
+// ascending order), so every sum has the forward's fixed order and no float atomics are needed.
+struct PillarBwdArgs {
+    GridSpec g;
+    const int* cell_count; const int* block_sum; const int* order2;
+    const float* xyz_t;
+    const float* pfn_w; const float* pfn_scale; const float* pfn_shift;
+    const float* d_image; int image_pitch;      // gradient w.r.t. this sweep's 32 image channels
+    float* partial;                             // [gridDim.x][9][32]
+    // scatter of the head's per-point gradient
+    const float* dhx; int dhx_pitch;            // [n][>=128]: d/d [img0 | img1 | dec] rows
+    float* d_b0; int b0_pitch; int group0, group1, n_groups;
+    float* d_dec; int dec_pitch;
+};
+
+__device__ inline int cell_offset_b(const PillarBwdArgs& a, int cell) {
+    const int n_cells = a.g.W * a.g.H;
+    return cell >= n_cells ? a.block_sum[(n_cells + kScanBlock - 1) / kScanBlock]
+                           : a.cell_count[cell] + a.block_sum[cell / kScanBlock];
+}
+
+// d loss / d pfn.weight[k][c] = sum over points of f_k * (d_image[cell][c] / cnt) * [v > 0] * scale[c]
+__global__ __launch_bounds__(256) void pfn_backward_kernel(PillarBwdArgs a) {
+    __shared__ float red[kCellsPerBlock][9][32];
+    const int sub = threadIdx.x >> 5, c = threadIdx.x & 31;
+    const int n_cells = a.g.W * a.g.H;
+    float w[9], dw[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { w[k] = a.pfn_w[k * 32 + c]; dw[k] = 0.f; }
+    const float scale = a.pfn_scale[c], shift = a.pfn_shift[c];
+    for (int cell = blockIdx.x * kCellsPerBlock + sub; cell < n_cells; cell += gridDim.x * kCellsPerBlock) {
+        const int beg = cell_offset_b(a, cell);
+        const int cnt = cell_offset_b(a, cell + 1) - beg;
+        if (cnt == 0) continue;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int j = 0; j < cnt; ++j) {
+            const float* p = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
+            sx += p[0]; sy += p[1]; sz += p[2];
+        }
+        const float fc = (float)cnt;
+        const float mx = sx / fc, my = sy / fc, mz = sz / fc;
+        const int iy = cell / a.g.W, ix = cell - iy * a.g.W;
+        const float ccx = (float)ix * a.g.vx + a.g.cx0, ccy = (float)iy * a.g.vy + a.g.cy0, ccz = 0.f * a.g.vz + a.g.cz0;
+        const float g = a.d_image[(int64_t)cell * a.image_pitch + c] / fc * scale;
+        for (int j = 0; j < cnt; ++j) {
+            const float* p = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
+            const float x = p[0], y = p[1], z = p[2];
+            const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
+            float v = f[0] * w[0];
+#pragma unroll
+            for (int k = 1; k < 9; ++k) v = fmaf(f[k], w[k], v);
+            v = v * scale + shift;
+            if (v > 0.f) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) dw[k] += f[k] * g;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[sub][k][c] = dw[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * 32; e += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < kCellsPerBlock; ++q) t += red[q][e / 32][e % 32];
+        a.partial[(int64_t)blockIdx.x * 288 + e] = t;
+    }
+}
+
+__global__ __launch_bounds__(288) void pfn_backward_reduce_kernel(const float* __restrict__ partial, int n_blocks, float* __restrict__ dw,
+                                                                  int accumulate) {
+    float t = 0.f;
+    for (int b = 0; b < n_blocks; ++b) t += partial[(int64_t)b * 288 + threadIdx.x];
+    dw[threadIdx.x] = accumulate ? dw[threadIdx.x] + t : t;
+}
+
+// adjoint of head_gather_kernel: the per-point gradient rows are summed per cell (ascending point order) into the
+// image gradients; the cells of groups that are not gathered from, and empty cells, are written as zeros
+__global__ __launch_bounds__(256) void head_scatter_kernel(PillarBwdArgs a) {
+    const int sub = threadIdx.x >> 5, c = threadIdx.x & 31;
+    const int cell = blockIdx.x * kCellsPerBlock + sub;
+    if (cell >= a.g.W * a.g.H) return;
+    const int beg = cell_offset_b(a, cell);
+    const int cnt = cell_offset_b(a, cell + 1) - beg;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int j = 0; j < cnt; ++j) {
+        const float* r = a.dhx + (int64_t)a.order2[beg + j] * a.dhx_pitch;
+        s0 += r[c]; s1 += r[32 + c]; s2 += r[64 + c]; s3 += r[96 + c];
+    }
+    float* b0 = a.d_b0 + (int64_t)cell * a.b0_pitch;
+    for (int g = 0; g < a.n_groups; ++g) b0[g * 32 + c] = g == a.group0 ? s0 : g == a.group1 ? s1 : 0.f;
+    float* dec = a.d_dec + (int64_t)cell * a.dec_pitch;
+    dec[c] = s2; dec[32 + c] = s3;
 }
 
 }  // namespace himo
@@ -277,5 +374,62 @@ extern "C" int himo_pillarize(int64_t n, const float* d_pts, int pc_stride, cons
         hipLaunchKernelGGL(pillar_feature_kernel, dim3((cells + kCellsPerBlock - 1) / kCellsPerBlock), dim3(256), 0, s, a);
     }
     HIMO_LAUNCH_CHECK("pillar_feature_kernel");
+    return HIMO_OK;
+}
+
+static void carve_bwd(PillarBwdArgs& a, int64_t n, int cells, void* d_workspace) {
+    char* ws = reinterpret_cast<char*>(d_workspace);
+    a.cell_count = reinterpret_cast<const int*>(ws);
+    a.block_sum = reinterpret_cast<const int*>(ws + 2 * ws_cells(cells));
+    a.order2 = reinterpret_cast<const int*>(ws + 2 * ws_cells(cells) + ws_blocks(cells)) + ws_points(n) / 4;
+}
+
+constexpr int kPfnBwdBlocks = 1024;
+
+extern "C" size_t himo_pfn_backward_workspace_bytes(void) { return (size_t)kPfnBwdBlocks * 288 * 4 + 64; }
+
+// d_pillar_workspace: the workspace himo_pillarize(n, ...) of the SAME sweep left behind (cell lists), untouched since
+extern "C" int himo_pfn_backward(int64_t n, const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
+                                 const float* d_pfn_weight, const float* d_pfn_scale, const float* d_pfn_shift,
+                                 const float* d_xyz_t, const void* d_pillar_workspace, const float* d_dimage, int image_pitch,
+                                 float* d_dweight, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || !h_voxel || !h_centre_offset || grid_w < 1 || grid_h < 1 || !d_pfn_weight || !d_pfn_scale || !d_pfn_shift ||
+        !d_pillar_workspace || !d_dimage || !d_dweight || !d_workspace || image_pitch < 32)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    if (n > 0 && !d_xyz_t) return HIMO_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < himo_pfn_backward_workspace_bytes()) return HIMO_ERR_WORKSPACE;
+    PillarBwdArgs a{};
+    a.g.vx = h_voxel[0]; a.g.vy = h_voxel[1]; a.g.vz = h_voxel[2];
+    a.g.cx0 = h_centre_offset[0]; a.g.cy0 = h_centre_offset[1]; a.g.cz0 = h_centre_offset[2];
+    a.g.W = grid_w; a.g.H = grid_h;
+    carve_bwd(a, n, grid_w * grid_h, const_cast<void*>(d_pillar_workspace));
+    a.xyz_t = d_xyz_t; a.pfn_w = d_pfn_weight; a.pfn_scale = d_pfn_scale; a.pfn_shift = d_pfn_shift;
+    a.d_image = d_dimage; a.image_pitch = image_pitch;
+    a.partial = reinterpret_cast<float*>(d_workspace);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        ProfScope ps("pfn_backward_kernel", s);
+        hipLaunchKernelGGL(pfn_backward_kernel, dim3(kPfnBwdBlocks), dim3(256), 0, s, a);
+    }
+    hipLaunchKernelGGL(pfn_backward_reduce_kernel, dim3(1), dim3(288), 0, s, a.partial, kPfnBwdBlocks, d_dweight, (flags & 1u) ? 1 : 0);
+    HIMO_LAUNCH_CHECK("pfn_backward kernels");
+    return HIMO_OK;
+}
+
+extern "C" int himo_head_scatter(int64_t n, int grid_w, int grid_h, const void* d_pillar_workspace, const float* d_dhx, int dhx_pitch,
+                                 float* d_db0, int b0_pitch, int group0, int group1, int n_groups, float* d_ddec, int dec_pitch,
+                                 void* stream) {
+    if (n < 0 || grid_w < 1 || grid_h < 1 || !d_pillar_workspace || !d_db0 || !d_ddec || dhx_pitch < 128 || n_groups < 1 ||
+        b0_pitch < 32 * n_groups || dec_pitch < 64 || (n > 0 && !d_dhx))
+        return HIMO_ERR_INVALID_ARGUMENT;
+    PillarBwdArgs a{};
+    a.g.W = grid_w; a.g.H = grid_h;
+    carve_bwd(a, n, grid_w * grid_h, const_cast<void*>(d_pillar_workspace));
+    a.dhx = d_dhx; a.dhx_pitch = dhx_pitch; a.d_b0 = d_db0; a.b0_pitch = b0_pitch; a.group0 = group0; a.group1 = group1;
+    a.n_groups = n_groups; a.d_dec = d_ddec; a.dec_pitch = dec_pitch;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("head_scatter_kernel", s);
+    hipLaunchKernelGGL(head_scatter_kernel, dim3((grid_w * grid_h + kCellsPerBlock - 1) / kCellsPerBlock), dim3(256), 0, s, a);
+    HIMO_LAUNCH_CHECK("head_scatter_kernel");
     return HIMO_OK;
 }

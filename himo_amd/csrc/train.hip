@@ -132,6 +132,172 @@ __global__ __launch_bounds__(256) void mask_rows_kernel(int64_t n, int cols, con
     if (pid[i] < 0) v[i * pitch + (int)(e % cols)] = 0.f;
 }
 
+// y[i][c] += b[i][c] (pitched 2-D views; gradient fan-in of a tensor with two consumers)
+__global__ __launch_bounds__(256) void add2d_kernel(int64_t rows, int cols, const float* __restrict__ b, int b_pitch,
+                                                    float* __restrict__ y, int y_pitch) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= rows * cols) return;
+    const int64_t i = e / cols;
+    const int c = (int)(e % cols);
+    y[i * y_pitch + c] += b[i * b_pitch + c];
+}
+
+// ---- convolution backward helpers ---------------------------------------------------------------------------------
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// w [k][k][cin][cout] -> wf [k][k][cout][cin] with the taps mirrored: the data-gradient of a stride-1 "same" convolution is
+// the same convolution of dY with these weights
+__global__ __launch_bounds__(256) void weight_flip_kernel(const float* __restrict__ w, int ks, int cin, int cout, float* __restrict__ wf) {
+    const int64_t total = (int64_t)ks * ks * cin * cout;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int co = (int)(e % cout);
+    const int ci = (int)((e / cout) % cin);
+    const int tap = (int)(e / ((int64_t)cout * cin));
+    const int ftap = ks * ks - 1 - tap;
+    wf[((int64_t)ftap * cout + co) * cin + ci] = w[e];
+}
+
+// z [2H][2W][C] with z[2y][2x] = dy[y][x], zeros elsewhere (H, W = dy size; out size 2H x 2W):
+// a stride-2 convolution's data gradient is the stride-1 data gradient of the zero-stuffed dY
+__global__ __launch_bounds__(256) void zero_stuff_kernel(int n_img, int H, int W, int C, const float* __restrict__ dy, int64_t dy_bs,
+                                                         int dy_pitch, float* __restrict__ z, int64_t z_bs, int z_pitch) {
+    const int c4 = C / 4;
+    const int64_t total = (int64_t)n_img * (2 * H) * (2 * W) * c4;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int q = (int)(e % c4);
+    int64_t pix = e / c4;
+    const int ox = (int)(pix % (2 * W)); pix /= 2 * W;
+    const int oy = (int)(pix % (2 * H));
+    const int img = (int)(pix / (2 * H));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(oy & 1) && !(ox & 1))
+        v = *reinterpret_cast<const float4*>(dy + img * dy_bs + ((int64_t)(oy / 2) * W + ox / 2) * dy_pitch + q * 4);
+    *reinterpret_cast<float4*>(z + img * z_bs + ((int64_t)oy * (2 * W) + ox) * z_pitch + q * 4) = v;
+}
+
+// adjoint of upsample2x_kernel (bilinear x2, align_corners): dx[y][x] = sum over the output pixels whose footprint
+// contains (y, x) of weight * dy -- a gather over at most 4 x 4 candidates, so no atomics
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(int H, int W, int C, const float* __restrict__ dy, int dy_pitch,
+                                                             float* __restrict__ dx, int dx_pitch, float ry, float rx) {
+    const int c4 = C / 4;
+    const int64_t total = (int64_t)H * W * c4;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int q = (int)(e % c4);
+    const int64_t pix = e / c4;
+    const int x = (int)(pix % W), y = (int)(pix / W);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // output rows whose source coordinate sy = ry * oy lies in (y - 1, y + 1)
+    // (a single-row / single-column image has ratio 0: every output row reads source row 0)
+    const int oy_lo = ry > 0.f ? max(0, (int)floorf((float)(y - 1) / ry)) : 0;
+    const int oy_hi = ry > 0.f ? min(2 * H - 1, (int)ceilf((float)(y + 1) / ry)) : 2 * H - 1;
+    const int ox_lo = rx > 0.f ? max(0, (int)floorf((float)(x - 1) / rx)) : 0;
+    const int ox_hi = rx > 0.f ? min(2 * W - 1, (int)ceilf((float)(x + 1) / rx)) : 2 * W - 1;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        const float sy = ry * (float)oy;
+        const int y0 = (int)sy, y1 = y0 + (y0 < H - 1 ? 1 : 0);
+        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+        float wy = 0.f;
+        if (y0 == y) wy += ly0;
+        if (y1 == y) wy += ly1;
+        if (wy == 0.f) continue;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            const float sx = rx * (float)ox;
+            const int x0 = (int)sx, x1 = x0 + (x0 < W - 1 ? 1 : 0);
+            const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+            float wx = 0.f;
+            if (x0 == x) wx += lx0;
+            if (x1 == x) wx += lx1;
+            if (wx == 0.f) continue;
+            const float4 g = *reinterpret_cast<const float4*>(dy + ((int64_t)oy * (2 * W) + ox) * dy_pitch + q * 4);
+            const float w = wy * wx;
+            acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+        }
+    }
+    *reinterpret_cast<float4*>(dx + pix * dx_pitch + q * 4) = acc;
+}
+
+// weight gradient of a 3x3 (pad 1, stride S) convolution: dW[tap][ci][co] = sum_pixels X[pix*S + tap - 1][ci] dY[pix][co]
+// as a split-K matrix product per (tap, 128x128 tile): fragments straight from global memory (see fastnsf.hip)
+struct ConvWgradArgs {
+    const float* x; int x_pitch; int H, W;          // input image (one image per launch)
+    const float* dy; int dy_pitch; int Ho, Wo;      // output-gradient image
+    int cin, cout, stride, chunk;                   // chunk = output pixels per block (even)
+    float* partial;                                 // [tap][tile][chunks][128][128]
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(ConvWgradArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int co_tiles = (a.cout + 127) / 128, ci_tiles = (a.cin + 127) / 128;
+    const int tiles = ci_tiles * co_tiles;
+    const int tap = (int)blockIdx.y / tiles, tile = (int)blockIdx.y % tiles;
+    const int ci0 = (tile / co_tiles) * 128, co0 = (tile % co_tiles) * 128;
+    const int ky = tap / 3 - 1, kx = tap % 3 - 1;
+    const int64_t P = (int64_t)a.Ho * a.Wo;
+    const int64_t p0 = (int64_t)blockIdx.x * a.chunk;
+    const int64_t p1 = p0 + a.chunk < P ? p0 + a.chunk : P;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int ci[2], co[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { ci[t] = ci0 + wm * 64 + t * 32 + li; co[t] = co0 + wn * 64 + t * 32 + li; }
+    if (ci0 + wm * 64 < a.cin && co0 + wn * 64 < a.cout) {
+#pragma unroll 2
+        for (int64_t p = p0; p < p1; p += 2) {
+            const int64_t pp = p + lh;
+            const int oy = (int)(pp / a.Wo), ox = (int)(pp % a.Wo);
+            const int iy = oy * a.stride + ky, ix = ox * a.stride + kx;
+            const bool okp = pp < p1;
+            const bool okx = okp && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const int64_t xin = ((int64_t)iy * a.W + ix) * a.x_pitch;
+            float af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = (okx && ci[t] < a.cin) ? a.x[xin + ci[t]] : 0.f;
+                bf[t] = (okp && co[t] < a.cout) ? a.dy[pp * a.dy_pitch + co[t]] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* out = a.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 * 128;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wn * 64 + j * 32 + li] = acc[i][j][r];
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int cin, int cout,
+                                                                float* __restrict__ dW, int accumulate) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = 9ll * cin * cout;
+    if (e >= total) return;
+    const int co = (int)(e % cout);
+    const int ci = (int)((e / cout) % cin);
+    const int tap = (int)(e / ((int64_t)cout * cin));
+    const int co_tiles = (cout + 127) / 128, tiles = ((cin + 127) / 128) * co_tiles;
+    const int tile = (ci / 128) * co_tiles + co / 128;
+    const float* p = partial + ((int64_t)(tap * tiles + tile) * chunks) * 128 * 128 + (ci % 128) * 128 + (co % 128);
+    float s = 0.f;
+    for (int b = 0; b < chunks; ++b) s += p[(int64_t)b * 128 * 128];
+    dW[e] = accumulate ? dW[e] + s : s;
+}
+
 }  // namespace himo
 
 using namespace himo;
@@ -209,5 +375,75 @@ extern "C" int himo_mask_rows(int64_t n, int cols, const int32_t* d_pid, float* 
     if (!d_pid || !d_v) return HIMO_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(mask_rows_kernel, HIMO_GRID(n * cols), n, cols, d_pid, d_v, pitch);
     HIMO_LAUNCH_CHECK("mask_rows_kernel");
+    return HIMO_OK;
+}
+
+extern "C" int himo_weight_flip(const float* d_w, int ksize, int cin, int cout, float* d_wf, void* stream) {
+    if (!d_w || !d_wf || ksize < 1 || cin < 1 || cout < 1) return HIMO_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(weight_flip_kernel, HIMO_GRID((int64_t)ksize * ksize * cin * cout), d_w, ksize, cin, cout, d_wf);
+    HIMO_LAUNCH_CHECK("weight_flip_kernel");
+    return HIMO_OK;
+}
+
+extern "C" int himo_zero_stuff2x(int n_img, int h, int w, int c, const float* d_dy, int64_t dy_batch_stride, int dy_pitch,
+                                 float* d_z, int64_t z_batch_stride, int z_pitch, void* stream) {
+    if (n_img < 1 || h < 1 || w < 1 || c < 4 || (c & 3) || (dy_pitch & 3) || (z_pitch & 3) || !d_dy || !d_z) return HIMO_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(zero_stuff_kernel, HIMO_GRID((int64_t)n_img * 4 * h * w * (c / 4)), n_img, h, w, c, d_dy, dy_batch_stride,
+                       dy_pitch, d_z, z_batch_stride, z_pitch);
+    HIMO_LAUNCH_CHECK("zero_stuff_kernel");
+    return HIMO_OK;
+}
+
+extern "C" int himo_upsample2x_bwd(const float* d_dy, int dy_pitch, int h, int w, int c, float* d_dx, int dx_pitch, void* stream) {
+    if (!d_dy || !d_dx || h < 1 || w < 1 || c < 4 || (c & 3) || (dy_pitch & 3) || (dx_pitch & 3)) return HIMO_ERR_INVALID_ARGUMENT;
+    const float ry = h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f, rx = w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, HIMO_GRID((int64_t)h * w * (c / 4)), h, w, c, d_dy, dy_pitch, d_dx, dx_pitch, ry, rx);
+    HIMO_LAUNCH_CHECK("upsample2x_bwd_kernel");
+    return HIMO_OK;
+}
+
+static int conv_wgrad_chunk(int64_t pixels) {
+    int64_t c = (pixels + 47) / 48;                 // aim for <= 48 chunks
+    if (c < 256) c = 256;
+    return (int)((c + 1) / 2 * 2);
+}
+
+extern "C" size_t himo_conv_wgrad_workspace_bytes(int ho, int wo, int cin, int cout) {
+    const int64_t P = (int64_t)ho * wo;
+    const int chunk = conv_wgrad_chunk(P);
+    const size_t chunks = (size_t)((P + chunk - 1) / chunk);
+    const size_t tiles = (size_t)((cin + 127) / 128) * ((cout + 127) / 128);
+    return 9 * tiles * chunks * 128 * 128 * 4 + 64;
+}
+
+// one image: X [h][w] pixels (pitch x_pitch), dY [ho][wo]; 3x3 pad 1, stride 1|2; flags bit 0 = accumulate into d_dw
+extern "C" int himo_conv3x3_wgrad(const float* d_x, int x_pitch, int h, int w, int cin, const float* d_dy, int dy_pitch, int cout,
+                                  int stride, float* d_dw, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!d_x || !d_dy || !d_dw || !d_workspace || h < 1 || w < 1 || cin < 1 || cout < 1 || !(stride == 1 || stride == 2))
+        return HIMO_ERR_INVALID_ARGUMENT;
+    const int ho = stride == 2 ? (h + 1) / 2 : h, wo = stride == 2 ? (w + 1) / 2 : w;
+    if (workspace_bytes < himo_conv_wgrad_workspace_bytes(ho, wo, cin, cout) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
+    ConvWgradArgs a{d_x, x_pitch, h, w, d_dy, dy_pitch, ho, wo, cin, cout, stride, conv_wgrad_chunk((int64_t)ho * wo),
+                    reinterpret_cast<float*>(d_workspace)};
+    const int64_t P = (int64_t)ho * wo;
+    const int chunks = (int)((P + a.chunk - 1) / a.chunk);
+    const int tiles = ((cin + 127) / 128) * ((cout + 127) / 128);
+    hipStream_t s = (hipStream_t)stream;
+    {
+        ProfScope ps("conv_wgrad_partial_kernel", s);
+        hipLaunchKernelGGL(conv_wgrad_partial_kernel, dim3(chunks, 9 * tiles), dim3(256), 0, s, a);
+    }
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((9ll * cin * cout + 255) / 256)), dim3(256), 0, s, a.partial, chunks, cin,
+                       cout, d_dw, (flags & 1u) ? 1 : 0);
+    HIMO_LAUNCH_CHECK("conv_wgrad kernels");
+    return HIMO_OK;
+}
+
+extern "C" int himo_add2d(int64_t rows, int cols, const float* d_b, int b_pitch, float* d_y, int y_pitch, void* stream) {
+    if (rows < 0 || cols < 1 || b_pitch < cols || y_pitch < cols) return HIMO_ERR_INVALID_ARGUMENT;
+    if (rows == 0) return HIMO_OK;
+    if (!d_b || !d_y) return HIMO_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(add2d_kernel, HIMO_GRID(rows * cols), rows, cols, d_b, b_pitch, d_y, y_pitch);
+    HIMO_LAUNCH_CHECK("add2d_kernel");
     return HIMO_OK;
 }

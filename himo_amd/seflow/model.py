@@ -72,6 +72,7 @@ class SeFlowNet:
             raise ValueError(precision)
         self.precision = precision
         self.autotune = autotune
+        self.keep_cell_lists = False
         self.tiles = {}
         self.lib = _lib.load()
         self.device = device if device is not None else _lib.require_gpu()
@@ -139,6 +140,8 @@ class SeFlowNet:
         self.max_points = n
         need = int(self.lib.himo_pillar_workspace_bytes(n, self.W, self.H))
         self.ws = torch.empty(need + 64, dtype=torch.uint8, device=dev)
+        # training keeps every sweep's cell lists for the backward pass: one workspace per frame slot
+        self.ws_slots = [torch.empty(need + 64, dtype=torch.uint8, device=dev) for _ in range(self.F)] if self.keep_cell_lists else None
         self.xyz_t = torch.empty((self.F, n, 3), dtype=torch.float32, device=dev)
         self.pid = torch.empty((self.F, n), dtype=torch.int32, device=dev)
         self.offsets = torch.empty((self.F, n, 3), dtype=torch.float32, device=dev)
@@ -200,6 +203,11 @@ class SeFlowNet:
     # ---- stages ---------------------------------------------------------------------------------------
     def backbone(self):
         """B0 (3 pillar images) -> DEC (64 x H x W)."""
+        self.encoder()
+        return self.decoder()
+
+    def encoder(self):
+        """B0 -> the three concat buffers F1 / F2 / F3 (frames stacked on channels)."""
         H, W, F = self.H, self.W, self.F
         p = self.p
         # encoder: frames are the batch; the last conv of a stage writes into the concat buffer
@@ -220,7 +228,10 @@ class SeFlowNet:
                     self._conv(src, src_bs, src_pitch, name, dst, dst_bs, dst_pitch, F, ho, wo, cout, cout, 3, 1,
                                EPI_BIAS_BN_GELU, scale=p[f"{name}.scale"], shift=p[f"{name}.shift"])
                 src, src_bs, src_pitch = dst, dst_bs, dst_pitch
-        # decoder
+
+    def decoder(self):
+        """B0, F1, F2, F3 -> DEC; every intermediate keeps its own buffer (the training backward pass reads them)."""
+        H, W, F = self.H, self.W, self.F
         def block(name, coarse, c_in, ch, cw, tmp, cat, skip, skip_c, lat, out, work):
             self._conv(coarse, 0, c_in, f"{name}.u1", tmp, 0, lat, 1, 1, ch * cw, c_in, lat, 1, 1, EPI_BIAS)
             self._up(tmp, lat, ch, cw, lat, cat, 2 * lat)
@@ -281,11 +292,12 @@ class SeFlowNet:
         n = pts.shape[0]
         self._reserve_points(n)
         T = _f32x(np.asarray(transform, dtype=np.float32).reshape(-1))
+        ws = self.ws if self.ws_slots is None else self.ws_slots[slot]
         st = self.lib.himo_pillarize(n, pts.data_ptr(), pts.shape[1], T, self._range, self._voxel, self._centre,
                                      self.W, self.H, self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
                                      self.p["pfn.shift"].data_ptr(), self.xyz_t[slot].data_ptr(), self.pid[slot].data_ptr(),
                                      self.offsets[slot].data_ptr(), self.B0.data_ptr() + 4 * 32 * slot, 32 * self.F,
-                                     self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle())
+                                     ws.data_ptr(), ws.numel(), _lib.stream_handle())
         _lib.check(st, "himo_pillarize")
 
 

@@ -5,8 +5,10 @@ PARITY UNPINNED: the reference trains through ``OpenSceneFlow/train.py`` (assets
 is absent.  Conventions of this build: BatchNorm statistics frozen (scale / shift are constants), Adam, unit-weight
 SeFlow-style loss (himo_amd/ssl_loss.py).  The oracle is PyTorch CPU autograd through oracle/seflow_oracle.py.
 
-This module currently implements the per-point HEAD (gather -> 4 GRU iterations -> MLP) forward/backward; the
-convolutional backbone's backward pass is the next step.
+``HeadTrainer``: the per-point head (4 GRU iterations -> MLP) with saved states and its BPTT backward pass.
+``SeFlowTrainer``: the whole network -- pillar features, encoder, decoder, head -- forward with saved activations,
+backward (every gradient a fixed-order reduction: no float atomics), one flat parameter / gradient / Adam-moment
+buffer, and a single all-reduce of the flat gradient across ranks.
 """
 from __future__ import annotations
 
@@ -31,7 +33,49 @@ _lib.register({
     "himo_wgrad_workspace_bytes_ex": (ctypes.c_size_t, [c_l, c_i, c_i]),
     "himo_linear_wgrad_ex": (c_i, [c_l, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
     "himo_transpose": (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    "himo_weight_flip": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
+    "himo_zero_stuff2x": (c_i, [c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p]),
+    "himo_upsample2x_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "himo_conv_wgrad_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i, c_i]),
+    "himo_conv3x3_wgrad": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
 })
+
+
+# ---- stand-alone backward operators (tests): the kernels the trainer strings together ---------------------------------
+def conv3x3_backward_nhwc(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, stride: int = 1):
+    """x [N,H,W,Cin], weight [3,3,Cin,Cout], dy [N,Ho,Wo,Cout] -> (dx [N,H,W,Cin], dw [3,3,Cin,Cout], db [Cout]) of
+    y = conv3x3(x, weight, pad 1, stride) + b."""
+    from .model import conv2d_nhwc
+    lib = _lib.load()
+    n, h, w, cin = x.shape
+    cout = weight.shape[3]
+    ho, wo = dy.shape[1], dy.shape[2]
+    s = _lib.stream_handle
+    wf = torch.empty((3, 3, cout, cin), dtype=torch.float32, device=x.device)
+    _lib.check(lib.himo_weight_flip(weight.data_ptr(), 3, cin, cout, wf.data_ptr(), s()), "himo_weight_flip")
+    zero_b = torch.zeros(cin, dtype=torch.float32, device=x.device)
+    if stride == 2:
+        z = torch.empty((n, 2 * ho, 2 * wo, cout), dtype=torch.float32, device=x.device)
+        _lib.check(lib.himo_zero_stuff2x(n, ho, wo, cout, dy.data_ptr(), ho * wo * cout, cout, z.data_ptr(), 4 * ho * wo * cout, cout, s()),
+                   "himo_zero_stuff2x")
+        dx = conv2d_nhwc(z, wf, zero_b)
+    else:
+        dx = conv2d_nhwc(dy, wf, zero_b)
+    dw = torch.empty_like(weight)
+    ws = torch.empty(int(lib.himo_conv_wgrad_workspace_bytes(ho, wo, cin, cout)), dtype=torch.uint8, device=x.device)
+    for i in range(n):
+        _lib.check(lib.himo_conv3x3_wgrad(x[i].data_ptr(), cin, h, w, cin, dy[i].data_ptr(), cout, cout, stride, dw.data_ptr(),
+                                          1 if i else 0, ws.data_ptr(), ws.numel(), s()), "himo_conv3x3_wgrad")
+    return dx, dw, dy.sum((0, 1, 2))
+
+
+def upsample2x_backward_nhwc(dy: torch.Tensor) -> torch.Tensor:
+    """dy [2H,2W,C] -> dx [H,W,C]: adjoint of the bilinear x2 (align_corners) upsampling."""
+    lib = _lib.load()
+    h, w, c = dy.shape[0] // 2, dy.shape[1] // 2, dy.shape[2]
+    dx = torch.empty((h, w, c), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.himo_upsample2x_bwd(dy.data_ptr(), c, h, w, c, dx.data_ptr(), c, _lib.stream_handle()), "himo_upsample2x_bwd")
+    return dx
 
 
 class HeadTrainer:
@@ -39,21 +83,30 @@ class HeadTrainer:
     [192,128], ``q.bias`` [128], ``dec1.weight`` [192,32], ``dec1.bias`` [32], ``dec2.weight`` [32,4] (column 3 zero),
     ``dec2.bias`` [4]."""
 
-    def __init__(self, params: dict, device=None):
+    @staticmethod
+    def host_params(params: dict) -> dict:
+        """spec parameter dict -> this class's layout (z|r fused, dec2 padded to 4 columns), numpy float32"""
+        w2 = np.zeros((32, 4), np.float32); w2[:, :3] = params["head.dec2.weight"]
+        b2 = np.zeros(4, np.float32); b2[:3] = params["head.dec2.bias"]
+        return {
+            "zr.weight": np.concatenate([params["head.gru.z.weight"], params["head.gru.r.weight"]], axis=1),
+            "zr.bias": np.concatenate([params["head.gru.z.bias"], params["head.gru.r.bias"]]),
+            "q.weight": params["head.gru.q.weight"], "q.bias": params["head.gru.q.bias"],
+            "dec1.weight": params["head.dec1.weight"], "dec1.bias": params["head.dec1.bias"],
+            "dec2.weight": w2, "dec2.bias": b2,
+        }
+
+    def __init__(self, params: dict | None = None, device=None, p: dict | None = None, g: dict | None = None):
+        """Either ``params`` (spec dict, copied to the device) or ``p`` / ``g``: device views owned by the caller."""
         self.lib = _lib.load()
         self.device = device if device is not None else _lib.require_gpu()
         dev = self.device
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
-        w2 = np.zeros((32, 4), np.float32); w2[:, :3] = params["head.dec2.weight"]
-        b2 = np.zeros(4, np.float32); b2[:3] = params["head.dec2.bias"]
-        self.p = {
-            "zr.weight": t(np.concatenate([params["head.gru.z.weight"], params["head.gru.r.weight"]], axis=1)),
-            "zr.bias": t(np.concatenate([params["head.gru.z.bias"], params["head.gru.r.bias"]])),
-            "q.weight": t(params["head.gru.q.weight"]), "q.bias": t(params["head.gru.q.bias"]),
-            "dec1.weight": t(params["head.dec1.weight"]), "dec1.bias": t(params["head.dec1.bias"]),
-            "dec2.weight": t(w2), "dec2.bias": t(b2),
-        }
-        self.g = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        if p is None:
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+            self.p = {k: t(v) for k, v in self.host_params(params).items()}
+            self.g = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        else:
+            self.p, self.g = p, g
         self.n = 0
 
     def _reserve(self, n):
@@ -140,4 +193,306 @@ class HeadTrainer:
         out = torch.empty((n, 192), dtype=torch.float32, device=self.device)
         out[:, :128].copy_(self.DH)
         out[:, 128:].copy_(self.DX)
+        return out
+
+
+_lib.register({
+    "himo_add2d": (c_i, [c_l, c_i, c_p, c_i, c_p, c_i, c_p]),
+    "himo_colsum": (c_i, [c_l, c_p, c_i, c_i, c_p, ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
+    "himo_pfn_backward_workspace_bytes": (ctypes.c_size_t, []),
+    "himo_pfn_backward": (c_i, [c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
+    "himo_head_scatter": (c_i, [c_l, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
+    "himo_adam_step": (c_i, [c_l, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_p]),
+})
+
+
+class SeFlowTrainer:
+    """Whole-network training step.  Conventions (PARITY UNPINNED, this build's own): float32 MFMA kernels, BatchNorm
+    fully frozen (running statistics AND affine folded into constant scale / shift), trainable = every weight and bias.
+
+        tr = SeFlowTrainer(params)                       # spec parameter dict
+        res = tr.forward(pch1, pc0, pc1, pose_h1, pose0, pose1)     # [n0, 4] network flow of pc0 rows (col 3 = 0)
+        tr.backward(dres)                                # d loss / d res -> tr.flat_g (and the views tr.g[name])
+        tr.allreduce(); tr.adam_step(lr)
+    """
+
+    def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, seed: int = 0):
+        from .model import SeFlowNet
+        self.lib = _lib.load()
+        self.device = dev = device if device is not None else _lib.require_gpu()
+        params = spec.init_params(seed) if params is None else params
+        net = self.net = SeFlowNet(params, device=dev, max_points=1, precision="f32", autotune=False)
+        net.keep_cell_lists = True
+        net.max_points = 0
+        net._reserve_points(max_points)
+        H, W, F = net.H, net.W, net.F
+        # ---- one flat buffer for parameters / gradients / Adam moments; net.p entries become views of it
+        host = {"pfn.weight": params["pfn.weight"]}
+        for name, *_ in spec.ENCODER:
+            host[f"{name}.weight"], host[f"{name}.bias"] = params[f"{name}.weight"], params[f"{name}.bias"]
+        for name, *_ in spec.DECODER:
+            for u in ("u1", "u3", "u4", "u5"):
+                host[f"{name}.{u}.weight"], host[f"{name}.{u}.bias"] = params[f"{name}.{u}.weight"], params[f"{name}.{u}.bias"]
+        host["dec4.weight"], host["dec4.bias"] = params["dec4.weight"], params["dec4.bias"]
+        host["head.offset.weight"], host["head.offset.bias"] = params["head.offset.weight"], params["head.offset.bias"]
+        for k, v in HeadTrainer.host_params(params).items():
+            host[f"head.{k}"] = v
+        self.names = list(host)
+        sizes = [int(np.prod(host[k].shape)) for k in self.names]
+        pad = lambda n: (n + 3) // 4 * 4                                   # 16-byte aligned views
+        total = sum(pad(n) for n in sizes)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.p, self.g = {}, {}
+        o = 0
+        for k, n in zip(self.names, sizes):
+            shp = tuple(host[k].shape)
+            self.p[k] = self.flat_p[o:o + n].view(shp)
+            self.g[k] = self.flat_g[o:o + n].view(shp)
+            self.p[k].copy_(torch.from_numpy(np.ascontiguousarray(host[k], dtype=np.float32)))
+            o += pad(n)
+        for k in self.names:
+            if not k.startswith("head.") or k.startswith("head.offset"):
+                net.p[k] = self.p[k]
+        hp = {k[5:]: v for k, v in self.p.items() if k.startswith("head.") and not k.startswith("head.offset")}
+        hg = {k[5:]: v for k, v in self.g.items() if k.startswith("head.") and not k.startswith("head.offset")}
+        self.head = HeadTrainer(device=dev, p=hp, g=hg)
+        self.step_count = 0
+        # ---- saved encoder activations: PRE (after BN, before GELU) and Y per layer, frames as the batch
+        buf = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        self.layers = []          # (name, cin, cout, stride, h_in, w_in, ho, wo, last_of_stage)
+        h, w = H, W
+        for i, (name, cin, cout, stride) in enumerate(spec.ENCODER):
+            ho, wo = (h // 2, w // 2) if stride == 2 else (h, w)
+            last = i + 1 == len(spec.ENCODER) or spec.ENCODER[i + 1][3] == 2
+            self.layers.append((name, cin, cout, stride, h, w, ho, wo, last))
+            h, w = ho, wo
+        self.PRE = [buf(F, L[6] * L[7], L[2]) for L in self.layers]
+        self.Y = [None if L[8] else buf(F, L[6] * L[7], L[2]) for L in self.layers]
+        # ---- gradient buffers
+        self.dB0, self.dDEC = buf(H * W, 32 * F), buf(H * W, 64)
+        self.dF1, self.dF2, self.dF3 = buf(H * W // 4, 64 * F), buf(H * W // 16, 128 * F), buf(H * W // 64, 256 * F)
+        big = F * (H // 2) * (W // 2) * 64                       # the largest encoder activation (floats)
+        self.dA, self.dB, self.DP = buf(big), buf(big), buf(big)
+        self.Z = buf(F * H * W * 64)                             # zero-stuffed dY of the stride-2 layers (largest: enc1.0)
+        self.TMP = buf(max(H * W * 128, F * H * W * 32))        # a decoder-sized scratch / the enc1.0 data gradient
+        self.dWORK = [buf(H * W * 64) for _ in range(2)]         # d work[0] and d (block input) ping-pong
+        self.dCAT = buf(H * W * 128)
+        self.dTMPc = buf((H // 2) * (W // 2) * 64)               # gradient of the 1x1-projected coarse map
+        self.dCO = [buf((H // 2) * (W // 2) * 128) for _ in range(2)]   # d coarse of dec3 / dec2
+        self.WF = buf(3 * 3 * 512 * 256)                         # flipped / transposed weights of the layer being differentiated
+        ws = max(int(self.lib.himo_conv_wgrad_workspace_bytes(H // 4, W // 4, 512, 256)),
+                 int(self.lib.himo_conv_wgrad_workspace_bytes(H, W, 128, 64)),
+                 int(self.lib.himo_conv_wgrad_workspace_bytes(H // 2, W // 2, 256, 128)),
+                 int(self.lib.himo_wgrad_workspace_bytes_ex(H * W, 96, 64)),
+                 int(self.lib.himo_wgrad_workspace_bytes_ex(H * W // 4, 192, 128)),
+                 int(self.lib.himo_wgrad_workspace_bytes_ex(H * W // 16, 384, 256)),
+                 int(self.lib.himo_wgrad_workspace_bytes_ex(max_points, 192, 256)),
+                 int(self.lib.himo_pfn_backward_workspace_bytes()))
+        self.ws = torch.empty(ws + 64, dtype=torch.uint8, device=dev)
+        self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
+
+    # ---- launch helpers (raw device addresses: most operands are channel groups of wider buffers) --------------
+    def _conv(self, x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride=1):
+        d = ConvDesc()
+        d.x, d.x_batch_stride, d.x_pitch = x, x_bs, x_pitch
+        d.w = w; d.bias = bias
+        d.y, d.y_batch_stride, d.y_pitch = y, y_bs, y_pitch
+        d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = n, h, wd, cin, cout, ks, stride, EPI_BIAS
+        _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), "himo_conv2d(train)")
+
+    def _wgrad3(self, x, x_pitch, h, w, cin, dy, dy_pitch, cout, stride, gname, acc):
+        _lib.check(self.lib.himo_conv3x3_wgrad(x, x_pitch, h, w, cin, dy, dy_pitch, cout, stride, self.g[gname].data_ptr(),
+                                               1 if acc else 0, self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle()), "conv3x3_wgrad")
+
+    def _colsum(self, rows, z, pitch, cout, gname, acc=False):
+        _lib.check(self.lib.himo_colsum(rows, z, pitch, cout, self.g[gname].data_ptr(), 1 if acc else 0, self.ws.data_ptr(),
+                                        self.ws.numel(), _lib.stream_handle()), "colsum")
+
+    def _wgrad1(self, rows, x, x_pitch, cin, dz, z_pitch, cout, name):
+        _lib.check(self.lib.himo_linear_wgrad_ex(rows, x, x_pitch, cin, dz, z_pitch, cout, self.g[f"{name}.weight"].data_ptr(),
+                                                 self.g[f"{name}.bias"].data_ptr(), 0, self.ws.data_ptr(), self.ws.numel(),
+                                                 _lib.stream_handle()), "linear_wgrad")
+
+    def _flip(self, name, ks, cin, cout):
+        _lib.check(self.lib.himo_weight_flip(self.p[f"{name}.weight"].data_ptr(), ks, cin, cout, self.WF.data_ptr(), _lib.stream_handle()), "flip")
+        return self.WF.data_ptr()
+
+    def _add2d(self, rows, cols, b, b_pitch, y, y_pitch):
+        _lib.check(self.lib.himo_add2d(rows, cols, b, b_pitch, y, y_pitch, _lib.stream_handle()), "add2d")
+
+    # ---- forward -------------------------------------------------------------------------------------------------
+    def forward(self, pch1, pc0, pc1, pose_h1, pose0, pose1) -> torch.Tensor:
+        net, lib, s = self.net, self.lib, _lib.stream_handle
+        dev = self.device
+        to_dev = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(dev, torch.float32).contiguous()
+        pch1, pc0, pc1 = to_dev(pch1), to_dev(pc0), to_dev(pc1)
+        inv1 = np.linalg.inv(np.asarray(pose1, np.float64))
+        self.n_pts = [pch1.shape[0], pc0.shape[0], pc1.shape[0]]
+        net.pillarize_into(0, pch1, inv1 @ np.asarray(pose_h1, np.float64))
+        net.pillarize_into(1, pc0, inv1 @ np.asarray(pose0, np.float64))
+        net.pillarize_into(2, pc1, np.eye(4))
+        F = net.F
+        # encoder with saved activations
+        src, src_bs, src_pitch = net.B0.data_ptr(), 32, 32 * F
+        cat = {64: net.F1, 128: net.F2, 256: net.F3}
+        self.inputs = []
+        for li, (name, cin, cout, stride, h, w, ho, wo, last) in enumerate(self.layers):
+            self.inputs.append((src, src_bs, src_pitch))
+            pre = self.PRE[li]
+            self._conv(src, src_bs, src_pitch, self.p[f"{name}.weight"].data_ptr(), self.p[f"{name}.bias"].data_ptr(),
+                       pre.data_ptr(), ho * wo * cout, cout, F, h, w, cin, cout, 3, stride)
+            sc, sh = net.p[f"{name}.scale"].data_ptr(), net.p[f"{name}.shift"].data_ptr()
+            if last:
+                dst = cat[cout]
+                for f in range(F):
+                    _lib.check(lib.himo_affine_gelu_fwd(ho * wo, cout, pre[f].data_ptr(), cout, sc, sh, pre[f].data_ptr(), cout,
+                                                        dst.data_ptr() + 4 * cout * f, cout * F, s()), "affine_gelu_fwd")
+                src, src_bs, src_pitch = dst.data_ptr(), cout, cout * F
+            else:
+                y = self.Y[li]
+                _lib.check(lib.himo_affine_gelu_fwd(F * ho * wo, cout, pre.data_ptr(), cout, sc, sh, pre.data_ptr(), cout,
+                                                    y.data_ptr(), cout, s()), "affine_gelu_fwd")
+                src, src_bs, src_pitch = y.data_ptr(), ho * wo * cout, cout
+        net.decoder()
+        # head: gather -> GRU with saved states
+        n0 = pc0.shape[0]
+        self.n0 = n0
+        hx0 = torch.empty((n0, 192), dtype=torch.float32, device=dev)
+        rhx = torch.empty((n0, 192), dtype=torch.float32, device=dev)
+        _lib.check(lib.himo_head_gather(n0, net.pid[1].data_ptr(), net.offsets[1].data_ptr(), net.B0.data_ptr() + 4 * 32,
+                                        net.B0.data_ptr() + 4 * 64, 32 * F, net.DEC.data_ptr(), 64,
+                                        self.p["head.offset.weight"].data_ptr(), self.p["head.offset.bias"].data_ptr(),
+                                        hx0.data_ptr(), rhx.data_ptr(), 192, s()), "himo_head_gather")
+        res = self.head.forward(hx0)
+        _lib.check(lib.himo_mask_rows(n0, 4, net.pid[1].data_ptr(), res.data_ptr(), 4, s()), "mask_rows")
+        return res
+
+    # ---- backward ----------------------------------------------------------------------------------------------
+    def _block_bwd(self, name, coarse, c_in, ch, cw, skip, skip_c, lat, out, cat, work0, d_out, d_in, d_coarse, d_skip, skip_acc):
+        """UpsampleSkip block: d_out (gradient of its output, [P][out]) -> parameter gradients, d_coarse ([ch*cw][c_in]),
+        d_skip ([P][skip_c], added when ``skip_acc``).  ``d_in`` is scratch for the gradient of work[0]."""
+        lib, s = self.lib, _lib.stream_handle
+        h2, w2 = 2 * ch, 2 * cw
+        P = h2 * w2
+        zb = self.zero_bias.data_ptr()
+        # u5
+        self._wgrad3(work0.data_ptr(), out, h2, w2, out, d_out, out, out, 1, f"{name}.u5.weight", False)
+        self._colsum(P, d_out, out, out, f"{name}.u5.bias")
+        self._conv(d_out, 0, out, self._flip(f"{name}.u5", 3, out, out), zb, d_in, 0, out, 1, h2, w2, out, out, 3)
+        # u4
+        self._wgrad3(cat.data_ptr(), 2 * lat, h2, w2, 2 * lat, d_in, out, out, 1, f"{name}.u4.weight", False)
+        self._colsum(P, d_in, out, out, f"{name}.u4.bias")
+        dcat = self.dCAT.data_ptr()
+        self._conv(d_in, 0, out, self._flip(f"{name}.u4", 3, 2 * lat, out), zb, dcat, 0, 2 * lat, 1, h2, w2, out, 2 * lat, 3)
+        # u3 (1x1 on the skip): gradient rows are the right half of dCAT
+        self._wgrad1(P, skip.data_ptr(), skip_c, skip_c, dcat + 4 * lat, 2 * lat, lat, f"{name}.u3")
+        wt = self._flip(f"{name}.u3", 1, skip_c, lat)                       # [lat][skip_c]
+        if skip_acc:
+            self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, self.TMP.data_ptr(), 0, skip_c, 1, 1, P, lat, skip_c, 1)
+            self._add2d(P, skip_c, self.TMP.data_ptr(), skip_c, d_skip, skip_c)
+        else:
+            self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, d_skip, 0, skip_c, 1, 1, P, lat, skip_c, 1)
+        # upsample, u1 (1x1 on the coarse map)
+        dtmp = self.dTMPc.data_ptr()
+        _lib.check(lib.himo_upsample2x_bwd(dcat, 2 * lat, ch, cw, lat, dtmp, lat, s()), "upsample2x_bwd")
+        self._wgrad1(ch * cw, coarse.data_ptr(), c_in, c_in, dtmp, lat, lat, f"{name}.u1")
+        self._conv(dtmp, 0, lat, self._flip(f"{name}.u1", 1, c_in, lat), zb, d_coarse, 0, c_in, 1, 1, ch * cw, lat, c_in, 1)
+
+    def backward(self, dres: torch.Tensor):
+        """dres [n0,4] = d loss / d res.  Gradients of every trainable tensor land in ``self.flat_g``."""
+        net, lib, s = self.net, self.lib, _lib.stream_handle
+        H, W, F, n0 = net.H, net.W, net.F, self.n0
+        dres = dres.contiguous().clone()
+        _lib.check(lib.himo_mask_rows(n0, 4, net.pid[1].data_ptr(), dres.data_ptr(), 4, s()), "mask_rows")
+        dhx0 = self.head.backward(dres)
+        # offset embedding x = offsets @ W + b
+        _lib.check(lib.himo_linear_wgrad_ex(n0, net.offsets[1].data_ptr(), 3, 3, dhx0.data_ptr() + 4 * 128, 192, 64,
+                                            self.g["head.offset.weight"].data_ptr(), self.g["head.offset.bias"].data_ptr(), 0,
+                                            self.ws.data_ptr(), self.ws.numel(), s()), "offset wgrad")
+        # gather adjoint: per-point rows -> image gradients (pc0 is slot 1; it gathers from groups 1 and 2 and from DEC)
+        _lib.check(lib.himo_head_scatter(n0, W, H, net.ws_slots[1].data_ptr(), dhx0.data_ptr(), 192, self.dB0.data_ptr(), 32 * F,
+                                         1, 2, F, self.dDEC.data_ptr(), 64, s()), "head_scatter")
+        zb = self.zero_bias.data_ptr()
+        # dec4
+        u = net.U[1]
+        self._wgrad3(u.data_ptr(), 64, H, W, 64, self.dDEC.data_ptr(), 64, 64, 1, "dec4.weight", False)
+        self._colsum(H * W, self.dDEC.data_ptr(), 64, 64, "dec4.bias")
+        d_u = self.dWORK[0].data_ptr()
+        self._conv(self.dDEC.data_ptr(), 0, 64, self._flip("dec4", 3, 64, 64), zb, d_u, 0, 64, 1, H, W, 64, 64, 3)
+        # decoder blocks, last to first
+        d_t, d_s = self.dCO[0].data_ptr(), self.dCO[1].data_ptr()
+        self._block_bwd("dec3", net.T[1], 128, H // 2, W // 2, net.B0, 32 * F, 64, 64, net.CAT3, net.U[0], d_u, self.dWORK[1].data_ptr(),
+                        d_t, self.dB0.data_ptr(), True)
+        self._block_bwd("dec2", net.S[1], 256, H // 4, W // 4, net.F1, 64 * F, 128, 128, net.CAT2, net.T[0], d_t, self.dWORK[1].data_ptr(),
+                        d_s, self.dF1.data_ptr(), False)
+        self._block_bwd("dec1", net.F3, 256 * F, H // 8, W // 8, net.F2, 128 * F, 256, 256, net.CAT1, net.S[0], d_s, self.dWORK[1].data_ptr(),
+                        self.dF3.data_ptr(), self.dF2.data_ptr(), False)
+        # encoder, last layer to first
+        dcat = {256: self.dF3, 128: self.dF2, 64: self.dF1, 32: self.dB0}
+        dy = None
+        for li in range(len(self.layers) - 1, -1, -1):
+            name, cin, cout, stride, h, w, ho, wo, last = self.layers[li]
+            pre = self.PRE[li]
+            sc = net.p[f"{name}.scale"].data_ptr()
+            dp = self.DP.data_ptr()
+            if last:                                             # gradient arrives in the concat layout
+                src = dcat[cout]
+                for f in range(F):
+                    _lib.check(lib.himo_affine_gelu_bwd(ho * wo, cout, src.data_ptr() + 4 * cout * f, cout * F, pre[f].data_ptr(), cout, sc,
+                                                        dp + 4 * f * ho * wo * cout, cout, s()), "affine_gelu_bwd")
+            else:
+                _lib.check(lib.himo_affine_gelu_bwd(F * ho * wo, cout, dy, cout, pre.data_ptr(), cout, sc, dp, cout, s()), "affine_gelu_bwd")
+            self._colsum(F * ho * wo, dp, cout, cout, f"{name}.bias")
+            x, x_bs, x_pitch = self.inputs[li]
+            for f in range(F):
+                self._wgrad3(x + 4 * x_bs * f, x_pitch, h, w, cin, dp + 4 * f * ho * wo * cout, cout, cout, stride, f"{name}.weight", f > 0)
+            wf = self._flip(name, 3, cin, cout)
+            if stride == 2:
+                z = self.Z.data_ptr()
+                _lib.check(lib.himo_zero_stuff2x(F, ho, wo, cout, dp, ho * wo * cout, cout, z, h * w * cout, cout, s()), "zero_stuff")
+                tmp = self.TMP.data_ptr()
+                self._conv(z, h * w * cout, cout, wf, zb, tmp, h * w * cin, cin, F, h, w, cout, cin, 3)
+                dst = dcat[cin]                                  # fan-in: add to the decoder's skip gradient
+                for f in range(F):
+                    self._add2d(h * w, cin, tmp + 4 * f * h * w * cin, cin, dst.data_ptr() + 4 * cin * f, cin * F)
+            else:
+                nxt = self.dA.data_ptr() if dy != self.dA.data_ptr() else self.dB.data_ptr()
+                self._conv(dp, ho * wo * cout, cout, wf, zb, nxt, h * w * cin, cin, F, h, w, cout, cin, 3)
+                dy = nxt
+        # pillar feature net
+        for slot in range(F):
+            _lib.check(lib.himo_pfn_backward(self.n_pts[slot], net._voxel, net._centre, W, H, self.p["pfn.weight"].data_ptr(),
+                                             net.p["pfn.scale"].data_ptr(), net.p["pfn.shift"].data_ptr(), net.xyz_t[slot].data_ptr(),
+                                             net.ws_slots[slot].data_ptr(), self.dB0.data_ptr() + 4 * 32 * slot, 32 * F,
+                                             self.g["pfn.weight"].data_ptr(), 1 if slot else 0, self.ws.data_ptr(), self.ws.numel(), s()),
+                       "pfn_backward")
+
+    # ---- optimiser / data parallel -----------------------------------------------------------------------------
+    def allreduce(self):
+        """Mean of the flat gradient over ranks: ONE collective per step (RCCL over xGMI; gloo in the CPU tests)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
+            self.flat_g.div_(dist.get_world_size())
+
+    def adam_step(self, lr: float = 2e-4, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
+        self.step_count += 1
+        _lib.check(self.lib.himo_adam_step(self.flat_p.numel(), self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                                           self.flat_v.data_ptr(), lr, beta1, beta2, eps, self.step_count, _lib.stream_handle()), "adam")
+
+    def export_params(self) -> dict:
+        """spec-layout numpy parameter dict (BatchNorm constants unchanged) for SeFlowNet / the oracle."""
+        out = {k: v.cpu().numpy().copy() for k, v in self.net.p.items() if k in spec.param_shapes()}
+        for k in self.names:
+            if k in out:
+                out[k] = self.p[k].cpu().numpy().copy()
+        zr_w, zr_b = self.p["head.zr.weight"].cpu().numpy(), self.p["head.zr.bias"].cpu().numpy()
+        out["head.gru.z.weight"], out["head.gru.r.weight"] = zr_w[:, :128].copy(), zr_w[:, 128:].copy()
+        out["head.gru.z.bias"], out["head.gru.r.bias"] = zr_b[:128].copy(), zr_b[128:].copy()
+        out["head.gru.q.weight"], out["head.gru.q.bias"] = self.p["head.q.weight"].cpu().numpy().copy(), self.p["head.q.bias"].cpu().numpy().copy()
+        out["head.dec1.weight"], out["head.dec1.bias"] = self.p["head.dec1.weight"].cpu().numpy().copy(), self.p["head.dec1.bias"].cpu().numpy().copy()
+        out["head.dec2.weight"], out["head.dec2.bias"] = self.p["head.dec2.weight"].cpu().numpy()[:, :3].copy(), self.p["head.dec2.bias"].cpu().numpy()[:3].copy()
         return out

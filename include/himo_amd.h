@@ -325,6 +325,32 @@ int himo_affine_gelu_bwd(int64_t rows, int ch, const float* d_dy, int dy_pitch, 
                          const float* d_scale, float* d_dx, int dx_pitch, void* stream);
 /* zero the rows of v whose cell id is negative */
 int himo_mask_rows(int64_t n, int cols, const int32_t* d_pid, float* d_v, int pitch, void* stream);
+/* convolution backward: wf[k][k][cout][cin] = w[k][k][cin][cout] with mirrored taps (the data gradient of a stride-1 "same"
+ * convolution is himo_conv2d of dY with wf); zero-stuffing of dY for the stride-2 layers; the adjoint of himo_upsample2x;
+ * the 3x3 weight gradient of ONE image as a split-K MFMA product (flags bit 0: accumulate) */
+int himo_weight_flip(const float* d_w, int ksize, int cin, int cout, float* d_wf, void* stream);
+int himo_zero_stuff2x(int n_img, int h, int w, int c, const float* d_dy, int64_t dy_batch_stride, int dy_pitch,
+                      float* d_z, int64_t z_batch_stride, int z_pitch, void* stream);
+int himo_upsample2x_bwd(const float* d_dy, int dy_pitch, int h, int w, int c, float* d_dx, int dx_pitch, void* stream);
+int himo_add2d(int64_t rows, int cols, const float* d_b, int b_pitch, float* d_y, int y_pitch, void* stream);   /* y += b */
+/* column sums of a pitched [n][cout] matrix (bias gradients); workspace >= ceil(cout/128)*ceil(n/256)*512 bytes */
+int himo_colsum(int64_t n, const float* d_z, int z_pitch, int cout, float* d_out, unsigned flags, void* d_workspace,
+                size_t workspace_bytes, void* stream);
+/* backward of the pillar stage; d_pillar_workspace = the workspace himo_pillarize(n, ...) of the same sweep left behind.
+ * himo_pfn_backward: d loss / d pfn.weight [9][32] from the gradient of the sweep's 32 image channels (flags bit 0:
+ * accumulate).  himo_head_scatter: adjoint of himo_head_gather -- per-point rows [d img0 | d img1 | d dec] (128 columns)
+ * summed per pillar into channel groups group0 / group1 of d_db0 (other groups and empty cells zeroed) and d_ddec. */
+size_t himo_pfn_backward_workspace_bytes(void);
+int himo_pfn_backward(int64_t n, const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
+                      const float* d_pfn_weight, const float* d_pfn_scale, const float* d_pfn_shift,
+                      const float* d_xyz_t, const void* d_pillar_workspace, const float* d_dimage, int image_pitch,
+                      float* d_dweight, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);
+int himo_head_scatter(int64_t n, int grid_w, int grid_h, const void* d_pillar_workspace, const float* d_dhx, int dhx_pitch,
+                      float* d_db0, int b0_pitch, int group0, int group1, int n_groups, float* d_ddec, int dec_pitch,
+                      void* stream);
+size_t himo_conv_wgrad_workspace_bytes(int ho, int wo, int cin, int cout);
+int himo_conv3x3_wgrad(const float* d_x, int x_pitch, int h, int w, int cin, const float* d_dy, int dy_pitch, int cout,
+                       int stride, float* d_dw, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a9 helper (host memory, no GPU): LZ4-frame decoder for the compressed buffers of Feather V2 files as pandas /

@@ -162,3 +162,21 @@ def forward(params, pch1, pc0, pc1, pose_h1, pose0, pose1, return_intermediates:
         return out, {"imgs": imgs.numpy(), "dec": dec.numpy(), "valid0": valid0.numpy(), "pose_flow": pose_flow.numpy(),
                      "res": res.numpy()}
     return out
+
+
+def forward_train(params, pch1, pc0, pc1, pose_h1, pose0, pose1):
+    """Differentiable restatement for the training tests: ``params`` maps names to torch tensors (leaves that require
+    grad for the trainable ones; BatchNorm tensors are constants = frozen BN).  Returns (res (n_valid,3) with graph,
+    valid0 (N0,) bool, pc0 in pc1's frame (N0,3))."""
+    p0 = _t(pc0)[:, :3].float()
+    T0, Th = ego_transform(pose0, pose1), ego_transform(pose_h1, pose1)
+    p0t = transform_points(p0, T0)
+    pht = transform_points(pch1, Th)
+    p1 = _t(pc1)[:, :3].float()
+    img_h, *_ = pillar_image(params, pht)
+    img0, valid0, pid0, off0 = pillar_image(params, p0t)
+    img1, *_ = pillar_image(params, p1)
+    imgs = torch.stack([img_h, img0, img1])
+    dec = backbone(params, imgs)
+    res = head(params, img0, img1, dec, pid0[valid0], off0[valid0])
+    return res, valid0, p0t

@@ -71,3 +71,94 @@ def test_tiled_wgrad_with_accumulate(gpu):
     ref = (x.double().T @ dz.double()).float() * 2
     assert (dw - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
     assert (db - 2 * dz.double().sum(0).float()).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("stride,h,w,cin,cout,n", [(1, 24, 40, 64, 64, 2), (2, 32, 48, 32, 64, 3), (1, 16, 16, 192, 128, 1),
+                                                   (2, 16, 24, 128, 256, 1)])
+def test_conv3x3_backward_matches_autograd(gpu, stride, h, w, cin, cout, n):
+    from himo_amd.seflow.train import conv3x3_backward_nhwc
+    rng = np.random.default_rng(stride * 100 + cin)
+    x = rng.normal(size=(n, h, w, cin)).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    ho, wo = (h // 2, w // 2) if stride == 2 else (h, w)
+    dy = rng.normal(size=(n, ho, wo, cout)).astype(np.float32)
+    dx, dw, db = conv3x3_backward_nhwc(*(torch.from_numpy(a).to(gpu) for a in (x, wt)), torch.from_numpy(dy).to(gpu), stride)
+    tx = torch.from_numpy(x).permute(0, 3, 1, 2).double().requires_grad_(True)
+    tw = torch.from_numpy(wt).permute(3, 2, 0, 1).double().requires_grad_(True)
+    y = F.conv2d(tx, tw, None, stride=stride, padding=1)
+    (y * torch.from_numpy(dy).permute(0, 3, 1, 2).double()).sum().backward()
+    ref_dx = tx.grad.permute(0, 2, 3, 1).numpy()
+    ref_dw = tw.grad.permute(2, 3, 1, 0).numpy()
+    assert np.abs(dx.cpu().numpy() - ref_dx).max() <= 1e-4 * np.abs(ref_dx).max()
+    assert np.abs(dw.cpu().numpy() - ref_dw).max() <= 1e-4 * np.abs(ref_dw).max()
+    assert np.abs(db.cpu().numpy() - dy.sum((0, 1, 2))).max() <= 1e-3
+
+
+def test_upsample2x_backward_is_the_adjoint(gpu):
+    from himo_amd.seflow.train import upsample2x_backward_nhwc
+    rng = np.random.default_rng(5)
+    for h, w, c in [(8, 12, 8), (1, 5, 4), (32, 32, 64)]:
+        dy = rng.normal(size=(2 * h, 2 * w, c)).astype(np.float32)
+        dx = upsample2x_backward_nhwc(torch.from_numpy(dy).to(gpu)).cpu().numpy()
+        tx = torch.zeros((1, c, h, w), dtype=torch.float64, requires_grad=True)
+        y = F.interpolate(tx, scale_factor=2, mode="bilinear", align_corners=True)
+        (y * torch.from_numpy(dy).permute(2, 0, 1)[None].double()).sum().backward()
+        ref = tx.grad[0].permute(1, 2, 0).numpy()
+        assert np.abs(dx - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1.0), (h, w, c)
+
+
+def _sample(n, seed=0):
+    from himo_amd.synthetic import make_frame
+    f = make_frame(seed, n_points=n, n_instances=6)
+    rng = np.random.default_rng(seed)
+    pose0, pose1 = np.asarray(f["pose0"], np.float64), np.asarray(f["pose1"], np.float64)
+    pose_h = pose0.copy(); pose_h[:3, 3] -= pose1[:3, 3] - pose0[:3, 3]
+    pc0 = np.asarray(f["pc0"], np.float32)[:, :3]
+    pc1 = (pc0 + rng.normal(0, 0.05, pc0.shape)).astype(np.float32)[rng.permutation(len(pc0))[: n - 37]]
+    pch = (pc0 + rng.normal(0, 0.05, pc0.shape)).astype(np.float32)[rng.permutation(len(pc0))[: n - 101]]
+    return pch, pc0, pc1, pose_h, pose0, pose1
+
+
+def test_full_network_gradients_match_autograd(gpu):
+    """Every trainable tensor's gradient (pillar net, 16 encoder convs, decoder, head) against CPU autograd through the
+    oracle network, for the linear functional L = sum(res * G)."""
+    import oracle.seflow_oracle as so
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.train import SeFlowTrainer
+    params = spec.init_params(4)
+    pch, pc0, pc1, pose_h, pose0, pose1 = _sample(6000, seed=3)
+    tr = SeFlowTrainer(params, device=gpu, max_points=8000)
+    res = tr.forward(pch, pc0, pc1, pose_h, pose0, pose1)
+    rng = np.random.default_rng(9)
+    G = np.zeros((len(pc0), 4), np.float32)
+    G[:, :3] = rng.normal(0, 1.0, (len(pc0), 3)).astype(np.float32)
+    tr.backward(torch.from_numpy(G).to(gpu))
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in tr.g.items()}
+    res_gpu = res.cpu().numpy()
+
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    P = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    for k in P:
+        if k.endswith(".weight") or k.endswith(".bias"):
+            P[k].requires_grad_(True)
+    ref_res, valid, _ = so.forward_train(P, pch, pc0, pc1, pose_h, pose0, pose1)
+    v = valid.numpy()
+    assert np.abs(res_gpu[v][:, :3] - ref_res.detach().numpy()).max() <= 1e-4
+    assert np.all(res_gpu[~v] == 0)
+    (ref_res * torch.from_numpy(G[v][:, :3])).sum().backward()
+    ref = {k: P[k].grad.numpy() for k in P if P[k].grad is not None}
+    pairs = {k: ref[k] for k in got if k in ref}
+    pairs["head.zr.weight"] = np.concatenate([ref["head.gru.z.weight"], ref["head.gru.r.weight"]], 1)
+    pairs["head.zr.bias"] = np.concatenate([ref["head.gru.z.bias"], ref["head.gru.r.bias"]])
+    pairs["head.q.weight"], pairs["head.q.bias"] = ref["head.gru.q.weight"], ref["head.gru.q.bias"]
+    assert set(pairs) | {"head.dec2.weight", "head.dec2.bias"} >= set(got), set(got) - set(pairs)
+    worst = {}
+    for k, r in pairs.items():
+        g = got[k]
+        if k.startswith("head.dec2"):
+            g = g[..., :3]
+        scale = max(np.abs(r).max(), 1e-12)
+        worst[k] = np.abs(g - r).max() / scale
+    bad = {k: e for k, e in worst.items() if not e <= 2e-3}
+    assert not bad, bad
