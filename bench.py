@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "compdis"])
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "compdis", "train"])
     ap.add_argument("--frames-per-step", type=int, default=None, help="frames per rank per step")
     ap.add_argument("--points", type=int, default=POINTS_PER_FRAME)
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "f32"],
@@ -51,7 +51,12 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget for the baseline leg")
     ap.add_argument("--traffic-json", default=str(REPO / "profiles" / "traffic_latest.json"))
     a = ap.parse_args()
-    if a.workload == "pipeline":
+    if a.workload == "train":
+        a.steps = 10 if a.steps is None else a.steps
+        a.warmup = 2 if a.warmup is None else a.warmup
+        a.frames_per_step = 1 if a.frames_per_step is None else a.frames_per_step
+        a.precision = "f32"
+    elif a.workload == "pipeline":
         a.steps = 10 if a.steps is None else a.steps
         a.warmup = 2 if a.warmup is None else a.warmup
         a.frames_per_step = 8 if a.frames_per_step is None else a.frames_per_step
@@ -221,6 +226,26 @@ def main():
 
         def step():
             eng.run(batch, sensor_dt=0.1, refined=args.refined, out=out)
+    elif args.workload == "train":
+        # BASELINE config 5: self-supervised training, one sample per rank per optimiser step, ONE flat-gradient
+        # all-reduce over RCCL, Adam.  Labels: ~10 % of the points in 30 dynamic clusters.
+        from himo_amd.seflow import spec
+        from himo_amd.seflow.train import SeFlowTrainer
+        params = spec.init_params(0)
+        trainer = SeFlowTrainer(params, device=device, max_points=P)
+        samples = synthetic_samples(B, P, device, seed=rank)
+        g = torch.Generator(device=device); g.manual_seed(99 + rank)
+        labels = []
+        for _ in range(B):
+            pick = torch.rand(P, generator=g, device=device) < 0.1
+            lab = torch.randint(1, 31, (P,), generator=g, device=device, dtype=torch.int32) * pick.to(torch.int32)
+            labels.append((lab, lab.clone()))
+        result = {}
+
+        def step():
+            for smp, (l0, l1) in zip(samples, labels):
+                _, total = trainer.train_step(smp.pch1, smp.pc0, smp.pc1, smp.pose_h1, smp.pose0, smp.pose1, l0, l1, n_labels=31)
+                result["loss"] = total
     else:
         from himo_amd.pipeline import HiMoPipeline
         from himo_amd.seflow import spec
@@ -250,6 +275,9 @@ def main():
             d = got.astype(np.float64) - ref
             parity = {"comp_dis_mean_epe_vs_ref": float(np.linalg.norm(d, axis=1).mean()),
                       "comp_dis_max_abs_vs_ref": float(np.abs(d).max()), "bit_exact_fraction": float((got == ref).mean())}
+        elif args.workload == "train":
+            parity = {"loss_after_warmup": float(result["loss"].item()),
+                      "note": "gradient parity vs CPU autograd through the oracle network: tests/test_train_gpu.py"}
         elif not args.no_cpu_baseline:
             import seflow_oracle as so
             s = samples[0]
@@ -298,6 +326,21 @@ def main():
             workload = ("flow->comp_dis fused path only (a1-a4: ego-motion removal, dt0, flow2compDis; f64 chain, f32 I/O) "
                         "over a ragged HBM-resident batch; network forward NOT included")
             dtype = "f64"
+        elif args.workload == "train":
+            from himo_amd.seflow import spec
+            # forward + data-gradient convolutions run on conv3x3_mfma_kernel (float32 MFMA); 2 x the forward's 3x3 flops
+            # per step (forward + dgrad of the same shapes, stride-2 layers aside)
+            k = prof.get("conv3x3_mfma_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
+            n_steps = B * args.steps
+            alg_tf = 2.0 * spec.conv3x3_flops() * n_steps / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
+            roofline = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (v_mfma_f32_32x32x2_f32; forward + data gradient)",
+                        "achieved": alg_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": alg_tf / MFMA_F32_PEAK_TF,
+                        "traffic": None, "avg_launch_ms": k["avg_ms"], "launches_timed": k["count"],
+                        "share_of_step_time": k["total_ms"] / (elapsed * 1e3)}
+            workload = ("self-supervised TRAINING step (BASELINE config 5): pillarise 3 sweeps -> network forward with saved "
+                        "activations -> 4-term NN/Chamfer loss -> full backward -> flat-gradient all-reduce -> Adam; "
+                        "one 120k-point sample per GPU per step")
+            dtype = "f32"
         else:
             from himo_amd.seflow import spec
             bf = args.precision == "bf16x3"
@@ -334,7 +377,10 @@ def main():
                        "parallelism": f"frames sharded x{world}", "refined_output": bool(args.refined)},
             "roofline": roofline, "kernels": per_kernel, "parity": parity,
         }
-        if not args.no_cpu_baseline:
+        if args.workload == "train":
+            line["metric"] = "train_frames_per_sec_120k"
+            line["config"]["parallelism"] = f"data parallel x{world}, one flat all-reduce per step"
+        if not args.no_cpu_baseline and args.workload != "train":
             if args.workload == "compdis":
                 frames = [frame_to_host(batch, i) for i in range(min(8, B))]
                 line["cpu_baseline"] = cpu_baseline_compdis(frames, args.cpu_seconds)

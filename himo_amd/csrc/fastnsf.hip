@@ -28,15 +28,15 @@ constexpr int kWgRows = 256;     // point rows per block
 // partial[tile][b][128][128]: tile = (ci tile, co tile) = blockIdx.y, b = row chunk = blockIdx.x
 __global__ __launch_bounds__(256) void wgrad_partial_kernel(int64_t n, const float* __restrict__ X, int x_pitch, int cin,
                                                            const float* __restrict__ dZ, int z_pitch, int cout,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial, int rows_pb) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = wave & 1, wn = wave >> 1;            // wave tile: ci in [64 wm, +64), co in [64 wn, +64)
     const int li = lane & 31, lh = lane >> 5;
     const int co_tiles = (cout + 127) / 128;
     const int ci0 = ((int)blockIdx.y / co_tiles) * 128, co0 = ((int)blockIdx.y % co_tiles) * 128;
     X += ci0; dZ += co0; cin -= ci0; cout -= co0;       // this block's 128 x 128 window
-    const int64_t r0 = (int64_t)blockIdx.x * kWgRows;
-    const int64_t r1 = r0 + kWgRows < n ? r0 + kWgRows : n;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_pb;
+    const int64_t r1 = r0 + rows_pb < n ? r0 + rows_pb : n;
     floatx16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -94,11 +94,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 // bias gradient: column sums of dZ, two stages with fixed order
 __global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t n, const float* __restrict__ dZ, int z_pitch, int cout,
-                                                            float* __restrict__ partial) {
-    // block = 256 rows x 128 columns (column tile blockIdx.y): thread t sums column (t % 128) over rows of parity (t / 128)
+                                                            float* __restrict__ partial, int rows_pb) {
+    // block = rows_pb rows x 128 columns (column tile blockIdx.y): thread t sums column (t % 128) over rows of parity (t / 128)
     const int col = (int)blockIdx.y * 128 + (threadIdx.x & 127), half = threadIdx.x >> 7;
-    const int64_t r0 = (int64_t)blockIdx.x * kWgRows;
-    const int64_t r1 = r0 + kWgRows < n ? r0 + kWgRows : n;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_pb;
+    const int64_t r1 = r0 + rows_pb < n ? r0 + rows_pb : n;
     float s = 0.f;
     if (col < cout)
         for (int64_t r = r0 + half; r < r1; r += 2) s += dZ[r * z_pitch + col];
@@ -109,13 +109,49 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t n, const fl
     if (half == 0) partial[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 + lc] = sh[lc] + sh[lc + 128];
 }
 
-__global__ __launch_bounds__(128) void colsum_reduce_kernel(const float* __restrict__ partial, int n_blocks, int cout,
-                                                           float* __restrict__ db, int accumulate) {
-    const int col = (int)blockIdx.x * 128 + threadIdx.x;
-    if (col >= cout) return;
+// the same partial sums with 16-byte loads: 8 row groups x 32 float4 columns per block (needs 16-byte aligned rows)
+__global__ __launch_bounds__(256) void colsum_partial_v4_kernel(int64_t n, const float* __restrict__ dZ, int z_pitch, int cout,
+                                                               float* __restrict__ partial, int rows_pb) {
+    const int q = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int col = (int)blockIdx.y * 128 + q * 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_pb;
+    const int64_t r1 = r0 + rows_pb < n ? r0 + rows_pb : n;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < cout) {
+#pragma unroll 4
+        for (int64_t r = r0 + grp; r < r1; r += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(dZ + r * z_pitch + col);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    __shared__ float4 sh[8][32];
+    sh[grp][q] = s;
+    __syncthreads();
+    if (grp == 0) {
+        float4 t = sh[0][q];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) { t.x += sh[g][q].x; t.y += sh[g][q].y; t.z += sh[g][q].z; t.w += sh[g][q].w; }
+        *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 + q * 4) = t;
+    }
+}
+
+// 8 groups x 128 columns: group g sums partials g, g+8, ...; fixed-order combine
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ partial, int n_blocks, int cout,
+                                                            float* __restrict__ db, int accumulate) {
+    __shared__ float sh[8][128];
+    const int lc = threadIdx.x & 127, grp = threadIdx.x >> 7;
+    const int col = (int)blockIdx.x * 128 + lc;
     float s = 0.f;
-    for (int b = 0; b < n_blocks; ++b) s += partial[((int64_t)blockIdx.x * n_blocks + b) * 128 + threadIdx.x];
-    db[col] = accumulate ? db[col] + s : s;
+    if (col < cout)
+        for (int b = grp; b < n_blocks; b += 8) s += partial[((int64_t)blockIdx.x * n_blocks + b) * 128 + lc];
+    sh[grp][lc] = s;
+    __syncthreads();
+    if (grp == 0 && col < cout) {
+        float t = sh[0][lc];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += sh[g][lc];
+        db[col] = accumulate ? db[col] + t : t;
+    }
 }
 
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ wt) {
@@ -224,6 +260,27 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 
 using namespace himo;
 
+static int wgrad_rows_per_block(int64_t n, int tiles) {
+    const int64_t target_blocks = 512 / tiles > 0 ? 512 / tiles : 1;
+    int64_t rows = (n + target_blocks - 1) / target_blocks;
+    if (rows < kWgRows) rows = kWgRows;
+    return (int)((rows + 7) / 8 * 8);
+}
+
+// column sums into d_out; colpart holds ceil(cout/128) * nb * 128 floats with nb <= n / 256 + 1
+static int colsum_launch(int64_t n, const float* d_z, int z_pitch, int cout, float* d_out, int acc, float* colpart, hipStream_t s) {
+    const int co_tiles = (cout + 127) / 128;
+    const int rows_pb = wgrad_rows_per_block(n, 1);
+    const int nb = (int)((n + rows_pb - 1) / rows_pb);
+    if ((z_pitch & 3) == 0 && (cout & 3) == 0 && (reinterpret_cast<uintptr_t>(d_z) & 15) == 0)
+        hipLaunchKernelGGL(colsum_partial_v4_kernel, dim3(nb, co_tiles), dim3(256), 0, s, n, d_z, z_pitch, cout, colpart, rows_pb);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, co_tiles), dim3(256), 0, s, n, d_z, z_pitch, cout, colpart, rows_pb);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(co_tiles), dim3(1024), 0, s, colpart, nb, cout, d_out, acc);
+    HIMO_LAUNCH_CHECK("colsum kernels");
+    return HIMO_OK;
+}
+
 static size_t wgrad_ws(int64_t n_rows, int cin, int cout) {
     const size_t nb = (size_t)((n_rows + kWgRows - 1) / kWgRows) + 1;
     const size_t tiles = (size_t)((cin + 127) / 128) * ((cout + 127) / 128), ctiles = (size_t)(cout + 127) / 128;
@@ -239,21 +296,22 @@ extern "C" int himo_linear_wgrad_ex(int64_t n, const float* d_x, int x_pitch, in
     if (n < 1 || cin < 1 || cout < 1 || !d_x || !d_dz || !d_dw || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
     if (workspace_bytes < wgrad_ws(n, cin, cout) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    const int nb = (int)((n + kWgRows - 1) / kWgRows);
     const int ci_tiles = (cin + 127) / 128, co_tiles = (cout + 127) / 128;
+    // rows per block: 256 for short inputs, longer runs when that would mean > ~512 blocks (the partial tiles, 64 KB
+    // each, are written and read back: fewer, longer blocks keep that traffic below the operand traffic)
+    const int rows_pb = wgrad_rows_per_block(n, ci_tiles * co_tiles);
+    const int nb = (int)((n + rows_pb - 1) / rows_pb);
     float* partial = reinterpret_cast<float*>(d_workspace);
     float* colpart = partial + (size_t)ci_tiles * co_tiles * (nb + 1) * 128 * 128;
     const int acc = (flags & 1u) ? 1 : 0;
     {
         ProfScope ps("wgrad_partial_kernel", s);
-        hipLaunchKernelGGL(wgrad_partial_kernel, dim3(nb, ci_tiles * co_tiles), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch, cout, partial);
+        hipLaunchKernelGGL(wgrad_partial_kernel, dim3(nb, ci_tiles * co_tiles), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch, cout,
+                           partial, rows_pb);
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cin * cout + 255) / 256), dim3(256), 0, s, partial, nb, cin, cout, d_dw, acc);
-    if (d_db) {
-        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, co_tiles), dim3(256), 0, s, n, d_dz, z_pitch, cout, colpart);
-        hipLaunchKernelGGL(colsum_reduce_kernel, dim3(co_tiles), dim3(128), 0, s, colpart, nb, cout, d_db, acc);
-    }
     HIMO_LAUNCH_CHECK("wgrad kernels");
+    if (d_db) return colsum_launch(n, d_dz, z_pitch, cout, d_db, acc, colpart, s);
     return HIMO_OK;
 }
 
@@ -269,12 +327,7 @@ extern "C" int himo_colsum(int64_t n, const float* d_z, int z_pitch, int cout, f
     if (n < 1 || cout < 1 || z_pitch < cout || !d_z || !d_out || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
     const int nb = (int)((n + kWgRows - 1) / kWgRows), co_tiles = (cout + 127) / 128;
     if (workspace_bytes < (size_t)co_tiles * nb * 128 * 4) return HIMO_ERR_WORKSPACE;
-    float* colpart = reinterpret_cast<float*>(d_workspace);
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, co_tiles), dim3(256), 0, s, n, d_z, z_pitch, cout, colpart);
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(co_tiles), dim3(128), 0, s, colpart, nb, cout, d_out, (flags & 1u) ? 1 : 0);
-    HIMO_LAUNCH_CHECK("colsum kernels");
-    return HIMO_OK;
+    return colsum_launch(n, d_z, z_pitch, cout, d_out, (flags & 1u) ? 1 : 0, reinterpret_cast<float*>(d_workspace), (hipStream_t)stream);
 }
 
 extern "C" int himo_transpose(const float* d_w, int rows, int cols, float* d_wt, void* stream) {

@@ -278,11 +278,21 @@ __global__ __launch_bounds__(256) void pfn_backward_kernel(PillarBwdArgs a) {
     }
 }
 
-__global__ __launch_bounds__(288) void pfn_backward_reduce_kernel(const float* __restrict__ partial, int n_blocks, float* __restrict__ dw,
+// one block per feature k: 8 groups x 32 channels, each group sums every 8th partial, fixed-order combine
+__global__ __launch_bounds__(256) void pfn_backward_reduce_kernel(const float* __restrict__ partial, int n_blocks, float* __restrict__ dw,
                                                                   int accumulate) {
+    __shared__ float sh[8][32];
+    const int c = threadIdx.x & 31, grp = threadIdx.x >> 5, k = blockIdx.x;
     float t = 0.f;
-    for (int b = 0; b < n_blocks; ++b) t += partial[(int64_t)b * 288 + threadIdx.x];
-    dw[threadIdx.x] = accumulate ? dw[threadIdx.x] + t : t;
+    for (int b = grp; b < n_blocks; b += 8) t += partial[(int64_t)b * 288 + k * 32 + c];
+    sh[grp][c] = t;
+    __syncthreads();
+    if (grp == 0) {
+        float r = sh[0][c];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) r += sh[g][c];
+        dw[k * 32 + c] = accumulate ? dw[k * 32 + c] + r : r;
+    }
 }
 
 // adjoint of head_gather_kernel: the per-point gradient rows are summed per cell (ascending point order) into the
@@ -411,7 +421,7 @@ extern "C" int himo_pfn_backward(int64_t n, const float* h_voxel, const float* h
         ProfScope ps("pfn_backward_kernel", s);
         hipLaunchKernelGGL(pfn_backward_kernel, dim3(kPfnBwdBlocks), dim3(256), 0, s, a);
     }
-    hipLaunchKernelGGL(pfn_backward_reduce_kernel, dim3(1), dim3(288), 0, s, a.partial, kPfnBwdBlocks, d_dweight, (flags & 1u) ? 1 : 0);
+    hipLaunchKernelGGL(pfn_backward_reduce_kernel, dim3(9), dim3(256), 0, s, a.partial, kPfnBwdBlocks, d_dweight, (flags & 1u) ? 1 : 0);
     HIMO_LAUNCH_CHECK("pfn_backward kernels");
     return HIMO_OK;
 }

@@ -282,6 +282,117 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(ConvWgradArgs a
                 out[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wn * 64 + j * 32 + li] = acc[i][j][r];
 }
 
+// ---- weight gradient, LDS-tiled ------------------------------------------------------------------------------------
+// Block tile: 64 input channels x 64 output channels x all 9 taps, accumulated over a run of pixel tiles (TR output rows
+// x 32 output columns each).  Per pixel tile the block stages dY [TR*32 px][64 co] and the X halo [HR rows x HC cols][64 ci]
+// in LDS ONCE and all nine taps read it (shifted), so a k-step is 9 MFMAs on 10 LDS reads -- matrix-core bound, where
+// the fragment-from-global kernel above is load bound.  Wave (wm, wn) owns the 32x32 sub-tile for all taps: 144
+// accumulators.  Columns are XOR-swizzled so that the two half-waves of a fragment (two neighbouring output pixels)
+// land in different banks.  Stride 1: TR = 2, halo 4 x 34; stride 2: TR = 1, halo 3 x 65.
+struct ConvWgradTiledArgs {
+    const float* x; int64_t x_bs; int x_pitch;
+    const float* dy; int64_t dy_bs; int dy_pitch;
+    int n_img, H, W, Ho, Wo, cin, cout;   // H, W: input image; Ho, Wo: output-gradient image
+    int tiles_per_chunk;           // pixel tiles per block
+    float* partial;                // [ci_tile][co_tile][chunk][9][64][64]
+};
+
+template <int S> struct WgTile {
+    static constexpr int TR = S == 1 ? 2 : 1;
+    static constexpr int HR = (TR - 1) * S + 3, HC = 31 * S + 3;
+    static constexpr int HaloPx = HR * HC, TilePx = TR * 32;
+};
+
+// halo pixels of the two half-waves differ by S in index: swizzle on the bit that differs
+template <int S> __device__ inline int swz(int px, int col) { return px * 64 + (col ^ (((px >> (S - 1)) & 1) << 5)); }
+
+template <int S>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(ConvWgradTiledArgs a) {
+    using T = WgTile<S>;
+    __shared__ float Xs[T::HaloPx * 64];
+    __shared__ float Ys[T::TilePx * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int co_tiles = a.cout / 64;
+    const int ci0 = ((int)blockIdx.y / co_tiles) * 64, co0 = ((int)blockIdx.y % co_tiles) * 64;
+    const int ci_quads = min(16, (a.cin - ci0) / 4);            // a 32-channel input (enc1.0) fills half the tile
+    const int col_blocks = a.Wo / 32, row_groups = a.Ho / T::TR;
+    const int tiles_per_img = col_blocks * row_groups;
+    const int n_tiles = a.n_img * tiles_per_img;
+    const int t0 = (int)blockIdx.x * a.tiles_per_chunk;
+    const int t1 = min(t0 + a.tiles_per_chunk, n_tiles);
+
+    floatx16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int t = t0; t < t1; ++t) {
+        const int img = t / tiles_per_img;
+        const int rem = t - img * tiles_per_img;
+        const int y0 = (rem / col_blocks) * T::TR, x0 = (rem % col_blocks) * 32;       // output coordinates
+        const float* xi = a.x + img * a.x_bs + ci0;
+        const float* di = a.dy + img * a.dy_bs + co0;
+        __syncthreads();
+        for (int e = threadIdx.x; e < T::HaloPx * 16; e += 256) {
+            const int px = e >> 4, q = e & 15;
+            const int hy = px / T::HC, hx = px - hy * T::HC;
+            const int iy = y0 * S - 1 + hy, ix = x0 * S - 1 + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < ci_quads && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v = *reinterpret_cast<const float4*>(xi + ((int64_t)iy * a.W + ix) * a.x_pitch + q * 4);
+            *reinterpret_cast<float4*>(&Xs[swz<S>(px, q * 4)]) = v;
+        }
+        for (int e = threadIdx.x; e < T::TilePx * 16; e += 256) {
+            const int px = e >> 4, q = e & 15;
+            const int ry = px >> 5, rx = px & 31;
+            const float4 v = *reinterpret_cast<const float4*>(di + ((int64_t)(y0 + ry) * a.Wo + x0 + rx) * a.dy_pitch + q * 4);
+            *reinterpret_cast<float4*>(&Ys[swz<1>(px, q * 4)]) = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int kk = 0; kk < T::TilePx / 2; ++kk) {
+            const int r = kk >> 4, c = ((kk & 15) << 1) + lh;
+            const float b = Ys[swz<1>(r * 32 + c, wn * 32 + li)];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float av = Xs[swz<S>((r * S + ky) * T::HC + c * S + kx, wm * 32 + li)];
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[ky * 3 + kx], 0, 0, 0);
+                }
+        }
+    }
+    float* out = a.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 * 64 * 64;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            out[t * 4096 + (wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + wn * 32 + li] = acc[t][r];
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_tiled_reduce_kernel(const float* __restrict__ partial, int chunks, int cin, int cout,
+                                                                      float* __restrict__ dW, int accumulate) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= 9ll * cin * cout) return;
+    const int co = (int)(e % cout);
+    const int ci = (int)((e / cout) % cin);
+    const int tap = (int)(e / ((int64_t)cout * cin));
+    const int tile = (ci / 64) * (cout / 64) + co / 64;
+    const float* p = partial + ((int64_t)tile * chunks) * 9 * 4096 + tap * 4096 + (ci % 64) * 64 + (co % 64);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four independent chains: more loads in flight, fixed order
+    int b = 0;
+    for (; b + 3 < chunks; b += 4) {
+        s0 += p[(int64_t)b * 9 * 4096]; s1 += p[(int64_t)(b + 1) * 9 * 4096];
+        s2 += p[(int64_t)(b + 2) * 9 * 4096]; s3 += p[(int64_t)(b + 3) * 9 * 4096];
+    }
+    for (; b < chunks; ++b) s0 += p[(int64_t)b * 9 * 4096];
+    const float s = (s0 + s1) + (s2 + s3);
+    dW[e] = accumulate ? dW[e] + s : s;
+}
+
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int cin, int cout,
                                                                 float* __restrict__ dW, int accumulate) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -445,5 +556,54 @@ extern "C" int himo_add2d(int64_t rows, int cols, const float* d_b, int b_pitch,
     if (!d_b || !d_y) return HIMO_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(add2d_kernel, HIMO_GRID(rows * cols), rows, cols, d_b, b_pitch, d_y, y_pitch);
     HIMO_LAUNCH_CHECK("add2d_kernel");
+    return HIMO_OK;
+}
+
+static int wgrad_tiled_chunks(int n_tiles, int tiles_xy) {
+    // ~2 blocks per CU over the whole launch, at least 4 pixel tiles per block (each block writes 144 KB of partials)
+    int chunks = (2 * 256 + tiles_xy - 1) / tiles_xy;
+    if (chunks > n_tiles / 4) chunks = n_tiles / 4;
+    if (chunks < 1) chunks = 1;
+    return chunks;
+}
+
+static bool wgrad_tiled_ok(int h, int w, int cin, int cout, int stride) {
+    if (stride == 1) return !(h & 1) && !(w % 32) && !(cin % 64) && !(cout % 64);
+    return stride == 2 && !(h & 1) && !(w % 64) && (cin == 32 || !(cin % 64)) && !(cout % 64);
+}
+
+extern "C" size_t himo_conv_wgrad_batch_workspace_bytes(int n_img, int h, int w, int cin, int cout, int stride) {
+    if (!wgrad_tiled_ok(h, w, cin, cout, stride)) return 0;
+    const int ho = h / stride, wo = w / stride;
+    const int n_tiles = n_img * (ho / (stride == 1 ? 2 : 1)) * (wo / 32), tiles_xy = ((cin + 63) / 64) * (cout / 64);
+    return (size_t)tiles_xy * wgrad_tiled_chunks(n_tiles, tiles_xy) * 9 * 4096 * 4 + 64;
+}
+
+// 3x3 (pad 1) weight gradient over a batch of images (frames), LDS-tiled.  stride 1: h even, w % 32 == 0, cin % 64 == 0;
+// stride 2: h even, w % 64 == 0, cin == 32 or cin % 64 == 0; cout % 64 == 0, pitches % 4 == 0
+// (HIMO_ERR_UNSUPPORTED otherwise: use himo_conv3x3_wgrad)
+extern "C" int himo_conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int cin,
+                                        const float* d_dy, int64_t dy_batch_stride, int dy_pitch, int cout, int stride, float* d_dw,
+                                        unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!d_x || !d_dy || !d_dw || !d_workspace || n_img < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return HIMO_ERR_INVALID_ARGUMENT;
+    if (!wgrad_tiled_ok(h, w, cin, cout, stride) || (x_pitch & 3) || (dy_pitch & 3) || (x_batch_stride & 3) || (dy_batch_stride & 3))
+        return HIMO_ERR_UNSUPPORTED;
+    if (workspace_bytes < himo_conv_wgrad_batch_workspace_bytes(n_img, h, w, cin, cout, stride) || !aligned16(d_workspace))
+        return HIMO_ERR_WORKSPACE;
+    const int ho = h / stride, wo = w / stride;
+    const int n_tiles = n_img * (ho / (stride == 1 ? 2 : 1)) * (wo / 32), tiles_xy = ((cin + 63) / 64) * (cout / 64);
+    const int chunks = wgrad_tiled_chunks(n_tiles, tiles_xy);
+    ConvWgradTiledArgs a{d_x, x_batch_stride, x_pitch, d_dy, dy_batch_stride, dy_pitch, n_img, h, w, ho, wo, cin, cout,
+                         (n_tiles + chunks - 1) / chunks, reinterpret_cast<float*>(d_workspace)};
+    const int grid_x = (n_tiles + a.tiles_per_chunk - 1) / a.tiles_per_chunk;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        ProfScope ps("conv_wgrad_tiled_kernel", s);
+        if (stride == 1) hipLaunchKernelGGL(conv_wgrad_tiled_kernel<1>, dim3(grid_x, tiles_xy), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(conv_wgrad_tiled_kernel<2>, dim3(grid_x, tiles_xy), dim3(256), 0, s, a);
+    }
+    hipLaunchKernelGGL(conv_wgrad_tiled_reduce_kernel, dim3((unsigned)((9ll * cin * cout + 255) / 256)), dim3(256), 0, s, a.partial, grid_x,
+                       cin, cout, d_dw, (flags & 1u) ? 1 : 0);
+    HIMO_LAUNCH_CHECK("conv_wgrad_tiled kernels");
     return HIMO_OK;
 }

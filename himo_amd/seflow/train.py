@@ -37,6 +37,8 @@ _lib.register({
     "himo_zero_stuff2x": (c_i, [c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p]),
     "himo_upsample2x_bwd": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "himo_conv_wgrad_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i, c_i]),
+    "himo_conv_wgrad_batch_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i, c_i, c_i, c_i]),
+    "himo_conv3x3_wgrad_batch": (c_i, [c_i, c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_i, c_i, c_p, ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
     "himo_conv3x3_wgrad": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
 })
 
@@ -62,6 +64,12 @@ def conv3x3_backward_nhwc(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tenso
     else:
         dx = conv2d_nhwc(dy, wf, zero_b)
     dw = torch.empty_like(weight)
+    need = int(lib.himo_conv_wgrad_batch_workspace_bytes(n, h, w, cin, cout, stride))
+    if need:                                                                                    # LDS-tiled batch kernel
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.himo_conv3x3_wgrad_batch(n, x.data_ptr(), h * w * cin, cin, h, w, cin, dy.data_ptr(), ho * wo * cout, cout, cout,
+                                                stride, dw.data_ptr(), 0, ws.data_ptr(), ws.numel(), s()), "himo_conv3x3_wgrad_batch")
+        return dx, dw, dy.sum((0, 1, 2))
     ws = torch.empty(int(lib.himo_conv_wgrad_workspace_bytes(ho, wo, cin, cout)), dtype=torch.uint8, device=x.device)
     for i in range(n):
         _lib.check(lib.himo_conv3x3_wgrad(x[i].data_ptr(), cin, h, w, cin, dy[i].data_ptr(), cout, cout, stride, dw.data_ptr(),
@@ -206,6 +214,16 @@ _lib.register({
 })
 
 
+def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
+    """In-place mean over the ranks of the default process group (no-op without one): the data-parallel exchange of a
+    training step is this single collective on the flat gradient buffer."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+    return flat
+
+
 class SeFlowTrainer:
     """Whole-network training step.  Conventions (PARITY UNPINNED, this build's own): float32 MFMA kernels, BatchNorm
     fully frozen (running statistics AND affine folded into constant scale / shift), trainable = every weight and bias.
@@ -216,8 +234,15 @@ class SeFlowTrainer:
         tr.allreduce(); tr.adam_step(lr)
     """
 
-    def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, seed: int = 0):
+    def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, seed: int = 0,
+                 precision: str = "bf16x3"):
+        """``precision``: "bf16x3" runs every stride-1 convolution of the forward and data-gradient passes as split-bf16
+        on the matrix cores (float32-class accuracy, csrc/convbf.hip; weights are re-packed after every optimiser step);
+        "f32" keeps float32 MFMA.  Weight gradients are float32 MFMA either way."""
         from .model import SeFlowNet
+        if precision not in ("bf16x3", "f32"):
+            raise ValueError(precision)
+        self.precision = precision
         self.lib = _lib.load()
         self.device = dev = device if device is not None else _lib.require_gpu()
         params = spec.init_params(seed) if params is None else params
@@ -284,6 +309,11 @@ class SeFlowTrainer:
         self.dCO = [buf((H // 2) * (W // 2) * 128) for _ in range(2)]   # d coarse of dec3 / dec2
         self.WF = buf(3 * 3 * 512 * 256)                         # flipped / transposed weights of the layer being differentiated
         ws = max(int(self.lib.himo_conv_wgrad_workspace_bytes(H // 4, W // 4, 512, 256)),
+                 max(int(self.lib.himo_conv_wgrad_batch_workspace_bytes(n, h_, w_, ci, co, st)) for n, h_, w_, ci, co, st in
+                     [(F, H // 2, W // 2, 64, 64, 1), (F, H // 4, W // 4, 128, 128, 1), (F, H // 8, W // 8, 256, 256, 1),
+                      (1, H // 4, W // 4, 512, 256, 1), (1, H // 4, W // 4, 256, 256, 1), (1, H // 2, W // 2, 256, 128, 1),
+                      (1, H // 2, W // 2, 128, 128, 1), (1, H, W, 128, 64, 1), (1, H, W, 64, 64, 1),
+                      (F, H, W, 32, 64, 2), (F, H // 2, W // 2, 64, 128, 2), (F, H // 4, W // 4, 128, 256, 2)]),
                  int(self.lib.himo_conv_wgrad_workspace_bytes(H, W, 128, 64)),
                  int(self.lib.himo_conv_wgrad_workspace_bytes(H // 2, W // 2, 256, 128)),
                  int(self.lib.himo_wgrad_workspace_bytes_ex(H * W, 96, 64)),
@@ -293,17 +323,43 @@ class SeFlowTrainer:
                  int(self.lib.himo_pfn_backward_workspace_bytes()))
         self.ws = torch.empty(ws + 64, dtype=torch.uint8, device=dev)
         self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
+        # split-bf16 copies of the convolution weights (forward) and a scratch for the flipped ones (data gradient)
+        self.packed = {}
+        if precision == "bf16x3":
+            for k in self.names:
+                v = self.p[k]
+                if k.endswith(".weight") and v.dim() == 4:
+                    ks, _, cin, cout = v.shape
+                    self.packed[k] = torch.empty(int(self.lib.himo_conv_packed_weight_bytes(ks, cin, cout)), dtype=torch.uint8, device=dev)
+            self.WFP = torch.empty(int(self.lib.himo_conv_packed_weight_bytes(3, 512, 256)), dtype=torch.uint8, device=dev)
+            net.packed = self.packed                      # the decoder forward runs through net._conv
+        self._repack()
+
+    def _repack(self):
+        """refresh the split-bf16 weight copies (after construction and after every optimiser step)"""
+        for k, buf in self.packed.items():
+            ks, _, cin, cout = self.p[k].shape
+            _lib.check(self.lib.himo_conv_pack_weights(self.p[k].data_ptr(), ks, cin, cout, buf.data_ptr(), _lib.stream_handle()), "pack")
 
     # ---- launch helpers (raw device addresses: most operands are channel groups of wider buffers) --------------
-    def _conv(self, x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride=1):
+    def _conv(self, x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride=1, packed=None):
         d = ConvDesc()
         d.x, d.x_batch_stride, d.x_pitch = x, x_bs, x_pitch
         d.w = w; d.bias = bias
+        d.w_packed = packed
         d.y, d.y_batch_stride, d.y_pitch = y, y_bs, y_pitch
         d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = n, h, wd, cin, cout, ks, stride, EPI_BIAS
         _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), "himo_conv2d(train)")
 
+    def _wgrad3_batch(self, n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, gname, stride=1):
+        """weight gradient over n images in one launch (LDS-tiled kernel)"""
+        _lib.check(self.lib.himo_conv3x3_wgrad_batch(n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, stride,
+                                                     self.g[gname].data_ptr(), 0, self.ws.data_ptr(), self.ws.numel(),
+                                                     _lib.stream_handle()), "conv3x3_wgrad_batch")
+
     def _wgrad3(self, x, x_pitch, h, w, cin, dy, dy_pitch, cout, stride, gname, acc):
+        if stride == 1 and not acc:
+            return self._wgrad3_batch(1, x, 0, x_pitch, h, w, cin, dy, 0, dy_pitch, cout, gname)
         _lib.check(self.lib.himo_conv3x3_wgrad(x, x_pitch, h, w, cin, dy, dy_pitch, cout, stride, self.g[gname].data_ptr(),
                                                1 if acc else 0, self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle()), "conv3x3_wgrad")
 
@@ -317,8 +373,12 @@ class SeFlowTrainer:
                                                  _lib.stream_handle()), "linear_wgrad")
 
     def _flip(self, name, ks, cin, cout):
+        """flipped / transposed weights of one layer for its data gradient: (float32 address, split-bf16 address or None)"""
         _lib.check(self.lib.himo_weight_flip(self.p[f"{name}.weight"].data_ptr(), ks, cin, cout, self.WF.data_ptr(), _lib.stream_handle()), "flip")
-        return self.WF.data_ptr()
+        if self.precision != "bf16x3":
+            return self.WF.data_ptr(), None
+        _lib.check(self.lib.himo_conv_pack_weights(self.WF.data_ptr(), ks, cout, cin, self.WFP.data_ptr(), _lib.stream_handle()), "pack")
+        return self.WF.data_ptr(), self.WFP.data_ptr()
 
     def _add2d(self, rows, cols, b, b_pitch, y, y_pitch):
         _lib.check(self.lib.himo_add2d(rows, cols, b, b_pitch, y, y_pitch, _lib.stream_handle()), "add2d")
@@ -342,8 +402,9 @@ class SeFlowTrainer:
         for li, (name, cin, cout, stride, h, w, ho, wo, last) in enumerate(self.layers):
             self.inputs.append((src, src_bs, src_pitch))
             pre = self.PRE[li]
+            pk = self.packed.get(f"{name}.weight")
             self._conv(src, src_bs, src_pitch, self.p[f"{name}.weight"].data_ptr(), self.p[f"{name}.bias"].data_ptr(),
-                       pre.data_ptr(), ho * wo * cout, cout, F, h, w, cin, cout, 3, stride)
+                       pre.data_ptr(), ho * wo * cout, cout, F, h, w, cin, cout, 3, stride, packed=None if pk is None else pk.data_ptr())
             sc, sh = net.p[f"{name}.scale"].data_ptr(), net.p[f"{name}.shift"].data_ptr()
             if last:
                 dst = cat[cout]
@@ -381,25 +442,28 @@ class SeFlowTrainer:
         # u5
         self._wgrad3(work0.data_ptr(), out, h2, w2, out, d_out, out, out, 1, f"{name}.u5.weight", False)
         self._colsum(P, d_out, out, out, f"{name}.u5.bias")
-        self._conv(d_out, 0, out, self._flip(f"{name}.u5", 3, out, out), zb, d_in, 0, out, 1, h2, w2, out, out, 3)
+        wf, wp = self._flip(f"{name}.u5", 3, out, out)
+        self._conv(d_out, 0, out, wf, zb, d_in, 0, out, 1, h2, w2, out, out, 3, packed=wp)
         # u4
         self._wgrad3(cat.data_ptr(), 2 * lat, h2, w2, 2 * lat, d_in, out, out, 1, f"{name}.u4.weight", False)
         self._colsum(P, d_in, out, out, f"{name}.u4.bias")
         dcat = self.dCAT.data_ptr()
-        self._conv(d_in, 0, out, self._flip(f"{name}.u4", 3, 2 * lat, out), zb, dcat, 0, 2 * lat, 1, h2, w2, out, 2 * lat, 3)
+        wf, wp = self._flip(f"{name}.u4", 3, 2 * lat, out)
+        self._conv(d_in, 0, out, wf, zb, dcat, 0, 2 * lat, 1, h2, w2, out, 2 * lat, 3, packed=wp)
         # u3 (1x1 on the skip): gradient rows are the right half of dCAT
         self._wgrad1(P, skip.data_ptr(), skip_c, skip_c, dcat + 4 * lat, 2 * lat, lat, f"{name}.u3")
-        wt = self._flip(f"{name}.u3", 1, skip_c, lat)                       # [lat][skip_c]
+        wt, wp = self._flip(f"{name}.u3", 1, skip_c, lat)                   # [lat][skip_c]
         if skip_acc:
-            self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, self.TMP.data_ptr(), 0, skip_c, 1, 1, P, lat, skip_c, 1)
+            self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, self.TMP.data_ptr(), 0, skip_c, 1, 1, P, lat, skip_c, 1, packed=wp)
             self._add2d(P, skip_c, self.TMP.data_ptr(), skip_c, d_skip, skip_c)
         else:
-            self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, d_skip, 0, skip_c, 1, 1, P, lat, skip_c, 1)
+            self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, d_skip, 0, skip_c, 1, 1, P, lat, skip_c, 1, packed=wp)
         # upsample, u1 (1x1 on the coarse map)
         dtmp = self.dTMPc.data_ptr()
         _lib.check(lib.himo_upsample2x_bwd(dcat, 2 * lat, ch, cw, lat, dtmp, lat, s()), "upsample2x_bwd")
         self._wgrad1(ch * cw, coarse.data_ptr(), c_in, c_in, dtmp, lat, lat, f"{name}.u1")
-        self._conv(dtmp, 0, lat, self._flip(f"{name}.u1", 1, c_in, lat), zb, d_coarse, 0, c_in, 1, 1, ch * cw, lat, c_in, 1)
+        wt, wp = self._flip(f"{name}.u1", 1, c_in, lat)
+        self._conv(dtmp, 0, lat, wt, zb, d_coarse, 0, c_in, 1, 1, ch * cw, lat, c_in, 1, packed=wp)
 
     def backward(self, dres: torch.Tensor):
         """dres [n0,4] = d loss / d res.  Gradients of every trainable tensor land in ``self.flat_g``."""
@@ -421,7 +485,8 @@ class SeFlowTrainer:
         self._wgrad3(u.data_ptr(), 64, H, W, 64, self.dDEC.data_ptr(), 64, 64, 1, "dec4.weight", False)
         self._colsum(H * W, self.dDEC.data_ptr(), 64, 64, "dec4.bias")
         d_u = self.dWORK[0].data_ptr()
-        self._conv(self.dDEC.data_ptr(), 0, 64, self._flip("dec4", 3, 64, 64), zb, d_u, 0, 64, 1, H, W, 64, 64, 3)
+        wf, wp = self._flip("dec4", 3, 64, 64)
+        self._conv(self.dDEC.data_ptr(), 0, 64, wf, zb, d_u, 0, 64, 1, H, W, 64, 64, 3, packed=wp)
         # decoder blocks, last to first
         d_t, d_s = self.dCO[0].data_ptr(), self.dCO[1].data_ptr()
         self._block_bwd("dec3", net.T[1], 128, H // 2, W // 2, net.B0, 32 * F, 64, 64, net.CAT3, net.U[0], d_u, self.dWORK[1].data_ptr(),
@@ -447,20 +512,19 @@ class SeFlowTrainer:
                 _lib.check(lib.himo_affine_gelu_bwd(F * ho * wo, cout, dy, cout, pre.data_ptr(), cout, sc, dp, cout, s()), "affine_gelu_bwd")
             self._colsum(F * ho * wo, dp, cout, cout, f"{name}.bias")
             x, x_bs, x_pitch = self.inputs[li]
-            for f in range(F):
-                self._wgrad3(x + 4 * x_bs * f, x_pitch, h, w, cin, dp + 4 * f * ho * wo * cout, cout, cout, stride, f"{name}.weight", f > 0)
-            wf = self._flip(name, 3, cin, cout)
+            self._wgrad3_batch(F, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride)
+            wf, wp = self._flip(name, 3, cin, cout)
             if stride == 2:
                 z = self.Z.data_ptr()
                 _lib.check(lib.himo_zero_stuff2x(F, ho, wo, cout, dp, ho * wo * cout, cout, z, h * w * cout, cout, s()), "zero_stuff")
                 tmp = self.TMP.data_ptr()
-                self._conv(z, h * w * cout, cout, wf, zb, tmp, h * w * cin, cin, F, h, w, cout, cin, 3)
+                self._conv(z, h * w * cout, cout, wf, zb, tmp, h * w * cin, cin, F, h, w, cout, cin, 3, packed=wp)
                 dst = dcat[cin]                                  # fan-in: add to the decoder's skip gradient
                 for f in range(F):
                     self._add2d(h * w, cin, tmp + 4 * f * h * w * cin, cin, dst.data_ptr() + 4 * cin * f, cin * F)
             else:
                 nxt = self.dA.data_ptr() if dy != self.dA.data_ptr() else self.dB.data_ptr()
-                self._conv(dp, ho * wo * cout, cout, wf, zb, nxt, h * w * cin, cin, F, h, w, cout, cin, 3)
+                self._conv(dp, ho * wo * cout, cout, wf, zb, nxt, h * w * cin, cin, F, h, w, cout, cin, 3, packed=wp)
                 dy = nxt
         # pillar feature net
         for slot in range(F):
@@ -472,16 +536,31 @@ class SeFlowTrainer:
 
     # ---- optimiser / data parallel -----------------------------------------------------------------------------
     def allreduce(self):
-        """Mean of the flat gradient over ranks: ONE collective per step (RCCL over xGMI; gloo in the CPU tests)."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
-            self.flat_g.div_(dist.get_world_size())
+        """Mean of the flat gradient over ranks: ONE collective per step (RCCL over xGMI)."""
+        allreduce_mean_(self.flat_g)
+
+    def train_step(self, pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels: int | None = None, lr: float = 2e-4):
+        """One optimisation step on one sample per rank: forward, self-supervised loss (himo_amd/ssl_loss.py; the flow
+        it scores is the network's residual flow of pc0 in pc1's frame), backward, gradient all-reduce, Adam.
+        Returns ({term: 0-d float64 device tensor}, total)."""
+        from ..ssl_loss import SeFlowLoss
+        if not hasattr(self, "loss"):
+            self.loss = SeFlowLoss(device=self.device)
+        res = self.forward(pch1, pc0, pc1, pose_h1, pose0, pose1)
+        n0, n1 = self.n_pts[1], self.n_pts[2]
+        terms, total, grad = self.loss(self.net.xyz_t[1][:n0], self.net.xyz_t[2][:n1], res[:, :3].contiguous(), label0, label1, n_labels)
+        dres = torch.zeros((n0, 4), dtype=torch.float32, device=self.device)
+        dres[:, :3] = grad
+        self.backward(dres)
+        self.allreduce()
+        self.adam_step(lr)
+        return terms, total
 
     def adam_step(self, lr: float = 2e-4, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
         self.step_count += 1
         _lib.check(self.lib.himo_adam_step(self.flat_p.numel(), self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                            self.flat_v.data_ptr(), lr, beta1, beta2, eps, self.step_count, _lib.stream_handle()), "adam")
+        self._repack()
 
     def export_params(self) -> dict:
         """spec-layout numpy parameter dict (BatchNorm constants unchanged) for SeFlowNet / the oracle."""

@@ -348,6 +348,13 @@ int himo_pfn_backward(int64_t n, const float* h_voxel, const float* h_centre_off
 int himo_head_scatter(int64_t n, int grid_w, int grid_h, const void* d_pillar_workspace, const float* d_dhx, int dhx_pitch,
                       float* d_db0, int b0_pitch, int group0, int group1, int n_groups, float* d_ddec, int dec_pitch,
                       void* stream);
+/* the 3x3 weight gradient over a batch of images, LDS-tiled (dY tile + X halo staged once, all 9 taps read them);
+ * h, w = INPUT image size.  stride 1: h even, w % 32 == 0, cin % 64 == 0; stride 2: h even, w % 64 == 0, cin == 32 or
+ * cin % 64 == 0; cout % 64 == 0 -- HIMO_ERR_UNSUPPORTED otherwise (workspace_bytes returns 0) */
+size_t himo_conv_wgrad_batch_workspace_bytes(int n_img, int h, int w, int cin, int cout, int stride);
+int himo_conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int cin,
+                             const float* d_dy, int64_t dy_batch_stride, int dy_pitch, int cout, int stride, float* d_dw,
+                             unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);
 size_t himo_conv_wgrad_workspace_bytes(int ho, int wo, int cin, int cout);
 int himo_conv3x3_wgrad(const float* d_x, int x_pitch, int h, int w, int cin, const float* d_dy, int dy_pitch, int cout,
                        int stride, float* d_dw, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);

@@ -141,3 +141,21 @@ def test_bench_reduction_is_max_time_and_total_frames(tmp_path):
     e1, t1 = json.loads(Path(tmp_path, "b1.json").read_text())
     assert e0 == e1 == 1.5            # max over ranks
     assert t0 == 240 and t1 == 0      # whole-job frame count lands on rank 0
+
+
+def _worker_grad_allreduce(rank, world, port, out_dir):
+    _init(rank, world, port)
+    from himo_amd.seflow.train import allreduce_mean_
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)          # rank r holds (r+1) * [0..999]
+    allreduce_mean_(g)
+    Path(out_dir, f"g{rank}.npy").write_bytes(g.numpy().tobytes())
+    dist.destroy_process_group()
+
+
+def test_training_gradient_exchange_is_one_mean_allreduce(tmp_path):
+    """The data-parallel training step (config 5) exchanges exactly one flat buffer: its mean over ranks."""
+    mp.spawn(_worker_grad_allreduce, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    want = np.arange(1000, dtype=np.float32) * 1.5
+    for r in range(2):
+        got = np.frombuffer(Path(tmp_path, f"g{r}.npy").read_bytes(), np.float32)
+        assert np.array_equal(got, want)

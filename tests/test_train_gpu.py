@@ -73,7 +73,7 @@ def test_tiled_wgrad_with_accumulate(gpu):
     assert (db - 2 * dz.double().sum(0).float()).abs().max().item() <= 2e-2
 
 
-@pytest.mark.parametrize("stride,h,w,cin,cout,n", [(1, 24, 40, 64, 64, 2), (2, 32, 48, 32, 64, 3), (1, 16, 16, 192, 128, 1),
+@pytest.mark.parametrize("stride,h,w,cin,cout,n", [(1, 24, 40, 64, 64, 2), (2, 32, 48, 32, 64, 3), (1, 16, 16, 192, 128, 1), (1, 16, 64, 64, 128, 2), (1, 8, 32, 128, 64, 3), (1, 64, 96, 64, 64, 1), (2, 16, 64, 32, 64, 3), (2, 8, 128, 64, 128, 2), (2, 32, 64, 128, 256, 1),
                                                    (2, 16, 24, 128, 256, 1)])
 def test_conv3x3_backward_matches_autograd(gpu, stride, h, w, cin, cout, n):
     from himo_amd.seflow.train import conv3x3_backward_nhwc
@@ -119,7 +119,8 @@ def _sample(n, seed=0):
     return pch, pc0, pc1, pose_h, pose0, pose1
 
 
-def test_full_network_gradients_match_autograd(gpu):
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+def test_full_network_gradients_match_autograd(gpu, precision):
     """Every trainable tensor's gradient (pillar net, 16 encoder convs, decoder, head) against CPU autograd through the
     oracle network, for the linear functional L = sum(res * G)."""
     import oracle.seflow_oracle as so
@@ -127,7 +128,7 @@ def test_full_network_gradients_match_autograd(gpu):
     from himo_amd.seflow.train import SeFlowTrainer
     params = spec.init_params(4)
     pch, pc0, pc1, pose_h, pose0, pose1 = _sample(6000, seed=3)
-    tr = SeFlowTrainer(params, device=gpu, max_points=8000)
+    tr = SeFlowTrainer(params, device=gpu, max_points=8000, precision=precision)
     res = tr.forward(pch, pc0, pc1, pose_h, pose0, pose1)
     rng = np.random.default_rng(9)
     G = np.zeros((len(pc0), 4), np.float32)
@@ -162,3 +163,42 @@ def test_full_network_gradients_match_autograd(gpu):
         worst[k] = np.abs(g - r).max() / scale
     bad = {k: e for k, e in worst.items() if not e <= 2e-3}
     assert not bad, bad
+
+
+def _labelled_sample(n, seed):
+    from himo_amd.synthetic import make_frame
+    f = make_frame(seed, n_points=n, n_instances=8)
+    rng = np.random.default_rng(seed)
+    pose0, pose1 = np.asarray(f["pose0"], np.float64), np.asarray(f["pose1"], np.float64)
+    ego = np.linalg.inv(pose1) @ pose0
+    pc0 = np.asarray(f["pc0"], np.float32)[:, :3]
+    lab0 = np.asarray(f["flow_instance_id"], np.int32)
+    moved = (pc0.astype(np.float64) + f["flow"].astype(np.float64)).astype(np.float32)      # pc0 at t1, in pc1's frame
+    perm = rng.permutation(n)
+    pc1, lab1 = moved[perm], lab0[perm]
+    pose_h = pose0 @ np.linalg.inv(ego)                                                    # one step back in time
+    pch = (pc0.astype(np.float64) - (f["flow"].astype(np.float64) - (pc0 @ ego[:3, :3].T + ego[:3, 3] - pc0))).astype(np.float32)
+    return (pch, pc0, pc1, pose_h, pose0, pose1), lab0, lab1
+
+
+def test_train_steps_reduce_the_loss(gpu):
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.train import SeFlowTrainer
+    (pch, pc0, pc1, pose_h, pose0, pose1), lab0, lab1 = _labelled_sample(8000, 11)
+    tr = SeFlowTrainer(spec.init_params(5), device=gpu, max_points=8000)
+    l0, l1 = torch.from_numpy(lab0).to(gpu), torch.from_numpy(lab1).to(gpu)
+    totals = []
+    for _ in range(6):
+        _, total = tr.train_step(pch, pc0, pc1, pose_h, pose0, pose1, l0, l1, n_labels=int(lab0.max()) + 1, lr=1e-3)
+        totals.append(float(total.item()))
+    assert all(np.isfinite(totals)), totals
+    assert totals[-1] < 0.9 * totals[0], totals
+    # the exported parameters drive the inference network to the trainer's own forward result
+    from himo_amd.seflow.model import SeFlowNet
+    res = tr.forward(pch, pc0, pc1, pose_h, pose0, pose1)[:, :3].cpu().numpy()
+    net = SeFlowNet(tr.export_params(), device=gpu, max_points=8000, precision="f32")
+    flow = net.forward(pch, pc0, pc1, pose_h, pose0, pose1).cpu().numpy()
+    ego = np.linalg.inv(pose1) @ pose0
+    valid = net.pid[1][: len(pc0)].cpu().numpy() >= 0
+    pose_flow = net.xyz_t[1][: len(pc0)].cpu().numpy() - pc0
+    assert np.abs((flow - pose_flow)[valid] - res[valid]).max() <= 2e-4
