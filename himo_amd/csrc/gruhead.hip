@@ -1,0 +1,248 @@
+// gruhead.hip -- the whole per-point head of the scene-flow network in ONE kernel (inference, split-bf16):
+// gather -> 4 GRU iterations (2 GEMMs + gates each) -> Linear(192,32) + GELU -> Linear(32,3) -> flow output.
+//
+// PARITY UNPINNED (reference network absent): specification himo_amd/seflow/spec.py step 5-6, oracle
+// oracle/seflow_oracle.py::head.  Replaces 11 launches (head_gather, 8 GRU row-GEMMs with gate epilogues, dec1,
+// head_final) whose state traffic -- ~5 KB per point per iteration through HBM/L2 -- was the binding resource.
+//
+// Design.  A block owns 64 points for the whole head.  The GEMM A operand [h | x] (192 columns) lives in LDS, already
+// split into the three bf16 planes, for all four iterations; the hidden state itself stays in REGISTERS in MFMA
+// accumulator layout: wave w owns hidden columns [32w, 32w+32) of all 64 rows, and in the z|r GEMM it owns exactly the
+// z and r column tiles of those columns, in the q GEMM the q tile of those columns -- so z, r*h, q and the state update
+// never leave the wave; only the new A operand (r*h, then h') is written back to LDS.  Weights are pre-split
+// (himo_conv_pack_weights layout [slab][term][cout][16]); every wave needs different output columns, so B fragments
+// are read straight from global memory/L2 (a fragment load is 32 columns x 32 bytes = 1 KB contiguous) with a
+// one-slab register prefetch -- staging them in LDS would buy no reuse.
+// LDS planes are [term][slab][row][16 bf16] with the two 16-byte halves of a row swapped for rows 16..31 of each
+// 32-row tile: with ds_read_b128's lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) every group then touches
+// all 16 slots of the 256-byte bank row exactly once.
+#include "conv_common.h"
+#include "bf16x3.h"
+
+namespace himo {
+
+struct GruHeadArgs {
+    int64_t n;
+    const int* pid; const float* offsets;
+    const float* img0; const float* img1; int img_pitch;
+    const float* dec; int dec_pitch;
+    const float* w_off; const float* b_off;             // Linear(3,64)
+    const unsigned short* wzr; const float* bzr;        // packed 192 -> 256 (z | r)
+    const unsigned short* wq; const float* bq;          // packed 192 -> 128
+    const unsigned short* w1; const float* b1;          // packed 192 -> 32
+    const float* w2; const float* b2;                   // [32][3], [3]
+    const float* xyz_t; const float* pts; int stride;
+    float* flow;
+    int iters;
+};
+
+constexpr int kGhRows = 64, kGhSlabs = 12;              // 192 / 16
+constexpr int kGhPlane = kGhSlabs * kGhRows * 32;       // bytes per bf16 plane
+
+__device__ inline int a_slot(int s, int slab, int row, int half) {
+    return ((s * kGhSlabs + slab) * kGhRows + row) * 32 + ((half ^ ((row >> 4) & 1)) << 4);
+}
+
+// one value of the A operand, column k of `row`, into the three planes
+__device__ inline void a_store(unsigned char* A, int row, int k, float v) {
+    unsigned h, m, l;
+    split3(v, h, m, l);
+    const int slab = k >> 4, kk = k & 15;
+    const int off = a_slot(0, slab, row, kk >> 3) + (kk & 7) * 2;
+    *reinterpret_cast<unsigned short*>(A + off) = (unsigned short)h;
+    *reinterpret_cast<unsigned short*>(A + off + kGhPlane) = (unsigned short)m;
+    *reinterpret_cast<unsigned short*>(A + off + 2 * kGhPlane) = (unsigned short)l;
+}
+
+// acc[rt][t] += A[rows of tile rt][0..192) * W[:, col[t] + li] for the wave's NT column tiles; RT row tiles starting at rt0
+template <int RT, int NT>
+__device__ inline void gemm192(const unsigned char* A, const unsigned short* __restrict__ wpk, int cout, const int (&col)[NT],
+                               floatx16 (&acc)[RT][NT], int rt0, int li, int lh) {
+    uint4 bcur[NT][3], bnxt[NT][3];
+    auto load_b = [&](int slab, uint4 (&b)[NT][3]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                b[t][s] = *reinterpret_cast<const uint4*>(wpk + (((int64_t)slab * 3 + s) * cout + col[t] + li) * 16 + lh * 8);
+    };
+    load_b(0, bcur);
+#pragma unroll 2
+    for (int slab = 0; slab < kGhSlabs; ++slab) {
+        if (slab + 1 < kGhSlabs) load_b(slab + 1, bnxt);
+        bf16x8 af[RT][3];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                af[rt][s] = *reinterpret_cast<const bf16x8*>(A + a_slot(s, slab, (rt0 + rt) * 32 + li, lh));
+#define HIMO_TERM(SA, SB)                                                                                          \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int t = 0; t < NT; ++t)                  \
+        acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][SA], __builtin_bit_cast(bf16x8, bcur[t][SB]), acc[rt][t], 0, 0, 0);
+        HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
+#undef HIMO_TERM
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) bcur[t][s] = bnxt[t][s];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gru_head_kernel(GruHeadArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char A[3 * kGhPlane];
+    __shared__ int s_pid[kGhRows];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int li = lane & 31, lh = lane >> 5;
+    const int64_t r0 = (int64_t)blockIdx.x * kGhRows;
+
+    if (threadIdx.x < kGhRows) {
+        const int64_t i = r0 + threadIdx.x;
+        s_pid[threadIdx.x] = i < a.n ? a.pid[i] : -1;
+    }
+    // x = Linear(3,64)(offset to the pillar centre): thread -> (row, 16-column slab), columns 128 + 16 q ..
+    {
+        const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const int64_t i = r0 + row;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        if (i < a.n) { o0 = a.offsets[i * 3]; o1 = a.offsets[i * 3 + 1]; o2 = a.offsets[i * 3 + 2]; }
+        unsigned hh[16], mm[16], ll[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int c = q * 16 + k;
+            const float v = fmaf(o2, a.w_off[128 + c], fmaf(o1, a.w_off[64 + c], o0 * a.w_off[c])) + a.b_off[c];
+            split3(v, hh[k], mm[k], ll[k]);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int off = a_slot(0, 8 + q, row, half);
+            const int b = half * 8;
+            *reinterpret_cast<uint4*>(A + off) = make_uint4(hh[b] | (hh[b + 1] << 16), hh[b + 2] | (hh[b + 3] << 16),
+                                                             hh[b + 4] | (hh[b + 5] << 16), hh[b + 6] | (hh[b + 7] << 16));
+            *reinterpret_cast<uint4*>(A + off + kGhPlane) = make_uint4(mm[b] | (mm[b + 1] << 16), mm[b + 2] | (mm[b + 3] << 16),
+                                                                        mm[b + 4] | (mm[b + 5] << 16), mm[b + 6] | (mm[b + 7] << 16));
+            *reinterpret_cast<uint4*>(A + off + 2 * kGhPlane) = make_uint4(ll[b] | (ll[b + 1] << 16), ll[b + 2] | (ll[b + 3] << 16),
+                                                                            ll[b + 4] | (ll[b + 5] << 16), ll[b + 6] | (ll[b + 7] << 16));
+        }
+    }
+    __syncthreads();
+
+    // h0: wave w gathers its 32 hidden columns (0: pc0 image, 1: pc1 image, 2,3: decoder map) in accumulator layout
+    const float* src = wave == 0 ? a.img0 : wave == 1 ? a.img1 : a.dec + (wave - 2) * 32;
+    const int src_pitch = wave < 2 ? a.img_pitch : a.dec_pitch;
+    float h[2][16];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int cell = s_pid[row];
+            const float v = cell >= 0 ? src[(int64_t)cell * src_pitch + li] : 0.f;
+            h[rt][r] = v;
+            a_store(A, row, wave * 32 + li, v);
+        }
+    __syncthreads();
+
+    const int col_zr[2] = {wave * 32, 128 + wave * 32};
+    const int col_q[1] = {wave * 32};
+    const float bz = a.bzr[wave * 32 + li], br = a.bzr[128 + wave * 32 + li], bq = a.bq[wave * 32 + li];
+
+#pragma unroll 1
+    for (int it = 0; it < a.iters; ++it) {
+        floatx16 acc[2][2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
+        gemm192<2, 2>(A, a.wzr, 256, col_zr, acc, 0, li, lh);
+        __syncthreads();                                        // every wave has read [h | x]
+        float z[2][16];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                z[rt][r] = sigmoid_f(acc[rt][0][r] + bz);
+                const float rr = sigmoid_f(acc[rt][1][r] + br);
+                a_store(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, rr * h[rt][r]);
+            }
+        __syncthreads();                                        // A = [r*h | x]
+        floatx16 acq[2][1];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acq[rt][0][r] = 0.f;
+        gemm192<2, 1>(A, a.wq, 128, col_q, acq, 0, li, lh);
+        __syncthreads();
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float q = tanh_f(acq[rt][0][r] + bq);
+                const float hn = (1.0f - z[rt][r]) * h[rt][r] + z[rt][r] * q;
+                h[rt][r] = hn;
+                a_store(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, hn);
+            }
+        __syncthreads();                                        // A = [h' | x]
+    }
+
+    // y1 = gelu([h | x] W1 + b1): waves 0 and 1 take one 32-row tile each
+    floatx16 ac1[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ac1[0][0][r] = 0.f;
+    const int col_1[1] = {0};
+    if (wave < 2) gemm192<1, 1>(A, a.w1, 32, col_1, ac1, wave, li, lh);
+    __syncthreads();                                            // A is dead from here: reuse it for y1 [64][32] float32
+    float* Y = reinterpret_cast<float*>(A);
+    if (wave < 2) {
+        const float b1 = a.b1[li];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Y[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = gelu_exact(ac1[0][0][r] + b1);
+    }
+    __syncthreads();
+    // flow = pose_flow (+ Linear(32,3)(y1) for in-range points): head_final_kernel's arithmetic
+    if (threadIdx.x < 3 * kGhRows) {
+        const int row = threadIdx.x / 3, c = threadIdx.x % 3;
+        const int64_t i = r0 + row;
+        if (i < a.n) {
+            const float pose_flow = a.xyz_t[i * 3 + c] - a.pts[i * a.stride + c];
+            float out = pose_flow;
+            if (s_pid[row] >= 0) {
+                const float* y = Y + row * 32;
+                float s = y[0] * a.w2[c];
+#pragma unroll
+                for (int k = 1; k < 32; ++k) s = fmaf(y[k], a.w2[k * 3 + c], s);
+                out = pose_flow + (s + a.b2[c]);
+            }
+            a.flow[i * 3 + c] = out;
+        }
+    }
+}
+
+}  // namespace himo
+
+using namespace himo;
+
+// hidden 128 (= 32 + 32 + 64 gathered channels), x 64, dec1 width 32: the head of himo_amd/seflow/spec.py.  Packed
+// weights: himo_conv_pack_weights(w, 1, 192, cout) of zr [192][256], q [192][128], dec1 [192][32].
+extern "C" int himo_gru_head(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0, const float* d_img1,
+                             int img_pitch, const float* d_dec, int dec_pitch, const float* d_w_off, const float* d_b_off,
+                             const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
+                             const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
+                             const float* d_xyz_t, const float* d_pts, int pc_stride, float* d_flow, int iters, void* stream) {
+    if (n < 0 || iters < 0 || pc_stride < 3 || img_pitch < 32 || dec_pitch < 64) return HIMO_ERR_INVALID_ARGUMENT;
+    if (n == 0) return HIMO_OK;
+    if (!d_pid || !d_offsets || !d_img0 || !d_img1 || !d_dec || !d_w_off || !d_b_off || !d_wzr_packed || !d_bzr || !d_wq_packed ||
+        !d_bq || !d_w1_packed || !d_b1 || !d_w2 || !d_b2 || !d_xyz_t || !d_pts || !d_flow)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    if ((reinterpret_cast<uintptr_t>(d_wzr_packed) | reinterpret_cast<uintptr_t>(d_wq_packed) | reinterpret_cast<uintptr_t>(d_w1_packed)) & 15)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    GruHeadArgs a{n, d_pid, d_offsets, d_img0, d_img1, img_pitch, d_dec, dec_pitch, d_w_off, d_b_off,
+                  (const unsigned short*)d_wzr_packed, d_bzr, (const unsigned short*)d_wq_packed, d_bq,
+                  (const unsigned short*)d_w1_packed, d_b1, d_w2, d_b2, d_xyz_t, d_pts, pc_stride, d_flow, iters};
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("gru_head_kernel", s);
+    hipLaunchKernelGGL(gru_head_kernel, dim3((unsigned)((n + kGhRows - 1) / kGhRows)), dim3(256), 0, s, a);
+    HIMO_LAUNCH_CHECK("gru_head_kernel");
+    return HIMO_OK;
+}

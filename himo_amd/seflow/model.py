@@ -47,6 +47,8 @@ _lib.register({
                                               ctypes.c_void_p]),
     "himo_upsample2x": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "himo_gru_head": (ctypes.c_int, [ctypes.c_int64] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+                      + [ctypes.c_void_p] * 12 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "himo_head_gather": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
@@ -73,6 +75,7 @@ class SeFlowNet:
         self.precision = precision
         self.autotune = autotune
         self.keep_cell_lists = False
+        self.fused_head = precision == "bf16x3"       # one kernel for gather + GRU + output (csrc/gruhead.hip)
         self.tiles = {}
         self.lib = _lib.load()
         self.device = device if device is not None else _lib.require_gpu()
@@ -249,6 +252,22 @@ class SeFlowNet:
         n = pc0.shape[0]
         p = self.p
         F = self.F
+        if self.fused_head:
+            flow = out if out is not None else torch.empty((n, 3), dtype=torch.float32, device=self.device)
+            if flow.shape != (n, 3) or flow.dtype != torch.float32 or not flow.is_contiguous():
+                raise ValueError("out must be a contiguous (N0,3) float32 tensor")
+            pk = self.packed
+            st = self.lib.himo_gru_head(n, self.pid[slot0].data_ptr(), self.offsets[slot0].data_ptr(),
+                                        self.B0.data_ptr() + 4 * 32 * slot0, self.B0.data_ptr() + 4 * 32 * slot1, 32 * F,
+                                        self.DEC.data_ptr(), 64, p["head.offset.weight"].data_ptr(), p["head.offset.bias"].data_ptr(),
+                                        pk["head.gru.zr.weight"].data_ptr(), p["head.gru.zr.bias"].data_ptr(),
+                                        pk["head.gru.q.weight"].data_ptr(), p["head.gru.q.bias"].data_ptr(),
+                                        pk["head.dec1.weight"].data_ptr(), p["head.dec1.bias"].data_ptr(),
+                                        p["head.dec2.weight"].data_ptr(), p["head.dec2.bias"].data_ptr(),
+                                        self.xyz_t[slot0].data_ptr(), pc0.data_ptr(), pc0.shape[1], flow.data_ptr(),
+                                        spec.GRU_ITERS, _lib.stream_handle())
+            _lib.check(st, "himo_gru_head")
+            return flow
         st = self.lib.himo_head_gather(n, self.pid[slot0].data_ptr(), self.offsets[slot0].data_ptr(),
                                        self.B0.data_ptr() + 4 * 32 * slot0, self.B0.data_ptr() + 4 * 32 * slot1, 32 * F,
                                        self.DEC.data_ptr(), 64, p["head.offset.weight"].data_ptr(),

@@ -120,3 +120,22 @@ def test_full_forward_matches_cpu_restatement(gpu, so, params, precision):
     inv = ~inter["valid0"]
     assert inv.any() and np.array_equal(got[inv], inter["pose_flow"][inv])
     assert np.abs(inter["res"]).mean() > 0.05       # the network output is not trivially zero
+
+
+def test_fused_head_equals_the_multi_launch_head(gpu, params):
+    """gruhead.hip (one kernel: gather, 4 GRU iterations, MLP, output) against the same network run as head_gather + 8
+    row-GEMMs with gate epilogues + dec1 + head_final; ragged row counts exercise the partial last block."""
+    from himo_amd.seflow.model import SeFlowNet
+    from himo_amd.synthetic import make_frame
+    net = SeFlowNet(params, device=gpu, max_points=20_000, precision="bf16x3")
+    assert net.fused_head
+    for n0 in (12_345, 64, 1):
+        fh, f0, f1 = make_frame(30, n_points=15_000), make_frame(31, n_points=n0), make_frame(32, n_points=14_000)
+        args = (fh["pc0"], f0["pc0"], f1["pc0"], fh["pose0"], f0["pose0"], f0["pose1"])
+        net.fused_head = True
+        a = net.forward(*args).cpu().numpy()
+        net.fused_head = False
+        b = net.forward(*args).cpu().numpy()
+        net.fused_head = True
+        assert a.shape == b.shape == (n0, 3)
+        assert np.abs(a - b).max() <= 2e-5, (n0, np.abs(a - b).max())
