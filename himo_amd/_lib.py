@@ -20,6 +20,7 @@ SIGNATURES = {
     "himo_status_string": (c_char_p, [c_int]),
     "himo_last_hip_error": (c_char_p, []),
     "himo_prof_enable": (None, [c_int]),
+    "himo_prof_filter": (None, [ctypes.c_char_p]),
     "himo_prof_reset": (None, []),
     "himo_prof_summary": (c_size_t, [ctypes.c_char_p, c_size_t]),
     "himo_compdis_workspace_bytes": (c_size_t, [c_int]),
@@ -128,9 +129,11 @@ def stream_handle() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def prof_start():
+def prof_start(only: str | None = None):
+    """Start per-kernel timing (HIP events around every launch whose ProfScope name contains ``only``; all when None)."""
     lib = load()
     lib.himo_prof_reset()
+    lib.himo_prof_filter((only or "").encode())
     lib.himo_prof_enable(1)
 
 

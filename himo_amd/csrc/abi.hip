@@ -17,7 +17,17 @@ struct ProfRec { const char* name; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static bool g_prof_on = false;
+static char g_prof_filter[64] = "";            // when non-empty: only kernels whose name contains it are timed
+static std::vector<hipEvent_t> g_event_pool;   // events are recycled: creating two per launch costs host time
 bool prof_enabled() { return g_prof_on; }
+bool prof_wants(const char* name) { return g_prof_on && (!g_prof_filter[0] || strstr(name, g_prof_filter) != nullptr); }
+hipEvent_t prof_event() {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return e;
+}
 void prof_push(const char* name, hipEvent_t a, hipEvent_t b) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back({name, a, b});
@@ -26,9 +36,16 @@ void prof_push(const char* name, hipEvent_t a, hipEvent_t b) {
 
 extern "C" void himo_prof_enable(int on) { himo::g_prof_on = on != 0; }
 
+// restrict the per-kernel timing to kernels whose name contains `substr` (NULL or "" = every kernel): two event
+// records per launch are not free, so a throughput measurement times only the kernel it reports on
+extern "C" void himo_prof_filter(const char* substr) {
+    std::lock_guard<std::mutex> lk(himo::g_prof_mu);
+    snprintf(himo::g_prof_filter, sizeof(himo::g_prof_filter), "%s", substr ? substr : "");
+}
+
 extern "C" void himo_prof_reset(void) {
     std::lock_guard<std::mutex> lk(himo::g_prof_mu);
-    for (auto& r : himo::g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& r : himo::g_prof) { himo::g_event_pool.push_back(r.a); himo::g_event_pool.push_back(r.b); }
     himo::g_prof.clear();
 }
 

@@ -310,7 +310,7 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
     a.Wo = d->stride == 2 ? (d->w_in + 1) / 2 : d->w_in;
     a.aux_in = d->aux_in; a.aux_in_pitch = d->aux_in_pitch; a.aux_out = d->aux_out; a.aux_out_pitch = d->aux_out_pitch;
     hipStream_t s = (hipStream_t)stream;
-    if (d->w_packed && d->stride == 1) return launch_conv_bf16x3(a, d->ksize, d->epilogue, d->w_packed, d->tile_hint, s);
+    if (d->w_packed && d->stride == 1) return launch_conv_bf16x3(a, d->ksize, d->epilogue, d->w_packed, d->tile_hint, d->packed_format, s);
     // tile choice: 128 x 128 when that still gives >= 2 blocks per CU, else shrink M then N so the chip is filled
     auto blocks_for = [&](int bn, int mi) -> int64_t {
         const int bm = 64 * mi, th = 4 * mi;

@@ -25,7 +25,8 @@ namespace himo {
 
 constexpr int kRowBytes = 48;      // LDS pitch of one pixel / one output channel: 16 bf16 + 8 bf16 of padding
 
-// weights [T][Cin][Cout] float32 -> [T][slabs][3][Cout][16] bf16
+// weights [T][Cin][Cout] float32 -> [T][slabs][FMT][Cout][16] (FMT = 3: bf16 h, m, l; FMT = 2: fp16 h, l')
+template <int FMT>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int T, int Cin, int Cout,
                                                            unsigned short* __restrict__ out) {
     const int slabs = (Cin + 15) / 16;
@@ -38,15 +39,19 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     const int tap = (int)(item / (16 * (int64_t)Cout * slabs));
     const int ci = slab * 16 + k;
     const float x = ci < Cin ? w[((int64_t)tap * Cin + ci) * Cout + co] : 0.f;
-    unsigned h, m, l;
-    split3(x, h, m, l);
-    const int64_t base = (((int64_t)tap * slabs + slab) * 3) * Cout * 16 + (int64_t)co * 16 + k;
+    unsigned h, m = 0, l;
+    if (FMT == 3) split3(x, h, m, l); else split2(x, h, l);
+    const int64_t base = (((int64_t)tap * slabs + slab) * FMT) * Cout * 16 + (int64_t)co * 16 + k;
     out[base] = (unsigned short)h;
-    out[base + (int64_t)Cout * 16] = (unsigned short)m;
-    out[base + 2 * (int64_t)Cout * 16] = (unsigned short)l;
+    if (FMT == 3) {
+        out[base + (int64_t)Cout * 16] = (unsigned short)m;
+        out[base + 2 * (int64_t)Cout * 16] = (unsigned short)l;
+    } else {
+        out[base + (int64_t)Cout * 16] = (unsigned short)l;
+    }
 }
 
-template <int KS, int BN, int EPI, int MI>
+template <int KS, int BN, int EPI, int MI, int FMT>
 __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int TW = 32, TH = 2 * MI, BM = 64 * MI;
     constexpr int PH = KS == 1 ? 1 : TH + 2;
@@ -56,10 +61,15 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
     constexpr int WN = BN / 2, NI = WN / 32;
     constexpr int kPatchItems = NPIX * 4;                       // float4 (4 channels) per item
     constexpr int kPatchPerThread = (kPatchItems + 255) / 256;
-    constexpr int kWItems = 3 * BN * 2;                         // 16-byte half rows
+    // taps whose weights are staged together (one barrier per group): the whole kernel row for the fp16 split, whose
+    // two planes leave the LDS room; one tap for the three-plane bf16 split
+    constexpr int G = (KS == 3 && FMT == 2) ? 3 : 1;
+    constexpr int kWItemsTap = FMT * BN * 2;                    // 16-byte half rows of one tap
+    constexpr int kWItems = G * kWItemsTap;
     constexpr int kWPerThread = (kWItems + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char patch[3][NPIX * kRowBytes];
-    __shared__ __attribute__((aligned(16))) unsigned char wts[2][3][BN * kRowBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char patch[FMT][NPIX * kRowBytes];
+    constexpr int WB = G == 1 ? 2 : 1;      // a staged kernel row is single-buffered (the register prefetch hides the loads)
+    __shared__ __attribute__((aligned(16))) unsigned char wts[WB][G][FMT][BN * kRowBytes];
 
     const int n_tiles_n = (a.Cout + BN - 1) / BN;
     int bid = blockIdx.x;
@@ -89,12 +99,16 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
     for (int mi = 0; mi < MI; ++mi) ppA[mi] = KS == 1 ? (wm * MI + mi) * 32 + li : (wm * MI + mi) * PW + li;
 
     floatx16 acc[MI][NI];
+    floatx16 acx[FMT == 2 ? MI : 1][FMT == 2 ? NI : 1];         // fp16 split: the cross terms (scaled by 2^11)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[mi][ni][r] = 0.f;
+                if (FMT == 2) acx[mi][ni][r] = 0.f;
+            }
 
     const int iy0 = oy0 - (KS / 2), ix0 = ox0 - (KS / 2);
     const int64_t in_rows = (int64_t)a.H * a.W;
@@ -127,24 +141,30 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
             if (item < kPatchItems) {
                 const int pp = item >> 2, q = item & 3;
                 unsigned h[4], m[4], l[4];
-                split3(r[it].x, h[0], m[0], l[0]); split3(r[it].y, h[1], m[1], l[1]);
-                split3(r[it].z, h[2], m[2], l[2]); split3(r[it].w, h[3], m[3], l[3]);
                 const int off = pp * kRowBytes + q * 8;
+                if (FMT == 3) {
+                    split3(r[it].x, h[0], m[0], l[0]); split3(r[it].y, h[1], m[1], l[1]);
+                    split3(r[it].z, h[2], m[2], l[2]); split3(r[it].w, h[3], m[3], l[3]);
+                    *reinterpret_cast<uint2*>(&patch[1][off]) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+                } else {
+                    split2(r[it].x, h[0], l[0]); split2(r[it].y, h[1], l[1]);
+                    split2(r[it].z, h[2], l[2]); split2(r[it].w, h[3], l[3]);
+                }
                 *reinterpret_cast<uint2*>(&patch[0][off]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                *reinterpret_cast<uint2*>(&patch[1][off]) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-                *reinterpret_cast<uint2*>(&patch[2][off]) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                *reinterpret_cast<uint2*>(&patch[FMT - 1][off]) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
             }
         }
     };
-    auto load_w = [&](int tap, int slab, uint4 (&r)[kWPerThread]) {
-        const unsigned short* base = wpk + (((int64_t)tap * slabs + slab) * 3) * a.Cout * 16;
+    auto load_w = [&](int tap0, int slab, uint4 (&r)[kWPerThread]) {       // taps tap0 .. tap0 + G - 1 of one slab
 #pragma unroll
         for (int it = 0; it < kWPerThread; ++it) {
             const int item = it * 256 + threadIdx.x;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (item < kWItems) {
-                const int s = item / (BN * 2), rem = item % (BN * 2);
+                const int t = item / kWItemsTap, rest = item % kWItemsTap;
+                const int s = rest / (BN * 2), rem = rest % (BN * 2);
                 const int co = n0 + (rem >> 1), half = rem & 1;
+                const unsigned short* base = wpk + (((int64_t)(tap0 + t) * slabs + slab) * FMT) * a.Cout * 16;
                 if (co < a.Cout) v = *reinterpret_cast<const uint4*>(base + ((int64_t)s * a.Cout + co) * 16 + half * 8);
             }
             r[it] = v;
@@ -155,8 +175,9 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
         for (int it = 0; it < kWPerThread; ++it) {
             const int item = it * 256 + threadIdx.x;
             if (item < kWItems) {
-                const int s = item / (BN * 2), rem = item % (BN * 2);
-                *reinterpret_cast<uint4*>(&wts[buf][s][(rem >> 1) * kRowBytes + (rem & 1) * 16]) = r[it];
+                const int t = item / kWItemsTap, rest = item % kWItemsTap;
+                const int s = rest / (BN * 2), rem = rest % (BN * 2);
+                *reinterpret_cast<uint4*>(&wts[buf][t][s][(rem >> 1) * kRowBytes + (rem & 1) * 16]) = r[it];
             }
         }
     };
@@ -173,38 +194,58 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
 #pragma unroll 1
     for (int slab = 0; slab < slabs; ++slab) {
 #pragma unroll 1
-        for (int tap = 0; tap < T; ++tap) {
-            const bool last_tap = tap == T - 1;
-            const bool has_next = !(last_tap && slab + 1 >= slabs);
-            const int ntap = last_tap ? 0 : tap + 1, nslab = last_tap ? slab + 1 : slab;
+        for (int tap0 = 0; tap0 < T; tap0 += G) {
+            const bool last_grp = tap0 + G >= T;
+            const bool has_next = !(last_grp && slab + 1 >= slabs);
+            const int ntap = last_grp ? 0 : tap0 + G, nslab = last_grp ? slab + 1 : slab;
             if (has_next) {
                 load_w(ntap, nslab, wr);
-                if (last_tap) load_patch(nslab, pr);
+                if (last_grp) load_patch(nslab, pr);
             }
-            const int tapoff = KS == 1 ? 0 : (tap / KS) * PW + (tap % KS);
-            bf16x8 af[MI][3], bf[NI][3];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
+            for (int t = 0; t < G; ++t) {
+                const int tap = tap0 + t;
+                const int tapoff = KS == 1 ? 0 : (tap / KS) * PW + (tap % KS);
+                bf16x8 af[MI][FMT], bf[NI][FMT];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[s][(ppA[mi] + tapoff) * kRowBytes + lh * 16]);
+                for (int s = 0; s < FMT; ++s) {
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    bf[ni][s] = *reinterpret_cast<const bf16x8*>(&wts[wbuf][s][(wn * WN + ni * 32 + li) * kRowBytes + lh * 16]);
-            }
-            // six cross terms, smallest first; accumulators rotate so consecutive MFMAs are independent
+                    for (int mi = 0; mi < MI; ++mi)
+                        af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[s][(ppA[mi] + tapoff) * kRowBytes + lh * 16]);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        bf[ni][s] = *reinterpret_cast<const bf16x8*>(&wts[wbuf][t][s][(wn * WN + ni * 32 + li) * kRowBytes + lh * 16]);
+                }
+                // cross terms, smallest first; accumulators rotate so consecutive MFMAs are independent
 #define HIMO_TERM(SA, SB)                                                                                         \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)            \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][SA], bf[ni][SB], acc[mi][ni], 0, 0, 0);
-            HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
+#define HIMO_TERM16(ACC, SA, SB)                                                                                  \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)            \
+        ACC[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[mi][SA]),                 \
+                                                            __builtin_bit_cast(f16x8, bf[ni][SB]), ACC[mi][ni], 0, 0, 0);
+                if constexpr (FMT == 3) {
+                    HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
+                } else {
+                    HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1)
+                }
+#undef HIMO_TERM16
 #undef HIMO_TERM
-            if (has_next) store_w(wbuf ^ 1, wr);
-            if (last_tap && has_next) {
-                __syncthreads();                                // every wave is done with this slab's patch
-                store_patch(pr);
             }
-            __syncthreads();
-            wbuf ^= 1;
+            if (WB == 2) {
+                if (has_next) store_w(wbuf ^ 1, wr);
+                if (last_grp && has_next) {
+                    __syncthreads();                            // every wave is done with this slab's patch
+                    store_patch(pr);
+                }
+                __syncthreads();
+                wbuf ^= 1;
+            } else if (has_next) {
+                __syncthreads();                                // every wave is done with these weights (and the patch)
+                store_w(0, wr);
+                if (last_grp) store_patch(pr);
+                __syncthreads();
+            }
         }
     }
 
@@ -230,32 +271,42 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
                     ok = oy < a.Ho && ox < a.Wo;
                     pix = (int64_t)oy * a.Wo + ox;
                 }
-                if (ok) epilogue_store<EPI>(a, yout, pix, co, acc[mi][ni][r] + b, sc, sh);
+                float v = acc[mi][ni][r];
+                if (FMT == 2) v += acx[mi][ni][r] * kF16LowInv;
+                if (ok) epilogue_store<EPI>(a, yout, pix, co, v + b, sc, sh);
             }
         }
     }
 }
 
-template <int KS, int BN, int MI>
+template <int KS, int BN, int MI, int FMT>
 static void launch_bf_epi(const ConvArgs& a, int epi, const unsigned short* w, dim3 grid, hipStream_t s) {
     switch (epi) {
-        case kEpiBias: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBias, MI>), grid, dim3(256), 0, s, a, w); break;
-        case kEpiBiasBnGelu: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBiasBnGelu, MI>), grid, dim3(256), 0, s, a, w); break;
-        case kEpiBiasGelu: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBiasGelu, MI>), grid, dim3(256), 0, s, a, w); break;
-        case kEpiGruZR: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiGruZR, MI>), grid, dim3(256), 0, s, a, w); break;
-        case kEpiBiasRelu: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBiasRelu, MI>), grid, dim3(256), 0, s, a, w); break;
-        case kEpiReluMask: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiReluMask, MI>), grid, dim3(256), 0, s, a, w); break;
-        default: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiGruQ, MI>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBias: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBias, MI, FMT>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBiasBnGelu: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBiasBnGelu, MI, FMT>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBiasGelu: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBiasGelu, MI, FMT>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiGruZR: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiGruZR, MI, FMT>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBiasRelu: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBiasRelu, MI, FMT>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiReluMask: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiReluMask, MI, FMT>), grid, dim3(256), 0, s, a, w); break;
+        default: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiGruQ, MI, FMT>), grid, dim3(256), 0, s, a, w); break;
     }
 }
 
-template <int KS>
+template <int KS, int FMT>
 static void launch_bf_tile(const ConvArgs& a, int epi, int bn, int mi, const unsigned short* w, dim3 grid, hipStream_t s) {
-    if (bn == 128) { if (mi == 2) launch_bf_epi<KS, 128, 2>(a, epi, w, grid, s); else launch_bf_epi<KS, 128, 1>(a, epi, w, grid, s); }
-    else { if (mi == 2) launch_bf_epi<KS, 64, 2>(a, epi, w, grid, s); else launch_bf_epi<KS, 64, 1>(a, epi, w, grid, s); }
+    if (bn == 128) { if (mi == 2) launch_bf_epi<KS, 128, 2, FMT>(a, epi, w, grid, s); else launch_bf_epi<KS, 128, 1, FMT>(a, epi, w, grid, s); }
+    else { if (mi == 2) launch_bf_epi<KS, 64, 2, FMT>(a, epi, w, grid, s); else launch_bf_epi<KS, 64, 1, FMT>(a, epi, w, grid, s); }
 }
 
-int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w_packed, int tile_hint, hipStream_t s) {
+bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, int format, int rows_hint, hipStream_t s);   // convsp.hip
+
+int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w_packed, int tile_hint, int format, hipStream_t s) {
+    // 3x3 layers: the weights-from-L2 structure (convsp.hip; tile_hint 0x1000 | rows-per-wave pins its variant) unless the
+    // caller pins a tile of this file's kernel
+    if (ksize == 3 && (!tile_hint || (tile_hint & 0x1000)) && launch_conv3_split(a, epilogue, w_packed, format, tile_hint & 15, s)) {
+        HIMO_LAUNCH_CHECK("conv3_split_kernel");
+        return HIMO_OK;
+    }
     auto blocks_for = [&](int bn, int mi) -> int64_t {
         const int bm = 64 * mi, th = 2 * mi;
         const int64_t tm = ksize == 1 ? (int64_t)a.N * (((int64_t)a.Ho * a.Wo + bm - 1) / bm)
@@ -272,11 +323,13 @@ int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w
         if ((hb == 64 || (hb == 128 && can128)) && (hm == 1 || hm == 2)) { bn = hb; mi = hm; }
     }
     const dim3 grid((unsigned)blocks_for(bn, mi));
-    const char* name = ksize == 1 ? "conv1x1_bf16x3_kernel" : "conv3x3_bf16x3_kernel";
+    const bool f16 = format == 1;
+    const char* name = ksize == 1 ? (f16 ? "conv1x1_f16x2_kernel" : "conv1x1_bf16x3_kernel") : (f16 ? "conv3x3_f16x2_kernel" : "conv3x3_bf16x3_kernel");
     {
         ProfScope ps(name, s);
-        if (ksize == 1) launch_bf_tile<1>(a, epilogue, bn, mi, (const unsigned short*)w_packed, grid, s);
-        else launch_bf_tile<3>(a, epilogue, bn, mi, (const unsigned short*)w_packed, grid, s);
+        const unsigned short* w = (const unsigned short*)w_packed;
+        if (ksize == 1) { if (f16) launch_bf_tile<1, 2>(a, epilogue, bn, mi, w, grid, s); else launch_bf_tile<1, 3>(a, epilogue, bn, mi, w, grid, s); }
+        else { if (f16) launch_bf_tile<3, 2>(a, epilogue, bn, mi, w, grid, s); else launch_bf_tile<3, 3>(a, epilogue, bn, mi, w, grid, s); }
     }
     HIMO_LAUNCH_CHECK("conv_bf16x3_kernel");
     return HIMO_OK;
@@ -290,12 +343,17 @@ extern "C" size_t himo_conv_packed_weight_bytes(int ksize, int cin, int cout) {
     return (size_t)ksize * ksize * ((cin + 15) / 16) * 3 * (size_t)cout * 16 * 2;
 }
 
-extern "C" int himo_conv_pack_weights(const float* d_w, int ksize, int cin, int cout, void* d_packed, void* stream) {
-    if (!d_w || !d_packed || cin < 1 || cout < 1 || !(ksize == 1 || ksize == 3)) return HIMO_ERR_INVALID_ARGUMENT;
+extern "C" int himo_conv_pack_weights_ex(const float* d_w, int ksize, int cin, int cout, int format, void* d_packed, void* stream) {
+    if (!d_w || !d_packed || cin < 1 || cout < 1 || !(ksize == 1 || ksize == 3) || !(format == 0 || format == 1)) return HIMO_ERR_INVALID_ARGUMENT;
     const int T = ksize * ksize;
     const int64_t total = (int64_t)T * ((cin + 15) / 16) * cout * 16;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_w, T, cin,
-                       cout, (unsigned short*)d_packed);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (format == 1) hipLaunchKernelGGL(pack_weights_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, d_w, T, cin, cout, (unsigned short*)d_packed);
+    else hipLaunchKernelGGL(pack_weights_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, d_w, T, cin, cout, (unsigned short*)d_packed);
     HIMO_LAUNCH_CHECK("pack_weights_kernel");
     return HIMO_OK;
+}
+
+extern "C" int himo_conv_pack_weights(const float* d_w, int ksize, int cin, int cout, void* d_packed, void* stream) {
+    return himo_conv_pack_weights_ex(d_w, ksize, cin, cout, 0, d_packed, stream);
 }

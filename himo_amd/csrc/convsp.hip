@@ -1,0 +1,204 @@
+// convsp.hip -- 3x3 stride-1 NHWC convolution on split-precision matrix instructions, second structure:
+// WEIGHT FRAGMENTS STRAIGHT FROM L2, ONE BARRIER PER 16-CHANNEL SLAB.
+//
+// Same arithmetic as convbf.hip (FMT = 3: three bf16 planes, six products; FMT = 2: two fp16 planes with a 2^11-scaled
+// low part, three products) and the same packed-weight layout [tap][slab][FMT][cout][16]; what changes is who reads
+// what.  PMC on convbf.hip's kernel showed the matrix pipe 30 % busy with waves parked 46 % of the time at the
+// per-tap barriers that hand the weight tiles through LDS.  Here a wave owns 128 pixels (four image rows x 32 columns)
+// x 32 output channels: no two waves of a pixel group need the same weights, so a weight fragment is one 16-byte
+// global load per lane (32 channels x 32 bytes = 1 KB contiguous in the packed layout) with a one-tap register
+// prefetch, and LDS holds only the activations: the halo patch of a slab, split into planes while it is staged,
+// double-buffered -- ONE barrier per slab (9 taps = 108 / 216 matrix instructions per wave).
+//   PH = 1: block = 128 pixels x 128 channels (waves = 4 channel tiles);
+//   PH = 2: block = 256 pixels x  64 channels (waves = 2 pixel groups x 2 channel tiles), for the 64-channel layers.
+// Specification / oracle as conv.hip (reference network absent: PARITY UNPINNED).
+#include "conv_common.h"
+#include "bf16x3.h"
+
+namespace himo {
+
+constexpr int kSpRowBytes = 48;      // LDS pitch of one patch pixel: 16 x 2 bytes + 16 of padding (conflict-free b128 reads)
+
+template <int EPI, int PH, int FMT, int MI>
+__global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
+    constexpr int TW = 32, TH = MI * PH, PW = TW + 2, PHt = TH + 2, NPIX = PHt * PW;
+    constexpr int BN = (4 / PH) * 32;
+    constexpr int kPatchItems = NPIX * 4;
+    constexpr int kPatchPerThread = (kPatchItems + 255) / 256;
+    // double-buffered while two blocks still fit a CU's LDS; else single-buffered with a second barrier per slab
+    constexpr int NB = 2 * FMT * NPIX * kSpRowBytes <= 66 * 1024 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char patch[NB][FMT][NPIX * kSpRowBytes];
+
+    const int n_tiles_n = (a.Cout + BN - 1) / BN;
+    int bid = blockIdx.x;
+    const int tn = bid % n_tiles_n; bid /= n_tiles_n;
+    const int tx = (a.Wo + TW - 1) / TW, ty = (a.Ho + TH - 1) / TH;
+    const int ox0 = (bid % tx) * TW; bid /= tx;
+    const int oy0 = (bid % ty) * TH;
+    const int img = bid / ty;
+    const float* __restrict__ xin = a.x + (int64_t)img * a.x_batch_stride;
+    const int slabs = (a.Cin + 15) / 16;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wp = wave % PH, wc = wave / PH;
+    const int li = lane & 31, lh = lane >> 5;
+    const int co = tn * BN + wc * 32 + li;
+    const bool co_ok = co < a.Cout;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+
+    floatx16 acc[MI];
+    floatx16 acx[FMT == 2 ? MI : 1];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[mi][r] = 0.f;
+            if (FMT == 2) acx[mi][r] = 0.f;
+        }
+
+    auto load_patch = [&](int slab, float4 (&r)[kPatchPerThread]) {
+#pragma unroll
+        for (int it = 0; it < kPatchPerThread; ++it) {
+            const int item = it * 256 + threadIdx.x;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (item < kPatchItems) {
+                const int pp = item >> 2, q = item & 3;
+                const int iy = iy0 + pp / PW, ix = ix0 + pp % PW;
+                const int ci = slab * 16 + q * 4;
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ci < a.Cin)
+                    v = *reinterpret_cast<const float4*>(xin + ((int64_t)iy * a.W + ix) * a.x_pitch + ci);
+            }
+            r[it] = v;
+        }
+    };
+    auto store_patch = [&](int buf, const float4 (&r)[kPatchPerThread]) {
+#pragma unroll
+        for (int it = 0; it < kPatchPerThread; ++it) {
+            const int item = it * 256 + threadIdx.x;
+            if (item < kPatchItems) {
+                const int pp = item >> 2, q = item & 3;
+                unsigned h[4], m[4], l[4];
+                const int off = pp * kSpRowBytes + q * 8;
+                if (FMT == 3) {
+                    split3(r[it].x, h[0], m[0], l[0]); split3(r[it].y, h[1], m[1], l[1]);
+                    split3(r[it].z, h[2], m[2], l[2]); split3(r[it].w, h[3], m[3], l[3]);
+                    *reinterpret_cast<uint2*>(&patch[buf][1][off]) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+                } else {
+                    split2(r[it].x, h[0], l[0]); split2(r[it].y, h[1], l[1]);
+                    split2(r[it].z, h[2], l[2]); split2(r[it].w, h[3], l[3]);
+                }
+                *reinterpret_cast<uint2*>(&patch[buf][0][off]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                *reinterpret_cast<uint2*>(&patch[buf][FMT - 1][off]) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+            }
+        }
+    };
+    // this wave's weight fragments of one (tap, slab): FMT x 16 bytes per lane
+    auto load_b = [&](int tap, int slab, uint4 (&b)[FMT]) {
+        const unsigned short* base = wpk + (((int64_t)tap * slabs + slab) * FMT) * a.Cout * 16 + (int64_t)co * 16 + lh * 8;
+#pragma unroll
+        for (int s = 0; s < FMT; ++s)
+            b[s] = co_ok ? *reinterpret_cast<const uint4*>(base + (int64_t)s * a.Cout * 16) : make_uint4(0u, 0u, 0u, 0u);
+    };
+
+    float4 pr[kPatchPerThread];
+    uint4 bcur[FMT], bnxt[FMT];
+    load_patch(0, pr);
+    load_b(0, 0, bcur);
+    store_patch(0, pr);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int slab = 0; slab < slabs; ++slab) {
+        const int buf = NB == 2 ? (slab & 1) : 0;
+        const bool more = slab + 1 < slabs;
+        if (more) load_patch(slab + 1, pr);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) load_b(tap + 1, slab, bnxt);
+            else if (more) load_b(0, slab + 1, bnxt);
+            const int tapoff = (tap / 3) * PW + (tap % 3);
+            bf16x8 af[MI][FMT];
+#pragma unroll
+            for (int s = 0; s < FMT; ++s)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[buf][s][((wp * MI + mi) * PW + li + tapoff) * kSpRowBytes + lh * 16]);
+#define HIMO_TERM(SA, SB)                                                                                          \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                \
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][SA], __builtin_bit_cast(bf16x8, bcur[SB]), acc[mi], 0, 0, 0);
+#define HIMO_TERM16(ACC, SA, SB)                                                                                   \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                \
+        ACC[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[mi][SA]),                      \
+                                                        __builtin_bit_cast(f16x8, bcur[SB]), ACC[mi], 0, 0, 0);
+            if constexpr (FMT == 3) {
+                HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
+            } else {
+                HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1)
+            }
+#undef HIMO_TERM16
+#undef HIMO_TERM
+#pragma unroll
+            for (int s = 0; s < FMT; ++s) bcur[s] = bnxt[s];
+        }
+        if (more) {
+            if (NB == 1) __syncthreads();      // single buffer: every wave is done reading this slab's patch
+            store_patch(NB == 2 ? buf ^ 1 : 0, pr);   // (double buffer: the other one was last read before the previous barrier)
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ yout = a.y + (int64_t)img * a.y_batch_stride;
+    if (!co_ok) return;
+    const float b = a.bias ? a.bias[co] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int oy = oy0 + wp * MI + mi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float v = acc[mi][r];
+            if (FMT == 2) v += acx[mi][r] * kF16LowInv;
+            if (oy < a.Ho && ox < a.Wo) epilogue_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v + b, sc, sh);
+        }
+    }
+}
+
+template <int PH, int FMT, int MI>
+static void launch_sp_epi(const ConvArgs& a, int epi, const unsigned short* w, dim3 grid, hipStream_t s) {
+    switch (epi) {
+        case kEpiBias: hipLaunchKernelGGL((conv3_split_kernel<kEpiBias, PH, FMT, MI>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBiasBnGelu: hipLaunchKernelGGL((conv3_split_kernel<kEpiBiasBnGelu, PH, FMT, MI>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBiasGelu: hipLaunchKernelGGL((conv3_split_kernel<kEpiBiasGelu, PH, FMT, MI>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBiasRelu: hipLaunchKernelGGL((conv3_split_kernel<kEpiBiasRelu, PH, FMT, MI>), grid, dim3(256), 0, s, a, w); break;
+        default: hipLaunchKernelGGL((conv3_split_kernel<kEpiReluMask, PH, FMT, MI>), grid, dim3(256), 0, s, a, w); break;
+    }
+}
+
+template <int PH, int FMT>
+static void launch_sp_mi(const ConvArgs& a, int epi, int mi, const unsigned short* w, dim3 grid, hipStream_t s) {
+    if (mi == 4) launch_sp_epi<PH, FMT, 4>(a, epi, w, grid, s); else launch_sp_epi<PH, FMT, 2>(a, epi, w, grid, s);
+}
+
+// 3x3 stride-1 layers with a plain epilogue; returns false when this structure does not apply (GRU epilogues).
+// rows_hint: 0 = heuristic, else image rows per wave (4 | 2).
+bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, int format, int rows_hint, hipStream_t s) {
+    if (epilogue == kEpiGruZR || epilogue == kEpiGruQ) return false;
+    const bool wide = a.Cout > 64;                     // PH = 1: 128-channel tiles; PH = 2: 64-channel tiles
+    const int bn = wide ? 128 : 64, ph = wide ? 1 : 2;
+    auto blocks_for = [&](int mi) -> int64_t {
+        const int th = mi * ph;
+        return (int64_t)a.N * ((a.Ho + th - 1) / th) * ((a.Wo + 31) / 32) * ((a.Cout + bn - 1) / bn);
+    };
+    int mi = blocks_for(4) >= 1024 ? 4 : 2;            // two blocks per CU, at least two rounds of them
+    if (rows_hint == 4 || rows_hint == 2) mi = rows_hint;
+    const dim3 grid((unsigned)blocks_for(mi));
+    const unsigned short* w = (const unsigned short*)w_packed;
+    ProfScope ps(format == 1 ? "conv3x3_f16x2_kernel" : "conv3x3_bf16x3_kernel", s);
+    if (format == 1) { if (wide) launch_sp_mi<1, 2>(a, epilogue, mi, w, grid, s); else launch_sp_mi<2, 2>(a, epilogue, mi, w, grid, s); }
+    else { if (wide) launch_sp_mi<1, 3>(a, epilogue, mi, w, grid, s); else launch_sp_mi<2, 3>(a, epilogue, mi, w, grid, s); }
+    return true;
+}
+
+}  // namespace himo

@@ -31,12 +31,15 @@ inline int check_hip(hipError_t e, const char* where) {
 // Optional per-kernel timing with HIP events on the launch stream (himo_prof_* in the ABI).
 // Off by default; when on, every ProfScope brackets one kernel launch with two events.
 bool prof_enabled();
+bool prof_wants(const char* name);             // enabled and the name passes himo_prof_filter
+hipEvent_t prof_event();                       // from a recycled pool
 void prof_push(const char* name, hipEvent_t a, hipEvent_t b);
 struct ProfScope {
     const char* name; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
-    ProfScope(const char* n, hipStream_t st) : name(n), s(st), on(prof_enabled()) {
+    ProfScope(const char* n, hipStream_t st) : name(n), s(st), on(prof_wants(n)) {
         if (on) {
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            a = prof_event(); b = prof_event();
+            if (!a || !b) { on = false; return; }
             (void)hipEventRecord(a, s);
         }
     }

@@ -51,6 +51,7 @@ class HiMoPipeline:
         self.compdis = CompDisEngine(device=self.device)
         self._batch = None
         self._key = None
+        self._finite = None          # device flag of the previous batch (fp16-split precision only)
 
     def _batch_for(self, samples) -> FrameBatch:
         """Ragged batch container over the pc0 sweeps of ``samples`` (rebuilt only when the batch changes)."""
@@ -72,6 +73,16 @@ class HiMoPipeline:
             self._key = key
         return self._batch
 
+    def sync_check(self):
+        """fp16-split precision only: an activation beyond fp16's range (65504) turns into NaN at the next layer's
+        split and reaches the flow; this raises instead of handing such a batch on.  Checked one batch late by
+        ``run`` (so it never stalls the stream) and by the caller after the last batch."""
+        if self._finite is not None:
+            ok, self._finite = bool(self._finite.item()), None
+            if not ok:
+                raise FloatingPointError("non-finite flow: activations left the fp16 range of precision='f16x2'; "
+                                         "use SeFlowNet(precision='bf16x3') for these weights")
+
     def flow(self, s: Sample, out: torch.Tensor | None = None) -> torch.Tensor:
         """Network only: (N0,3) flow including ego motion (the h5 ``<res_name>`` payload)."""
         return self.net.forward_device(s.pch1, s.pc0, s.pc1, s.pose_h1, s.pose0, s.pose1, out=out)
@@ -81,7 +92,10 @@ class HiMoPipeline:
         Returns {"flow", "comp_dis"[, "refined"]} as (T,3) tensors plus "batch" for splitting per frame."""
         batch = self._batch_for(samples)
         o = batch.offsets_host
+        self.sync_check()                                    # the PREVIOUS batch's flag: no stall on this one
         for k, s in enumerate(samples):
             self.flow(s, out=batch.flow[int(o[k]):int(o[k + 1])])
+        if self.net.precision == "f16x2":
+            self._finite = torch.isfinite(batch.flow).all()
         res = self.compdis.run(batch, sensor_dt=sensor_dt, refined=refined, out=self._out)
         return {"flow": batch.flow, "comp_dis": res["comp_dis"], "refined": res.get("refined"), "batch": batch}

@@ -30,7 +30,7 @@ class ConvDesc(ctypes.Structure):
                 ("cout", ctypes.c_int), ("ksize", ctypes.c_int), ("stride", ctypes.c_int), ("epilogue", ctypes.c_int),
                 ("aux_in", ctypes.c_void_p), ("aux_in_pitch", ctypes.c_int),
                 ("aux_out", ctypes.c_void_p), ("aux_out_pitch", ctypes.c_int), ("w_packed", ctypes.c_void_p),
-                ("tile_hint", ctypes.c_int)]
+                ("tile_hint", ctypes.c_int), ("packed_format", ctypes.c_int)]
 
 
 _lib.register({
@@ -47,6 +47,8 @@ _lib.register({
                                               ctypes.c_void_p]),
     "himo_upsample2x": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "himo_conv_pack_weights_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                 ctypes.c_void_p]),
     "himo_gru_head": (ctypes.c_int, [ctypes.c_int64] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
                       + [ctypes.c_void_p] * 12 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "himo_head_gather": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -55,6 +57,19 @@ _lib.register({
     "himo_head_final": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_void_p]),
+})
+
+
+class HimoOp(ctypes.Structure):
+    """mirror of `himo_op` (include/himo_amd.h)"""
+    _fields_ = [("kind", ctypes.c_int), ("conv", ConvDesc),
+                ("up_x", ctypes.c_void_p), ("up_x_pitch", ctypes.c_int), ("up_h", ctypes.c_int), ("up_w", ctypes.c_int),
+                ("up_c", ctypes.c_int), ("up_y", ctypes.c_void_p), ("up_y_pitch", ctypes.c_int)]
+
+
+_lib.register({
+    "himo_run_ops": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_void_p]),
+    "himo_ops_release": (None, [ctypes.c_void_p]),
 })
 
 
@@ -69,13 +84,20 @@ class SeFlowNet:
     def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, seed: int = 0,
                  precision: str = "bf16x3", autotune: bool = True):
         """``precision``: "bf16x3" = split-bf16 matrix instructions for every stride-1 convolution / GEMM (float32-class
-        accuracy, see csrc/convbf.hip); "f32" = float32 MFMA everywhere."""
-        if precision not in ("bf16x3", "f32"):
+        accuracy, float32 range; csrc/convbf.hip); "f16x2" = two-term fp16 split with a scaled low part for the
+        convolutions (22-bit products, HALF the matrix instructions of bf16x3; activations and weights must stay
+        below fp16's 65504 -- true for this normalised network; the head keeps bf16x3); "f32" = float32 MFMA everywhere."""
+        if precision not in ("bf16x3", "f16x2", "f32"):
             raise ValueError(precision)
         self.precision = precision
         self.autotune = autotune
         self.keep_cell_lists = False
-        self.fused_head = precision == "bf16x3"       # one kernel for gather + GRU + output (csrc/gruhead.hip)
+        self.fused_head = precision != "f32"          # one kernel for gather + GRU + output (csrc/gruhead.hip)
+        self.use_plan = True                          # replay the backbone's operator list from one call (csrc/plan.hip)
+        self.use_graph = True                         # ... as a captured hipGraph
+        self._plan = None
+        self._recording = None
+        self.packed_format = 1 if precision == "f16x2" else 0
         self.tiles = {}
         self.lib = _lib.load()
         self.device = device if device is not None else _lib.require_gpu()
@@ -97,14 +119,15 @@ class SeFlowNet:
         derived["head.gru.zr.bias"] = torch.cat([cpu["head.gru.z.bias"], cpu["head.gru.r.bias"]]).contiguous()
         self.p = {k: v.to(self.device) for k, v in {**cpu, **derived}.items()}
         self.packed = {}
-        if precision == "bf16x3":
+        if precision != "f32":
             for k, v in self.p.items():
                 if k.endswith(".weight") and k != "pfn.weight" and not k.startswith("head.offset") and k != "head.dec2.weight":
                     w = v if v.dim() == 4 else v.reshape(1, 1, *v.shape)          # linears are 1x1 convolutions
                     ks, _, cin, cout = w.shape
+                    fmt = 0 if k.startswith("head.") else self.packed_format      # the head kernels read bf16x3
                     buf = torch.empty(int(self.lib.himo_conv_packed_weight_bytes(ks, cin, cout)), dtype=torch.uint8, device=self.device)
-                    _lib.check(self.lib.himo_conv_pack_weights(w.contiguous().data_ptr(), ks, cin, cout, buf.data_ptr(),
-                                                               _lib.stream_handle()), "himo_conv_pack_weights")
+                    _lib.check(self.lib.himo_conv_pack_weights_ex(w.contiguous().data_ptr(), ks, cin, cout, fmt, buf.data_ptr(),
+                                                                  _lib.stream_handle()), "himo_conv_pack_weights_ex")
                     self.packed[k] = buf
 
         H, W = spec.GRID
@@ -168,10 +191,14 @@ class SeFlowNet:
         d.aux_out = None if aux_out is None else aux_out.data_ptr(); d.aux_out_pitch = aux_out_pitch
         pk = self.packed.get(f"{wname}.weight")
         d.w_packed = None if pk is None else pk.data_ptr()
+        d.packed_format = 0 if wname.startswith("head.") else self.packed_format
         key = (n, h, w, cin, cout, ks, stride, epi, pk is not None)
         if self.autotune and key not in self.tiles:
             self.tiles[key] = self._tune(d)
         d.tile_hint = self.tiles.get(key, 0)
+        if self._recording is not None and epi not in (EPI_GRU_ZR, EPI_GRU_Q):
+            op = HimoOp(); op.kind = 0; op.conv = d
+            self._recording.append(op)
         _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), f"himo_conv2d({wname})")
 
     def _tune(self, d: "ConvDesc") -> int:
@@ -181,33 +208,53 @@ class SeFlowNet:
             return 0
         best, best_t = 0, float("inf")
         stream = _lib.stream_handle()
-        for bn in (128, 64):
-            if bn == 128 and d.cout % 128:
-                continue
-            for mi in (2, 1):
-                d.tile_hint = (bn << 4) | mi
-                for _ in range(2):
-                    self.lib.himo_conv2d(ctypes.byref(d), stream)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(3):
-                    self.lib.himo_conv2d(ctypes.byref(d), stream)
-                e1.record()
-                e1.synchronize()
-                t = e0.elapsed_time(e1)
-                if t < best_t:
-                    best, best_t = d.tile_hint, t
+        cands = [(bn << 4) | mi for bn in (128, 64) if not (bn == 128 and d.cout % 128) for mi in (2, 1)]
+        if d.w_packed and d.ksize == 3 and d.stride == 1:
+            cands += [0x1000 | 4, 0x1000 | 2]                 # the weights-from-L2 structure (csrc/convsp.hip)
+        for hint in cands:
+            d.tile_hint = hint
+            for _ in range(2):
+                self.lib.himo_conv2d(ctypes.byref(d), stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                self.lib.himo_conv2d(ctypes.byref(d), stream)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if t < best_t:
+                best, best_t = d.tile_hint, t
         return best
 
     def _up(self, x, x_pitch, h, w, c, y, y_pitch):
+        if self._recording is not None:
+            op = HimoOp(); op.kind = 1
+            op.up_x, op.up_x_pitch, op.up_h, op.up_w, op.up_c, op.up_y, op.up_y_pitch = x.data_ptr(), x_pitch, h, w, c, y.data_ptr(), y_pitch
+            self._recording.append(op)
         _lib.check(self.lib.himo_upsample2x(x.data_ptr(), x_pitch, h, w, c, y.data_ptr(), y_pitch, _lib.stream_handle()),
                    "himo_upsample2x")
 
     # ---- stages ---------------------------------------------------------------------------------------
     def backbone(self):
-        """B0 (3 pillar images) -> DEC (64 x H x W)."""
+        """B0 (3 pillar images) -> DEC (64 x H x W).  The first call runs (and tile-tunes) layer by layer while recording
+        the operator list; later calls replay it from one C call / one hipGraph launch."""
+        if self.use_plan and self._plan is not None:
+            ops, n = self._plan
+            _lib.check(self.lib.himo_run_ops(ctypes.addressof(ops), n, 1 if self.use_graph else 0, _lib.stream_handle()), "himo_run_ops")
+            return self.DEC
+        self._recording = [] if self.use_plan else None
         self.encoder()
-        return self.decoder()
+        self.decoder()
+        if self._recording is not None:
+            rec, self._recording = self._recording, None
+            self._plan = ((HimoOp * len(rec))(*rec), len(rec))
+        return self.DEC
+
+    def drop_plan(self):
+        """forget the recorded operator list (call after changing weights buffers, precision or tile choices)"""
+        if self._plan is not None:
+            self.lib.himo_ops_release(ctypes.addressof(self._plan[0]))
+            self._plan = None
 
     def encoder(self):
         """B0 -> the three concat buffers F1 / F2 / F3 (frames stacked on channels)."""
@@ -322,7 +369,8 @@ class SeFlowNet:
 
 # ---- stand-alone operators (tests / experiments): the same kernels on caller-provided tensors -------------------
 def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: int = 1, epilogue: int = EPI_BIAS,
-                scale: torch.Tensor | None = None, shift: torch.Tensor | None = None, precision: str = "f32") -> torch.Tensor:
+                scale: torch.Tensor | None = None, shift: torch.Tensor | None = None, precision: str = "f32",
+                tile_hint: int = 0) -> torch.Tensor:
     """x [N,H,W,Cin] float32 (contiguous, device), weight [k,k,Cin,Cout] -> y [N,Ho,Wo,Cout]."""
     lib = _lib.load()
     n, h, w, cin = x.shape
@@ -339,11 +387,13 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, strid
     else:
         d.n, d.h, d.w_in = n, h, w
     d.cin, d.cout, d.ksize, d.stride, d.epilogue = cin, cout, k, stride, epilogue
-    if precision == "bf16x3" and stride == 1:
+    d.tile_hint = tile_hint
+    if precision in ("bf16x3", "f16x2") and stride == 1:
+        fmt = 1 if precision == "f16x2" else 0
         pk = torch.empty(int(lib.himo_conv_packed_weight_bytes(k, cin, cout)), dtype=torch.uint8, device=x.device)
-        _lib.check(lib.himo_conv_pack_weights(weight.contiguous().data_ptr(), k, cin, cout, pk.data_ptr(), _lib.stream_handle()),
-                   "himo_conv_pack_weights")
-        d.w_packed = pk.data_ptr()
+        _lib.check(lib.himo_conv_pack_weights_ex(weight.contiguous().data_ptr(), k, cin, cout, fmt, pk.data_ptr(), _lib.stream_handle()),
+                   "himo_conv_pack_weights_ex")
+        d.w_packed = pk.data_ptr(); d.packed_format = fmt
     _lib.check(lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), "himo_conv2d")
     return y
 

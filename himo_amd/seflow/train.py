@@ -248,6 +248,7 @@ class SeFlowTrainer:
         params = spec.init_params(seed) if params is None else params
         net = self.net = SeFlowNet(params, device=dev, max_points=1, precision="f32", autotune=False)
         net.keep_cell_lists = True
+        net.use_plan = False
         net.max_points = 0
         net._reserve_points(max_points)
         H, W, F = net.H, net.W, net.F

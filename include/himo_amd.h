@@ -60,6 +60,8 @@ const char* himo_last_hip_error(void);
  * himo_prof_summary waits for the recorded launches and writes one line per kernel name:
  * "<name> <count> <total_ms> <min_ms> <max_ms>\n"; returns the bytes needed (incl. NUL). */
 void himo_prof_enable(int on);
+/* time only kernels whose name contains `substr` (NULL or "" = all): keeps the event records out of the other launches */
+void himo_prof_filter(const char* substr);
 void himo_prof_reset(void);
 size_t himo_prof_summary(char* buf, size_t cap);
 
@@ -230,15 +232,41 @@ typedef struct himo_conv_desc {
                                                               stride == 1 the split-bf16 kernel runs (same accuracy
                                                               class, 2.67x the float32-MFMA rate) */
     int tile_hint;                                         /* 0 = library heuristic; else (channel tile 64|128) << 4 | (1|2):
-                                                              pixel tile 64|128 -- for callers that time the variants */
+                                                              pixel tile 64|128 of the LDS-staged-weights kernel, or
+                                                              0x1000 | (4|2): image rows per wave of the weights-from-L2
+                                                              kernel (3x3, split precision) -- for callers that time
+                                                              the variants */
+    int packed_format;                                     /* format of w_packed: 0 = three bf16 planes (float32 range,
+                                                              6 matrix instructions per product block), 1 = two fp16
+                                                              planes with a 2^11-scaled low part (|values| < 65504,
+                                                              3 matrix instructions): himo_conv_pack_weights_ex */
 } himo_conv_desc;
 int himo_conv2d(const himo_conv_desc* h_desc, void* stream);
 /* one-time weight preparation for the split-bf16 path: [k][k][cin][cout] float32 -> three bf16 planes */
 size_t himo_conv_packed_weight_bytes(int ksize, int cin, int cout);
 int himo_conv_pack_weights(const float* d_w, int ksize, int cin, int cout, void* d_packed, void* stream);
+#define HIMO_PACK_BF16X3 0
+#define HIMO_PACK_F16X2 1
+int himo_conv_pack_weights_ex(const float* d_w, int ksize, int cin, int cout, int format, void* d_packed, void* stream);
 
 /* bilinear x2 upsampling, align_corners = true; c channels of every pixel, NHWC with pitches */
 int himo_upsample2x(const float* d_x, int x_pitch, int h, int w, int c, float* d_y, int y_pitch, void* stream);
+
+/* A prepared operator list (the static part of a forward pass: fixed buffers, shapes, weights) run from one call.
+ * With HIMO_OPS_GRAPH the list is captured once into a hipGraph, keyed by the h_ops address, and replayed with one
+ * hipGraphLaunch -- the caller must not modify the list afterwards without himo_ops_release(h_ops).  The graph path is
+ * skipped while the himo_prof_* profiler is on, and falls back to plain launches if capture is not possible. */
+#define HIMO_OP_CONV 0
+#define HIMO_OP_UPSAMPLE2X 1
+#define HIMO_OPS_GRAPH 0x1u
+typedef struct himo_op {
+    int kind;
+    himo_conv_desc conv;                                   /* HIMO_OP_CONV */
+    const float* up_x; int up_x_pitch, up_h, up_w, up_c;   /* HIMO_OP_UPSAMPLE2X: the arguments of himo_upsample2x */
+    float* up_y; int up_y_pitch;
+} himo_op;
+int himo_run_ops(const himo_op* h_ops, int n_ops, unsigned flags, void* stream);
+void himo_ops_release(const himo_op* h_ops);
 
 /* The whole per-point head in one kernel (inference, split-bf16): gather -> `iters` GRU iterations -> Linear(192,32)+GELU
  * -> Linear(32,3) -> flow (pose_flow + residual for in-range points, pose_flow otherwise).  Same inputs and result as

@@ -8,6 +8,7 @@ from himo_amd.seflow.model import conv2d_nhwc
 
 dev = torch.device("cuda", 0)
 PREC = sys.argv[1] if len(sys.argv) > 1 else "f32"
+HINT = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0
 shapes = [  # (N, H, W, Cin, Cout, k, stride, epi)
     (3, 256, 256, 64, 64, 3, 1, 1), (3, 128, 128, 128, 128, 3, 1, 1), (3, 64, 64, 256, 256, 3, 1, 1),
     (1, 128, 128, 512, 256, 3, 1, 0), (1, 128, 128, 256, 256, 3, 1, 0), (1, 256, 256, 256, 128, 3, 1, 0),
@@ -19,10 +20,10 @@ for (n, h, w, ci, co, k, s, epi) in shapes:
     x = torch.randn(n, h, w, ci, device=dev)
     wt = torch.randn(k, k, ci, co, device=dev) * 0.05
     b = torch.zeros(co, device=dev); sc = torch.ones(co, device=dev); sh = torch.zeros(co, device=dev)
-    for _ in range(2): conv2d_nhwc(x, wt, b, stride=s, epilogue=epi, scale=sc, shift=sh, precision=PREC)
+    for _ in range(2): conv2d_nhwc(x, wt, b, stride=s, epilogue=epi, scale=sc, shift=sh, precision=PREC, tile_hint=HINT)
     torch.cuda.synchronize()
     _lib.prof_start()
-    for _ in range(5): conv2d_nhwc(x, wt, b, stride=s, epilogue=epi, scale=sc, shift=sh, precision=PREC)
+    for _ in range(5): conv2d_nhwc(x, wt, b, stride=s, epilogue=epi, scale=sc, shift=sh, precision=PREC, tile_hint=HINT)
     torch.cuda.synchronize()
     p = _lib.prof_stop()
     ms = min(v["min_ms"] for v in p.values())

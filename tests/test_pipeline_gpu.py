@@ -70,3 +70,30 @@ def test_save_then_save_zip_then_eval_round_trip(gpu, oracle, tmp_path):
             va = a[cat]["overall"][k] if "overall" in a[cat] else a[cat][k]
             vb = b[cat]["overall"][k] if "overall" in b[cat] else b[cat][k]
             assert va == pytest.approx(vb, rel=1e-9, abs=1e-12)
+
+
+def test_fp16_split_pipeline_matches_and_flags_overflow(gpu):
+    """precision='f16x2' (two-term fp16 split): same 1e-4 flow parity as the bf16 split, and weights that push an
+    activation past fp16's range make the pipeline raise instead of returning NaN flows."""
+    import seflow_oracle as so
+    from himo_amd.pipeline import HiMoPipeline, Sample
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.model import SeFlowNet
+    from himo_amd.synthetic import make_frame
+    params = spec.init_params(3)
+    frames = [make_frame(40 + i, n_points=16_000) for i in range(3)]
+    samples = [Sample.from_frames(frames[0], frames[1], frames[2], device=gpu)]
+    pipe = HiMoPipeline(SeFlowNet(params, device=gpu, max_points=20_000, precision="f16x2"), device=gpu)
+    out = pipe.run(samples)
+    pipe.sync_check()
+    ref = so.forward(params, frames[0]["pc0"], frames[1]["pc0"], frames[2]["pc0"], frames[0]["pose0"], frames[1]["pose0"], frames[1]["pose1"])
+    assert np.abs(out["flow"].cpu().numpy() - ref).max() <= 1e-4
+    big = dict(params)
+    big["dec3.u5.weight"] = params["dec3.u5.weight"] * 1e7          # dec4 then sees inputs ~1e7 > 65504
+    pipe = HiMoPipeline(SeFlowNet(big, device=gpu, max_points=20_000, precision="f16x2"), device=gpu)
+    pipe.run(samples)
+    with pytest.raises(FloatingPointError):
+        pipe.sync_check()
+    # the bf16 split has float32's range: same weights, finite result
+    pipe = HiMoPipeline(SeFlowNet(big, device=gpu, max_points=20_000, precision="bf16x3"), device=gpu)
+    assert torch.isfinite(pipe.run(samples)["flow"]).all()

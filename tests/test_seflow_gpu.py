@@ -34,7 +34,7 @@ def net(gpu, params):
     (16, 32, 32, 64, 3, 1, 1), (24, 48, 64, 128, 3, 1, 0), (32, 32, 32, 64, 3, 2, 1), (16, 16, 128, 256, 3, 2, 1),
     (8, 16, 768, 256, 1, 1, 0), (40, 40, 96, 64, 1, 1, 0), (8, 16, 512, 256, 3, 1, 0), (19, 37, 16, 64, 3, 1, 2),
 ])
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_conv_layer_matches_torch(gpu, cfg, precision):
     from himo_amd.seflow.model import conv2d_nhwc
     H, W, ci, co, k, s, epi = cfg
@@ -99,7 +99,7 @@ def test_pillar_front_end_is_deterministic_and_handles_out_of_range(gpu, net):
     assert torch.equal(a, net.B0)                              # every cell rewritten: no stale data
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2", "f32"])
 def test_full_forward_matches_cpu_restatement(gpu, so, params, precision):
     from himo_amd.seflow.model import SeFlowNet
     from himo_amd.synthetic import make_frame
