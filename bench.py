@@ -376,7 +376,8 @@ def main():
             else:
                 achieved, peak, note = alg_tf, MFMA_F32_PEAK_TF, "v_mfma_f32_32x32x2_f32"
             roofline = {"bound": "mfma", "kernel": f"{kname} ({note})", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                        "frac": achieved / peak, "traffic": traffic.get("conv3x3_mfma_kernel", {}).get("hbm_bytes_per_launch"),
+                        "frac": achieved / peak,
+                        "traffic": traffic.get("conv3x3_mfma_kernel" if args.precision == "f32" else "conv3x3_split_kernel", {}).get("hbm_bytes_per_launch"),
                         "algorithmic_f32_equivalent_tflops": alg_tf, "vs_f32_mfma_peak_157_3": alg_tf / MFMA_F32_PEAK_TF,
                         "algorithmic_flops_per_launch": flops3 / max(launches_per_fwd, 1e-9), "avg_launch_ms": k["avg_ms"],
                         "launches_timed": k["count"], "launches_per_forward": launches_per_fwd,

@@ -8,9 +8,12 @@ from collections import defaultdict
 from pathlib import Path
 
 root = Path(sys.argv[1])
-FAMILIES = {"compdis_kernel": "compdis_kernel<", "frame_prep_kernel": "frame_prep_kernel",
-            "conv3x3_mfma_kernel": "conv_mfma_kernel<3, 1,", "conv3x3s2_mfma_kernel": "conv_mfma_kernel<3, 2,",
-            "conv1x1_mfma_kernel": "conv_mfma_kernel<1, 1,", "pillar_feature_kernel": "pillar_feature_kernel"}
+FAMILIES = {"compdis_kernel": ("compdis_kernel<",), "frame_prep_kernel": ("frame_prep_kernel",),
+            "conv3x3_mfma_kernel": ("conv_mfma_kernel<3, 1,",), "conv3x3s2_mfma_kernel": ("conv_mfma_kernel<3, 2,",),
+            "conv1x1_mfma_kernel": ("conv_mfma_kernel<1, 1,",), "pillar_feature_kernel": ("pillar_feature_kernel",),
+            # the 20 stride-1 3x3 layers of a forward in split precision: both kernel structures (autotuned per layer)
+            "conv3x3_split_kernel": ("conv3_split_kernel<", "conv_bf16x3_kernel<3,"),
+            "conv1x1_split_kernel": ("conv_bf16x3_kernel<1,",), "gru_head_kernel": ("gru_head_kernel",)}
 # each kernel family is read from the workload whose bench configuration is the quoted one
 SOURCE = {"compdis_kernel": "compdis", "frame_prep_kernel": "compdis"}
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -23,8 +26,8 @@ for d in sorted(root.glob("*_*_SIZE")):
                 if row.get("Counter_Name") != counter:
                     continue
                 name = row.get("Kernel_Name", "")
-                for fam, pat in FAMILIES.items():
-                    if pat in name and SOURCE.get(fam, "pipeline") == workload:
+                for fam, pats in FAMILIES.items():
+                    if any(pat in name for pat in pats) and SOURCE.get(fam, "pipeline") == workload:
                         a = acc[fam][counter]
                         a[0] += float(row["Counter_Value"]); a[1] += 1
 out = {}
