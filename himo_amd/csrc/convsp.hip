@@ -71,11 +71,14 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
             r[it] = v;
         }
     };
-    auto store_patch = [&](int buf, const float4 (&r)[kPatchPerThread]) {
+    // part 0..2: a third of the items each (the staging of the NEXT slab is spread over the three kernel rows of the
+    // current one, so its conversion work runs in the shadow of the matrix instructions); part < 0: everything
+    auto store_patch = [&](int buf, const float4 (&r)[kPatchPerThread], int part) {
 #pragma unroll
         for (int it = 0; it < kPatchPerThread; ++it) {
             const int item = it * 256 + threadIdx.x;
-            if (item < kPatchItems) {
+            const int mine = it * 3 / kPatchPerThread;          // compile-time per unrolled iteration
+            if (item < kPatchItems && (part < 0 || part == mine)) {
                 const int pp = item >> 2, q = item & 3;
                 unsigned h[4], m[4], l[4];
                 const int off = pp * kSpRowBytes + q * 8;
@@ -93,36 +96,48 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
         }
     };
     // this wave's weight fragments of one (tap, slab): FMT x 16 bytes per lane
+    const int co_ld = co_ok ? co : a.Cout - 1;        // out-of-range lanes read a valid column; their results are never stored
     auto load_b = [&](int tap, int slab, uint4 (&b)[FMT]) {
-        const unsigned short* base = wpk + (((int64_t)tap * slabs + slab) * FMT) * a.Cout * 16 + (int64_t)co * 16 + lh * 8;
+        const unsigned short* base = wpk + (((int64_t)tap * slabs + slab) * FMT) * a.Cout * 16 + (int64_t)co_ld * 16 + lh * 8;
 #pragma unroll
-        for (int s = 0; s < FMT; ++s)
-            b[s] = co_ok ? *reinterpret_cast<const uint4*>(base + (int64_t)s * a.Cout * 16) : make_uint4(0u, 0u, 0u, 0u);
+        for (int s = 0; s < FMT; ++s) b[s] = *reinterpret_cast<const uint4*>(base + (int64_t)s * a.Cout * 16);
     };
 
+    // Weight fragments run TWO taps ahead of their use (an L2 round trip outlasts one tap's matrix work) in three
+    // register sets whose roles rotate statically -- tap t reads set t % 3 and loads tap t + 2 into set (t + 2) % 3 --
+    // so no copy ever forces a wait on a load issued in the same tap; 9 taps = 3 kernel rows keep the rotation aligned
+    // across slabs.  The loads are unconditional (clamped indices) to keep the loop body free of branches.
     float4 pr[kPatchPerThread];
-    uint4 bcur[FMT], bnxt[FMT];
+    uint4 bq[3][FMT];
     load_patch(0, pr);
-    load_b(0, 0, bcur);
-    store_patch(0, pr);
+    load_b(0, 0, bq[0]);
+    load_b(1, 0, bq[1]);
+    store_patch(0, pr, -1);
     __syncthreads();
 
 #pragma unroll 1
     for (int slab = 0; slab < slabs; ++slab) {
         const int buf = NB == 2 ? (slab & 1) : 0;
         const bool more = slab + 1 < slabs;
+        const int nslab = more ? slab + 1 : slab;            // clamped: the last slab re-loads its own (unused) weights
         if (more) load_patch(slab + 1, pr);
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 8) load_b(tap + 1, slab, bnxt);
-            else if (more) load_b(0, slab + 1, bnxt);
-            const int tapoff = (tap / 3) * PW + (tap % 3);
-            bf16x8 af[MI][FMT];
+        for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-            for (int s = 0; s < FMT; ++s)
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tap = ky * 3 + kx;
+                {   // prefetch tap + 2 (of this slab, or taps 0 / 1 of the next)
+                    const int t2 = tap + 2;
+                    load_b(t2 < 9 ? t2 : t2 - 9, t2 < 9 ? slab : nslab, bq[(kx + 2) % 3]);
+                }
+                const int tapoff = ky * PW + kx;
+                bf16x8 af[MI][FMT];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[buf][s][((wp * MI + mi) * PW + li + tapoff) * kSpRowBytes + lh * 16]);
+                for (int s = 0; s < FMT; ++s)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[buf][s][((wp * MI + mi) * PW + li + tapoff) * kSpRowBytes + lh * 16]);
+                const uint4 (&bcur)[FMT] = bq[kx];
 #define HIMO_TERM(SA, SB)                                                                                          \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                \
         acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][SA], __builtin_bit_cast(bf16x8, bcur[SB]), acc[mi], 0, 0, 0);
@@ -130,19 +145,21 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                \
         ACC[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[mi][SA]),                      \
                                                         __builtin_bit_cast(f16x8, bcur[SB]), ACC[mi], 0, 0, 0);
-            if constexpr (FMT == 3) {
-                HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
-            } else {
-                HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1)
-            }
+                if constexpr (FMT == 3) {
+                    HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
+                } else {
+                    HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1)
+                }
 #undef HIMO_TERM16
 #undef HIMO_TERM
-#pragma unroll
-            for (int s = 0; s < FMT; ++s) bcur[s] = bnxt[s];
+            }
+            if (NB == 2 && more) store_patch(buf ^ 1, pr, ky);   // the other buffer was last read before the previous barrier
         }
         if (more) {
-            if (NB == 1) __syncthreads();      // single buffer: every wave is done reading this slab's patch
-            store_patch(NB == 2 ? buf ^ 1 : 0, pr);   // (double buffer: the other one was last read before the previous barrier)
+            if (NB == 1) {
+                __syncthreads();               // single buffer: every wave is done reading this slab's patch
+                store_patch(0, pr, -1);
+            }
             __syncthreads();
         }
     }
