@@ -37,59 +37,88 @@ struct GruHeadArgs {
 };
 
 constexpr int kGhRows = 64, kGhSlabs = 12;              // 192 / 16
-constexpr int kGhPlane = kGhSlabs * kGhRows * 32;       // bytes per bf16 plane
+constexpr int kGhPlane = kGhSlabs * kGhRows * 32;       // bytes per 16-bit plane
 
 __device__ inline int a_slot(int s, int slab, int row, int half) {
     return ((s * kGhSlabs + slab) * kGhRows + row) * 32 + ((half ^ ((row >> 4) & 1)) << 4);
 }
 
-// one value of the A operand, column k of `row`, into the three planes
+// one value of the A operand, column k of `row`, into the FMT planes (FMT = 3: bf16 h, m, l; FMT = 2: fp16 h, l')
+template <int FMT>
 __device__ inline void a_store(unsigned char* A, int row, int k, float v) {
-    unsigned h, m, l;
-    split3(v, h, m, l);
+    unsigned h, m = 0, l;
+    if (FMT == 3) split3(v, h, m, l); else split2(v, h, l);
     const int slab = k >> 4, kk = k & 15;
     const int off = a_slot(0, slab, row, kk >> 3) + (kk & 7) * 2;
     *reinterpret_cast<unsigned short*>(A + off) = (unsigned short)h;
-    *reinterpret_cast<unsigned short*>(A + off + kGhPlane) = (unsigned short)m;
-    *reinterpret_cast<unsigned short*>(A + off + 2 * kGhPlane) = (unsigned short)l;
+    if (FMT == 3) *reinterpret_cast<unsigned short*>(A + off + kGhPlane) = (unsigned short)m;
+    *reinterpret_cast<unsigned short*>(A + off + (FMT - 1) * kGhPlane) = (unsigned short)l;
 }
 
 // acc[rt][t] += A[rows of tile rt][0..192) * W[:, col[t] + li] for the wave's NT column tiles; RT row tiles starting at rt0
-template <int RT, int NT>
+// FMT = 2: acx collects the cross terms (scaled by 2^11), folded in by finish()
+template <int RT, int NT, int FMT>
 __device__ inline void gemm192(const unsigned char* A, const unsigned short* __restrict__ wpk, int cout, const int (&col)[NT],
                                floatx16 (&acc)[RT][NT], int rt0, int li, int lh) {
-    uint4 bcur[NT][3], bnxt[NT][3];
-    auto load_b = [&](int slab, uint4 (&b)[NT][3]) {
+    floatx16 acx[FMT == 2 ? RT : 1][FMT == 2 ? NT : 1];
+    if (FMT == 2) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acx[rt][t][r] = 0.f;
+    }
+    uint4 bcur[NT][FMT], bnxt[NT][FMT];
+    auto load_b = [&](int slab, uint4 (&b)[NT][FMT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
-                b[t][s] = *reinterpret_cast<const uint4*>(wpk + (((int64_t)slab * 3 + s) * cout + col[t] + li) * 16 + lh * 8);
+            for (int s = 0; s < FMT; ++s)
+                b[t][s] = *reinterpret_cast<const uint4*>(wpk + (((int64_t)slab * FMT + s) * cout + col[t] + li) * 16 + lh * 8);
     };
     load_b(0, bcur);
 #pragma unroll 2
     for (int slab = 0; slab < kGhSlabs; ++slab) {
         if (slab + 1 < kGhSlabs) load_b(slab + 1, bnxt);
-        bf16x8 af[RT][3];
+        bf16x8 af[RT][FMT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < FMT; ++s)
                 af[rt][s] = *reinterpret_cast<const bf16x8*>(A + a_slot(s, slab, (rt0 + rt) * 32 + li, lh));
 #define HIMO_TERM(SA, SB)                                                                                          \
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int t = 0; t < NT; ++t)                  \
         acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][SA], __builtin_bit_cast(bf16x8, bcur[t][SB]), acc[rt][t], 0, 0, 0);
-        HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
+#define HIMO_TERM16(ACC, SA, SB)                                                                                   \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int t = 0; t < NT; ++t)                  \
+        ACC[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[rt][SA]),                    \
+                                                           __builtin_bit_cast(f16x8, bcur[t][SB]), ACC[rt][t], 0, 0, 0);
+        if constexpr (FMT == 3) {
+            HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
+        } else {
+            HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1)
+        }
+#undef HIMO_TERM16
 #undef HIMO_TERM
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) bcur[t][s] = bnxt[t][s];
+            for (int s = 0; s < FMT; ++s) bcur[t][s] = bnxt[t][s];
+    }
+    if (FMT == 2) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rt][t][r] += acx[rt][t][r] * kF16LowInv;
     }
 }
 
+template <int FMT>
 __global__ __launch_bounds__(256, 2) void gru_head_kernel(GruHeadArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char A[3 * kGhPlane];
+    __shared__ __attribute__((aligned(16))) unsigned char A[FMT * kGhPlane];
     __shared__ int s_pid[kGhRows];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
@@ -105,23 +134,11 @@ __global__ __launch_bounds__(256, 2) void gru_head_kernel(GruHeadArgs a) {
         const int64_t i = r0 + row;
         float o0 = 0.f, o1 = 0.f, o2 = 0.f;
         if (i < a.n) { o0 = a.offsets[i * 3]; o1 = a.offsets[i * 3 + 1]; o2 = a.offsets[i * 3 + 2]; }
-        unsigned hh[16], mm[16], ll[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int c = q * 16 + k;
             const float v = fmaf(o2, a.w_off[128 + c], fmaf(o1, a.w_off[64 + c], o0 * a.w_off[c])) + a.b_off[c];
-            split3(v, hh[k], mm[k], ll[k]);
-        }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int off = a_slot(0, 8 + q, row, half);
-            const int b = half * 8;
-            *reinterpret_cast<uint4*>(A + off) = make_uint4(hh[b] | (hh[b + 1] << 16), hh[b + 2] | (hh[b + 3] << 16),
-                                                             hh[b + 4] | (hh[b + 5] << 16), hh[b + 6] | (hh[b + 7] << 16));
-            *reinterpret_cast<uint4*>(A + off + kGhPlane) = make_uint4(mm[b] | (mm[b + 1] << 16), mm[b + 2] | (mm[b + 3] << 16),
-                                                                        mm[b + 4] | (mm[b + 5] << 16), mm[b + 6] | (mm[b + 7] << 16));
-            *reinterpret_cast<uint4*>(A + off + 2 * kGhPlane) = make_uint4(ll[b] | (ll[b + 1] << 16), ll[b + 2] | (ll[b + 3] << 16),
-                                                                            ll[b + 4] | (ll[b + 5] << 16), ll[b + 6] | (ll[b + 7] << 16));
+            a_store<FMT>(A, row, 128 + c, v);
         }
     }
     __syncthreads();
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void gru_head_kernel(GruHeadArgs a) {
             const int cell = s_pid[row];
             const float v = cell >= 0 ? src[(int64_t)cell * src_pitch + li] : 0.f;
             h[rt][r] = v;
-            a_store(A, row, wave * 32 + li, v);
+            a_store<FMT>(A, row, wave * 32 + li, v);
         }
     __syncthreads();
 
@@ -155,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void gru_head_kernel(GruHeadArgs a) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
-        gemm192<2, 2>(A, a.wzr, 256, col_zr, acc, 0, li, lh);
+        gemm192<2, 2, FMT>(A, a.wzr, 256, col_zr, acc, 0, li, lh);
         __syncthreads();                                        // every wave has read [h | x]
         float z[2][16];
 #pragma unroll
@@ -164,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void gru_head_kernel(GruHeadArgs a) {
             for (int r = 0; r < 16; ++r) {
                 z[rt][r] = sigmoid_f(acc[rt][0][r] + bz);
                 const float rr = sigmoid_f(acc[rt][1][r] + br);
-                a_store(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, rr * h[rt][r]);
+                a_store<FMT>(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, rr * h[rt][r]);
             }
         __syncthreads();                                        // A = [r*h | x]
         floatx16 acq[2][1];
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void gru_head_kernel(GruHeadArgs a) {
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acq[rt][0][r] = 0.f;
-        gemm192<2, 1>(A, a.wq, 128, col_q, acq, 0, li, lh);
+        gemm192<2, 1, FMT>(A, a.wq, 128, col_q, acq, 0, li, lh);
         __syncthreads();
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -181,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void gru_head_kernel(GruHeadArgs a) {
                 const float q = tanh_f(acq[rt][0][r] + bq);
                 const float hn = (1.0f - z[rt][r]) * h[rt][r] + z[rt][r] * q;
                 h[rt][r] = hn;
-                a_store(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, hn);
+                a_store<FMT>(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, hn);
             }
         __syncthreads();                                        // A = [h' | x]
     }
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void gru_head_kernel(GruHeadArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) ac1[0][0][r] = 0.f;
     const int col_1[1] = {0};
-    if (wave < 2) gemm192<1, 1>(A, a.w1, 32, col_1, ac1, wave, li, lh);
+    if (wave < 2) gemm192<1, 1, FMT>(A, a.w1, 32, col_1, ac1, wave, li, lh);
     __syncthreads();                                            // A is dead from here: reuse it for y1 [64][32] float32
     float* Y = reinterpret_cast<float*>(A);
     if (wave < 2) {
@@ -224,13 +241,14 @@ __global__ __launch_bounds__(256, 2) void gru_head_kernel(GruHeadArgs a) {
 using namespace himo;
 
 // hidden 128 (= 32 + 32 + 64 gathered channels), x 64, dec1 width 32: the head of himo_amd/seflow/spec.py.  Packed
-// weights: himo_conv_pack_weights(w, 1, 192, cout) of zr [192][256], q [192][128], dec1 [192][32].
+// weights: himo_conv_pack_weights_ex(w, 1, 192, cout, packed_format) of zr [192][256], q [192][128], dec1 [192][32].
 extern "C" int himo_gru_head(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0, const float* d_img1,
                              int img_pitch, const float* d_dec, int dec_pitch, const float* d_w_off, const float* d_b_off,
                              const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
                              const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
-                             const float* d_xyz_t, const float* d_pts, int pc_stride, float* d_flow, int iters, void* stream) {
-    if (n < 0 || iters < 0 || pc_stride < 3 || img_pitch < 32 || dec_pitch < 64) return HIMO_ERR_INVALID_ARGUMENT;
+                             const float* d_xyz_t, const float* d_pts, int pc_stride, float* d_flow, int iters, int packed_format,
+                             void* stream) {
+    if (n < 0 || iters < 0 || !(packed_format == 0 || packed_format == 1) || pc_stride < 3 || img_pitch < 32 || dec_pitch < 64) return HIMO_ERR_INVALID_ARGUMENT;
     if (n == 0) return HIMO_OK;
     if (!d_pid || !d_offsets || !d_img0 || !d_img1 || !d_dec || !d_w_off || !d_b_off || !d_wzr_packed || !d_bzr || !d_wq_packed ||
         !d_bq || !d_w1_packed || !d_b1 || !d_w2 || !d_b2 || !d_xyz_t || !d_pts || !d_flow)
@@ -242,7 +260,9 @@ extern "C" int himo_gru_head(int64_t n, const int32_t* d_pid, const float* d_off
                   (const unsigned short*)d_w1_packed, d_b1, d_w2, d_b2, d_xyz_t, d_pts, pc_stride, d_flow, iters};
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("gru_head_kernel", s);
-    hipLaunchKernelGGL(gru_head_kernel, dim3((unsigned)((n + kGhRows - 1) / kGhRows)), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)((n + kGhRows - 1) / kGhRows));
+    if (packed_format == 1) hipLaunchKernelGGL(gru_head_kernel<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gru_head_kernel<3>, grid, dim3(256), 0, s, a);
     HIMO_LAUNCH_CHECK("gru_head_kernel");
     return HIMO_OK;
 }

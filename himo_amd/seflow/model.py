@@ -50,7 +50,7 @@ _lib.register({
     "himo_conv_pack_weights_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                  ctypes.c_void_p]),
     "himo_gru_head": (ctypes.c_int, [ctypes.c_int64] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
-                      + [ctypes.c_void_p] * 12 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+                      + [ctypes.c_void_p] * 12 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "himo_head_gather": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
@@ -124,7 +124,7 @@ class SeFlowNet:
                 if k.endswith(".weight") and k != "pfn.weight" and not k.startswith("head.offset") and k != "head.dec2.weight":
                     w = v if v.dim() == 4 else v.reshape(1, 1, *v.shape)          # linears are 1x1 convolutions
                     ks, _, cin, cout = w.shape
-                    fmt = 0 if k.startswith("head.") else self.packed_format      # the head kernels read bf16x3
+                    fmt = self.packed_format
                     buf = torch.empty(int(self.lib.himo_conv_packed_weight_bytes(ks, cin, cout)), dtype=torch.uint8, device=self.device)
                     _lib.check(self.lib.himo_conv_pack_weights_ex(w.contiguous().data_ptr(), ks, cin, cout, fmt, buf.data_ptr(),
                                                                   _lib.stream_handle()), "himo_conv_pack_weights_ex")
@@ -191,7 +191,7 @@ class SeFlowNet:
         d.aux_out = None if aux_out is None else aux_out.data_ptr(); d.aux_out_pitch = aux_out_pitch
         pk = self.packed.get(f"{wname}.weight")
         d.w_packed = None if pk is None else pk.data_ptr()
-        d.packed_format = 0 if wname.startswith("head.") else self.packed_format
+        d.packed_format = self.packed_format
         key = (n, h, w, cin, cout, ks, stride, epi, pk is not None)
         if self.autotune and key not in self.tiles:
             self.tiles[key] = self._tune(d)
@@ -312,7 +312,7 @@ class SeFlowNet:
                                         pk["head.dec1.weight"].data_ptr(), p["head.dec1.bias"].data_ptr(),
                                         p["head.dec2.weight"].data_ptr(), p["head.dec2.bias"].data_ptr(),
                                         self.xyz_t[slot0].data_ptr(), pc0.data_ptr(), pc0.shape[1], flow.data_ptr(),
-                                        spec.GRU_ITERS, _lib.stream_handle())
+                                        spec.GRU_ITERS, self.packed_format, _lib.stream_handle())
             _lib.check(st, "himo_gru_head")
             return flow
         st = self.lib.himo_head_gather(n, self.pid[slot0].data_ptr(), self.offsets[slot0].data_ptr(),

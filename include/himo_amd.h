@@ -271,13 +271,14 @@ void himo_ops_release(const himo_op* h_ops);
 /* The whole per-point head in one kernel (inference, split-bf16): gather -> `iters` GRU iterations -> Linear(192,32)+GELU
  * -> Linear(32,3) -> flow (pose_flow + residual for in-range points, pose_flow otherwise).  Same inputs and result as
  * himo_head_gather + the GRU row-GEMMs of himo_conv2d + himo_head_final; the hidden state never leaves the chip.
- * Fixed widths: hidden 128 (32 + 32 + 64 gathered channels), x 64.  Packed weights = himo_conv_pack_weights(w, 1, 192, cout)
- * of zr [192][256] (z | r), q [192][128], dec1 [192][32].  Specification: himo_amd/seflow/spec.py (reference absent). */
+ * Fixed widths: hidden 128 (32 + 32 + 64 gathered channels), x 64.  Packed weights =
+ * himo_conv_pack_weights_ex(w, 1, 192, cout, packed_format) of zr [192][256] (z | r), q [192][128], dec1 [192][32].  Specification: himo_amd/seflow/spec.py (reference absent). */
 int himo_gru_head(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0, const float* d_img1,
                   int img_pitch, const float* d_dec, int dec_pitch, const float* d_w_off, const float* d_b_off,
                   const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
                   const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
-                  const float* d_xyz_t, const float* d_pts, int pc_stride, float* d_flow, int iters, void* stream);
+                  const float* d_xyz_t, const float* d_pts, int pc_stride, float* d_flow, int iters, int packed_format,
+                  void* stream);
 /* per-point head glue: hx[i] = [img0[cell], img1[cell], dec[cell], Linear(3,64)(offset)] (192 floats; zeros for
  * dropped points), rhx[i][128:192] = the same Linear output */
 int himo_head_gather(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0,
