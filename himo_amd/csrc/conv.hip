@@ -310,7 +310,10 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
     a.Wo = d->stride == 2 ? (d->w_in + 1) / 2 : d->w_in;
     a.aux_in = d->aux_in; a.aux_in_pitch = d->aux_in_pitch; a.aux_out = d->aux_out; a.aux_out_pitch = d->aux_out_pitch;
     hipStream_t s = (hipStream_t)stream;
-    if (d->w_packed && d->stride == 1) return launch_conv_bf16x3(a, d->ksize, d->epilogue, d->w_packed, d->tile_hint, d->packed_format, s);
+    // split precision: every stride-1 layer, and the 3x3 stride-2 layers unless the caller pins a float32 tile
+    if (d->w_packed && (d->stride == 1 || (d->ksize == 3 && d->epilogue != kEpiGruZR && d->epilogue != kEpiGruQ &&
+                                          (d->tile_hint == 0 || (d->tile_hint & 0x1000)))))
+        return launch_conv_bf16x3(a, d->ksize, d->epilogue, d->w_packed, d->tile_hint, d->packed_format, d->stride, s);
     // tile choice: 128 x 128 when that still gives >= 2 blocks per CU, else shrink M then N so the chip is filled
     auto blocks_for = [&](int bn, int mi) -> int64_t {
         const int bm = 64 * mi, th = 4 * mi;

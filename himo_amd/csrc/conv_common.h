@@ -68,6 +68,6 @@ __device__ inline void epilogue_store(const ConvArgs& a, float* __restrict__ you
 }
 
 // implemented in convbf.hip: stride-1 convolutions / row GEMMs on split-bf16 matrix instructions
-int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w_packed, int tile_hint, int format, hipStream_t s);
+int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w_packed, int tile_hint, int format, int stride, hipStream_t s);
 
 }  // namespace himo

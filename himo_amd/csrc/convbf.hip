@@ -298,15 +298,17 @@ static void launch_bf_tile(const ConvArgs& a, int epi, int bn, int mi, const uns
     else { if (mi == 2) launch_bf_epi<KS, 64, 2, FMT>(a, epi, w, grid, s); else launch_bf_epi<KS, 64, 1, FMT>(a, epi, w, grid, s); }
 }
 
-bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, int format, int rows_hint, hipStream_t s);   // convsp.hip
+bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, int format, int rows_hint, int stride, hipStream_t s);   // convsp.hip
 
-int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w_packed, int tile_hint, int format, hipStream_t s) {
+int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w_packed, int tile_hint, int format, int stride, hipStream_t s) {
     // 3x3 layers: the weights-from-L2 structure (convsp.hip; tile_hint 0x1000 | rows-per-wave pins its variant) unless the
     // caller pins a tile of this file's kernel
-    if (ksize == 3 && (!tile_hint || (tile_hint & 0x1000)) && launch_conv3_split(a, epilogue, w_packed, format, tile_hint & 15, s)) {
+    if (ksize == 3 && (!tile_hint || (tile_hint & 0x1000) || stride == 2) &&
+        launch_conv3_split(a, epilogue, w_packed, format, tile_hint & 15, stride, s)) {
         HIMO_LAUNCH_CHECK("conv3_split_kernel");
         return HIMO_OK;
     }
+    if (stride != 1) return HIMO_ERR_UNSUPPORTED;
     auto blocks_for = [&](int bn, int mi) -> int64_t {
         const int bm = 64 * mi, th = 2 * mi;
         const int64_t tm = ksize == 1 ? (int64_t)a.N * (((int64_t)a.Ho * a.Wo + bm - 1) / bm)

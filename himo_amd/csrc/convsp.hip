@@ -19,9 +19,13 @@ namespace himo {
 
 constexpr int kSpRowBytes = 48;      // LDS pitch of one patch pixel: 16 x 2 bytes + 16 of padding (conflict-free b128 reads)
 
-template <int EPI, int PH, int FMT, int MI>
+// S = 2 (the three stride-2 layers): the halo patch is (2 TH + 1) x 65 input pixels, stored with even and odd
+// columns de-interleaved ([33 even | 32 odd] per row) so that the 32 output pixels of a fragment -- input columns
+// 2 li + kx -- are again 32 CONSECUTIVE patch pixels for every tap.
+template <int EPI, int PH, int FMT, int MI, int S>
 __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
-    constexpr int TW = 32, TH = MI * PH, PW = TW + 2, PHt = TH + 2, NPIX = PHt * PW;
+    constexpr int TW = 32, TH = MI * PH;
+    constexpr int PW = S == 1 ? TW + 2 : 2 * TW + 1, PHt = S == 1 ? TH + 2 : 2 * TH + 1, NPIX = PHt * PW;
     constexpr int BN = (4 / PH) * 32;
     constexpr int kPatchItems = NPIX * 4;
     constexpr int kPatchPerThread = (kPatchItems + 255) / 256;
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
     const int li = lane & 31, lh = lane >> 5;
     const int co = tn * BN + wc * 32 + li;
     const bool co_ok = co < a.Cout;
-    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
 
     floatx16 acc[MI];
     floatx16 acx[FMT == 2 ? MI : 1];
@@ -63,7 +67,8 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (item < kPatchItems) {
                 const int pp = item >> 2, q = item & 3;
-                const int iy = iy0 + pp / PW, ix = ix0 + pp % PW;
+                const int pc = pp % PW;
+                const int iy = iy0 + pp / PW, ix = ix0 + (S == 1 ? pc : pc < 33 ? 2 * pc : 2 * (pc - 33) + 1);
                 const int ci = slab * 16 + q * 4;
                 if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ci < a.Cin)
                     v = *reinterpret_cast<const float4*>(xin + ((int64_t)iy * a.W + ix) * a.x_pitch + ci);
@@ -130,13 +135,13 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
                     const int t2 = tap + 2;
                     load_b(t2 < 9 ? t2 : t2 - 9, t2 < 9 ? slab : nslab, bq[(kx + 2) % 3]);
                 }
-                const int tapoff = ky * PW + kx;
+                const int tapoff = S == 1 ? ky * PW + kx : ky * PW + (kx & 1) * 33 + (kx >> 1);
                 bf16x8 af[MI][FMT];
 #pragma unroll
                 for (int s = 0; s < FMT; ++s)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[buf][s][((wp * MI + mi) * PW + li + tapoff) * kSpRowBytes + lh * 16]);
+                        af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[buf][s][((wp * MI + mi) * S * PW + li + tapoff) * kSpRowBytes + lh * 16]);
                 const uint4 (&bcur)[FMT] = bq[kx];
 #define HIMO_TERM(SA, SB)                                                                                          \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                \
@@ -182,25 +187,27 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
     }
 }
 
-template <int PH, int FMT, int MI>
+template <int PH, int FMT, int MI, int S>
 static void launch_sp_epi(const ConvArgs& a, int epi, const unsigned short* w, dim3 grid, hipStream_t s) {
     switch (epi) {
-        case kEpiBias: hipLaunchKernelGGL((conv3_split_kernel<kEpiBias, PH, FMT, MI>), grid, dim3(256), 0, s, a, w); break;
-        case kEpiBiasBnGelu: hipLaunchKernelGGL((conv3_split_kernel<kEpiBiasBnGelu, PH, FMT, MI>), grid, dim3(256), 0, s, a, w); break;
-        case kEpiBiasGelu: hipLaunchKernelGGL((conv3_split_kernel<kEpiBiasGelu, PH, FMT, MI>), grid, dim3(256), 0, s, a, w); break;
-        case kEpiBiasRelu: hipLaunchKernelGGL((conv3_split_kernel<kEpiBiasRelu, PH, FMT, MI>), grid, dim3(256), 0, s, a, w); break;
-        default: hipLaunchKernelGGL((conv3_split_kernel<kEpiReluMask, PH, FMT, MI>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBias: hipLaunchKernelGGL((conv3_split_kernel<kEpiBias, PH, FMT, MI, S>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBiasBnGelu: hipLaunchKernelGGL((conv3_split_kernel<kEpiBiasBnGelu, PH, FMT, MI, S>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBiasGelu: hipLaunchKernelGGL((conv3_split_kernel<kEpiBiasGelu, PH, FMT, MI, S>), grid, dim3(256), 0, s, a, w); break;
+        case kEpiBiasRelu: hipLaunchKernelGGL((conv3_split_kernel<kEpiBiasRelu, PH, FMT, MI, S>), grid, dim3(256), 0, s, a, w); break;
+        default: hipLaunchKernelGGL((conv3_split_kernel<kEpiReluMask, PH, FMT, MI, S>), grid, dim3(256), 0, s, a, w); break;
     }
 }
 
 template <int PH, int FMT>
-static void launch_sp_mi(const ConvArgs& a, int epi, int mi, const unsigned short* w, dim3 grid, hipStream_t s) {
-    if (mi == 4) launch_sp_epi<PH, FMT, 4>(a, epi, w, grid, s); else launch_sp_epi<PH, FMT, 2>(a, epi, w, grid, s);
+static void launch_sp_mi(const ConvArgs& a, int epi, int mi, int stride, const unsigned short* w, dim3 grid, hipStream_t s) {
+    if (stride == 2) launch_sp_epi<PH, FMT, 2, 2>(a, epi, w, grid, s);          // stride 2: two output rows per wave
+    else if (mi == 4) launch_sp_epi<PH, FMT, 4, 1>(a, epi, w, grid, s);
+    else launch_sp_epi<PH, FMT, 2, 1>(a, epi, w, grid, s);
 }
 
-// 3x3 stride-1 layers with a plain epilogue; returns false when this structure does not apply (GRU epilogues).
-// rows_hint: 0 = heuristic, else image rows per wave (4 | 2).
-bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, int format, int rows_hint, hipStream_t s) {
+// 3x3 layers (stride 1 | 2) with a plain epilogue; returns false when this structure does not apply (GRU epilogues).
+// rows_hint: 0 = heuristic, else image rows per wave (4 | 2; stride 2 always uses 2).
+bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, int format, int rows_hint, int stride, hipStream_t s) {
     if (epilogue == kEpiGruZR || epilogue == kEpiGruQ) return false;
     const bool wide = a.Cout > 64;                     // PH = 1: 128-channel tiles; PH = 2: 64-channel tiles
     const int bn = wide ? 128 : 64, ph = wide ? 1 : 2;
@@ -210,11 +217,14 @@ bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, i
     };
     int mi = blocks_for(4) >= 1024 ? 4 : 2;            // two blocks per CU, at least two rounds of them
     if (rows_hint == 4 || rows_hint == 2) mi = rows_hint;
+    if (stride == 2) mi = 2;
     const dim3 grid((unsigned)blocks_for(mi));
     const unsigned short* w = (const unsigned short*)w_packed;
-    ProfScope ps(format == 1 ? "conv3x3_f16x2_kernel" : "conv3x3_bf16x3_kernel", s);
-    if (format == 1) { if (wide) launch_sp_mi<1, 2>(a, epilogue, mi, w, grid, s); else launch_sp_mi<2, 2>(a, epilogue, mi, w, grid, s); }
-    else { if (wide) launch_sp_mi<1, 3>(a, epilogue, mi, w, grid, s); else launch_sp_mi<2, 3>(a, epilogue, mi, w, grid, s); }
+    const char* name = stride == 2 ? (format == 1 ? "conv3x3s2_f16x2_kernel" : "conv3x3s2_bf16x3_kernel")
+                                   : (format == 1 ? "conv3x3_f16x2_kernel" : "conv3x3_bf16x3_kernel");
+    ProfScope ps(name, s);
+    if (format == 1) { if (wide) launch_sp_mi<1, 2>(a, epilogue, mi, stride, w, grid, s); else launch_sp_mi<2, 2>(a, epilogue, mi, stride, w, grid, s); }
+    else { if (wide) launch_sp_mi<1, 3>(a, epilogue, mi, stride, w, grid, s); else launch_sp_mi<2, 3>(a, epilogue, mi, stride, w, grid, s); }
     return true;
 }
 

@@ -209,8 +209,8 @@ class SeFlowNet:
         best, best_t = 0, float("inf")
         stream = _lib.stream_handle()
         cands = [(bn << 4) | mi for bn in (128, 64) if not (bn == 128 and d.cout % 128) for mi in (2, 1)]
-        if d.w_packed and d.ksize == 3 and d.stride == 1:
-            cands += [0x1000 | 4, 0x1000 | 2]                 # the weights-from-L2 structure (csrc/convsp.hip)
+        if d.w_packed and d.ksize == 3:
+            cands += [0x1000 | 4, 0x1000 | 2] if d.stride == 1 else [0x1000 | 2]   # weights-from-L2 structure (csrc/convsp.hip)
         for hint in cands:
             d.tile_hint = hint
             for _ in range(2):
@@ -388,7 +388,7 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, strid
         d.n, d.h, d.w_in = n, h, w
     d.cin, d.cout, d.ksize, d.stride, d.epilogue = cin, cout, k, stride, epilogue
     d.tile_hint = tile_hint
-    if precision in ("bf16x3", "f16x2") and stride == 1:
+    if precision in ("bf16x3", "f16x2") and (stride == 1 or k == 3):
         fmt = 1 if precision == "f16x2" else 0
         pk = torch.empty(int(lib.himo_conv_packed_weight_bytes(k, cin, cout)), dtype=torch.uint8, device=x.device)
         _lib.check(lib.himo_conv_pack_weights_ex(weight.contiguous().data_ptr(), k, cin, cout, fmt, pk.data_ptr(), _lib.stream_handle()),

@@ -228,9 +228,9 @@ typedef struct himo_conv_desc {
     int n, h, w_in, cin, cout, ksize, stride, epilogue;
     const float* aux_in; int aux_in_pitch;                 /* GRU epilogues, [rows][pitch] */
     float* aux_out; int aux_out_pitch;
-    const void* w_packed;                                  /* optional: himo_conv_pack_weights output; when set and
-                                                              stride == 1 the split-bf16 kernel runs (same accuracy
-                                                              class, 2.67x the float32-MFMA rate) */
+    const void* w_packed;                                  /* optional: himo_conv_pack_weights[_ex] output; when set the
+                                                              split-precision kernels run (stride 1, and 3x3 stride 2):
+                                                              float32-class accuracy at a multiple of the float32-MFMA rate */
     int tile_hint;                                         /* 0 = library heuristic; else (channel tile 64|128) << 4 | (1|2):
                                                               pixel tile 64|128 of the LDS-staged-weights kernel, or
                                                               0x1000 | (4|2): image rows per wave of the weights-from-L2
