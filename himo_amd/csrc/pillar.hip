@@ -139,73 +139,99 @@ __global__ __launch_bounds__(256) void pillar_fill_kernel(PillarArgs a) {
 constexpr int kCellsPerBlock = 8;     // 8 cells x 32 lanes = 256 threads
 constexpr int kMaxStage = 128;        // points of one cell staged (and sorted) in LDS at a time
 
+constexpr int kFeatCells = 64;        // cells per block of the feature kernel
+
+// A block owns 64 consecutive cells.  Most cells of a sweep are empty (120k points over 262k cells): their 128-byte
+// rows are zero-filled cooperatively, and the non-empty ones are compacted into a short list that the block's eight
+// half-waves (32 lanes = 32 channels) work through -- 8x fewer, better balanced waves than one half-wave per cell.
 __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarArgs a) {
+    __shared__ int s_beg[kFeatCells + 1];
+    __shared__ int s_list[kFeatCells];
+    __shared__ int s_nlist;
     __shared__ int s_idx[kCellsPerBlock][kMaxStage];
     __shared__ int s_sorted[kCellsPerBlock][kMaxStage];
     const int sub = threadIdx.x >> 5, c = threadIdx.x & 31;
-    const int cell = blockIdx.x * kCellsPerBlock + sub;
     const int n_cells = a.g.W * a.g.H;
-    const bool live = cell < n_cells;
-    const int beg = live ? cell_offset(a, cell) : 0;
-    const int cnt = live ? cell_offset(a, cell + 1) - beg : 0;
-    const bool staged = cnt <= kMaxStage;
-
-    // ascending point order: rank every index among the cell's (short) list
-    if (staged)
-        for (int j = c; j < cnt; j += 32) s_idx[sub][j] = a.order[beg + j];
+    const int cell0 = blockIdx.x * kFeatCells;
+    if (threadIdx.x <= kFeatCells) s_beg[threadIdx.x] = cell_offset(a, min(cell0 + (int)threadIdx.x, n_cells));
     __syncthreads();
-    if (staged)
-        for (int j = c; j < cnt; j += 32) {
-            const int v = s_idx[sub][j];
-            int rank = 0;
-            for (int k = 0; k < cnt; ++k) rank += s_idx[sub][k] < v;
-            s_sorted[sub][rank] = v;
-            a.order2[beg + rank] = v;        // kept for the training backward pass (pfn_backward / scatter kernels)
-        }
-    if (!staged) {
-        // crowded cell (rare: > kMaxStage returns in one 0.2 m pillar): same ranking, through global memory
-        for (int j = c; j < cnt; j += 32) {
-            const int v = a.order[beg + j];
-            int rank = 0;
-            for (int k = 0; k < cnt; ++k) rank += a.order[beg + k] < v;
-            a.order2[beg + rank] = v;
-        }
-        __threadfence_block();
+    if (threadIdx.x < 64) {                                   // wave 0 compacts the non-empty cells (ascending)
+        const bool full = cell0 + (int)threadIdx.x < n_cells && s_beg[threadIdx.x + 1] > s_beg[threadIdx.x];
+        const unsigned long long mask = __ballot(full);
+        if (full) s_list[__popcll(mask & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
+        if (threadIdx.x == 0) s_nlist = __popcll(mask);
+    }
+    // zero rows of the empty cells
+#pragma unroll
+    for (int i = 0; i < kFeatCells / kCellsPerBlock; ++i) {
+        const int lc = i * kCellsPerBlock + sub;
+        if (cell0 + lc < n_cells && s_beg[lc + 1] == s_beg[lc]) a.image[(int64_t)(cell0 + lc) * a.image_pitch + c] = 0.f;
     }
     __syncthreads();
-    if (!live) return;
-    float* out = a.image + (int64_t)cell * a.image_pitch;
-    if (cnt == 0) { out[c] = 0.f; return; }
-    auto pt = [&](int j) { return staged ? s_sorted[sub][j] : a.order2[beg + j]; };
-
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int j = 0; j < cnt; ++j) {
-        const float* p = a.xyz_t + (int64_t)pt(j) * 3;
-        sx += p[0]; sy += p[1]; sz += p[2];
-    }
-    const float fc = (float)cnt;
-    const float mx = sx / fc, my = sy / fc, mz = sz / fc;
-    const int iy = cell / a.g.W, ix = cell - iy * a.g.W;
-    const float ccx = (float)ix * a.g.vx + a.g.cx0, ccy = (float)iy * a.g.vy + a.g.cy0, ccz = 0.f * a.g.vz + a.g.cz0;
-
+    const int nlist = s_nlist;
     float w[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) w[k] = a.pfn_w[k * 32 + c];
     const float scale = a.pfn_scale[c], shift = a.pfn_shift[c];
-    float acc = 0.f;
-    for (int j = 0; j < cnt; ++j) {
-        const int idx = pt(j);
-        const float* p = a.xyz_t + (int64_t)idx * 3;
-        const float x = p[0], y = p[1], z = p[2];
-        const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
-        float v = f[0] * w[0];
+
+    for (int k0 = 0; k0 < nlist; k0 += kCellsPerBlock) {      // block-uniform trip count: barriers inside are legal
+        const bool live = k0 + sub < nlist;
+        const int lc = live ? s_list[k0 + sub] : 0;
+        const int cell = cell0 + lc;
+        const int beg = live ? s_beg[lc] : 0;
+        const int cnt = live ? s_beg[lc + 1] - beg : 0;
+        const bool staged = cnt <= kMaxStage;
+        // ascending point order: rank every index among the cell's (short) list
+        if (staged)
+            for (int j = c; j < cnt; j += 32) s_idx[sub][j] = a.order[beg + j];
+        __syncthreads();
+        if (staged)
+            for (int j = c; j < cnt; j += 32) {
+                const int v = s_idx[sub][j];
+                int rank = 0;
+                for (int k = 0; k < cnt; ++k) rank += s_idx[sub][k] < v;
+                s_sorted[sub][rank] = v;
+                a.order2[beg + rank] = v;        // kept for the training backward pass (pfn_backward / scatter kernels)
+            }
+        if (!staged) {
+            // crowded cell (rare: > kMaxStage returns in one 0.2 m pillar): same ranking, through global memory
+            for (int j = c; j < cnt; j += 32) {
+                const int v = a.order[beg + j];
+                int rank = 0;
+                for (int k = 0; k < cnt; ++k) rank += a.order[beg + k] < v;
+                a.order2[beg + rank] = v;
+            }
+            __threadfence_block();
+        }
+        __syncthreads();
+        if (live) {
+            auto pt = [&](int j) { return staged ? s_sorted[sub][j] : a.order2[beg + j]; };
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (int j = 0; j < cnt; ++j) {
+                const float* p = a.xyz_t + (int64_t)pt(j) * 3;
+                sx += p[0]; sy += p[1]; sz += p[2];
+            }
+            const float fc = (float)cnt;
+            const float mx = sx / fc, my = sy / fc, mz = sz / fc;
+            const int iy = cell / a.g.W, ix = cell - iy * a.g.W;
+            const float ccx = (float)ix * a.g.vx + a.g.cx0, ccy = (float)iy * a.g.vy + a.g.cy0, ccz = 0.f * a.g.vz + a.g.cz0;
+            float acc = 0.f;
+            for (int j = 0; j < cnt; ++j) {
+                const int idx = pt(j);
+                const float* p = a.xyz_t + (int64_t)idx * 3;
+                const float x = p[0], y = p[1], z = p[2];
+                const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
+                float v = f[0] * w[0];
 #pragma unroll
-        for (int k = 1; k < 9; ++k) v = fmaf(f[k], w[k], v);
-        v = v * scale + shift;
-        acc += fmaxf(v, 0.f);
-        if (c < 3) a.offsets[(int64_t)idx * 3 + c] = f[6 + c];
+                for (int k = 1; k < 9; ++k) v = fmaf(f[k], w[k], v);
+                v = v * scale + shift;
+                acc += fmaxf(v, 0.f);
+                if (c < 3) a.offsets[(int64_t)idx * 3 + c] = f[6 + c];
+            }
+            a.image[(int64_t)cell * a.image_pitch + c] = acc / fc;
+        }
+        __syncthreads();                                      // s_idx / s_sorted are reused by the next round
     }
-    out[c] = acc / fc;
 }
 
 // ---- training backward (stage a11) ------------------------------------------------------------------------------
@@ -381,7 +407,7 @@ extern "C" int himo_pillarize(int64_t n, const float* d_pts, int pc_stride, cons
     HIMO_LAUNCH_CHECK("pillar_fill_kernel");
     {
         ProfScope ps("pillar_feature_kernel", s);
-        hipLaunchKernelGGL(pillar_feature_kernel, dim3((cells + kCellsPerBlock - 1) / kCellsPerBlock), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(pillar_feature_kernel, dim3((cells + kFeatCells - 1) / kFeatCells), dim3(256), 0, s, a);
     }
     HIMO_LAUNCH_CHECK("pillar_feature_kernel");
     return HIMO_OK;
