@@ -116,6 +116,7 @@ class HeadTrainer:
         else:
             self.p, self.g = p, g
         self.n = 0
+        self._descs = {}
 
     def _reserve(self, n):
         if n == self.n:
@@ -138,11 +139,19 @@ class HeadTrainer:
         self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
 
     def _gemm(self, x, w, bias, y, cin, cout, epi=EPI_BIAS):
-        d = ConvDesc()
-        d.x = x.data_ptr(); d.x_pitch = x.shape[1]
-        d.w = w.data_ptr(); d.bias = None if bias is None else bias.data_ptr()
-        d.y = y.data_ptr(); d.y_pitch = y.shape[1]
-        d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = 1, 1, x.shape[0], cin, cout, 1, 1, epi
+        # descriptors are cached per call site (same buffers every step): filling a ConvDesc costs more host time
+        # than the launch itself, and a training step makes ~450 launches
+        key = (x.data_ptr(), x.shape[0], x.shape[1], w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), y.shape[1], cin, cout, epi)
+        d = self._descs.get(key)
+        if d is None:
+            d = ConvDesc()
+            d.x = x.data_ptr(); d.x_pitch = x.shape[1]
+            d.w = w.data_ptr(); d.bias = None if bias is None else bias.data_ptr()
+            d.y = y.data_ptr(); d.y_pitch = y.shape[1]
+            d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = 1, 1, x.shape[0], cin, cout, 1, 1, epi
+            if len(self._descs) > 4096:
+                self._descs.clear()
+            self._descs[key] = d
         _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), "himo_conv2d(head)")
 
     def forward(self, hx0: torch.Tensor) -> torch.Tensor:
@@ -286,6 +295,7 @@ class SeFlowTrainer:
         hg = {k[5:]: v for k, v in self.g.items() if k.startswith("head.") and not k.startswith("head.offset")}
         self.head = HeadTrainer(device=dev, p=hp, g=hg)
         self.step_count = 0
+        self._descs = {}
         # ---- saved encoder activations: PRE (after BN, before GELU) and Y per layer, frames as the batch
         buf = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         self.layers = []          # (name, cin, cout, stride, h_in, w_in, ho, wo, last_of_stage)
@@ -344,12 +354,18 @@ class SeFlowTrainer:
 
     # ---- launch helpers (raw device addresses: most operands are channel groups of wider buffers) --------------
     def _conv(self, x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride=1, packed=None):
-        d = ConvDesc()
-        d.x, d.x_batch_stride, d.x_pitch = x, x_bs, x_pitch
-        d.w = w; d.bias = bias
-        d.w_packed = packed
-        d.y, d.y_batch_stride, d.y_pitch = y, y_bs, y_pitch
-        d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = n, h, wd, cin, cout, ks, stride, EPI_BIAS
+        key = (x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride, packed)
+        d = self._descs.get(key)                 # cached per call site: see HeadTrainer._gemm
+        if d is None:
+            d = ConvDesc()
+            d.x, d.x_batch_stride, d.x_pitch = x, x_bs, x_pitch
+            d.w = w; d.bias = bias
+            d.w_packed = packed
+            d.y, d.y_batch_stride, d.y_pitch = y, y_bs, y_pitch
+            d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = n, h, wd, cin, cout, ks, stride, EPI_BIAS
+            if len(self._descs) > 4096:
+                self._descs.clear()
+            self._descs[key] = d
         _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), "himo_conv2d(train)")
 
     def _wgrad3_batch(self, n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, gname, stride=1):
