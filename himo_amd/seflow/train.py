@@ -556,10 +556,9 @@ class SeFlowTrainer:
         """Mean of the flat gradient over ranks: ONE collective per step (RCCL over xGMI)."""
         allreduce_mean_(self.flat_g)
 
-    def train_step(self, pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels: int | None = None, lr: float = 2e-4):
-        """One optimisation step on one sample per rank: forward, self-supervised loss (himo_amd/ssl_loss.py; the flow
-        it scores is the network's residual flow of pc0 in pc1's frame), backward, gradient all-reduce, Adam.
-        Returns ({term: 0-d float64 device tensor}, total)."""
+    def loss_and_grad(self, pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels: int | None = None):
+        """forward + self-supervised loss (himo_amd/ssl_loss.py; the flow it scores is the network's residual flow of
+        pc0 in pc1's frame) + backward: this sample's gradient lands in ``flat_g``.  Returns (terms, total)."""
         from ..ssl_loss import SeFlowLoss
         if not hasattr(self, "loss"):
             self.loss = SeFlowLoss(device=self.device)
@@ -569,9 +568,41 @@ class SeFlowTrainer:
         dres = torch.zeros((n0, 4), dtype=torch.float32, device=self.device)
         dres[:, :3] = grad
         self.backward(dres)
+        return terms, total
+
+    def train_step(self, pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels: int | None = None, lr: float = 6e-5):
+        """One optimisation step on one sample per rank: forward, loss, backward, gradient all-reduce, Adam
+        (``lr`` default = the reference launcher's ``optimizer.lr=6e-5``, assets/slurm/ssl-train-av2.sh:33).
+        Returns ({term: 0-d float64 device tensor}, total)."""
+        terms, total = self.loss_and_grad(pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels)
         self.allreduce()
         self.adam_step(lr)
         return terms, total
+
+    def train_batch(self, samples, lr: float = 6e-5):
+        """One optimisation step on SEVERAL samples per rank (the launcher's ``batch_size=8`` on fewer than 8 GPUs):
+        ``samples`` = iterable of (pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels); the per-sample
+        gradients are averaged in a second flat buffer, then one all-reduce and one Adam step.  Returns the mean loss."""
+        if not hasattr(self, "flat_acc"):
+            self.flat_acc = torch.zeros_like(self.flat_g)
+        self.flat_acc.zero_()
+        mean, count = None, 0
+        for smp in samples:
+            _, total = self.loss_and_grad(*smp)
+            self.flat_acc.add_(self.flat_g)
+            mean = total if mean is None else mean + total
+            count += 1
+        if count == 0:
+            raise ValueError("train_batch needs at least one sample")
+        torch.mul(self.flat_acc, 1.0 / count, out=self.flat_g)
+        self.allreduce()
+        self.adam_step(lr)
+        return mean / count
+
+    @staticmethod
+    def step_lr(epoch: int, base_lr: float = 6e-5, step_size: int = 3, gamma: float = 0.5) -> float:
+        """The launcher's ``StepLR(3, 0.5)`` schedule (assets/slurm/ssl-train-av2.sh:33): lr of a 0-based epoch."""
+        return base_lr * gamma ** (epoch // step_size)
 
     def adam_step(self, lr: float = 2e-4, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
         self.step_count += 1

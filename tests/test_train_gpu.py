@@ -202,3 +202,23 @@ def test_train_steps_reduce_the_loss(gpu):
     valid = net.pid[1][: len(pc0)].cpu().numpy() >= 0
     pose_flow = net.xyz_t[1][: len(pc0)].cpu().numpy() - pc0
     assert np.abs((flow - pose_flow)[valid] - res[valid]).max() <= 2e-4
+
+
+def test_train_batch_averages_the_per_sample_gradients(gpu):
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.train import SeFlowTrainer
+    tr = SeFlowTrainer(spec.init_params(6), device=gpu, max_points=6000)
+    batch, grads = [], []
+    for seed in (21, 22):
+        args, lab0, lab1 = _labelled_sample(5000, seed)
+        smp = (*args, torch.from_numpy(lab0).to(gpu), torch.from_numpy(lab1).to(gpu), int(lab0.max()) + 1)
+        batch.append(smp)
+        tr.loss_and_grad(*smp)
+        grads.append(tr.flat_g.clone())
+    p0 = tr.flat_p.clone()
+    loss = tr.train_batch(batch, lr=0.0)                     # lr 0: parameters stay, flat_g holds the batch gradient
+    assert np.isfinite(float(loss.item()))
+    assert torch.equal(tr.flat_p, p0)
+    want = (grads[0] + grads[1]) * 0.5
+    assert (tr.flat_g - want).abs().max().item() <= 1e-6 * max(want.abs().max().item(), 1e-12)
+    assert SeFlowTrainer.step_lr(0) == 6e-5 and SeFlowTrainer.step_lr(3) == 3e-5 and SeFlowTrainer.step_lr(7) == 1.5e-5
