@@ -218,11 +218,12 @@ template <int PH, int FMT>
 static void launch_sp_mi(const ConvArgs& a, int epi, int mi, int stride, const unsigned short* w, dim3 grid, hipStream_t s) {
     if (stride == 2) launch_sp_epi<PH, FMT, 2, 2>(a, epi, w, grid, s);          // stride 2: two output rows per wave
     else if (mi == 4) launch_sp_epi<PH, FMT, 4, 1>(a, epi, w, grid, s);
+    else if (mi == 1) launch_sp_epi<PH, FMT, 1, 1>(a, epi, w, grid, s);         // small images: more, smaller blocks
     else launch_sp_epi<PH, FMT, 2, 1>(a, epi, w, grid, s);
 }
 
 // 3x3 layers (stride 1 | 2) with a plain epilogue; returns false when this structure does not apply (GRU epilogues).
-// rows_hint: 0 = heuristic, else image rows per wave (4 | 2; stride 2 always uses 2).
+// rows_hint: 0 = heuristic, else image rows per wave (4 | 2 | 1; stride 2 always uses 2).
 bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, int format, int rows_hint, int stride, hipStream_t s) {
     if (epilogue == kEpiGruZR || epilogue == kEpiGruQ) return false;
     const bool wide = a.Cout > 64;                     // PH = 1: 128-channel tiles; PH = 2: 64-channel tiles
@@ -232,7 +233,7 @@ bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, i
         return (int64_t)a.N * ((a.Ho + th - 1) / th) * ((a.Wo + 31) / 32) * ((a.Cout + bn - 1) / bn);
     };
     int mi = blocks_for(4) >= 1024 ? 4 : 2;            // two blocks per CU, at least two rounds of them
-    if (rows_hint == 4 || rows_hint == 2) mi = rows_hint;
+    if (rows_hint == 4 || rows_hint == 2 || rows_hint == 1) mi = rows_hint;
     if (stride == 2) mi = 2;
     const dim3 grid((unsigned)blocks_for(mi));
     const unsigned short* w = (const unsigned short*)w_packed;
