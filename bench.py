@@ -286,7 +286,14 @@ def main():
                      "pose0": s.pose0, "pose1": s.pose1}
             ref_cd = oracle.comp_dis_frame_f32(frame, "seflowpp_best")
             got_cd = result["comp_dis"][:P].cpu().numpy()
+            # the same frame through the float32-MFMA kernels (no split arithmetic anywhere): what the split costs
+            net32 = SeFlowNet(params, device=device, max_points=P, precision="f32", autotune=False)
+            flow32 = net32.forward_device(s.pch1, s.pc0, s.pc1, s.pose_h1, s.pose0, s.pose1).cpu().numpy()
+            del net32
+            torch.cuda.empty_cache()
             parity = {"flow_mean_epe_vs_cpu_restatement": float(np.linalg.norm(got_flow - ref_flow, axis=1).mean()),
+                      "flow_max_abs_vs_float32_mfma_kernels": float(np.abs(got_flow - flow32).max()),
+                      "float32_mfma_kernels_max_abs_vs_cpu_restatement": float(np.abs(flow32 - ref_flow).max()),
                       "flow_max_abs_vs_cpu_restatement": float(np.abs(got_flow - ref_flow).max()),
                       "comp_dis_max_abs_vs_cpu_restatement": float(np.abs(got_cd.astype(np.float64) - ref_cd).max()),
                       "note": "network parity is against this build's own CPU restatement (reference source absent)"}
