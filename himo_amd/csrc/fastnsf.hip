@@ -79,17 +79,27 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(int64_t n, const flo
             }
 }
 
-// dW[ci][co] (+)= sum_b partial[tile][b][ci % 128][co % 128] in chunk order (deterministic); one thread per element
+// dW[ci][co] (+)= sum_b partial[tile][b][ci % 128][co % 128], deterministic: a block owns 64 consecutive elements, its
+// four thread groups sum every fourth chunk (four loads in flight per element instead of one serial chain), and the
+// groups are combined in a fixed order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int n_blocks, int cin, int cout,
                                                            float* __restrict__ dW, int accumulate) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= cin * cout) return;
-    const int ci = e / cout, co = e % cout;
-    const int tile = (ci / 128) * ((cout + 127) / 128) + co / 128;
-    const float* p = partial + (int64_t)tile * n_blocks * 128 * 128 + (ci % 128) * 128 + (co % 128);
+    __shared__ float sh[4][64];
+    const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + o;
     float s = 0.f;
-    for (int b = 0; b < n_blocks; ++b) s += p[(int64_t)b * 128 * 128];
-    dW[e] = accumulate ? dW[e] + s : s;
+    if (e < cin * cout) {
+        const int ci = e / cout, co = e % cout;
+        const int tile = (ci / 128) * ((cout + 127) / 128) + co / 128;
+        const float* p = partial + (int64_t)tile * n_blocks * 128 * 128 + (ci % 128) * 128 + (co % 128);
+        for (int b = grp; b < n_blocks; b += 4) s += p[(int64_t)b * 128 * 128];
+    }
+    sh[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && e < cin * cout) {
+        const float t = (sh[0][o] + sh[1][o]) + (sh[2][o] + sh[3][o]);
+        dW[e] = accumulate ? dW[e] + t : t;
+    }
 }
 
 // bias gradient: column sums of dZ, two stages with fixed order
@@ -309,7 +319,7 @@ extern "C" int himo_linear_wgrad_ex(int64_t n, const float* d_x, int x_pitch, in
         hipLaunchKernelGGL(wgrad_partial_kernel, dim3(nb, ci_tiles * co_tiles), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch, cout,
                            partial, rows_pb);
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cin * cout + 255) / 256), dim3(256), 0, s, partial, nb, cin, cout, d_dw, acc);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cin * cout + 63) / 64), dim3(256), 0, s, partial, nb, cin, cout, d_dw, acc);
     HIMO_LAUNCH_CHECK("wgrad kernels");
     if (d_db) return colsum_launch(n, d_dz, z_pitch, cout, d_db, acc, colpart, s);
     return HIMO_OK;

@@ -68,31 +68,47 @@ class FastNSF:
         self.lr, self.iters, self.seed, self.trunc = lr, iters, seed, trunc
         self.early_patience, self.early_min_delta = early_patience, early_min_delta
         self.loss_history = []
+        self._descs = {}
 
     # ---- parameters: stored padded to multiples of 4 channels (3 -> 4) -----------------------------------------------
     def _load(self, layers):
+        """Parameters, gradients and Adam moments live in ONE flat buffer each (views per layer): the optimiser step of
+        an iteration is a single launch instead of one per tensor."""
         dev = self.device
-        self.W, self.b, self.Wt = [], [], []
-        for k, (w, b) in enumerate(layers):
+        shapes = []
+        for w, b in layers:
             cin, cout = w.shape
-            pin, pout = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
-            wp = np.zeros((pin, pout), np.float32); wp[:cin, :cout] = w
-            bp = np.zeros(pout, np.float32); bp[:cout] = b
-            self.W.append(torch.from_numpy(wp).to(dev)); self.b.append(torch.from_numpy(bp).to(dev))
+            shapes.append(((cin + 3) // 4 * 4, (cout + 3) // 4 * 4))
+        total = sum(pi * po + po for pi, po in shapes)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g, self.flat_m, self.flat_v = (torch.zeros_like(self.flat_p) for _ in range(3))
+        self.W, self.b, self.gW, self.gb, self.Wt = [], [], [], [], []
+        host = np.zeros(total, np.float32)
+        o = 0
+        for (w, b), (pin, pout) in zip(layers, shapes):
+            cin, cout = w.shape
+            wp = host[o:o + pin * pout].reshape(pin, pout); wp[:cin, :cout] = w
+            self.W.append(self.flat_p[o:o + pin * pout].view(pin, pout)); self.gW.append(self.flat_g[o:o + pin * pout].view(pin, pout))
+            o += pin * pout
+            host[o:o + cout] = b
+            self.b.append(self.flat_p[o:o + pout]); self.gb.append(self.flat_g[o:o + pout])
+            o += pout
             self.Wt.append(torch.empty((pout, pin), dtype=torch.float32, device=dev))
-        z = lambda t: torch.zeros_like(t)
-        self.gW, self.gb = [z(w) for w in self.W], [z(b) for b in self.b]
-        self.mW, self.vW = [z(w) for w in self.W], [z(w) for w in self.W]
-        self.mb, self.vb = [z(b) for b in self.b], [z(b) for b in self.b]
+        self.flat_p.copy_(torch.from_numpy(host))
+        self._descs = {}
 
     def _gemm(self, x, w, bias, y, n, cin, cout, epi, aux=None):
-        d = ConvDesc()
-        d.x = x.data_ptr(); d.x_batch_stride = 0; d.x_pitch = x.shape[1]
-        d.w = w.data_ptr(); d.bias = None if bias is None else bias.data_ptr()
-        d.y = y.data_ptr(); d.y_batch_stride = 0; d.y_pitch = y.shape[1]
-        d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = 1, 1, n, cin, cout, 1, 1, epi
-        if aux is not None:
-            d.aux_in = aux.data_ptr(); d.aux_in_pitch = aux.shape[1]
+        key = (x.data_ptr(), w.data_ptr(), y.data_ptr(), epi)          # descriptors are cached per call site
+        d = self._descs.get(key)
+        if d is None:
+            d = ConvDesc()
+            d.x = x.data_ptr(); d.x_batch_stride = 0; d.x_pitch = x.shape[1]
+            d.w = w.data_ptr(); d.bias = None if bias is None else bias.data_ptr()
+            d.y = y.data_ptr(); d.y_batch_stride = 0; d.y_pitch = y.shape[1]
+            d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = 1, 1, n, cin, cout, 1, 1, epi
+            if aux is not None:
+                d.aux_in = aux.data_ptr(); d.aux_in_pitch = aux.shape[1]
+            self._descs[key] = d
         _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), "himo_conv2d(mlp)")
 
     def _forward(self, n):
@@ -153,10 +169,8 @@ class FastNSF:
                     nxt = self.dH[k % 2]
                     self._gemm(dz, self.Wt[k], None, nxt, n, cout, cin, EPI_RELU_MASK, aux=self.H[k - 1])
                     dz = nxt
-            for k in range(L):
-                for p, g, m, v in ((self.W[k], self.gW[k], self.mW[k], self.vW[k]), (self.b[k], self.gb[k], self.mb[k], self.vb[k])):
-                    _lib.check(lib.himo_adam_step(p.numel(), p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), self.lr, 0.9, 0.999,
-                                                  1e-8, it, s()), "adam")
+            _lib.check(lib.himo_adam_step(self.flat_p.numel(), self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
+                                          self.flat_v.data_ptr(), self.lr, 0.9, 0.999, 1e-8, it, s()), "adam")
             if self.early_patience > 0 or it == self.iters or it <= 3:
                 lv = float(loss.item())
                 self.loss_history.append((it, lv))
