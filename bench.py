@@ -414,7 +414,7 @@ def main():
         if args.workload == "train":
             line["metric"] = "train_frames_per_sec_120k"
             line["config"]["parallelism"] = f"data parallel x{world}, one flat all-reduce per step"
-        if not args.no_cpu_baseline and args.workload != "train":
+        if not args.no_cpu_baseline and args.workload != "train" and world == 1:     # CPU leg: rank 0 at N = 1 only
             if args.workload == "compdis":
                 frames = [frame_to_host(batch, i) for i in range(min(8, B))]
                 line["cpu_baseline"] = cpu_baseline_compdis(frames, args.cpu_seconds)
