@@ -79,6 +79,89 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(int64_t n, const flo
             }
 }
 
+// The same partial tiles with the operands staged through LDS: 32 rows x 128 columns of X and of dZ per stage, loaded
+// with 16-byte accesses (the fragment-from-global kernel above issues one 4-byte load per lane per fragment and is bound
+// by the number of load instructions, not by bytes), double-buffered; fragments are conflict-free ds_read_b32 (the two
+// half-waves of a fragment read two different rows).  Needs 16-byte aligned rows; the caller falls back otherwise.
+constexpr int kWtRows = 32;
+
+__global__ __launch_bounds__(256, 2) void wgrad_partial_lds_kernel(int64_t n, const float* __restrict__ X, int x_pitch, int cin,
+                                                                   const float* __restrict__ dZ, int z_pitch, int cout,
+                                                                   float* __restrict__ partial, int rows_pb) {
+    __shared__ __attribute__((aligned(16))) float Xs[2][kWtRows][128];
+    __shared__ __attribute__((aligned(16))) float Zs[2][kWtRows][128];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int co_tiles = (cout + 127) / 128;
+    const int ci0 = ((int)blockIdx.y / co_tiles) * 128, co0 = ((int)blockIdx.y % co_tiles) * 128;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_pb;
+    const int64_t r1 = r0 + rows_pb < n ? r0 + rows_pb : n;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // staging: thread -> (row = it * 8 + t / 32, float4 column q = t % 32), 4 rows x 2 matrices per thread per stage
+    const int q = threadIdx.x & 31, srow = threadIdx.x >> 5;
+    float4 px[4], pz[4];
+    auto load_stage = [&](int64_t base) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int64_t row = base + it * 8 + srow;
+            const bool ok = row < r1;
+            px[it] = (ok && ci0 + q * 4 < cin) ? *reinterpret_cast<const float4*>(X + row * x_pitch + ci0 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pz[it] = (ok && co0 + q * 4 < cout) ? *reinterpret_cast<const float4*>(dZ + row * z_pitch + co0 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            *reinterpret_cast<float4*>(&Xs[buf][it * 8 + srow][q * 4]) = px[it];
+            *reinterpret_cast<float4*>(&Zs[buf][it * 8 + srow][q * 4]) = pz[it];
+        }
+    };
+    load_stage(r0);
+    store_stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t base = r0; base < r1; base += kWtRows) {
+        const bool more = base + kWtRows < r1;
+        if (more) load_stage(base + kWtRows);
+#pragma unroll 4
+        for (int kk = 0; kk < kWtRows / 2; ++kk) {
+            const int row = 2 * kk + lh;
+            float af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = Xs[buf][row][wm * 64 + t * 32 + li];
+                bf[t] = Zs[buf][row][wn * 64 + t * 32 + li];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) {
+            store_stage(buf ^ 1);             // the other buffer was last read before the previous barrier
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    float* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 * 128;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wn * 64 + b * 32 + li] = acc[a][b][r];
+}
+
 // dW[ci][co] (+)= sum_b partial[tile][b][ci % 128][co % 128], deterministic: a block owns 64 consecutive elements, its
 // four thread groups sum every fourth chunk (four loads in flight per element instead of one serial chain), and the
 // groups are combined in a fixed order
@@ -274,7 +357,7 @@ static int wgrad_rows_per_block(int64_t n, int tiles) {
     const int64_t target_blocks = 512 / tiles > 0 ? 512 / tiles : 1;
     int64_t rows = (n + target_blocks - 1) / target_blocks;
     if (rows < kWgRows) rows = kWgRows;
-    return (int)((rows + 7) / 8 * 8);
+    return (int)((rows + 31) / 32 * 32);
 }
 
 // column sums into d_out; colpart holds ceil(cout/128) * nb * 128 floats with nb <= n / 256 + 1
@@ -316,8 +399,14 @@ extern "C" int himo_linear_wgrad_ex(int64_t n, const float* d_x, int x_pitch, in
     const int acc = (flags & 1u) ? 1 : 0;
     {
         ProfScope ps("wgrad_partial_kernel", s);
-        hipLaunchKernelGGL(wgrad_partial_kernel, dim3(nb, ci_tiles * co_tiles), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch, cout,
-                           partial, rows_pb);
+        const bool vec = !(x_pitch & 3) && !(z_pitch & 3) && !(cin & 3) && !(cout & 3) &&
+                         !((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_dz)) & 15);
+        if (vec)
+            hipLaunchKernelGGL(wgrad_partial_lds_kernel, dim3(nb, ci_tiles * co_tiles), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch,
+                               cout, partial, rows_pb);
+        else
+            hipLaunchKernelGGL(wgrad_partial_kernel, dim3(nb, ci_tiles * co_tiles), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch, cout,
+                               partial, rows_pb);
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cin * cout + 63) / 64), dim3(256), 0, s, partial, nb, cin, cout, d_dw, acc);
     HIMO_LAUNCH_CHECK("wgrad kernels");
