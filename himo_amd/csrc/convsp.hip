@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
         const int buf = NB == 2 ? (slab & 1) : 0;
         const bool more = slab + 1 < slabs;
         const int nslab = more ? slab + 1 : slab;            // clamped: the last slab re-loads its own (unused) weights
+#ifndef HIMO_EXP_NOSTAGE
         if (more) load_patch(slab + 1, pr);
+#endif
 #pragma unroll 1
         for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -174,9 +176,15 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
                     __builtin_amdgcn_sched_group_barrier(0x008, MI * 6, 0);
                 }
             }
+#ifndef HIMO_EXP_NOSTAGE
             if (NB == 2 && more) store_patch(buf ^ 1, pr, ky);   // the other buffer was last read before the previous barrier
+#endif
         }
+#ifdef HIMO_EXP_NOSTAGE
+        if (false) {
+#else
         if (more) {
+#endif
             if (NB == 1) {
                 __syncthreads();               // single buffer: every wave is done reading this slab's patch
                 store_patch(0, pr, -1);

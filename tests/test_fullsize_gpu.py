@@ -1,0 +1,89 @@
+"""BASELINE-size (120k points per sweep) checks of the network pipeline through size-independent properties -- the CPU
+restatement takes ~6 s per frame at this size, so only one frame is compared against it (bench.py does that check on
+every run); everything else here is oracle-free: determinism, agreement of the three matrix arithmetics, the
+dropped-point contract, and the fused path against the reference's own per-stage functions run on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N = 120_000
+
+
+@pytest.fixture(scope="module")
+def samples(gpu):
+    from himo_amd.pipeline import Sample
+    from himo_amd.synthetic import make_frame
+    frames = [make_frame(300 + i, n_points=N - 1000 * i) for i in range(4)]          # ragged: 120k, 119k, 118k, 117k
+    return frames, [Sample.from_frames(frames[0], frames[1], frames[2], device=gpu),
+                    Sample.from_frames(frames[1], frames[2], frames[3], device=gpu)]
+
+
+@pytest.fixture(scope="module")
+def runs(gpu, samples):
+    from himo_amd.pipeline import HiMoPipeline
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.model import SeFlowNet
+    params = spec.init_params(7)
+    out = {}
+    for prec in ("f16x2", "bf16x3", "f32"):
+        pipe = HiMoPipeline(SeFlowNet(params, device=gpu, max_points=N, precision=prec), device=gpu)
+        a = pipe.run(samples[1], refined=True)
+        first = {k: a[k].clone() for k in ("flow", "comp_dis", "refined")}
+        b = pipe.run(samples[1], refined=True)
+        pipe.sync_check()
+        out[prec] = (first, {k: b[k].clone() for k in ("flow", "comp_dis", "refined")}, pipe)
+    torch.cuda.synchronize()
+    return out
+
+
+def test_full_size_runs_are_bit_reproducible(runs):
+    for prec, (first, again, _) in runs.items():
+        for k in first:
+            assert torch.equal(first[k], again[k]), (prec, k)
+            assert torch.isfinite(first[k]).all(), (prec, k)
+
+
+def test_the_three_matrix_arithmetics_agree_within_the_parity_budget(runs):
+    ref = runs["f32"][0]["flow"]
+    for prec in ("f16x2", "bf16x3"):
+        d = (runs[prec][0]["flow"] - ref).abs().max().item()
+        assert d <= 1e-4, (prec, d)
+        dc = (runs[prec][0]["comp_dis"] - runs["f32"][0]["comp_dis"]).abs().max().item()
+        assert dc <= 1e-4, (prec, dc)
+
+
+def test_dropped_points_carry_pose_flow_only_and_rows_stay_aligned(runs, samples):
+    frames, smp = samples
+    first, _, pipe = runs["f16x2"]
+    net = pipe.net
+    flows = first["flow"]
+    assert flows.shape == (sum(s.pc0.shape[0] for s in smp), 3)
+    # last sample of the batch is still in the network's buffers: pid < 0 rows got pose flow only
+    n0 = smp[-1].pc0.shape[0]
+    pid = net.pid[1][:n0]
+    pose_flow = net.xyz_t[1][:n0] - smp[-1].pc0[:, :3]
+    got = flows[-n0:]
+    dropped = pid < 0
+    assert dropped.any() and (~dropped).any()
+    assert torch.equal(got[dropped], pose_flow[dropped])
+    assert (got[~dropped] - pose_flow[~dropped]).abs().mean().item() > 1e-3          # in-range rows do carry network flow
+
+
+def test_fused_comp_dis_equals_the_reference_stage_functions_on_the_gpu_flow(runs, samples, oracle):
+    """comp_dis and refined points of the fused batch kernel == save_zip.py:114-121 applied to the GPU's own flow
+    (the pinned numpy oracle), bit for bit in float32, on full-size frames."""
+    frames, smp = samples
+    first, _, _ = runs["f16x2"]
+    o = 0
+    for k, f0 in enumerate((frames[1], frames[2])):
+        n = smp[k].pc0.shape[0]
+        flow = first["flow"][o:o + n].cpu().numpy()
+        want = oracle.comp_dis_frame_f32(dict(f0, seflowpp_best=flow), "seflowpp_best")
+        got = first["comp_dis"][o:o + n].cpu().numpy()
+        assert np.abs(got.astype(np.float64) - want).max() <= 1e-9
+        ref_pts = oracle.refine_pts(f0["pc0"], want)             # float64 (comp_dis is float64 in the reference chain)
+        got_pts = first["refined"][o:o + n].cpu().numpy()        # stored as float32: one rounding of |x| <= 64
+        assert np.abs(got_pts.astype(np.float64) - ref_pts).max() <= 4e-6
+        o += n
