@@ -49,6 +49,8 @@ struct PillarArgs {
     int* cell_cursor;         // [H*W]
     int* order;               // [n] point indices grouped by cell (scatter order)
     int* order2;              // [n] ascending order for cells too crowded for the LDS stage
+    float* cell_xyz;          // [n][3] transformed points in cell-list (scatter) order: the feature kernel reads a cell's
+                              //        indices AND coordinates as two contiguous runs instead of index -> point chains
 };
 
 __global__ __launch_bounds__(256) void pillar_assign_kernel(PillarArgs a) {
@@ -133,7 +135,9 @@ __global__ __launch_bounds__(256) void pillar_fill_kernel(PillarArgs a) {
     const int cell = a.pid[i];
     if (cell < 0) return;
     const int slot = atomicAdd(&a.cell_cursor[cell], 1);
-    a.order[cell_offset(a, cell) + slot] = (int)i;
+    const int at = cell_offset(a, cell) + slot;
+    a.order[at] = (int)i;
+    a.cell_xyz[(int64_t)at * 3] = a.xyz_t[i * 3]; a.cell_xyz[(int64_t)at * 3 + 1] = a.xyz_t[i * 3 + 1]; a.cell_xyz[(int64_t)at * 3 + 2] = a.xyz_t[i * 3 + 2];
 }
 
 constexpr int kCellsPerBlock = 8;     // 8 cells x 32 lanes = 256 threads
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarArgs a) {
     __shared__ int s_nlist;
     __shared__ int s_idx[kCellsPerBlock][kMaxStage];
     __shared__ int s_sorted[kCellsPerBlock][kMaxStage];
+    __shared__ float s_xyz[kCellsPerBlock][kMaxStage][3];      // the cell's points, in ascending point order
     const int sub = threadIdx.x >> 5, c = threadIdx.x & 31;
     const int n_cells = a.g.W * a.g.H;
     const int cell0 = blockIdx.x * kFeatCells;
@@ -188,9 +193,12 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarArgs a) {
         if (staged)
             for (int j = c; j < cnt; j += 32) {
                 const int v = s_idx[sub][j];
+                const float* p = a.cell_xyz + (int64_t)(beg + j) * 3;
+                const float px = p[0], py = p[1], pz = p[2];
                 int rank = 0;
                 for (int k = 0; k < cnt; ++k) rank += s_idx[sub][k] < v;
                 s_sorted[sub][rank] = v;
+                s_xyz[sub][rank][0] = px; s_xyz[sub][rank][1] = py; s_xyz[sub][rank][2] = pz;
                 a.order2[beg + rank] = v;        // kept for the training backward pass (pfn_backward / scatter kernels)
             }
         if (!staged) {
@@ -206,10 +214,15 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarArgs a) {
         __syncthreads();
         if (live) {
             auto pt = [&](int j) { return staged ? s_sorted[sub][j] : a.order2[beg + j]; };
+            auto xyz = [&](int j, float& x, float& y, float& z) {
+                if (staged) { x = s_xyz[sub][j][0]; y = s_xyz[sub][j][1]; z = s_xyz[sub][j][2]; }
+                else { const float* p = a.xyz_t + (int64_t)a.order2[beg + j] * 3; x = p[0]; y = p[1]; z = p[2]; }
+            };
             float sx = 0.f, sy = 0.f, sz = 0.f;
             for (int j = 0; j < cnt; ++j) {
-                const float* p = a.xyz_t + (int64_t)pt(j) * 3;
-                sx += p[0]; sy += p[1]; sz += p[2];
+                float x, y, z;
+                xyz(j, x, y, z);
+                sx += x; sy += y; sz += z;
             }
             const float fc = (float)cnt;
             const float mx = sx / fc, my = sy / fc, mz = sz / fc;
@@ -218,8 +231,8 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarArgs a) {
             float acc = 0.f;
             for (int j = 0; j < cnt; ++j) {
                 const int idx = pt(j);
-                const float* p = a.xyz_t + (int64_t)idx * 3;
-                const float x = p[0], y = p[1], z = p[2];
+                float x, y, z;
+                xyz(j, x, y, z);
                 const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
                 float v = f[0] * w[0];
 #pragma unroll
@@ -347,7 +360,7 @@ using namespace himo;
 static size_t ws_cells(int cells) { return round_up((size_t)cells * 4, 16); }
 static size_t ws_blocks(int cells) { return round_up(((size_t)(cells + kScanBlock - 1) / kScanBlock + 1) * 4, 16); }
 static size_t ws_points(int64_t n) { return round_up((size_t)(n > 0 ? n : 1) * 4, 16); }
-static size_t pillar_ws(int64_t n, int cells) { return 2 * ws_cells(cells) + ws_blocks(cells) + 2 * ws_points(n); }
+static size_t pillar_ws(int64_t n, int cells) { return 2 * ws_cells(cells) + ws_blocks(cells) + 2 * ws_points(n) + 3 * ws_points(n); }
 
 extern "C" size_t himo_pillar_workspace_bytes(int64_t max_points, int grid_w, int grid_h) {
     return pillar_ws(max_points, grid_w * grid_h) + 64;
@@ -384,6 +397,7 @@ extern "C" int himo_pillarize(int64_t n, const float* d_pts, int pc_stride, cons
     a.block_sum = reinterpret_cast<int*>(ws + 2 * ws_cells(cells));
     a.order = reinterpret_cast<int*>(ws + 2 * ws_cells(cells) + ws_blocks(cells));
     a.order2 = a.order + ws_points(n) / 4;
+    a.cell_xyz = reinterpret_cast<float*>(a.order2 + ws_points(n) / 4);
     const int nblk = (cells + kScanBlock - 1) / kScanBlock;
     if (nblk > 1024) return HIMO_ERR_UNSUPPORTED;   // grids beyond 1M cells need a third scan level
 
