@@ -53,7 +53,13 @@ struct PillarArgs {
                               //        indices AND coordinates as two contiguous runs instead of index -> point chains
 };
 
-__global__ __launch_bounds__(256) void pillar_assign_kernel(PillarArgs a) {
+// up to four sweeps per launch (blockIdx.y selects the sweep): the stage's kernels are latency chains on small grids,
+// so the three sweeps of a sample share each launch instead of queueing behind one another
+constexpr int kMaxSweeps = 4;
+struct PillarBatch { PillarArgs s[kMaxSweeps]; };
+
+__global__ __launch_bounds__(256) void pillar_assign_kernel(PillarBatch m) {
+    const PillarArgs& a = m.s[blockIdx.y];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
     const float* p = a.pts + i * a.stride;
@@ -84,7 +90,10 @@ __global__ __launch_bounds__(256) void pillar_assign_kernel(PillarArgs a) {
 // Consumers read cell_offset(cell) = v[cell] + block_sum[cell / 1024].
 constexpr int kScanBlock = 1024;
 
-__global__ __launch_bounds__(256) void cell_scan_local_kernel(int* v, int n, int* block_sum) {
+__global__ __launch_bounds__(256) void cell_scan_local_kernel(PillarBatch m) {
+    int* v = m.s[blockIdx.y].cell_count;
+    int* block_sum = m.s[blockIdx.y].block_sum;
+    const int n = m.s[blockIdx.y].g.W * m.s[blockIdx.y].g.H;
     __shared__ int wsum[4];
     const int base = blockIdx.x * kScanBlock + threadIdx.x * 4;
     int x[4];
@@ -106,7 +115,8 @@ __global__ __launch_bounds__(256) void cell_scan_local_kernel(int* v, int n, int
     if (threadIdx.x == 255) block_sum[blockIdx.x] = run;
 }
 
-__global__ __launch_bounds__(1024) void cell_scan_top_kernel(int* block_sum, int nblk) {
+__global__ __launch_bounds__(1024) void cell_scan_top_kernel(PillarBatch m, int nblk) {
+    int* block_sum = m.s[blockIdx.y].block_sum;
     __shared__ int part[1024];
     const int x = (int)threadIdx.x < nblk ? block_sum[threadIdx.x] : 0;
     part[threadIdx.x] = x;
@@ -129,7 +139,8 @@ __device__ inline int cell_offset(const PillarArgs& a, int cell) {
                            : a.cell_count[cell] + a.block_sum[cell / kScanBlock];
 }
 
-__global__ __launch_bounds__(256) void pillar_fill_kernel(PillarArgs a) {
+__global__ __launch_bounds__(256) void pillar_fill_kernel(PillarBatch m) {
+    const PillarArgs& a = m.s[blockIdx.y];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
     const int cell = a.pid[i];
@@ -148,7 +159,8 @@ constexpr int kFeatCells = 64;        // cells per block of the feature kernel
 // A block owns 64 consecutive cells.  Most cells of a sweep are empty (120k points over 262k cells): their 128-byte
 // rows are zero-filled cooperatively, and the non-empty ones are compacted into a short list that the block's eight
 // half-waves (32 lanes = 32 channels) work through -- 8x fewer, better balanced waves than one half-wave per cell.
-__global__ __launch_bounds__(256) void pillar_feature_kernel(PillarArgs a) {
+__global__ __launch_bounds__(256) void pillar_feature_kernel(PillarBatch m) {
+    const PillarArgs& a = m.s[blockIdx.y];
     __shared__ int s_beg[kFeatCells + 1];
     __shared__ int s_list[kFeatCells];
     __shared__ int s_nlist;
@@ -366,12 +378,11 @@ extern "C" size_t himo_pillar_workspace_bytes(int64_t max_points, int grid_w, in
     return pillar_ws(max_points, grid_w * grid_h) + 64;
 }
 
-extern "C" int himo_pillarize(int64_t n, const float* d_pts, int pc_stride, const float* h_transform,
-                              const float* h_range, const float* h_voxel, const float* h_centre_offset,
-                              int grid_w, int grid_h,
-                              const float* d_pfn_weight, const float* d_pfn_scale, const float* d_pfn_shift,
-                              float* d_xyz_t, int32_t* d_pid, float* d_offsets, float* d_image, int image_pitch,
-                              void* d_workspace, size_t workspace_bytes, void* stream) {
+// validate one sweep's arguments and fill its kernel argument block
+static int pillar_args(PillarArgs& a, int64_t n, const float* d_pts, int pc_stride, const float* h_transform, const float* h_range,
+                       const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight,
+                       const float* d_pfn_scale, const float* d_pfn_shift, float* d_xyz_t, int32_t* d_pid, float* d_offsets,
+                       float* d_image, int image_pitch, void* d_workspace, size_t workspace_bytes) {
     if (n < 0 || pc_stride < 3 || grid_w < 1 || grid_h < 1 || !h_transform || !h_range || !h_voxel || !h_centre_offset)
         return HIMO_ERR_INVALID_ARGUMENT;
     if (!d_pfn_weight || !d_pfn_scale || !d_pfn_shift || !d_image || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
@@ -379,9 +390,8 @@ extern "C" int himo_pillarize(int64_t n, const float* d_pts, int pc_stride, cons
     if (n > 0x7fffffff || image_pitch < 32) return HIMO_ERR_UNSUPPORTED;
     const int cells = grid_w * grid_h;
     if (workspace_bytes < pillar_ws(n, cells) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-
-    PillarArgs a{};
+    if ((cells + kScanBlock - 1) / kScanBlock > 1024) return HIMO_ERR_UNSUPPORTED;   // grids beyond 1M cells need a third scan level
+    a = PillarArgs{};
     a.n = n; a.pts = d_pts; a.stride = pc_stride;
     for (int i = 0; i < 9; ++i) a.R[i] = h_transform[(i / 3) * 4 + (i % 3)];
     for (int i = 0; i < 3; ++i) a.t[i] = h_transform[i * 4 + 3];
@@ -398,33 +408,74 @@ extern "C" int himo_pillarize(int64_t n, const float* d_pts, int pc_stride, cons
     a.order = reinterpret_cast<int*>(ws + 2 * ws_cells(cells) + ws_blocks(cells));
     a.order2 = a.order + ws_points(n) / 4;
     a.cell_xyz = reinterpret_cast<float*>(a.order2 + ws_points(n) / 4);
-    const int nblk = (cells + kScanBlock - 1) / kScanBlock;
-    if (nblk > 1024) return HIMO_ERR_UNSUPPORTED;   // grids beyond 1M cells need a third scan level
+    return HIMO_OK;
+}
 
-    HIMO_HIP(hipMemsetAsync(a.cell_count, 0, 2 * ws_cells(cells), s));
-    const unsigned pblocks = (unsigned)((n + 255) / 256);
-    if (n > 0) {
+// the stage's five launches over `count` sweeps (same grid size for all of them)
+static int pillar_launch(const PillarBatch& m, int count, hipStream_t s) {
+    const int cells = m.s[0].g.W * m.s[0].g.H;
+    const int nblk = (cells + kScanBlock - 1) / kScanBlock;
+    int64_t nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        HIMO_HIP(hipMemsetAsync(m.s[i].cell_count, 0, 2 * ws_cells(cells), s));
+        if (m.s[i].n > nmax) nmax = m.s[i].n;
+    }
+    const unsigned pblocks = (unsigned)((nmax + 255) / 256);
+    if (nmax > 0) {
         ProfScope ps("pillar_assign_kernel", s);
-        hipLaunchKernelGGL(pillar_assign_kernel, dim3(pblocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(pillar_assign_kernel, dim3(pblocks, count), dim3(256), 0, s, m);
     }
     HIMO_LAUNCH_CHECK("pillar_assign_kernel");
     {
         ProfScope ps("cell_scan_kernels", s);
-        hipLaunchKernelGGL(cell_scan_local_kernel, dim3(nblk), dim3(256), 0, s, a.cell_count, cells, a.block_sum);
-        hipLaunchKernelGGL(cell_scan_top_kernel, dim3(1), dim3(1024), 0, s, a.block_sum, nblk);
+        hipLaunchKernelGGL(cell_scan_local_kernel, dim3(nblk, count), dim3(256), 0, s, m);
+        hipLaunchKernelGGL(cell_scan_top_kernel, dim3(1, count), dim3(1024), 0, s, m, nblk);
     }
     HIMO_LAUNCH_CHECK("cell_scan_kernels");
-    if (n > 0) {
+    if (nmax > 0) {
         ProfScope ps("pillar_fill_kernel", s);
-        hipLaunchKernelGGL(pillar_fill_kernel, dim3(pblocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(pillar_fill_kernel, dim3(pblocks, count), dim3(256), 0, s, m);
     }
     HIMO_LAUNCH_CHECK("pillar_fill_kernel");
     {
         ProfScope ps("pillar_feature_kernel", s);
-        hipLaunchKernelGGL(pillar_feature_kernel, dim3((cells + kFeatCells - 1) / kFeatCells), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(pillar_feature_kernel, dim3((cells + kFeatCells - 1) / kFeatCells, count), dim3(256), 0, s, m);
     }
     HIMO_LAUNCH_CHECK("pillar_feature_kernel");
     return HIMO_OK;
+}
+
+extern "C" int himo_pillarize(int64_t n, const float* d_pts, int pc_stride, const float* h_transform,
+                              const float* h_range, const float* h_voxel, const float* h_centre_offset,
+                              int grid_w, int grid_h,
+                              const float* d_pfn_weight, const float* d_pfn_scale, const float* d_pfn_shift,
+                              float* d_xyz_t, int32_t* d_pid, float* d_offsets, float* d_image, int image_pitch,
+                              void* d_workspace, size_t workspace_bytes, void* stream) {
+    PillarBatch m{};
+    const int st = pillar_args(m.s[0], n, d_pts, pc_stride, h_transform, h_range, h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight,
+                               d_pfn_scale, d_pfn_shift, d_xyz_t, d_pid, d_offsets, d_image, image_pitch, d_workspace, workspace_bytes);
+    if (st != HIMO_OK) return st;
+    return pillar_launch(m, 1, (hipStream_t)stream);
+}
+
+// several sweeps of one sample (history, pc0, pc1) in the same five launches; every sweep has its own outputs, image
+// channel group and workspace (workspace_bytes each)
+extern "C" int himo_pillarize_multi(int n_sweeps, const himo_sweep* h_sweeps, const float* h_range, const float* h_voxel,
+                                    const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight,
+                                    const float* d_pfn_scale, const float* d_pfn_shift, int image_pitch, size_t workspace_bytes,
+                                    void* stream) {
+    if (n_sweeps < 1 || n_sweeps > kMaxSweeps || !h_sweeps) return HIMO_ERR_INVALID_ARGUMENT;
+    PillarBatch m{};
+    for (int i = 0; i < n_sweeps; ++i) {
+        const himo_sweep& w = h_sweeps[i];
+        const int st = pillar_args(m.s[i], w.n, w.d_pts, w.pc_stride, w.transform, h_range, h_voxel, h_centre_offset, grid_w, grid_h,
+                                   d_pfn_weight, d_pfn_scale, d_pfn_shift, w.d_xyz_t, w.d_pid, w.d_offsets, w.d_image, image_pitch,
+                                   w.d_workspace, workspace_bytes);
+        if (st != HIMO_OK) return st;
+        for (int j = 0; j < i; ++j)
+            if (h_sweeps[j].d_workspace == w.d_workspace) return HIMO_ERR_INVALID_ARGUMENT;     // one workspace per sweep
+    }
+    return pillar_launch(m, n_sweeps, (hipStream_t)stream);
 }
 
 static void carve_bwd(PillarBwdArgs& a, int64_t n, int cells, void* d_workspace) {

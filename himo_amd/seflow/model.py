@@ -60,6 +60,13 @@ _lib.register({
 })
 
 
+class HimoSweep(ctypes.Structure):
+    """mirror of `himo_sweep` (include/himo_amd.h)"""
+    _fields_ = [("n", ctypes.c_int64), ("d_pts", ctypes.c_void_p), ("pc_stride", ctypes.c_int), ("transform", ctypes.c_float * 16),
+                ("d_xyz_t", ctypes.c_void_p), ("d_pid", ctypes.c_void_p), ("d_offsets", ctypes.c_void_p), ("d_image", ctypes.c_void_p),
+                ("d_workspace", ctypes.c_void_p)]
+
+
 class HimoOp(ctypes.Structure):
     """mirror of `himo_op` (include/himo_amd.h)"""
     _fields_ = [("kind", ctypes.c_int), ("conv", ConvDesc),
@@ -68,6 +75,9 @@ class HimoOp(ctypes.Structure):
 
 
 _lib.register({
+    "himo_pillarize_multi": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t,
+                                            ctypes.c_void_p]),
     "himo_run_ops": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_void_p]),
     "himo_ops_release": (None, [ctypes.c_void_p]),
 })
@@ -166,8 +176,9 @@ class SeFlowNet:
         self.max_points = n
         need = int(self.lib.himo_pillar_workspace_bytes(n, self.W, self.H))
         self.ws = torch.empty(need + 64, dtype=torch.uint8, device=dev)
-        # training keeps every sweep's cell lists for the backward pass: one workspace per frame slot
-        self.ws_slots = [torch.empty(need + 64, dtype=torch.uint8, device=dev) for _ in range(self.F)] if self.keep_cell_lists else None
+        # one workspace per frame slot: the three sweeps of a sample share their launches (himo_pillarize_multi), and
+        # training keeps every sweep's cell lists for the backward pass
+        self.ws_slots = [torch.empty(need + 64, dtype=torch.uint8, device=dev) for _ in range(self.F)]
         self.xyz_t = torch.empty((self.F, n, 3), dtype=torch.float32, device=dev)
         self.pid = torch.empty((self.F, n), dtype=torch.int32, device=dev)
         self.offsets = torch.empty((self.F, n, 3), dtype=torch.float32, device=dev)
@@ -347,18 +358,33 @@ class SeFlowNet:
         inv1 = np.linalg.inv(np.asarray(pose1, np.float64))
         T0 = inv1 @ np.asarray(pose0, np.float64)
         Th = inv1 @ np.asarray(pose_h1, np.float64)
-        self.pillarize_into(0, pch1, Th)
-        self.pillarize_into(1, pc0, T0)
-        self.pillarize_into(2, pc1, np.eye(4))
+        self.pillarize_all((pch1, pc0, pc1), (Th, T0, np.eye(4)))
         self.backbone()
         return self.head(pc0, out=out)
+
+    def pillarize_all(self, sweeps, transforms):
+        """The F sweeps of a sample -> the F channel groups of B0, sharing every launch of the stage."""
+        for t in sweeps:
+            self._reserve_points(t.shape[0])
+        arr = (HimoSweep * self.F)()
+        for slot, (pts, T) in enumerate(zip(sweeps, transforms)):
+            w = arr[slot]
+            w.n, w.d_pts, w.pc_stride = pts.shape[0], pts.data_ptr(), pts.shape[1]
+            w.transform = _f32x(np.asarray(T, dtype=np.float32).reshape(-1))
+            w.d_xyz_t, w.d_pid, w.d_offsets = self.xyz_t[slot].data_ptr(), self.pid[slot].data_ptr(), self.offsets[slot].data_ptr()
+            w.d_image = self.B0.data_ptr() + 4 * 32 * slot
+            w.d_workspace = self.ws_slots[slot].data_ptr()
+        st = self.lib.himo_pillarize_multi(self.F, ctypes.addressof(arr), self._range, self._voxel, self._centre, self.W, self.H,
+                                           self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
+                                           self.p["pfn.shift"].data_ptr(), 32 * self.F, self.ws_slots[0].numel(), _lib.stream_handle())
+        _lib.check(st, "himo_pillarize_multi")
 
     def pillarize_into(self, slot: int, pts: torch.Tensor, transform):
         """Sweep -> channel group ``slot`` of B0 (pitch 96)."""
         n = pts.shape[0]
         self._reserve_points(n)
         T = _f32x(np.asarray(transform, dtype=np.float32).reshape(-1))
-        ws = self.ws if self.ws_slots is None else self.ws_slots[slot]
+        ws = self.ws_slots[slot]
         st = self.lib.himo_pillarize(n, pts.data_ptr(), pts.shape[1], T, self._range, self._voxel, self._centre,
                                      self.W, self.H, self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
                                      self.p["pfn.shift"].data_ptr(), self.xyz_t[slot].data_ptr(), self.pid[slot].data_ptr(),

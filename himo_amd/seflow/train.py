@@ -408,9 +408,7 @@ class SeFlowTrainer:
         pch1, pc0, pc1 = to_dev(pch1), to_dev(pc0), to_dev(pc1)
         inv1 = np.linalg.inv(np.asarray(pose1, np.float64))
         self.n_pts = [pch1.shape[0], pc0.shape[0], pc1.shape[0]]
-        net.pillarize_into(0, pch1, inv1 @ np.asarray(pose_h1, np.float64))
-        net.pillarize_into(1, pc0, inv1 @ np.asarray(pose0, np.float64))
-        net.pillarize_into(2, pc1, np.eye(4))
+        net.pillarize_all((pch1, pc0, pc1), (inv1 @ np.asarray(pose_h1, np.float64), inv1 @ np.asarray(pose0, np.float64), np.eye(4)))
         F = net.F
         # encoder with saved activations
         src, src_bs, src_pitch = net.B0.data_ptr(), 32, 32 * F

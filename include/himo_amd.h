@@ -210,6 +210,20 @@ int himo_pillarize(int64_t n, const float* d_pts, int pc_stride, const float* h_
                    const float* d_pfn_weight, const float* d_pfn_scale, const float* d_pfn_shift,
                    float* d_xyz_t, int32_t* d_pid, float* d_offsets, float* d_image, int image_pitch,
                    void* d_workspace, size_t workspace_bytes, void* stream);
+/* The sweeps of one sample (history, pc0, pc1; up to 4) through the same five launches: the stage's kernels are latency
+ * chains on small grids, so sharing launches is worth ~2x on the stage.  Every sweep has its own outputs, image channel
+ * group and workspace of `workspace_bytes` (himo_pillar_workspace_bytes of the largest sweep). */
+typedef struct himo_sweep {
+    int64_t n; const float* d_pts; int pc_stride;
+    float transform[16];                                   /* row-major 4x4, sweep -> common frame */
+    float* d_xyz_t; int32_t* d_pid; float* d_offsets;      /* per-point outputs as in himo_pillarize */
+    float* d_image;                                        /* first of this sweep's 32 image channels */
+    void* d_workspace;
+} himo_sweep;
+int himo_pillarize_multi(int n_sweeps, const himo_sweep* h_sweeps, const float* h_range, const float* h_voxel,
+                         const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight,
+                         const float* d_pfn_scale, const float* d_pfn_shift, int image_pitch, size_t workspace_bytes,
+                         void* stream);
 
 /* NHWC float32 convolution (ksize 3 pad 1 stride 1|2, or ksize 1) / row GEMM on v_mfma_f32_32x32x2_f32
  * with a fused epilogue. */
