@@ -11,7 +11,16 @@
 using namespace himo;
 
 namespace {
-struct GraphEntry { hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; int n = 0; bool failed = false; };
+struct GraphEntry { hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; int n = 0; uint64_t hash = 0; bool failed = false; };
+
+// FNV-1a over the list's bytes: a cached graph is replayed only for the exact contents it was captured from (the key
+// is the list's address, which a freed and re-allocated list can share)
+uint64_t ops_hash(const himo_op* ops, int n) {
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(ops);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < sizeof(himo_op) * (size_t)n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
 std::mutex g_mu;
 std::map<const void*, GraphEntry> g_graphs;
 hipStream_t g_capture_stream = nullptr;
@@ -37,7 +46,8 @@ extern "C" int himo_run_ops(const himo_op* h_ops, int n_ops, unsigned flags, voi
     std::lock_guard<std::mutex> lk(g_mu);
     GraphEntry& e = g_graphs[h_ops];
     if (e.failed) return run_plain(h_ops, n_ops, stream);
-    if (!e.exec || e.n != n_ops) {
+    const uint64_t hash = ops_hash(h_ops, n_ops);
+    if (!e.exec || e.n != n_ops || e.hash != hash) {
         // capture on a private stream (the caller's may be the legacy default stream, which cannot capture)
         if (!g_capture_stream && hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError(); e.failed = true; return run_plain(h_ops, n_ops, stream);
@@ -58,6 +68,7 @@ extern "C" int himo_run_ops(const himo_op* h_ops, int n_ops, unsigned flags, voi
             return run_plain(h_ops, n_ops, stream);
         }
         e.n = n_ops;
+        e.hash = hash;
     }
     HIMO_HIP(hipGraphLaunch(e.exec, (hipStream_t)stream));
     return HIMO_OK;

@@ -261,6 +261,12 @@ class SeFlowNet:
             self._plan = ((HimoOp * len(rec))(*rec), len(rec))
         return self.DEC
 
+    def __del__(self):
+        try:
+            self.drop_plan()
+        except Exception:
+            pass
+
     def drop_plan(self):
         """forget the recorded operator list (call after changing weights buffers, precision or tile choices)"""
         if self._plan is not None:

@@ -267,8 +267,9 @@ int himo_conv_pack_weights_ex(const float* d_w, int ksize, int cin, int cout, in
 int himo_upsample2x(const float* d_x, int x_pitch, int h, int w, int c, float* d_y, int y_pitch, void* stream);
 
 /* A prepared operator list (the static part of a forward pass: fixed buffers, shapes, weights) run from one call.
- * With HIMO_OPS_GRAPH the list is captured once into a hipGraph, keyed by the h_ops address, and replayed with one
- * hipGraphLaunch -- the caller must not modify the list afterwards without himo_ops_release(h_ops).  The graph path is
+ * With HIMO_OPS_GRAPH the list is captured once into a hipGraph, keyed by the h_ops address and validated by a hash of
+ * the list's bytes (a changed list is re-captured), and replayed with one hipGraphLaunch; himo_ops_release(h_ops)
+ * frees the cached graph.  The graph path is
  * skipped while the himo_prof_* profiler is on, and falls back to plain launches if capture is not possible. */
 #define HIMO_OP_CONV 0
 #define HIMO_OP_UPSAMPLE2X 1
