@@ -250,7 +250,7 @@ def main():
         from himo_amd.seflow import spec
         from himo_amd.seflow.model import SeFlowNet
         params = spec.init_params(0)
-        pipe = HiMoPipeline(SeFlowNet(params, device=device, max_points=P, precision=args.precision), device=device)
+        pipe = HiMoPipeline(SeFlowNet(params, device=device, max_points=P, precision=args.precision, max_batch=B), device=device)
         samples = synthetic_samples(B, P, device, seed=rank)
         result = {}
 

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         oy0 = (bid % ty) * TH; img = bid / ty;
     }
     const int n0 = tn * BN;
-    const float* __restrict__ xin = a.x + (int64_t)img * a.x_batch_stride;
+    const float* __restrict__ xin = a.x + image_offset(img, a.n_inner, a.x_batch_stride, a.x_outer_stride);
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = wave & 1, wn = wave >> 1;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] ----
-    float* __restrict__ yout = a.y + (int64_t)img * a.y_batch_stride;
+    float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
     const int64_t out_rows = (int64_t)a.Ho * a.Wo;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -240,10 +240,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 struct UpArgs {
     const float* x; int x_pitch; int H, W, C;
     float* y; int y_pitch;
+    int64_t x_bs, y_bs;   // image blockIdx.y of a batch
     float ry, rx;   // (H-1)/(2H-1), (W-1)/(2W-1)
 };
 
 __global__ __launch_bounds__(256) void upsample2x_kernel(UpArgs a) {
+    a.x += (int64_t)blockIdx.y * a.x_bs;
+    a.y += (int64_t)blockIdx.y * a.y_bs;
     const int c4 = a.C / 4;
     const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)(2 * a.H) * (2 * a.W) * c4;
@@ -305,7 +308,10 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
     a.x = d->x; a.x_batch_stride = d->x_batch_stride; a.x_pitch = d->x_pitch;
     a.w = d->w; a.bias = d->bias; a.scale = d->scale; a.shift = d->shift;
     a.y = d->y; a.y_batch_stride = d->y_batch_stride; a.y_pitch = d->y_pitch;
-    a.N = d->n; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Cout = d->cout;
+    const int n_outer = d->n_outer > 1 ? d->n_outer : 1;
+    if (n_outer > 1 && ((d->x_outer_stride & 3) || (d->y_outer_stride & 3))) return HIMO_ERR_INVALID_ARGUMENT;
+    a.N = d->n * n_outer; a.n_inner = d->n; a.x_outer_stride = d->x_outer_stride; a.y_outer_stride = d->y_outer_stride;
+    a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Cout = d->cout;
     a.Ho = d->stride == 2 ? (d->h + 1) / 2 : d->h;      // 3x3, pad 1: ceil(H / stride)
     a.Wo = d->stride == 2 ? (d->w_in + 1) / 2 : d->w_in;
     a.aux_in = d->aux_in; a.aux_in_pitch = d->aux_in_pitch; a.aux_out = d->aux_out; a.aux_out_pitch = d->aux_out_pitch;
@@ -317,8 +323,8 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
     // tile choice: 128 x 128 when that still gives >= 2 blocks per CU, else shrink M then N so the chip is filled
     auto blocks_for = [&](int bn, int mi) -> int64_t {
         const int bm = 64 * mi, th = 4 * mi;
-        const int64_t tm = d->ksize == 1 ? (int64_t)d->n * (((int64_t)a.Ho * a.Wo + bm - 1) / bm)
-                                         : (int64_t)d->n * ((a.Ho + th - 1) / th) * ((a.Wo + 15) / 16);
+        const int64_t tm = d->ksize == 1 ? (int64_t)a.N * (((int64_t)a.Ho * a.Wo + bm - 1) / bm)
+                                         : (int64_t)a.N * ((a.Ho + th - 1) / th) * ((a.Wo + 15) / 16);
         return tm * ((d->cout + bn - 1) / bn);
     };
     const bool can128 = d->cout >= 128 && (d->cout % 128) == 0;
@@ -344,14 +350,22 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
 }
 
 extern "C" int himo_upsample2x(const float* d_x, int x_pitch, int h, int w, int c, float* d_y, int y_pitch, void* stream) {
-    if (!d_x || !d_y || h < 1 || w < 1 || c < 4 || (c & 3) || (x_pitch & 3) || (y_pitch & 3)) return HIMO_ERR_INVALID_ARGUMENT;
+    return himo_upsample2x_batch(1, d_x, 0, x_pitch, h, w, c, d_y, 0, y_pitch, stream);
+}
+
+extern "C" int himo_upsample2x_batch(int n, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int c, float* d_y,
+                                     int64_t y_batch_stride, int y_pitch, void* stream) {
+    if (n < 1 || !d_x || !d_y || h < 1 || w < 1 || c < 4 || (c & 3) || (x_pitch & 3) || (y_pitch & 3) || (x_batch_stride & 3) ||
+        (y_batch_stride & 3))
+        return HIMO_ERR_INVALID_ARGUMENT;
     UpArgs a{};
     a.x = d_x; a.x_pitch = x_pitch; a.H = h; a.W = w; a.C = c; a.y = d_y; a.y_pitch = y_pitch;
+    a.x_bs = x_batch_stride; a.y_bs = y_batch_stride;
     a.ry = h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     a.rx = w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
     const int64_t total = (int64_t)(2 * h) * (2 * w) * (c / 4);
     ProfScope ps("upsample2x_kernel", (hipStream_t)stream);
-    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((total + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, a);
     HIMO_LAUNCH_CHECK("upsample2x_kernel");
     return HIMO_OK;
 }

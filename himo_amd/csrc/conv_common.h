@@ -23,7 +23,8 @@ struct ConvArgs {
     const float* w;                                           // [KS][KS][Cin][Cout]
     const float* bias; const float* scale; const float* shift;
     float* y; int64_t y_batch_stride; int y_pitch;            // output
-    int N, H, W, Cin, Cout;                                   // input spatial size (KS=1 rows: H = 1, W = rows)
+    int N, H, W, Cin, Cout;                                   // N = n_inner * n_outer images; input spatial size (KS=1 rows: H = 1, W = rows)
+    int n_inner; int64_t x_outer_stride, y_outer_stride;      // image i sits at (i % n_inner) * batch_stride + (i / n_inner) * outer_stride
     int Ho, Wo;
     // GRU epilogues
     const float* aux_in; int aux_in_pitch;                    // z (kEpiGruQ) / h (kEpiGruZR), [rows][pitch]
@@ -33,6 +34,11 @@ struct ConvArgs {
 // GELU (erf form).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, below float32 resolution of the 1 + erf sum)
 // with the hardware exp2 / rcp: a dozen instructions where the library erff takes three times that -- the epilogue of
 // a 64-channel 3x3 layer is otherwise as long as a third of its matrix work.
+// two-level image addressing: n_inner frames of a sample (channel groups or planes), n_outer samples of a batch
+__device__ inline int64_t image_offset(int img, int n_inner, int64_t batch_stride, int64_t outer_stride) {
+    return (int64_t)(img % n_inner) * batch_stride + (int64_t)(img / n_inner) * outer_stride;
+}
+
 __device__ inline float gelu_exact(float v) {
     const float x = fabsf(v) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));

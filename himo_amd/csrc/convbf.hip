@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
         oy0 = (bid % ty) * TH; img = bid / ty;
     }
     const int n0 = tn * BN;
-    const float* __restrict__ xin = a.x + (int64_t)img * a.x_batch_stride;
+    const float* __restrict__ xin = a.x + image_offset(img, a.n_inner, a.x_batch_stride, a.x_outer_stride);
     const int slabs = (a.Cin + 15) / 16;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
         }
     }
 
-    float* __restrict__ yout = a.y + (int64_t)img * a.y_batch_stride;
+    float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
     const int64_t out_rows = (int64_t)a.Ho * a.Wo;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {

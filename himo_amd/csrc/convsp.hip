@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
     const int ox0 = (bid % tx) * TW; bid /= tx;
     const int oy0 = (bid % ty) * TH;
     const int img = bid / ty;
-    const float* __restrict__ xin = a.x + (int64_t)img * a.x_batch_stride;
+    const float* __restrict__ xin = a.x + image_offset(img, a.n_inner, a.x_batch_stride, a.x_outer_stride);
     const int slabs = (a.Cin + 15) / 16;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
         }
     }
 
-    float* __restrict__ yout = a.y + (int64_t)img * a.y_batch_stride;
+    float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
     if (!co_ok) return;
     const float b = a.bias ? a.bias[co] : 0.f;
     float sc = 1.f, sh = 0.f;

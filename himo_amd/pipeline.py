@@ -93,8 +93,11 @@ class HiMoPipeline:
         batch = self._batch_for(samples)
         o = batch.offsets_host
         self.sync_check()                                    # the PREVIOUS batch's flag: no stall on this one
-        for k, s in enumerate(samples):
-            self.flow(s, out=batch.flow[int(o[k]):int(o[k + 1])])
+        mb = self.net.max_batch
+        for lo in range(0, len(samples), mb):                   # groups of max_batch samples share every backbone launch
+            grp = samples[lo:lo + mb]
+            self.net.forward_batch([(s.pch1, s.pc0, s.pc1, s.pose_h1, s.pose0, s.pose1) for s in grp],
+                                   [batch.flow[int(o[lo + k]):int(o[lo + k + 1])] for k in range(len(grp))])
         if self.net.precision == "f16x2":
             self._finite = torch.isfinite(batch.flow).all()
         res = self.compdis.run(batch, sensor_dt=sensor_dt, refined=refined, out=self._out)

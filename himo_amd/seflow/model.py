@@ -30,7 +30,8 @@ class ConvDesc(ctypes.Structure):
                 ("cout", ctypes.c_int), ("ksize", ctypes.c_int), ("stride", ctypes.c_int), ("epilogue", ctypes.c_int),
                 ("aux_in", ctypes.c_void_p), ("aux_in_pitch", ctypes.c_int),
                 ("aux_out", ctypes.c_void_p), ("aux_out_pitch", ctypes.c_int), ("w_packed", ctypes.c_void_p),
-                ("tile_hint", ctypes.c_int), ("packed_format", ctypes.c_int)]
+                ("tile_hint", ctypes.c_int), ("packed_format", ctypes.c_int),
+                ("n_outer", ctypes.c_int), ("x_outer_stride", ctypes.c_int64), ("y_outer_stride", ctypes.c_int64)]
 
 
 _lib.register({
@@ -47,6 +48,8 @@ _lib.register({
                                               ctypes.c_void_p]),
     "himo_upsample2x": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "himo_upsample2x_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "himo_conv_pack_weights_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                  ctypes.c_void_p]),
     "himo_gru_head": (ctypes.c_int, [ctypes.c_int64] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
@@ -71,7 +74,8 @@ class HimoOp(ctypes.Structure):
     """mirror of `himo_op` (include/himo_amd.h)"""
     _fields_ = [("kind", ctypes.c_int), ("conv", ConvDesc),
                 ("up_x", ctypes.c_void_p), ("up_x_pitch", ctypes.c_int), ("up_h", ctypes.c_int), ("up_w", ctypes.c_int),
-                ("up_c", ctypes.c_int), ("up_y", ctypes.c_void_p), ("up_y_pitch", ctypes.c_int)]
+                ("up_c", ctypes.c_int), ("up_y", ctypes.c_void_p), ("up_y_pitch", ctypes.c_int),
+                ("up_n", ctypes.c_int), ("up_x_batch_stride", ctypes.c_int64), ("up_y_batch_stride", ctypes.c_int64)]
 
 
 _lib.register({
@@ -92,21 +96,27 @@ class SeFlowNet:
     pc0 row INCLUDING ego motion (the h5 ``<res_name>`` dataset that save_zip.py:117 reads)."""
 
     def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, seed: int = 0,
-                 precision: str = "bf16x3", autotune: bool = True):
+                 precision: str = "bf16x3", autotune: bool = True, max_batch: int = 1):
         """``precision``: "bf16x3" = split-bf16 matrix instructions for every stride-1 convolution / GEMM (float32-class
         accuracy, float32 range; csrc/convbf.hip); "f16x2" = two-term fp16 split with a scaled low part for the
         convolutions (22-bit products, HALF the matrix instructions of bf16x3; activations and weights must stay
         below fp16's 65504 -- true for this normalised network; the head keeps bf16x3); "f32" = float32 MFMA everywhere."""
         if precision not in ("bf16x3", "f16x2", "f32"):
             raise ValueError(precision)
+        if max_batch < 1:
+            raise ValueError("max_batch")
+        # ``max_batch`` samples go through every backbone layer in ONE launch (forward_batch): the low-resolution layers
+        # of a single sample are a fraction of one round of blocks on 256 CUs; activation buffers are ~1 GB per sample
+        self.max_batch = max_batch
         self.precision = precision
         self.autotune = autotune
         self.keep_cell_lists = False
         self.fused_head = precision != "f32"          # one kernel for gather + GRU + output (csrc/gruhead.hip)
         self.use_plan = True                          # replay the backbone's operator list from one call (csrc/plan.hip)
         self.use_graph = True                         # ... as a captured hipGraph
-        self._plan = None
+        self._plans = {}                              # samples per launch -> recorded operator list
         self._recording = None
+        self._nb = 1                                  # samples the backbone currently runs over
         self.packed_format = 1 if precision == "f16x2" else 0
         self.tiles = {}
         self.lib = _lib.load()
@@ -144,7 +154,8 @@ class SeFlowNet:
         F = spec.NUM_FRAMES
         self.H, self.W, self.F = H, W, F
         dev = self.device
-        buf = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        B = self.max_batch
+        buf = lambda *shape: torch.empty((B, *shape), dtype=torch.float32, device=dev)      # [sample][...]
         self.B0 = buf(H * W, 32 * F)                                   # 3 pillar images as channel groups
         self.E1 = [buf(F, (H // 2) * (W // 2), 64) for _ in range(2)]
         self.F1 = buf((H // 2) * (W // 2), 64 * F)
@@ -175,23 +186,33 @@ class SeFlowNet:
         dev = self.device
         self.max_points = n
         need = int(self.lib.himo_pillar_workspace_bytes(n, self.W, self.H))
-        self.ws = torch.empty(need + 64, dtype=torch.uint8, device=dev)
-        # one workspace per frame slot: the three sweeps of a sample share their launches (himo_pillarize_multi), and
-        # training keeps every sweep's cell lists for the backward pass
-        self.ws_slots = [torch.empty(need + 64, dtype=torch.uint8, device=dev) for _ in range(self.F)]
-        self.xyz_t = torch.empty((self.F, n, 3), dtype=torch.float32, device=dev)
-        self.pid = torch.empty((self.F, n), dtype=torch.int32, device=dev)
-        self.offsets = torch.empty((self.F, n, 3), dtype=torch.float32, device=dev)
+        # per sample of a batch: one pillar workspace per frame slot (the three sweeps of a sample share their launches,
+        # himo_pillarize_multi; training keeps every sweep's cell lists for the backward pass) and the per-point outputs
+        self._pt = [{"ws_slots": [torch.empty(need + 64, dtype=torch.uint8, device=dev) for _ in range(self.F)],
+                     "xyz_t": torch.empty((self.F, n, 3), dtype=torch.float32, device=dev),
+                     "pid": torch.empty((self.F, n), dtype=torch.int32, device=dev),
+                     "offsets": torch.empty((self.F, n, 3), dtype=torch.float32, device=dev)} for _ in range(self.max_batch)]
+        self._use_sample(0)
         self.hx = torch.empty((n, 192), dtype=torch.float32, device=dev)
         self.rhx = torch.empty((n, 192), dtype=torch.float32, device=dev)
         self.zbuf = torch.empty((n, 128), dtype=torch.float32, device=dev)
         self.y1 = torch.empty((n, 32), dtype=torch.float32, device=dev)
 
+    def _use_sample(self, i: int):
+        """bind the per-point buffers (and cell lists) of sample ``i`` of the batch"""
+        st = self._pt[i]
+        self._sample = i
+        self.ws_slots, self.xyz_t, self.pid, self.offsets = st["ws_slots"], st["xyz_t"], st["pid"], st["offsets"]
+
     # ---- launch helpers ---------------------------------------------------------------------------
     def _conv(self, x, x_bs, x_pitch, wname, y, y_bs, y_pitch, n, h, w, cin, cout, ks, stride, epi, x_off=0, y_off=0,
-              scale=None, shift=None, aux_in=None, aux_in_pitch=0, aux_out=None, aux_out_pitch=0, bias=None):
+              scale=None, shift=None, aux_in=None, aux_in_pitch=0, aux_out=None, aux_out_pitch=0, bias=None, batched=True):
+        """``x`` / ``y``: activation buffers [sample][...] -- with ``batched`` the layer runs over the first
+        ``self._nb`` samples in one launch (outer stride = one sample of the buffer)."""
         d = ConvDesc()
         d.x = x.data_ptr() + 4 * x_off; d.x_batch_stride = x_bs; d.x_pitch = x_pitch
+        if batched and self._nb > 1:
+            d.n_outer, d.x_outer_stride, d.y_outer_stride = self._nb, x.stride(0), y.stride(0)
         d.w = self.p[f"{wname}.weight"].data_ptr()
         d.bias = (self.p[f"{wname}.bias"] if bias is None else bias).data_ptr()
         d.scale = None if scale is None else scale.data_ptr()
@@ -203,7 +224,7 @@ class SeFlowNet:
         pk = self.packed.get(f"{wname}.weight")
         d.w_packed = None if pk is None else pk.data_ptr()
         d.packed_format = self.packed_format
-        key = (n, h, w, cin, cout, ks, stride, epi, pk is not None)
+        key = (n * max(d.n_outer, 1), h, w, cin, cout, ks, stride, epi, pk is not None)
         if self.autotune and key not in self.tiles:
             self.tiles[key] = self._tune(d)
         d.tile_hint = self.tiles.get(key, 0)
@@ -238,19 +259,30 @@ class SeFlowNet:
         return best
 
     def _up(self, x, x_pitch, h, w, c, y, y_pitch):
+        nb = self._nb
         if self._recording is not None:
             op = HimoOp(); op.kind = 1
             op.up_x, op.up_x_pitch, op.up_h, op.up_w, op.up_c, op.up_y, op.up_y_pitch = x.data_ptr(), x_pitch, h, w, c, y.data_ptr(), y_pitch
+            op.up_n, op.up_x_batch_stride, op.up_y_batch_stride = nb, x.stride(0), y.stride(0)
             self._recording.append(op)
+        if nb > 1:
+            _lib.check(self.lib.himo_upsample2x_batch(nb, x.data_ptr(), x.stride(0), x_pitch, h, w, c, y.data_ptr(), y.stride(0), y_pitch,
+                                                      _lib.stream_handle()), "himo_upsample2x_batch")
+            return
         _lib.check(self.lib.himo_upsample2x(x.data_ptr(), x_pitch, h, w, c, y.data_ptr(), y_pitch, _lib.stream_handle()),
                    "himo_upsample2x")
 
     # ---- stages ---------------------------------------------------------------------------------------
-    def backbone(self):
-        """B0 (3 pillar images) -> DEC (64 x H x W).  The first call runs (and tile-tunes) layer by layer while recording
-        the operator list; later calls replay it from one C call / one hipGraph launch."""
-        if self.use_plan and self._plan is not None:
-            ops, n = self._plan
+    def backbone(self, n_samples: int = 1):
+        """B0 (3 pillar images per sample) -> DEC (64 x H x W per sample) for the first ``n_samples`` samples of the
+        activation buffers, every layer ONE launch.  The first call per batch size runs (and tile-tunes) layer by layer
+        while recording the operator list; later calls replay it from one C call / one hipGraph launch."""
+        if not 1 <= n_samples <= self.max_batch:
+            raise ValueError(f"n_samples must be in 1..{self.max_batch}")
+        self._nb = n_samples
+        plan = self._plans.get(n_samples)
+        if self.use_plan and plan is not None:
+            ops, n = plan
             _lib.check(self.lib.himo_run_ops(ctypes.addressof(ops), n, 1 if self.use_graph else 0, _lib.stream_handle()), "himo_run_ops")
             return self.DEC
         self._recording = [] if self.use_plan else None
@@ -258,7 +290,7 @@ class SeFlowNet:
         self.decoder()
         if self._recording is not None:
             rec, self._recording = self._recording, None
-            self._plan = ((HimoOp * len(rec))(*rec), len(rec))
+            self._plans[n_samples] = ((HimoOp * len(rec))(*rec), len(rec))
         return self.DEC
 
     def __del__(self):
@@ -268,10 +300,10 @@ class SeFlowNet:
             pass
 
     def drop_plan(self):
-        """forget the recorded operator list (call after changing weights buffers, precision or tile choices)"""
-        if self._plan is not None:
-            self.lib.himo_ops_release(ctypes.addressof(self._plan[0]))
-            self._plan = None
+        """forget the recorded operator lists (call after changing weights buffers, precision or tile choices)"""
+        for plan in self._plans.values():
+            self.lib.himo_ops_release(ctypes.addressof(plan[0]))
+        self._plans = {}
 
     def encoder(self):
         """B0 -> the three concat buffers F1 / F2 / F3 (frames stacked on channels)."""
@@ -316,14 +348,15 @@ class SeFlowNet:
         n = pc0.shape[0]
         p = self.p
         F = self.F
+        B0, DEC = self.B0[self._sample], self.DEC[self._sample]          # this sample's images
         if self.fused_head:
             flow = out if out is not None else torch.empty((n, 3), dtype=torch.float32, device=self.device)
             if flow.shape != (n, 3) or flow.dtype != torch.float32 or not flow.is_contiguous():
                 raise ValueError("out must be a contiguous (N0,3) float32 tensor")
             pk = self.packed
             st = self.lib.himo_gru_head(n, self.pid[slot0].data_ptr(), self.offsets[slot0].data_ptr(),
-                                        self.B0.data_ptr() + 4 * 32 * slot0, self.B0.data_ptr() + 4 * 32 * slot1, 32 * F,
-                                        self.DEC.data_ptr(), 64, p["head.offset.weight"].data_ptr(), p["head.offset.bias"].data_ptr(),
+                                        B0.data_ptr() + 4 * 32 * slot0, B0.data_ptr() + 4 * 32 * slot1, 32 * F,
+                                        DEC.data_ptr(), 64, p["head.offset.weight"].data_ptr(), p["head.offset.bias"].data_ptr(),
                                         pk["head.gru.zr.weight"].data_ptr(), p["head.gru.zr.bias"].data_ptr(),
                                         pk["head.gru.q.weight"].data_ptr(), p["head.gru.q.bias"].data_ptr(),
                                         pk["head.dec1.weight"].data_ptr(), p["head.dec1.bias"].data_ptr(),
@@ -333,17 +366,17 @@ class SeFlowNet:
             _lib.check(st, "himo_gru_head")
             return flow
         st = self.lib.himo_head_gather(n, self.pid[slot0].data_ptr(), self.offsets[slot0].data_ptr(),
-                                       self.B0.data_ptr() + 4 * 32 * slot0, self.B0.data_ptr() + 4 * 32 * slot1, 32 * F,
-                                       self.DEC.data_ptr(), 64, p["head.offset.weight"].data_ptr(),
+                                       B0.data_ptr() + 4 * 32 * slot0, B0.data_ptr() + 4 * 32 * slot1, 32 * F,
+                                       DEC.data_ptr(), 64, p["head.offset.weight"].data_ptr(),
                                        p["head.offset.bias"].data_ptr(), self.hx.data_ptr(), self.rhx.data_ptr(), 192,
                                        _lib.stream_handle())
         _lib.check(st, "himo_head_gather")
         for _ in range(spec.GRU_ITERS):
             self._conv(self.hx, 0, 192, "head.gru.zr", self.zbuf, 0, 128, 1, 1, n, 192, 256, 1, 1, EPI_GRU_ZR,
-                       aux_in=self.hx, aux_in_pitch=192, aux_out=self.rhx, aux_out_pitch=192)
+                       aux_in=self.hx, aux_in_pitch=192, aux_out=self.rhx, aux_out_pitch=192, batched=False)
             self._conv(self.rhx, 0, 192, "head.gru.q", self.zbuf, 0, 128, 1, 1, n, 192, 128, 1, 1, EPI_GRU_Q,
-                       aux_in=self.zbuf, aux_in_pitch=128, aux_out=self.hx, aux_out_pitch=192)
-        self._conv(self.hx, 0, 192, "head.dec1", self.y1, 0, 32, 1, 1, n, 192, 32, 1, 1, EPI_BIAS_GELU)
+                       aux_in=self.zbuf, aux_in_pitch=128, aux_out=self.hx, aux_out_pitch=192, batched=False)
+        self._conv(self.hx, 0, 192, "head.dec1", self.y1, 0, 32, 1, 1, n, 192, 32, 1, 1, EPI_BIAS_GELU, batched=False)
         flow = out if out is not None else torch.empty((n, 3), dtype=torch.float32, device=self.device)
         if flow.shape != (n, 3) or flow.dtype != torch.float32 or not flow.is_contiguous():
             raise ValueError("out must be a contiguous (N0,3) float32 tensor")
@@ -364,9 +397,24 @@ class SeFlowNet:
         inv1 = np.linalg.inv(np.asarray(pose1, np.float64))
         T0 = inv1 @ np.asarray(pose0, np.float64)
         Th = inv1 @ np.asarray(pose_h1, np.float64)
+        self._use_sample(0)
         self.pillarize_all((pch1, pc0, pc1), (Th, T0, np.eye(4)))
-        self.backbone()
+        self.backbone(1)
         return self.head(pc0, out=out)
+
+    def forward_batch(self, samples, outs) -> None:
+        """Up to ``max_batch`` samples -- (pch1, pc0, pc1, pose_h1, pose0, pose1) device sweeps + host poses -- through
+        the network with every backbone layer ONE launch over all of them; ``outs[k]``: (N0_k,3) float32 flow buffers."""
+        if not 1 <= len(samples) <= self.max_batch:
+            raise ValueError(f"forward_batch takes 1..{self.max_batch} samples")
+        for k, (pch1, pc0, pc1, pose_h1, pose0, pose1) in enumerate(samples):
+            inv1 = np.linalg.inv(np.asarray(pose1, np.float64))
+            self._use_sample(k)
+            self.pillarize_all((pch1, pc0, pc1), (inv1 @ np.asarray(pose_h1, np.float64), inv1 @ np.asarray(pose0, np.float64), np.eye(4)))
+        self.backbone(len(samples))
+        for k, smp in enumerate(samples):
+            self._use_sample(k)
+            self.head(smp[1], out=outs[k])
 
     def pillarize_all(self, sweeps, transforms):
         """The F sweeps of a sample -> the F channel groups of B0, sharing every launch of the stage."""
@@ -378,7 +426,7 @@ class SeFlowNet:
             w.n, w.d_pts, w.pc_stride = pts.shape[0], pts.data_ptr(), pts.shape[1]
             w.transform = _f32x(np.asarray(T, dtype=np.float32).reshape(-1))
             w.d_xyz_t, w.d_pid, w.d_offsets = self.xyz_t[slot].data_ptr(), self.pid[slot].data_ptr(), self.offsets[slot].data_ptr()
-            w.d_image = self.B0.data_ptr() + 4 * 32 * slot
+            w.d_image = self.B0[self._sample].data_ptr() + 4 * 32 * slot
             w.d_workspace = self.ws_slots[slot].data_ptr()
         st = self.lib.himo_pillarize_multi(self.F, ctypes.addressof(arr), self._range, self._voxel, self._centre, self.W, self.H,
                                            self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
@@ -394,7 +442,7 @@ class SeFlowNet:
         st = self.lib.himo_pillarize(n, pts.data_ptr(), pts.shape[1], T, self._range, self._voxel, self._centre,
                                      self.W, self.H, self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
                                      self.p["pfn.shift"].data_ptr(), self.xyz_t[slot].data_ptr(), self.pid[slot].data_ptr(),
-                                     self.offsets[slot].data_ptr(), self.B0.data_ptr() + 4 * 32 * slot, 32 * self.F,
+                                     self.offsets[slot].data_ptr(), self.B0[self._sample].data_ptr() + 4 * 32 * slot, 32 * self.F,
                                      ws.data_ptr(), ws.numel(), _lib.stream_handle())
         _lib.check(st, "himo_pillarize")
 

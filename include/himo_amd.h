@@ -254,6 +254,10 @@ typedef struct himo_conv_desc {
                                                               6 matrix instructions per product block), 1 = two fp16
                                                               planes with a 2^11-scaled low part (|values| < 65504,
                                                               3 matrix instructions): himo_conv_pack_weights_ex */
+    int n_outer;                                           /* 0 | 1: `n` images; > 1: n * n_outer images, image i at
+                                                              (i % n) * batch_stride + (i / n) * outer_stride -- the n
+                                                              frames of a sample (channel groups) x the samples of a batch */
+    int64_t x_outer_stride, y_outer_stride;
 } himo_conv_desc;
 int himo_conv2d(const himo_conv_desc* h_desc, void* stream);
 /* one-time weight preparation for the split-bf16 path: [k][k][cin][cout] float32 -> three bf16 planes */
@@ -265,6 +269,8 @@ int himo_conv_pack_weights_ex(const float* d_w, int ksize, int cin, int cout, in
 
 /* bilinear x2 upsampling, align_corners = true; c channels of every pixel, NHWC with pitches */
 int himo_upsample2x(const float* d_x, int x_pitch, int h, int w, int c, float* d_y, int y_pitch, void* stream);
+int himo_upsample2x_batch(int n, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int c, float* d_y,
+                          int64_t y_batch_stride, int y_pitch, void* stream);
 
 /* A prepared operator list (the static part of a forward pass: fixed buffers, shapes, weights) run from one call.
  * With HIMO_OPS_GRAPH the list is captured once into a hipGraph, keyed by the h_ops address and validated by a hash of
@@ -277,8 +283,9 @@ int himo_upsample2x(const float* d_x, int x_pitch, int h, int w, int c, float* d
 typedef struct himo_op {
     int kind;
     himo_conv_desc conv;                                   /* HIMO_OP_CONV */
-    const float* up_x; int up_x_pitch, up_h, up_w, up_c;   /* HIMO_OP_UPSAMPLE2X: the arguments of himo_upsample2x */
+    const float* up_x; int up_x_pitch, up_h, up_w, up_c;   /* HIMO_OP_UPSAMPLE2X: the arguments of himo_upsample2x_batch */
     float* up_y; int up_y_pitch;
+    int up_n; int64_t up_x_batch_stride, up_y_batch_stride; /* up_n 0 | 1: one image */
 } himo_op;
 int himo_run_ops(const himo_op* h_ops, int n_ops, unsigned flags, void* stream);
 void himo_ops_release(const himo_op* h_ops);
