@@ -53,9 +53,10 @@ struct PillarArgs {
                               //        indices AND coordinates as two contiguous runs instead of index -> point chains
 };
 
-// up to four sweeps per launch (blockIdx.y selects the sweep): the stage's kernels are latency chains on small grids,
-// so the three sweeps of a sample share each launch instead of queueing behind one another
-constexpr int kMaxSweeps = 4;
+// up to twelve sweeps per launch (blockIdx.y selects the sweep): the stage's kernels are latency chains on small grids,
+// so the three sweeps of a sample -- and of up to four samples of a batch -- share each launch instead of queueing
+// behind one another (12 argument blocks = 2.8 KB of the 4 KB kernel-argument segment)
+constexpr int kMaxSweeps = 12;
 struct PillarBatch { PillarArgs s[kMaxSweeps]; };
 
 __global__ __launch_bounds__(256) void pillar_assign_kernel(PillarBatch m) {

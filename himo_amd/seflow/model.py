@@ -407,31 +407,45 @@ class SeFlowNet:
         the network with every backbone layer ONE launch over all of them; ``outs[k]``: (N0_k,3) float32 flow buffers."""
         if not 1 <= len(samples) <= self.max_batch:
             raise ValueError(f"forward_batch takes 1..{self.max_batch} samples")
+        jobs = []
         for k, (pch1, pc0, pc1, pose_h1, pose0, pose1) in enumerate(samples):
             inv1 = np.linalg.inv(np.asarray(pose1, np.float64))
-            self._use_sample(k)
-            self.pillarize_all((pch1, pc0, pc1), (inv1 @ np.asarray(pose_h1, np.float64), inv1 @ np.asarray(pose0, np.float64), np.eye(4)))
+            jobs.append((k, (pch1, pc0, pc1), (inv1 @ np.asarray(pose_h1, np.float64), inv1 @ np.asarray(pose0, np.float64), np.eye(4))))
+        self.pillarize_many(jobs)
         self.backbone(len(samples))
         for k, smp in enumerate(samples):
             self._use_sample(k)
             self.head(smp[1], out=outs[k])
 
     def pillarize_all(self, sweeps, transforms):
-        """The F sweeps of a sample -> the F channel groups of B0, sharing every launch of the stage."""
-        for t in sweeps:
-            self._reserve_points(t.shape[0])
-        arr = (HimoSweep * self.F)()
-        for slot, (pts, T) in enumerate(zip(sweeps, transforms)):
-            w = arr[slot]
-            w.n, w.d_pts, w.pc_stride = pts.shape[0], pts.data_ptr(), pts.shape[1]
-            w.transform = _f32x(np.asarray(T, dtype=np.float32).reshape(-1))
-            w.d_xyz_t, w.d_pid, w.d_offsets = self.xyz_t[slot].data_ptr(), self.pid[slot].data_ptr(), self.offsets[slot].data_ptr()
-            w.d_image = self.B0[self._sample].data_ptr() + 4 * 32 * slot
-            w.d_workspace = self.ws_slots[slot].data_ptr()
-        st = self.lib.himo_pillarize_multi(self.F, ctypes.addressof(arr), self._range, self._voxel, self._centre, self.W, self.H,
-                                           self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
-                                           self.p["pfn.shift"].data_ptr(), 32 * self.F, self.ws_slots[0].numel(), _lib.stream_handle())
-        _lib.check(st, "himo_pillarize_multi")
+        """The F sweeps of the current sample -> the F channel groups of its B0, sharing every launch of the stage."""
+        self.pillarize_many([(self._sample, sweeps, transforms)])
+
+    MAX_SWEEPS = 12                       # kMaxSweeps of csrc/pillar.hip
+
+    def pillarize_many(self, jobs):
+        """``jobs``: [(sample index, F sweeps, F transforms)] -- up to 12 sweeps (4 samples) share the stage's launches."""
+        for _, sweeps, _ in jobs:
+            for t in sweeps:
+                self._reserve_points(t.shape[0])
+        per_call = self.MAX_SWEEPS // self.F
+        for lo in range(0, len(jobs), per_call):
+            grp = jobs[lo:lo + per_call]
+            arr = (HimoSweep * (len(grp) * self.F))()
+            for j, (sample, sweeps, transforms) in enumerate(grp):
+                st = self._pt[sample]
+                for slot, (pts, T) in enumerate(zip(sweeps, transforms)):
+                    w = arr[j * self.F + slot]
+                    w.n, w.d_pts, w.pc_stride = pts.shape[0], pts.data_ptr(), pts.shape[1]
+                    w.transform = _f32x(np.asarray(T, dtype=np.float32).reshape(-1))
+                    w.d_xyz_t, w.d_pid, w.d_offsets = st["xyz_t"][slot].data_ptr(), st["pid"][slot].data_ptr(), st["offsets"][slot].data_ptr()
+                    w.d_image = self.B0[sample].data_ptr() + 4 * 32 * slot
+                    w.d_workspace = st["ws_slots"][slot].data_ptr()
+            status = self.lib.himo_pillarize_multi(len(arr), ctypes.addressof(arr), self._range, self._voxel, self._centre, self.W, self.H,
+                                                   self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
+                                                   self.p["pfn.shift"].data_ptr(), 32 * self.F, self._pt[0]["ws_slots"][0].numel(),
+                                                   _lib.stream_handle())
+            _lib.check(status, "himo_pillarize_multi")
 
     def pillarize_into(self, slot: int, pts: torch.Tensor, transform):
         """Sweep -> channel group ``slot`` of B0 (pitch 96)."""

@@ -210,7 +210,7 @@ int himo_pillarize(int64_t n, const float* d_pts, int pc_stride, const float* h_
                    const float* d_pfn_weight, const float* d_pfn_scale, const float* d_pfn_shift,
                    float* d_xyz_t, int32_t* d_pid, float* d_offsets, float* d_image, int image_pitch,
                    void* d_workspace, size_t workspace_bytes, void* stream);
-/* The sweeps of one sample (history, pc0, pc1; up to 4) through the same five launches: the stage's kernels are latency
+/* The sweeps of one sample (history, pc0, pc1) -- or of several samples, up to 12 sweeps -- through the same five launches: the stage's kernels are latency
  * chains on small grids, so sharing launches is worth ~2x on the stage.  Every sweep has its own outputs, image channel
  * group and workspace of `workspace_bytes` (himo_pillar_workspace_bytes of the largest sweep). */
 typedef struct himo_sweep {

@@ -9,6 +9,7 @@ from himo_amd.seflow.model import conv2d_nhwc
 dev = torch.device("cuda", 0)
 PREC = sys.argv[1] if len(sys.argv) > 1 else "f32"
 HINT = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0
+BATCH = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # samples per launch (images = N * BATCH)
 shapes = [  # (N, H, W, Cin, Cout, k, stride, epi)
     (3, 256, 256, 64, 64, 3, 1, 1), (3, 128, 128, 128, 128, 3, 1, 1), (3, 64, 64, 256, 256, 3, 1, 1),
     (1, 128, 128, 512, 256, 3, 1, 0), (1, 128, 128, 256, 256, 3, 1, 0), (1, 256, 256, 256, 128, 3, 1, 0),
@@ -17,6 +18,9 @@ shapes = [  # (N, H, W, Cin, Cout, k, stride, epi)
     (1, 512, 512, 96, 64, 1, 1, 0),
 ]
 for (n, h, w, ci, co, k, s, epi) in shapes:
+    if k == 1 and h == 1:
+        continue
+    n *= BATCH
     x = torch.randn(n, h, w, ci, device=dev)
     wt = torch.randn(k, k, ci, co, device=dev) * 0.05
     b = torch.zeros(co, device=dev); sc = torch.ones(co, device=dev); sh = torch.zeros(co, device=dev)
