@@ -27,17 +27,16 @@ __device__ inline void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
 // 11 + 11 mantissa bits (relative representation error 2^-22); the product keeps three terms,
 //     acc0 += ha*hb ;  acc1 += ha*lb' + la'*hb ;  result = acc0 + 2^-11 * acc1       (dropped: 2^-22 la' lb')
 // i.e. THREE fp16 matrix instructions per float32 product block instead of six bf16 ones.  The 2^11 scale keeps the low
-// parts out of the fp16 subnormal range (weights ~0.05 would otherwise lose their low part); an h that would itself be
-// subnormal (|x| < 2^-14) is moved entirely into l'.  Range: |x| must stay below 65504 (fp16 max) -- true for
-// normalised activations; the bf16 split has float32's range and remains available.
+// parts out of the fp16 subnormal range (weights ~0.05 would otherwise lose most of their low part's bits).  An h that
+// is itself subnormal (|x| < 2^-14) needs no special case: v_cvt_f16_f32 and v_mfma_f32_32x32x16_f16 both keep
+// subnormals on gfx950 (measured: a 2^-20 input comes through the matrix instruction exactly).  Range: |x| must stay
+// below 65504 (fp16 max) -- true for normalised activations; the bf16 split has float32's range and remains available.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float kF16LowScale = 2048.0f, kF16LowInv = 1.0f / 2048.0f;
 
 __device__ inline void split2(float x, unsigned& h, unsigned& l) {
-    _Float16 hh = (_Float16)x;                                  // round to nearest even
-    float hf = (float)hh;
-    if (fabsf(hf) < 6.103515625e-05f) { hh = (_Float16)0.0f; hf = 0.0f; }
-    const _Float16 ll = (_Float16)((x - hf) * kF16LowScale);
+    const _Float16 hh = (_Float16)x;                            // round to nearest even
+    const _Float16 ll = (_Float16)((x - (float)hh) * kF16LowScale);
     h = __builtin_bit_cast(unsigned short, hh);
     l = __builtin_bit_cast(unsigned short, ll);
 }
