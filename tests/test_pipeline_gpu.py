@@ -97,3 +97,22 @@ def test_fp16_split_pipeline_matches_and_flags_overflow(gpu):
     # the bf16 split has float32's range: same weights, finite result
     pipe = HiMoPipeline(SeFlowNet(big, device=gpu, max_points=20_000, precision="bf16x3"), device=gpu)
     assert torch.isfinite(pipe.run(samples)["flow"]).all()
+
+
+def test_batched_backbone_equals_one_sample_at_a_time(gpu):
+    """max_batch > 1 (every backbone layer one launch over several samples: two-level image addressing, batched upsample,
+    up to 12 sweeps per pillar launch) must reproduce the per-sample path bit for bit, for full and partial groups."""
+    from himo_amd.pipeline import HiMoPipeline, Sample
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.model import SeFlowNet
+    from himo_amd.synthetic import make_frame
+    params = spec.init_params(2)
+    frames = [make_frame(60 + i, n_points=9_000 + 700 * i) for i in range(8)]
+    samples = [Sample.from_frames(frames[i], frames[i + 1], frames[i + 2], device=gpu) for i in range(6)]     # ragged sizes
+    for prec in ("f16x2", "bf16x3"):
+        one = HiMoPipeline(SeFlowNet(params, device=gpu, max_points=16_000, precision=prec, max_batch=1, autotune=False), device=gpu)
+        ref = one.run(samples)["flow"].clone()
+        many = HiMoPipeline(SeFlowNet(params, device=gpu, max_points=16_000, precision=prec, max_batch=4, autotune=False), device=gpu)
+        got = many.run(samples)["flow"].clone()                 # groups of 4 + 2
+        assert torch.equal(got, ref), prec
+        assert torch.equal(many.run(samples[:5])["flow"], ref[: sum(s.pc0.shape[0] for s in samples[:5])]), prec      # 4 + 1
