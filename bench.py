@@ -391,7 +391,7 @@ def main():
                         "traffic": traffic.get("conv3x3_mfma_kernel" if args.precision == "f32" else "conv3x3_split_kernel", {}).get("hbm_bytes_per_launch"),
                         "algorithmic_f32_equivalent_tflops": alg_tf, "vs_f32_mfma_peak_157_3": alg_tf / MFMA_F32_PEAK_TF,
                         "algorithmic_flops_per_launch": flops3 / max(launches_per_fwd, 1e-9), "avg_launch_ms": k["avg_ms"],
-                        "launches_timed": k["count"], "launches_per_forward": launches_per_fwd,
+                        "launches_timed": k["count"], "launches_per_frame": launches_per_fwd, "samples_per_launch": B,
                         "share_of_step_time": k["total_ms"] / (elapsed * 1e3)}
             workload = ("per-frame pipeline: pillarise 3 sweeps (512x512 grid) -> SeFlow++-style encoder/decoder + GRU head "
                         "(random-init, self-specified: reference network source absent) -> per-point flow -> ego-motion "
@@ -411,6 +411,9 @@ def main():
             "kernels_note": "one extra untimed step with every kernel timed; the timed region times only the roofline kernel",
             "parity": parity,
         }
+        if args.workload == "pipeline":
+            line["config"]["matrix_arithmetic"] = args.precision
+            line["config"]["samples_per_backbone_launch"] = B
         if args.workload == "train":
             line["metric"] = "train_frames_per_sec_120k"
             line["config"]["parallelism"] = f"data parallel x{world}, one flat all-reduce per step"
