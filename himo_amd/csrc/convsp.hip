@@ -224,7 +224,10 @@ static void launch_sp_epi(const ConvArgs& a, int epi, const unsigned short* w, d
 
 template <int PH, int FMT>
 static void launch_sp_mi(const ConvArgs& a, int epi, int mi, int stride, const unsigned short* w, dim3 grid, hipStream_t s) {
-    if (stride == 2) launch_sp_epi<PH, FMT, 2, 2>(a, epi, w, grid, s);          // stride 2: two output rows per wave
+    if (stride == 2) {                                                         // stride 2: two output rows per wave, or one
+        if (mi == 1) launch_sp_epi<PH, FMT, 1, 2>(a, epi, w, grid, s);        // (64-channel blocks: keeps the 5 x 65 patch double-buffered)
+        else launch_sp_epi<PH, FMT, 2, 2>(a, epi, w, grid, s);
+    }
     else if (mi == 4) launch_sp_epi<PH, FMT, 4, 1>(a, epi, w, grid, s);
     else if (mi == 1) launch_sp_epi<PH, FMT, 1, 1>(a, epi, w, grid, s);         // small images: more, smaller blocks
     else launch_sp_epi<PH, FMT, 2, 1>(a, epi, w, grid, s);
@@ -242,7 +245,7 @@ bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, i
     };
     int mi = blocks_for(4) >= 1024 ? 4 : 2;            // two blocks per CU, at least two rounds of them
     if (rows_hint == 4 || rows_hint == 2 || rows_hint == 1) mi = rows_hint;
-    if (stride == 2) mi = 2;
+    if (stride == 2) mi = (rows_hint == 1 || rows_hint == 2) ? rows_hint : (wide ? 2 : 1);
     const dim3 grid((unsigned)blocks_for(mi));
     const unsigned short* w = (const unsigned short*)w_packed;
     const char* name = stride == 2 ? (format == 1 ? "conv3x3s2_f16x2_kernel" : "conv3x3s2_bf16x3_kernel")

@@ -242,7 +242,7 @@ class SeFlowNet:
         stream = _lib.stream_handle()
         cands = [(bn << 4) | mi for bn in (128, 64) if not (bn == 128 and d.cout % 128) for mi in (2, 1)]
         if d.w_packed and d.ksize == 3:
-            cands += [0x1000 | 4, 0x1000 | 2, 0x1000 | 1] if d.stride == 1 else [0x1000 | 2]   # weights-from-L2 structure (csrc/convsp.hip)
+            cands += [0x1000 | 4, 0x1000 | 2, 0x1000 | 1] if d.stride == 1 else [0x1000 | 2, 0x1000 | 1]   # weights-from-L2 structure (csrc/convsp.hip)
         for hint in cands:
             d.tile_hint = hint
             for _ in range(2):

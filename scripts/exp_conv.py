@@ -17,6 +17,8 @@ shapes = [  # (N, H, W, Cin, Cout, k, stride, epi)
     (3, 512, 512, 32, 64, 3, 2, 1), (1, 1, 120000, 192, 256, 1, 1, 0), (1, 1, 120000, 192, 128, 1, 1, 0),
     (1, 512, 512, 96, 64, 1, 1, 0),
 ]
+if len(sys.argv) > 4 and sys.argv[4] == "s2":          # the three stride-2 layers
+    shapes = [(3, 512, 512, 32, 64, 3, 2, 1), (3, 256, 256, 64, 128, 3, 2, 1), (3, 128, 128, 128, 256, 3, 2, 1)]   # S2SHAPES
 for (n, h, w, ci, co, k, s, epi) in shapes:
     if k == 1 and h == 1:
         continue
