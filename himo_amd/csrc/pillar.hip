@@ -13,9 +13,9 @@
 //   cell_scan_*_kernel      two-level exclusive scan of the 262,144 cell counts
 //   pillar_fill_kernel      counting-sort scatter of point indices into per-cell lists
 //   pillar_feature_kernel   half a wavefront (32 lanes = 32 channels) per cell: the cell's point
-//                           list is staged in LDS (through global memory for the rare cell with more
-//                           than 128 points) and put in ascending point order (so sums are
-//                           order-deterministic and match a sequential CPU scatter), then
+//                           list is held in registers (through global memory for cells with more
+//                           than 32 points) and put in ascending point order with wavefront shuffles
+//                           (so sums are order-deterministic and match a sequential CPU scatter), then
 //                           mean -> 9 features -> Linear(9,32) -> BN -> ReLU -> mean over the cell,
 //                           one 128-byte NHWC store per cell; empty cells are written as zeros
 //                           (so no separate memset of the 32 MB image).
@@ -153,21 +153,23 @@ __global__ __launch_bounds__(256) void pillar_fill_kernel(PillarBatch m) {
 }
 
 constexpr int kCellsPerBlock = 8;     // 8 cells x 32 lanes = 256 threads
-constexpr int kMaxStage = 128;        // points of one cell staged (and sorted) in LDS at a time
 
 constexpr int kFeatCells = 64;        // cells per block of the feature kernel
 
 // A block owns 64 consecutive cells.  Most cells of a sweep are empty (120k points over 262k cells): their 128-byte
 // rows are zero-filled cooperatively, and the non-empty ones are compacted into a short list that the block's eight
-// half-waves (32 lanes = 32 channels) work through -- 8x fewer, better balanced waves than one half-wave per cell.
+// half-waves (32 lanes = 32 channels) work through INDEPENDENTLY: a cell's points live in the half-wave's registers
+// (lane j = point j), are ranked and permuted into ascending point order with wavefront shuffles, and the sequential
+// (order-deterministic) sums broadcast one point at a time -- no LDS, no barrier after the prologue.  Cells with more
+// than 32 points rank in 32-point chunks and go through the order2 array in global memory.
+__device__ inline float shfl32(float v, int src) { return __shfl(v, src, 32); }
+__device__ inline int shfl32(int v, int src) { return __shfl(v, src, 32); }
+
 __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarBatch m) {
     const PillarArgs& a = m.s[blockIdx.y];
     __shared__ int s_beg[kFeatCells + 1];
     __shared__ int s_list[kFeatCells];
     __shared__ int s_nlist;
-    __shared__ int s_idx[kCellsPerBlock][kMaxStage];
-    __shared__ int s_sorted[kCellsPerBlock][kMaxStage];
-    __shared__ float s_xyz[kCellsPerBlock][kMaxStage][3];      // the cell's points, in ascending point order
     const int sub = threadIdx.x >> 5, c = threadIdx.x & 31;
     const int n_cells = a.g.W * a.g.H;
     const int cell0 = blockIdx.x * kFeatCells;
@@ -192,71 +194,78 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarBatch m) {
     for (int k = 0; k < 9; ++k) w[k] = a.pfn_w[k * 32 + c];
     const float scale = a.pfn_scale[c], shift = a.pfn_shift[c];
 
-    for (int k0 = 0; k0 < nlist; k0 += kCellsPerBlock) {      // block-uniform trip count: barriers inside are legal
-        const bool live = k0 + sub < nlist;
-        const int lc = live ? s_list[k0 + sub] : 0;
+    for (int k = sub; k < nlist; k += kCellsPerBlock) {
+        const int lc = s_list[k];
         const int cell = cell0 + lc;
-        const int beg = live ? s_beg[lc] : 0;
-        const int cnt = live ? s_beg[lc + 1] - beg : 0;
-        const bool staged = cnt <= kMaxStage;
-        // ascending point order: rank every index among the cell's (short) list
-        if (staged)
-            for (int j = c; j < cnt; j += 32) s_idx[sub][j] = a.order[beg + j];
-        __syncthreads();
-        if (staged)
-            for (int j = c; j < cnt; j += 32) {
-                const int v = s_idx[sub][j];
-                const float* p = a.cell_xyz + (int64_t)(beg + j) * 3;
-                const float px = p[0], py = p[1], pz = p[2];
-                int rank = 0;
-                for (int k = 0; k < cnt; ++k) rank += s_idx[sub][k] < v;
-                s_sorted[sub][rank] = v;
-                s_xyz[sub][rank][0] = px; s_xyz[sub][rank][1] = py; s_xyz[sub][rank][2] = pz;
-                a.order2[beg + rank] = v;        // kept for the training backward pass (pfn_backward / scatter kernels)
-            }
-        if (!staged) {
-            // crowded cell (rare: > kMaxStage returns in one 0.2 m pillar): same ranking, through global memory
-            for (int j = c; j < cnt; j += 32) {
-                const int v = a.order[beg + j];
-                int rank = 0;
-                for (int k = 0; k < cnt; ++k) rank += a.order[beg + k] < v;
-                a.order2[beg + rank] = v;
-            }
-            __threadfence_block();
-        }
-        __syncthreads();
-        if (live) {
-            auto pt = [&](int j) { return staged ? s_sorted[sub][j] : a.order2[beg + j]; };
-            auto xyz = [&](int j, float& x, float& y, float& z) {
-                if (staged) { x = s_xyz[sub][j][0]; y = s_xyz[sub][j][1]; z = s_xyz[sub][j][2]; }
-                else { const float* p = a.xyz_t + (int64_t)a.order2[beg + j] * 3; x = p[0]; y = p[1]; z = p[2]; }
-            };
+        const int beg = s_beg[lc];
+        const int cnt = s_beg[lc + 1] - beg;
+        const int iy = cell / a.g.W, ix = cell - iy * a.g.W;
+        const float ccx = (float)ix * a.g.vx + a.g.cx0, ccy = (float)iy * a.g.vy + a.g.cy0, ccz = 0.f * a.g.vz + a.g.cz0;
+        const float fc = (float)cnt;
+        float acc = 0.f;
+        if (cnt <= 32) {
+            // lane j holds point j of the cell's (scatter-ordered) list; rank by point index, permute into ascending order
+            const bool have = c < cnt;
+            const int idx = have ? a.order[beg + c] : 0x7fffffff;
+            const float* p = a.cell_xyz + (int64_t)(beg + (have ? c : 0)) * 3;
+            const float ux = p[0], uy = p[1], uz = p[2];
+            int rank = 0;
+            for (int j = 0; j < cnt; ++j) rank += shfl32(idx, j) < idx;
+            int src = 0;
+            for (int j = 0; j < cnt; ++j)
+                if (shfl32(rank, j) == c) src = j;
+            const int sidx = shfl32(idx, src);
+            const float px = shfl32(ux, src), py = shfl32(uy, src), pz = shfl32(uz, src);
+            if (have) a.order2[beg + c] = sidx;               // kept for the training backward pass
             float sx = 0.f, sy = 0.f, sz = 0.f;
-            for (int j = 0; j < cnt; ++j) {
-                float x, y, z;
-                xyz(j, x, y, z);
-                sx += x; sy += y; sz += z;
-            }
-            const float fc = (float)cnt;
+            for (int j = 0; j < cnt; ++j) { sx += shfl32(px, j); sy += shfl32(py, j); sz += shfl32(pz, j); }
             const float mx = sx / fc, my = sy / fc, mz = sz / fc;
-            const int iy = cell / a.g.W, ix = cell - iy * a.g.W;
-            const float ccx = (float)ix * a.g.vx + a.g.cx0, ccy = (float)iy * a.g.vy + a.g.cy0, ccz = 0.f * a.g.vz + a.g.cz0;
-            float acc = 0.f;
             for (int j = 0; j < cnt; ++j) {
-                const int idx = pt(j);
-                float x, y, z;
-                xyz(j, x, y, z);
+                const float x = shfl32(px, j), y = shfl32(py, j), z = shfl32(pz, j);
+                const int pj = shfl32(sidx, j);
                 const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
                 float v = f[0] * w[0];
 #pragma unroll
-                for (int k = 1; k < 9; ++k) v = fmaf(f[k], w[k], v);
+                for (int q = 1; q < 9; ++q) v = fmaf(f[q], w[q], v);
                 v = v * scale + shift;
                 acc += fmaxf(v, 0.f);
-                if (c < 3) a.offsets[(int64_t)idx * 3 + c] = f[6 + c];
+                if (c < 3) a.offsets[(int64_t)pj * 3 + c] = f[6 + c];
             }
-            a.image[(int64_t)cell * a.image_pitch + c] = acc / fc;
+        } else {
+            // crowded cell: rank every point against the list in 32-point chunks held in registers, ascending order
+            // through order2 in global memory
+            for (int j0 = 0; j0 < cnt; j0 += 32) {
+                const bool have = j0 + c < cnt;
+                const int idx = have ? a.order[beg + j0 + c] : 0x7fffffff;
+                int rank = 0;
+                for (int k0 = 0; k0 < cnt; k0 += 32) {
+                    const int other = k0 + c < cnt ? a.order[beg + k0 + c] : 0x7fffffff;
+                    const int lim = min(32, cnt - k0);
+                    for (int j = 0; j < lim; ++j) rank += shfl32(other, j) < idx;
+                }
+                if (have) a.order2[beg + rank] = idx;
+            }
+            __threadfence_block();
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            for (int j = 0; j < cnt; ++j) {
+                const float* p = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
+                sx += p[0]; sy += p[1]; sz += p[2];
+            }
+            const float mx = sx / fc, my = sy / fc, mz = sz / fc;
+            for (int j = 0; j < cnt; ++j) {
+                const int pj = a.order2[beg + j];
+                const float* p = a.xyz_t + (int64_t)pj * 3;
+                const float x = p[0], y = p[1], z = p[2];
+                const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
+                float v = f[0] * w[0];
+#pragma unroll
+                for (int q = 1; q < 9; ++q) v = fmaf(f[q], w[q], v);
+                v = v * scale + shift;
+                acc += fmaxf(v, 0.f);
+                if (c < 3) a.offsets[(int64_t)pj * 3 + c] = f[6 + c];
+            }
         }
-        __syncthreads();                                      // s_idx / s_sorted are reused by the next round
+        a.image[(int64_t)cell * a.image_pitch + c] = acc / fc;
     }
 }
 
