@@ -46,6 +46,9 @@ __device__ inline int a_slot(int s, int slab, int row, int half) {
 // one value of the A operand, column k of `row`, into the FMT planes (FMT = 3: bf16 h, m, l; FMT = 2: fp16 h, l')
 template <int FMT>
 __device__ inline void a_store(unsigned char* A, int row, int k, float v) {
+#ifdef HIMO_EXP_HNOSTORE
+    if (v != 12345.678f) return;
+#endif
     unsigned h, m = 0, l;
     if (FMT == 3) split3(v, h, m, l); else split2(v, h, l);
     const int slab = k >> 4, kk = k & 15;
@@ -80,7 +83,9 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
     load_b(0, bcur);
 #pragma unroll 2
     for (int slab = 0; slab < kGhSlabs; ++slab) {
+#ifndef HIMO_EXP_HNOB
         if (slab + 1 < kGhSlabs) load_b(slab + 1, bnxt);
+#endif
         bf16x8 af[RT][FMT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
