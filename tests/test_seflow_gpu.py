@@ -139,3 +139,22 @@ def test_fused_head_equals_the_multi_launch_head(gpu, params):
         net.fused_head = True
         assert a.shape == b.shape == (n0, 3)
         assert np.abs(a - b).max() <= 2e-5, (n0, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3"])
+def test_every_tile_variant_gives_the_same_bits(gpu, precision):
+    """The tile autotune may pick any structure / tile per layer: LDS-staged weights (convbf.hip, 4 tiles) or weights from
+    L2 (convsp.hip, 4 | 2 | 1 rows per wave).  The summation order over K does not depend on the tile, so every variant
+    must produce identical bits -- which is what makes the tuned network reproducible."""
+    from himo_amd.seflow.model import conv2d_nhwc
+    g = torch.Generator().manual_seed(11)
+    for (n, h, w, ci, co, epi) in [(2, 40, 72, 64, 128, 1), (1, 17, 33, 128, 256, 0), (3, 64, 64, 256, 64, 1)]:
+        x = torch.randn(n, h, w, ci, generator=g).to(gpu)
+        wt = (torch.randn(3, 3, ci, co, generator=g) * 0.05).to(gpu)
+        b = (torch.randn(co, generator=g) * 0.1).to(gpu)
+        sc, sh = (torch.rand(co, generator=g) + 0.5).to(gpu), (torch.randn(co, generator=g) * 0.1).to(gpu)
+        ref = conv2d_nhwc(x, wt, b, epilogue=epi, scale=sc, shift=sh, precision=precision, tile_hint=0x1004)
+        hints = [0x1002, 0x1001, 0x41, 0x42] + ([0x81, 0x82] if co % 128 == 0 else [])
+        for hint in hints:
+            y = conv2d_nhwc(x, wt, b, epilogue=epi, scale=sc, shift=sh, precision=precision, tile_hint=hint)
+            assert torch.equal(y, ref), (precision, (n, h, w, ci, co, epi), hex(hint))
