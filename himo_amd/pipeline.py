@@ -45,9 +45,13 @@ class Sample:
 
 
 class HiMoPipeline:
-    def __init__(self, net: SeFlowNet | None = None, device=None, max_points: int = 140_000):
+    def __init__(self, net: SeFlowNet | None = None, device=None, max_points: int = 140_000, max_batch: int = 8,
+                 precision: str = "bf16x3"):
+        """``net``: a ready network, or None to build one (random-init weights; ``max_batch`` samples per backbone launch,
+        ``precision`` "bf16x3" | "f16x2" | "f32" -- see SeFlowNet)."""
         self.device = device if device is not None else _lib.require_gpu()
-        self.net = net if net is not None else SeFlowNet(device=self.device, max_points=max_points)
+        self.net = net if net is not None else SeFlowNet(device=self.device, max_points=max_points, max_batch=max_batch,
+                                                         precision=precision)
         self.compdis = CompDisEngine(device=self.device)
         self._batch = None
         self._key = None
@@ -72,6 +76,15 @@ class HiMoPipeline:
             self._out = {}
             self._key = key
         return self._batch
+
+    def flows(self, samples) -> list:
+        """Network only, for a list of samples: [(N0_k,3) flow incl. ego motion], ``max_batch`` samples per backbone launch."""
+        outs = [torch.empty((s.pc0.shape[0], 3), dtype=torch.float32, device=self.device) for s in samples]
+        mb = self.net.max_batch
+        for lo in range(0, len(samples), mb):
+            grp = samples[lo:lo + mb]
+            self.net.forward_batch([(s.pch1, s.pc0, s.pc1, s.pose_h1, s.pose0, s.pose1) for s in grp], outs[lo:lo + mb])
+        return outs
 
     def sync_check(self):
         """fp16-split precision only: an activation beyond fp16's range (65504) turns into NaN at the next layer's

@@ -47,9 +47,24 @@ def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, si
     import torch.distributed as dist
     from .seflow.model import SeFlowNet
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
-    pipe = pipeline if pipeline is not None else HiMoPipeline(SeFlowNet(params))
+    pipe = pipeline if pipeline is not None else HiMoPipeline(SeFlowNet(params, max_batch=max(1, batch_frames)))
     results = {} if sink is None else None
     done = 0
+    pending = []                                               # (index, frame, sample): up to batch_frames per network pass
+
+    def flush():
+        nonlocal done
+        if not pending:
+            return
+        for (i, f0, _), flow in zip(pending, pipe.flows([p[2] for p in pending])):
+            flow = flow.cpu().numpy()
+            if sink is None:
+                results[i] = flow
+            else:
+                sink(i, f0, flow)
+            done += 1
+        pending.clear()
+
     for i in range(rank, len(dataset), world):
         f0 = dataset[i]
         if "pc1" not in f0:
@@ -58,13 +73,10 @@ def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, si
             f1 = dataset[i + 1]
         else:
             f1 = None
-        s = Sample.from_frames(history_of(dataset, i), f0, f1, device=pipe.device)
-        flow = pipe.flow(s).cpu().numpy()
-        if sink is None:
-            results[i] = flow
-        else:
-            sink(i, f0, flow)
-        done += 1
+        pending.append((i, f0, Sample.from_frames(history_of(dataset, i), f0, f1, device=pipe.device)))
+        if len(pending) >= max(1, batch_frames):
+            flush()
+    flush()
     return results if sink is None else done
 
 
