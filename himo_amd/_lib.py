@@ -17,6 +17,7 @@ LIB_PATH = Path(os.environ.get("HIMO_AMD_LIB", _PKG / "libhimo_amd.so"))
 # name -> (restype, argtypes); mirrors include/himo_amd.h one to one
 SIGNATURES = {
     "himo_abi_version": (c_int, []),
+    "himo_abi_sizeof": (c_size_t, [ctypes.c_char_p]),
     "himo_status_string": (c_char_p, [c_int]),
     "himo_last_hip_error": (c_char_p, []),
     "himo_prof_enable": (None, [c_int]),

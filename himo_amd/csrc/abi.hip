@@ -75,6 +75,16 @@ extern "C" size_t himo_prof_summary(char* buf, size_t cap) {
 
 extern "C" int himo_abi_version(void) { return HIMO_ABI_VERSION; }
 
+// sizeof of the structs that cross the boundary by address, so a binding can check its mirror before the first call
+extern "C" size_t himo_abi_sizeof(const char* struct_name) {
+    if (!struct_name) return 0;
+    if (!strcmp(struct_name, "himo_conv_desc")) return sizeof(himo_conv_desc);
+    if (!strcmp(struct_name, "himo_op")) return sizeof(himo_op);
+    if (!strcmp(struct_name, "himo_sweep")) return sizeof(himo_sweep);
+    if (!strcmp(struct_name, "himo_instance_record")) return sizeof(himo_instance_record);
+    return 0;
+}
+
 extern "C" const char* himo_last_hip_error(void) { return himo::g_hip_error; }
 
 extern "C" const char* himo_status_string(int status) {

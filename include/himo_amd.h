@@ -51,6 +51,9 @@ typedef enum himo_status {
                                     computed by the caller, e.g. with numpy); `pose1` is ignored / may be NULL */
 
 int himo_abi_version(void);
+/* sizeof(struct) for "himo_conv_desc" | "himo_op" | "himo_sweep" | "himo_instance_record" (0 for an unknown name): lets
+ * a binding verify its mirror of the structs that cross the boundary by address */
+size_t himo_abi_sizeof(const char* struct_name);
 const char* himo_status_string(int status);
 /* text of the last HIP error seen by this thread (empty string if none) */
 const char* himo_last_hip_error(void);

@@ -74,3 +74,15 @@ def test_product_never_imports_the_oracle():
         src = p.read_text()
         assert not pat.search(src), p
         assert "sys.path" not in src or "oracle" not in src, p      # no path games either
+
+
+def test_ctypes_mirrors_have_the_c_struct_sizes():
+    """The structs that cross the boundary by address: the Python mirrors must match the compiled layout."""
+    from himo_amd import _lib
+    from himo_amd.eval import InstanceRecord
+    from himo_amd.seflow.model import ConvDesc, HimoOp, HimoSweep
+    import ctypes
+    lib = _lib.load()
+    for name, mirror in (("himo_conv_desc", ConvDesc), ("himo_op", HimoOp), ("himo_sweep", HimoSweep), ("himo_instance_record", InstanceRecord)):
+        assert lib.himo_abi_sizeof(name.encode()) == ctypes.sizeof(mirror), name
+    assert lib.himo_abi_sizeof(b"no_such_struct") == 0
