@@ -32,7 +32,23 @@ __device__ inline void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
 // subnormals on gfx950 (measured: a 2^-20 input comes through the matrix instruction exactly).  Range: |x| must stay
 // below 65504 (fp16 max) -- true for normalised activations; the bf16 split has float32's range and remains available.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// kF16Scaled = false (default): the low part is stored UNSCALED (l = x - h).  It is then an fp16 subnormal for |x| < 1/4
+// -- kept exactly by the conversion and by the matrix instruction on gfx950 -- so a value is represented to
+// max(2^-25 absolute, 2^-23 relative) and all three products share one scale and ONE accumulator: half the accumulator
+// registers (one more wave per SIMD for the 4-row tiles) and no epilogue combine.  -DHIMO_F16_SCALED restores the 2^11
+// scaling with its separate cross-term accumulator (22-bit relative precision at every magnitude).
+// The WEIGHTS (typically ~0.05, whose low parts would be deep in the subnormal range) are packed multiplied by 2^6 --
+// exact, |w| < 1023 -- and the accumulator is multiplied by 2^-6 in the epilogue: their low parts become normal fp16
+// numbers again, which is where the unscaled form lost its precision (measured flow error 5.3e-5 -> back to ~3e-5).
+#ifdef HIMO_F16_SCALED
+constexpr bool kF16Scaled = true;
 constexpr float kF16LowScale = 2048.0f, kF16LowInv = 1.0f / 2048.0f;
+constexpr float kF16WeightScale = 1.0f, kF16AccScale = 1.0f;
+#else
+constexpr bool kF16Scaled = false;
+constexpr float kF16LowScale = 1.0f, kF16LowInv = 1.0f;
+constexpr float kF16WeightScale = 64.0f, kF16AccScale = 1.0f / 64.0f;
+#endif
 
 __device__ inline void split2(float x, unsigned& h, unsigned& l) {
     const _Float16 hh = (_Float16)x;                            // round to nearest even

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     const int ci = slab * 16 + k;
     const float x = ci < Cin ? w[((int64_t)tap * Cin + ci) * Cout + co] : 0.f;
     unsigned h, m = 0, l;
-    if (FMT == 3) split3(x, h, m, l); else split2(x, h, l);
+    if (FMT == 3) split3(x, h, m, l); else split2(x * kF16WeightScale, h, l);
     const int64_t base = (((int64_t)tap * slabs + slab) * FMT) * Cout * 16 + (int64_t)co * 16 + k;
     out[base] = (unsigned short)h;
     if (FMT == 3) {
@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
     for (int mi = 0; mi < MI; ++mi) ppA[mi] = KS == 1 ? (wm * MI + mi) * 32 + li : (wm * MI + mi) * PW + li;
 
     floatx16 acc[MI][NI];
-    floatx16 acx[FMT == 2 ? MI : 1][FMT == 2 ? NI : 1];         // fp16 split: the cross terms (scaled by 2^11)
+    constexpr bool XACC = FMT == 2 && kF16Scaled;               // scaled fp16 split: the cross terms (scaled by 2^11)
+    floatx16 acx[XACC ? MI : 1][XACC ? NI : 1];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[mi][ni][r] = 0.f;
-                if (FMT == 2) acx[mi][ni][r] = 0.f;
+                if (XACC) acx[mi][ni][r] = 0.f;
             }
 
     const int iy0 = oy0 - (KS / 2), ix0 = ox0 - (KS / 2);
@@ -232,7 +233,8 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
                 if constexpr (FMT == 3) {
                     HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
                 } else {
-                    HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1)
+                    if constexpr (XACC) { HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1) }
+                    else { HIMO_TERM16(acc, 1, 0) HIMO_TERM16(acc, 0, 1) HIMO_TERM16(acc, 0, 0) }
                 }
 #undef HIMO_TERM16
 #undef HIMO_TERM
@@ -277,7 +279,8 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
                     pix = (int64_t)oy * a.Wo + ox;
                 }
                 float v = acc[mi][ni][r];
-                if (FMT == 2) v += acx[mi][ni][r] * kF16LowInv;
+                if (XACC) v += acx[mi][ni][r] * kF16LowInv;
+                if (FMT == 2) v *= kF16AccScale;
                 if (ok) epilogue_store<EPI>(a, yout, pix, co, v + b, sc, sh);
             }
         }

@@ -23,7 +23,8 @@ constexpr int kSpRowBytes = 48;      // LDS pitch of one patch pixel: 16 x 2 byt
 // columns de-interleaved ([33 even | 32 odd] per row) so that the 32 output pixels of a fragment -- input columns
 // 2 li + kx -- are again 32 CONSECUTIVE patch pixels for every tap.
 template <int EPI, int PH, int FMT, int MI, int S>
-__global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
+__global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled && PH == 1 && S == 1) ? 3 : 2)
+void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int TW = 32, TH = MI * PH;
     constexpr int PW = S == 1 ? TW + 2 : 2 * TW + 1, PHt = S == 1 ? TH + 2 : 2 * TH + 1, NPIX = PHt * PW;
     constexpr int BN = (4 / PH) * 32;
@@ -51,13 +52,14 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
 
     floatx16 acc[MI];
-    floatx16 acx[FMT == 2 ? MI : 1];
+    constexpr bool XACC = FMT == 2 && kF16Scaled;              // scaled fp16 split: separate cross-term accumulator
+    floatx16 acx[XACC ? MI : 1];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             acc[mi][r] = 0.f;
-            if (FMT == 2) acx[mi][r] = 0.f;
+            if (XACC) acx[mi][r] = 0.f;
         }
 
     auto load_patch = [&](int slab, float4 (&r)[kPatchPerThread]) {
@@ -161,7 +163,8 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
                 if constexpr (FMT == 3) {
                     HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
                 } else {
-                    HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1)
+                    if constexpr (XACC) { HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1) }
+                    else { HIMO_TERM16(acc, 1, 0) HIMO_TERM16(acc, 0, 1) HIMO_TERM16(acc, 0, 0) }
                 }
 #undef HIMO_TERM16
 #undef HIMO_TERM
@@ -205,7 +208,8 @@ __global__ __launch_bounds__(256, 2) void conv3_split_kernel(ConvArgs a, const u
         for (int r = 0; r < 16; ++r) {
             const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             float v = acc[mi][r];
-            if (FMT == 2) v += acx[mi][r] * kF16LowInv;
+            if (XACC) v += acx[mi][r] * kF16LowInv;
+            if (FMT == 2) v *= kF16AccScale;
             if (oy < a.Ho && ox < a.Wo) epilogue_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v + b, sc, sh);
         }
     }

@@ -63,8 +63,9 @@ __device__ inline void a_store(unsigned char* A, int row, int k, float v) {
 template <int RT, int NT, int FMT>
 __device__ inline void gemm192(const unsigned char* A, const unsigned short* __restrict__ wpk, int cout, const int (&col)[NT],
                                floatx16 (&acc)[RT][NT], int rt0, int li, int lh) {
-    floatx16 acx[FMT == 2 ? RT : 1][FMT == 2 ? NT : 1];
-    if (FMT == 2) {
+    constexpr bool XACC = FMT == 2 && kF16Scaled;
+    floatx16 acx[XACC ? RT : 1][XACC ? NT : 1];
+    if (XACC) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -102,7 +103,8 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
         if constexpr (FMT == 3) {
             HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
         } else {
-            HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1)
+            if constexpr (XACC) { HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1) }
+            else { HIMO_TERM16(acc, 1, 0) HIMO_TERM16(acc, 0, 1) HIMO_TERM16(acc, 0, 0) }
         }
 #undef HIMO_TERM16
 #undef HIMO_TERM
@@ -111,13 +113,14 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
 #pragma unroll
             for (int s = 0; s < FMT; ++s) bcur[t][s] = bnxt[t][s];
     }
-    if (FMT == 2) {
+    if (FMT == 2) {                                     // fold the cross terms in and undo the weights' packing scale
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[rt][t][r] += acx[rt][t][r] * kF16LowInv;
+                for (int r = 0; r < 16; ++r)
+                    acc[rt][t][r] = (XACC ? acc[rt][t][r] + acx[rt][t][r] * kF16LowInv : acc[rt][t][r]) * kF16AccScale;
     }
 }
 
