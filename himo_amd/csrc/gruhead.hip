@@ -125,7 +125,7 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
 }
 
 template <int FMT>
-__global__ __launch_bounds__(256, 2) void gru_head_kernel(GruHeadArgs a) {
+__global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_head_kernel(GruHeadArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char A[FMT * kGhPlane];
     __shared__ int s_pid[kGhRows];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
