@@ -382,7 +382,7 @@ def main():
                 # `achieved` is the bf16 MFMA work actually issued, priced against the dense bf16 peak
                 achieved, peak, note = 6.0 * alg_tf, MFMA_BF16_PEAK_TF, "v_mfma_f32_32x32x16_bf16, 6 per float32 product block"
             elif f16:
-                # two-term fp16 split (scaled low part): THREE fp16 matrix multiply-adds per float32 multiply-add
+                # two-term fp16 split: THREE fp16 matrix multiply-adds per float32 multiply-add
                 achieved, peak, note = 3.0 * alg_tf, MFMA_BF16_PEAK_TF, "v_mfma_f32_32x32x16_f16, 3 per float32 product block"
             else:
                 achieved, peak, note = alg_tf, MFMA_F32_PEAK_TF, "v_mfma_f32_32x32x2_f32"
@@ -397,7 +397,7 @@ def main():
                         "(random-init, self-specified: reference network source absent) -> per-point flow -> ego-motion "
                         "removal + dt0 + flow2compDis -> comp_dis")
             dtype = ("bf16x3 (three-term split bf16 on the matrix cores, float32 accumulate; float32-class accuracy)" if bf else
-                     "f16x2 (two-term split fp16 with a 2^11-scaled low part on the matrix cores, float32 accumulate; 22-bit products)"
+                     "f16x2 (two-term split fp16, x = h + l with exact subnormals, on the matrix cores; float32 accumulate; ~22-bit products)"
                      if f16 else "f32")
         line = {
             "metric": "lidar_frames_per_sec_120k", "value": total_frames / elapsed, "unit": "frames/s",

@@ -23,23 +23,21 @@ __device__ inline void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
 }
 
 
-// ---- two-term fp16 split with a scaled low part:  x = h + 2^-11 * l', h and l' both NORMAL fp16 numbers -------------
-// 11 + 11 mantissa bits (relative representation error 2^-22); the product keeps three terms,
-//     acc0 += ha*hb ;  acc1 += ha*lb' + la'*hb ;  result = acc0 + 2^-11 * acc1       (dropped: 2^-22 la' lb')
-// i.e. THREE fp16 matrix instructions per float32 product block instead of six bf16 ones.  The 2^11 scale keeps the low
-// parts out of the fp16 subnormal range (weights ~0.05 would otherwise lose most of their low part's bits).  An h that
-// is itself subnormal (|x| < 2^-14) needs no special case: v_cvt_f16_f32 and v_mfma_f32_32x32x16_f16 both keep
-// subnormals on gfx950 (measured: a 2^-20 input comes through the matrix instruction exactly).  Range: |x| must stay
-// below 65504 (fp16 max) -- true for normalised activations; the bf16 split has float32's range and remains available.
+// ---- two-term fp16 split:  x = h + l,  h = fp16(x),  l = fp16(x - h) -----------------------------------------------
+// The product keeps three terms, ha*hb + ha*lb + la*hb (dropped: la*lb, 2^-22 relative): THREE fp16 matrix instructions
+// per float32 product block instead of six bf16 ones -- all into ONE accumulator, because the low part is stored
+// UNSCALED.  That is only sound because gfx950 keeps fp16 subnormals exactly, in v_cvt_f16_f32 and in
+// v_mfma_f32_32x32x16_f16 (measured: a 2^-20 operand comes through the matrix instruction exactly): l is subnormal for
+// |x| < 1/4, so a value is represented to max(2^-25 absolute, 2^-23 relative).  For the WEIGHTS (typically ~0.05, whose
+// low parts would sit deep in the subnormal range) that absolute floor would cost precision, so they are packed
+// multiplied by 2^6 -- exact, |w| < 1023 -- and the accumulator is multiplied by 2^-6 in the epilogue (measured flow error
+// without the weight scale 5.3e-5, with it 3.1e-5 = the float32-MFMA kernels' own 3.05e-5).
+// One accumulator instead of two halves the accumulator registers: the 4-row convolution tiles and the fused head run
+// three waves per SIMD instead of two (+13 % on the 128/256-channel layers).
+// -DHIMO_F16_SCALED builds the earlier form: l' = 2^11 (x - h) (always a normal number), cross terms in a second
+// accumulator, result = acc0 + 2^-11 acc1.
+// Range: |x| must stay below 65504 (fp16 max) -- true for normalised activations; the bf16 split has float32's range.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// kF16Scaled = false (default): the low part is stored UNSCALED (l = x - h).  It is then an fp16 subnormal for |x| < 1/4
-// -- kept exactly by the conversion and by the matrix instruction on gfx950 -- so a value is represented to
-// max(2^-25 absolute, 2^-23 relative) and all three products share one scale and ONE accumulator: half the accumulator
-// registers (one more wave per SIMD for the 4-row tiles) and no epilogue combine.  -DHIMO_F16_SCALED restores the 2^11
-// scaling with its separate cross-term accumulator (22-bit relative precision at every magnitude).
-// The WEIGHTS (typically ~0.05, whose low parts would be deep in the subnormal range) are packed multiplied by 2^6 --
-// exact, |w| < 1023 -- and the accumulator is multiplied by 2^-6 in the epilogue: their low parts become normal fp16
-// numbers again, which is where the unscaled form lost its precision (measured flow error 5.3e-5 -> back to ~3e-5).
 #ifdef HIMO_F16_SCALED
 constexpr bool kF16Scaled = true;
 constexpr float kF16LowScale = 2048.0f, kF16LowInv = 1.0f / 2048.0f;

@@ -19,7 +19,7 @@
 //     rotating over the MI*NI accumulators so that consecutive MFMAs never share one;
 //   * the next tap's weights (and the next slab's patch) are prefetched into registers under the MFMAs.
 //
-// FMT = 2 runs the same structure on the two-term fp16 split (bf16x3.h: x = h + 2^-11 l', three products per block);
+// FMT = 2 runs the same structure on the two-term fp16 split (bf16x3.h: x = h + l, three products per block);
 // its two planes leave LDS room to stage a whole kernel row of weights per barrier.  The 3x3 layers normally run the
 // second structure in convsp.hip (weight fragments straight from L2, one barrier per slab); this file keeps the row
 // GEMMs (1x1 layers, GRU epilogues) and remains selectable per layer through himo_conv_desc.tile_hint.

@@ -1,8 +1,8 @@
 // convsp.hip -- 3x3 stride-1 NHWC convolution on split-precision matrix instructions, second structure:
 // WEIGHT FRAGMENTS STRAIGHT FROM L2, ONE BARRIER PER 16-CHANNEL SLAB.
 //
-// Same arithmetic as convbf.hip (FMT = 3: three bf16 planes, six products; FMT = 2: two fp16 planes with a 2^11-scaled
-// low part, three products) and the same packed-weight layout [tap][slab][FMT][cout][16]; what changes is who reads
+// Same arithmetic as convbf.hip (FMT = 3: three bf16 planes, six products; FMT = 2: two fp16 planes, x = h + l,
+// three products) and the same packed-weight layout [tap][slab][FMT][cout][16]; what changes is who reads
 // what.  PMC on convbf.hip's kernel showed the matrix pipe 30 % busy with waves parked 46 % of the time at the
 // per-tap barriers that hand the weight tiles through LDS.  Here a wave owns 128 pixels (four image rows x 32 columns)
 // x 32 output channels: no two waves of a pixel group need the same weights, so a weight fragment is one 16-byte

@@ -59,7 +59,7 @@ __device__ inline void a_store(unsigned char* A, int row, int k, float v) {
 }
 
 // acc[rt][t] += A[rows of tile rt][0..192) * W[:, col[t] + li] for the wave's NT column tiles; RT row tiles starting at rt0
-// FMT = 2: acx collects the cross terms (scaled by 2^11), folded in by finish()
+// FMT = 2: one accumulator (bf16x3.h); with -DHIMO_F16_SCALED acx collects the 2^11-scaled cross terms
 template <int RT, int NT, int FMT>
 __device__ inline void gemm192(const unsigned char* A, const unsigned short* __restrict__ wpk, int cout, const int (&col)[NT],
                                floatx16 (&acc)[RT][NT], int rt0, int li, int lh) {

@@ -98,7 +98,7 @@ class SeFlowNet:
     def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, seed: int = 0,
                  precision: str = "bf16x3", autotune: bool = True, max_batch: int = 1):
         """``precision``: "bf16x3" = split-bf16 matrix instructions for every stride-1 convolution / GEMM (float32-class
-        accuracy, float32 range; csrc/convbf.hip); "f16x2" = two-term fp16 split with a scaled low part for the
+        accuracy, float32 range; csrc/convbf.hip); "f16x2" = two-term fp16 split (x = h + l, one accumulator) for the
         convolutions (22-bit products, HALF the matrix instructions of bf16x3; activations and weights must stay
         below fp16's 65504 -- true for this normalised network; the head keeps bf16x3); "f32" = float32 MFMA everywhere."""
         if precision not in ("bf16x3", "f16x2", "f32"):

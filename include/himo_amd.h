@@ -255,7 +255,7 @@ typedef struct himo_conv_desc {
                                                               the variants */
     int packed_format;                                     /* format of w_packed: 0 = three bf16 planes (float32 range,
                                                               6 matrix instructions per product block), 1 = two fp16
-                                                              planes with a 2^11-scaled low part (|values| < 65504,
+                                                              planes, x = h + l with weights packed x 2^6 (|values| < 65504,
                                                               3 matrix instructions): himo_conv_pack_weights_ex */
     int n_outer;                                           /* 0 | 1: `n` images; > 1: n * n_outer images, image i at
                                                               (i % n) * batch_stride + (i / n) * outer_stride -- the n
