@@ -17,13 +17,30 @@
 
 namespace himo {
 
-constexpr int kSpRowBytes = 48;      // LDS pitch of one patch pixel: 16 x 2 bytes + 16 of padding (conflict-free b128 reads)
+// LDS layout of one patch pixel (16 channels x 2 bytes per plane), two ways to make the ds_read_b128 fragment reads --
+// 32 CONSECUTIVE pixels from an arbitrary start (the tap offset) -- conflict-free:
+//   padded  : 48-byte pitch (16 bytes of padding), no address arithmetic;
+//   swizzled: 32-byte pitch, the two 16-byte halves swapped for pixels with bit 3 set.  ds_read_b128's lane groups
+//             ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) pair lanes whose pixels are 8 or 24 apart, so with the swap
+//             every group covers the 16 slots of the 256-byte bank row exactly once wherever the run starts.
+// The swizzle costs three integer instructions per fragment read but a third less LDS: it is used where that buys
+// occupancy or double buffering (the 256-pixel blocks of the 64-channel layers, the stride-2 patches), the padding
+// where it does not (measured: 388 vs 362 TFLOP/s float32-equivalent on the 128-pixel blocks).
+template <bool SWZ> struct PatchLayout;
+template <> struct PatchLayout<false> {
+    static constexpr int kPitch = 48;
+    __device__ static inline int slot(int pix, int half) { return pix * 48 + (half << 4); }
+};
+template <> struct PatchLayout<true> {
+    static constexpr int kPitch = 32;
+    __device__ static inline int slot(int pix, int half) { return pix * 32 + ((half ^ ((pix >> 3) & 1)) << 4); }
+};
 
 // S = 2 (the three stride-2 layers): the halo patch is (2 TH + 1) x 65 input pixels, stored with even and odd
 // columns de-interleaved ([33 even | 32 odd] per row) so that the 32 output pixels of a fragment -- input columns
 // 2 li + kx -- are again 32 CONSECUTIVE patch pixels for every tap.
 template <int EPI, int PH, int FMT, int MI, int S>
-__global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled && PH == 1 && S == 1) ? 3 : 2)
+__global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled && S == 1) ? 3 : 2)
 void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int TW = 32, TH = MI * PH;
     constexpr int PW = S == 1 ? TW + 2 : 2 * TW + 1, PHt = S == 1 ? TH + 2 : 2 * TH + 1, NPIX = PHt * PW;
@@ -31,8 +48,9 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int kPatchItems = NPIX * 4;
     constexpr int kPatchPerThread = (kPatchItems + 255) / 256;
     // double-buffered while two blocks still fit a CU's LDS; else single-buffered with a second barrier per slab
-    constexpr int NB = 2 * FMT * NPIX * kSpRowBytes <= 66 * 1024 ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) unsigned char patch[NB][FMT][NPIX * kSpRowBytes];
+    using PL = PatchLayout<(PH == 2 || S == 2)>;
+    constexpr int NB = 2 * FMT * NPIX * PL::kPitch <= 66 * 1024 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char patch[NB][FMT][NPIX * PL::kPitch];
 
     const int n_tiles_n = (a.Cout + BN - 1) / BN;
     int bid = blockIdx.x;
@@ -88,7 +106,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
             if (item < kPatchItems && (part < 0 || part == mine)) {
                 const int pp = item >> 2, q = item & 3;
                 unsigned h[4], m[4], l[4];
-                const int off = pp * kSpRowBytes + q * 8;
+                const int off = PL::slot(pp, q >> 1) + (q & 1) * 8;
                 if (FMT == 3) {
                     split3(r[it].x, h[0], m[0], l[0]); split3(r[it].y, h[1], m[1], l[1]);
                     split3(r[it].z, h[2], m[2], l[2]); split3(r[it].w, h[3], m[3], l[3]);
@@ -148,9 +166,9 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #ifdef HIMO_EXP_NOA
-                        af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[0][s][(li) * kSpRowBytes + lh * 16 + (slab & 1) * 64]);
+                        af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[0][s][PL::slot(li, lh) + (slab & 1) * 64]);
 #else
-                        af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[buf][s][((wp * MI + mi) * S * PW + li + tapoff) * kSpRowBytes + lh * 16]);
+                        af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[buf][s][PL::slot((wp * MI + mi) * S * PW + li + tapoff, lh)]);
 #endif
                 const uint4 (&bcur)[FMT] = bq[kx];
 #define HIMO_TERM(SA, SB)                                                                                          \
