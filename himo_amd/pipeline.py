@@ -46,12 +46,15 @@ class Sample:
 
 class HiMoPipeline:
     def __init__(self, net: SeFlowNet | None = None, device=None, max_points: int = 140_000, max_batch: int = 8,
-                 precision: str = "bf16x3"):
-        """``net``: a ready network, or None to build one (random-init weights; ``max_batch`` samples per backbone launch,
-        ``precision`` "bf16x3" | "f16x2" | "f32" -- see SeFlowNet)."""
+                 precision: str = "auto", params: dict | None = None):
+        """``net``: a ready network, or None to build one from ``params`` (random-init when None; ``max_batch`` samples per
+        backbone launch).  ``precision``: "bf16x3" | "f16x2" | "f32" (see SeFlowNet) or "auto": start in the fast fp16
+        split, check every batch's flow for non-finite values and, the first time an activation leaves fp16's range,
+        rebuild the network in the bf16 split (float32 range), redo that batch and stay there."""
         self.device = device if device is not None else _lib.require_gpu()
-        self.net = net if net is not None else SeFlowNet(device=self.device, max_points=max_points, max_batch=max_batch,
-                                                         precision=precision)
+        self.auto = net is None and precision == "auto"
+        self._net_args = dict(params=params, device=self.device, max_points=max_points, max_batch=max_batch)
+        self.net = net if net is not None else SeFlowNet(precision="f16x2" if self.auto else precision, **self._net_args)
         self.compdis = CompDisEngine(device=self.device)
         self._batch = None
         self._key = None
@@ -106,12 +109,21 @@ class HiMoPipeline:
         batch = self._batch_for(samples)
         o = batch.offsets_host
         self.sync_check()                                    # the PREVIOUS batch's flag: no stall on this one
-        mb = self.net.max_batch
-        for lo in range(0, len(samples), mb):                   # groups of max_batch samples share every backbone launch
-            grp = samples[lo:lo + mb]
-            self.net.forward_batch([(s.pch1, s.pc0, s.pc1, s.pose_h1, s.pose0, s.pose1) for s in grp],
-                                   [batch.flow[int(o[lo + k]):int(o[lo + k + 1])] for k in range(len(grp))])
+
+        def network():
+            mb = self.net.max_batch
+            for lo in range(0, len(samples), mb):               # groups of max_batch samples share every backbone launch
+                grp = samples[lo:lo + mb]
+                self.net.forward_batch([(s.pch1, s.pc0, s.pc1, s.pose_h1, s.pose0, s.pose1) for s in grp],
+                                       [batch.flow[int(o[lo + k]):int(o[lo + k + 1])] for k in range(len(grp))])
+
+        network()
         if self.net.precision == "f16x2":
-            self._finite = torch.isfinite(batch.flow).all()
+            finite = torch.isfinite(batch.flow).all()
+            if not self.auto:
+                self._finite = finite                            # checked one batch late (sync_check)
+            elif not bool(finite.item()):                        # auto: checked now (one host sync per batch)
+                self.net = SeFlowNet(precision="bf16x3", **self._net_args)
+                network()
         res = self.compdis.run(batch, sensor_dt=sensor_dt, refined=refined, out=self._out)
         return {"flow": batch.flow, "comp_dis": res["comp_dis"], "refined": res.get("refined"), "batch": batch}

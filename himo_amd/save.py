@@ -47,7 +47,7 @@ def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, si
     import torch.distributed as dist
     from .seflow.model import SeFlowNet
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
-    pipe = pipeline if pipeline is not None else HiMoPipeline(SeFlowNet(params, max_batch=max(1, batch_frames)))
+    pipe = pipeline if pipeline is not None else HiMoPipeline(params=params, max_batch=max(1, batch_frames))
     results = {} if sink is None else None
     done = 0
     pending = []                                               # (index, frame, sample): up to batch_frames per network pass

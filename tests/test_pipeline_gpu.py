@@ -96,7 +96,16 @@ def test_fp16_split_pipeline_matches_and_flags_overflow(gpu):
         pipe.sync_check()
     # the bf16 split has float32's range: same weights, finite result
     pipe = HiMoPipeline(SeFlowNet(big, device=gpu, max_points=20_000, precision="bf16x3"), device=gpu)
-    assert torch.isfinite(pipe.run(samples)["flow"]).all()
+    want = pipe.run(samples)["flow"].clone()
+    assert torch.isfinite(want).all()
+    # precision="auto": starts in the fp16 split, notices the overflow, rebuilds in the bf16 split and redoes the batch
+    auto = HiMoPipeline(device=gpu, max_points=20_000, max_batch=2, params=big)
+    assert auto.net.precision == "f16x2"
+    got = auto.run(samples)["flow"]
+    assert auto.net.precision == "bf16x3" and torch.equal(got, want)
+    ok = HiMoPipeline(device=gpu, max_points=20_000, max_batch=2, params=params)
+    ok.run(samples)
+    assert ok.net.precision == "f16x2"                           # well-scaled weights stay on the fast path
 
 
 def test_batched_backbone_equals_one_sample_at_a_time(gpu):
