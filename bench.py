@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--points", type=int, default=POINTS_PER_FRAME)
     ap.add_argument("--precision", default="f16x2", choices=["bf16x3", "f16x2", "f32"],
                     help="network matrix arithmetic: split-bf16 (float32-class accuracy) or float32 MFMA")
+    ap.add_argument("--train-precision", default="mixed", choices=["mixed", "bf16x3", "f32"],
+                    help="train workload: forward fp16-split + data-gradient split-bf16 (mixed), all split-bf16, or float32 MFMA")
     ap.add_argument("--refined", action="store_true", help="also write refined points (+12 B/pt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget for the baseline leg")
@@ -231,7 +233,7 @@ def main():
         from himo_amd.seflow import spec
         from himo_amd.seflow.train import SeFlowTrainer
         params = spec.init_params(0)
-        trainer = SeFlowTrainer(params, device=device, max_points=P)
+        trainer = SeFlowTrainer(params, device=device, max_points=P, precision=args.train_precision)
         samples = synthetic_samples(B, P, device, seed=rank)
         g = torch.Generator(device=device); g.manual_seed(99 + rank)
         labels = []
@@ -427,6 +429,7 @@ def main():
         if args.workload == "train":
             line["metric"] = "train_frames_per_sec_120k"
             line["config"]["parallelism"] = f"data parallel x{world}, one flat all-reduce per step"
+            line["config"]["matrix_arithmetic"] = args.train_precision
         if not args.no_cpu_baseline and args.workload != "train" and world == 1:     # CPU leg: rank 0 at N = 1 only
             if args.workload == "compdis":
                 frames = [frame_to_host(batch, i) for i in range(min(8, B))]

@@ -247,11 +247,14 @@ class SeFlowTrainer:
                  precision: str = "bf16x3"):
         """``precision``: "bf16x3" runs every stride-1 convolution of the forward and data-gradient passes as split-bf16
         on the matrix cores (float32-class accuracy, csrc/convbf.hip; weights are re-packed after every optimiser step);
-        "f32" keeps float32 MFMA.  Weight gradients are float32 MFMA either way."""
+        "mixed" runs the FORWARD convolutions as the two-term fp16 split (activations are O(1): inside fp16's range) and
+        keeps the data gradient split-bf16 (gradients are far below fp16's subnormal floor); "f32" keeps float32 MFMA.
+        Weight gradients are float32 MFMA either way."""
         from .model import SeFlowNet
-        if precision not in ("bf16x3", "f32"):
+        if precision not in ("bf16x3", "mixed", "f32"):
             raise ValueError(precision)
         self.precision = precision
+        self.fwd_format = 1 if precision == "mixed" else 0          # HIMO_PACK_F16X2 / HIMO_PACK_BF16X3
         self.lib = _lib.load()
         self.device = dev = device if device is not None else _lib.require_gpu()
         params = spec.init_params(seed) if params is None else params
@@ -336,7 +339,7 @@ class SeFlowTrainer:
         self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
         # split-bf16 copies of the convolution weights (forward) and a scratch for the flipped ones (data gradient)
         self.packed = {}
-        if precision == "bf16x3":
+        if precision != "f32":
             for k in self.names:
                 v = self.p[k]
                 if k.endswith(".weight") and v.dim() == 4:
@@ -344,23 +347,25 @@ class SeFlowTrainer:
                     self.packed[k] = torch.empty(int(self.lib.himo_conv_packed_weight_bytes(ks, cin, cout)), dtype=torch.uint8, device=dev)
             self.WFP = torch.empty(int(self.lib.himo_conv_packed_weight_bytes(3, 512, 256)), dtype=torch.uint8, device=dev)
             net.packed = self.packed                      # the decoder forward runs through net._conv
+            net.packed_format = self.fwd_format
         self._repack()
 
     def _repack(self):
         """refresh the split-bf16 weight copies (after construction and after every optimiser step)"""
         for k, buf in self.packed.items():
             ks, _, cin, cout = self.p[k].shape
-            _lib.check(self.lib.himo_conv_pack_weights(self.p[k].data_ptr(), ks, cin, cout, buf.data_ptr(), _lib.stream_handle()), "pack")
+            _lib.check(self.lib.himo_conv_pack_weights_ex(self.p[k].data_ptr(), ks, cin, cout, self.fwd_format, buf.data_ptr(),
+                                                          _lib.stream_handle()), "pack")
 
     # ---- launch helpers (raw device addresses: most operands are channel groups of wider buffers) --------------
-    def _conv(self, x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride=1, packed=None):
-        key = (x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride, packed)
+    def _conv(self, x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride=1, packed=None, fmt=0):
+        key = (x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride, packed, fmt)
         d = self._descs.get(key)                 # cached per call site: see HeadTrainer._gemm
         if d is None:
             d = ConvDesc()
             d.x, d.x_batch_stride, d.x_pitch = x, x_bs, x_pitch
             d.w = w; d.bias = bias
-            d.w_packed = packed
+            d.w_packed = packed; d.packed_format = fmt
             d.y, d.y_batch_stride, d.y_pitch = y, y_bs, y_pitch
             d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = n, h, wd, cin, cout, ks, stride, EPI_BIAS
             if len(self._descs) > 4096:
@@ -392,7 +397,7 @@ class SeFlowTrainer:
     def _flip(self, name, ks, cin, cout):
         """flipped / transposed weights of one layer for its data gradient: (float32 address, split-bf16 address or None)"""
         _lib.check(self.lib.himo_weight_flip(self.p[f"{name}.weight"].data_ptr(), ks, cin, cout, self.WF.data_ptr(), _lib.stream_handle()), "flip")
-        if self.precision != "bf16x3":
+        if self.precision == "f32":
             return self.WF.data_ptr(), None
         _lib.check(self.lib.himo_conv_pack_weights(self.WF.data_ptr(), ks, cout, cin, self.WFP.data_ptr(), _lib.stream_handle()), "pack")
         return self.WF.data_ptr(), self.WFP.data_ptr()
@@ -419,7 +424,8 @@ class SeFlowTrainer:
             pre = self.PRE[li]
             pk = self.packed.get(f"{name}.weight")
             self._conv(src, src_bs, src_pitch, self.p[f"{name}.weight"].data_ptr(), self.p[f"{name}.bias"].data_ptr(),
-                       pre.data_ptr(), ho * wo * cout, cout, F, h, w, cin, cout, 3, stride, packed=None if pk is None else pk.data_ptr())
+                       pre.data_ptr(), ho * wo * cout, cout, F, h, w, cin, cout, 3, stride, packed=None if pk is None else pk.data_ptr(),
+                       fmt=self.fwd_format)
             sc, sh = net.p[f"{name}.scale"].data_ptr(), net.p[f"{name}.shift"].data_ptr()
             if last:
                 dst = cat[cout]

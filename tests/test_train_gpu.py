@@ -119,7 +119,7 @@ def _sample(n, seed=0):
     return pch, pc0, pc1, pose_h, pose0, pose1
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+@pytest.mark.parametrize("precision", ["bf16x3", "mixed", "f32"])
 def test_full_network_gradients_match_autograd(gpu, precision):
     """Every trainable tensor's gradient (pillar net, 16 encoder convs, decoder, head) against CPU autograd through the
     oracle network, for the linear functional L = sum(res * G)."""
