@@ -315,6 +315,14 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
     a.Ho = d->stride == 2 ? (d->h + 1) / 2 : d->h;      // 3x3, pad 1: ceil(H / stride)
     a.Wo = d->stride == 2 ? (d->w_in + 1) / 2 : d->w_in;
     a.aux_in = d->aux_in; a.aux_in_pitch = d->aux_in_pitch; a.aux_out = d->aux_out; a.aux_out_pitch = d->aux_out_pitch;
+    a.act_flags = d->act_layout;
+    if (d->act_layout) {          // split activation format: fp16-split 3x3 layers only, whole 16-channel groups
+        if ((d->act_layout & ~3) || !d->w_packed || d->packed_format != 1 || d->ksize != 3) return HIMO_ERR_UNSUPPORTED;
+        if (d->epilogue != kEpiBias && d->epilogue != kEpiBiasBnGelu) return HIMO_ERR_UNSUPPORTED;
+        if (((d->act_layout & 1) && ((d->cin & 15) || (d->x_pitch & 15) || d->stride != 1)) ||
+            ((d->act_layout & 2) && ((d->cout & 15) || (d->y_pitch & 15))))
+            return HIMO_ERR_UNSUPPORTED;
+    }
     hipStream_t s = (hipStream_t)stream;
     // split precision: every stride-1 layer, and the 3x3 stride-2 layers unless the caller pins a float32 tile
     if (d->w_packed && (d->stride == 1 || (d->ksize == 3 && d->epilogue != kEpiGruZR && d->epilogue != kEpiGruQ &&

@@ -2,6 +2,7 @@
 // convolution (conv.hip) and the split-bf16 convolution (convbf.hip).
 #pragma once
 #include "himo_common.h"
+#include "bf16x3.h"
 #include <math.h>
 
 namespace himo {
@@ -29,7 +30,9 @@ struct ConvArgs {
     // GRU epilogues
     const float* aux_in; int aux_in_pitch;                    // z (kEpiGruQ) / h (kEpiGruZR), [rows][pitch]
     float* aux_out; int aux_out_pitch;                        // r*h (kEpiGruZR) / h in place (kEpiGruQ)
+    int act_flags;                                            // kActSplitIn | kActSplitOut: split activation format (convsg.hip)
 };
+enum ActFlags { kActSplitIn = 1, kActSplitOut = 2 };
 
 // GELU (erf form).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, below float32 resolution of the 1 + erf sum)
 // with the hardware exp2 / rcp: a dozen instructions where the library erff takes three times that -- the epilogue of
@@ -83,6 +86,23 @@ __device__ inline void epilogue_store(const ConvArgs& a, float* __restrict__ you
         const float h = a.aux_out[pix * a.aux_out_pitch + co];
         a.aux_out[pix * a.aux_out_pitch + co] = (1.0f - z) * h + z * q;
     }
+}
+
+// one output element in the split activation format (convsg.hip): activation, then x = h + l as two fp16 into the
+// pixel's 64-byte record of the 16-channel group [h0..h15 | l0..l15]
+template <int EPI>
+__device__ inline void split_store(const ConvArgs& a, float* __restrict__ yout, int64_t pix, int co, float v, float sc, float sh) {
+    if (EPI == kEpiBiasBnGelu) v = gelu_exact(v * sc + sh);
+    else if (EPI == kEpiBiasGelu) v = gelu_exact(v);
+    else if (EPI == kEpiBiasRelu) v = fmaxf(v, 0.f);
+    // keep the float32 rounding of v: without the barrier the compiler folds the last multiply of the activation into
+    // v_fma_mixlo_f16 (ONE rounding to fp16), and ties then split differently from a float32 value split by its consumer
+    asm("" : "+v"(v));
+    unsigned h, l;
+    split2(v, h, l);
+    unsigned short* rec = reinterpret_cast<unsigned short*>(yout + pix * a.y_pitch + (co & ~15));
+    rec[co & 15] = (unsigned short)h;
+    rec[16 + (co & 15)] = (unsigned short)l;
 }
 
 // implemented in convbf.hip: stride-1 convolutions / row GEMMs on split-bf16 matrix instructions

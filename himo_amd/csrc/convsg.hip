@@ -1,0 +1,203 @@
+// convsg.hip -- 3x3 stride-1 convolution on the two-term fp16 split whose INPUT is already split in HBM
+// ("split activation format"), staged global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no
+// conversion work and no ds_write in the consumer.
+//
+// Split activation format: same addressing as float32 NHWC (pixel pitch `x_pitch` floats), but every 16-channel group
+// of a pixel -- 64 bytes -- holds [h0..h15 | l0..l15] (fp16 high parts, fp16 low parts; x = h + l, bf16x3.h) instead of
+// sixteen floats.  The producing layer's epilogue writes it (OSPLIT below, and the stride-2 / 3x3 kernels of convsp.hip),
+// so a value is split ONCE instead of once per consuming block and halo overlap; the numbers that reach the matrix
+// instructions are bit-identical to convsp.hip's.
+//
+// LDS image of a slab's halo patch: (TH + 2) rows x 48 pixels (34 used) x 64 bytes; the four 16-byte pieces of a pixel
+// (plane s, k-half lh) sit at slot (2 s + lh) ^ ((px >> 2) & 3).  Rows start on 16-pixel boundaries, so the XOR term
+// depends on the column alone and a fragment read is `ds_read_b128 v[kx][s] offset:row` with six per-lane offsets
+// computed once; every 16-lane group of a ds_read_b128 covers the 256-byte bank row exactly once ({0,12,20,24} and
+// {4,8,16,28} give four different (px >> 2) & 3).  LDS-DMA writes lane-linearly (M0 base + lane * 16), so the same XOR is
+// applied to each lane's SOURCE address: a permutation inside the pixel's 64 bytes -- coalescing is unchanged.
+// Pixels outside the image (and the 14 unused columns of a 48-pixel row) read a 64-byte zero page.
+//
+// Everything else as convsp.hip: a wave owns MI rows x 32 pixels x 32 output channels, weight fragments straight from
+// L2 two taps ahead in three statically rotated register sets, patch double-buffered, ONE barrier per 16-channel slab.
+// The DMA of slab + 1 is issued before the first tap of slab; the in-order vmcnt of the weight loads behind it has
+// retired it by tap 2, the explicit wait before the barrier only documents that.
+// Specification / oracle as conv.hip (reference network absent: PARITY UNPINNED).
+#include "conv_common.h"
+#include "bf16x3.h"
+
+namespace himo {
+
+__device__ __attribute__((aligned(64))) unsigned char g_zero_page[64];
+
+__device__ inline void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int EPI, int PH, int MI, bool OSPLIT>
+__global__ __launch_bounds__(256, 3)
+void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
+    constexpr int TW = 32, TH = MI * PH, PHt = TH + 2, PWP = 48;
+    constexpr int kRow = PWP * 64, kBuf = PHt * kRow;
+    constexpr int kUnits = PHt * 3, kUPW = (kUnits + 3) / 4;      // DMA units of 16 pixels; units per wave
+    constexpr int BN = (4 / PH) * 32;
+    __shared__ __attribute__((aligned(1024))) unsigned char patch[2 * kBuf];
+
+    const int n_tiles_n = (a.Cout + BN - 1) / BN;
+    int bid = blockIdx.x;
+    const int tn = bid % n_tiles_n; bid /= n_tiles_n;
+    const int tx = (a.Wo + TW - 1) / TW, ty = (a.Ho + TH - 1) / TH;
+    const int ox0 = (bid % tx) * TW; bid /= tx;
+    const int oy0 = (bid % ty) * TH;
+    const int img = bid / ty;
+    const unsigned char* __restrict__ xin = reinterpret_cast<const unsigned char*>(a.x + image_offset(img, a.n_inner, a.x_batch_stride, a.x_outer_stride));
+    const int slabs = a.Cin >> 4;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wp = wave % PH, wc = wave / PH;
+    const int li = lane & 31, lh = lane >> 5;
+    const int co = tn * BN + wc * 32 + li;
+    const bool co_ok = co < a.Cout;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(&patch[0]);
+
+    // this lane's DMA sources: unit u = wave + 4 k covers patch row u / 3, pixels 16 (u % 3) .. + 15
+    const unsigned char* src[kUPW];
+    int step[kUPW];
+#pragma unroll
+    for (int k = 0; k < kUPW; ++k) {
+        const int u = wave + 4 * k;
+        const int row = u / 3, px = (u % 3) * 16 + (lane >> 2);
+        const int iy = iy0 + row, ix = ix0 + px;
+        const bool ok = u < kUnits && px < TW + 2 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const int sl = (lane & 3) ^ ((px >> 2) & 3);
+        src[k] = ok ? xin + ((int64_t)iy * a.W + ix) * a.x_pitch * 4 + sl * 16 : g_zero_page + (lane & 3) * 16;
+        step[k] = ok ? 64 : 0;
+    }
+    auto stage = [&](int slab, int buf) {
+#pragma unroll
+        for (int k = 0; k < kUPW; ++k) {
+            const int u = wave + 4 * k;
+            if (u < kUnits) glds16(src[k] + slab * step[k], lds_base + buf * kBuf + ((u / 3) * PWP + (u % 3) * 16) * 64);
+        }
+    };
+
+    floatx16 acc[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+
+    const int co_ld = co_ok ? co : a.Cout - 1;
+    auto load_b = [&](int tap, int slab, uint4 (&b)[2]) {
+        const unsigned short* base = wpk + (((int64_t)tap * slabs + slab) * 2) * a.Cout * 16 + (int64_t)co_ld * 16 + lh * 8;
+        b[0] = *reinterpret_cast<const uint4*>(base);
+        b[1] = *reinterpret_cast<const uint4*>(base + (int64_t)a.Cout * 16);
+    };
+
+    // fragment read offsets (buffer 0, kernel row 0, this wave's first image row): [kx][plane]
+    int rd[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int p = li + kx, f = (p >> 2) & 3;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) rd[kx][s] = wp * MI * kRow + p * 64 + (((2 * s + lh) ^ f) << 4);
+    }
+
+    uint4 bq[3][2];
+    stage(0, 0);
+    load_b(0, 0, bq[0]);
+    load_b(1, 0, bq[1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#pragma unroll 1
+    for (int slab = 0; slab < slabs; ++slab) {
+        const int buf = slab & 1;
+        const bool more = slab + 1 < slabs;
+        const int nslab = more ? slab + 1 : slab;
+        if (more) stage(slab + 1, buf ^ 1);                  // that buffer was last read before the previous barrier
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+            const int rowoff = buf * kBuf + ky * kRow;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tap = ky * 3 + kx;
+                const int t2 = tap + 2;
+                load_b(t2 < 9 ? t2 : t2 - 9, t2 < 9 ? slab : nslab, bq[(kx + 2) % 3]);
+                f16x8 af[MI][2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        af[mi][s] = *reinterpret_cast<const f16x8*>(&patch[rd[kx][s] + rowoff + mi * kRow]);
+                const uint4 (&bcur)[2] = bq[kx];
+#define HIMO_TERM16(SA, SB)                                                                                        \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                \
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][SA], __builtin_bit_cast(f16x8, bcur[SB]), acc[mi], 0, 0, 0);
+                HIMO_TERM16(1, 0) HIMO_TERM16(0, 1) HIMO_TERM16(0, 0)
+#undef HIMO_TERM16
+            }
+        }
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // at most the next slab's first two weight fragments stay in flight
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
+    if (!co_ok) return;
+    const float b = a.bias ? a.bias[co] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int oy = oy0 + wp * MI + mi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float v = acc[mi][r] * kF16AccScale + b;
+            if (oy < a.Ho && ox < a.Wo) {
+                if (OSPLIT) split_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v, sc, sh);
+                else epilogue_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v, sc, sh);
+            }
+        }
+    }
+}
+
+template <int PH, int MI>
+static void launch_sg(const ConvArgs& a, int epi, bool osplit, const unsigned short* w, dim3 grid, hipStream_t s) {
+#define HIMO_SG(E, O) hipLaunchKernelGGL((conv3_presplit_kernel<E, PH, MI, O>), grid, dim3(256), 0, s, a, w)
+    if (epi == kEpiBias) { if (osplit) HIMO_SG(kEpiBias, true); else HIMO_SG(kEpiBias, false); }
+    else { if (osplit) HIMO_SG(kEpiBiasBnGelu, true); else HIMO_SG(kEpiBiasBnGelu, false); }
+#undef HIMO_SG
+}
+
+// 3x3 stride-1 layers whose input is in the split activation format (fp16-split weights, Cin a multiple of 16, bias or
+// bias + BN + GELU epilogue).  rows_hint: image rows per wave (4 | 2 | 1), 0 = heuristic.  false = not applicable.
+bool launch_conv3_presplit(const ConvArgs& a, int epilogue, const void* w_packed, int rows_hint, bool out_split, hipStream_t s) {
+    if ((epilogue != kEpiBias && epilogue != kEpiBiasBnGelu) || (a.Cin & 15) || (out_split && (a.Cout & 15))) return false;
+    const bool wide = a.Cout > 64;
+    const int bn = wide ? 128 : 64, ph = wide ? 1 : 2;
+    auto blocks_for = [&](int mi) -> int64_t {
+        const int th = mi * ph;
+        return (int64_t)a.N * ((a.Ho + th - 1) / th) * ((a.Wo + 31) / 32) * ((a.Cout + bn - 1) / bn);
+    };
+    int mi = blocks_for(4) >= 1024 ? 4 : 2;
+    if (rows_hint == 4 || rows_hint == 2 || rows_hint == 1) mi = rows_hint;
+    if (!wide && mi == 4) mi = 2;                       // 64-channel blocks: 8-row patches would not leave three blocks per CU
+    const dim3 grid((unsigned)blocks_for(mi));
+    const unsigned short* w = (const unsigned short*)w_packed;
+    ProfScope ps("conv3x3_f16x2_kernel", s);
+    if (wide) {
+        if (mi == 4) launch_sg<1, 4>(a, epilogue, out_split, w, grid, s);
+        else if (mi == 2) launch_sg<1, 2>(a, epilogue, out_split, w, grid, s);
+        else launch_sg<1, 1>(a, epilogue, out_split, w, grid, s);
+    } else {
+        if (mi == 2) launch_sg<2, 2>(a, epilogue, out_split, w, grid, s);
+        else launch_sg<2, 1>(a, epilogue, out_split, w, grid, s);
+    }
+    return true;
+}
+
+}  // namespace himo

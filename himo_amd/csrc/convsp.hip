@@ -219,6 +219,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     const float b = a.bias ? a.bias[co] : 0.f;
     float sc = 1.f, sh = 0.f;
     if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
+    const bool osplit = (a.act_flags & kActSplitOut) != 0;       // output in the split activation format (convsg.hip)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int oy = oy0 + wp * MI + mi;
@@ -228,7 +229,10 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
             float v = acc[mi][r];
             if (XACC) v += acx[mi][r] * kF16LowInv;
             if (FMT == 2) v *= kF16AccScale;
-            if (oy < a.Ho && ox < a.Wo) epilogue_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v + b, sc, sh);
+            if (oy < a.Ho && ox < a.Wo) {
+                if (FMT == 2 && osplit) split_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v + b, sc, sh);
+                else epilogue_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v + b, sc, sh);
+            }
         }
     }
 }

@@ -31,7 +31,11 @@ class ConvDesc(ctypes.Structure):
                 ("aux_in", ctypes.c_void_p), ("aux_in_pitch", ctypes.c_int),
                 ("aux_out", ctypes.c_void_p), ("aux_out_pitch", ctypes.c_int), ("w_packed", ctypes.c_void_p),
                 ("tile_hint", ctypes.c_int), ("packed_format", ctypes.c_int),
-                ("n_outer", ctypes.c_int), ("x_outer_stride", ctypes.c_int64), ("y_outer_stride", ctypes.c_int64)]
+                ("n_outer", ctypes.c_int), ("x_outer_stride", ctypes.c_int64), ("y_outer_stride", ctypes.c_int64),
+                ("act_layout", ctypes.c_int)]
+
+
+ACT_SPLIT_IN, ACT_SPLIT_OUT = 1, 2      # himo_conv_desc.act_layout: x / y in the split activation format (csrc/convsg.hip)
 
 
 _lib.register({
@@ -464,8 +468,9 @@ class SeFlowNet:
 # ---- stand-alone operators (tests / experiments): the same kernels on caller-provided tensors -------------------
 def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: int = 1, epilogue: int = EPI_BIAS,
                 scale: torch.Tensor | None = None, shift: torch.Tensor | None = None, precision: str = "f32",
-                tile_hint: int = 0) -> torch.Tensor:
-    """x [N,H,W,Cin] float32 (contiguous, device), weight [k,k,Cin,Cout] -> y [N,Ho,Wo,Cout]."""
+                tile_hint: int = 0, act_layout: int = 0) -> torch.Tensor:
+    """x [N,H,W,Cin] float32 (contiguous, device), weight [k,k,Cin,Cout] -> y [N,Ho,Wo,Cout].  ``act_layout``:
+    ACT_SPLIT_IN / ACT_SPLIT_OUT -- x / y hold the split activation format (same shape, fp16 pairs; f16x2 3x3 layers only)."""
     lib = _lib.load()
     n, h, w, cin = x.shape
     k, _, _, cout = weight.shape
@@ -482,6 +487,7 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, strid
         d.n, d.h, d.w_in = n, h, w
     d.cin, d.cout, d.ksize, d.stride, d.epilogue = cin, cout, k, stride, epilogue
     d.tile_hint = tile_hint
+    d.act_layout = act_layout
     if precision in ("bf16x3", "f16x2") and (stride == 1 or k == 3):
         fmt = 1 if precision == "f16x2" else 0
         pk = torch.empty(int(lib.himo_conv_packed_weight_bytes(k, cin, cout)), dtype=torch.uint8, device=x.device)

@@ -261,7 +261,14 @@ typedef struct himo_conv_desc {
                                                               (i % n) * batch_stride + (i / n) * outer_stride -- the n
                                                               frames of a sample (channel groups) x the samples of a batch */
     int64_t x_outer_stride, y_outer_stride;
+    int act_layout;                                        /* 0 = float32 activations; HIMO_ACT_SPLIT_IN | HIMO_ACT_SPLIT_OUT:
+                                                              x / y in the split activation format (same addressing, every
+                                                              16-channel group of a pixel = [16 fp16 high | 16 fp16 low]):
+                                                              3x3 layers with packed_format 1, bias or bias+BN+GELU epilogue,
+                                                              channel counts and pitches multiples of 16; SPLIT_IN: stride 1 */
 } himo_conv_desc;
+#define HIMO_ACT_SPLIT_IN 1
+#define HIMO_ACT_SPLIT_OUT 2
 int himo_conv2d(const himo_conv_desc* h_desc, void* stream);
 /* one-time weight preparation for the split-bf16 path: [k][k][cin][cout] float32 -> three bf16 planes */
 size_t himo_conv_packed_weight_bytes(int ksize, int cin, int cout);
