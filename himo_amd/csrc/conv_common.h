@@ -89,8 +89,11 @@ __device__ inline void epilogue_store(const ConvArgs& a, float* __restrict__ you
 }
 
 // one output element in the split activation format (convsg.hip): activation, then x = h + l as two fp16 into the
-// pixel's 64-byte record of the 16-channel group [h0..h15 | l0..l15]
-template <int EPI>
+// pixel's 64-byte record of the 16-channel group [h0..h15 | l0..l15].
+// PAIRED (accumulator layouts where lane parity = channel parity and both lanes of a pair hold the same pixel): the even
+// lane takes its neighbour's high part, the odd lane its neighbour's low part, and each stores ONE 32-bit word -- a
+// wave's 32 channels of a pixel leave as one full 128-byte line per store instruction, as the float32 epilogue does.
+template <int EPI, bool PAIRED>
 __device__ inline void split_store(const ConvArgs& a, float* __restrict__ yout, int64_t pix, int co, float v, float sc, float sh) {
     if (EPI == kEpiBiasBnGelu) v = gelu_exact(v * sc + sh);
     else if (EPI == kEpiBiasGelu) v = gelu_exact(v);
@@ -100,9 +103,16 @@ __device__ inline void split_store(const ConvArgs& a, float* __restrict__ yout, 
     asm("" : "+v"(v));
     unsigned h, l;
     split2(v, h, l);
-    unsigned short* rec = reinterpret_cast<unsigned short*>(yout + pix * a.y_pitch + (co & ~15));
-    rec[co & 15] = (unsigned short)h;
-    rec[16 + (co & 15)] = (unsigned short)l;
+    if (PAIRED) {
+        const bool odd = co & 1;
+        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? h : l), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+        unsigned* rec = reinterpret_cast<unsigned*>(yout + pix * a.y_pitch + (co & ~15));
+        rec[(odd ? 8 : 0) + ((co & 15) >> 1)] = odd ? (recv | (l << 16)) : (h | (recv << 16));
+    } else {
+        unsigned short* rec = reinterpret_cast<unsigned short*>(yout + pix * a.y_pitch + (co & ~15));
+        rec[co & 15] = (unsigned short)h;
+        rec[16 + (co & 15)] = (unsigned short)l;
+    }
 }
 
 // implemented in convbf.hip: stride-1 convolutions / row GEMMs on split-bf16 matrix instructions

@@ -35,7 +35,7 @@ __device__ inline void glds16(const void* gsrc, unsigned lds_dst) {
 }
 
 template <int EPI, int PH, int MI, bool OSPLIT>
-__global__ __launch_bounds__(256, 3)
+__global__ __launch_bounds__(256, 4)
 void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int TW = 32, TH = MI * PH, PHt = TH + 2, PWP = 48;
     constexpr int kRow = PWP * 64, kBuf = PHt * kRow;
@@ -61,9 +61,9 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(&patch[0]);
 
-    // this lane's DMA sources: unit u = wave + 4 k covers patch row u / 3, pixels 16 (u % 3) .. + 15
-    const unsigned char* src[kUPW];
-    int step[kUPW];
+    // this lane's DMA sources: unit u = wave + 4 k covers patch row u / 3, pixels 16 (u % 3) .. + 15; a byte offset into
+    // the image (an image is < 2 GB), or -1 for the zero page
+    int src[kUPW];
 #pragma unroll
     for (int k = 0; k < kUPW; ++k) {
         const int u = wave + 4 * k;
@@ -71,14 +71,15 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         const int iy = iy0 + row, ix = ix0 + px;
         const bool ok = u < kUnits && px < TW + 2 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         const int sl = (lane & 3) ^ ((px >> 2) & 3);
-        src[k] = ok ? xin + ((int64_t)iy * a.W + ix) * a.x_pitch * 4 + sl * 16 : g_zero_page + (lane & 3) * 16;
-        step[k] = ok ? 64 : 0;
+        src[k] = ok ? (int)((((int64_t)iy * a.W + ix) * a.x_pitch) * 4 + sl * 16) : -1;
     }
+    const unsigned char* zero = g_zero_page + (lane & 3) * 16;
     auto stage = [&](int slab, int buf) {
 #pragma unroll
         for (int k = 0; k < kUPW; ++k) {
             const int u = wave + 4 * k;
-            if (u < kUnits) glds16(src[k] + slab * step[k], lds_base + buf * kBuf + ((u / 3) * PWP + (u % 3) * 16) * 64);
+            if (u < kUnits)
+                glds16(src[k] >= 0 ? xin + (unsigned)(src[k] + slab * 64) : zero, lds_base + buf * kBuf + ((u / 3) * PWP + (u % 3) * 16) * 64);
         }
     };
 
@@ -108,6 +109,9 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     stage(0, 0);
     load_b(0, 0, bq[0]);
     load_b(1, 0, bq[1]);
+#ifdef HIMO_EXP_NOB
+    load_b(2, 0, bq[2]);                       // experiment: real operand values, loaded once
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -116,7 +120,9 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         const int buf = slab & 1;
         const bool more = slab + 1 < slabs;
         const int nslab = more ? slab + 1 : slab;
+#ifndef HIMO_EXP_NOSTAGE
         if (more) stage(slab + 1, buf ^ 1);                  // that buffer was last read before the previous barrier
+#endif
 #pragma unroll 1
         for (int ky = 0; ky < 3; ++ky) {
             const int rowoff = buf * kBuf + ky * kRow;
@@ -124,7 +130,9 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
             for (int kx = 0; kx < 3; ++kx) {
                 const int tap = ky * 3 + kx;
                 const int t2 = tap + 2;
+#ifndef HIMO_EXP_NOB
                 load_b(t2 < 9 ? t2 : t2 - 9, t2 < 9 ? slab : nslab, bq[(kx + 2) % 3]);
+#endif
                 f16x8 af[MI][2];
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
@@ -139,10 +147,12 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #undef HIMO_TERM16
             }
         }
+#ifndef HIMO_EXP_NOBAR
         if (more) {
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // at most the next slab's first two weight fragments stay in flight
             __syncthreads();
         }
+#endif
     }
 
     float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
@@ -158,7 +168,7 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
             const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             float v = acc[mi][r] * kF16AccScale + b;
             if (oy < a.Ho && ox < a.Wo) {
-                if (OSPLIT) split_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v, sc, sh);
+                if (OSPLIT) split_store<EPI, true>(a, yout, (int64_t)oy * a.Wo + ox, co, v, sc, sh);
                 else epilogue_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v, sc, sh);
             }
         }

@@ -230,7 +230,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
             if (XACC) v += acx[mi][r] * kF16LowInv;
             if (FMT == 2) v *= kF16AccScale;
             if (oy < a.Ho && ox < a.Wo) {
-                if (FMT == 2 && osplit) split_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v + b, sc, sh);
+                if (FMT == 2 && osplit) split_store<EPI, true>(a, yout, (int64_t)oy * a.Wo + ox, co, v + b, sc, sh);
                 else epilogue_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v + b, sc, sh);
             }
         }

@@ -122,6 +122,9 @@ class SeFlowNet:
         self._recording = None
         self._nb = 1                                  # samples the backbone currently runs over
         self.packed_format = 1 if precision == "f16x2" else 0
+        # fp16 split: maps that only travel between two 3x3 layers are stored already split (csrc/convsg.hip); results
+        # are bit-identical either way.  False keeps every activation buffer float32 (the training pass reads them)
+        self.split_acts = precision == "f16x2"
         self.tiles = {}
         self.lib = _lib.load()
         self.device = device if device is not None else _lib.require_gpu()
@@ -210,9 +213,11 @@ class SeFlowNet:
 
     # ---- launch helpers ---------------------------------------------------------------------------
     def _conv(self, x, x_bs, x_pitch, wname, y, y_bs, y_pitch, n, h, w, cin, cout, ks, stride, epi, x_off=0, y_off=0,
-              scale=None, shift=None, aux_in=None, aux_in_pitch=0, aux_out=None, aux_out_pitch=0, bias=None, batched=True):
+              scale=None, shift=None, aux_in=None, aux_in_pitch=0, aux_out=None, aux_out_pitch=0, bias=None, batched=True,
+              act=0):
         """``x`` / ``y``: activation buffers [sample][...] -- with ``batched`` the layer runs over the first
-        ``self._nb`` samples in one launch (outer stride = one sample of the buffer)."""
+        ``self._nb`` samples in one launch (outer stride = one sample of the buffer).  ``act``: ACT_SPLIT_IN / _OUT when
+        x / y are in the split activation format (only honoured with ``self.split_acts``)."""
         d = ConvDesc()
         d.x = x.data_ptr() + 4 * x_off; d.x_batch_stride = x_bs; d.x_pitch = x_pitch
         if batched and self._nb > 1:
@@ -228,7 +233,8 @@ class SeFlowNet:
         pk = self.packed.get(f"{wname}.weight")
         d.w_packed = None if pk is None else pk.data_ptr()
         d.packed_format = self.packed_format
-        key = (n * max(d.n_outer, 1), h, w, cin, cout, ks, stride, epi, pk is not None)
+        d.act_layout = act if self.split_acts else 0
+        key = (n * max(d.n_outer, 1), h, w, cin, cout, ks, stride, epi, pk is not None, d.act_layout)
         if self.autotune and key not in self.tiles:
             self.tiles[key] = self._tune(d)
         d.tile_hint = self.tiles.get(key, 0)
@@ -245,6 +251,8 @@ class SeFlowNet:
         best, best_t = 0, float("inf")
         stream = _lib.stream_handle()
         cands = [(bn << 4) | mi for bn in (128, 64) if not (bn == 128 and d.cout % 128) for mi in (2, 1)]
+        if d.act_layout:
+            cands = []                                    # split activation format: only the weights-from-L2 structures
         if d.w_packed and d.ksize == 3:
             cands += [0x1000 | 4, 0x1000 | 2, 0x1000 | 1] if d.stride == 1 else [0x1000 | 2, 0x1000 | 1]   # weights-from-L2 structure (csrc/convsp.hip)
         for hint in cands:
@@ -324,28 +332,31 @@ class SeFlowNet:
                 last = i == n_conv - 1
                 dst = catbuf if last else pingpong[i % 2]
                 dst_bs, dst_pitch = (cout, cout * F) if last else (ho * wo * cout, cout)
+                # the ping-pong maps between two 3x3 layers travel in the split activation format (csrc/convsg.hip)
+                act = (0 if i == 0 else ACT_SPLIT_IN) | (0 if last else ACT_SPLIT_OUT)
                 if i == 0:
                     self._conv(src, src_bs, src_pitch, name, dst, dst_bs, dst_pitch, F, h, w, cin, cout, 3, 2,
-                               EPI_BIAS_BN_GELU, scale=p[f"{name}.scale"], shift=p[f"{name}.shift"])
+                               EPI_BIAS_BN_GELU, scale=p[f"{name}.scale"], shift=p[f"{name}.shift"], act=act)
                 else:
                     self._conv(src, src_bs, src_pitch, name, dst, dst_bs, dst_pitch, F, ho, wo, cout, cout, 3, 1,
-                               EPI_BIAS_BN_GELU, scale=p[f"{name}.scale"], shift=p[f"{name}.shift"])
+                               EPI_BIAS_BN_GELU, scale=p[f"{name}.scale"], shift=p[f"{name}.shift"], act=act)
                 src, src_bs, src_pitch = dst, dst_bs, dst_pitch
 
     def decoder(self):
         """B0, F1, F2, F3 -> DEC; every intermediate keeps its own buffer (the training backward pass reads them)."""
         H, W, F = self.H, self.W, self.F
-        def block(name, coarse, c_in, ch, cw, tmp, cat, skip, skip_c, lat, out, work):
+        def block(name, coarse, c_in, ch, cw, tmp, cat, skip, skip_c, lat, out, work, out_split=False):
             self._conv(coarse, 0, c_in, f"{name}.u1", tmp, 0, lat, 1, 1, ch * cw, c_in, lat, 1, 1, EPI_BIAS)
             self._up(tmp, lat, ch, cw, lat, cat, 2 * lat)
             self._conv(skip, 0, skip_c, f"{name}.u3", cat, 0, 2 * lat, 1, 1, 4 * ch * cw, skip_c, lat, 1, 1, EPI_BIAS, y_off=lat)
-            self._conv(cat, 0, 2 * lat, f"{name}.u4", work[0], 0, out, 1, 2 * ch, 2 * cw, 2 * lat, out, 3, 1, EPI_BIAS)
-            self._conv(work[0], 0, out, f"{name}.u5", work[1], 0, out, 1, 2 * ch, 2 * cw, out, out, 3, 1, EPI_BIAS)
+            self._conv(cat, 0, 2 * lat, f"{name}.u4", work[0], 0, out, 1, 2 * ch, 2 * cw, 2 * lat, out, 3, 1, EPI_BIAS, act=ACT_SPLIT_OUT)
+            self._conv(work[0], 0, out, f"{name}.u5", work[1], 0, out, 1, 2 * ch, 2 * cw, out, out, 3, 1, EPI_BIAS,
+                       act=ACT_SPLIT_IN | (ACT_SPLIT_OUT if out_split else 0))
             return work[1]
         s = block("dec1", self.F3, 256 * F, H // 8, W // 8, self.T1, self.CAT1, self.F2, 128 * F, 256, 256, self.S)
         t = block("dec2", s, 256, H // 4, W // 4, self.T2, self.CAT2, self.F1, 64 * F, 128, 128, self.T)
-        u = block("dec3", t, 128, H // 2, W // 2, self.T3, self.CAT3, self.B0, 32 * F, 64, 64, self.U)
-        self._conv(u, 0, 64, "dec4", self.DEC, 0, 64, 1, H, W, 64, 64, 3, 1, EPI_BIAS)
+        u = block("dec3", t, 128, H // 2, W // 2, self.T3, self.CAT3, self.B0, 32 * F, 64, 64, self.U, out_split=True)   # only dec4 reads it
+        self._conv(u, 0, 64, "dec4", self.DEC, 0, 64, 1, H, W, 64, 64, 3, 1, EPI_BIAS, act=ACT_SPLIT_IN)
         return self.DEC
 
     def head(self, pc0: torch.Tensor, slot0: int = 1, slot1: int = 2, out: torch.Tensor | None = None) -> torch.Tensor:

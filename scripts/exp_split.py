@@ -11,7 +11,7 @@ dev = torch.device("cuda", 0)
 BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 torch.manual_seed(0)
 # ---- correctness: two-layer chains ----
-for (n, h, w, c0, c1, c2, s0) in [(2, 37, 45, 32, 64, 64, 1), (3, 64, 64, 64, 128, 128, 1), (1, 50, 70, 128, 256, 128, 1), (2, 61, 67, 32, 64, 128, 2)]:
+for (n, h, w, c0, c1, c2, s0) in [] if "--timing-only" in sys.argv else [(2, 37, 45, 32, 64, 64, 1), (3, 64, 64, 64, 128, 128, 1), (1, 50, 70, 128, 256, 128, 1), (2, 61, 67, 32, 64, 128, 2)]:
     x = torch.randn(n, h, w, c0, device=dev)
     w0 = torch.randn(3, 3, c0, c1, device=dev) * 0.05; b0 = torch.randn(c1, device=dev) * 0.1
     w1 = torch.randn(3, 3, c1, c2, device=dev) * 0.05; b1 = torch.randn(c2, device=dev) * 0.1

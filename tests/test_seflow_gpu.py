@@ -158,3 +158,73 @@ def test_every_tile_variant_gives_the_same_bits(gpu, precision):
         for hint in hints:
             y = conv2d_nhwc(x, wt, b, epilogue=epi, scale=sc, shift=sh, precision=precision, tile_hint=hint)
             assert torch.equal(y, ref), (precision, (n, h, w, ci, co, epi), hex(hint))
+
+
+def _decode_split(t):
+    """split activation format -> float32 (h + l of every [16 fp16 high | 16 fp16 low] group)"""
+    return t.view(torch.float16).reshape(*t.shape[:-1], t.shape[-1] // 16, 2, 16).float().sum(-2).reshape(t.shape)
+
+
+def test_split_activation_format_is_bit_identical(gpu):
+    """convsg.hip: a map written already split by its producer (x = h + l, fp16 pairs in place of floats) and staged by
+    LDS-DMA must give exactly the bits of the float32-activation path, through chains of layers, for every rows-per-wave
+    variant, both channel-tile widths, ragged image sizes (partial tiles, halo on every side) and a stride-2 producer."""
+    from himo_amd.seflow.model import conv2d_nhwc, ACT_SPLIT_IN, ACT_SPLIT_OUT
+    g = torch.Generator().manual_seed(23)
+    rnd = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(gpu)
+    for (n, h, w, c0, c1, c2, s0) in [(2, 37, 45, 32, 64, 64, 1), (3, 64, 64, 64, 128, 128, 1), (1, 50, 70, 128, 256, 128, 1),
+                                      (2, 61, 67, 32, 64, 128, 2), (1, 1, 1, 16, 16, 16, 1), (1, 3, 33, 16, 48, 32, 1)]:
+        x = rnd(n, h, w, c0)
+        w0, b0 = rnd(3, 3, c0, c1, k=0.05), rnd(c1, k=0.1)
+        w1, b1 = rnd(3, 3, c1, c1, k=0.05), rnd(c1, k=0.1)
+        w2, b2 = rnd(3, 3, c1, c2, k=0.05), rnd(c2, k=0.1)
+        sc, sh = (torch.rand(c1, generator=g) + 0.5).to(gpu), rnd(c1, k=0.1)
+        kw = dict(scale=sc, shift=sh, precision="f16x2")
+        r0 = conv2d_nhwc(x, w0, b0, stride=s0, epilogue=1, **kw)
+        r1 = conv2d_nhwc(r0, w1, b1, epilogue=1, **kw)
+        r2 = conv2d_nhwc(r1, w2, b2, precision="f16x2")
+        s_0 = conv2d_nhwc(x, w0, b0, stride=s0, epilogue=1, act_layout=ACT_SPLIT_OUT, **kw)
+        h0 = r0.half()
+        assert torch.equal(_decode_split(s_0), h0.float() + (r0 - h0.float()).half().float())     # the format itself
+        for hint in (0, 0x1004, 0x1002, 0x1001):
+            s_1 = conv2d_nhwc(s_0, w1, b1, epilogue=1, act_layout=ACT_SPLIT_IN | ACT_SPLIT_OUT, tile_hint=hint, **kw)
+            assert torch.equal(conv2d_nhwc(s_0, w1, b1, epilogue=1, act_layout=ACT_SPLIT_IN, tile_hint=hint, **kw), r1)
+            assert torch.equal(conv2d_nhwc(s_1, w2, b2, precision="f16x2", act_layout=ACT_SPLIT_IN, tile_hint=hint), r2), \
+                ((n, h, w, c0, c1, c2, s0), hex(hint))
+
+
+def test_split_activation_format_rejects_what_it_does_not_cover(gpu):
+    from himo_amd import _lib
+    from himo_amd.seflow.model import conv2d_nhwc, ACT_SPLIT_IN, ACT_SPLIT_OUT
+    x = torch.randn(1, 8, 8, 16, device=gpu)
+    w3, w1, b = torch.randn(3, 3, 16, 16, device=gpu), torch.randn(1, 1, 16, 16, device=gpu), torch.zeros(16, device=gpu)
+    for kwargs in (dict(weight=w3, precision="bf16x3", act_layout=ACT_SPLIT_OUT),      # fp16 split only
+                   dict(weight=w3, precision="f32", act_layout=ACT_SPLIT_IN),
+                   dict(weight=w1, precision="f16x2", act_layout=ACT_SPLIT_OUT),       # 3x3 only
+                   dict(weight=w3, precision="f16x2", act_layout=ACT_SPLIT_IN, stride=2),
+                   dict(weight=w3, precision="f16x2", act_layout=ACT_SPLIT_IN, epilogue=2),
+                   dict(weight=w3, precision="f16x2", act_layout=4)):
+        weight = kwargs.pop("weight")
+        with pytest.raises(_lib.HimoError):
+            conv2d_nhwc(x, weight, b, **kwargs)
+    x12 = torch.randn(1, 8, 8, 24, device=gpu)                                          # whole 16-channel groups only
+    with pytest.raises(_lib.HimoError):
+        conv2d_nhwc(x12, torch.randn(3, 3, 24, 16, device=gpu), b, precision="f16x2", act_layout=ACT_SPLIT_IN)
+
+
+def test_network_with_split_activations_gives_the_same_flow_bits(gpu, params):
+    """SeFlowNet(precision="f16x2") keeps the maps between consecutive 3x3 layers split in HBM; switching that off must
+    not change a single bit of the flow (batched and single-sample plans)."""
+    from himo_amd.seflow.model import SeFlowNet
+    from himo_amd.synthetic import make_frame
+    fh, f0, f1 = make_frame(40, n_points=20_000), make_frame(41, n_points=25_000), make_frame(42, n_points=22_000)
+    args = (fh["pc0"], f0["pc0"], f1["pc0"], fh["pose0"], f0["pose0"], f0["pose1"])
+    a = SeFlowNet(params, device=gpu, max_points=30_000, precision="f16x2")
+    assert a.split_acts
+    fa = a.forward(*args).clone()
+    fa2 = a.forward(*args).clone()                     # second call: replayed operator list / graph
+    b = SeFlowNet(params, device=gpu, max_points=30_000, precision="f16x2", autotune=False)
+    b.split_acts = False
+    fb = b.forward(*args)
+    assert torch.equal(fa, fb) and torch.equal(fa2, fb)
+    assert torch.equal(a.DEC, b.DEC)
