@@ -79,6 +79,7 @@ extern "C" int himo_abi_version(void) { return HIMO_ABI_VERSION; }
 extern "C" size_t himo_abi_sizeof(const char* struct_name) {
     if (!struct_name) return 0;
     if (!strcmp(struct_name, "himo_conv_desc")) return sizeof(himo_conv_desc);
+    if (!strcmp(struct_name, "himo_head_sample")) return sizeof(himo_head_sample);
     if (!strcmp(struct_name, "himo_op")) return sizeof(himo_op);
     if (!strcmp(struct_name, "himo_sweep")) return sizeof(himo_sweep);
     if (!strcmp(struct_name, "himo_instance_record")) return sizeof(himo_instance_record);

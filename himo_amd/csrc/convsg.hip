@@ -195,7 +195,9 @@ bool launch_conv3_presplit(const ConvArgs& a, int epilogue, const void* w_packed
     };
     int mi = blocks_for(4) >= 1024 ? 4 : 2;
     if (rows_hint == 4 || rows_hint == 2 || rows_hint == 1) mi = rows_hint;
+#ifndef HIMO_EXP_PH2MI4
     if (!wide && mi == 4) mi = 2;                       // 64-channel blocks: 8-row patches would not leave three blocks per CU
+#endif
     const dim3 grid((unsigned)blocks_for(mi));
     const unsigned short* w = (const unsigned short*)w_packed;
     ProfScope ps("conv3x3_f16x2_kernel", s);
@@ -204,6 +206,9 @@ bool launch_conv3_presplit(const ConvArgs& a, int epilogue, const void* w_packed
         else if (mi == 2) launch_sg<1, 2>(a, epilogue, out_split, w, grid, s);
         else launch_sg<1, 1>(a, epilogue, out_split, w, grid, s);
     } else {
+#ifdef HIMO_EXP_PH2MI4
+        if (mi == 4) launch_sg<2, 4>(a, epilogue, out_split, w, grid, s); else
+#endif
         if (mi == 2) launch_sg<2, 2>(a, epilogue, out_split, w, grid, s);
         else launch_sg<2, 1>(a, epilogue, out_split, w, grid, s);
     }

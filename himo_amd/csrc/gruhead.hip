@@ -36,6 +36,20 @@ struct GruHeadArgs {
     int iters;
 };
 
+// several samples in one launch (himo_gru_head_batch): a block finds its sample from the running block counts -- one
+// sample's 120k points are only ~2.4 rounds of blocks on 256 CUs, so per-sample launches end in a half-empty round each
+constexpr int kGhMaxSamples = 16;
+struct GruHeadSample {
+    int64_t n;
+    const int* pid; const float* offsets; const float* img0; const float* img1; const float* dec;
+    const float* xyz_t; const float* pts; float* flow; int stride;
+};
+struct GruHeadBatch {
+    int n_samples;
+    int block_start[kGhMaxSamples + 1];
+    GruHeadSample s[kGhMaxSamples];
+};
+
 constexpr int kGhRows = 64, kGhSlabs = 12;              // 192 / 16
 constexpr int kGhPlane = kGhSlabs * kGhRows * 32;       // bytes per 16-bit plane
 
@@ -125,12 +139,21 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
 }
 
 template <int FMT>
-__global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_head_kernel(GruHeadArgs a) {
+__global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_head_kernel(GruHeadArgs a, GruHeadBatch batch) {
     __shared__ __attribute__((aligned(16))) unsigned char A[FMT * kGhPlane];
     __shared__ int s_pid[kGhRows];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 31, lh = lane >> 5;
-    const int64_t r0 = (int64_t)blockIdx.x * kGhRows;
+    int bid = blockIdx.x;
+    {   // this block's sample (uniform: scalar loads from the argument block)
+        int smp = 0;
+        while (smp + 1 < batch.n_samples && bid >= batch.block_start[smp + 1]) ++smp;
+        bid -= batch.block_start[smp];
+        const GruHeadSample& g = batch.s[smp];
+        a.n = g.n; a.pid = g.pid; a.offsets = g.offsets; a.img0 = g.img0; a.img1 = g.img1; a.dec = g.dec;
+        a.xyz_t = g.xyz_t; a.pts = g.pts; a.flow = g.flow; a.stride = g.stride;
+    }
+    const int64_t r0 = (int64_t)bid * kGhRows;
 
     if (threadIdx.x < kGhRows) {
         const int64_t i = r0 + threadIdx.x;
@@ -250,27 +273,53 @@ using namespace himo;
 
 // hidden 128 (= 32 + 32 + 64 gathered channels), x 64, dec1 width 32: the head of himo_amd/seflow/spec.py.  Packed
 // weights: himo_conv_pack_weights_ex(w, 1, 192, cout, packed_format) of zr [192][256], q [192][128], dec1 [192][32].
+extern "C" int himo_gru_head_batch(int n_samples, const himo_head_sample* h_samples, int img_pitch, int dec_pitch,
+                                   const float* d_w_off, const float* d_b_off,
+                                   const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
+                                   const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
+                                   int iters, int packed_format, void* stream) {
+    if (n_samples < 0 || n_samples > kGhMaxSamples || (n_samples && !h_samples)) return HIMO_ERR_INVALID_ARGUMENT;
+    if (iters < 0 || !(packed_format == 0 || packed_format == 1) || img_pitch < 32 || dec_pitch < 64) return HIMO_ERR_INVALID_ARGUMENT;
+    if (!d_w_off || !d_b_off || !d_wzr_packed || !d_bzr || !d_wq_packed || !d_bq || !d_w1_packed || !d_b1 || !d_w2 || !d_b2)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    if ((reinterpret_cast<uintptr_t>(d_wzr_packed) | reinterpret_cast<uintptr_t>(d_wq_packed) | reinterpret_cast<uintptr_t>(d_w1_packed)) & 15)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    GruHeadBatch b{};
+    int64_t blocks = 0;
+    for (int i = 0; i < n_samples; ++i) {
+        const himo_head_sample& h = h_samples[i];
+        if (h.n < 0 || h.pc_stride < 3) return HIMO_ERR_INVALID_ARGUMENT;
+        if (h.n == 0) continue;                         // empty samples take no blocks
+        if (!h.d_pid || !h.d_offsets || !h.d_img0 || !h.d_img1 || !h.d_dec || !h.d_xyz_t || !h.d_pts || !h.d_flow) return HIMO_ERR_INVALID_ARGUMENT;
+        GruHeadSample& g = b.s[b.n_samples];
+        g.n = h.n; g.pid = h.d_pid; g.offsets = h.d_offsets; g.img0 = h.d_img0; g.img1 = h.d_img1; g.dec = h.d_dec;
+        g.xyz_t = h.d_xyz_t; g.pts = h.d_pts; g.flow = h.d_flow; g.stride = h.pc_stride;
+        b.block_start[b.n_samples] = (int)blocks;
+        blocks += (h.n + kGhRows - 1) / kGhRows;
+        if (blocks > 0x7fffffff) return HIMO_ERR_INVALID_ARGUMENT;
+        b.block_start[++b.n_samples] = (int)blocks;
+    }
+    if (!blocks) return HIMO_OK;
+    GruHeadArgs a{};
+    a.img_pitch = img_pitch; a.dec_pitch = dec_pitch; a.w_off = d_w_off; a.b_off = d_b_off;
+    a.wzr = (const unsigned short*)d_wzr_packed; a.bzr = d_bzr; a.wq = (const unsigned short*)d_wq_packed; a.bq = d_bq;
+    a.w1 = (const unsigned short*)d_w1_packed; a.b1 = d_b1; a.w2 = d_w2; a.b2 = d_b2; a.iters = iters;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("gru_head_kernel", s);
+    const dim3 grid((unsigned)blocks);
+    if (packed_format == 1) hipLaunchKernelGGL(gru_head_kernel<2>, grid, dim3(256), 0, s, a, b);
+    else hipLaunchKernelGGL(gru_head_kernel<3>, grid, dim3(256), 0, s, a, b);
+    HIMO_LAUNCH_CHECK("gru_head_kernel");
+    return HIMO_OK;
+}
+
 extern "C" int himo_gru_head(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0, const float* d_img1,
                              int img_pitch, const float* d_dec, int dec_pitch, const float* d_w_off, const float* d_b_off,
                              const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
                              const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
                              const float* d_xyz_t, const float* d_pts, int pc_stride, float* d_flow, int iters, int packed_format,
                              void* stream) {
-    if (n < 0 || iters < 0 || !(packed_format == 0 || packed_format == 1) || pc_stride < 3 || img_pitch < 32 || dec_pitch < 64) return HIMO_ERR_INVALID_ARGUMENT;
-    if (n == 0) return HIMO_OK;
-    if (!d_pid || !d_offsets || !d_img0 || !d_img1 || !d_dec || !d_w_off || !d_b_off || !d_wzr_packed || !d_bzr || !d_wq_packed ||
-        !d_bq || !d_w1_packed || !d_b1 || !d_w2 || !d_b2 || !d_xyz_t || !d_pts || !d_flow)
-        return HIMO_ERR_INVALID_ARGUMENT;
-    if ((reinterpret_cast<uintptr_t>(d_wzr_packed) | reinterpret_cast<uintptr_t>(d_wq_packed) | reinterpret_cast<uintptr_t>(d_w1_packed)) & 15)
-        return HIMO_ERR_INVALID_ARGUMENT;
-    GruHeadArgs a{n, d_pid, d_offsets, d_img0, d_img1, img_pitch, d_dec, dec_pitch, d_w_off, d_b_off,
-                  (const unsigned short*)d_wzr_packed, d_bzr, (const unsigned short*)d_wq_packed, d_bq,
-                  (const unsigned short*)d_w1_packed, d_b1, d_w2, d_b2, d_xyz_t, d_pts, pc_stride, d_flow, iters};
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope ps("gru_head_kernel", s);
-    const dim3 grid((unsigned)((n + kGhRows - 1) / kGhRows));
-    if (packed_format == 1) hipLaunchKernelGGL(gru_head_kernel<2>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(gru_head_kernel<3>, grid, dim3(256), 0, s, a);
-    HIMO_LAUNCH_CHECK("gru_head_kernel");
-    return HIMO_OK;
+    himo_head_sample h{n, d_pid, d_offsets, d_img0, d_img1, d_dec, d_xyz_t, d_pts, pc_stride, d_flow};
+    return himo_gru_head_batch(1, &h, img_pitch, dec_pitch, d_w_off, d_b_off, d_wzr_packed, d_bzr, d_wq_packed, d_bq,
+                               d_w1_packed, d_b1, d_w2, d_b2, iters, packed_format, stream);
 }

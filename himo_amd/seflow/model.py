@@ -58,6 +58,8 @@ _lib.register({
                                                  ctypes.c_void_p]),
     "himo_gru_head": (ctypes.c_int, [ctypes.c_int64] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
                       + [ctypes.c_void_p] * 12 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "himo_gru_head_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 10
+                            + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "himo_head_gather": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
@@ -65,6 +67,13 @@ _lib.register({
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_void_p]),
 })
+
+
+class HimoHeadSample(ctypes.Structure):
+    """mirror of `himo_head_sample` (include/himo_amd.h)"""
+    _fields_ = [("n", ctypes.c_int64), ("d_pid", ctypes.c_void_p), ("d_offsets", ctypes.c_void_p), ("d_img0", ctypes.c_void_p),
+                ("d_img1", ctypes.c_void_p), ("d_dec", ctypes.c_void_p), ("d_xyz_t", ctypes.c_void_p), ("d_pts", ctypes.c_void_p),
+                ("pc_stride", ctypes.c_int), ("d_flow", ctypes.c_void_p)]
 
 
 class HimoSweep(ctypes.Structure):
@@ -428,9 +437,39 @@ class SeFlowNet:
             jobs.append((k, (pch1, pc0, pc1), (inv1 @ np.asarray(pose_h1, np.float64), inv1 @ np.asarray(pose0, np.float64), np.eye(4))))
         self.pillarize_many(jobs)
         self.backbone(len(samples))
+        if self.fused_head:
+            self.head_batch([smp[1] for smp in samples], outs)
+            return
         for k, smp in enumerate(samples):
             self._use_sample(k)
             self.head(smp[1], out=outs[k])
+
+    MAX_HEAD_SAMPLES = 16                 # kGhMaxSamples of csrc/gruhead.hip
+
+    def head_batch(self, pc0s, outs, slot0: int = 1, slot1: int = 2) -> None:
+        """The fused head (csrc/gruhead.hip) over samples 0..len(pc0s)-1 of the activation buffers in ONE launch."""
+        p, pk, F = self.p, self.packed, self.F
+        for lo in range(0, len(pc0s), self.MAX_HEAD_SAMPLES):
+            grp = range(lo, min(lo + self.MAX_HEAD_SAMPLES, len(pc0s)))
+            arr = (HimoHeadSample * len(grp))()
+            for j, k in enumerate(grp):
+                pc0, flow, st = pc0s[k], outs[k], self._pt[k]
+                n = pc0.shape[0]
+                if flow.shape != (n, 3) or flow.dtype != torch.float32 or not flow.is_contiguous():
+                    raise ValueError("out must be a contiguous (N0,3) float32 tensor")
+                h = arr[j]
+                h.n, h.d_pid, h.d_offsets = n, st["pid"][slot0].data_ptr(), st["offsets"][slot0].data_ptr()
+                h.d_img0, h.d_img1 = self.B0[k].data_ptr() + 4 * 32 * slot0, self.B0[k].data_ptr() + 4 * 32 * slot1
+                h.d_dec, h.d_xyz_t = self.DEC[k].data_ptr(), st["xyz_t"][slot0].data_ptr()
+                h.d_pts, h.pc_stride, h.d_flow = pc0.data_ptr(), pc0.shape[1], flow.data_ptr()
+            st = self.lib.himo_gru_head_batch(len(arr), ctypes.addressof(arr), 32 * F, 64,
+                                              p["head.offset.weight"].data_ptr(), p["head.offset.bias"].data_ptr(),
+                                              pk["head.gru.zr.weight"].data_ptr(), p["head.gru.zr.bias"].data_ptr(),
+                                              pk["head.gru.q.weight"].data_ptr(), p["head.gru.q.bias"].data_ptr(),
+                                              pk["head.dec1.weight"].data_ptr(), p["head.dec1.bias"].data_ptr(),
+                                              p["head.dec2.weight"].data_ptr(), p["head.dec2.bias"].data_ptr(),
+                                              spec.GRU_ITERS, self.packed_format, _lib.stream_handle())
+            _lib.check(st, "himo_gru_head_batch")
 
     def pillarize_all(self, sweeps, transforms):
         """The F sweeps of the current sample -> the F channel groups of its B0, sharing every launch of the stage."""

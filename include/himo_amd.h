@@ -311,6 +311,18 @@ int himo_gru_head(int64_t n, const int32_t* d_pid, const float* d_offsets, const
                   const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
                   const float* d_xyz_t, const float* d_pts, int pc_stride, float* d_flow, int iters, int packed_format,
                   void* stream);
+/* The same over several samples in ONE launch (a sample's ~1900 blocks are 2.4 rounds on 256 CUs: per-sample launches
+ * each end in a half-empty round).  Up to 16 samples; samples with n == 0 are skipped; weights shared. */
+typedef struct himo_head_sample {
+    int64_t n;
+    const int32_t* d_pid; const float* d_offsets; const float* d_img0; const float* d_img1; const float* d_dec;
+    const float* d_xyz_t; const float* d_pts; int pc_stride; float* d_flow;
+} himo_head_sample;
+int himo_gru_head_batch(int n_samples, const himo_head_sample* h_samples, int img_pitch, int dec_pitch,
+                        const float* d_w_off, const float* d_b_off,
+                        const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
+                        const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
+                        int iters, int packed_format, void* stream);
 /* per-point head glue: hx[i] = [img0[cell], img1[cell], dec[cell], Linear(3,64)(offset)] (192 floats; zeros for
  * dropped points), rhx[i][128:192] = the same Linear output */
 int himo_head_gather(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0,

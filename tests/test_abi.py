@@ -80,9 +80,10 @@ def test_ctypes_mirrors_have_the_c_struct_sizes():
     """The structs that cross the boundary by address: the Python mirrors must match the compiled layout."""
     from himo_amd import _lib
     from himo_amd.eval import InstanceRecord
-    from himo_amd.seflow.model import ConvDesc, HimoOp, HimoSweep
+    from himo_amd.seflow.model import ConvDesc, HimoOp, HimoSweep, HimoHeadSample
     import ctypes
     lib = _lib.load()
-    for name, mirror in (("himo_conv_desc", ConvDesc), ("himo_op", HimoOp), ("himo_sweep", HimoSweep), ("himo_instance_record", InstanceRecord)):
+    for name, mirror in (("himo_conv_desc", ConvDesc), ("himo_op", HimoOp), ("himo_sweep", HimoSweep), ("himo_instance_record", InstanceRecord),
+                         ("himo_head_sample", HimoHeadSample)):
         assert lib.himo_abi_sizeof(name.encode()) == ctypes.sizeof(mirror), name
     assert lib.himo_abi_sizeof(b"no_such_struct") == 0
