@@ -48,6 +48,8 @@ def parse_args():
                     help="network matrix arithmetic: split-bf16 (float32-class accuracy) or float32 MFMA")
     ap.add_argument("--train-precision", default="mixed", choices=["mixed", "bf16x3", "f32"],
                     help="train workload: forward fp16-split + data-gradient split-bf16 (mixed), all split-bf16, or float32 MFMA")
+    ap.add_argument("--float32-activations", action="store_true",
+                    help="pipeline, f16x2: keep the backbone's maps float32 in HBM instead of the split activation format (A/B switch)")
     ap.add_argument("--refined", action="store_true", help="also write refined points (+12 B/pt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget for the baseline leg")
@@ -252,7 +254,10 @@ def main():
         from himo_amd.seflow import spec
         from himo_amd.seflow.model import SeFlowNet
         params = spec.init_params(0)
-        pipe = HiMoPipeline(SeFlowNet(params, device=device, max_points=P, precision=args.precision, max_batch=B), device=device)
+        net = SeFlowNet(params, device=device, max_points=P, precision=args.precision, max_batch=B)
+        if args.float32_activations:
+            net.split_acts = False
+        pipe = HiMoPipeline(net, device=device)
         samples = synthetic_samples(B, P, device, seed=rank)
         result = {}
 

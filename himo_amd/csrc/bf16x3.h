@@ -58,4 +58,12 @@ __device__ inline void split2(float x, unsigned& h, unsigned& l) {
     l = __builtin_bit_cast(unsigned short, ll);
 }
 
+// split of a float32 value that was just COMPUTED (an epilogue result): the empty asm keeps its float32 rounding.  Without it
+// the compiler folds the producing multiply / add into v_fma_mixlo_f16 -- ONE rounding to fp16 -- and ties then split
+// differently from the same float32 value split by a consumer that loaded it from memory.
+__device__ inline void split2_rounded(float x, unsigned& h, unsigned& l) {
+    asm("" : "+v"(x));
+    split2(x, h, l);
+}
+
 }  // namespace himo

@@ -242,6 +242,7 @@ struct UpArgs {
     float* y; int y_pitch;
     int64_t x_bs, y_bs;   // image blockIdx.y of a batch
     float ry, rx;   // (H-1)/(2H-1), (W-1)/(2W-1)
+    int out_split;  // y in the split activation format (convsg.hip)
 };
 
 __global__ __launch_bounds__(256) void upsample2x_kernel(UpArgs a) {
@@ -266,6 +267,15 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(UpArgs a) {
     o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
     o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
     o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+    if (a.out_split) {          // [16 fp16 high | 16 fp16 low] per 16-channel group: this thread's 4 channels = 8 + 8 bytes
+        unsigned h[4], l[4];
+        split2_rounded(o.x, h[0], l[0]); split2_rounded(o.y, h[1], l[1]);
+        split2_rounded(o.z, h[2], l[2]); split2_rounded(o.w, h[3], l[3]);
+        unsigned char* rec = reinterpret_cast<unsigned char*>(a.y + pix * a.y_pitch + (q >> 2) * 16) + (q & 3) * 8;
+        *reinterpret_cast<uint2*>(rec) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        *reinterpret_cast<uint2*>(rec + 32) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+        return;
+    }
     *reinterpret_cast<float4*>(a.y + pix * a.y_pitch + q * 4) = o;
 }
 
@@ -317,9 +327,10 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
     a.aux_in = d->aux_in; a.aux_in_pitch = d->aux_in_pitch; a.aux_out = d->aux_out; a.aux_out_pitch = d->aux_out_pitch;
     a.act_flags = d->act_layout;
     if (d->act_layout) {          // split activation format: fp16-split 3x3 layers only, whole 16-channel groups
-        if ((d->act_layout & ~3) || !d->w_packed || d->packed_format != 1 || d->ksize != 3) return HIMO_ERR_UNSUPPORTED;
+        if ((d->act_layout & ~3) || !d->w_packed || d->packed_format != 1) return HIMO_ERR_UNSUPPORTED;
+        if (d->ksize == 1 && !(d->act_layout & 1)) return HIMO_ERR_UNSUPPORTED;      // 1x1: split output only with split input
         if (d->epilogue != kEpiBias && d->epilogue != kEpiBiasBnGelu) return HIMO_ERR_UNSUPPORTED;
-        if (((d->act_layout & 1) && ((d->cin & 15) || (d->x_pitch & 15) || d->stride != 1)) ||
+        if (((d->act_layout & 1) && ((d->cin & 15) || (d->x_pitch & 15))) ||
             ((d->act_layout & 2) && ((d->cout & 15) || (d->y_pitch & 15))))
             return HIMO_ERR_UNSUPPORTED;
     }
@@ -363,12 +374,18 @@ extern "C" int himo_upsample2x(const float* d_x, int x_pitch, int h, int w, int 
 
 extern "C" int himo_upsample2x_batch(int n, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int c, float* d_y,
                                      int64_t y_batch_stride, int y_pitch, void* stream) {
+    return himo_upsample2x_batch_ex(n, d_x, x_batch_stride, x_pitch, h, w, c, d_y, y_batch_stride, y_pitch, 0, stream);
+}
+
+extern "C" int himo_upsample2x_batch_ex(int n, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int c, float* d_y,
+                                        int64_t y_batch_stride, int y_pitch, int out_split, void* stream) {
+    if (out_split && ((c & 15) || (y_pitch & 15) || (y_batch_stride & 15) || (reinterpret_cast<uintptr_t>(d_y) & 63))) return HIMO_ERR_INVALID_ARGUMENT;
     if (n < 1 || !d_x || !d_y || h < 1 || w < 1 || c < 4 || (c & 3) || (x_pitch & 3) || (y_pitch & 3) || (x_batch_stride & 3) ||
         (y_batch_stride & 3))
         return HIMO_ERR_INVALID_ARGUMENT;
     UpArgs a{};
     a.x = d_x; a.x_pitch = x_pitch; a.H = h; a.W = w; a.C = c; a.y = d_y; a.y_pitch = y_pitch;
-    a.x_bs = x_batch_stride; a.y_bs = y_batch_stride;
+    a.x_bs = x_batch_stride; a.y_bs = y_batch_stride; a.out_split = out_split ? 1 : 0;
     a.ry = h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     a.rx = w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
     const int64_t total = (int64_t)(2 * h) * (2 * w) * (c / 4);

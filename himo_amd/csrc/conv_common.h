@@ -98,11 +98,8 @@ __device__ inline void split_store(const ConvArgs& a, float* __restrict__ yout, 
     if (EPI == kEpiBiasBnGelu) v = gelu_exact(v * sc + sh);
     else if (EPI == kEpiBiasGelu) v = gelu_exact(v);
     else if (EPI == kEpiBiasRelu) v = fmaxf(v, 0.f);
-    // keep the float32 rounding of v: without the barrier the compiler folds the last multiply of the activation into
-    // v_fma_mixlo_f16 (ONE rounding to fp16), and ties then split differently from a float32 value split by its consumer
-    asm("" : "+v"(v));
     unsigned h, l;
-    split2(v, h, l);
+    split2_rounded(v, h, l);
     if (PAIRED) {
         const bool odd = co & 1;
         const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? h : l), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]

@@ -308,11 +308,17 @@ static void launch_bf_tile(const ConvArgs& a, int epi, int bn, int mi, const uns
 
 bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, int format, int rows_hint, int stride, hipStream_t s);   // convsp.hip
 
-bool launch_conv3_presplit(const ConvArgs& a, int epilogue, const void* w_packed, int rows_hint, bool out_split, hipStream_t s);   // convsg.hip
+bool launch_conv3_presplit(const ConvArgs& a, int epilogue, const void* w_packed, int rows_hint, bool out_split, int stride, hipStream_t s);
+bool launch_conv1_presplit(const ConvArgs& a, int epilogue, const void* w_packed, int rows_hint, bool out_split, hipStream_t s);   // convsg.hip
 
 int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w_packed, int tile_hint, int format, int stride, hipStream_t s) {
+    if ((a.act_flags & kActSplitIn) && ksize == 1) {
+        if (!launch_conv1_presplit(a, epilogue, w_packed, tile_hint & 15, (a.act_flags & kActSplitOut) != 0, s)) return HIMO_ERR_UNSUPPORTED;
+        HIMO_LAUNCH_CHECK("conv1_presplit_kernel");
+        return HIMO_OK;
+    }
     if (a.act_flags & kActSplitIn) {            // input already split in HBM: the LDS-DMA kernel
-        if (!launch_conv3_presplit(a, epilogue, w_packed, tile_hint & 15, (a.act_flags & kActSplitOut) != 0, s)) return HIMO_ERR_UNSUPPORTED;
+        if (!launch_conv3_presplit(a, epilogue, w_packed, tile_hint & 15, (a.act_flags & kActSplitOut) != 0, stride, s)) return HIMO_ERR_UNSUPPORTED;
         HIMO_LAUNCH_CHECK("conv3_presplit_kernel");
         return HIMO_OK;
     }

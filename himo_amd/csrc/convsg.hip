@@ -34,12 +34,16 @@ __device__ inline void glds16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int EPI, int PH, int MI, bool OSPLIT>
-__global__ __launch_bounds__(256, 4)
+// S = 2 (the stride-2 layers): a patch row holds the 65 input columns DE-INTERLEAVED -- even columns 0, 2, .. 64 in slots
+// 0 .. 32 (padded to 48), odd columns 1, 3, .. 63 in slots 48 .. 79 -- so that the 32 output pixels of a fragment (input
+// columns 2 li + kx) are again 32 consecutive slots for every tap (kx = 0: li, 1: 48 + li, 2: li + 1).  The gather costs
+// nothing: every DMA lane has its own source address anyway.
+template <int EPI, int PH, int MI, bool OSPLIT, int S>
+__global__ __launch_bounds__(256, S == 2 ? 3 : 4)
 void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
-    constexpr int TW = 32, TH = MI * PH, PHt = TH + 2, PWP = 48;
+    constexpr int TW = 32, TH = MI * PH, PHt = S == 1 ? TH + 2 : 2 * TH + 1, PWP = S == 1 ? 48 : 80, UPR = PWP / 16;
     constexpr int kRow = PWP * 64, kBuf = PHt * kRow;
-    constexpr int kUnits = PHt * 3, kUPW = (kUnits + 3) / 4;      // DMA units of 16 pixels; units per wave
+    constexpr int kUnits = PHt * UPR, kUPW = (kUnits + 3) / 4;    // DMA units of 16 pixels; units per wave
     constexpr int BN = (4 / PH) * 32;
     __shared__ __attribute__((aligned(1024))) unsigned char patch[2 * kBuf];
 
@@ -58,18 +62,19 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     const int li = lane & 31, lh = lane >> 5;
     const int co = tn * BN + wc * 32 + li;
     const bool co_ok = co < a.Cout;
-    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(&patch[0]);
 
-    // this lane's DMA sources: unit u = wave + 4 k covers patch row u / 3, pixels 16 (u % 3) .. + 15; a byte offset into
-    // the image (an image is < 2 GB), or -1 for the zero page
+    // this lane's DMA sources: unit u = wave + 4 k covers patch row u / UPR, slots 16 (u % UPR) .. + 15; a byte offset
+    // into the image (an image is < 2 GB), or -1 for the zero page
     int src[kUPW];
 #pragma unroll
     for (int k = 0; k < kUPW; ++k) {
         const int u = wave + 4 * k;
-        const int row = u / 3, px = (u % 3) * 16 + (lane >> 2);
-        const int iy = iy0 + row, ix = ix0 + px;
-        const bool ok = u < kUnits && px < TW + 2 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const int row = u / UPR, px = (u % UPR) * 16 + (lane >> 2);         // slot within the patch row
+        const int col = S == 1 ? px : px < 48 ? 2 * px : 2 * (px - 48) + 1;   // input column it holds
+        const int iy = iy0 + row, ix = ix0 + col;
+        const bool ok = u < kUnits && (S == 1 ? px < TW + 2 : px <= 32 || px >= 48) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         const int sl = (lane & 3) ^ ((px >> 2) & 3);
         src[k] = ok ? (int)((((int64_t)iy * a.W + ix) * a.x_pitch) * 4 + sl * 16) : -1;
     }
@@ -79,7 +84,7 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         for (int k = 0; k < kUPW; ++k) {
             const int u = wave + 4 * k;
             if (u < kUnits)
-                glds16(src[k] >= 0 ? xin + (unsigned)(src[k] + slab * 64) : zero, lds_base + buf * kBuf + ((u / 3) * PWP + (u % 3) * 16) * 64);
+                glds16(src[k] >= 0 ? xin + (unsigned)(src[k] + slab * 64) : zero, lds_base + buf * kBuf + ((u / UPR) * PWP + (u % UPR) * 16) * 64);
         }
     };
 
@@ -100,9 +105,9 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     int rd[3][2];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-        const int p = li + kx, f = (p >> 2) & 3;
+        const int p = S == 1 ? li + kx : (kx & 1) * 48 + li + (kx >> 1), f = (p >> 2) & 3;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) rd[kx][s] = wp * MI * kRow + p * 64 + (((2 * s + lh) ^ f) << 4);
+        for (int s = 0; s < 2; ++s) rd[kx][s] = wp * MI * S * kRow + p * 64 + (((2 * s + lh) ^ f) << 4);
     }
 
     uint4 bq[3][2];
@@ -138,7 +143,7 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-                        af[mi][s] = *reinterpret_cast<const f16x8*>(&patch[rd[kx][s] + rowoff + mi * kRow]);
+                        af[mi][s] = *reinterpret_cast<const f16x8*>(&patch[rd[kx][s] + rowoff + mi * S * kRow]);
                 const uint4 (&bcur)[2] = bq[kx];
 #define HIMO_TERM16(SA, SB)                                                                                        \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                \
@@ -175,20 +180,184 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     }
 }
 
+// 1x1 layers (row GEMMs over the pixels of an image) on the same structure: a block owns TH = MI * PH segments of 32
+// consecutive pixels, two 16-channel slabs are staged per barrier step, weight fragments run one slab ahead in two
+// register sets.  Same summation order as convbf.hip's row GEMM (slab by slab, terms l*h, h*l, h*h): identical bits.
+template <int EPI, int PH, int MI, bool OSPLIT>
+__global__ __launch_bounds__(256, 4)
+void conv1_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
+    constexpr int G = 2, TH = MI * PH, BM = TH * 32;
+    constexpr int kSeg = 32 * 64, kSlab = TH * kSeg, kBuf = G * kSlab;
+    constexpr int kUnits = G * TH * 2, kUPW = (kUnits + 3) / 4;
+    constexpr int BN = (4 / PH) * 32;
+    __shared__ __attribute__((aligned(1024))) unsigned char patch[2 * kBuf];
+
+    const int n_tiles_n = (a.Cout + BN - 1) / BN;
+    int bid = blockIdx.x;
+    const int tn = bid % n_tiles_n; bid /= n_tiles_n;
+    const int64_t rows = (int64_t)a.Ho * a.Wo;
+    const int tiles = (int)((rows + BM - 1) / BM);
+    const int img = bid / tiles;
+    const int64_t row0 = (int64_t)(bid % tiles) * BM;
+    const unsigned char* __restrict__ xin = reinterpret_cast<const unsigned char*>(a.x + image_offset(img, a.n_inner, a.x_batch_stride, a.x_outer_stride));
+    const int slabs = a.Cin >> 4, steps = (slabs + G - 1) / G;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wp = wave % PH, wc = wave / PH;
+    const int li = lane & 31, lh = lane >> 5;
+    const int co = tn * BN + wc * 32 + li;
+    const bool co_ok = co < a.Cout;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(&patch[0]);
+
+    // DMA unit u = wave + 4 k: slab g = u / (2 TH) of the step, segment (u / 2) % TH, pixels 16 (u % 2) .. + 15
+    int src[kUPW];
+#pragma unroll
+    for (int k = 0; k < kUPW; ++k) {
+        const int u = wave + 4 * k;
+        const int g = u / (2 * TH), seg = (u >> 1) % TH, px = (u & 1) * 16 + (lane >> 2);
+        const int64_t pix = row0 + seg * 32 + px;
+        const int sl = (lane & 3) ^ ((px >> 2) & 3);
+        src[k] = (u < kUnits && pix < rows) ? (int)(pix * a.x_pitch * 4 + sl * 16 + g * 64) : -1;
+    }
+    const unsigned char* zero = g_zero_page + (lane & 3) * 16;
+    auto stage = [&](int step, int buf) {
+#pragma unroll
+        for (int k = 0; k < kUPW; ++k) {
+            const int u = wave + 4 * k;
+            if (u < kUnits) {
+                const int g = u / (2 * TH);
+                const bool ok = src[k] >= 0 && step * G + g < slabs;
+                glds16(ok ? xin + (unsigned)(src[k] + step * (G * 64)) : zero, lds_base + buf * kBuf + g * kSlab + ((u >> 1) % TH) * kSeg + (u & 1) * 1024);
+            }
+        }
+    };
+
+    floatx16 acc[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+
+    const int co_ld = co_ok ? co : a.Cout - 1;
+    auto load_b = [&](int slab, uint4 (&b)[2]) {
+        const unsigned short* base = wpk + ((int64_t)slab * 2) * a.Cout * 16 + (int64_t)co_ld * 16 + lh * 8;
+        b[0] = *reinterpret_cast<const uint4*>(base);
+        b[1] = *reinterpret_cast<const uint4*>(base + (int64_t)a.Cout * 16);
+    };
+    int rd[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) rd[s] = wp * MI * kSeg + li * 64 + (((2 * s + lh) ^ ((li >> 2) & 3)) << 4);
+
+    uint4 bq[2][2];
+    stage(0, 0);
+    load_b(0, bq[0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#pragma unroll 1
+    for (int step = 0; step < steps; ++step) {
+        const int buf = step & 1;
+        const bool more = step + 1 < steps;
+        if (more) stage(step + 1, buf ^ 1);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int nslab = step * G + g + 1;
+            load_b(nslab < slabs ? nslab : slabs - 1, bq[(g + 1) & 1]);         // clamped: a slab past the end meets zero activations
+            f16x8 af[MI][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    af[mi][s] = *reinterpret_cast<const f16x8*>(&patch[rd[s] + buf * kBuf + g * kSlab + mi * kSeg]);
+            const uint4 (&bcur)[2] = bq[g & 1];
+#define HIMO_TERM16(SA, SB)                                                                                        \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                \
+        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][SA], __builtin_bit_cast(f16x8, bcur[SB]), acc[mi], 0, 0, 0);
+            HIMO_TERM16(1, 0) HIMO_TERM16(0, 1) HIMO_TERM16(0, 0)
+#undef HIMO_TERM16
+        }
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // only the next slab's weight fragments stay in flight
+            __syncthreads();
+        }
+    }
+
+    float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
+    if (!co_ok) return;
+    const float b = a.bias ? a.bias[co] : 0.f;
+    float sc = 1.f, sh = 0.f;
+    if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t pix = row0 + (wp * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float v = acc[mi][r] * kF16AccScale + b;
+            if (pix < rows) {
+                if (OSPLIT) split_store<EPI, true>(a, yout, pix, co, v, sc, sh);
+                else epilogue_store<EPI>(a, yout, pix, co, v, sc, sh);
+            }
+        }
+    }
+}
+
 template <int PH, int MI>
-static void launch_sg(const ConvArgs& a, int epi, bool osplit, const unsigned short* w, dim3 grid, hipStream_t s) {
-#define HIMO_SG(E, O) hipLaunchKernelGGL((conv3_presplit_kernel<E, PH, MI, O>), grid, dim3(256), 0, s, a, w)
+static void launch_sg1(const ConvArgs& a, int epi, bool osplit, const unsigned short* w, dim3 grid, hipStream_t s) {
+#define HIMO_SG(E, O) hipLaunchKernelGGL((conv1_presplit_kernel<E, PH, MI, O>), grid, dim3(256), 0, s, a, w)
     if (epi == kEpiBias) { if (osplit) HIMO_SG(kEpiBias, true); else HIMO_SG(kEpiBias, false); }
     else { if (osplit) HIMO_SG(kEpiBiasBnGelu, true); else HIMO_SG(kEpiBiasBnGelu, false); }
 #undef HIMO_SG
 }
 
-// 3x3 stride-1 layers whose input is in the split activation format (fp16-split weights, Cin a multiple of 16, bias or
-// bias + BN + GELU epilogue).  rows_hint: image rows per wave (4 | 2 | 1), 0 = heuristic.  false = not applicable.
-bool launch_conv3_presplit(const ConvArgs& a, int epilogue, const void* w_packed, int rows_hint, bool out_split, hipStream_t s) {
+// 1x1 layers whose input is in the split activation format.  rows_hint: 32-pixel segments per wave (4 | 2 | 1).
+bool launch_conv1_presplit(const ConvArgs& a, int epilogue, const void* w_packed, int rows_hint, bool out_split, hipStream_t s) {
     if ((epilogue != kEpiBias && epilogue != kEpiBiasBnGelu) || (a.Cin & 15) || (out_split && (a.Cout & 15))) return false;
+    if ((int64_t)a.Ho * a.Wo * a.x_pitch * 4 >= (int64_t)1 << 31) return false;       // 32-bit DMA source offsets
     const bool wide = a.Cout > 64;
     const int bn = wide ? 128 : 64, ph = wide ? 1 : 2;
+    auto blocks_for = [&](int mi) -> int64_t {
+        return (int64_t)a.N * (((int64_t)a.Ho * a.Wo + mi * ph * 32 - 1) / (mi * ph * 32)) * ((a.Cout + bn - 1) / bn);
+    };
+    int mi = wide ? 4 : 2;
+    while (mi > 1 && blocks_for(mi) < 2048) mi >>= 1;
+    if (rows_hint == 4 || rows_hint == 2 || rows_hint == 1) mi = rows_hint;
+    if (!wide && mi == 4) mi = 2;
+    const dim3 grid((unsigned)blocks_for(mi));
+    const unsigned short* w = (const unsigned short*)w_packed;
+    ProfScope ps("conv1x1_f16x2_kernel", s);
+    if (wide) {
+        if (mi == 4) launch_sg1<1, 4>(a, epilogue, out_split, w, grid, s);
+        else if (mi == 2) launch_sg1<1, 2>(a, epilogue, out_split, w, grid, s);
+        else launch_sg1<1, 1>(a, epilogue, out_split, w, grid, s);
+    } else {
+        if (mi == 2) launch_sg1<2, 2>(a, epilogue, out_split, w, grid, s);
+        else launch_sg1<2, 1>(a, epilogue, out_split, w, grid, s);
+    }
+    return true;
+}
+
+template <int PH, int MI, int S = 1>
+static void launch_sg(const ConvArgs& a, int epi, bool osplit, const unsigned short* w, dim3 grid, hipStream_t s) {
+#define HIMO_SG(E, O) hipLaunchKernelGGL((conv3_presplit_kernel<E, PH, MI, O, S>), grid, dim3(256), 0, s, a, w)
+    if (epi == kEpiBias) { if (osplit) HIMO_SG(kEpiBias, true); else HIMO_SG(kEpiBias, false); }
+    else { if (osplit) HIMO_SG(kEpiBiasBnGelu, true); else HIMO_SG(kEpiBiasBnGelu, false); }
+#undef HIMO_SG
+}
+
+// 3x3 layers (stride 1 | 2) whose input is in the split activation format (fp16-split weights, Cin a multiple of 16,
+// bias or bias + BN + GELU epilogue).  rows_hint: image rows per wave (4 | 2 | 1), 0 = heuristic.  false = not applicable.
+bool launch_conv3_presplit(const ConvArgs& a, int epilogue, const void* w_packed, int rows_hint, bool out_split, int stride, hipStream_t s) {
+    if ((epilogue != kEpiBias && epilogue != kEpiBiasBnGelu) || (a.Cin & 15) || (out_split && (a.Cout & 15))) return false;
+    if ((int64_t)a.H * a.W * a.x_pitch * 4 >= (int64_t)1 << 31) return false;       // 32-bit DMA source offsets
+    const bool wide = a.Cout > 64;
+    const int bn = wide ? 128 : 64, ph = wide ? 1 : 2;
+    if (stride == 2) {                                  // two output rows per block: a 5-row x 80-slot patch, double-buffered
+        const int64_t blocks = (int64_t)a.N * ((a.Ho + 1) / 2) * ((a.Wo + 31) / 32) * ((a.Cout + bn - 1) / bn);
+        ProfScope ps("conv3x3s2_f16x2_kernel", s);
+        if (wide) launch_sg<1, 2, 2>(a, epilogue, out_split, (const unsigned short*)w_packed, dim3((unsigned)blocks), s);
+        else launch_sg<2, 1, 2>(a, epilogue, out_split, (const unsigned short*)w_packed, dim3((unsigned)blocks), s);
+        return true;
+    }
     auto blocks_for = [&](int mi) -> int64_t {
         const int th = mi * ph;
         return (int64_t)a.N * ((a.Ho + th - 1) / th) * ((a.Wo + 31) / 32) * ((a.Cout + bn - 1) / bn);

@@ -34,6 +34,7 @@ struct GruHeadArgs {
     const float* xyz_t; const float* pts; int stride;
     float* flow;
     int iters;
+    int img_split;                                      // img0 / img1 rows in the split activation format (convsg.hip)
 };
 
 // several samples in one launch (himo_gru_head_batch): a block finds its sample from the running block counts -- one
@@ -184,7 +185,23 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
         for (int r = 0; r < 16; ++r) {
             const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int cell = s_pid[row];
-            const float v = cell >= 0 ? src[(int64_t)cell * src_pitch + li] : 0.f;
+            float v = 0.f;
+            if (cell >= 0) {
+                if (FMT == 2 && wave < 2) {
+                    // fp16 split: an image feature IS its two-term value h + l -- read as stored when the pillar stage wrote
+                    // the image split, rounded here when it wrote float32 -- so both layouts give the same bits
+                    unsigned hh, ll;
+                    if (a.img_split) {
+                        const unsigned short* rec = reinterpret_cast<const unsigned short*>(src + (int64_t)cell * src_pitch + (li & ~15));
+                        hh = rec[li & 15]; ll = rec[16 + (li & 15)];
+                    } else {
+                        split2(src[(int64_t)cell * src_pitch + li], hh, ll);
+                    }
+                    v = (float)__builtin_bit_cast(_Float16, (unsigned short)hh) + (float)__builtin_bit_cast(_Float16, (unsigned short)ll) * kF16LowInv;
+                } else {
+                    v = src[(int64_t)cell * src_pitch + li];
+                }
+            }
             h[rt][r] = v;
             a_store<FMT>(A, row, wave * 32 + li, v);
         }
@@ -277,7 +294,8 @@ extern "C" int himo_gru_head_batch(int n_samples, const himo_head_sample* h_samp
                                    const float* d_w_off, const float* d_b_off,
                                    const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
                                    const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
-                                   int iters, int packed_format, void* stream) {
+                                   int iters, int packed_format, int img_split, void* stream) {
+    if (img_split && (packed_format != 1 || (img_pitch & 15))) return HIMO_ERR_INVALID_ARGUMENT;
     if (n_samples < 0 || n_samples > kGhMaxSamples || (n_samples && !h_samples)) return HIMO_ERR_INVALID_ARGUMENT;
     if (iters < 0 || !(packed_format == 0 || packed_format == 1) || img_pitch < 32 || dec_pitch < 64) return HIMO_ERR_INVALID_ARGUMENT;
     if (!d_w_off || !d_b_off || !d_wzr_packed || !d_bzr || !d_wq_packed || !d_bq || !d_w1_packed || !d_b1 || !d_w2 || !d_b2)
@@ -304,6 +322,7 @@ extern "C" int himo_gru_head_batch(int n_samples, const himo_head_sample* h_samp
     a.img_pitch = img_pitch; a.dec_pitch = dec_pitch; a.w_off = d_w_off; a.b_off = d_b_off;
     a.wzr = (const unsigned short*)d_wzr_packed; a.bzr = d_bzr; a.wq = (const unsigned short*)d_wq_packed; a.bq = d_bq;
     a.w1 = (const unsigned short*)d_w1_packed; a.b1 = d_b1; a.w2 = d_w2; a.b2 = d_b2; a.iters = iters;
+    a.img_split = img_split ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("gru_head_kernel", s);
     const dim3 grid((unsigned)blocks);
@@ -321,5 +340,5 @@ extern "C" int himo_gru_head(int64_t n, const int32_t* d_pid, const float* d_off
                              void* stream) {
     himo_head_sample h{n, d_pid, d_offsets, d_img0, d_img1, d_dec, d_xyz_t, d_pts, pc_stride, d_flow};
     return himo_gru_head_batch(1, &h, img_pitch, dec_pitch, d_w_off, d_b_off, d_wzr_packed, d_bzr, d_wq_packed, d_bq,
-                               d_w1_packed, d_b1, d_w2, d_b2, iters, packed_format, stream);
+                               d_w1_packed, d_b1, d_w2, d_b2, iters, packed_format, 0, stream);
 }

@@ -21,6 +21,7 @@
 //                           (so no separate memset of the 32 MB image).
 // Only integer atomics are used; the output is bit-deterministic.
 #include "himo_common.h"
+#include "bf16x3.h"
 #include <math.h>
 
 namespace himo {
@@ -44,6 +45,7 @@ struct PillarArgs {
     int* pid;                 // [n]  cell id (iy * W + ix) or -1
     float* offsets;           // [n][3] point - cell centre (zeros for dropped points)
     float* image; int image_pitch;   // [H*W][pitch], 32 channels written per cell
+    int image_split;                 // 1: the 32 channels as two records of the split activation format (convsg.hip)
     int* cell_count;          // [H*W] -> block-local exclusive offsets after the scan
     int* block_sum;           // [H*W/1024 + 1] exclusive offsets of the 1024-cell blocks
     int* cell_cursor;         // [H*W]
@@ -265,7 +267,17 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarBatch m) {
                 if (c < 3) a.offsets[(int64_t)pj * 3 + c] = f[6 + c];
             }
         }
-        a.image[(int64_t)cell * a.image_pitch + c] = acc / fc;
+        const float feat = acc / fc;
+        if (a.image_split) {         // [16 fp16 high | 16 fp16 low] per 16 channels; lane pairs exchange halves: one 32-bit store each
+            unsigned h, l;
+            split2_rounded(feat, h, l);
+            const bool odd = c & 1;
+            const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? h : l), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+            unsigned* rec = reinterpret_cast<unsigned*>(a.image + (int64_t)cell * a.image_pitch + (c & ~15));
+            rec[(odd ? 8 : 0) + ((c & 15) >> 1)] = odd ? (recv | (l << 16)) : (h | (recv << 16));
+        } else {
+            a.image[(int64_t)cell * a.image_pitch + c] = feat;
+        }
     }
 }
 
@@ -474,6 +486,15 @@ extern "C" int himo_pillarize_multi(int n_sweeps, const himo_sweep* h_sweeps, co
                                     const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight,
                                     const float* d_pfn_scale, const float* d_pfn_shift, int image_pitch, size_t workspace_bytes,
                                     void* stream) {
+    return himo_pillarize_multi_ex(n_sweeps, h_sweeps, h_range, h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight, d_pfn_scale,
+                                   d_pfn_shift, image_pitch, workspace_bytes, 0, stream);
+}
+
+extern "C" int himo_pillarize_multi_ex(int n_sweeps, const himo_sweep* h_sweeps, const float* h_range, const float* h_voxel,
+                                       const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight,
+                                       const float* d_pfn_scale, const float* d_pfn_shift, int image_pitch, size_t workspace_bytes,
+                                       int image_split, void* stream) {
+    if (image_split && (image_pitch & 15)) return HIMO_ERR_INVALID_ARGUMENT;
     if (n_sweeps < 1 || n_sweeps > kMaxSweeps || !h_sweeps) return HIMO_ERR_INVALID_ARGUMENT;
     PillarBatch m{};
     for (int i = 0; i < n_sweeps; ++i) {
@@ -482,6 +503,8 @@ extern "C" int himo_pillarize_multi(int n_sweeps, const himo_sweep* h_sweeps, co
                                    d_pfn_weight, d_pfn_scale, d_pfn_shift, w.d_xyz_t, w.d_pid, w.d_offsets, w.d_image, image_pitch,
                                    w.d_workspace, workspace_bytes);
         if (st != HIMO_OK) return st;
+        if (image_split && (reinterpret_cast<uintptr_t>(w.d_image) & 63)) return HIMO_ERR_INVALID_ARGUMENT;
+        m.s[i].image_split = image_split ? 1 : 0;
         for (int j = 0; j < i; ++j)
             if (h_sweeps[j].d_workspace == w.d_workspace) return HIMO_ERR_INVALID_ARGUMENT;     // one workspace per sweep
     }

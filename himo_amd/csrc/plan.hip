@@ -30,8 +30,9 @@ int run_plain(const himo_op* ops, int n, void* stream) {
         int st;
         if (ops[i].kind == HIMO_OP_CONV) st = himo_conv2d(&ops[i].conv, stream);
         else if (ops[i].kind == HIMO_OP_UPSAMPLE2X)
-            st = himo_upsample2x_batch(ops[i].up_n > 1 ? ops[i].up_n : 1, ops[i].up_x, ops[i].up_x_batch_stride, ops[i].up_x_pitch, ops[i].up_h,
-                                       ops[i].up_w, ops[i].up_c, ops[i].up_y, ops[i].up_y_batch_stride, ops[i].up_y_pitch, stream);
+            st = himo_upsample2x_batch_ex(ops[i].up_n > 1 ? ops[i].up_n : 1, ops[i].up_x, ops[i].up_x_batch_stride, ops[i].up_x_pitch, ops[i].up_h,
+                                          ops[i].up_w, ops[i].up_c, ops[i].up_y, ops[i].up_y_batch_stride, ops[i].up_y_pitch,
+                                          ops[i].up_out_split, stream);
         else st = HIMO_ERR_INVALID_ARGUMENT;
         if (st != HIMO_OK) return st;
     }

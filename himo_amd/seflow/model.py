@@ -54,12 +54,14 @@ _lib.register({
                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "himo_upsample2x_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "himo_upsample2x_batch_ex": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "himo_conv_pack_weights_ex": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                  ctypes.c_void_p]),
     "himo_gru_head": (ctypes.c_int, [ctypes.c_int64] + [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
                       + [ctypes.c_void_p] * 12 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "himo_gru_head_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 10
-                            + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+                            + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "himo_head_gather": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
@@ -88,13 +90,17 @@ class HimoOp(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("conv", ConvDesc),
                 ("up_x", ctypes.c_void_p), ("up_x_pitch", ctypes.c_int), ("up_h", ctypes.c_int), ("up_w", ctypes.c_int),
                 ("up_c", ctypes.c_int), ("up_y", ctypes.c_void_p), ("up_y_pitch", ctypes.c_int),
-                ("up_n", ctypes.c_int), ("up_x_batch_stride", ctypes.c_int64), ("up_y_batch_stride", ctypes.c_int64)]
+                ("up_n", ctypes.c_int), ("up_x_batch_stride", ctypes.c_int64), ("up_y_batch_stride", ctypes.c_int64),
+                ("up_out_split", ctypes.c_int)]
 
 
 _lib.register({
     "himo_pillarize_multi": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t,
                                             ctypes.c_void_p]),
+    "himo_pillarize_multi_ex": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t,
+                                               ctypes.c_int, ctypes.c_void_p]),
     "himo_run_ops": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_void_p]),
     "himo_ops_release": (None, [ctypes.c_void_p]),
 })
@@ -131,8 +137,9 @@ class SeFlowNet:
         self._recording = None
         self._nb = 1                                  # samples the backbone currently runs over
         self.packed_format = 1 if precision == "f16x2" else 0
-        # fp16 split: maps that only travel between two 3x3 layers are stored already split (csrc/convsg.hip); results
-        # are bit-identical either way.  False keeps every activation buffer float32 (the training pass reads them)
+        # fp16 split: every map of the backbone (pillar images, encoder / decoder maps; not the decoder output the head
+        # gathers) is stored already split -- fp16 pairs in place of floats, csrc/convsg.hip -- and staged by LDS-DMA;
+        # results are bit-identical either way.  False keeps every activation buffer float32 (the training pass reads them)
         self.split_acts = precision == "f16x2"
         self.tiles = {}
         self.lib = _lib.load()
@@ -260,8 +267,10 @@ class SeFlowNet:
         best, best_t = 0, float("inf")
         stream = _lib.stream_handle()
         cands = [(bn << 4) | mi for bn in (128, 64) if not (bn == 128 and d.cout % 128) for mi in (2, 1)]
-        if d.act_layout:
-            cands = []                                    # split activation format: only the weights-from-L2 structures
+        if d.act_layout:                                  # split activation format: only the weights-from-L2 structures
+            if d.stride == 2 and (d.act_layout & ACT_SPLIT_IN):
+                return 0                                  # one variant
+            cands = [0x1000 | 4, 0x1000 | 2, 0x1000 | 1] if d.ksize == 1 else []
         if d.w_packed and d.ksize == 3:
             cands += [0x1000 | 4, 0x1000 | 2, 0x1000 | 1] if d.stride == 1 else [0x1000 | 2, 0x1000 | 1]   # weights-from-L2 structure (csrc/convsp.hip)
         for hint in cands:
@@ -279,19 +288,17 @@ class SeFlowNet:
                 best, best_t = d.tile_hint, t
         return best
 
-    def _up(self, x, x_pitch, h, w, c, y, y_pitch):
+    def _up(self, x, x_pitch, h, w, c, y, y_pitch, out_split=False):
         nb = self._nb
+        osp = 1 if (out_split and self.split_acts) else 0
         if self._recording is not None:
             op = HimoOp(); op.kind = 1
             op.up_x, op.up_x_pitch, op.up_h, op.up_w, op.up_c, op.up_y, op.up_y_pitch = x.data_ptr(), x_pitch, h, w, c, y.data_ptr(), y_pitch
             op.up_n, op.up_x_batch_stride, op.up_y_batch_stride = nb, x.stride(0), y.stride(0)
+            op.up_out_split = osp
             self._recording.append(op)
-        if nb > 1:
-            _lib.check(self.lib.himo_upsample2x_batch(nb, x.data_ptr(), x.stride(0), x_pitch, h, w, c, y.data_ptr(), y.stride(0), y_pitch,
-                                                      _lib.stream_handle()), "himo_upsample2x_batch")
-            return
-        _lib.check(self.lib.himo_upsample2x(x.data_ptr(), x_pitch, h, w, c, y.data_ptr(), y_pitch, _lib.stream_handle()),
-                   "himo_upsample2x")
+        _lib.check(self.lib.himo_upsample2x_batch_ex(nb, x.data_ptr(), x.stride(0) if nb > 1 else 0, x_pitch, h, w, c, y.data_ptr(),
+                                                     y.stride(0) if nb > 1 else 0, y_pitch, osp, _lib.stream_handle()), "himo_upsample2x_batch_ex")
 
     # ---- stages ---------------------------------------------------------------------------------------
     def backbone(self, n_samples: int = 1):
@@ -341,8 +348,8 @@ class SeFlowNet:
                 last = i == n_conv - 1
                 dst = catbuf if last else pingpong[i % 2]
                 dst_bs, dst_pitch = (cout, cout * F) if last else (ho * wo * cout, cout)
-                # the ping-pong maps between two 3x3 layers travel in the split activation format (csrc/convsg.hip)
-                act = (0 if i == 0 else ACT_SPLIT_IN) | (0 if last else ACT_SPLIT_OUT)
+                # with split_acts every map of the backbone travels in the split activation format (csrc/convsg.hip)
+                act = ACT_SPLIT_IN | ACT_SPLIT_OUT
                 if i == 0:
                     self._conv(src, src_bs, src_pitch, name, dst, dst_bs, dst_pitch, F, h, w, cin, cout, 3, 2,
                                EPI_BIAS_BN_GELU, scale=p[f"{name}.scale"], shift=p[f"{name}.shift"], act=act)
@@ -354,18 +361,20 @@ class SeFlowNet:
     def decoder(self):
         """B0, F1, F2, F3 -> DEC; every intermediate keeps its own buffer (the training backward pass reads them)."""
         H, W, F = self.H, self.W, self.F
-        def block(name, coarse, c_in, ch, cw, tmp, cat, skip, skip_c, lat, out, work, out_split=False):
-            self._conv(coarse, 0, c_in, f"{name}.u1", tmp, 0, lat, 1, 1, ch * cw, c_in, lat, 1, 1, EPI_BIAS)
-            self._up(tmp, lat, ch, cw, lat, cat, 2 * lat)
-            self._conv(skip, 0, skip_c, f"{name}.u3", cat, 0, 2 * lat, 1, 1, 4 * ch * cw, skip_c, lat, 1, 1, EPI_BIAS, y_off=lat)
-            self._conv(cat, 0, 2 * lat, f"{name}.u4", work[0], 0, out, 1, 2 * ch, 2 * cw, 2 * lat, out, 3, 1, EPI_BIAS, act=ACT_SPLIT_OUT)
-            self._conv(work[0], 0, out, f"{name}.u5", work[1], 0, out, 1, 2 * ch, 2 * cw, out, out, 3, 1, EPI_BIAS,
-                       act=ACT_SPLIT_IN | (ACT_SPLIT_OUT if out_split else 0))
+        IN, IO = ACT_SPLIT_IN, ACT_SPLIT_IN | ACT_SPLIT_OUT
+        def block(name, coarse, c_in, ch, cw, tmp, cat, skip, skip_c, lat, out, work):
+            # the 1x1 output that feeds the bilinear upsampling stays float32 (the interpolation reads float32); its result
+            # and everything else is written split
+            self._conv(coarse, 0, c_in, f"{name}.u1", tmp, 0, lat, 1, 1, ch * cw, c_in, lat, 1, 1, EPI_BIAS, act=IN)
+            self._up(tmp, lat, ch, cw, lat, cat, 2 * lat, out_split=True)
+            self._conv(skip, 0, skip_c, f"{name}.u3", cat, 0, 2 * lat, 1, 1, 4 * ch * cw, skip_c, lat, 1, 1, EPI_BIAS, y_off=lat, act=IO)
+            self._conv(cat, 0, 2 * lat, f"{name}.u4", work[0], 0, out, 1, 2 * ch, 2 * cw, 2 * lat, out, 3, 1, EPI_BIAS, act=IO)
+            self._conv(work[0], 0, out, f"{name}.u5", work[1], 0, out, 1, 2 * ch, 2 * cw, out, out, 3, 1, EPI_BIAS, act=IO)
             return work[1]
         s = block("dec1", self.F3, 256 * F, H // 8, W // 8, self.T1, self.CAT1, self.F2, 128 * F, 256, 256, self.S)
         t = block("dec2", s, 256, H // 4, W // 4, self.T2, self.CAT2, self.F1, 64 * F, 128, 128, self.T)
-        u = block("dec3", t, 128, H // 2, W // 2, self.T3, self.CAT3, self.B0, 32 * F, 64, 64, self.U, out_split=True)   # only dec4 reads it
-        self._conv(u, 0, 64, "dec4", self.DEC, 0, 64, 1, H, W, 64, 64, 3, 1, EPI_BIAS, act=ACT_SPLIT_IN)
+        u = block("dec3", t, 128, H // 2, W // 2, self.T3, self.CAT3, self.B0, 32 * F, 64, 64, self.U)
+        self._conv(u, 0, 64, "dec4", self.DEC, 0, 64, 1, H, W, 64, 64, 3, 1, EPI_BIAS, act=IN)      # DEC stays float32: the head gathers it
         return self.DEC
 
     def head(self, pc0: torch.Tensor, slot0: int = 1, slot1: int = 2, out: torch.Tensor | None = None) -> torch.Tensor:
@@ -377,18 +386,10 @@ class SeFlowNet:
             flow = out if out is not None else torch.empty((n, 3), dtype=torch.float32, device=self.device)
             if flow.shape != (n, 3) or flow.dtype != torch.float32 or not flow.is_contiguous():
                 raise ValueError("out must be a contiguous (N0,3) float32 tensor")
-            pk = self.packed
-            st = self.lib.himo_gru_head(n, self.pid[slot0].data_ptr(), self.offsets[slot0].data_ptr(),
-                                        B0.data_ptr() + 4 * 32 * slot0, B0.data_ptr() + 4 * 32 * slot1, 32 * F,
-                                        DEC.data_ptr(), 64, p["head.offset.weight"].data_ptr(), p["head.offset.bias"].data_ptr(),
-                                        pk["head.gru.zr.weight"].data_ptr(), p["head.gru.zr.bias"].data_ptr(),
-                                        pk["head.gru.q.weight"].data_ptr(), p["head.gru.q.bias"].data_ptr(),
-                                        pk["head.dec1.weight"].data_ptr(), p["head.dec1.bias"].data_ptr(),
-                                        p["head.dec2.weight"].data_ptr(), p["head.dec2.bias"].data_ptr(),
-                                        self.xyz_t[slot0].data_ptr(), pc0.data_ptr(), pc0.shape[1], flow.data_ptr(),
-                                        spec.GRU_ITERS, self.packed_format, _lib.stream_handle())
-            _lib.check(st, "himo_gru_head")
+            self.head_batch([pc0], [flow], slot0, slot1, samples=[self._sample])
             return flow
+        if self.split_acts:
+            raise RuntimeError("the multi-launch head reads float32 pillar images: set split_acts = False (or use the fused head)")
         st = self.lib.himo_head_gather(n, self.pid[slot0].data_ptr(), self.offsets[slot0].data_ptr(),
                                        B0.data_ptr() + 4 * 32 * slot0, B0.data_ptr() + 4 * 32 * slot1, 32 * F,
                                        DEC.data_ptr(), 64, p["head.offset.weight"].data_ptr(),
@@ -446,14 +447,17 @@ class SeFlowNet:
 
     MAX_HEAD_SAMPLES = 16                 # kGhMaxSamples of csrc/gruhead.hip
 
-    def head_batch(self, pc0s, outs, slot0: int = 1, slot1: int = 2) -> None:
-        """The fused head (csrc/gruhead.hip) over samples 0..len(pc0s)-1 of the activation buffers in ONE launch."""
+    def head_batch(self, pc0s, outs, slot0: int = 1, slot1: int = 2, samples=None) -> None:
+        """The fused head (csrc/gruhead.hip) over samples ``samples`` (default 0..len(pc0s)-1) of the activation buffers
+        in ONE launch."""
         p, pk, F = self.p, self.packed, self.F
+        samples = list(range(len(pc0s))) if samples is None else list(samples)
         for lo in range(0, len(pc0s), self.MAX_HEAD_SAMPLES):
             grp = range(lo, min(lo + self.MAX_HEAD_SAMPLES, len(pc0s)))
             arr = (HimoHeadSample * len(grp))()
-            for j, k in enumerate(grp):
-                pc0, flow, st = pc0s[k], outs[k], self._pt[k]
+            for j, i in enumerate(grp):
+                k = samples[i]
+                pc0, flow, st = pc0s[i], outs[i], self._pt[k]
                 n = pc0.shape[0]
                 if flow.shape != (n, 3) or flow.dtype != torch.float32 or not flow.is_contiguous():
                     raise ValueError("out must be a contiguous (N0,3) float32 tensor")
@@ -468,7 +472,7 @@ class SeFlowNet:
                                               pk["head.gru.q.weight"].data_ptr(), p["head.gru.q.bias"].data_ptr(),
                                               pk["head.dec1.weight"].data_ptr(), p["head.dec1.bias"].data_ptr(),
                                               p["head.dec2.weight"].data_ptr(), p["head.dec2.bias"].data_ptr(),
-                                              spec.GRU_ITERS, self.packed_format, _lib.stream_handle())
+                                              spec.GRU_ITERS, self.packed_format, 1 if self.split_acts else 0, _lib.stream_handle())
             _lib.check(st, "himo_gru_head_batch")
 
     def pillarize_all(self, sweeps, transforms):
@@ -495,24 +499,28 @@ class SeFlowNet:
                     w.d_xyz_t, w.d_pid, w.d_offsets = st["xyz_t"][slot].data_ptr(), st["pid"][slot].data_ptr(), st["offsets"][slot].data_ptr()
                     w.d_image = self.B0[sample].data_ptr() + 4 * 32 * slot
                     w.d_workspace = st["ws_slots"][slot].data_ptr()
-            status = self.lib.himo_pillarize_multi(len(arr), ctypes.addressof(arr), self._range, self._voxel, self._centre, self.W, self.H,
-                                                   self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
-                                                   self.p["pfn.shift"].data_ptr(), 32 * self.F, self._pt[0]["ws_slots"][0].numel(),
-                                                   _lib.stream_handle())
-            _lib.check(status, "himo_pillarize_multi")
+            status = self.lib.himo_pillarize_multi_ex(len(arr), ctypes.addressof(arr), self._range, self._voxel, self._centre, self.W, self.H,
+                                                      self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
+                                                      self.p["pfn.shift"].data_ptr(), 32 * self.F, self._pt[0]["ws_slots"][0].numel(),
+                                                      1 if self.split_acts else 0, _lib.stream_handle())
+            _lib.check(status, "himo_pillarize_multi_ex")
 
     def pillarize_into(self, slot: int, pts: torch.Tensor, transform):
         """Sweep -> channel group ``slot`` of B0 (pitch 96)."""
         n = pts.shape[0]
         self._reserve_points(n)
-        T = _f32x(np.asarray(transform, dtype=np.float32).reshape(-1))
-        ws = self.ws_slots[slot]
-        st = self.lib.himo_pillarize(n, pts.data_ptr(), pts.shape[1], T, self._range, self._voxel, self._centre,
-                                     self.W, self.H, self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
-                                     self.p["pfn.shift"].data_ptr(), self.xyz_t[slot].data_ptr(), self.pid[slot].data_ptr(),
-                                     self.offsets[slot].data_ptr(), self.B0[self._sample].data_ptr() + 4 * 32 * slot, 32 * self.F,
-                                     ws.data_ptr(), ws.numel(), _lib.stream_handle())
-        _lib.check(st, "himo_pillarize")
+        arr = (HimoSweep * 1)()
+        w = arr[0]
+        w.n, w.d_pts, w.pc_stride = n, pts.data_ptr(), pts.shape[1]
+        w.transform = _f32x(np.asarray(transform, dtype=np.float32).reshape(-1))
+        w.d_xyz_t, w.d_pid, w.d_offsets = self.xyz_t[slot].data_ptr(), self.pid[slot].data_ptr(), self.offsets[slot].data_ptr()
+        w.d_image = self.B0[self._sample].data_ptr() + 4 * 32 * slot
+        w.d_workspace = self.ws_slots[slot].data_ptr()
+        st = self.lib.himo_pillarize_multi_ex(1, ctypes.addressof(arr), self._range, self._voxel, self._centre, self.W, self.H,
+                                              self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
+                                              self.p["pfn.shift"].data_ptr(), 32 * self.F, self.ws_slots[slot].numel(),
+                                              1 if self.split_acts else 0, _lib.stream_handle())
+        _lib.check(st, "himo_pillarize_multi_ex")
 
 
 # ---- stand-alone operators (tests / experiments): the same kernels on caller-provided tensors -------------------

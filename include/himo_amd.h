@@ -227,6 +227,12 @@ int himo_pillarize_multi(int n_sweeps, const himo_sweep* h_sweeps, const float* 
                          const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight,
                          const float* d_pfn_scale, const float* d_pfn_shift, int image_pitch, size_t workspace_bytes,
                          void* stream);
+/* image_split != 0: each sweep's 32 image channels are written in the split activation format (himo_conv_desc.act_layout;
+ * image_pitch a multiple of 16 floats, d_image 64-byte aligned); empty cells are zero either way */
+int himo_pillarize_multi_ex(int n_sweeps, const himo_sweep* h_sweeps, const float* h_range, const float* h_voxel,
+                         const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight,
+                         const float* d_pfn_scale, const float* d_pfn_shift, int image_pitch, size_t workspace_bytes, int image_split,
+                         void* stream);
 
 /* NHWC float32 convolution (ksize 3 pad 1 stride 1|2, or ksize 1) / row GEMM on v_mfma_f32_32x32x2_f32
  * with a fused epilogue. */
@@ -281,6 +287,9 @@ int himo_conv_pack_weights_ex(const float* d_w, int ksize, int cin, int cout, in
 int himo_upsample2x(const float* d_x, int x_pitch, int h, int w, int c, float* d_y, int y_pitch, void* stream);
 int himo_upsample2x_batch(int n, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int c, float* d_y,
                           int64_t y_batch_stride, int y_pitch, void* stream);
+/* out_split != 0: y in the split activation format (himo_conv_desc.act_layout; c, y_pitch multiples of 16, d_y 64-byte aligned) */
+int himo_upsample2x_batch_ex(int n, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int c, float* d_y,
+                             int64_t y_batch_stride, int y_pitch, int out_split, void* stream);
 
 /* A prepared operator list (the static part of a forward pass: fixed buffers, shapes, weights) run from one call.
  * With HIMO_OPS_GRAPH the list is captured once into a hipGraph, keyed by the h_ops address and validated by a hash of
@@ -296,6 +305,7 @@ typedef struct himo_op {
     const float* up_x; int up_x_pitch, up_h, up_w, up_c;   /* HIMO_OP_UPSAMPLE2X: the arguments of himo_upsample2x_batch */
     float* up_y; int up_y_pitch;
     int up_n; int64_t up_x_batch_stride, up_y_batch_stride; /* up_n 0 | 1: one image */
+    int up_out_split;                                       /* himo_upsample2x_batch_ex's out_split */
 } himo_op;
 int himo_run_ops(const himo_op* h_ops, int n_ops, unsigned flags, void* stream);
 void himo_ops_release(const himo_op* h_ops);
@@ -312,7 +322,9 @@ int himo_gru_head(int64_t n, const int32_t* d_pid, const float* d_offsets, const
                   const float* d_xyz_t, const float* d_pts, int pc_stride, float* d_flow, int iters, int packed_format,
                   void* stream);
 /* The same over several samples in ONE launch (a sample's ~1900 blocks are 2.4 rounds on 256 CUs: per-sample launches
- * each end in a half-empty round).  Up to 16 samples; samples with n == 0 are skipped; weights shared. */
+ * each end in a half-empty round).  Up to 16 samples; samples with n == 0 are skipped; weights shared.
+ * img_split != 0 (packed_format 1 only): d_img0 / d_img1 rows are in the split activation format.  With packed_format 1
+ * an image feature enters the head as its two-term fp16 value h + l in either layout, so both give the same bits. */
 typedef struct himo_head_sample {
     int64_t n;
     const int32_t* d_pid; const float* d_offsets; const float* d_img0; const float* d_img1; const float* d_dec;
@@ -322,7 +334,7 @@ int himo_gru_head_batch(int n_samples, const himo_head_sample* h_samples, int im
                         const float* d_w_off, const float* d_b_off,
                         const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
                         const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
-                        int iters, int packed_format, void* stream);
+                        int iters, int packed_format, int img_split, void* stream);
 /* per-point head glue: hx[i] = [img0[cell], img1[cell], dec[cell], Linear(3,64)(offset)] (192 floats; zeros for
  * dropped points), rhx[i][128:192] = the same Linear output */
 int himo_head_gather(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0,

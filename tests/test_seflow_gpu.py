@@ -193,6 +193,47 @@ def test_split_activation_format_is_bit_identical(gpu):
                 ((n, h, w, c0, c1, c2, s0), hex(hint))
 
 
+def test_split_activation_format_stride2_1x1_and_upsampling(gpu):
+    """The other consumers / producers of split maps: the stride-2 3x3 kernel (de-interleaving DMA gather), the 1x1 row GEMM
+    (convsg.hip) and the bilinear upsampling's split output -- each bit-identical to its float32-activation twin."""
+    from himo_amd import _lib
+    from himo_amd.seflow.model import conv2d_nhwc, ACT_SPLIT_IN, ACT_SPLIT_OUT
+    g = torch.Generator().manual_seed(29)
+    rnd = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(gpu)
+    split_of = lambda t: t.half().float() + (t - t.half().float()).half().float()
+    for (n, h, w, c0, c1, c2) in [(2, 37, 45, 32, 96, 64), (1, 64, 64, 16, 48, 128), (2, 61, 67, 32, 192, 256), (1, 1, 1, 16, 16, 16),
+                                  (1, 2, 66, 16, 16, 32)]:
+        x = rnd(n, h, w, c0)
+        w0, b0 = rnd(3, 3, c0, c1, k=0.05), rnd(c1, k=0.1)
+        w3, b3 = rnd(3, 3, c1, c2, k=0.05), rnd(c2, k=0.1)
+        w1, b1 = rnd(1, 1, c1, c2, k=0.05), rnd(c2, k=0.1)
+        sc, sh = (torch.rand(c2, generator=g) + 0.5).to(gpu), rnd(c2, k=0.1)
+        mid_r = conv2d_nhwc(x, w0, b0, precision="f16x2")
+        mid_s = conv2d_nhwc(x, w0, b0, precision="f16x2", act_layout=ACT_SPLIT_OUT)
+        kw = dict(stride=2, epilogue=1, scale=sc, shift=sh, precision="f16x2")
+        ref = conv2d_nhwc(mid_r, w3, b3, **kw)
+        assert torch.equal(conv2d_nhwc(mid_s, w3, b3, act_layout=ACT_SPLIT_IN, **kw), ref), ("stride 2", n, h, w, c1, c2)
+        assert torch.equal(_decode_split(conv2d_nhwc(mid_s, w3, b3, act_layout=ACT_SPLIT_IN | ACT_SPLIT_OUT, **kw)), split_of(ref))
+        ref = conv2d_nhwc(mid_r, w1, b1, precision="f16x2")
+        for hint in (0, 0x1004, 0x1002, 0x1001):
+            assert torch.equal(conv2d_nhwc(mid_s, w1, b1, precision="f16x2", act_layout=ACT_SPLIT_IN, tile_hint=hint), ref), ("1x1", hex(hint))
+            got = conv2d_nhwc(mid_s, w1, b1, precision="f16x2", act_layout=ACT_SPLIT_IN | ACT_SPLIT_OUT, tile_hint=hint)
+            assert torch.equal(_decode_split(got), split_of(ref))
+    # upsampling: float32 in, split out, into a channel group of a wider buffer
+    lib = _lib.load()
+    for (n, h, w, c, pitch, off) in [(2, 5, 7, 32, 64, 32), (1, 1, 1, 16, 16, 0), (3, 16, 9, 48, 112, 64)]:
+        x = rnd(n, h, w, c)
+        yr = torch.zeros(n, 2 * h, 2 * w, pitch, device=gpu)
+        ys = torch.zeros_like(yr)
+        for y, osp in ((yr, 0), (ys, 1)):
+            _lib.check(lib.himo_upsample2x_batch_ex(n, x.data_ptr(), h * w * c, c, h, w, c, y.data_ptr() + 4 * off, 4 * h * w * pitch, pitch,
+                                                    osp, _lib.stream_handle()), "upsample")
+        assert torch.equal(_decode_split(ys[..., off:off + c].contiguous()), split_of(yr[..., off:off + c]))
+        assert torch.equal(ys[..., :off], yr[..., :off]) and torch.equal(ys[..., off + c:], yr[..., off + c:])
+    with pytest.raises(ValueError):              # whole 16-channel groups only
+        _lib.check(lib.himo_upsample2x_batch_ex(1, x.data_ptr(), 0, 24, 4, 4, 24, yr.data_ptr(), 0, 24, 1, _lib.stream_handle()), "upsample")
+
+
 def test_split_activation_format_rejects_what_it_does_not_cover(gpu):
     from himo_amd import _lib
     from himo_amd.seflow.model import conv2d_nhwc, ACT_SPLIT_IN, ACT_SPLIT_OUT
@@ -201,7 +242,7 @@ def test_split_activation_format_rejects_what_it_does_not_cover(gpu):
     for kwargs in (dict(weight=w3, precision="bf16x3", act_layout=ACT_SPLIT_OUT),      # fp16 split only
                    dict(weight=w3, precision="f32", act_layout=ACT_SPLIT_IN),
                    dict(weight=w1, precision="f16x2", act_layout=ACT_SPLIT_OUT),       # 3x3 only
-                   dict(weight=w3, precision="f16x2", act_layout=ACT_SPLIT_IN, stride=2),
+                   dict(weight=w1, precision="bf16x3", act_layout=ACT_SPLIT_IN),
                    dict(weight=w3, precision="f16x2", act_layout=ACT_SPLIT_IN, epilogue=2),
                    dict(weight=w3, precision="f16x2", act_layout=4)):
         weight = kwargs.pop("weight")
