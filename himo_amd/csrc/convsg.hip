@@ -39,7 +39,7 @@ __device__ inline void glds16(const void* gsrc, unsigned lds_dst) {
 // columns 2 li + kx) are again 32 consecutive slots for every tap (kx = 0: li, 1: 48 + li, 2: li + 1).  The gather costs
 // nothing: every DMA lane has its own source address anyway.
 template <int EPI, int PH, int MI, bool OSPLIT, int S>
-__global__ __launch_bounds__(256, S == 2 ? 3 : 4)
+__global__ __launch_bounds__(256, (S == 2 || MI == 4) ? 3 : 4)
 void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int TW = 32, TH = MI * PH, PHt = S == 1 ? TH + 2 : 2 * TH + 1, PWP = S == 1 ? 48 : 80, UPR = PWP / 16;
     constexpr int kRow = PWP * 64, kBuf = PHt * kRow;
@@ -94,11 +94,16 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
 
+    // weight fragments: uniform base + 32-bit offsets (the packed weights are a few MB): one scalar multiply-add for the
+    // (tap, slab) block and one vector add per load
     const int co_ld = co_ok ? co : a.Cout - 1;
+    const unsigned char* __restrict__ wb = reinterpret_cast<const unsigned char*>(wpk);
+    const unsigned b_lane = (unsigned)co_ld * 32u + (unsigned)lh * 16u;
+    const unsigned b_plane = (unsigned)a.Cout * 32u, b_block = 2u * b_plane;          // bytes per plane, per (tap, slab)
     auto load_b = [&](int tap, int slab, uint4 (&b)[2]) {
-        const unsigned short* base = wpk + (((int64_t)tap * slabs + slab) * 2) * a.Cout * 16 + (int64_t)co_ld * 16 + lh * 8;
-        b[0] = *reinterpret_cast<const uint4*>(base);
-        b[1] = *reinterpret_cast<const uint4*>(base + (int64_t)a.Cout * 16);
+        const unsigned off = (unsigned)(tap * slabs + slab) * b_block + b_lane;
+        b[0] = *reinterpret_cast<const uint4*>(wb + off);
+        b[1] = *reinterpret_cast<const uint4*>(wb + (off + b_plane));
     };
 
     // fragment read offsets (buffer 0, kernel row 0, this wave's first image row): [kx][plane]
@@ -150,6 +155,13 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][SA], __builtin_bit_cast(f16x8, bcur[SB]), acc[mi], 0, 0, 0);
                 HIMO_TERM16(1, 0) HIMO_TERM16(0, 1) HIMO_TERM16(0, 0)
 #undef HIMO_TERM16
+#ifndef HIMO_EXP_NOSCHED
+                // this tap's weight prefetch and ALL its activation-fragment reads before its matrix instructions (the
+                // compiler otherwise feeds each MFMA pair from a just-issued ds_read and sinks the prefetch next to its use)
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, MI * 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MI * 3, 0);
+#endif
             }
         }
 #ifndef HIMO_EXP_NOBAR
@@ -239,10 +251,12 @@ void conv1_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
 
     const int co_ld = co_ok ? co : a.Cout - 1;
+    const unsigned char* __restrict__ wb = reinterpret_cast<const unsigned char*>(wpk);
+    const unsigned b_lane = (unsigned)co_ld * 32u + (unsigned)lh * 16u, b_plane = (unsigned)a.Cout * 32u;
     auto load_b = [&](int slab, uint4 (&b)[2]) {
-        const unsigned short* base = wpk + ((int64_t)slab * 2) * a.Cout * 16 + (int64_t)co_ld * 16 + lh * 8;
-        b[0] = *reinterpret_cast<const uint4*>(base);
-        b[1] = *reinterpret_cast<const uint4*>(base + (int64_t)a.Cout * 16);
+        const unsigned off = (unsigned)slab * (2u * b_plane) + b_lane;
+        b[0] = *reinterpret_cast<const uint4*>(wb + off);
+        b[1] = *reinterpret_cast<const uint4*>(wb + (off + b_plane));
     };
     int rd[2];
 #pragma unroll

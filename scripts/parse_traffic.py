@@ -3,7 +3,7 @@
 FETCH_SIZE / WRITE_SIZE are reported in KiB.  Per MI355X_MICROARCH.md section HBM, on gfx950 FETCH_SIZE reports
 exactly half of the bytes of a wide coalesced streaming read, so the read side is doubled; WRITE_SIZE is taken
 as reported (uncalibrated)."""
-import csv, json, sys
+import csv, json, re, sys
 from collections import defaultdict
 from pathlib import Path
 
@@ -11,9 +11,12 @@ root = Path(sys.argv[1])
 FAMILIES = {"compdis_kernel": ("compdis_kernel<",), "frame_prep_kernel": ("frame_prep_kernel",),
             "conv3x3_mfma_kernel": ("conv_mfma_kernel<3, 1,",), "conv3x3s2_mfma_kernel": ("conv_mfma_kernel<3, 2,",),
             "conv1x1_mfma_kernel": ("conv_mfma_kernel<1, 1,",), "pillar_feature_kernel": ("pillar_feature_kernel",),
-            # the 20 stride-1 3x3 layers of a forward in split precision: both kernel structures (autotuned per layer)
-            "conv3x3_split_kernel": ("conv3_split_kernel<", "conv_bf16x3_kernel<3,"),
-            "conv1x1_split_kernel": ("conv_bf16x3_kernel<1,",), "gru_head_kernel": ("gru_head_kernel",)}
+            # the 20 stride-1 3x3 layers of a forward in split precision: every kernel structure (autotuned per layer; the
+            # last template argument of the weights-from-L2 kernels is the stride)
+            "conv3x3_split_kernel": (r"conv3_split_kernel<.*, 1>", "conv_bf16x3_kernel<3,", r"conv3_presplit_kernel<.*, 1>"),
+            "conv3x3s2_split_kernel": (r"conv3_split_kernel<.*, 2>", r"conv3_presplit_kernel<.*, 2>"),
+            "conv1x1_split_kernel": ("conv_bf16x3_kernel<1,", "conv1_presplit_kernel<"), "gru_head_kernel": ("gru_head_kernel",),
+            "upsample2x_kernel": ("upsample2x_kernel",)}
 # each kernel family is read from the workload whose bench configuration is the quoted one
 SOURCE = {"compdis_kernel": "compdis", "frame_prep_kernel": "compdis"}
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -27,7 +30,7 @@ for d in sorted(root.glob("*_*_SIZE")):
                     continue
                 name = row.get("Kernel_Name", "")
                 for fam, pats in FAMILIES.items():
-                    if any(pat in name for pat in pats) and SOURCE.get(fam, "pipeline") == workload:
+                    if any(re.search(pat, name) for pat in pats) and SOURCE.get(fam, "pipeline") == workload:
                         a = acc[fam][counter]
                         a[0] += float(row["Counter_Value"]); a[1] += 1
 out = {}

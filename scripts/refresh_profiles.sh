@@ -1,0 +1,29 @@
+#!/bin/bash
+# Regenerates everything under profiles/ for one round (run on the MI355X box from the repo root, via gpurun):
+#   bash scripts/refresh_profiles.sh r01
+# Outputs land in gpurun_out/profiles_<round>/ (gpurun merges that back); copy them into profiles/ afterwards.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+RN=${1:-r01}
+OUT=$R/gpurun_out/profiles_$RN
+mkdir -p $OUT
+cd $R
+bash scripts/collect_traffic.sh > $OUT/traffic.log 2>&1            # PMC passes first: bench.py reads profiles/traffic_latest.json
+cp gpurun_out/pmc/traffic.json $OUT/traffic_latest.json
+cp $OUT/traffic_latest.json profiles/traffic_latest.json
+python bench.py > $OUT/${RN}_bench_pipeline_n1.json 2> $OUT/pipeline.err
+python bench.py --precision bf16x3 --no-cpu-baseline > $OUT/${RN}_bench_pipeline_n1_bf16x3.json 2>> $OUT/pipeline.err
+python bench.py --float32-activations --no-cpu-baseline > $OUT/${RN}_bench_pipeline_n1_float32_activations.json 2>> $OUT/pipeline.err
+python bench.py --workload compdis > $OUT/${RN}_bench_compdis_n1.json 2> $OUT/compdis.err
+python bench.py --workload train > $OUT/${RN}_bench_train_n1.json 2> $OUT/train.err
+cd /tmp && export TMPDIR=/tmp
+for wl in pipeline compdis train; do
+  ARGS="--workload $wl --no-cpu-baseline"
+  [ $wl = train ] && ARGS="$ARGS --steps 3 --warmup 1"
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$wl -o $wl -- python $R/bench.py $ARGS > $OUT/${RN}_bench_${wl}_n1_under_rocprof.json 2> $OUT/prof_$wl.err
+  f=$(find $OUT/prof_$wl -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $OUT/${RN}_${wl}_rocprofv3_kernel_stats.csv
+  rm -rf $OUT/prof_$wl
+done
+cd $R
+ls -la $OUT
