@@ -245,38 +245,45 @@ struct UpArgs {
     int out_split;  // y in the split activation format (convsg.hip)
 };
 
+// SPLIT = false: float32 output, 4 channels per thread.  SPLIT = true: output in the split activation format, 8 channels per
+// thread -- one 16-byte store of high parts and one of low parts into the pixel's [16 high | 16 low] record.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void upsample2x_kernel(UpArgs a) {
+    constexpr int CPT = SPLIT ? 8 : 4;
     a.x += (int64_t)blockIdx.y * a.x_bs;
     a.y += (int64_t)blockIdx.y * a.y_bs;
-    const int c4 = a.C / 4;
+    const int cq = a.C / CPT;
     const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)(2 * a.H) * (2 * a.W) * c4;
+    const int64_t total = (int64_t)(2 * a.H) * (2 * a.W) * cq;
     if (item >= total) return;
-    const int q = (int)(item % c4);
-    const int64_t pix = item / c4;
+    const int q = (int)(item % cq);
+    const int64_t pix = item / cq;
     const int ox = (int)(pix % (2 * a.W)), oy = (int)(pix / (2 * a.W));
     const float sy = a.ry * (float)oy, sx = a.rx * (float)ox;
     const int y0 = (int)sy, x0 = (int)sx;
     const int y1 = y0 + (y0 < a.H - 1 ? 1 : 0), x1 = x0 + (x0 < a.W - 1 ? 1 : 0);
     const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
     const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-    auto ld = [&](int yy, int xx) { return *reinterpret_cast<const float4*>(a.x + ((int64_t)yy * a.W + xx) * a.x_pitch + q * 4); };
-    const float4 v00 = ld(y0, x0), v01 = ld(y0, x1), v10 = ld(y1, x0), v11 = ld(y1, x1);
-    float4 o;
-    o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
-    o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
-    o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
-    o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
-    if (a.out_split) {          // [16 fp16 high | 16 fp16 low] per 16-channel group: this thread's 4 channels = 8 + 8 bytes
-        unsigned h[4], l[4];
-        split2_rounded(o.x, h[0], l[0]); split2_rounded(o.y, h[1], l[1]);
-        split2_rounded(o.z, h[2], l[2]); split2_rounded(o.w, h[3], l[3]);
-        unsigned char* rec = reinterpret_cast<unsigned char*>(a.y + pix * a.y_pitch + (q >> 2) * 16) + (q & 3) * 8;
-        *reinterpret_cast<uint2*>(rec) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-        *reinterpret_cast<uint2*>(rec + 32) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
-        return;
+    float o[CPT];
+#pragma unroll
+    for (int part = 0; part < CPT / 4; ++part) {
+        auto ld = [&](int yy, int xx) { return *reinterpret_cast<const float4*>(a.x + ((int64_t)yy * a.W + xx) * a.x_pitch + q * CPT + part * 4); };
+        const float4 v00 = ld(y0, x0), v01 = ld(y0, x1), v10 = ld(y1, x0), v11 = ld(y1, x1);
+        o[part * 4 + 0] = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+        o[part * 4 + 1] = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+        o[part * 4 + 2] = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+        o[part * 4 + 3] = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
     }
-    *reinterpret_cast<float4*>(a.y + pix * a.y_pitch + q * 4) = o;
+    if constexpr (SPLIT) {
+        unsigned h[8], l[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) split2_rounded(o[k], h[k], l[k]);
+        unsigned char* rec = reinterpret_cast<unsigned char*>(a.y + pix * a.y_pitch + (q >> 1) * 16) + (q & 1) * 16;
+        *reinterpret_cast<uint4*>(rec) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        *reinterpret_cast<uint4*>(rec + 32) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    } else {
+        *reinterpret_cast<float4*>(a.y + pix * a.y_pitch + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
 }
 
 template <int KS, int S, int BN, int MI>
@@ -388,9 +395,11 @@ extern "C" int himo_upsample2x_batch_ex(int n, const float* d_x, int64_t x_batch
     a.x_bs = x_batch_stride; a.y_bs = y_batch_stride; a.out_split = out_split ? 1 : 0;
     a.ry = h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     a.rx = w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
-    const int64_t total = (int64_t)(2 * h) * (2 * w) * (c / 4);
+    const int64_t total = (int64_t)(2 * h) * (2 * w) * (c / (out_split ? 8 : 4));
     ProfScope ps("upsample2x_kernel", (hipStream_t)stream);
-    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((total + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)((total + 255) / 256), n);
+    if (out_split) hipLaunchKernelGGL(upsample2x_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(upsample2x_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     HIMO_LAUNCH_CHECK("upsample2x_kernel");
     return HIMO_OK;
 }
