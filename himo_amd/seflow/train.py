@@ -104,8 +104,16 @@ class HeadTrainer:
             "dec2.weight": w2, "dec2.bias": b2,
         }
 
-    def __init__(self, params: dict | None = None, device=None, p: dict | None = None, g: dict | None = None):
-        """Either ``params`` (spec dict, copied to the device) or ``p`` / ``g``: device views owned by the caller."""
+    def __init__(self, params: dict | None = None, device=None, p: dict | None = None, g: dict | None = None,
+                 precision: str = "f32"):
+        """Either ``params`` (spec dict, copied to the device) or ``p`` / ``g``: device views owned by the caller.
+        ``precision``: arithmetic of the 192-wide row GEMMs -- "f32" (float32 MFMA), "bf16x3" (split-bf16 forward and
+        backward) or "mixed" (fp16-split forward: the GRU state and gates are O(1); split-bf16 backward).  The weights
+        are re-packed on every call (a few small launches), so the owner may update them freely."""
+        if precision not in ("f32", "bf16x3", "mixed"):
+            raise ValueError(precision)
+        self.fmt_fwd = {"f32": None, "bf16x3": 0, "mixed": 1}[precision]
+        self.fmt_bwd = None if precision == "f32" else 0
         self.lib = _lib.load()
         self.device = device if device is not None else _lib.require_gpu()
         dev = self.device
@@ -135,13 +143,22 @@ class HeadTrainer:
         self.DH, self.DHP, self.DZ, self.DAQ, self.DAZR = buf(n, 128), buf(n, 128), buf(n, 128), buf(n, 128), buf(n, 256)
         self.DX = buf(n, 64)
         self.WT = {k: torch.empty((v.shape[1], v.shape[0]), dtype=torch.float32, device=dev) for k, v in self.p.items() if v.dim() == 2}
+        pk = lambda cin, cout: torch.empty(int(self.lib.himo_conv_packed_weight_bytes(1, cin, cout)), dtype=torch.uint8, device=dev)
+        # split copies of the three wide matrices and of their transposes (dec2 is 32 x 4: stays float32)
+        self.PK = {k: pk(*self.p[f"{k}.weight"].shape) for k in ("zr", "q", "dec1")} if self.fmt_fwd is not None else {}
+        self.PKT = {k: pk(*self.p[f"{k}.weight"].shape[::-1]) for k in ("zr", "q", "dec1")} if self.fmt_bwd is not None else {}
         need = int(self.lib.himo_wgrad_workspace_bytes_ex(n, 192, 256))
         self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
 
-    def _gemm(self, x, w, bias, y, cin, cout, epi=EPI_BIAS):
+    def _pack(self, w, buf, fmt):
+        _lib.check(self.lib.himo_conv_pack_weights_ex(w.data_ptr(), 1, w.shape[0], w.shape[1], fmt, buf.data_ptr(), _lib.stream_handle()), "pack")
+        return buf
+
+    def _gemm(self, x, w, bias, y, cin, cout, epi=EPI_BIAS, packed=None, fmt=0):
         # descriptors are cached per call site (same buffers every step): filling a ConvDesc costs more host time
         # than the launch itself, and a training step makes ~450 launches
-        key = (x.data_ptr(), x.shape[0], x.shape[1], w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), y.shape[1], cin, cout, epi)
+        key = (x.data_ptr(), x.shape[0], x.shape[1], w.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(), y.shape[1], cin, cout, epi,
+               None if packed is None else packed.data_ptr(), fmt)
         d = self._descs.get(key)
         if d is None:
             d = ConvDesc()
@@ -149,6 +166,8 @@ class HeadTrainer:
             d.w = w.data_ptr(); d.bias = None if bias is None else bias.data_ptr()
             d.y = y.data_ptr(); d.y_pitch = y.shape[1]
             d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = 1, 1, x.shape[0], cin, cout, 1, 1, epi
+            if packed is not None:
+                d.w_packed, d.packed_format = packed.data_ptr(), fmt
             if len(self._descs) > 4096:
                 self._descs.clear()
             self._descs[key] = d
@@ -159,15 +178,17 @@ class HeadTrainer:
         n = hx0.shape[0]
         self._reserve(n)
         lib, s, p = self.lib, _lib.stream_handle, self.p
+        ff = self.fmt_fwd
+        pk = {k: self._pack(p[f"{k}.weight"], self.PK[k], ff) for k in self.PK}
         self.HX[0].copy_(hx0)
         for t in range(spec.GRU_ITERS):
-            self._gemm(self.HX[t], p["zr.weight"], p["zr.bias"], self.AZR, 192, 256)
+            self._gemm(self.HX[t], p["zr.weight"], p["zr.bias"], self.AZR, 192, 256, packed=pk.get("zr"), fmt=ff or 0)
             _lib.check(lib.himo_gru_gates_fwd(n, 1, self.AZR.data_ptr(), None, self.HX[t].data_ptr(), self.Z[t].data_ptr(),
                                               self.R[t].data_ptr(), None, self.RHX[t].data_ptr(), s()), "gru_gates_fwd")
-            self._gemm(self.RHX[t], p["q.weight"], p["q.bias"], self.AQ, 192, 128)
+            self._gemm(self.RHX[t], p["q.weight"], p["q.bias"], self.AQ, 192, 128, packed=pk.get("q"), fmt=ff or 0)
             _lib.check(lib.himo_gru_gates_fwd(n, 2, self.AQ.data_ptr(), self.Z[t].data_ptr(), self.HX[t].data_ptr(), None, None,
                                               self.Q[t].data_ptr(), self.HX[t + 1].data_ptr(), s()), "gru_gates_fwd")
-        self._gemm(self.HX[-1], p["dec1.weight"], p["dec1.bias"], self.A1, 192, 32)
+        self._gemm(self.HX[-1], p["dec1.weight"], p["dec1.bias"], self.A1, 192, 32, packed=pk.get("dec1"), fmt=ff or 0)
         _lib.check(lib.himo_affine_gelu_fwd(n, 32, self.A1.data_ptr(), 32, None, None, self.PRE1.data_ptr(), 32, self.Y1.data_ptr(), 32, s()), "gelu_fwd")
         self._gemm(self.Y1, p["dec2.weight"], p["dec2.bias"], self.RES, 32, 4)
         return self.RES
@@ -182,6 +203,11 @@ class HeadTrainer:
         _lib.check(self.lib.himo_transpose(w.data_ptr(), w.shape[0], w.shape[1], self.WT[f"{name}.weight"].data_ptr(), _lib.stream_handle()), "transpose")
         return self.WT[f"{name}.weight"]
 
+    def _transposed_packed(self, name):
+        """(transposed float32 weights, their split-bf16 copy or None) for a data gradient dX = dZ W^T"""
+        wt = self._transposed(name)
+        return wt, (self._pack(wt, self.PKT[name], self.fmt_bwd) if name in self.PKT else None)
+
     def backward(self, dres: torch.Tensor) -> torch.Tensor:
         """dres [n,4] (d loss / d res, column 3 ignored) -> d loss / d hx0 [n,192]; parameter gradients land in ``self.g``."""
         n = self.n
@@ -191,21 +217,22 @@ class HeadTrainer:
         self._gemm(dres, self._transposed("dec2"), None, self.DY1, 4, 32)
         _lib.check(lib.himo_affine_gelu_bwd(n, 32, self.DY1.data_ptr(), 32, self.PRE1.data_ptr(), 32, None, self.DY1.data_ptr(), 32, s()), "gelu_bwd")
         self._wgrad(self.HX[-1], 192, self.DY1, 32, "dec1")
-        self._gemm(self.DY1, self._transposed("dec1"), None, self.DHX, 32, 192)
+        w1_t, w1_p = self._transposed_packed("dec1")
+        self._gemm(self.DY1, w1_t, None, self.DHX, 32, 192, packed=w1_p)
         # split d[h | x] of the last state
         self.DH.copy_(self.DHX[:, :128])
         self.DX.copy_(self.DHX[:, 128:])
-        wq_t, wzr_t = self._transposed("q"), self._transposed("zr")
+        (wq_t, wq_p), (wzr_t, wzr_p) = self._transposed_packed("q"), self._transposed_packed("zr")
         for t in range(spec.GRU_ITERS - 1, -1, -1):
             acc = t != spec.GRU_ITERS - 1
             _lib.check(lib.himo_gru_bwd1(n, self.DH.data_ptr(), self.Z[t].data_ptr(), self.Q[t].data_ptr(), self.HX[t].data_ptr(),
                                          self.DAQ.data_ptr(), self.DZ.data_ptr(), self.DHP.data_ptr(), s()), "gru_bwd1")
             self._wgrad(self.RHX[t], 192, self.DAQ, 128, "q", accumulate=acc)
-            self._gemm(self.DAQ, wq_t, None, self.DRHX, 128, 192)
+            self._gemm(self.DAQ, wq_t, None, self.DRHX, 128, 192, packed=wq_p)
             _lib.check(lib.himo_gru_bwd2(n, self.DRHX.data_ptr(), self.HX[t].data_ptr(), self.Z[t].data_ptr(), self.R[t].data_ptr(),
                                          self.DZ.data_ptr(), self.DHP.data_ptr(), self.DAZR.data_ptr(), self.DX.data_ptr(), s()), "gru_bwd2")
             self._wgrad(self.HX[t], 192, self.DAZR, 256, "zr", accumulate=acc)
-            self._gemm(self.DAZR, wzr_t, None, self.DHX, 256, 192)
+            self._gemm(self.DAZR, wzr_t, None, self.DHX, 256, 192, packed=wzr_p)
             _lib.check(lib.himo_gru_bwd3(n, self.DHX.data_ptr(), self.DHP.data_ptr(), self.DH.data_ptr(), self.DX.data_ptr(), s()), "gru_bwd3")
         out = torch.empty((n, 192), dtype=torch.float32, device=self.device)
         out[:, :128].copy_(self.DH)
@@ -296,7 +323,7 @@ class SeFlowTrainer:
                 net.p[k] = self.p[k]
         hp = {k[5:]: v for k, v in self.p.items() if k.startswith("head.") and not k.startswith("head.offset")}
         hg = {k[5:]: v for k, v in self.g.items() if k.startswith("head.") and not k.startswith("head.offset")}
-        self.head = HeadTrainer(device=dev, p=hp, g=hg)
+        self.head = HeadTrainer(device=dev, p=hp, g=hg, precision=precision)
         self.step_count = 0
         self._descs = {}
         # ---- saved encoder activations: PRE (after BN, before GELU) and Y per layer, frames as the batch
