@@ -183,11 +183,12 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarBatch m) {
         if (full) s_list[__popcll(mask & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
         if (threadIdx.x == 0) s_nlist = __popcll(mask);
     }
-    // zero rows of the empty cells
+    // zero rows of the empty cells: 16 bytes per lane, 8 lanes per 128-byte row, 32 rows per pass
 #pragma unroll
-    for (int i = 0; i < kFeatCells / kCellsPerBlock; ++i) {
-        const int lc = i * kCellsPerBlock + sub;
-        if (cell0 + lc < n_cells && s_beg[lc + 1] == s_beg[lc]) a.image[(int64_t)(cell0 + lc) * a.image_pitch + c] = 0.f;
+    for (int i = 0; i < kFeatCells / 32; ++i) {
+        const int lc = i * 32 + (threadIdx.x >> 3);
+        if (cell0 + lc < n_cells && s_beg[lc + 1] == s_beg[lc])
+            *reinterpret_cast<float4*>(a.image + (int64_t)(cell0 + lc) * a.image_pitch + (threadIdx.x & 7) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     const int nlist = s_nlist;
@@ -410,6 +411,7 @@ static int pillar_args(PillarArgs& a, int64_t n, const float* d_pts, int pc_stri
     if (!d_pfn_weight || !d_pfn_scale || !d_pfn_shift || !d_image || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
     if (n > 0 && (!d_pts || !d_xyz_t || !d_pid || !d_offsets)) return HIMO_ERR_INVALID_ARGUMENT;
     if (n > 0x7fffffff || image_pitch < 32) return HIMO_ERR_UNSUPPORTED;
+    if ((image_pitch & 3) || (reinterpret_cast<uintptr_t>(d_image) & 15)) return HIMO_ERR_UNSUPPORTED;     // 16-byte row stores
     const int cells = grid_w * grid_h;
     if (workspace_bytes < pillar_ws(n, cells) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
     if ((cells + kScanBlock - 1) / kScanBlock > 1024) return HIMO_ERR_UNSUPPORTED;   // grids beyond 1M cells need a third scan level

@@ -203,7 +203,8 @@ int himo_eval_instances(int n_frames, int64_t total_points,
  */
 /* One sweep: rigid transform (h_transform: row-major 4x4 float32), dynamic pillarisation on a
  * grid_w x grid_h grid (h_range = min xyz, h_voxel = cell size, h_centre_offset = voxel/2 + min as
- * float32), pillar feature net Linear(9,32)+BN+ReLU+mean -> 32 floats at d_image[cell * image_pitch] (every cell written).
+ * float32), pillar feature net Linear(9,32)+BN+ReLU+mean -> 32 floats at d_image[cell * image_pitch] (every cell written;
+ * d_image 16-byte aligned, image_pitch a multiple of 4 floats).
  * Also returns the transformed points, each point's cell (-1 = out of range) and its offset to the cell
  * centre. */
 size_t himo_pillar_workspace_bytes(int64_t max_points, int grid_w, int grid_h);
