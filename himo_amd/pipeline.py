@@ -60,6 +60,23 @@ class HiMoPipeline:
         self._key = None
         self._finite = None          # device flag of the previous batch (fp16-split precision only)
 
+    def _upload_small(self, host_bytes: np.ndarray) -> torch.Tensor:
+        """uint8 array -> device, asynchronously, through a ring of pinned blocks (reused once their copy has completed)"""
+        if not hasattr(self, "_pin_ring"):
+            self._pin_ring, self._pin_next = [[torch.empty(1 << 16, dtype=torch.uint8, pin_memory=True), None] for _ in range(4)], 0
+        n = host_bytes.size
+        slot = self._pin_ring[self._pin_next]
+        self._pin_next = (self._pin_next + 1) % len(self._pin_ring)
+        if slot[0].numel() < n:
+            slot[0] = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        elif slot[1] is not None:
+            slot[1].synchronize()
+        np.copyto(slot[0].numpy()[:n], host_bytes)
+        out = slot[0][:n].to(self.device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(self.device))
+        return out
+
     def _batch_for(self, samples) -> FrameBatch:
         """Ragged batch container over the pc0 sweeps of ``samples`` (rebuilt only when the batch changes)."""
         key = tuple(id(s) for s in samples)
@@ -68,10 +85,17 @@ class HiMoPipeline:
             offsets = np.zeros(len(samples) + 1, dtype=np.int64)
             np.cumsum(counts, out=offsets[1:])
             dev = self.device
+            # offsets and poses go up in ONE asynchronous copy from a small pinned ring: a pageable upload would block the
+            # launch thread until the previous batch's kernels have drained (a bubble per batch when batches change)
+            F = len(samples)
+            meta = np.concatenate([offsets.view(np.uint8), np.stack([s.pose0 for s in samples]).astype(np.float64).reshape(-1).view(np.uint8),
+                                   np.stack([s.pose1 for s in samples]).astype(np.float64).reshape(-1).view(np.uint8)])
+            meta_dev = self._upload_small(meta)
+            o_end, p_len = (F + 1) * 8, F * 128
             self._batch = FrameBatch(
-                offsets_host=offsets, offsets=torch.from_numpy(offsets).to(dev),
-                pose0=torch.from_numpy(np.stack([s.pose0 for s in samples])).to(dev),
-                pose1=torch.from_numpy(np.stack([s.pose1 for s in samples])).to(dev),
+                offsets_host=offsets, offsets=meta_dev[:o_end].view(torch.int64),
+                pose0=meta_dev[o_end:o_end + p_len].view(torch.float64).view(F, 4, 4),
+                pose1=meta_dev[o_end + p_len:o_end + 2 * p_len].view(torch.float64).view(F, 4, 4),
                 pc0=torch.cat([s.pc0 for s in samples], dim=0).contiguous(),
                 lidar_dt=torch.cat([s.lidar_dt for s in samples], dim=0).contiguous(),
                 flow=torch.empty((int(offsets[-1]), 3), dtype=torch.float32, device=dev),

@@ -11,6 +11,7 @@ in memory; an h5 sink needs ``h5py`` (not installed here).
 """
 from __future__ import annotations
 
+import os
 from pathlib import Path
 
 import numpy as np
@@ -37,34 +38,13 @@ class NpzResultSink:
         with np.load(path) as z:
             arrays = {k: z[k] for k in z.files}
         arrays[self.res_name] = flow.astype(np.float32)
-        np.savez(path, **arrays)
+        tmp = path.with_name(path.stem + ".writing.npz")       # written aside, then renamed: the feeder thread may be reading
+        np.savez(tmp, **arrays)                                 # this very file as a later frame's history sweep
+        os.replace(tmp, path)
 
 
-def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, sink=None, pipeline: HiMoPipeline | None = None,
-        batch_frames: int = 4) -> int:
-    """Flow for every frame of ``dataset`` that has a ``pc1`` / next sweep.  Returns the frames this rank processed."""
-    import torch
-    import torch.distributed as dist
-    from .seflow.model import SeFlowNet
-    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
-    pipe = pipeline if pipeline is not None else HiMoPipeline(params=params, max_batch=max(1, batch_frames))
-    results = {} if sink is None else None
-    done = 0
-    pending = []                                               # (index, frame, sample): up to batch_frames per network pass
-
-    def flush():
-        nonlocal done
-        if not pending:
-            return
-        for (i, f0, _), flow in zip(pending, pipe.flows([p[2] for p in pending])):
-            flow = flow.cpu().numpy()
-            if sink is None:
-                results[i] = flow
-            else:
-                sink(i, f0, flow)
-            done += 1
-        pending.clear()
-
+def frame_source(dataset, rank: int = 0, world: int = 1):
+    """(index, history frame, frame, next frame | None) for every frame of this rank that has a next sweep to flow into."""
     for i in range(rank, len(dataset), world):
         f0 = dataset[i]
         if "pc1" not in f0:
@@ -73,10 +53,37 @@ def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, si
             f1 = dataset[i + 1]
         else:
             f1 = None
-        pending.append((i, f0, Sample.from_frames(history_of(dataset, i), f0, f1, device=pipe.device)))
-        if len(pending) >= max(1, batch_frames):
-            flush()
-    flush()
+        yield i, history_of(dataset, i), f0, f1
+
+
+def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, sink=None, pipeline: HiMoPipeline | None = None,
+        batch_frames: int = 4) -> int:
+    """Flow for every frame of ``dataset`` that has a ``pc1`` / next sweep.  Returns the frames this rank processed.
+    Frames are read, staged in pinned memory and copied to the device by a background thread two batches ahead of the
+    network (``feeder.SampleFeeder``); results leave through pinned buffers and a writer thread (``feeder.ResultDrain``),
+    so neither the dataset reads nor the sink's file writes stall the launch thread."""
+    import torch.distributed as dist
+    from .feeder import ResultDrain, SampleFeeder
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    pipe = pipeline if pipeline is not None else HiMoPipeline(params=params, max_batch=max(1, batch_frames))
+    results = {} if sink is None else None
+
+    def deliver(key, flow):
+        i, f0 = key
+        if sink is None:
+            results[i] = flow
+        else:
+            sink(i, f0, flow)
+
+    drain = ResultDrain(deliver, device=pipe.device)
+    done = 0
+    try:
+        for batch in SampleFeeder(frame_source(dataset, rank, world), device=pipe.device, batch=max(1, batch_frames)):
+            for (i, f0, _), flow in zip(batch, pipe.flows([s for _, _, s in batch])):
+                drain.put((i, f0), flow)
+                done += 1
+    finally:
+        drain.close()
     return results if sink is None else done
 
 

@@ -125,3 +125,45 @@ def test_batched_backbone_equals_one_sample_at_a_time(gpu):
         got = many.run(samples)["flow"].clone()                 # groups of 4 + 2
         assert torch.equal(got, ref), prec
         assert torch.equal(many.run(samples[:5])["flow"], ref[: sum(s.pc0.shape[0] for s in samples[:5])]), prec      # 4 + 1
+
+
+def test_feeder_and_drain_deliver_the_same_bits_as_the_serial_path(gpu):
+    """feeder.SampleFeeder (pinned staging + side-stream copies, batches ahead) and feeder.ResultDrain (pinned D2H + writer
+    thread) against the serial Sample.from_frames / .cpu() path: same samples, same flows, in order; a failing source or
+    sink surfaces on the caller's thread."""
+    from himo_amd.feeder import ResultDrain, SampleFeeder
+    from himo_amd.pipeline import HiMoPipeline, Sample
+    from himo_amd.synthetic import make_frame
+    frames = [make_frame(90 + i, n_points=5_000 + 700 * i) for i in range(7)]
+    source = [(i, frames[max(i - 1, 0)], frames[i], frames[i + 1]) for i in range(6)]
+    pipe = HiMoPipeline(device=gpu, max_points=12_000, max_batch=4, precision="f16x2")
+    want = {}
+    for i, fh, f0, f1 in source:
+        s = Sample.from_frames(fh, f0, f1, device=gpu)
+        want[i] = pipe.flows([s])[0].cpu().numpy()
+    got, order = {}, []
+    drain = ResultDrain(lambda key, arr: (got.__setitem__(key, arr), order.append(key)), device=gpu)
+    n_batches = 0
+    for batch in SampleFeeder(iter(source), device=gpu, batch=4, depth=2):
+        n_batches += 1
+        for (i, f0, s) in batch:
+            ref = Sample.from_frames(source[i][1], f0, source[i][3], device=gpu)
+            assert torch.equal(s.pc0, ref.pc0) and torch.equal(s.pch1, ref.pch1) and torch.equal(s.pc1, ref.pc1)
+            assert torch.equal(s.lidar_dt, ref.lidar_dt) and np.array_equal(s.pose1, ref.pose1)
+        for (i, _, _), flow in zip(batch, pipe.flows([s for _, _, s in batch])):
+            drain.put(i, flow)
+    drain.close()
+    assert n_batches == 2 and order == list(range(6))
+    for i in want:
+        assert np.array_equal(got[i], want[i]), i
+
+    def bad_source():
+        yield source[0]
+        raise OSError("disk gone")
+    with pytest.raises(OSError):
+        for _ in SampleFeeder(bad_source(), device=gpu, batch=1):
+            pass
+    drain = ResultDrain(lambda key, arr: (_ for _ in ()).throw(ValueError("sink failed")), device=gpu)
+    drain.put(0, torch.zeros(4, device=gpu))
+    with pytest.raises(ValueError):
+        drain.close()
