@@ -167,3 +167,36 @@ def test_feeder_and_drain_deliver_the_same_bits_as_the_serial_path(gpu):
     drain.put(0, torch.zeros(4, device=gpu))
     with pytest.raises(ValueError):
         drain.close()
+
+
+def test_degenerate_sweeps_in_a_batch(gpu):
+    """Sweeps with no points at all (sensor drop-out) and with a single point travel through a batch next to ordinary
+    ones: every sample's result equals what it gets on its own, and empty pc0 sweeps give empty outputs."""
+    from himo_amd.pipeline import HiMoPipeline, Sample
+    from himo_amd.synthetic import make_frame
+    pipe = HiMoPipeline(device=gpu, max_points=9_000, max_batch=4, precision="f16x2")
+    full = [make_frame(120 + i, n_points=6_000 + 500 * i) for i in range(3)]
+    def variant(f, n):
+        g = dict(f)
+        g["pc0"], g["lidar_dt"] = f["pc0"][:n].copy(), f["lidar_dt"][:n].copy()
+        return g
+    cases = [(full[0], full[1], full[2]),                       # ordinary
+             (variant(full[0], 0), full[1], full[2]),            # empty history sweep
+             (full[0], variant(full[1], 0), full[2]),            # empty pc0: nothing to compensate
+             (full[0], full[1], variant(full[2], 0)),            # empty pc1
+             (full[0], variant(full[1], 1), full[2])]            # a single point
+    samples = [Sample.from_frames(fh, f0, f1, device=gpu) for fh, f0, f1 in cases]
+    alone = []
+    for s in samples:
+        out = pipe.run([s])
+        alone.append((out["flow"].clone(), out["comp_dis"].clone()))
+    for lo in (0, 1):
+        grp = samples[lo:lo + 4]
+        out = pipe.run(grp)
+        o = out["batch"].offsets_host
+        for k in range(len(grp)):
+            a, b = int(o[k]), int(o[k + 1])
+            assert b - a == grp[k].pc0.shape[0]
+            assert torch.equal(out["flow"][a:b], alone[lo + k][0]) and torch.equal(out["comp_dis"][a:b], alone[lo + k][1]), (lo, k)
+    pipe.sync_check()
+    assert alone[2][0].shape == (0, 3) and alone[4][0].shape == (1, 3) and torch.isfinite(alone[4][0]).all()
