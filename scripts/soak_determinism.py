@@ -1,0 +1,30 @@
+"""GPU soak: the full-size pipeline (8 x 120k-point samples) run repeatedly on the same inputs must return the same bits
+every time -- a race in the LDS-DMA staging (csrc/convsg.hip: hand-counted s_waitcnt vmcnt) or in the batched head would
+show up here as a differing step.  usage: python scripts/soak_determinism.py [steps]"""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+from himo_amd.pipeline import HiMoPipeline, Sample
+from himo_amd.seflow import spec
+from himo_amd.seflow.model import SeFlowNet
+from himo_amd.synthetic import make_frame
+
+dev = torch.device("cuda", 0)
+B, P, STEPS = 8, 120_000, int(sys.argv[1]) if len(sys.argv) > 1 else 200
+frames = [make_frame(i, n_points=P - 997 * i) for i in range(B + 2)]          # ragged sizes
+samples = [Sample.from_frames(frames[k], frames[k + 1], frames[k + 2], device=dev) for k in range(B)]
+pipe = HiMoPipeline(SeFlowNet(spec.init_params(0), device=dev, max_points=P, precision="f16x2", max_batch=B), device=dev)
+out = pipe.run(samples)
+ref_flow, ref_cd, ref_dec = out["flow"].clone(), out["comp_dis"].clone(), pipe.net.DEC.clone()
+bad = 0
+t0 = time.perf_counter()
+for step in range(STEPS):
+    out = pipe.run(samples)
+    if not (torch.equal(out["flow"], ref_flow) and torch.equal(out["comp_dis"], ref_cd) and torch.equal(pipe.net.DEC, ref_dec)):
+        bad += 1
+        print("step", step, "differs: flow", int((out["flow"] != ref_flow).sum()), "dec", int((pipe.net.DEC != ref_dec).sum()))
+pipe.sync_check()
+torch.cuda.synchronize()
+print(f"{STEPS} steps, {bad} differing, {time.perf_counter() - t0:.1f} s, finite: {bool(torch.isfinite(ref_flow).all())}")
+sys.exit(1 if bad else 0)

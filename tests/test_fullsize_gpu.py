@@ -87,3 +87,23 @@ def test_fused_comp_dis_equals_the_reference_stage_functions_on_the_gpu_flow(run
         got_pts = first["refined"][o:o + n].cpu().numpy()        # stored as float32: one rounding of |x| <= 64
         assert np.abs(got_pts.astype(np.float64) - ref_pts).max() <= 4e-6
         o += n
+
+
+def test_repeated_full_size_batches_never_differ(gpu, samples):
+    """A race in the hand-counted LDS-DMA waits of the split-activation kernels (csrc/convsg.hip) or in the batched head
+    would make some step differ: 25 steps of a 4-sample batch, every output bit and the decoder map equal to step 0
+    (scripts/soak_determinism.py runs the 8-sample / 300-step version)."""
+    from himo_amd.pipeline import HiMoPipeline
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.model import SeFlowNet
+    _, smp = samples
+    batch = [smp[0], smp[1], smp[1], smp[0]]
+    pipe = HiMoPipeline(SeFlowNet(spec.init_params(7), device=gpu, max_points=N, precision="f16x2", max_batch=4), device=gpu)
+    out = pipe.run(batch)
+    flow0, cd0, dec0 = out["flow"].clone(), out["comp_dis"].clone(), pipe.net.DEC.clone()
+    for step in range(25):
+        out = pipe.run(batch)
+        assert torch.equal(out["flow"], flow0) and torch.equal(out["comp_dis"], cd0) and torch.equal(pipe.net.DEC, dec0), step
+    pipe.sync_check()
+    o = out["batch"].offsets_host
+    assert torch.equal(flow0[int(o[0]):int(o[1])], flow0[int(o[3]):int(o[4])])        # same sample twice in the batch: same bits
