@@ -206,7 +206,22 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarBatch m) {
         const float ccx = (float)ix * a.g.vx + a.g.cx0, ccy = (float)iy * a.g.vy + a.g.cy0, ccz = 0.f * a.g.vz + a.g.cz0;
         const float fc = (float)cnt;
         float acc = 0.f;
-        if (cnt <= 32) {
+        if (cnt == 1) {
+            // a single point (the common case on sparse sweeps): no ordering, the mean IS the point, so the three
+            // offset-to-mean features are exactly zero and their products drop out of the sum (fma(0, w, v) == v)
+            const int pj = a.order[beg];
+            const float* p = a.cell_xyz + (int64_t)beg * 3;
+            const float x = p[0], y = p[1], z = p[2];
+            if (c == 0) a.order2[beg] = pj;
+            const float f6[3] = {x - ccx, y - ccy, z - ccz};
+            float v = x * w[0];
+            v = fmaf(y, w[1], v); v = fmaf(z, w[2], v);
+            v = fmaf(x - x, w[3], v); v = fmaf(y - y, w[4], v); v = fmaf(z - z, w[5], v);
+            v = fmaf(f6[0], w[6], v); v = fmaf(f6[1], w[7], v); v = fmaf(f6[2], w[8], v);
+            v = v * scale + shift;
+            acc = 0.f + fmaxf(v, 0.f);
+            if (c < 3) a.offsets[(int64_t)pj * 3 + c] = f6[c];
+        } else if (cnt <= 32) {
             // lane j holds point j of the cell's (scatter-ordered) list; rank by point index, permute into ascending order
             const bool have = c < cnt;
             const int idx = have ? a.order[beg + c] : 0x7fffffff;
