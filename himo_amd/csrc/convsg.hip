@@ -1,12 +1,12 @@
-// convsg.hip -- 3x3 stride-1 convolution on the two-term fp16 split whose INPUT is already split in HBM
-// ("split activation format"), staged global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no
+// convsg.hip -- the convolutions of the fp16-split network (3x3 stride 1, 3x3 stride 2, 1x1) whose INPUT is already split
+// in HBM ("split activation format"), staged global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no
 // conversion work and no ds_write in the consumer.
 //
 // Split activation format: same addressing as float32 NHWC (pixel pitch `x_pitch` floats), but every 16-channel group
 // of a pixel -- 64 bytes -- holds [h0..h15 | l0..l15] (fp16 high parts, fp16 low parts; x = h + l, bf16x3.h) instead of
-// sixteen floats.  The producing layer's epilogue writes it (OSPLIT below, and the stride-2 / 3x3 kernels of convsp.hip),
-// so a value is split ONCE instead of once per consuming block and halo overlap; the numbers that reach the matrix
-// instructions are bit-identical to convsp.hip's.
+// sixteen floats.  The producer writes it -- the epilogues here (OSPLIT) and in convsp.hip, the pillar feature kernel, the
+// upsampling -- so a value is split ONCE instead of once per consuming block and halo overlap; the numbers that reach the
+// matrix instructions are bit-identical to the float32-activation kernels' (convsp.hip / convbf.hip).
 //
 // LDS image of a slab's halo patch: (TH + 2) rows x 48 pixels (34 used) x 64 bytes; the four 16-byte pieces of a pixel
 // (plane s, k-half lh) sit at slot (2 s + lh) ^ ((px >> 2) & 3).  Rows start on 16-pixel boundaries, so the XOR term
@@ -19,7 +19,9 @@
 // Everything else as convsp.hip: a wave owns MI rows x 32 pixels x 32 output channels, weight fragments straight from
 // L2 two taps ahead in three statically rotated register sets, patch double-buffered, ONE barrier per 16-channel slab.
 // The DMA of slab + 1 is issued before the first tap of slab; the in-order vmcnt of the weight loads behind it has
-// retired it by tap 2, the explicit wait before the barrier only documents that.
+// retired it by tap 2, the explicit wait before the barrier only documents that.  Weight fragments are addressed as
+// uniform base + 32-bit lane offset (saddr loads), and each tap's loads and fragment reads are pinned ahead of its matrix
+// instructions (sched_group_barrier): DESIGN.md section 4 has the measurements and the variants that did not pay.
 // Specification / oracle as conv.hip (reference network absent: PARITY UNPINNED).
 #include "conv_common.h"
 #include "bf16x3.h"
