@@ -11,6 +11,9 @@
 // double-buffered -- ONE barrier per slab (9 taps = 108 / 216 matrix instructions per wave).
 //   PH = 1: block = 128 pixels x 128 channels (waves = 4 channel tiles);
 //   PH = 2: block = 256 pixels x  64 channels (waves = 2 pixel groups x 2 channel tiles), for the 64-channel layers.
+// With float32 activations in HBM this is the kernel of every 3x3 layer (bf16 split: always; fp16 split: training, and
+// `SeFlowNet.split_acts = False`); the fp16-split inference network stores its maps already split and runs convsg.hip,
+// which replaces the register staging below by LDS-DMA.  This kernel's epilogue can WRITE that format (kActSplitOut).
 // Specification / oracle as conv.hip (reference network absent: PARITY UNPINNED).
 #include "conv_common.h"
 #include "bf16x3.h"
