@@ -264,7 +264,6 @@ class SeFlowNet:
         GRU ones update state in place, so they keep the library heuristic) and remember the fastest."""
         if d.epilogue in (EPI_GRU_ZR, EPI_GRU_Q):
             return 0
-        best, best_t = 0, float("inf")
         stream = _lib.stream_handle()
         cands = [(bn << 4) | mi for bn in (128, 64) if not (bn == 128 and d.cout % 128) for mi in (2, 1)]
         if d.act_layout:                                  # split activation format: only the weights-from-L2 structures
@@ -273,19 +272,22 @@ class SeFlowNet:
             cands = [0x1000 | 4, 0x1000 | 2, 0x1000 | 1] if d.ksize == 1 else []
         if d.w_packed and d.ksize == 3:
             cands += [0x1000 | 4, 0x1000 | 2, 0x1000 | 1] if d.stride == 1 else [0x1000 | 2, 0x1000 | 1]   # weights-from-L2 structure (csrc/convsp.hip)
-        for hint in cands:
-            d.tile_hint = hint
-            for _ in range(2):
-                self.lib.himo_conv2d(ctypes.byref(d), stream)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                self.lib.himo_conv2d(ctypes.byref(d), stream)
-            e1.record()
-            e1.synchronize()
-            t = e0.elapsed_time(e1)
-            if t < best_t:
-                best, best_t = d.tile_hint, t
+        if len(cands) < 2:
+            return cands[0] if cands else 0
+        times = {hint: float("inf") for hint in cands}
+        for _round in range(2):                           # two interleaved rounds, best of each candidate: the chip's clock
+            for hint in cands:                            # drifts with load, and a one-shot ranking of near-equal tiles flips
+                d.tile_hint = hint
+                for _ in range(2):
+                    self.lib.himo_conv2d(ctypes.byref(d), stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    self.lib.himo_conv2d(ctypes.byref(d), stream)
+                e1.record()
+                e1.synchronize()
+                times[hint] = min(times[hint], e0.elapsed_time(e1))
+        best = min(cands, key=lambda hint: times[hint])
         return best
 
     def _up(self, x, x_pitch, h, w, c, y, y_pitch, out_split=False):
