@@ -60,9 +60,11 @@ def parse_args():
         a.warmup = 2 if a.warmup is None else a.warmup
         a.frames_per_step = 1 if a.frames_per_step is None else a.frames_per_step
     elif a.workload == "pipeline":
-        a.steps = 30 if a.steps is None else a.steps            # 240 frames: ~0.7 s timed, host hiccups average out
+        a.steps = 20 if a.steps is None else a.steps            # 320 frames: ~0.55 s timed, host hiccups average out
         a.warmup = 3 if a.warmup is None else a.warmup
-        a.frames_per_step = 8 if a.frames_per_step is None else a.frames_per_step
+        # 16 samples per backbone launch (16 GB of activation buffers of the 288): +3 % over 8 -- the low-resolution
+        # layers and the batched head get whole rounds of blocks; 24 / 32 add under 1 % more
+        a.frames_per_step = 16 if a.frames_per_step is None else a.frames_per_step
     else:
         a.steps = 50 if a.steps is None else a.steps
         a.warmup = 5 if a.warmup is None else a.warmup
