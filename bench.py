@@ -11,6 +11,11 @@ Workloads (synthetic 120k-point sweeps already resident in HBM when the clock st
                       comp_dis.  A step = one batch of B frames (B network forwards + one fused comp_dis launch).
   compdis             only stages a1-a4 (the part of the path the reference tree contains) over a ragged batch of
                       B sweeps: the HBM-bound kernel on its own.
+  train               BASELINE config 5: the self-supervised training step, data parallel (one flat all-reduce per step).
+``--gpus N`` without a torchrun environment re-launches this file as N ranks (one per GPU) under
+``python -m torch.distributed.run`` on 127.0.0.1; with one (WORLD_SIZE set) it must agree with WORLD_SIZE.
+``--dry-run-cpu`` replaces ONLY the device work by a host stand-in (gloo instead of RCCL): it exists so that the launch,
+barrier, max-over-ranks and gather logic is covered by CPU tests; its numbers mean nothing and the line says so.
 Every rank owns its own frames (frames shard embarrassingly; weak scaling); the only collective is the final
 gather of per-rank counts after the timed region.  Rank 0 prints ONE JSON line that also carries
   "roofline":     dominant kernel: algorithmic flops|bytes per launch / HIP-event-timed launch duration vs peak,
@@ -52,7 +57,18 @@ def parse_args():
                     help="pipeline, f16x2: keep the backbone's maps float32 in HBM instead of the split activation format (A/B switch)")
     ap.add_argument("--refined", action="store_true", help="also write refined points (+12 B/pt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work budget for the baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=40.0,
+                    help="CPU work budget PER LEG (all cores / 1 thread) of the baseline; at least 3 frames are timed per leg")
+    ap.add_argument("--cpu-frames", type=int, default=0,
+                    help="time exactly this many frames per CPU leg after 5 warm-ups (BASELINE.md section 3 asks for >= 50), ignoring --cpu-seconds")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0 = torch's default)")
+    ap.add_argument("--no-extra-precisions", action="store_true",
+                    help="pipeline, N=1: skip the bf16x3 / f32 legs that follow the timed f16x2 region")
+    ap.add_argument("--cloud", default="uniform", choices=["uniform", "rings"],
+                    help="synthetic sweeps: SURVEY 8(d) uniform cloud with instances (default) or the LiDAR-like ring cloud")
+    ap.add_argument("--sample-sets", type=int, default=3, help="distinct input batches rotated through the timed steps")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="CPU test switch: host stand-in for the device work, gloo for RCCL; the reported numbers are meaningless")
     ap.add_argument("--traffic-json", default=str(REPO / "profiles" / "traffic_latest.json"))
     a = ap.parse_args()
     if a.workload == "train":
@@ -109,22 +125,21 @@ def synthetic_batch(n_frames: int, n_points: int, device, seed: int):
                       pc0=pc0, lidar_dt=lidar_dt, flow=flow)
 
 
-def synthetic_samples(n_frames: int, n_points: int, device, seed: int):
-    """B network inputs: history sweep, pc0, pc1 (each n_points x 4), poses, lidar_dt."""
-    import torch
+def synthetic_sample_sets(n_sets: int, n_frames: int, n_points: int, device, seed: int, cloud: str = "uniform"):
+    """``n_sets`` distinct batches of B network inputs.  Every sweep is a ``himo_amd.synthetic.make_frame`` frame (SURVEY.md
+    8(d): seeded by its frame index, ~30 box-shaped moving instances, yaw <= 2 deg + <= 3 m ego motion, lidar_dt U[0,0.1]);
+    sample j of a set is three consecutive frames (history, pc0, pc1) of a sliding window, so a set costs B + 2 frames.
+    Returns (sets of Samples on ``device``, the host frames of set 0's first sample for the parity / CPU legs)."""
     from himo_amd.pipeline import Sample
-    g = torch.Generator(device=device)
-    g.manual_seed(4321 + seed)
-    rng = np.random.default_rng(seed)
-    pose0, pose1 = _poses(n_frames, rng)
-    _, pose_h = _poses(n_frames, rng)
-    out = []
-    for k in range(n_frames):
-        out.append(Sample(_sweep(n_points, g, device), _sweep(n_points, g, device), _sweep(n_points, g, device),
-                          np.linalg.inv(pose_h[k]), pose0[k], pose1[k],
-                          torch.rand(n_points, generator=g, device=device, dtype=torch.float32) * 0.1,
-                          scene_id=f"bench-{seed}", timestamp=k))
-    return out
+    from himo_amd.synthetic import make_frame
+    sets, first = [], None
+    for k in range(n_sets):
+        base = 100_000 * seed + 1_000 * k
+        frames = [make_frame(base + i, n_points=n_points, cloud=cloud) for i in range(n_frames + 2)]
+        if first is None:
+            first = frames
+        sets.append([Sample.from_frames(frames[j], frames[j + 1], frames[j + 2], device=device) for j in range(n_frames)])
+    return sets, first
 
 
 def frame_to_host(batch, k: int) -> dict:
@@ -138,51 +153,78 @@ def frame_to_host(batch, k: int) -> dict:
 # ------------------------------------------------------------------------------------------------------
 # CPU baselines (the oracle is the thing timed here, never the thing shipped)
 # ------------------------------------------------------------------------------------------------------
-def cpu_baseline_compdis(frames: list[dict], budget_s: float) -> dict:
-    """numpy port of save_zip.py:113-121 incl. the f32 cast, single thread."""
+def cpu_baseline_compdis(frames: list[dict], budget_s: float, exact_frames: int = 0) -> dict:
+    """numpy port of save_zip.py:113-121 incl. the f32 cast (pinned against the reference's own output), timed per
+    BASELINE.md section 3: median after warm-up, BLAS pool at its default size and limited to 1 thread."""
     sys.path.insert(0, str(REPO / "oracle"))
     import himo_oracle as oracle
+    run_one = lambda i: oracle.comp_dis_frame_f32(frames[i], "seflowpp_best")
+    legs = {"all_cores": _median_rate(run_one, len(frames), budget_s / 2, exact_frames)}
     try:
         from threadpoolctl import threadpool_limits
-        threadpool_limits(limits=1)
-    except Exception:                                   # pragma: no cover
-        pass
-    for f in frames[:2]:
-        oracle.comp_dis_frame_f32(f, "seflowpp_best")   # warm-up
-    n, t0 = 0, time.perf_counter()
+        with threadpool_limits(limits=1):
+            legs["one_thread"] = _median_rate(run_one, len(frames), budget_s / 2, exact_frames)
+    except ImportError:                                   # pragma: no cover
+        legs["one_thread"] = legs["all_cores"]
+    a, o = legs["all_cores"], legs["one_thread"]
+    return {"value": a["frames_per_s"], "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "value_1_thread": o["frames_per_s"], "all_cores": a, "one_thread": o, "host_logical_cores": os.cpu_count(),
+            "sample": f"median of {a['frames_timed']} x {len(frames[0]['pc0'])}-pt frames (default BLAS threads) and of "
+                      f"{o['frames_timed']} (1 thread) after warm-up: numpy oracle/himo_oracle.py comp_dis_frame_f32 "
+                      f"(the arithmetic is element-wise numpy: the thread count barely matters)"}
+
+
+def _median_rate(run_one, n_frames_avail: int, budget_s: float, exact_frames: int):
+    """warm-up frames, then the MEDIAN per-frame time of the measured ones.  ``exact_frames`` > 0:
+    5 warm-ups + exactly that many frames; otherwise 1 warm-up + as many frames as fit in ``budget_s`` (at least 3)."""
+    warm = 5 if exact_frames > 0 else 1
+    for i in range(warm):
+        run_one(i % n_frames_avail)
+    times, t_start = [], time.perf_counter()
     while True:
-        oracle.comp_dis_frame_f32(frames[n % len(frames)], "seflowpp_best")
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 20000:
+        t0 = time.perf_counter()
+        run_one((warm + len(times)) % n_frames_avail)
+        times.append(time.perf_counter() - t0)
+        if exact_frames > 0:
+            if len(times) >= exact_frames:
+                break
+        elif len(times) >= 3 and (time.perf_counter() - t_start + times[-1] > budget_s or len(times) >= 50):
             break
-    return {"value": n / el, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} x {len(frames[0]['pc0'])}-pt frames in {el:.1f}s, numpy oracle/himo_oracle.py "
-                      f"comp_dis_frame_f32 (host has {os.cpu_count()} cores, 1 used)"}
+    med = float(np.median(times))
+    return {"frames_per_s": 1.0 / med, "ms_per_frame": med * 1e3, "frames_timed": len(times), "warmup_frames": warm,
+            "ms_min": float(np.min(times)) * 1e3, "ms_max": float(np.max(times)) * 1e3}
 
 
-def cpu_baseline_pipeline(samples, params, budget_s: float) -> dict:
-    """PyTorch-CPU float32 restatement of the network (oracle/seflow_oracle.py) + numpy comp_dis, all host cores
-    torch wants.  PARITY UNPINNED: this is the build's own restatement, not the reference's code (absent)."""
+def cpu_baseline_pipeline(host_samples, params, budget_s: float, exact_frames: int = 0, threads_all: int = 0) -> dict:
+    """PyTorch-CPU float32 restatement of the network (oracle/seflow_oracle.py) + numpy comp_dis on 120k-point frames, timed
+    per BASELINE.md section 3 at all cores AND at 1 thread (median after warm-up; core count stated).  ``host_samples``:
+    [(history frame, frame, next frame)] of host dicts.  PARITY UNPINNED: this is the build's own restatement, not the
+    reference's code (absent)."""
     import torch
     sys.path.insert(0, str(REPO / "oracle"))
     import himo_oracle as oracle
     import seflow_oracle as so
-    threads = torch.get_num_threads()
-    n, t0, el = 0, time.perf_counter(), 0.0
-    while True:
-        s = samples[n % len(samples)]
-        flow = so.forward(params, s.pch1.cpu().numpy(), s.pc0.cpu().numpy(), s.pc1.cpu().numpy(), s.pose_h1, s.pose0, s.pose1)
-        frame = {"pc0": s.pc0.cpu().numpy(), "seflowpp_best": flow, "lidar_dt": s.lidar_dt.cpu().numpy(),
-                 "pose0": s.pose0, "pose1": s.pose1}
-        oracle.comp_dis_frame_f32(frame, "seflowpp_best")
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 64:
-            break
-    return {"value": n / el, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} frame(s) of 3 x {len(samples[0].pc0)} pts in {el:.1f}s: PyTorch-CPU fp32 restatement "
-                      f"(oracle/seflow_oracle.py) + numpy comp_dis; torch threads={threads}, host cores={os.cpu_count()}"}
+
+    def run_one(i):
+        fh, f0, f1 = host_samples[i]
+        flow = so.forward(params, fh["pc0"], f0["pc0"], f1["pc0"], fh["pose0"], f0["pose0"], f0["pose1"])
+        oracle.comp_dis_frame_f32(dict(f0, seflowpp_best=flow), "seflowpp_best")
+
+    default_threads = torch.get_num_threads()
+    legs = {}
+    try:
+        for name, thr in (("all_cores", threads_all or default_threads), ("one_thread", 1)):
+            torch.set_num_threads(thr)
+            legs[name] = dict(_median_rate(run_one, len(host_samples), budget_s, exact_frames), threads=thr)
+    finally:
+        torch.set_num_threads(default_threads)
+    a, o = legs["all_cores"], legs["one_thread"]
+    return {"value": a["frames_per_s"], "unit": "frames/s", "cores": a["threads"], "kind": "port",
+            "value_1_thread": o["frames_per_s"], "all_cores": a, "one_thread": o, "host_logical_cores": os.cpu_count(),
+            "sample": f"median of {a['frames_timed']} frame(s) after {a['warmup_frames']} warm-up(s) at {a['threads']} torch threads "
+                      f"({a['ms_per_frame']:.0f} ms/frame) and of {o['frames_timed']} at 1 thread ({o['ms_per_frame']:.0f} ms/frame); "
+                      f"a frame = 3 x {len(host_samples[0][1]['pc0'])}-point sweeps through the PyTorch-CPU fp32 restatement "
+                      f"(oracle/seflow_oracle.py) + numpy comp_dis; host has {os.cpu_count()} logical cores"}
 
 
 def reduce_job(elapsed: float, frames_done: int, device, world: int, rank: int):
@@ -196,38 +238,116 @@ def reduce_job(elapsed: float, frames_done: int, device, world: int, rank: int):
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         gathered = [torch.zeros_like(done) for _ in range(world)]
         dist.all_gather(gathered, done)                 # every backend implements all_gather; rank 0 reports
-        total = int(sum(int(g.item()) for g in gathered)) if rank == 0 else 0
+        per_rank = [int(g.item()) for g in gathered]
     else:
-        total = int(done.item())
-    return float(el.item()), total
+        per_rank = [int(done.item())]
+    return float(el.item()), sum(per_rank), per_rank
 
 
-def main():
-    args = parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------
+# launch: one process per GPU
+# ------------------------------------------------------------------------------------------------------
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` outside a torchrun environment: start N ranks of this file, one per GPU, under
+    ``python -m torch.distributed.run`` on 127.0.0.1 (the driver's own multi-GPU command line) and pass their exit code
+    on.  Rank 0's JSON line goes to this process's stdout unchanged."""
+    import socket
+    import subprocess
+    if not args.dry_run_cpu:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible on this node")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _dry_run_step(args, rank: int, world: int):
+    """Host stand-in for the device work of --dry-run-cpu (tests only): a few microseconds of numpy per frame, and for the
+    train workload the real data-parallel exchange -- ``allreduce_mean_`` on a flat float32 buffer of the parameter count."""
     import torch
-    import torch.distributed as dist
+    flat = torch.full((1 << 16,), float(rank + 1)) if args.workload == "train" else None
+    sink = np.zeros(8)
 
+    def step():
+        sink[:] = np.sqrt(np.arange(8.0) + args.frames_per_step)
+        if flat is not None:
+            from himo_amd.seflow.train import allreduce_mean_
+            flat.fill_(float(rank + 1))
+            allreduce_mean_(flat)
+            want = (world + 1) / 2.0
+            if abs(float(flat[0]) - want) > 1e-6:
+                raise RuntimeError(f"all-reduce mean {float(flat[0])} != {want}")
+    return step
+
+
+def main() -> int:
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device; there is no CPU path to benchmark")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); "
+                         "they must agree (value is the whole-job rate over n_gpus)")
+    import torch
+    import torch.distributed as dist
+
+    dry = args.dry_run_cpu
+    if dry:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device; there is no CPU path to benchmark")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} HIP device(s) visible")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver
-        dist.init_process_group("nccl", device_id=device)
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)        # "nccl" IS RCCL on ROCm
+    try:
+        line = run_rank(args, rank, world, device, sync)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    return 0
 
-    from himo_amd import _lib
+
+def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
+    import torch
+    import torch.distributed as dist
+    dry = args.dry_run_cpu
     B, P = args.frames_per_step, args.points
     sys.path.insert(0, str(REPO / "oracle"))
+    _lib = None
+    if not dry:
+        from himo_amd import _lib
 
-    if args.workload == "compdis":
+    out, result, host_frames, params, pipe, batch, sets = {}, {}, None, None, None, None, None
+    turn = [0]
+    if dry:
+        step = _dry_run_step(args, rank, world)
+    elif args.workload == "compdis":
         from himo_amd.compdis import CompDisEngine
         batch = synthetic_batch(B, P, device, seed=rank)
         eng = CompDisEngine(device=device, max_frames=B)
-        out = {}
 
         def step():
             eng.run(batch, sensor_dt=0.1, refined=args.refined, out=out)
@@ -238,14 +358,14 @@ def main():
         from himo_amd.seflow.train import SeFlowTrainer
         params = spec.init_params(0)
         trainer = SeFlowTrainer(params, device=device, max_points=P, precision=args.train_precision)
-        samples = synthetic_samples(B, P, device, seed=rank)
+        sets, host_frames = synthetic_sample_sets(1, B, P, device, seed=rank, cloud=args.cloud)
+        samples = sets[0]
         g = torch.Generator(device=device); g.manual_seed(99 + rank)
         labels = []
         for _ in range(B):
             pick = torch.rand(P, generator=g, device=device) < 0.1
             lab = torch.randint(1, 31, (P,), generator=g, device=device, dtype=torch.int32) * pick.to(torch.int32)
             labels.append((lab, lab.clone()))
-        result = {}
 
         def step():
             for smp, (l0, l1) in zip(samples, labels):
@@ -260,25 +380,27 @@ def main():
         if args.float32_activations:
             net.split_acts = False
         pipe = HiMoPipeline(net, device=device)
-        samples = synthetic_samples(B, P, device, seed=rank)
-        result = {}
+        sets, host_frames = synthetic_sample_sets(max(1, args.sample_sets), B, P, device, seed=rank, cloud=args.cloud)
 
         def step():
-            result.update(pipe.run(samples, sensor_dt=0.1, refined=args.refined))
+            # a DIFFERENT batch every step (the sets rotate): the ragged batch container -- point / lidar_dt concatenation,
+            # offsets + poses upload -- is rebuilt inside the timed region, as a stream of fresh frames would make it
+            result.update(pipe.run(sets[turn[0] % len(sets)], sensor_dt=0.1, refined=args.refined))
+            turn[0] += 1
 
     step()                                      # priming pass on every rank (one-off tile autotune, operator-list recording,
-    torch.cuda.synchronize()                    # workspace growth): never inside the timed region, whatever --warmup is
+    sync()                                      # workspace growth): never inside the timed region, whatever --warmup is
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
 
     # parity spot-check on rank 0 (not timed): EPE / max abs vs the CPU oracle on one frame
-    parity = None
-    if rank == 0:
+    parity, ref_flow = None, None
+    if rank == 0 and not dry:
         import himo_oracle as oracle
-        step()
-        torch.cuda.synchronize()
         if args.workload == "compdis":
+            step()
+            sync()
             f = frame_to_host(batch, 0)
             ref = oracle.comp_dis_frame_f32(f, "seflowpp_best")
             got = out["comp_dis"][:P].cpu().numpy()
@@ -290,21 +412,13 @@ def main():
                       "note": "gradient parity vs CPU autograd through the oracle network: tests/test_train_gpu.py"}
         elif not args.no_cpu_baseline:
             import seflow_oracle as so
-            s = samples[0]
-            ref_flow = so.forward(params, s.pch1.cpu().numpy(), s.pc0.cpu().numpy(), s.pc1.cpu().numpy(), s.pose_h1, s.pose0, s.pose1)
-            got_flow = result["flow"][:P].cpu().numpy()
-            frame = {"pc0": s.pc0.cpu().numpy(), "seflowpp_best": ref_flow, "lidar_dt": s.lidar_dt.cpu().numpy(),
-                     "pose0": s.pose0, "pose1": s.pose1}
-            ref_cd = oracle.comp_dis_frame_f32(frame, "seflowpp_best")
-            got_cd = result["comp_dis"][:P].cpu().numpy()
-            # the same frame through the float32-MFMA kernels (no split arithmetic anywhere): what the split costs
-            net32 = SeFlowNet(params, device=device, max_points=P, precision="f32", autotune=False)
-            flow32 = net32.forward_device(s.pch1, s.pc0, s.pc1, s.pose_h1, s.pose0, s.pose1).cpu().numpy()
-            del net32
-            torch.cuda.empty_cache()
+            fh, f0, f1 = host_frames[0], host_frames[1], host_frames[2]
+            ref_flow = so.forward(params, fh["pc0"], f0["pc0"], f1["pc0"], fh["pose0"], f0["pose0"], f0["pose1"])
+            ref_cd = oracle.comp_dis_frame_f32(dict(f0, seflowpp_best=ref_flow), "seflowpp_best")
+            res = pipe.run(sets[0], sensor_dt=0.1, refined=args.refined)
+            sync()
+            got_flow, got_cd = res["flow"][:P].cpu().numpy(), res["comp_dis"][:P].cpu().numpy()
             parity = {"flow_mean_epe_vs_cpu_restatement": float(np.linalg.norm(got_flow - ref_flow, axis=1).mean()),
-                      "flow_max_abs_vs_float32_mfma_kernels": float(np.abs(got_flow - flow32).max()),
-                      "float32_mfma_kernels_max_abs_vs_cpu_restatement": float(np.abs(flow32 - ref_flow).max()),
                       "flow_max_abs_vs_cpu_restatement": float(np.abs(got_flow - ref_flow).max()),
                       "comp_dis_max_abs_vs_cpu_restatement": float(np.abs(got_cd.astype(np.float64) - ref_cd).max()),
                       "note": "network parity is against this build's own CPU restatement (reference source absent)"}
@@ -316,142 +430,198 @@ def main():
         args.workload, {"bf16x3": "conv3x3_bf16x3_kernel", "f16x2": "conv3x3_f16x2_kernel"}.get(args.precision, "conv3x3_mfma_kernel"))
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     import gc
     gc.collect()
     gc.disable()                                # no collector pauses inside the timed region
+    n_threads = torch.get_num_threads()
     if parity is not None:
         # the CPU restatement of the parity check just ran on every host core: let its worker threads park before the
         # launch thread is timed (spinning OpenMP workers otherwise cost ~5 % of the frame rate)
-        n_threads = torch.get_num_threads()
         torch.set_num_threads(1)
         time.sleep(1.0)
-    _lib.prof_start(only=dominant)
+    if _lib is not None:
+        _lib.prof_start(only=dominant)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if args.workload == "pipeline":
+    if pipe is not None:
         pipe.sync_check()                       # the last batch's finite-flow flag (fp16-split precision)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    if parity is not None:
-        torch.set_num_threads(n_threads)
-    prof = _lib.prof_stop()
+    torch.set_num_threads(n_threads)
+    prof = _lib.prof_stop() if _lib is not None else {}
     all_kernels = {}
-    if rank == 0:
+    if rank == 0 and _lib is not None:
         _lib.prof_start()
         step()
-        torch.cuda.synchronize()
+        sync()
         all_kernels = _lib.prof_stop()
 
-    elapsed, total_frames = reduce_job(elapsed, B * args.steps, device, world, rank)
+    elapsed, total_frames, per_rank = reduce_job(elapsed, B * args.steps, device, world, rank)
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        traffic = None
-        try:
-            traffic = json.loads(Path(args.traffic_json).read_text())
-        except Exception:
-            traffic = {}
-        per_kernel = {n: {"avg_ms": v["avg_ms"], "launches_per_step": v["count"], "ms_per_step": v["total_ms"]}
-                      for n, v in all_kernels.items()}
+    traffic = {}
+    try:
+        traffic = json.loads(Path(args.traffic_json).read_text())
+    except Exception:
+        pass
+    per_kernel = {n: {"avg_ms": v["avg_ms"], "launches_per_step": v["count"], "ms_per_step": v["total_ms"]}
+                  for n, v in all_kernels.items()}
+    extra = {}
+    if dry:
+        roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        workload, dtype = f"DRY RUN on the CPU ({args.workload}): no device work was done, the numbers are meaningless", "none"
+    elif args.workload == "compdis":
+        bytes_per_pt = 44 + (12 if args.refined else 0)     # xyzi 16 + flow 12 + dt 4 + comp_dis 12 [+ refined 12]
+        k = prof.get("compdis_kernel", {"avg_ms": float("nan"), "count": 0})
+        achieved = bytes_per_pt * B * P / (k["avg_ms"] * 1e-3) / 1e9 if k["count"] else float("nan")
+        roofline = {"bound": "hbm", "kernel": "compdis_kernel<4,f64>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic.get("compdis_kernel", {}).get("hbm_bytes_per_launch"),
+                    "algorithmic_bytes_per_launch": bytes_per_pt * B * P, "avg_launch_ms": k["avg_ms"],
+                    "launches_timed": k["count"]}
+        workload = ("flow->comp_dis fused path only (a1-a4: ego-motion removal, dt0, flow2compDis; f64 chain, f32 I/O) "
+                    "over a ragged HBM-resident batch; network forward NOT included")
+        dtype = "f64"
+    elif args.workload == "train":
+        from himo_amd.seflow import spec
+        # dominant kernel of the step: the 3x3 weight gradients (float32 MFMA, LDS-tiled split-K), 19 launches per step
+        k = prof.get("conv_wgrad_tiled_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
+        n_steps = B * args.steps
+        H, W = spec.GRID
+        flops_w = spec.conv3x3_flops() + sum(spec.NUM_FRAMES * 2.0 * (H // d) * (W // d) * ci * co * 9
+                                             for d, ci, co in ((2, 32, 64), (4, 64, 128), (8, 128, 256)))
+        alg_tf = flops_w * n_steps / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
+        roofline = {"bound": "mfma", "kernel": "conv_wgrad_tiled_kernel (v_mfma_f32_32x32x2_f32; 3x3 weight gradients)",
+                    "achieved": alg_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": alg_tf / MFMA_F32_PEAK_TF,
+                    "traffic": None, "avg_launch_ms": k["avg_ms"], "launches_timed": k["count"],
+                    "algorithmic_flops_per_step": flops_w, "share_of_step_time": k["total_ms"] / (elapsed * 1e3)}
+        workload = ("self-supervised TRAINING step (BASELINE config 5): pillarise 3 sweeps -> network forward with saved "
+                    "activations -> 4-term NN/Chamfer loss -> full backward -> flat-gradient all-reduce -> Adam; "
+                    "one 120k-point sample per GPU per step")
+        dtype = "f32 weight gradients / optimiser; bf16x3 (split bf16, float32-class) forward + data-gradient convolutions"
+    else:
+        roofline, dtype = conv_roofline(args.precision, prof, B, args.steps, elapsed, traffic)
+        workload = ("per-frame pipeline: pillarise 3 sweeps (512x512 grid) -> SeFlow++-style encoder/decoder + GRU head "
+                    "(random-init, self-specified: reference network source absent) -> per-point flow -> ego-motion "
+                    "removal + dt0 + flow2compDis -> comp_dis")
+        if world == 1 and not args.no_extra_precisions:
+            extra = extra_precision_legs(args, params, sets, device, ref_flow, exclude=args.precision)
+    line = {
+        "metric": "lidar_frames_per_sec_120k", "value": total_frames / elapsed, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic" if not dry else "none (dry run on the CPU: INVALID as a measurement)",
+        "config": {"workload": workload, "frames_per_step_per_gpu": B, "points_per_frame": P,
+                   "sweeps_per_frame": 3 if args.workload == "pipeline" else 1,
+                   "parallelism": f"frames sharded x{world}", "refined_output": bool(args.refined),
+                   "frames_per_rank": per_rank},
+        "roofline": roofline, "kernels": per_kernel,
+        "kernels_note": "one extra untimed step with every kernel timed; the timed region times only the roofline kernel",
+        "parity": parity,
+    }
+    line.update(extra)
+    if args.workload == "pipeline":
+        line["config"]["matrix_arithmetic"] = args.precision
+        line["config"]["samples_per_backbone_launch"] = B
+        line["config"]["input"] = (f"himo_amd.synthetic.make_frame sweeps (SURVEY 8(d) seeded frames, cloud={args.cloud}); "
+                                   f"{max(1, args.sample_sets)} distinct batches rotate through the steps, so the ragged batch "
+                                   "container is rebuilt from different samples inside every timed step")
+    if args.workload == "train":
+        line["metric"] = "train_frames_per_sec_120k"
+        line["config"]["parallelism"] = f"data parallel x{world}, one flat all-reduce per step"
+        line["config"]["matrix_arithmetic"] = args.train_precision
+    if not dry and not args.no_cpu_baseline and args.workload != "train" and world == 1:     # CPU leg: rank 0 at N = 1 only
         if args.workload == "compdis":
-            bytes_per_pt = 44 + (12 if args.refined else 0)     # xyzi 16 + flow 12 + dt 4 + comp_dis 12 [+ refined 12]
-            k = prof.get("compdis_kernel", {"avg_ms": float("nan"), "count": 0})
-            achieved = bytes_per_pt * B * P / (k["avg_ms"] * 1e-3) / 1e9 if k["count"] else float("nan")
-            roofline = {"bound": "hbm", "kernel": "compdis_kernel<4,f64>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic.get("compdis_kernel", {}).get("hbm_bytes_per_launch"),
-                        "algorithmic_bytes_per_launch": bytes_per_pt * B * P, "avg_launch_ms": k["avg_ms"],
-                        "launches_timed": k["count"]}
-            workload = ("flow->comp_dis fused path only (a1-a4: ego-motion removal, dt0, flow2compDis; f64 chain, f32 I/O) "
-                        "over a ragged HBM-resident batch; network forward NOT included")
-            dtype = "f64"
-        elif args.workload == "train":
-            from himo_amd.seflow import spec
-            # dominant kernel of the step: the 3x3 weight gradients (float32 MFMA, LDS-tiled split-K), 19 launches per step
-            k = prof.get("conv_wgrad_tiled_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
-            n_steps = B * args.steps
-            H, W = spec.GRID
-            flops_w = spec.conv3x3_flops() + sum(spec.NUM_FRAMES * 2.0 * (H // d) * (W // d) * ci * co * 9
-                                                 for d, ci, co in ((2, 32, 64), (4, 64, 128), (8, 128, 256)))
-            alg_tf = flops_w * n_steps / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
-            roofline = {"bound": "mfma", "kernel": "conv_wgrad_tiled_kernel (v_mfma_f32_32x32x2_f32; 3x3 weight gradients)",
-                        "achieved": alg_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": alg_tf / MFMA_F32_PEAK_TF,
-                        "traffic": None, "avg_launch_ms": k["avg_ms"], "launches_timed": k["count"],
-                        "algorithmic_flops_per_step": flops_w, "share_of_step_time": k["total_ms"] / (elapsed * 1e3)}
-            workload = ("self-supervised TRAINING step (BASELINE config 5): pillarise 3 sweeps -> network forward with saved "
-                        "activations -> 4-term NN/Chamfer loss -> full backward -> flat-gradient all-reduce -> Adam; "
-                        "one 120k-point sample per GPU per step")
-            dtype = "f32 weight gradients / optimiser; bf16x3 (split bf16, float32-class) forward + data-gradient convolutions"
+            frames = [frame_to_host(batch, i) for i in range(min(8, B))]
+            line["cpu_baseline"] = cpu_baseline_compdis(frames, args.cpu_seconds, args.cpu_frames)
         else:
-            from himo_amd.seflow import spec
-            bf, f16 = args.precision == "bf16x3", args.precision == "f16x2"
-            kname = "conv3x3_bf16x3_kernel" if bf else "conv3x3_f16x2_kernel" if f16 else "conv3x3_mfma_kernel"
-            k = prof.get(kname, {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
-            n_fwd = B * args.steps
-            # algorithmic flops of the 20 stride-1 3x3 convolutions of one forward (2*M*N*K each), see DESIGN.md
-            flops3 = spec.conv3x3_flops()
-            launches_per_fwd = k["count"] / max(n_fwd, 1)
-            alg_tf = flops3 * n_fwd / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
-            # `achieved` = ALGORITHMIC flops (2*M*N*K float32 multiply-adds of the 20 layers) / measured kernel time.  The peak it is
-            # priced against is the dense MFMA peak of the arithmetic the kernel runs in, in the same unit: a split-precision
-            # kernel spends `per` matrix multiply-adds per float32 multiply-add, so its ceiling is (2.5 PF dense fp16|bf16) / per.
-            if bf:
-                per, note = 6.0, "v_mfma_f32_32x32x16_bf16, 6 per float32 product block (h*h, h*m, m*h, m*m, h*l, l*h)"
-            elif f16:
-                per, note = 3.0, "v_mfma_f32_32x32x16_f16, 3 per float32 product block (h*h, h*l, l*h)"
-            else:
-                per, note = 1.0, "v_mfma_f32_32x32x2_f32"
-            peak = MFMA_F32_PEAK_TF if per == 1.0 else MFMA_BF16_PEAK_TF / per
-            roofline = {"bound": "mfma", "kernel": f"{kname} ({note})", "achieved": alg_tf, "peak": peak, "unit": "TFLOP/s",
-                        "frac": alg_tf / peak,
-                        "peak_note": ("dense float32 MFMA peak" if per == 1.0 else
-                                      f"{MFMA_BF16_PEAK_TF:.0f} TFLOP/s dense 16-bit MFMA peak / {per:.0f} matrix products per float32 product"),
-                        "issued_matrix_tflops": per * alg_tf,
-                        "traffic": traffic.get("conv3x3_mfma_kernel" if args.precision == "f32" else "conv3x3_split_kernel", {}).get("hbm_bytes_per_launch"),
-                        "vs_f32_mfma_peak_157_3": alg_tf / MFMA_F32_PEAK_TF,
-                        "algorithmic_flops_per_launch": flops3 / max(launches_per_fwd, 1e-9), "avg_launch_ms": k["avg_ms"],
-                        "launches_timed": k["count"], "launches_per_frame": launches_per_fwd, "samples_per_launch": B,
-                        "share_of_step_time": k["total_ms"] / (elapsed * 1e3)}
-            workload = ("per-frame pipeline: pillarise 3 sweeps (512x512 grid) -> SeFlow++-style encoder/decoder + GRU head "
-                        "(random-init, self-specified: reference network source absent) -> per-point flow -> ego-motion "
-                        "removal + dt0 + flow2compDis -> comp_dis")
-            dtype = ("bf16x3 (three-term split bf16 on the matrix cores, float32 accumulate; float32-class accuracy)" if bf else
-                     "f16x2 (two-term split fp16, x = h + l with exact subnormals, on the matrix cores; float32 accumulate; ~22-bit products)"
-                     if f16 else "f32")
-        line = {
-            "metric": "lidar_frames_per_sec_120k", "value": total_frames / elapsed, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": workload, "frames_per_step_per_gpu": B, "points_per_frame": P,
-                       "sweeps_per_frame": 3 if args.workload == "pipeline" else 1,
-                       "parallelism": f"frames sharded x{world}", "refined_output": bool(args.refined)},
-            "roofline": roofline, "kernels": per_kernel,
-            "kernels_note": "one extra untimed step with every kernel timed; the timed region times only the roofline kernel",
-            "parity": parity,
-        }
-        if args.workload == "pipeline":
-            line["config"]["matrix_arithmetic"] = args.precision
-            line["config"]["samples_per_backbone_launch"] = B
-        if args.workload == "train":
-            line["metric"] = "train_frames_per_sec_120k"
-            line["config"]["parallelism"] = f"data parallel x{world}, one flat all-reduce per step"
-            line["config"]["matrix_arithmetic"] = args.train_precision
-        if not args.no_cpu_baseline and args.workload != "train" and world == 1:     # CPU leg: rank 0 at N = 1 only
-            if args.workload == "compdis":
-                frames = [frame_to_host(batch, i) for i in range(min(8, B))]
-                line["cpu_baseline"] = cpu_baseline_compdis(frames, args.cpu_seconds)
-            else:
-                line["cpu_baseline"] = cpu_baseline_pipeline(samples, params, args.cpu_seconds)
-            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+            host_samples = [(host_frames[j], host_frames[j + 1], host_frames[j + 2]) for j in range(min(B, len(host_frames) - 2))]
+            line["cpu_baseline"] = cpu_baseline_pipeline(host_samples, params, args.cpu_seconds, args.cpu_frames, args.cpu_threads)
+        line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+    return line
+
+
+def conv_roofline(precision: str, prof: dict, B: int, steps: int, elapsed: float, traffic: dict):
+    """roofline object + dtype string of the pipeline workload's dominant kernel (the stride-1 3x3 convolutions) from the
+    HIP-event timings of ITS launches inside the timed region."""
+    from himo_amd.seflow import spec
+    bf, f16 = precision == "bf16x3", precision == "f16x2"
+    kname = "conv3x3_bf16x3_kernel" if bf else "conv3x3_f16x2_kernel" if f16 else "conv3x3_mfma_kernel"
+    k = prof.get(kname, {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
+    n_fwd = B * steps
+    # algorithmic flops of the 20 stride-1 3x3 convolutions of one forward (2*M*N*K each), see DESIGN.md
+    flops3 = spec.conv3x3_flops()
+    launches_per_fwd = k["count"] / max(n_fwd, 1)
+    alg_tf = flops3 * n_fwd / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
+    # `achieved` = ALGORITHMIC flops (2*M*N*K float32 multiply-adds of the 20 layers) / measured kernel time.  The peak it is
+    # priced against is the dense MFMA peak of the arithmetic the kernel runs in, in the same unit: a split-precision
+    # kernel spends `per` matrix multiply-adds per float32 multiply-add, so its ceiling is (2.5 PF dense fp16|bf16) / per.
+    if bf:
+        per, note = 6.0, "v_mfma_f32_32x32x16_bf16, 6 per float32 product block (h*h, h*m, m*h, m*m, h*l, l*h)"
+    elif f16:
+        per, note = 3.0, "v_mfma_f32_32x32x16_f16, 3 per float32 product block (h*h, h*l, l*h)"
+    else:
+        per, note = 1.0, "v_mfma_f32_32x32x2_f32"
+    peak = MFMA_F32_PEAK_TF if per == 1.0 else MFMA_BF16_PEAK_TF / per
+    roofline = {"bound": "mfma", "kernel": f"{kname} ({note})", "achieved": alg_tf, "peak": peak, "unit": "TFLOP/s",
+                "frac": alg_tf / peak,
+                "peak_note": ("dense float32 MFMA peak" if per == 1.0 else
+                              f"{MFMA_BF16_PEAK_TF:.0f} TFLOP/s dense 16-bit MFMA peak / {per:.0f} matrix products per float32 product"),
+                "issued_matrix_tflops": per * alg_tf,
+                "traffic": traffic.get("conv3x3_mfma_kernel" if precision == "f32" else "conv3x3_split_kernel", {}).get("hbm_bytes_per_launch"),
+                "vs_f32_mfma_peak_157_3": alg_tf / MFMA_F32_PEAK_TF,
+                "algorithmic_flops_per_launch": flops3 / max(launches_per_fwd, 1e-9), "avg_launch_ms": k["avg_ms"],
+                "launches_timed": k["count"], "launches_per_frame": launches_per_fwd, "samples_per_launch": B,
+                "share_of_step_time": k["total_ms"] / (elapsed * 1e3)}
+    dtype = ("bf16x3 (three-term split bf16 on the matrix cores, float32 accumulate; float32-class accuracy)" if bf else
+             "f16x2 (two-term split fp16, x = h + l with exact subnormals, on the matrix cores; float32 accumulate; ~22-bit products)"
+             if f16 else "f32")
+    return roofline, dtype
+
+
+def extra_precision_legs(args, params, sets, device, ref_flow, exclude: str) -> dict:
+    """N = 1 only, after the timed region: the SAME workload (same batches, same steps protocol: priming pass, warm-up,
+    K timed steps between synchronisations) in the other two matrix arithmetics, so the float32-range figures are measured
+    in the same run as ``value``: ``value_bf16x3`` / ``value_f32`` (+ their parity against the CPU restatement)."""
+    import torch
+    from himo_amd.pipeline import HiMoPipeline
+    from himo_amd.seflow.model import SeFlowNet
+    out = {}
+    B, P = args.frames_per_step, args.points
+    for prec, steps in (("f16x2", args.steps), ("bf16x3", max(3, args.steps // 2)), ("f32", max(3, args.steps // 4))):
+        if prec == exclude:
+            continue
+        net = SeFlowNet(params, device=device, max_points=P, precision=prec, max_batch=B)
+        pipe = HiMoPipeline(net, device=device)
+        res = pipe.run(sets[0], sensor_dt=0.1, refined=args.refined)                        # priming pass
+        torch.cuda.synchronize()
+        leg = {}
+        if ref_flow is not None:
+            got = res["flow"][:P].cpu().numpy()
+            leg["flow_max_abs_vs_cpu_restatement"] = float(np.abs(got - ref_flow).max())
+            leg["flow_mean_epe_vs_cpu_restatement"] = float(np.linalg.norm(got - ref_flow, axis=1).mean())
+        for k in range(2):
+            pipe.run(sets[k % len(sets)], sensor_dt=0.1, refined=args.refined)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            pipe.run(sets[k % len(sets)], sensor_dt=0.1, refined=args.refined)
+        pipe.sync_check()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        leg.update({"frames_per_s": B * steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": 2})
+        out[f"value_{prec}"] = leg["frames_per_s"]
+        out[f"leg_{prec}"] = leg
+        del pipe, net, res
+        torch.cuda.empty_cache()
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

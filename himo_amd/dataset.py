@@ -12,7 +12,9 @@ taken from the in-tree writers and consumers only:
 ``pose1`` is the pose of the next timestamp in the same scene (the flow is pc0 -> pc1).
 
 ``h5py`` is not installed in the build image; ``HDF5Dataset`` raises ImportError with that message
-rather than guessing.  ``NpzDataset`` is this package's own container for the same dicts.
+rather than guessing (its index / successor / key-renaming logic is exercised through the ``opener`` hook with an
+in-memory scene mapping, and against real files wherever h5py exists: tests/test_dataset.py).  ``NpzDataset`` is this
+package's own container for the same dicts.
 """
 from __future__ import annotations
 
@@ -41,9 +43,7 @@ class NpzDataset:
 
     def __init__(self, directory, vis_name: str = "", eval: bool = False):  # noqa: A002
         self.directory = Path(directory)
-        idx = self.directory / ("index_eval.pkl" if eval and (self.directory / "index_eval.pkl").exists() else "index_total.pkl")
-        with open(idx, "rb") as f:
-            self.index = pickle.load(f)
+        self.index = load_index(self.directory, eval=eval)
         self.vis_name = vis_name
 
     def __len__(self):
@@ -72,48 +72,80 @@ class NpzDataset:
                 pickle.dump([index[i] for i in eval_subset], fh)
 
 
-class HDF5Dataset:
-    """h5 scene files -> frame dicts (see module docstring for the provenance of the layout)."""
+def require_h5py():
+    try:
+        import h5py
+    except ImportError as e:
+        raise ImportError("the .h5 scene files need h5py, which is not installed in this image; "
+                          "use NpzDataset / SyntheticDataset, or install h5py on the target box") from e
+    return h5py
 
-    def __init__(self, directory, vis_name: str = "", eval: bool = False, n_frames: int = 2):  # noqa: A002
-        try:
-            import h5py  # noqa: F401
-        except ImportError as e:
-            raise ImportError("HDF5Dataset needs h5py, which is not installed in this image; "
-                              "use NpzDataset / SyntheticDataset, or install h5py on the target box") from e
-        self._h5py = h5py
+
+def _open_h5(path):
+    return require_h5py().File(path, "r")
+
+
+def load_index(directory, eval: bool = False) -> list:  # noqa: A002
+    """``index_eval.pkl`` (when ``eval`` and present) else ``index_total.pkl``: a pickled list of ``[scene_id, timestamp]``
+    pairs, timestamps as str or int (tools/pkl_extract.py:5-19 prints exactly this structure; the reference ships
+    assets/docs/av2/index_eval.pkl: 70 frames of 13 scenes)."""
+    directory = Path(directory)
+    name = "index_eval.pkl" if eval and (directory / "index_eval.pkl").exists() else "index_total.pkl"
+    with open(directory / name, "rb") as f:
+        return [[str(s), str(t)] for s, t in pickle.load(f)]
+
+
+class HDF5Dataset:
+    """h5 scene files -> frame dicts (see module docstring for the provenance of the layout).
+
+    ``pose1`` / ``pc1`` come from the next timestamp of the same scene in ``index_total.pkl``; a frame with no successor
+    (the last sweep of a scene) has no ``pose1`` to remove ego motion with (save_zip.py:115), so it is dropped from the
+    index at construction -- iterating the dataset never yields a frame the consumers cannot process.
+    ``opener(path)`` returns the scene file as a read-only mapping ``{timestamp: {name: array-like}}`` usable as a context
+    manager; the default is ``h5py.File(path, "r")`` (ImportError with a clear message when h5py is absent)."""
+
+    def __init__(self, directory, vis_name="", eval: bool = False, n_frames: int = 2, opener=None):  # noqa: A002
+        self._open = opener if opener is not None else _open_h5
+        if opener is None:
+            require_h5py()                                   # fail at construction, not at the first frame
         self.directory = Path(directory)
-        self.vis_name = vis_name if isinstance(vis_name, (list, tuple)) else [vis_name]
-        name = "index_eval.pkl" if eval and (self.directory / "index_eval.pkl").exists() else "index_total.pkl"
-        with open(self.directory / name, "rb") as f:
-            self.index = pickle.load(f)
-        with open(self.directory / "index_total.pkl", "rb") as f:
-            total = pickle.load(f)
+        self.vis_name = list(vis_name) if isinstance(vis_name, (list, tuple)) else [vis_name]
+        total = load_index(self.directory, eval=False)
         self._next = {}
         for (s0, t0), (s1, t1) in zip(total[:-1], total[1:]):
             if s0 == s1:
-                self._next[(s0, str(t0))] = str(t1)
+                self._next[(s0, t0)] = t1
+        self.index = [[s, t] for s, t in load_index(self.directory, eval=eval) if (s, t) in self._next]
 
     def __len__(self):
         return len(self.index)
 
+    def scene_path(self, scene_id: str) -> Path:
+        return self.directory / f"{scene_id}.h5"
+
     def __getitem__(self, i):
         scene_id, ts = self.index[i]
-        ts = str(ts)
-        with self._h5py.File(self.directory / f"{scene_id}.h5", "r") as f:
+        with self._open(self.scene_path(scene_id)) as f:
             g = f[ts]
-            d = {"scene_id": scene_id, "timestamp": int(ts), "pc0": g["lidar"][:], "pose0": g["pose"][:],
-                 "lidar_dt": g["lidar_dt"][:] if "lidar_dt" in g else np.zeros(g["lidar"].shape[0], np.float32)}
+            d = {"scene_id": scene_id, "timestamp": int(ts), "pc0": np.asarray(g["lidar"][:]), "pose0": np.asarray(g["pose"][:]),
+                 "lidar_dt": np.asarray(g["lidar_dt"][:]) if "lidar_dt" in g else np.zeros(g["lidar"].shape[0], np.float32)}
             if "ground_mask" in g:
-                d["gm0"] = g["ground_mask"][:].astype(bool)
+                d["gm0"] = np.asarray(g["ground_mask"][:]).astype(bool)        # the loader's rename (SURVEY 8b)
             for k in ("flow", "flow_is_valid", "flow_category_indices", "flow_instance_id", "lidar_id", "ego_motion"):
                 if k in g:
-                    d[k] = g[k][:]
+                    d[k] = np.asarray(g[k][:])
             for name in self.vis_name:
-                if name and name not in ("raw",) and name in g:
-                    d[name] = g[name][:]
-            nxt = self._next.get((scene_id, ts))
-            if nxt is not None and nxt in f:
-                d["pose1"] = f[nxt]["pose"][:]
-                d["pc1"] = f[nxt]["lidar"][:]
+                if name and name != "raw" and name in g:
+                    d[name] = np.asarray(g[name][:])
+            nxt = f[self._next[(scene_id, ts)]]
+            d["pose1"], d["pc1"] = np.asarray(nxt["pose"][:]), np.asarray(nxt["lidar"][:])
         return d
+
+
+def open_dataset(directory, vis_name="", eval: bool = False):  # noqa: A002
+    """The frame source behind ``HDF5Dataset(dir, vis_name=<res>, eval=True)`` at save_zip.py:111 / eval.py:279: the h5
+    scene files when the directory holds them, this package's npz container (``NpzDataset.write``) when it holds that."""
+    directory = Path(directory)
+    if any(directory.glob("*/*.npz")) and not any(directory.glob("*.h5")):
+        return NpzDataset(directory, vis_name=vis_name, eval=eval)
+    return HDF5Dataset(directory, vis_name=vis_name, eval=eval)

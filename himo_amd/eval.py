@@ -368,29 +368,38 @@ def chamfer_distance(pc1, pc2) -> float:
 
 
 def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo", res_name: str = "", comp_dis_zip: str = "",
-         batch_frames: int = 16, dataset=None):
-    from .dataset import HDF5Dataset
+         batch_frames: int = 16, dataset=None, file_name: str | None = None):
+    """eval.py:270-313.  Under ``torchrun`` sweep i is scored by rank i % world on its own GPU, the per-sweep contribution
+    logs are all-gathered once at the end and rank 0 alone prints / writes ``res-<data>.json``."""
+    from . import distenv
+    from .dataset import open_dataset
     from .save_zip import read_output_zip
     from .utils import check_valid
 
     data_name, eval_flag = check_valid(data_dir, res_name, comp_dis_zip)
-    metrics = InstanceMetrics(data_name=data_name)
-    if dataset is None:
-        dataset = HDF5Dataset(data_dir, vis_name=res_name if eval_flag == 2 else "", eval=True)
-    rank, world = 0, 1
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        rank, world = dist.get_rank(), dist.get_world_size()
-    mine = list(range(rank, len(dataset), world))
-    for lo in range(0, len(mine), batch_frames):
-        frames = [dataset[i] for i in mine[lo:lo + batch_frames]]
-        cds = None
-        if eval_flag == 1:
-            cds = [read_output_zip(comp_dis_zip, (f["scene_id"], str(f["timestamp"]))) for f in frames]
-        metrics.step_frames(frames, res_name=res_name, comp_dis=cds, keys=mine[lo:lo + batch_frames])
-    metrics.gather()
-    if rank == 0:
-        metrics.print(res_name=res_name, file_name=f"res-{data_name}.json")
+    with distenv.process_group() as (rank, world):
+        metrics = InstanceMetrics(data_name=data_name)
+        err = None
+        try:
+            if dataset is None:
+                dataset = open_dataset(data_dir, vis_name=res_name if eval_flag == 2 else "", eval=True)
+            mine = list(range(rank, len(dataset), world))
+            for lo in range(0, len(mine), batch_frames):
+                frames = [dataset[i] for i in mine[lo:lo + batch_frames]]
+                cds = None
+                if eval_flag == 1:
+                    cds = [read_output_zip(comp_dis_zip, (f["scene_id"], str(f["timestamp"]))) for f in frames]
+                metrics.step_frames(frames, res_name=res_name, comp_dis=cds, keys=mine[lo:lo + batch_frames])
+        except BaseException as e:
+            err = e
+        everyone = distenv.all_ranks_ok(err is None)
+        if err is not None:
+            raise err
+        if not everyone:
+            raise RuntimeError("another rank failed; no result file was written")
+        metrics.gather()
+        if rank == 0:
+            metrics.print(res_name=res_name, file_name=file_name or f"res-{data_name}.json")
     return metrics
 
 

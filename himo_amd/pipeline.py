@@ -57,7 +57,7 @@ class HiMoPipeline:
         self.net = net if net is not None else SeFlowNet(precision="f16x2" if self.auto else precision, **self._net_args)
         self.compdis = CompDisEngine(device=self.device)
         self._batch = None
-        self._key = None
+        self._bufs, self._turn = {}, 0
         self._finite = None          # device flag of the previous batch (fp16-split precision only)
 
     def _upload_small(self, host_bytes: np.ndarray) -> torch.Tensor:
@@ -77,40 +77,73 @@ class HiMoPipeline:
         slot[1].record(torch.cuda.current_stream(self.device))
         return out
 
+    def _rows(self, name: str, total: int, width: int | None, dtype=torch.float32) -> torch.Tensor:
+        """First ``total`` rows of a grow-only device buffer (reused from batch to batch; never keyed on object identity)."""
+        key = (name, width, self._turn)
+        buf = self._bufs.get(key)
+        if buf is None or buf.shape[0] < total:
+            cap = max(total, int(1.25 * buf.shape[0]) if buf is not None else 0)
+            buf = torch.empty((cap,) if width is None else (cap, width), dtype=dtype, device=self.device)
+            self._bufs[key] = buf
+        return buf[:total]
+
     def _batch_for(self, samples) -> FrameBatch:
-        """Ragged batch container over the pc0 sweeps of ``samples`` (rebuilt only when the batch changes)."""
-        key = tuple(id(s) for s in samples)
-        if self._key != key:
-            counts = [int(s.pc0.shape[0]) for s in samples]
-            offsets = np.zeros(len(samples) + 1, dtype=np.int64)
-            np.cumsum(counts, out=offsets[1:])
-            dev = self.device
-            # offsets and poses go up in ONE asynchronous copy from a small pinned ring: a pageable upload would block the
-            # launch thread until the previous batch's kernels have drained (a bubble per batch when batches change)
-            F = len(samples)
-            meta = np.concatenate([offsets.view(np.uint8), np.stack([s.pose0 for s in samples]).astype(np.float64).reshape(-1).view(np.uint8),
-                                   np.stack([s.pose1 for s in samples]).astype(np.float64).reshape(-1).view(np.uint8)])
-            meta_dev = self._upload_small(meta)
-            o_end, p_len = (F + 1) * 8, F * 128
-            self._batch = FrameBatch(
-                offsets_host=offsets, offsets=meta_dev[:o_end].view(torch.int64),
-                pose0=meta_dev[o_end:o_end + p_len].view(torch.float64).view(F, 4, 4),
-                pose1=meta_dev[o_end + p_len:o_end + 2 * p_len].view(torch.float64).view(F, 4, 4),
-                pc0=torch.cat([s.pc0 for s in samples], dim=0).contiguous(),
-                lidar_dt=torch.cat([s.lidar_dt for s in samples], dim=0).contiguous(),
-                flow=torch.empty((int(offsets[-1]), 3), dtype=torch.float32, device=dev),
-                meta=[(s.scene_id, s.timestamp) for s in samples])
-            self._out = {}
-            self._key = key
+        """Ragged batch container over the pc0 sweeps of ``samples``.  Rebuilt on EVERY call -- the sweeps are copied into
+        the batch buffers and the offsets / poses uploaded again -- because nothing cheap identifies "the same samples":
+        CPython reuses ``id()`` values as soon as an object is freed, so a streaming caller that builds its Samples on the
+        fly would otherwise be handed the previous batch's points and poses.  Only the device BUFFERS are reused: two sets
+        that alternate, so the tensors ``run`` returned for batch k stay intact while batch k+1 is in flight (a caller
+        draining results on a side stream) and are overwritten by batch k+2."""
+        self._turn ^= 1
+        counts = [int(s.pc0.shape[0]) for s in samples]
+        offsets = np.zeros(len(samples) + 1, dtype=np.int64)
+        np.cumsum(counts, out=offsets[1:])
+        T, F = int(offsets[-1]), len(samples)
+        width = int(samples[0].pc0.shape[1])
+        # offsets and poses go up in ONE asynchronous copy from a small pinned ring: a pageable upload would block the
+        # launch thread until the previous batch's kernels have drained (a bubble per batch)
+        meta = np.concatenate([offsets.view(np.uint8), np.stack([s.pose0 for s in samples]).astype(np.float64).reshape(-1).view(np.uint8),
+                               np.stack([s.pose1 for s in samples]).astype(np.float64).reshape(-1).view(np.uint8)])
+        meta_dev = self._upload_small(meta)
+        o_end, p_len = (F + 1) * 8, F * 128
+        pc0, dt = self._rows("pc0", T, width), self._rows("lidar_dt", T, None)
+        if F:
+            torch.cat([s.pc0 for s in samples], dim=0, out=pc0)
+            torch.cat([s.lidar_dt for s in samples], dim=0, out=dt)
+        self._batch = FrameBatch(
+            offsets_host=offsets, offsets=meta_dev[:o_end].view(torch.int64),
+            pose0=meta_dev[o_end:o_end + p_len].view(torch.float64).view(F, 4, 4),
+            pose1=meta_dev[o_end + p_len:o_end + 2 * p_len].view(torch.float64).view(F, 4, 4),
+            pc0=pc0, lidar_dt=dt, flow=self._rows("flow", T, 3),
+            meta=[(s.scene_id, s.timestamp) for s in samples])
         return self._batch
 
-    def flows(self, samples) -> list:
-        """Network only, for a list of samples: [(N0_k,3) flow incl. ego motion], ``max_batch`` samples per backbone launch."""
-        outs = [torch.empty((s.pc0.shape[0], 3), dtype=torch.float32, device=self.device) for s in samples]
+    def _forward(self, samples, outs) -> None:
+        """Network forward for ``samples`` into the per-sample (N0_k,3) views ``outs``, ``max_batch`` samples per backbone launch."""
         mb = self.net.max_batch
         for lo in range(0, len(samples), mb):
             grp = samples[lo:lo + mb]
             self.net.forward_batch([(s.pch1, s.pc0, s.pc1, s.pose_h1, s.pose0, s.pose1) for s in grp], outs[lo:lo + mb])
+
+    def _fall_back(self):
+        """precision="auto": leave the fp16 split for the bf16 split (float32 range) for good"""
+        self.net = SeFlowNet(precision="bf16x3", **self._net_args)
+
+    def flows(self, samples) -> list:
+        """Network only, for a list of samples: [(N0_k,3) flow incl. ego motion] -- the h5 ``<res_name>`` payload that
+        ``save.run`` writes.  In the fp16 split every call checks its flows for non-finite values BEFORE returning them (one
+        host sync per call): ``precision="auto"`` redoes the batch in the bf16 split and stays there, an explicit
+        ``"f16x2"`` raises FloatingPointError -- an overflowed activation never reaches a result file."""
+        counts = [int(s.pc0.shape[0]) for s in samples]
+        flat = torch.empty((sum(counts), 3), dtype=torch.float32, device=self.device)
+        outs = list(torch.split(flat, counts)) if counts else []
+        self._forward(samples, outs)
+        if self.net.precision == "f16x2" and not bool(torch.isfinite(flat).all().item()):
+            if not self.auto:
+                raise FloatingPointError("non-finite flow: activations left the fp16 range of precision='f16x2'; "
+                                         "use precision='bf16x3' (or 'auto') for these weights")
+            self._fall_back()
+            self._forward(samples, outs)
         return outs
 
     def sync_check(self):
@@ -134,20 +167,18 @@ class HiMoPipeline:
         o = batch.offsets_host
         self.sync_check()                                    # the PREVIOUS batch's flag: no stall on this one
 
-        def network():
-            mb = self.net.max_batch
-            for lo in range(0, len(samples), mb):               # groups of max_batch samples share every backbone launch
-                grp = samples[lo:lo + mb]
-                self.net.forward_batch([(s.pch1, s.pc0, s.pc1, s.pose_h1, s.pose0, s.pose1) for s in grp],
-                                       [batch.flow[int(o[lo + k]):int(o[lo + k + 1])] for k in range(len(grp))])
-
-        network()
+        outs = [batch.flow[int(o[k]):int(o[k + 1])] for k in range(len(samples))]
+        self._forward(samples, outs)
         if self.net.precision == "f16x2":
             finite = torch.isfinite(batch.flow).all()
             if not self.auto:
                 self._finite = finite                            # checked one batch late (sync_check)
             elif not bool(finite.item()):                        # auto: checked now (one host sync per batch)
-                self.net = SeFlowNet(precision="bf16x3", **self._net_args)
-                network()
-        res = self.compdis.run(batch, sensor_dt=sensor_dt, refined=refined, out=self._out)
+                self._fall_back()
+                self._forward(samples, outs)
+        T = batch.total_points
+        out = {"comp_dis": self._rows("comp_dis", T, 3)}
+        if refined:
+            out["refined"] = self._rows("refined", T, 3)
+        res = self.compdis.run(batch, sensor_dt=sensor_dt, refined=refined, out=out)
         return {"flow": batch.flow, "comp_dis": res["comp_dis"], "refined": res.get("refined"), "batch": batch}

@@ -5,9 +5,11 @@ which is exactly what ``save_zip.py:117`` / ``eval.py:302`` read back.
 
 The reference's ``save.py`` itself is in the absent submodule, so only the data contract is reproduced: the key
 name defaults to the checkpoint's stem (``seflowpp_best`` for ``seflowpp_best.ckpt``, README.md:50), frames are
-walked in dataset order, and under ``torchrun`` frame i goes to rank i % world.  Results are written through a
-``sink(frame_index, frame, flow)`` callable: ``NpzResultSink`` rewrites the frame's npz, ``dict_sink`` keeps them
-in memory; an h5 sink needs ``h5py`` (not installed here).
+walked in dataset order, and under ``torchrun`` frame i goes to rank i % world (h5 scene files: scene k goes to rank
+k % world, so every file has exactly one writer).  Results are written through a ``sink(frame_index, frame, flow)``
+callable: ``NpzResultSink`` rewrites the frame's npz, ``H5ResultSink`` creates / replaces the ``<res_name>`` dataset in
+group ``<timestamp>`` of ``<scene_id>.h5`` (the dataset ``tools/test/repack_h5_scania.py:50`` deletes by name; needs
+``h5py``), no sink keeps them in memory.
 """
 from __future__ import annotations
 
@@ -43,9 +45,54 @@ class NpzResultSink:
         os.replace(tmp, path)
 
 
-def frame_source(dataset, rank: int = 0, world: int = 1):
-    """(index, history frame, frame, next frame | None) for every frame of this rank that has a next sweep to flow into."""
-    for i in range(rank, len(dataset), world):
+class H5ResultSink:
+    """``(N,3) float32`` under ``<scene_id>.h5 : <timestamp>/<res_name>`` (consumers: save_zip.py:117 via the
+    loader's ``vis_name``, eval.py:302).  A scene's results are held back until the walk has moved on to the next scene
+    (frames arrive in dataset order and the reader runs ahead of the results, never behind), so the file is never open for
+    reading by the loader and for writing here at the same time; ``close()`` writes what is left."""
+
+    def __init__(self, directory, res_name: str, opener=None):
+        from .dataset import require_h5py
+        self.directory, self.res_name = Path(directory), res_name
+        self._open = opener if opener is not None else (lambda path: require_h5py().File(path, "a"))
+        if opener is None:
+            require_h5py()
+        self._scene, self._pending = None, []
+
+    def __call__(self, index: int, frame: dict, flow: np.ndarray):
+        if frame["scene_id"] != self._scene:
+            self.flush()
+            self._scene = frame["scene_id"]
+        if flow.shape != (len(frame["pc0"]), 3):
+            raise ValueError(f"flow {flow.shape} is not row-aligned with pc0 ({len(frame['pc0'])} points)")   # score.py:583
+        self._pending.append((str(frame["timestamp"]), np.ascontiguousarray(flow, dtype=np.float32)))
+
+    def flush(self):
+        if self._pending:
+            with self._open(self.directory / f"{self._scene}.h5") as f:
+                for ts, flow in self._pending:
+                    g = f[ts]
+                    if self.res_name in g:
+                        del g[self.res_name]                       # re-running a checkpoint replaces its result
+                    g.create_dataset(self.res_name, data=flow)
+            self._pending = []
+
+    def close(self):
+        self.flush()
+
+
+def frame_source(dataset, rank: int = 0, world: int = 1, by_scene: bool = False):
+    """(index, history frame, frame, next frame | None) for every frame of this rank that has a next sweep to flow into.
+    ``by_scene``: shard whole scenes (scene k of the walk -> rank k % world) instead of frames."""
+    index = getattr(dataset, "index", None)
+    if by_scene and index is not None:
+        scenes = {}
+        for s, _ in index:
+            scenes.setdefault(s, len(scenes))
+        mine = [i for i, (s, _) in enumerate(index) if scenes[s] % world == rank]
+    else:
+        mine = range(rank, len(dataset), world)
+    for i in mine:
         f0 = dataset[i]
         if "pc1" not in f0:
             if i + 1 >= len(dataset) or dataset[i + 1].get("scene_id") != f0.get("scene_id"):
@@ -57,11 +104,12 @@ def frame_source(dataset, rank: int = 0, world: int = 1):
 
 
 def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, sink=None, pipeline: HiMoPipeline | None = None,
-        batch_frames: int = 4) -> int:
+        batch_frames: int = 4, by_scene: bool = False) -> int:
     """Flow for every frame of ``dataset`` that has a ``pc1`` / next sweep.  Returns the frames this rank processed.
     Frames are read, staged in pinned memory and copied to the device by a background thread two batches ahead of the
     network (``feeder.SampleFeeder``); results leave through pinned buffers and a writer thread (``feeder.ResultDrain``),
-    so neither the dataset reads nor the sink's file writes stall the launch thread."""
+    so neither the dataset reads nor the sink's file writes stall the launch thread.  ``HiMoPipeline.flows`` checks every
+    batch for fp16-range overflow before it is handed to the sink (auto: redone in the bf16 split)."""
     import torch.distributed as dist
     from .feeder import ResultDrain, SampleFeeder
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
@@ -78,28 +126,42 @@ def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, si
     drain = ResultDrain(deliver, device=pipe.device)
     done = 0
     try:
-        for batch in SampleFeeder(frame_source(dataset, rank, world), device=pipe.device, batch=max(1, batch_frames)):
+        for batch in SampleFeeder(frame_source(dataset, rank, world, by_scene=by_scene), device=pipe.device, batch=max(1, batch_frames)):
             for (i, f0, _), flow in zip(batch, pipe.flows([s for _, _, s in batch])):
                 drain.put((i, f0), flow)
                 done += 1
     finally:
         drain.close()
+        if hasattr(sink, "close"):
+            sink.close()
     return results if sink is None else done
 
 
 def main(checkpoint: str = "", dataset_path: str = "", res_name: str = ""):
-    from .dataset import HDF5Dataset, NpzDataset
+    """``python -m himo_amd.save --checkpoint <weights.npz> --dataset_path <dir>``; under ``torchrun`` one rank per GPU."""
+    from . import distenv
+    from .dataset import NpzDataset, open_dataset
     name = res_name or (Path(checkpoint).stem if checkpoint else "seflowpp_best")
     params = None
     if checkpoint:
-        with np.load(checkpoint) as z:                        # an .npz of the arrays named in seflow/spec.py
-            params = {k: z[k] for k in z.files}
+        from .seflow.checkpoint import load_params
+        params = load_params(checkpoint)
     root = Path(dataset_path)
-    if (root / "index_total.pkl").exists() and any(root.glob("*/*.npz")):
-        ds = NpzDataset(root)
-        return run(ds, name, params, sink=NpzResultSink(root, name))
-    ds = HDF5Dataset(root, vis_name=name, eval=False)         # raises a clear ImportError without h5py
-    raise NotImplementedError("writing results back into .h5 needs h5py, which is not installed in this image")
+    with distenv.process_group():
+        ds = open_dataset(root, vis_name=name, eval=False)
+        npz = isinstance(ds, NpzDataset)
+        sink = NpzResultSink(root, name) if npz else H5ResultSink(root, name)
+        done, err = 0, None
+        try:
+            done = run(ds, name, params, sink=sink, by_scene=not npz)
+        except BaseException as e:                              # arrive at the rendezvous anyway, then re-raise
+            err = e
+        everyone = distenv.all_ranks_ok(err is None)
+        if err is not None:
+            raise err
+        if not everyone:
+            raise RuntimeError("another rank failed while writing flow results; this rank's share is complete")
+        return done
 
 
 if __name__ == "__main__":

@@ -123,18 +123,31 @@ def run_dataset(dataset, res_name: str, output_dir: Path, batch_frames: int = 32
 
 def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo/demo", res_name: str = "seflowpp_best",
          batch_frames: int = 32):
-    from .dataset import HDF5Dataset
+    """save_zip.py:102-125.  Under ``torchrun`` (one rank per GPU) the sweeps are sharded i % world, every rank writes its
+    own Feather files, and rank 0 zips once all of them are on disk (distenv.process_group joins / leaves the job's group;
+    a rank that fails still reaches the rendezvous, so nobody zips a partial result or waits for a dead process)."""
+    from . import distenv
+    from .dataset import open_dataset
 
     data_dir = Path(data_dir)
     output_dir = data_dir / "results"
     output_dir.mkdir(exist_ok=True, parents=True)
-    dataset = HDF5Dataset(data_dir, vis_name=res_name, eval=True)
-    run_dataset(dataset, res_name, output_dir, batch_frames=batch_frames)
-    rank, world, dist = _dist()
-    if dist is not None:
-        dist.barrier()                                                    # every rank's files are on disk
-    if rank == 0:
-        zip_res(output_dir, output_file=f"{output_dir}/{res_name}-submit.zip")
+    with distenv.process_group() as (rank, world):
+        err = None
+        try:
+            dataset = open_dataset(data_dir, vis_name=res_name, eval=True)
+            run_dataset(dataset, res_name, output_dir, batch_frames=batch_frames)
+        except BaseException as e:
+            err = e
+        everyone = distenv.all_ranks_ok(err is None)            # every rank's files are on disk -- or somebody failed
+        if err is not None:
+            raise err
+        if not everyone:
+            raise RuntimeError("another rank failed; no submit zip was written")
+        if rank == 0:
+            zip_res(output_dir, output_file=f"{output_dir}/{res_name}-submit.zip")
+        if world > 1:
+            distenv.all_ranks_ok(True)                           # nobody leaves before the zip exists
 
 
 def _cli(argv=None):

@@ -92,19 +92,30 @@ class ScoreMetrics:
             return
         if self._evaluator is None:
             self._evaluator = InstanceEvaluator()
+        min_vel = 1.5 if data_name == "scania" else 3.0
+        # The reference decides PER SWEEP whether the velocity filter and the pc0 offset apply (score.py:291-296, :270-283:
+        # ``if gt_flow_norm is not None`` / ``if pc0 is not None``), so sweeps only share a launch with sweeps of the same
+        # kind; the per-sweep results are then accumulated in the original sweep order.
+        kinds = {}
+        for k, sw in enumerate(sweeps):
+            kinds.setdefault((sw[5] is not None, sw[6] is not None), []).append(k)
+        per_sweep = [None] * len(sweeps)
+        for (have_norm, have_pc0), members in kinds.items():
+            recs = self._run_group([sweeps[k] for k in members], have_norm, have_pc0, sensor_dt)
+            bounds = np.searchsorted(recs["frame"], np.arange(len(members) + 1))
+            for j, k in enumerate(members):
+                per_sweep[k] = (recs[bounds[j]:bounds[j + 1]], have_norm)
+        for recs, have_norm in per_sweep:
+            self._accumulate(recs, min_vel, have_norm)
+
+    def _run_group(self, sweeps, have_norm: bool, have_pc0: bool, sensor_dt: float):
         ev, dev = self._evaluator, self._evaluator.device
         counts = [len(s[0]) for s in sweeps]
         offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)).to(dev)
         cat = lambda k, dt: torch.from_numpy(np.ascontiguousarray(np.concatenate([np.asarray(s[k]).astype(dt) for s in sweeps]))).to(dev)
-        have_norm = all(s[5] is not None for s in sweeps)
-        have_pc0 = all(s[6] is not None for s in sweeps)
-        recs = ev.run(len(sweeps), offsets, cat(6, np.float32) if have_pc0 else None, cat(0, np.float32), cat(1, np.float32),
+        return ev.run(len(sweeps), offsets, cat(6, np.float32) if have_pc0 else None, cat(0, np.float32), cat(1, np.float32),
                       cat(5, np.float32) if have_norm else None, cat(3, np.uint8), cat(4, np.int64), cat(2, np.uint8),
                       MODE_SCORE, sensor_dt=sensor_dt)
-        min_vel = 1.5 if data_name == "scania" else 3.0
-        bounds = np.searchsorted(recs["frame"], np.arange(len(sweeps) + 1))
-        for k in range(len(sweeps)):
-            self._accumulate(recs[bounds[k]:bounds[k + 1]], min_vel, have_norm)
 
     def _accumulate(self, recs, min_vel, have_norm):
         frame_score = {c: {r: {"num_pts": [], "mpe": [], "cham": []} for r in RANGES} for c in EVAL_GROUPS}

@@ -34,6 +34,25 @@ def _yaw_pose(yaw: float, tx: float, ty: float) -> np.ndarray:
     return pose
 
 
+GROUND_Z = -1.8          # ground plane of the "rings" cloud (sensor at the origin, 1.8 m above it)
+
+
+def lidar_rings(rng, n: int, n_beams: int = 64) -> np.ndarray:
+    """(n,3) float64 returns of a spinning multi-beam LiDAR at the origin: ``n_beams`` elevation angles between -25 and
+    +15 degrees, uniform azimuth; a downward ray ends on the ground plane or on the first vertical surface of its azimuth
+    sector (walls 12-70 m out), an upward ray on that surface.  The result has what real sweeps have and a uniform cloud
+    lacks: concentric ground rings whose spacing grows with range, hundreds of points per 0.2 m cell near the sensor,
+    and most of the 512 x 512 grid empty; returns beyond +-51.2 m / above 3 m exist and fall outside the network range."""
+    elev = np.deg2rad(np.linspace(-25.0, 15.0, n_beams))[rng.integers(0, n_beams, n)] + rng.normal(0.0, 2e-4, n)
+    az = rng.uniform(-np.pi, np.pi, n)
+    n_sectors = 72
+    wall = rng.uniform(12.0, 70.0, n_sectors)[((az + np.pi) / (2 * np.pi) * n_sectors).astype(np.int64) % n_sectors]
+    with np.errstate(divide="ignore"):
+        ground = np.where(elev < 0, -GROUND_Z / np.tan(-elev), np.inf)
+    r = np.minimum(ground, wall) + rng.normal(0.0, 0.02, n)
+    return np.stack([r * np.cos(az), r * np.sin(az), r * np.tan(elev)], axis=1)
+
+
 def make_frame(
     frame_idx: int,
     n_points: int = 120_000,
@@ -42,18 +61,26 @@ def make_frame(
     scene_id: str | None = None,
     est_noise: float = 0.05,
     data_name: str = "av2",
+    cloud: str = "uniform",
 ) -> dict:
     """One synthetic sweep as a reference-style frame dict.
 
     ``flow`` includes ego-motion (the reference subtracts ``pose_flow`` from it,
     save_zip.py:117); ``<res_name>`` is an "estimated" flow = GT + N(0, est_noise).
+    ``cloud``: "uniform" = SURVEY.md 8(d) (xyz uniform in the network range); "rings" = a spinning-LiDAR-like
+    background (``lidar_rings``): range-dependent density, crowded cells near the sensor, empty space far out.
     """
     rng = np.random.default_rng(frame_idx)
     n = int(n_points)
     lo = np.array(POINT_CLOUD_RANGE[:3], dtype=np.float64)
     hi = np.array(POINT_CLOUD_RANGE[3:], dtype=np.float64)
 
-    xyz = rng.uniform(lo, hi, size=(n, 3))
+    if cloud == "uniform":
+        xyz = rng.uniform(lo, hi, size=(n, 3))
+    elif cloud == "rings":
+        xyz = lidar_rings(rng, n)
+    else:
+        raise ValueError(f"cloud={cloud!r}")
     category = np.zeros(n, dtype=np.uint8)
     instance = np.zeros(n, dtype=np.uint32)
     obj_flow = np.zeros((n, 3), dtype=np.float64)
@@ -98,7 +125,7 @@ def make_frame(
     flow = (pose_flow + obj_flow + rng.normal(0.0, 0.02, size=(n, 3)) * (instance[:, None] > 0)).astype(np.float32)
     est = (flow + rng.normal(0.0, est_noise, size=(n, 3)) * (instance[:, None] > 0)).astype(np.float32)
 
-    gm0 = (pc0[:, 2] < -2.6) & (instance == 0)
+    gm0 = (pc0[:, 2] < (-2.6 if cloud == "uniform" else GROUND_Z + 0.12)) & (instance == 0)
     flow_is_valid = rng.uniform(size=n) > 0.01
 
     return {

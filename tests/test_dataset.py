@@ -1,0 +1,175 @@
+"""Frame sources and result sinks at the h5 boundary: index handling on the reference's own frame
+lists, the loader's key renaming and successor logic, the ``<res_name>`` result dataset.  ``h5py`` is absent from the build
+image, so the logic runs through the ``opener`` hook on an in-memory scene mapping; wherever h5py exists the same checks
+run on real files (importorskip)."""
+import json
+import pickle
+from contextlib import contextmanager
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from himo_amd import save
+from himo_amd.dataset import HDF5Dataset, NpzDataset, load_index, open_dataset
+from himo_amd.synthetic import make_frame
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def _scene_groups(frames):
+    """frames -> {scene: {timestamp: {h5 dataset name: array}}} with the on-disk names / dtypes of
+    dataprocess/extract_sca.py:76-93 and tools/test/repack_h5_scania.py:23-36"""
+    scenes = {}
+    for f in frames:
+        g = {"lidar": f["pc0"], "lidar_dt": f["lidar_dt"], "lidar_id": f["lidar_id"], "pose": f["pose0"],
+             "ground_mask": f["gm0"], "flow": f["flow"], "flow_is_valid": f["flow_is_valid"],
+             "flow_category_indices": f["flow_category_indices"], "flow_instance_id": f["flow_instance_id"]}
+        scenes.setdefault(f["scene_id"], {})[str(f["timestamp"])] = g
+    return scenes
+
+
+def _memory_opener(scenes, log=None):
+    @contextmanager
+    def opener(path):
+        if log is not None:
+            log.append(Path(path).name)
+        yield scenes[Path(path).stem]
+    return opener
+
+
+def _dataset_dir(tmp_path, frames, eval_subset=None):
+    index = [[f["scene_id"], str(f["timestamp"])] for f in frames]
+    with open(tmp_path / "index_total.pkl", "wb") as fh:
+        pickle.dump(index, fh)
+    if eval_subset is not None:
+        with open(tmp_path / "index_eval.pkl", "wb") as fh:
+            pickle.dump([index[i] for i in eval_subset], fh)
+    return index
+
+
+def test_reference_frame_lists_load_and_every_eval_frame_has_a_successor(tmp_path):
+    """The reference's own index files (BASELINE config 2's frame list): 70 eval frames of 13 scenes, all of which have a
+    next sweep in index_total -- so dropping successor-less frames loses none of them."""
+    idx = json.loads((GOLDEN / "av2_index.json").read_text())
+    for name in ("index_eval", "index_total"):
+        with open(tmp_path / f"{name}.pkl", "wb") as fh:
+            pickle.dump(idx[name], fh)
+    ev, total = load_index(tmp_path, eval=True), load_index(tmp_path)
+    assert len(ev) == 70 and len({s for s, _ in ev}) == 13 and len(total) == 2040
+    assert all(isinstance(s, str) and isinstance(t, str) for s, t in ev)
+    ds = HDF5Dataset(tmp_path, vis_name="seflowpp_best", eval=True, opener=_memory_opener({}))
+    assert len(ds) == 70 and ds.index == ev
+    full = HDF5Dataset(tmp_path, opener=_memory_opener({}))
+    assert len(full) == 2040 - 13                                  # the last sweep of each scene cannot be compensated
+    nxt = {(s, t): t1 for (s, t), (s1, t1) in zip(total[:-1], total[1:]) if s == s1}
+    assert all(int(nxt[(s, t)]) > int(t) for s, t in ev)
+
+
+def test_hdf5_dataset_logic_through_the_opener_hook(tmp_path):
+    frames = [make_frame(i, n_points=50 + i, scene_id=f"scene{i // 3}") for i in range(6)]     # two scenes of three sweeps
+    flow_name = "seflowpp_best"
+    scenes = _scene_groups(frames)
+    for f in frames:
+        scenes[f["scene_id"]][str(f["timestamp"])][flow_name] = f[flow_name]
+    _dataset_dir(tmp_path, frames, eval_subset=[0, 2, 4])
+    log = []
+    ds = HDF5Dataset(tmp_path, vis_name=flow_name, opener=_memory_opener(scenes, log))
+    assert len(ds) == 4                                            # frames 2 and 5 end their scenes
+    d = ds[1]
+    assert log == ["scene0.h5"]
+    assert d["scene_id"] == "scene0" and d["timestamp"] == frames[1]["timestamp"] and isinstance(d["timestamp"], int)
+    assert np.array_equal(d["pc0"], frames[1]["pc0"]) and np.array_equal(d["pose0"], frames[1]["pose0"])
+    assert np.array_equal(d["pose1"], frames[2]["pose0"]) and np.array_equal(d["pc1"], frames[2]["pc0"])   # successor's pose / points
+    assert d["gm0"].dtype == bool and np.array_equal(d["gm0"], frames[1]["gm0"]) and "ground_mask" not in d   # the loader's rename
+    assert np.array_equal(d[flow_name], frames[1][flow_name]) and d["lidar_dt"].dtype == np.float32
+    for k in ("flow", "flow_is_valid", "flow_category_indices", "flow_instance_id", "lidar_id"):
+        assert np.array_equal(d[k], frames[1][k]), k
+    ev = HDF5Dataset(tmp_path, vis_name=flow_name, eval=True, opener=_memory_opener(scenes))
+    assert [t for _, t in ev.index] == [str(frames[0]["timestamp"]), str(frames[4]["timestamp"])]      # frame 2 has no successor
+    raw = HDF5Dataset(tmp_path, vis_name="raw", opener=_memory_opener(scenes))[0]
+    assert flow_name not in raw
+    # the frames it yields are exactly what the comp_dis path consumes
+    from himo_amd.compdis import FrameBatch
+    import torch
+    b = FrameBatch.from_frames([ds[0], ds[1]], flow_name, device=torch.device("cpu"), with_masks=True)
+    assert b.total_points == 50 + 51
+
+
+def test_h5_result_sink_writes_res_name_per_timestamp_and_only_after_the_scene(tmp_path):
+    frames = [make_frame(i, n_points=40, scene_id=f"scene{i // 3}") for i in range(6)]
+    scenes = _scene_groups(frames)
+
+    class Group(dict):                                            # the three h5py.Group calls the sink makes
+        def create_dataset(self, name, data):
+            self[name] = np.array(data)
+
+    store = {s: {ts: Group(g) for ts, g in gs.items()} for s, gs in scenes.items()}
+    opened = []
+
+    @contextmanager
+    def opener(path):
+        opened.append(Path(path).name)
+        yield store[Path(path).stem]
+
+    sink = save.H5ResultSink(tmp_path, "seflowpp_best", opener=opener)
+    flows = [np.full((40, 3), i, np.float64) for i in range(6)]
+    for i in (0, 1):
+        sink(i, frames[i], flows[i])
+    assert opened == []                                            # scene0 may still be open for reading
+    sink(3, frames[3], flows[3])
+    assert opened == ["scene0.h5"]
+    sink.close()
+    assert opened == ["scene0.h5", "scene1.h5"]
+    for i in (0, 1, 3):
+        got = store[frames[i]["scene_id"]][str(frames[i]["timestamp"])]["seflowpp_best"]
+        assert got.dtype == np.float32 and got.shape == (40, 3) and (got == i).all()
+    assert "seflowpp_best" not in store["scene0"][str(frames[2]["timestamp"])]
+    sink(0, frames[0], flows[5])                                   # re-running a checkpoint replaces its dataset
+    sink.close()
+    assert (store["scene0"][str(frames[0]["timestamp"])]["seflowpp_best"] == 5).all()
+    with pytest.raises(ValueError):
+        sink(1, frames[1], np.zeros((39, 3)))                      # not row-aligned with pc0 (score.py:583)
+
+
+def test_frame_source_shards_whole_scenes_for_h5(tmp_path):
+    frames = [make_frame(i, n_points=30, scene_id=f"scene{i // 3}") for i in range(9)]
+    _dataset_dir(tmp_path, frames)
+    ds = HDF5Dataset(tmp_path, opener=_memory_opener(_scene_groups(frames)))
+    seen = []
+    for rank in range(2):
+        mine = [(f0["scene_id"], i) for i, _, f0, _ in save.frame_source(ds, rank, 2, by_scene=True)]
+        assert {s for s, _ in mine} == ({"scene0", "scene2"} if rank == 0 else {"scene1"})     # one writer per scene file
+        seen += [i for _, i in mine]
+    assert sorted(seen) == list(range(len(ds)))
+    i, fh, f0, f1 = next(iter(save.frame_source(ds, 0, 1)))
+    assert f1 is None and "pc1" in f0 and fh is f0 or fh["scene_id"] == f0["scene_id"]
+
+
+def test_open_dataset_picks_the_container(tmp_path):
+    frames = [make_frame(i, n_points=30) for i in range(3)]
+    NpzDataset.write(tmp_path, frames)
+    assert isinstance(open_dataset(tmp_path, vis_name="x", eval=True), NpzDataset)
+
+
+def test_real_h5_files_round_trip(tmp_path):
+    """Where h5py exists: the extract_sca.py:76-93 schema on disk -> HDF5Dataset -> H5ResultSink -> read back as <res_name>."""
+    h5py = pytest.importorskip("h5py")
+    frames = [make_frame(i, n_points=64 + i, scene_id=f"scene{i // 3}") for i in range(6)]
+    for scene, groups in _scene_groups(frames).items():
+        with h5py.File(tmp_path / f"{scene}.h5", "w") as f:
+            for ts, arrays in groups.items():
+                g = f.create_group(ts)
+                for name, a in arrays.items():
+                    g.create_dataset(name, data=a)
+    _dataset_dir(tmp_path, frames)
+    ds = HDF5Dataset(tmp_path, vis_name="seflowpp_best")
+    assert len(ds) == 4 and np.array_equal(ds[0]["pc0"], frames[0]["pc0"]) and np.array_equal(ds[0]["pose1"], frames[1]["pose0"])
+    sink = save.H5ResultSink(tmp_path, "seflowpp_best")
+    for i in range(len(ds)):
+        f0 = ds[i]
+        sink(i, f0, np.full((len(f0["pc0"]), 3), i, np.float32))
+    sink.close()
+    again = HDF5Dataset(tmp_path, vis_name="seflowpp_best")
+    for i in range(len(again)):
+        assert (again[i]["seflowpp_best"] == i).all() and again[i]["seflowpp_best"].dtype == np.float32

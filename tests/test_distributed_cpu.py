@@ -130,17 +130,17 @@ def _worker_bench(rank, world, port, out_dir):
     _init(rank, world, port)
     sys.argv = ["bench.py"]
     import bench
-    elapsed, total = bench.reduce_job(0.5 + rank, 80 * (rank + 1), torch.device("cpu"), world, rank)
-    Path(out_dir, f"b{rank}.json").write_text(json.dumps([elapsed, total]))
+    elapsed, total, per_rank = bench.reduce_job(0.5 + rank, 80 * (rank + 1), torch.device("cpu"), world, rank)
+    Path(out_dir, f"b{rank}.json").write_text(json.dumps([elapsed, total, per_rank]))
     dist.destroy_process_group()
 
 
 def test_bench_reduction_is_max_time_and_total_frames(tmp_path):
     mp.spawn(_worker_bench, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    e0, t0 = json.loads(Path(tmp_path, "b0.json").read_text())
-    e1, t1 = json.loads(Path(tmp_path, "b1.json").read_text())
+    e0, t0, p0 = json.loads(Path(tmp_path, "b0.json").read_text())
+    e1, t1, p1 = json.loads(Path(tmp_path, "b1.json").read_text())
     assert e0 == e1 == 1.5            # max over ranks
-    assert t0 == 240 and t1 == 0      # whole-job frame count lands on rank 0
+    assert t0 == t1 == 240 and p0 == p1 == [80, 160]      # whole-job frame count + what every rank did
 
 
 def _worker_grad_allreduce(rank, world, port, out_dir):
@@ -159,3 +159,150 @@ def test_training_gradient_exchange_is_one_mean_allreduce(tmp_path):
     for r in range(2):
         got = np.frombuffer(Path(tmp_path, f"g{r}.npy").read_bytes(), np.float32)
         assert np.array_equal(got, want)
+
+
+# ---- bench.py --gpus N: the self-launch path -------------------------------------------------------------------------
+def _run_bench(argv, env_extra=None, timeout=240):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(REPO / "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("workload", ["pipeline", "train"])
+def test_bench_gpus_n_self_launches_n_ranks(workload):
+    """``python bench.py --gpus 2`` outside torchrun must start TWO ranks (the driver's SCALE command line is exactly this),
+    take the max-over-ranks time and report n_gpus: 2 with both ranks' frame counts.  --dry-run-cpu swaps only the device
+    work (host stand-in; gloo for RCCL): launch, barrier, timing, gather and the JSON line are the real code.  For the
+    train workload the stand-in step runs the real gradient exchange (allreduce_mean_) and checks its result."""
+    r = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", workload, "--dry-run-cpu"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 alone prints
+    line = json.loads(lines[0])
+    per_step = 16 if workload == "pipeline" else 1
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["frames_per_rank"] == [4 * per_step, 4 * per_step]
+    assert line["value"] == pytest.approx(2 * 4 * per_step / (line["ms_per_step"] * 4e-3), rel=1e-6)
+    assert "INVALID" in line["data"] and "cpu_baseline" not in line       # a dry run can never pass for a measurement
+
+
+def test_bench_refuses_a_world_that_disagrees_with_gpus():
+    r = _run_bench(["--gpus", "2", "--dry-run-cpu"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "must agree" in r.stderr
+    r = _run_bench(["--gpus", "2"])                              # no HIP devices here: fails loudly instead of measuring N=1
+    assert r.returncode != 0 and "HIP device" in r.stderr
+
+
+# ---- the command-line entry points under torchrun-style environments ---------------------------------------------
+def _cli_env(rank, world, port):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "LOCAL_RANK": str(rank),
+                       "WORLD_SIZE": str(world)})
+    sys.path.insert(0, str(REPO))
+    sys.path.insert(0, str(REPO / "oracle"))
+
+
+def _cpu_compdis_double():
+    """test double for the device arithmetic of save_zip.run_dataset (the oracle computes; host logic is the real one)"""
+    import himo_oracle as oracle
+    from himo_amd import compdis
+
+    class CpuEngine:
+        def __init__(self, *a, **k):
+            pass
+
+        def run(self, batch, sensor_dt=0.1, **k):
+            cds = [oracle.comp_dis_frame_f32(f, "seflowpp_best", sensor_dt) for f in batch._frames]
+            return {"comp_dis": torch.from_numpy(np.concatenate(cds))}
+
+    real = compdis.FrameBatch.from_frames.__func__
+
+    def from_frames(cls, frames, res_name="seflowpp_best", device=None, with_masks=False):
+        b = real(cls, frames, res_name, device=torch.device("cpu"), with_masks=with_masks)
+        b._frames = list(frames)
+        return b
+
+    compdis.CompDisEngine = CpuEngine
+    compdis.FrameBatch.from_frames = classmethod(from_frames)
+
+
+def _worker_save_zip_cli(rank, world, port, data_dir, fail_rank):
+    _cli_env(rank, world, port)
+    _cpu_compdis_double()
+    from himo_amd import save_zip
+    if rank == fail_rank:
+        real = save_zip.write_output_file
+
+        def broken(*a, **k):
+            raise OSError("disk full on this rank")
+        save_zip.write_output_file = broken
+    try:
+        save_zip._cli(["--data_dir", data_dir, "--res_name", "seflowpp_best", "--batch_frames", "2"])
+        Path(data_dir, f"ok{rank}").write_text("done")
+    except BaseException as e:
+        Path(data_dir, f"err{rank}").write_text(type(e).__name__)
+    assert not dist.is_initialized()                             # the entry point left the group it joined
+
+
+def _write_npz_dataset(root, n=7):
+    from himo_amd.dataset import NpzDataset
+    from himo_amd.synthetic import make_frame
+    frames = [make_frame(i, n_points=400 + 13 * i, scene_id=f"scene{i // 4}") for i in range(n)]
+    NpzDataset.write(root, frames)
+    return frames
+
+
+def test_save_zip_cli_under_torchrun_env_shards_and_zips_once(tmp_path):
+    """``torchrun -m himo_amd.save_zip``: the entry point itself joins the process group (nothing else does), every rank
+    writes ITS sweeps only, rank 0 zips after the rendezvous."""
+    sys.path.insert(0, str(REPO / "oracle"))
+    import himo_oracle as oracle
+    from himo_amd.save_zip import read_output_zip
+    root = tmp_path / "av2" / "demo"
+    frames = _write_npz_dataset(root)
+    mp.spawn(_worker_save_zip_cli, args=(2, _free_port(), str(root), -1), nprocs=2, join=True)
+    assert (root / "ok0").exists() and (root / "ok1").exists()
+    z = root / "results" / "seflowpp_best-submit.zip"
+    from zipfile import ZipFile
+    with ZipFile(z) as zf:
+        assert len(zf.namelist()) == len(frames)
+    for f in frames:
+        cd = read_output_zip(str(z), (f["scene_id"], str(f["timestamp"])))
+        assert np.array_equal(cd, oracle.comp_dis_frame_f32(f, "seflowpp_best"))
+
+
+def test_save_zip_cli_a_failing_rank_stops_everyone_and_no_zip_is_written(tmp_path):
+    root = tmp_path / "av2" / "demo"
+    _write_npz_dataset(root)
+    mp.spawn(_worker_save_zip_cli, args=(2, _free_port(), str(root), 1), nprocs=2, join=True)     # returns: nobody hangs
+    assert (root / "err1").read_text() == "OSError" and (root / "err0").read_text() == "RuntimeError"
+    assert not (root / "results" / "seflowpp_best-submit.zip").exists()
+
+
+def _worker_eval_cli(rank, world, port, data_dir, out_dir):
+    _cli_env(rank, world, port)
+    import himo_oracle as oracle
+    from himo_amd import eval as ev
+
+    def step_frames(self, frames, res_name="", comp_dis=None, keys=None):      # device double: the oracle scores the sweep
+        for f, key in zip(frames, keys):
+            ref = oracle.InstanceMetrics(self.data_name)
+            oracle.eval_frame(ref, f, res_name=res_name)
+            self._log.append((key, None))
+            self.frame_cnt += 1
+    ev.InstanceMetrics.step_frames = step_frames
+    ev.InstanceMetrics._apply = lambda self, fs: setattr(self, "frame_cnt", self.frame_cnt + 1)
+    os.chdir(out_dir)
+    m = ev.main(data_dir, res_name="seflowpp_best", batch_frames=2, file_name=str(Path(out_dir) / f"res-rank{rank}.json"))
+    Path(out_dir, f"cnt{rank}").write_text(f"{m.frame_cnt} {sorted(k for k, _ in m._log)}")
+    assert not dist.is_initialized()
+
+
+def test_eval_cli_under_torchrun_env_shards_the_sweeps(tmp_path):
+    root = tmp_path / "av2" / "demo"
+    _write_npz_dataset(root)
+    out = tmp_path / "out"
+    out.mkdir()
+    mp.spawn(_worker_eval_cli, args=(2, _free_port(), str(root), str(out)), nprocs=2, join=True)
+    for r in range(2):                                           # after the gather every rank holds all 7 sweeps, once each
+        assert (out / f"cnt{r}").read_text() == "7 [0, 1, 2, 3, 4, 5, 6]"

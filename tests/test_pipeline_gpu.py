@@ -200,3 +200,54 @@ def test_degenerate_sweeps_in_a_batch(gpu):
             assert torch.equal(out["flow"][a:b], alone[lo + k][0]) and torch.equal(out["comp_dis"][a:b], alone[lo + k][1]), (lo, k)
     pipe.sync_check()
     assert alone[2][0].shape == (0, 3) and alone[4][0].shape == (1, 3) and torch.isfinite(alone[4][0]).all()
+
+
+def test_streaming_temporaries_never_see_a_previous_batch(gpu, oracle):
+    """A streaming caller builds its Samples on the fly and drops them after the call, so CPython hands the next Sample
+    the same ``id()``: every call must still use ITS points, poses and lidar_dt (same-sized sweeps, so a stale batch
+    could not be noticed by a shape check)."""
+    import gc
+    from himo_amd.pipeline import HiMoPipeline, Sample
+    from himo_amd.synthetic import make_frame
+    pipe = HiMoPipeline(device=gpu, max_points=9_000, max_batch=2, precision="f16x2")
+    frames = [make_frame(300 + i, n_points=7_000) for i in range(8)]
+    ids = set()
+    for i in range(6):
+        fh, f0, f1 = frames[i], frames[i + 1], frames[i + 2]
+        out = pipe.run([Sample.from_frames(fh, f0, f1, device=gpu)], refined=True)     # the Sample dies with this statement
+        ids.add(id(out["batch"]))
+        gc.collect()
+        flow = out["flow"].cpu().numpy()
+        alone = HiMoPipeline(net=pipe.net, device=gpu).flow(Sample.from_frames(fh, f0, f1, device=gpu)).cpu().numpy()
+        assert np.array_equal(flow, alone), i                          # this sample's sweeps went through the network
+        ref_cd = oracle.comp_dis_frame_f32(dict(f0, seflowpp_best=flow), "seflowpp_best")
+        assert np.abs(out["comp_dis"].cpu().numpy().astype(np.float64) - ref_cd).max() <= 1e-9, i    # ITS pc0 / pose / dt
+        ref_rf = f0["pc0"][:, :3].astype(np.float64) + ref_cd
+        assert np.abs(out["refined"].cpu().numpy() - ref_rf).max() <= 1e-5, i
+    # results of batch k survive batch k+1 (two alternating buffer sets)
+    a = pipe.run([Sample.from_frames(frames[0], frames[1], frames[2], device=gpu)])
+    keep = a["comp_dis"].clone()
+    pipe.run([Sample.from_frames(frames[3], frames[4], frames[5], device=gpu)])
+    assert torch.equal(a["comp_dis"], keep)
+    # refined is only handed out when asked for
+    assert a["refined"] is None
+
+
+def test_flows_never_returns_an_overflowed_batch(gpu):
+    """``flows`` (what ``save.run`` writes under <res_name>) checks before it returns: auto falls back to the bf16 split and
+    redoes the batch, an explicit f16x2 raises."""
+    from himo_amd.pipeline import HiMoPipeline, Sample
+    from himo_amd.seflow import spec
+    from himo_amd.synthetic import make_frame
+    params = spec.init_params(3)
+    big = dict(params)
+    big["dec3.u5.weight"] = params["dec3.u5.weight"] * 1e7
+    frames = [make_frame(40 + i, n_points=8_000) for i in range(3)]
+    samples = [Sample.from_frames(frames[0], frames[1], frames[2], device=gpu)]
+    want = HiMoPipeline(device=gpu, max_points=9_000, max_batch=1, params=big, precision="bf16x3").flows(samples)[0].clone()
+    assert torch.isfinite(want).all()
+    auto = HiMoPipeline(device=gpu, max_points=9_000, max_batch=1, params=big)
+    got = auto.flows(samples)[0]
+    assert auto.net.precision == "bf16x3" and torch.equal(got, want)
+    with pytest.raises(FloatingPointError):
+        HiMoPipeline(device=gpu, max_points=9_000, max_batch=1, params=big, precision="f16x2").flows(samples)

@@ -88,3 +88,31 @@ def test_save_zip_program_round_trip_on_gpu_box(gpu, gold, tmp_path):
         cd = save_zip.read_output_zip(z, (f["scene_id"], str(f["timestamp"])))
         ref = gold[f"av2/{i}/ref_comp_dis"]
         assert cd.dtype == np.float32 and np.abs(cd.astype(np.float64) - ref).max() <= 1e-9
+
+
+def test_mixed_sweep_kinds_in_one_batch_are_decided_per_sweep(gpu, gold, oracle):
+    """score.py:270-296 tests ``gt_flow_norm is not None`` / ``pc0 is not None`` for EACH sweep: a batch that mixes sweeps
+    with and without them must score every sweep as it would be scored alone (one sweep without gt_flow_norm must not
+    switch the velocity filter off for its neighbours, one without pc0 must not change their Chamfer inputs)."""
+    from himo_amd.score import ScoreMetrics
+    frames = golden_frames(gold, "av2")
+    sweeps = []
+    for i, f in enumerate(frames):
+        full = (gold[f"av2/{i}/ref_gt_comp_dis"], gold[f"av2/{i}/ref_comp_dis"], gold[f"av2/{i}/ref_eval_mask"],
+                f["flow_category_indices"], f["flow_instance_id"].astype(np.uint32), gold[f"av2/{i}/ref_gt_flow_norm"],
+                np.ascontiguousarray(f["pc0"][:, :3]))
+        kind = i % 4
+        sweeps.append(full if kind == 0 else full[:5] + (None, full[6]) if kind == 1 else full[:6] + (None,) if kind == 2
+                      else full[:5] + (None, None))
+    assert len({(s[5] is None, s[6] is None) for s in sweeps}) >= 3
+    batched, ref = ScoreMetrics(), oracle.ScoreMetrics()
+    batched.step_many(sweeps, data_name="av2")
+    for s in sweeps:
+        ref.step(s[0], s[1], s[2], gt_category=s[3], gt_instance=s[4], gt_flow_norm=s[5], pc0=s[6], data_name="av2")
+    a, b = batched.compute_scores(), ref.compute_scores()
+    assert b["num_instances"] > 0
+    for k, v in b.items():
+        if isinstance(v, float):
+            assert a[k] == pytest.approx(v, rel=2e-6), k
+        elif not isinstance(v, dict):
+            assert a[k] == v, k
