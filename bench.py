@@ -211,9 +211,20 @@ def cpu_baseline_pipeline(host_samples, params, budget_s: float, exact_frames: i
         oracle.comp_dis_frame_f32(dict(f0, seflowpp_best=flow), "seflowpp_best")
 
     default_threads = torch.get_num_threads()
-    legs = {}
+    legs, probe = {}, {}
     try:
-        for name, thr in (("all_cores", threads_all or default_threads), ("one_thread", 1)):
+        if not threads_all:
+            # "all cores" = the thread count at which this host runs the restatement FASTEST, found by one frame each: on the
+            # 2 x 64-core GPU box torch's default (128 threads) is 3x slower than 16-32 threads -- the element-wise ops between
+            # the convolutions are memory-bound and oversubscribed -- and a baseline slowed by its own thread pool is no baseline
+            for thr in sorted({default_threads, 64, 32, 16} & set(range(1, default_threads + 1)), reverse=True):
+                torch.set_num_threads(thr)
+                run_one(0)
+                t0 = time.perf_counter()
+                run_one(1 % len(host_samples))
+                probe[thr] = time.perf_counter() - t0
+            threads_all = min(probe, key=probe.get)
+        for name, thr in (("all_cores", threads_all), ("one_thread", 1)):
             torch.set_num_threads(thr)
             legs[name] = dict(_median_rate(run_one, len(host_samples), budget_s, exact_frames), threads=thr)
     finally:
@@ -221,7 +232,9 @@ def cpu_baseline_pipeline(host_samples, params, budget_s: float, exact_frames: i
     a, o = legs["all_cores"], legs["one_thread"]
     return {"value": a["frames_per_s"], "unit": "frames/s", "cores": a["threads"], "kind": "port",
             "value_1_thread": o["frames_per_s"], "all_cores": a, "one_thread": o, "host_logical_cores": os.cpu_count(),
+            "thread_probe_s_per_frame": {str(k): round(v, 3) for k, v in probe.items()},
             "sample": f"median of {a['frames_timed']} frame(s) after {a['warmup_frames']} warm-up(s) at {a['threads']} torch threads "
+                      f"(the fastest of {sorted(probe) or [a['threads']]} on this host) "
                       f"({a['ms_per_frame']:.0f} ms/frame) and of {o['frames_timed']} at 1 thread ({o['ms_per_frame']:.0f} ms/frame); "
                       f"a frame = 3 x {len(host_samples[0][1]['pc0'])}-point sweeps through the PyTorch-CPU fp32 restatement "
                       f"(oracle/seflow_oracle.py) + numpy comp_dis; host has {os.cpu_count()} logical cores"}
