@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 
     // ---- block -> (image, spatial tile, channel tile) ----
     const int n_tiles_n = (a.Cout + BN - 1) / BN;
-    int bid = blockIdx.x;
+    int bid = xcd_block_id(blockIdx.x, gridDim.x);
     const int tn = bid % n_tiles_n; bid /= n_tiles_n;
     int oy0, ox0, img;
     int64_t row0 = 0;                               // KS == 1: first linear pixel of the tile

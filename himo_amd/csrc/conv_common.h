@@ -32,7 +32,7 @@ struct ConvArgs {
     float* aux_out; int aux_out_pitch;                        // r*h (kEpiGruZR) / h in place (kEpiGruQ)
     int act_flags;                                            // kActSplitIn | kActSplitOut: split activation format (convsg.hip)
 };
-enum ActFlags { kActSplitIn = 1, kActSplitOut = 2 };
+enum ActFlags { kActSplitIn = 1, kActSplitOut = 2, kActVecStore = 4 };     // kActVecStore: set by the launchers (vec_store_ok)
 
 // GELU (erf form).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, below float32 resolution of the 1 + erf sum)
 // with the hardware exp2 / rcp: a dozen instructions where the library erff takes three times that -- the epilogue of
@@ -40,6 +40,23 @@ enum ActFlags { kActSplitIn = 1, kActSplitOut = 2 };
 // two-level image addressing: n_inner frames of a sample (channel groups or planes), n_outer samples of a batch
 __device__ inline int64_t image_offset(int img, int n_inner, int64_t batch_stride, int64_t outer_stride) {
     return (int64_t)(img % n_inner) * batch_stride + (int64_t)(img / n_inner) * outer_stride;
+}
+
+// XCD-aware block order.  The dispatcher is observed to place block b on XCD b % 8 (each XCD has its own 4 MB L2), so
+// consecutive block ids -- vertically / horizontally adjacent tiles that share halo rows, and the channel tiles of one
+// pixel tile that share the whole patch -- land on eight different L2s and every one of them fetches the shared rows from
+// HBM again.  This maps the hardware id to a logical id such that XCD x works through the CONTIGUOUS range
+// [x * n / 8, (x + 1) * n / 8) of the logical (image, tile row, tile column, channel tile) order: neighbours in that order
+// run on the same XCD close in time and meet in its L2.  Bijective for any grid size; a different placement would change
+// speed only.
+__device__ inline int xcd_block_id(int bid, int n_blocks) {
+#ifdef HIMO_EXP_NOXCD
+    return bid;
+#else
+    const int per = n_blocks >> 3, rem = n_blocks & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return xcd * per + (xcd < rem ? xcd : rem) + idx;
+#endif
 }
 
 __device__ inline float gelu_exact(float v) {
@@ -110,6 +127,63 @@ __device__ inline void split_store(const ConvArgs& a, float* __restrict__ yout, 
         rec[co & 15] = (unsigned short)h;
         rec[16 + (co & 15)] = (unsigned short)l;
     }
+}
+
+// the output admits 16-byte stores: base, pitches and strides multiples of four floats, whole 4-channel groups
+inline bool vec_store_ok(const ConvArgs& a) {
+    return (reinterpret_cast<uintptr_t>(a.y) & 15u) == 0 && !(a.y_pitch & 3) && !(a.y_batch_stride & 3) && !(a.y_outer_stride & 3) && !(a.Cout & 3);
+}
+
+// Epilogue of one accumulator block (v_mfma 32x32 layout: lane (li, lh) holds output channel ch0 + li of the 16 pixels
+// (r & 3) + 8 (r >> 2) + 4 lh, r = 0..15, of a 32-pixel row segment) as SIXTEEN-BYTE stores.  Written straight from the
+// accumulator layout a wave's tile leaves as 16 dword store instructions per block (64 for a 4-block tile), each covering
+// two 128-byte lines: measured, those stores -- not the activation / split arithmetic -- were the exposed part of the
+// epilogue (kernels 13 % faster with the stores removed, 3 % with the arithmetic removed).  Here the block's 32 pixels x
+// 128 bytes are transposed through a wave-private 4 KB LDS area -- 16 ds_write_b32, 4 ds_read_b128 -- and leave as 4
+// dwordx4 stores per lane, every instruction writing eight full 128-byte lines.  Pixel p sits in slot p ^ ((p >> 2) & 1):
+// the two half-waves write pixels 4 apart (512 bytes: the same banks) in the same instruction, the swap moves one of them
+// 128 bytes on.  DS operations of a wave execute in order, so no barrier is needed between its writes and reads.
+// word = this lane's 32-bit output for pixel r (float bits, or the paired split word of split_word()).
+template <bool OSPLIT>
+__device__ inline void store_block_vec(const ConvArgs& a, float* __restrict__ yout, unsigned char* stg, const unsigned (&word)[16],
+                                       int lane, int64_t pix0, int n_valid_px, int ch0) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int widx = OSPLIT ? (li >> 4) * 16 + ((li & 1) ? 8 : 0) + ((li & 15) >> 1) : li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int px = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int slot = px ^ ((px >> 2) & 1);
+        *reinterpret_cast<unsigned*>(stg + slot * 128 + widx * 4) = word[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int q = t * 64 + lane;
+        const int slot = q >> 3, piece = q & 7;
+        const int px = slot ^ ((slot >> 2) & 1);
+        const uint4 d = *reinterpret_cast<const uint4*>(stg + q * 16);
+        const int ch = ch0 + (OSPLIT ? (piece >> 2) * 16 : piece * 4);
+        if (px < n_valid_px && ch < a.Cout)
+            *reinterpret_cast<uint4*>(yout + (pix0 + px) * (int64_t)a.y_pitch + ch0 + piece * 4) = d;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// activation of one epilogue value (the two epilogues the split-input kernels support)
+template <int EPI>
+__device__ inline float epilogue_value(float v, float sc, float sh) {
+    if (EPI == kEpiBiasBnGelu) return gelu_exact(v * sc + sh);
+    if (EPI == kEpiBiasGelu) return gelu_exact(v);
+    if (EPI == kEpiBiasRelu) return fmaxf(v, 0.f);
+    return v;
+}
+// split x = h + l and pair up with the neighbouring lane (channel parity = lane parity, same pixel): the even lane ends up
+// with (h_even, h_odd), the odd lane with (l_even, l_odd) -- the 32-bit words of the split record (see split_store)
+__device__ inline unsigned split_word(float v, bool odd) {
+    unsigned h, l;
+    split2_rounded(v, h, l);
+    const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? h : l), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    return odd ? (recv | (l << 16)) : (h | (recv << 16));
 }
 
 // implemented in convbf.hip: stride-1 convolutions / row GEMMs on split-bf16 matrix instructions

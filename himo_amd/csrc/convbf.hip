@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
     __shared__ __attribute__((aligned(16))) unsigned char wts[WB][G][FMT][BN * kRowBytes];
 
     const int n_tiles_n = (a.Cout + BN - 1) / BN;
-    int bid = blockIdx.x;
+    int bid = xcd_block_id(blockIdx.x, gridDim.x);
     const int tn = bid % n_tiles_n; bid /= n_tiles_n;
     int oy0 = 0, ox0 = 0, img;
     int64_t row0 = 0;

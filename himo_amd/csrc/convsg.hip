@@ -30,6 +30,28 @@ namespace himo {
 
 __device__ __attribute__((aligned(64))) unsigned char g_zero_page[64];
 
+#ifdef HIMO_EXP_STAGGER
+// experiment: put the blocks that share a CU out of phase.  Blocks of one launch have identical lengths and the first round
+// starts together, so the OCC blocks of a CU reach their epilogues (VALU + a burst of stores, matrix pipe idle) together,
+// round after round.  Each first-round block takes a ticket from its CU's arrival counter (HW_ID: XCC / SE / SH / CU) and
+// waits ticket % OCC phases of `phase_cycles` before it starts; later blocks inherit the offsets.
+__device__ unsigned g_cu_arrivals[8 * 256];
+__device__ inline void stagger_start(int first_round_blocks, int occ, long long phase_cycles) {
+    if ((int)blockIdx.x >= first_round_blocks) return;
+    __shared__ int phase;
+    if (threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned slot = (xcc & 7) * 256 + ((hw >> 8) & 0xff);          // CU_ID[11:8] SH_ID[12] SE_ID[15:13]
+        phase = (int)(atomicAdd(&g_cu_arrivals[slot], 1u) % (unsigned)occ);
+    }
+    __syncthreads();
+    const long long until = clock64() + (long long)phase * phase_cycles;
+    while (clock64() < until) __builtin_amdgcn_s_sleep(32);
+}
+#endif
+
 __device__ inline void glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -49,8 +71,15 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int BN = (4 / PH) * 32;
     __shared__ __attribute__((aligned(1024))) unsigned char patch[2 * kBuf];
 
+#ifdef HIMO_EXP_STAGGER
+    {
+        constexpr int OCC = (S == 2 || MI == 4) ? 3 : 4;
+        if ((int)gridDim.x >= 256 * OCC * 6)                       // only launches of many rounds: the start-up wait is paid once
+            stagger_start(256 * OCC, OCC, (long long)(a.Cin >> 4) * 9 * 3 * MI * 32 * HIMO_EXP_STAGGER / 100);
+    }
+#endif
     const int n_tiles_n = (a.Cout + BN - 1) / BN;
-    int bid = blockIdx.x;
+    int bid = xcd_block_id(blockIdx.x, gridDim.x);
     const int tn = bid % n_tiles_n; bid /= n_tiles_n;
     const int tx = (a.Wo + TW - 1) / TW, ty = (a.Ho + TH - 1) / TH;
     const int ox0 = (bid % tx) * TW; bid /= tx;
@@ -175,10 +204,29 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     }
 
     float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
-    if (!co_ok) return;
-    const float b = a.bias ? a.bias[co] : 0.f;
+    const float b = a.bias ? a.bias[co_ld] : 0.f;
     float sc = 1.f, sh = 0.f;
-    if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
+    if (EPI == kEpiBiasBnGelu) { sc = a.scale[co_ld]; sh = a.shift[co_ld]; }
+#if !defined(HIMO_EXP_NOEPI) && !defined(HIMO_EXP_NOSTORE) && !defined(HIMO_EXP_DWORDSTORE)
+    if (a.act_flags & kActVecStore) {            // 16-byte stores through a wave-private LDS transpose (store_block_vec)
+        __syncthreads();                         // every wave has read its last patch rows: the patch memory is free
+        unsigned char* stg = patch + wave * 4096;
+        const int n_px = a.Wo - ox0 < 32 ? a.Wo - ox0 : 32;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int oy = oy0 + wp * MI + mi;
+            unsigned word[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = epilogue_value<EPI>(acc[mi][r] * kF16AccScale + b, sc, sh);
+                word[r] = OSPLIT ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
+            }
+            store_block_vec<OSPLIT>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, oy < a.Ho ? n_px : 0, tn * BN + wc * 32);
+        }
+        return;
+    }
+#endif
+    if (!co_ok) return;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int oy = oy0 + wp * MI + mi;
@@ -186,10 +234,20 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         for (int r = 0; r < 16; ++r) {
             const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             float v = acc[mi][r] * kF16AccScale + b;
+#if defined(HIMO_EXP_NOEPI)                    // experiment: no activation / split arithmetic, same stores (results are wrong)
+            if (oy < a.Ho && ox < a.Wo) yout[((int64_t)oy * a.Wo + ox) * a.y_pitch + (OSPLIT ? (co & ~15) + ((co & 1) ? 8 : 0) + ((co & 15) >> 1) : co)] = v;
+#elif defined(HIMO_EXP_NOSTORE)                // experiment: full epilogue arithmetic, (almost) no stores
+            if (oy < a.Ho && ox < a.Wo) {
+                if (EPI == kEpiBiasBnGelu) v = gelu_exact(v * sc + sh);
+                unsigned hh, ll; split2_rounded(v, hh, ll);
+                if ((hh ^ ll) == 0x12345u) yout[((int64_t)oy * a.Wo + ox) * a.y_pitch + co] = v;
+            }
+#else
             if (oy < a.Ho && ox < a.Wo) {
                 if (OSPLIT) split_store<EPI, true>(a, yout, (int64_t)oy * a.Wo + ox, co, v, sc, sh);
                 else epilogue_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v, sc, sh);
             }
+#endif
         }
     }
 }
@@ -204,10 +262,10 @@ void conv1_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int kSeg = 32 * 64, kSlab = TH * kSeg, kBuf = G * kSlab;
     constexpr int kUnits = G * TH * 2, kUPW = (kUnits + 3) / 4;
     constexpr int BN = (4 / PH) * 32;
-    __shared__ __attribute__((aligned(1024))) unsigned char patch[2 * kBuf];
+    __shared__ __attribute__((aligned(1024))) unsigned char patch[2 * kBuf < 16384 ? 16384 : 2 * kBuf];   // >= the epilogue's 4 x 4 KB
 
     const int n_tiles_n = (a.Cout + BN - 1) / BN;
-    int bid = blockIdx.x;
+    int bid = xcd_block_id(blockIdx.x, gridDim.x);
     const int tn = bid % n_tiles_n; bid /= n_tiles_n;
     const int64_t rows = (int64_t)a.Ho * a.Wo;
     const int tiles = (int)((rows + BM - 1) / BM);
@@ -299,10 +357,29 @@ void conv1_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     }
 
     float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
-    if (!co_ok) return;
-    const float b = a.bias ? a.bias[co] : 0.f;
+    const float b = a.bias ? a.bias[co_ld] : 0.f;
     float sc = 1.f, sh = 0.f;
-    if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
+    if (EPI == kEpiBiasBnGelu) { sc = a.scale[co_ld]; sh = a.shift[co_ld]; }
+#if !defined(HIMO_EXP_DWORDSTORE)
+    if (a.act_flags & kActVecStore) {            // 16-byte stores through a wave-private LDS transpose (store_block_vec)
+        __syncthreads();
+        unsigned char* stg = patch + wave * 4096;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int64_t pix0 = row0 + (wp * MI + mi) * 32;
+            const int64_t left = rows - pix0;
+            unsigned word[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = epilogue_value<EPI>(acc[mi][r] * kF16AccScale + b, sc, sh);
+                word[r] = OSPLIT ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
+            }
+            store_block_vec<OSPLIT>(a, yout, stg, word, lane, pix0, left < 0 ? 0 : left > 32 ? 32 : (int)left, tn * BN + wc * 32);
+        }
+        return;
+    }
+#endif
+    if (!co_ok) return;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -318,7 +395,9 @@ void conv1_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 }
 
 template <int PH, int MI>
-static void launch_sg1(const ConvArgs& a, int epi, bool osplit, const unsigned short* w, dim3 grid, hipStream_t s) {
+static void launch_sg1(const ConvArgs& a_in, int epi, bool osplit, const unsigned short* w, dim3 grid, hipStream_t s) {
+    ConvArgs a = a_in;
+    if (vec_store_ok(a)) a.act_flags |= kActVecStore;
 #define HIMO_SG(E, O) hipLaunchKernelGGL((conv1_presplit_kernel<E, PH, MI, O>), grid, dim3(256), 0, s, a, w)
     if (epi == kEpiBias) { if (osplit) HIMO_SG(kEpiBias, true); else HIMO_SG(kEpiBias, false); }
     else { if (osplit) HIMO_SG(kEpiBiasBnGelu, true); else HIMO_SG(kEpiBiasBnGelu, false); }
@@ -353,7 +432,9 @@ bool launch_conv1_presplit(const ConvArgs& a, int epilogue, const void* w_packed
 }
 
 template <int PH, int MI, int S = 1>
-static void launch_sg(const ConvArgs& a, int epi, bool osplit, const unsigned short* w, dim3 grid, hipStream_t s) {
+static void launch_sg(const ConvArgs& a_in, int epi, bool osplit, const unsigned short* w, dim3 grid, hipStream_t s) {
+    ConvArgs a = a_in;
+    if (vec_store_ok(a)) a.act_flags |= kActVecStore;
 #define HIMO_SG(E, O) hipLaunchKernelGGL((conv3_presplit_kernel<E, PH, MI, O, S>), grid, dim3(256), 0, s, a, w)
     if (epi == kEpiBias) { if (osplit) HIMO_SG(kEpiBias, true); else HIMO_SG(kEpiBias, false); }
     else { if (osplit) HIMO_SG(kEpiBiasBnGelu, true); else HIMO_SG(kEpiBiasBnGelu, false); }

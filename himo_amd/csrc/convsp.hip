@@ -56,7 +56,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     __shared__ __attribute__((aligned(16))) unsigned char patch[NB][FMT][NPIX * PL::kPitch];
 
     const int n_tiles_n = (a.Cout + BN - 1) / BN;
-    int bid = blockIdx.x;
+    int bid = xcd_block_id(blockIdx.x, gridDim.x);
     const int tn = bid % n_tiles_n; bid /= n_tiles_n;
     const int tx = (a.Wo + TW - 1) / TW, ty = (a.Ho + TH - 1) / TH;
     const int ox0 = (bid % tx) * TW; bid /= tx;
