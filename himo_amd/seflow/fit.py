@@ -1,0 +1,136 @@
+"""The training loop around ``SeFlowTrainer`` -- this build's counterpart of the reference's training job
+(``python train.py model=deflowpp ... loss_fn=seflowppLoss batch_size=8 epochs=12 save_top_model=3 optimizer.lr=6e-5
++optimizer.scheduler.name=StepLR +...step_size=3 +...gamma=0.5``, assets/slurm/ssl-train-av2.sh:31-34, on 4 GPUs :3).
+
+PARITY UNPINNED: ``OpenSceneFlow/train.py`` is absent, so only the launcher's numbers are mirrored: epochs over the
+dataset, ``batch_size`` samples per optimiser step (spread over the ranks: every rank averages the gradients of ITS
+samples, then ONE flat all-reduce averages the ranks), Adam at ``lr`` with StepLR(step_size, gamma) per epoch, the
+``save_top`` best checkpoints kept by the epoch's validation (or mean training) loss, and resuming from a checkpoint.
+Conventions of this build: BatchNorm stays FROZEN -- running statistics and affine folded into
+constants, the usual fine-tuning convention -- so there is no batch-statistics pass and no BN backward; labels are the
+frame's dynamic-cluster ids (``flow_instance_id`` here; the reference's ``ssl_label=seflow_auto`` files are absent).
+"""
+from __future__ import annotations
+
+import math
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .checkpoint import TopK
+from .train import SeFlowTrainer
+
+
+def triplets(dataset):
+    """(history, current, next) frame indices of every frame that has a successor in its scene (the history frame is the
+    previous sweep of the scene, else the frame itself -- ``num_frames=3``, ssl-train-av2.sh:32)."""
+    out = []
+    for i in range(len(dataset) - 1):
+        f0, f1 = dataset[i], dataset[i + 1]
+        if f0.get("scene_id") != f1.get("scene_id"):
+            continue
+        ih = i - 1 if i > 0 and dataset[i - 1].get("scene_id") == f0.get("scene_id") else i
+        out.append((ih, i, i + 1))
+    return out
+
+
+def make_sample(dataset, trip, device, label_key: str = "flow_instance_id"):
+    """(pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels) on ``device`` for one triplet."""
+    fh, f0, f1 = (dataset[i] for i in trip)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+    lab = lambda f: torch.from_numpy(np.ascontiguousarray(f[label_key]).astype(np.int32)).to(device)
+    l0, l1 = lab(f0), lab(f1)
+    n_labels = int(max(int(f0[label_key].max(initial=0)), int(f1[label_key].max(initial=0)))) + 1
+    return (up(fh["pc0"]), up(f0["pc0"]), up(f1["pc0"]), np.asarray(fh["pose0"], np.float64), np.asarray(f0["pose0"], np.float64),
+            np.asarray(f0["pose1"], np.float64), l0, l1, n_labels)
+
+
+def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, batch_size: int = 8, lr: float = 6e-5,
+        step_size: int = 3, gamma: float = 0.5, save_top: int = 3, val_dataset=None, resume=None, precision: str = "mixed",
+        max_points: int = 140_000, device=None, seed: int = 0, max_steps: int | None = None, log=print,
+        trainer: SeFlowTrainer | None = None) -> dict:
+    """Train for ``epochs`` passes over ``dataset``; returns {"trainer", "history", "best"}.
+
+    Ranks (torch.distributed, initialised by the caller / ``distenv.process_group``): step s of an epoch takes the global
+    samples [s * batch_size, (s + 1) * batch_size) of that epoch's seeded shuffle; rank r takes every world-th of them.
+    ``max_steps`` bounds the optimiser steps of the whole run (tests)."""
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    tr = trainer if trainer is not None else SeFlowTrainer(params, device=device, max_points=max_points, seed=seed, precision=precision)
+    dev = tr.device
+    start_epoch = 0
+    if resume is not None:
+        extra = tr.load_checkpoint(resume)
+        start_epoch = int(extra.get("epoch", -1)) + 1
+    top = TopK(out_dir, k=save_top) if (out_dir is not None and rank == 0) else None
+    trips = triplets(dataset)
+    if not trips:
+        raise ValueError("the dataset has no frame with a successor in its scene")
+    val_trips = triplets(val_dataset) if val_dataset is not None else []
+    steps_per_epoch = math.ceil(len(trips) / batch_size)
+    history, steps_done = [], 0
+    for epoch in range(start_epoch, epochs):
+        lr_e = SeFlowTrainer.step_lr(epoch, lr, step_size, gamma)
+        order = np.random.default_rng(seed * 1_000_003 + epoch).permutation(len(trips))      # same shuffle on every rank
+        losses = []
+        for s in range(steps_per_epoch):
+            if max_steps is not None and steps_done >= max_steps:
+                break
+            batch = order[s * batch_size:(s + 1) * batch_size]
+            mine = [trips[j] for j in batch[rank::world]]
+            if not mine:                                     # fewer samples than ranks in a last partial batch: an extra copy keeps
+                mine = [trips[batch[0]]]                     # every rank in the collective (weights it slightly more)
+            loss = tr.train_batch((make_sample(dataset, t, dev) for t in mine), lr=lr_e)
+            losses.append(loss)
+            steps_done += 1
+        train_loss = float(torch.stack(losses).mean().item()) if losses else float("nan")
+        val_loss = None
+        if val_trips:
+            vals = [tr.loss_only(*make_sample(val_dataset, t, dev)) for t in val_trips[rank::world]]
+            v = torch.stack(vals).sum() if vals else torch.zeros((), dtype=torch.float64, device=dev)
+            cnt = torch.tensor([float(len(vals))], dtype=torch.float64, device=dev)
+            tot = torch.stack([v.reshape(()), cnt.reshape(())])
+            if world > 1:
+                dist.all_reduce(tot)
+            val_loss = float((tot[0] / tot[1].clamp(min=1.0)).item())
+        entry = {"epoch": epoch, "lr": lr_e, "train_loss": train_loss, "val_loss": val_loss, "steps": len(losses)}
+        history.append(entry)
+        if log is not None and rank == 0:
+            log(f"epoch {epoch}: lr {lr_e:.3g}  train loss {train_loss:.6f}" + (f"  val loss {val_loss:.6f}" if val_loss is not None else ""))
+        if top is not None and losses:
+            figure = val_loss if val_loss is not None else train_loss
+            top.offer(figure, epoch, tr.export_params(), adam_m=tr.flat_m.cpu().numpy(), adam_v=tr.flat_v.cpu().numpy(), step=tr.step_count)
+        if max_steps is not None and steps_done >= max_steps:
+            break
+    return {"trainer": tr, "history": history, "best": top.best() if top is not None else None}
+
+
+def main(argv=None):
+    """``python -m himo_amd.seflow.fit --dataset_path <dir> [--checkpoint init.npz] [--out_dir ckpt]``; under torchrun one
+    rank per GPU (RCCL)."""
+    import argparse
+    from .. import distenv
+    from ..dataset import open_dataset
+    from .checkpoint import load_params
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dataset_path", required=True)
+    ap.add_argument("--val_path", default="")
+    ap.add_argument("--checkpoint", default="")
+    ap.add_argument("--resume", default="")
+    ap.add_argument("--out_dir", default="checkpoints")
+    ap.add_argument("--epochs", type=int, default=12)
+    ap.add_argument("--batch_size", type=int, default=8)
+    ap.add_argument("--lr", type=float, default=6e-5)
+    ap.add_argument("--save_top_model", type=int, default=3)
+    a = ap.parse_args(argv)
+    with distenv.process_group():
+        ds = open_dataset(Path(a.dataset_path))
+        val = open_dataset(Path(a.val_path)) if a.val_path else None
+        params = load_params(a.checkpoint) if a.checkpoint else None
+        return fit(ds, params, out_dir=a.out_dir, epochs=a.epochs, batch_size=a.batch_size, lr=a.lr, save_top=a.save_top_model,
+                   val_dataset=val, resume=a.resume or None)
+
+
+if __name__ == "__main__":
+    main()

@@ -601,6 +601,16 @@ class SeFlowTrainer:
         self.backward(dres)
         return terms, total
 
+    def loss_only(self, pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels: int | None = None):
+        """forward + loss without a backward pass (validation): the total as a 0-d float64 device tensor"""
+        from ..ssl_loss import SeFlowLoss
+        if not hasattr(self, "loss"):
+            self.loss = SeFlowLoss(device=self.device)
+        res = self.forward(pch1, pc0, pc1, pose_h1, pose0, pose1)
+        n0, n1 = self.n_pts[1], self.n_pts[2]
+        _, total, _ = self.loss(self.net.xyz_t[1][:n0], self.net.xyz_t[2][:n1], res[:, :3].contiguous(), label0, label1, n_labels)
+        return total
+
     def train_step(self, pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels: int | None = None, lr: float = 6e-5):
         """One optimisation step on one sample per rank: forward, loss, backward, gradient all-reduce, Adam
         (``lr`` default = the reference launcher's ``optimizer.lr=6e-5``, assets/slurm/ssl-train-av2.sh:33).
@@ -639,6 +649,44 @@ class SeFlowTrainer:
         self.step_count += 1
         _lib.check(self.lib.himo_adam_step(self.flat_p.numel(), self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                            self.flat_v.data_ptr(), lr, beta1, beta2, eps, self.step_count, _lib.stream_handle()), "adam")
+        self._repack()
+
+    # ---- checkpoints (seflow/checkpoint.py): parameters + Adam moments + step counter ---------------------------------
+    def save_checkpoint(self, path, **extra):
+        """Parameters in the spec layout + the flat Adam moments and the step counter (``extra``: epoch=, val=)."""
+        from .checkpoint import save_params
+        return save_params(path, self.export_params(), adam_m=self.flat_m.cpu().numpy(), adam_v=self.flat_v.cpu().numpy(),
+                           step=self.step_count, **extra)
+
+    def load_checkpoint(self, path) -> dict:
+        """Restore parameters (and, when the file carries them, optimiser state) written by ``save_checkpoint`` -- training
+        continues bit for bit where the saved run stood.  Returns the file's extra fields (epoch, val, ...)."""
+        from .checkpoint import load_params
+        params, extra = load_params(path, with_extra=True)
+        self.import_params(params)
+        if "adam_m" in extra and "adam_v" in extra:
+            if extra["adam_m"].shape != tuple(self.flat_m.shape):
+                raise ValueError("checkpoint optimiser state does not match this network's parameter count")
+            self.flat_m.copy_(torch.from_numpy(extra["adam_m"]))
+            self.flat_v.copy_(torch.from_numpy(extra["adam_v"]))
+            self.step_count = int(extra.get("step", 0))
+        return extra
+
+    def import_params(self, params: dict):
+        """spec-layout parameter dict -> the flat buffer, plus the (frozen) BatchNorm tensors and the scale / shift constants
+        folded from them exactly as SeFlowNet folds them: the whole network becomes the checkpoint's."""
+        host = {k: params[k] for k in self.names if k in params}
+        host.update({f"head.{k}": v for k, v in HeadTrainer.host_params(params).items()})
+        for k in self.names:
+            self.p[k].copy_(torch.from_numpy(np.ascontiguousarray(host[k], dtype=np.float32)))
+        t = lambda k: torch.from_numpy(np.ascontiguousarray(params[k], dtype=np.float32))
+        for prefix, eps, out in [("pfn.bn", spec.BN_EPS_PFN, "pfn")] + [(f"{n}.bn", spec.BN_EPS, n) for n, *_ in spec.ENCODER]:
+            scale = t(f"{prefix}.gamma") / torch.sqrt(t(f"{prefix}.var") + eps)
+            shift = t(f"{prefix}.beta") - t(f"{prefix}.mean") * scale
+            self.net.p[f"{out}.scale"].copy_(scale)
+            self.net.p[f"{out}.shift"].copy_(shift)
+            for k in ("gamma", "beta", "mean", "var"):
+                self.net.p[f"{prefix}.{k}"].copy_(t(f"{prefix}.{k}"))
         self._repack()
 
     def export_params(self) -> dict:
