@@ -25,6 +25,14 @@ EGO_BOX = {
 }
 
 
+def host_upload(dev):
+    """default ``upload(parts, dtype)``: concatenate on the host, one synchronous copy to ``dev``"""
+    def up(parts, dtype):
+        host = np.concatenate([np.asarray(p).astype(dtype, copy=False) for p in parts], axis=0)
+        return torch.from_numpy(np.ascontiguousarray(host)).to(dev, non_blocking=False)
+    return up
+
+
 @dataclass
 class FrameBatch:
     """Ragged batch of sweeps laid end to end in HBM (frame f owns rows offsets[f]:offsets[f+1])."""
@@ -54,10 +62,13 @@ class FrameBatch:
         return [t[int(o[i]):int(o[i + 1])] for i in range(self.n_frames)]
 
     @classmethod
-    def from_frames(cls, frames, res_name: str | None = "seflowpp_best", device=None, with_masks: bool = False):
+    def from_frames(cls, frames, res_name: str | None = "seflowpp_best", device=None, with_masks: bool = False, upload=None):
         """Pack reference-style frame dicts.  ``res_name`` "raw"/None => no flow (save_zip.py:117).
-        A missing result key raises ``KeyError`` exactly where the reference's ``data[res_name]`` does."""
+        A missing result key raises ``KeyError`` exactly where the reference's ``data[res_name]`` does.
+        ``upload(parts, dtype) -> device tensor`` of the row-wise concatenation of ``parts`` converted to ``dtype``: optional
+        staging hook (feeder.EvalFeeder concatenates straight into pinned memory and copies on its own stream)."""
         dev = device if device is not None else _lib.require_gpu()
+        to_dev = upload if upload is not None else host_upload(dev)
         frames = list(frames)
         if not frames:
             raise ValueError("empty batch")
@@ -73,17 +84,16 @@ class FrameBatch:
                 a = np.asarray(f[key])
                 if a.shape[0] != n:
                     raise ValueError(f"{key}: {a.shape[0]} rows for a sweep of {n} points")
-                parts.append(a.astype(dtype, copy=False))
-            host = np.concatenate(parts, axis=0) if parts else np.empty((0,) if width is None else (0, width), dtype)
-            return torch.from_numpy(np.ascontiguousarray(host)).to(dev, non_blocking=False)
+                parts.append(a)
+            return to_dev(parts, dtype)
 
         pose_dtypes = {np.asarray(f[k]).dtype for f in frames for k in ("pose0", "pose1")}
         f32_chain = all(dt == np.float32 for dt in pose_dtypes)
-        pose0 = torch.from_numpy(np.stack([np.asarray(f["pose0"], dtype=np.float64) for f in frames])).to(dev)
-        pose1 = torch.from_numpy(np.stack([np.asarray(f["pose1"], dtype=np.float64) for f in frames])).to(dev)
+        pose0 = to_dev([np.stack([np.asarray(f["pose0"], dtype=np.float64) for f in frames])], np.float64)
+        pose1 = to_dev([np.stack([np.asarray(f["pose1"], dtype=np.float64) for f in frames])], np.float64)
         b = cls(
             offsets_host=offsets,
-            offsets=torch.from_numpy(offsets).to(dev),
+            offsets=to_dev([offsets], np.int64),
             pose0=pose0, pose1=pose1,
             pc0=cat("pc0", np.float32, stride),
             lidar_dt=cat("lidar_dt", np.float32),

@@ -97,33 +97,98 @@ class InstanceEvaluator:
             self._ws = torch.empty(need + 64, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def run(self, n_frames, offsets, pc0, gt, est, lidar_dt, category, instance, eval_mask, mode, sensor_dt=0.1,
-            pose0=None, pose1=None, flags=0, max_records=None) -> np.ndarray:
+    def launch(self, n_frames, offsets, pc0, gt, est, lidar_dt, category, instance, eval_mask, mode, sensor_dt=0.1,
+               pose0=None, pose1=None, flags=0, max_records=None):
+        """Enqueue the kernels for one ragged batch and the device -> pinned-host copy of its counts + records; returns a
+        ticket for ``collect``.  Nothing here waits for the device, so the host can stage / launch the next batch (or
+        digest the previous one's records) while this one runs."""
         total = int(category.shape[0])
         if max_records is None:
             max_records = max(1024, min(total, 64 * n_frames + 4096))
-        while True:
-            recs = torch.empty(max_records * RECORD_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
-            counts = torch.zeros(2, dtype=torch.int64, device=self.device)
-            ws = self._workspace(n_frames, total, max_records)
-            lut = self._lut.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
-            st = self.lib.himo_eval_instances(
-                n_frames, total, _lib.ptr(offsets), _lib.ptr(pose0), _lib.ptr(pose1), _lib.ptr(pc0),
+        nbytes = max_records * RECORD_DTYPE.itemsize
+        recs = torch.empty(16 + nbytes, dtype=torch.uint8, device=self.device)       # [counts (2 x int64) | records]
+        recs[:16].zero_()
+        counts = recs[:16].view(torch.int64)
+        ws = self._workspace(n_frames, total, max_records)
+        lut = self._lut.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+        args = (n_frames, total, _lib.ptr(offsets), _lib.ptr(pose0), _lib.ptr(pose1), _lib.ptr(pc0),
                 0 if pc0 is None else pc0.shape[1], _lib.ptr(gt), _lib.ptr(est), _lib.ptr(lidar_dt), _lib.ptr(category),
-                _lib.ptr(instance), _lib.ptr(eval_mask), lut, float(sensor_dt), int(mode), int(flags), _lib.ptr(recs),
-                max_records, _lib.ptr(counts), _lib.ptr(ws), ws.numel(), _lib.stream_handle())
-            _lib.check(st, "himo_eval_instances")
-            n_sel, n_rec = (int(v) for v in counts.cpu().tolist())
-            if n_rec <= max_records:
-                break
-            max_records = n_rec                       # more instances than guessed: rerun with room for all
-        host = recs[: n_rec * RECORD_DTYPE.itemsize].cpu().numpy().view(RECORD_DTYPE)
-        return np.sort(host, order=["frame", "group", "instance"])    # np.unique order inside each class
+                _lib.ptr(instance), _lib.ptr(eval_mask), lut, float(sensor_dt), int(mode), int(flags))
+        st = self.lib.himo_eval_instances(*args, recs[16:].data_ptr(), max_records, counts.data_ptr(), _lib.ptr(ws), ws.numel(),
+                                          _lib.stream_handle())
+        _lib.check(st, "himo_eval_instances")
+        host = self._pinned(16 + nbytes)
+        host[:16 + nbytes].copy_(recs, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        keep = (offsets, pc0, gt, est, lidar_dt, category, instance, eval_mask, pose0, pose1, recs)     # alive until collected
+        return {"event": ev, "host": host, "max_records": max_records, "args": args, "keep": keep, "workspace": ws}
+
+    def _pinned(self, nbytes: int) -> torch.Tensor:
+        if not hasattr(self, "_pin_pool"):
+            self._pin_pool = []
+        for i, buf in enumerate(self._pin_pool):
+            if buf.numel() >= nbytes:
+                return self._pin_pool.pop(i)
+        return torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+
+    def collect(self, ticket) -> np.ndarray:
+        """Wait for a ticket's copy and return its records sorted (frame, group, instance); a batch with more instances
+        than the buffer had room for is run again, synchronously, with room for all."""
+        ticket["event"].synchronize()
+        host = ticket["host"]
+        n_sel, n_rec = (int(v) for v in host[:16].view(torch.int64).tolist())
+        if n_rec > ticket["max_records"]:
+            a = ticket["args"]
+            k = ticket["keep"]
+            self._pin_pool.append(host)
+            again = self.launch(a[0], k[0], k[1], k[2], k[3], k[4], k[5], k[6], k[7], a[15], sensor_dt=a[14], pose0=k[8], pose1=k[9],
+                                flags=a[16], max_records=n_rec)
+            return self.collect(again)
+        out = host[16:16 + n_rec * RECORD_DTYPE.itemsize].numpy().view(RECORD_DTYPE).copy()
+        self._pin_pool.append(host)
+        ticket["keep"] = None
+        return np.sort(out, order=["frame", "group", "instance"])    # np.unique order inside each class
+
+    def run(self, n_frames, offsets, pc0, gt, est, lidar_dt, category, instance, eval_mask, mode, sensor_dt=0.1,
+            pose0=None, pose1=None, flags=0, max_records=None) -> np.ndarray:
+        return self.collect(self.launch(n_frames, offsets, pc0, gt, est, lidar_dt, category, instance, eval_mask, mode,
+                                        sensor_dt=sensor_dt, pose0=pose0, pose1=pose1, flags=flags, max_records=max_records))
 
 
 def _dev(x, dtype, dev):
     t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
     return t.to(device=dev, dtype=dtype).contiguous()
+
+
+class EvalBatch:
+    """Everything the loop body of eval.py:281-310 reads from a list of frames, resident in HBM: the ragged sweep batch
+    (points, poses, lidar_dt, gm0 [, flow_is_valid]) plus ground-truth flow, category, instance id and the estimate
+    (``est``: the flow stored under <res_name>, a zip's comp_dis, or None for "raw")."""
+
+    def __init__(self, batch: FrameBatch, gt, category, instance, est, mode: int):
+        self.batch, self.gt, self.category, self.instance, self.est, self.mode = batch, gt, category, instance, est, mode
+
+    @classmethod
+    def from_frames(cls, frames, res_name: str = "", comp_dis=None, device=None, upload=None):
+        """Pack host frame dicts.  ``upload(parts, dtype) -> device tensor`` lets a feeder concatenate straight into pinned
+        memory and copy on its own stream (feeder.EvalFeeder); the default is a host concatenation + a synchronous copy."""
+        from .compdis import host_upload
+        dev = device if device is not None else _lib.require_gpu()
+        up = upload if upload is not None else host_upload(dev)
+        frames = list(frames)
+        batch = FrameBatch.from_frames(frames, "raw", device=dev, with_masks=True, upload=up)
+        cat = lambda key, dt: up([np.asarray(f[key]) for f in frames], dt)
+        gt = cat("flow", np.float32)
+        category = cat("flow_category_indices", np.uint8)
+        instance = cat("flow_instance_id", np.int64)
+        if comp_dis is not None:
+            est, mode = up([np.asarray(c) for c in comp_dis], np.float32), MODE_COMPDIS
+        elif res_name == "raw":
+            est, mode = None, MODE_RAW
+        else:
+            est, mode = cat(res_name, np.float32), MODE_FLOW          # KeyError like data[res_name]
+        return cls(batch, gt, category, instance, est, mode)
 
 
 class InstanceMetrics:
@@ -137,6 +202,7 @@ class InstanceMetrics:
         self._evaluator = None
         self._compdis = None
         self._log = []          # (sweep key, per-sweep contribution) so that ranks can merge in sweep order
+        self._pending = []      # tickets of batches whose records have not been digested yet (step_batch)
 
     # ---- containers --------------------------------------------------------------------------------
     def init_evaluate_data(self):
@@ -179,36 +245,47 @@ class InstanceMetrics:
                                   sensor_dt=self.sensor_dt, flags=flags) if n else np.empty(0, RECORD_DTYPE)
         self._accumulate_frame(recs, key=self.frame_cnt)
 
-    # ---- batched fast path: raw frame dicts in, everything on the device ---------------------------------
+    # ---- batched fast path: everything on the device --------------------------------------------------------------
+    def step_batch(self, eb: EvalBatch, keys=None, depth: int = 2):
+        """The loop body of eval.py:281-310 for a device-resident batch of sweeps: eval mask (fused comp_dis kernel),
+        per-instance grouping, both NN searches and the means are enqueued and the call returns; the few hundred bytes of
+        per-instance records come back through pinned memory and are digested -- in sweep order -- ``depth`` batches
+        later, so the host-side bucket bookkeeping of batch k overlaps the kernels of batch k + 1.  ``flush()`` digests
+        what is still in flight (``print`` / ``summary`` / ``gather`` call it)."""
+        ev = self.evaluator
+        if self._compdis is None:
+            self._compdis = CompDisEngine(device=ev.device)
+        b = eb.batch
+        mask = self._compdis.run(b, sensor_dt=self.sensor_dt, data_name=self.data_name)["eval_mask"]   # eval.py:288-296
+        ticket = ev.launch(b.n_frames, b.offsets, b.pc0, eb.gt, eb.est, b.lidar_dt, eb.category, eb.instance, mask, eb.mode,
+                           sensor_dt=self.sensor_dt, pose0=b.pose0, pose1=b.pose1)
+        base = self.frame_cnt + sum(t[1] for t in self._pending)
+        self._pending.append((ticket, b.n_frames, list(keys) if keys is not None else [base + k for k in range(b.n_frames)]))
+        while len(self._pending) > depth:
+            self._digest(self._pending.pop(0))
+
+    def _digest(self, item):
+        ticket, n_frames, keys = item
+        recs = self.evaluator.collect(ticket)
+        bounds = np.searchsorted(recs["frame"], np.arange(n_frames + 1))
+        for k in range(n_frames):
+            self._accumulate_frame(recs[bounds[k]:bounds[k + 1]], key=keys[k])
+
+    def flush(self):
+        while self._pending:
+            self._digest(self._pending.pop(0))
+
     def step_frames(self, frames, res_name: str = "", comp_dis=None, keys=None):
-        """The loop body of eval.py:281-310 for a list of frame dicts at once.  ``comp_dis``: optional list of
-        (N,3) float32 arrays read from a zip (EVAL_FLAG 1); otherwise the flow stored under ``res_name``
-        (or zeros for "raw") is compensated on the fly (EVAL_FLAG 2)."""
+        """Host frame dicts in: ``comp_dis`` = optional list of (N,3) float32 arrays read from a zip (EVAL_FLAG 1);
+        otherwise the flow stored under ``res_name`` (or zeros for "raw") is compensated on the fly (EVAL_FLAG 2).
+        Synchronous convenience form of ``step_batch`` (packs, uploads, digests); streams of frames should go through
+        ``feeder.EvalFeeder`` + ``step_batch``."""
         frames = list(frames)
         if not frames:
             return
-        ev = self.evaluator
-        dev = ev.device
-        if self._compdis is None:
-            self._compdis = CompDisEngine(device=dev)
-        batch = FrameBatch.from_frames(frames, "raw", device=dev, with_masks=True)
-        mask = self._compdis.run(batch, sensor_dt=self.sensor_dt, data_name=self.data_name)["eval_mask"]   # eval.py:288-296
-        cat = lambda key, dt: torch.from_numpy(np.ascontiguousarray(np.concatenate([np.asarray(f[key]).astype(dt) for f in frames]))).to(dev)
-        gt = cat("flow", np.float32)
-        category = cat("flow_category_indices", np.uint8)
-        instance = cat("flow_instance_id", np.int64)
-        if comp_dis is not None:
-            est = torch.from_numpy(np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.float32) for c in comp_dis]))).to(dev)
-            mode = MODE_COMPDIS
-        elif res_name == "raw":
-            est, mode = None, MODE_RAW
-        else:
-            est, mode = cat(res_name, np.float32), MODE_FLOW          # KeyError like data[res_name]
-        recs = ev.run(batch.n_frames, batch.offsets, batch.pc0, gt, est, batch.lidar_dt, category, instance, mask, mode,
-                      sensor_dt=self.sensor_dt, pose0=batch.pose0, pose1=batch.pose1)
-        bounds = np.searchsorted(recs["frame"], np.arange(batch.n_frames + 1))
-        for k in range(batch.n_frames):
-            self._accumulate_frame(recs[bounds[k]:bounds[k + 1]], key=self.frame_cnt if keys is None else keys[k])
+        self.flush()
+        self.step_batch(EvalBatch.from_frames(frames, res_name, comp_dis, device=self.evaluator.device), keys=keys)
+        self.flush()
 
     # ---- host bookkeeping: eval.py:75-147 on the per-instance records of ONE sweep ---------------------------
     def _accumulate_frame(self, recs, key=0):
@@ -264,6 +341,7 @@ class InstanceMetrics:
         contribution independent, so replaying all contributions in sweep-key order on every rank reproduces
         the single-process lists element for element.  One small object all-gather; no per-sweep traffic."""
         import torch.distributed as dist
+        self.flush()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         gathered = [None] * dist.get_world_size()
@@ -277,6 +355,7 @@ class InstanceMetrics:
 
     # ---- reporting: eval.py:151-268 ------------------------------------------------------------------------
     def summary(self) -> dict:
+        self.flush()
         wavg = lambda v, w: float(np.average(v, weights=w)) if len(v) > 0 and np.sum(w) > 0 else 0.0
         std = lambda v: float(np.std(v)) if len(v) > 0 else 0.0
         out, pooled = {}, {"mpe": [], "cham": [], "num_pts": []}
@@ -367,6 +446,22 @@ def chamfer_distance(pc1, pc2) -> float:
     return float((np.nanmean(d12) + np.nanmean(d21)) / 2.0)
 
 
+def stream_batches(metrics: "InstanceMetrics", source, res_name: str = ""):
+    """``source`` yields (sweep keys, frame dicts, comp_dis list | None) per batch.  The frames are read, staged in pinned
+    memory and copied to the device by a background thread two batches ahead (feeder.EvalFeeder); the launch thread only
+    enqueues kernels (``step_batch``) and digests the previous batches' records."""
+    from .feeder import EvalFeeder
+    keys_q = []
+
+    def gen():
+        for keys, frames, cds in source:
+            keys_q.append(list(keys))
+            yield (frames, cds) if cds is not None else frames
+    for eb in EvalFeeder(gen(), res_name=res_name, device=metrics.evaluator.device):
+        metrics.step_batch(eb, keys=keys_q.pop(0))
+    metrics.flush()
+
+
 def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo", res_name: str = "", comp_dis_zip: str = "",
          batch_frames: int = 16, dataset=None, file_name: str | None = None):
     """eval.py:270-313.  Under ``torchrun`` sweep i is scored by rank i % world on its own GPU, the per-sweep contribution
@@ -384,12 +479,15 @@ def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo", res_name: str = 
             if dataset is None:
                 dataset = open_dataset(data_dir, vis_name=res_name if eval_flag == 2 else "", eval=True)
             mine = list(range(rank, len(dataset), world))
-            for lo in range(0, len(mine), batch_frames):
-                frames = [dataset[i] for i in mine[lo:lo + batch_frames]]
-                cds = None
-                if eval_flag == 1:
-                    cds = [read_output_zip(comp_dis_zip, (f["scene_id"], str(f["timestamp"]))) for f in frames]
-                metrics.step_frames(frames, res_name=res_name, comp_dis=cds, keys=mine[lo:lo + batch_frames])
+
+            def batches():
+                for lo in range(0, len(mine), batch_frames):
+                    frames = [dataset[i] for i in mine[lo:lo + batch_frames]]
+                    cds = None
+                    if eval_flag == 1:
+                        cds = [read_output_zip(comp_dis_zip, (f["scene_id"], str(f["timestamp"]))) for f in frames]
+                    yield mine[lo:lo + batch_frames], frames, cds
+            stream_batches(metrics, batches(), res_name)
         except BaseException as e:
             err = e
         everyone = distenv.all_ranks_ok(err is None)

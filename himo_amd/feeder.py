@@ -44,6 +44,26 @@ class _PinnedArena:
         return self._buf[lo:lo + nbytes].view(dtype).view(*shape)
 
 
+# pinned staging arenas outlive the feeder that allocated them: a pinned allocation of a batch's ~100 MB costs tens of
+# milliseconds, more than staging the batch itself
+_ARENA_POOL: list = []
+_ARENA_LOCK = threading.Lock()
+
+
+def _borrow_arenas(n: int) -> list:
+    with _ARENA_LOCK:
+        got = [_ARENA_POOL.pop() for _ in range(min(n, len(_ARENA_POOL)))]
+    return got + [_PinnedArena() for _ in range(n - len(got))]
+
+
+def _return_arenas(arenas: list, events: list) -> None:
+    for ev in events:
+        if ev is not None:
+            ev.synchronize()                      # the copies out of these buffers have completed
+    with _ARENA_LOCK:
+        _ARENA_POOL.extend(arenas)
+
+
 class SampleFeeder:
     """Iterate batches ``[(index, f0, Sample), ...]`` of up to ``batch`` frames, prepared ``depth`` batches ahead.
 
@@ -180,3 +200,89 @@ class ResultDrain:
         self._thread.join()
         if self._error is not None:
             raise self._error
+
+
+class EvalFeeder:
+    """Iterate device-resident ``eval.EvalBatch`` objects for the evaluator / scorer, prepared ``depth`` batches ahead.
+
+    ``source`` yields lists of frame dicts (one list = one batch), or ``(frames, comp_dis_list)`` pairs for the zip mode
+    (eval.py:303-304).  A background thread concatenates the per-frame arrays straight into PINNED staging memory (numpy,
+    GIL released) and issues the host -> device copies on its own stream; the consumer's stream is ordered after them by an
+    event, so ``InstanceMetrics.step_batch`` never waits for a copy it did not need yet."""
+
+    _END = object()
+
+    def __init__(self, source, res_name: str = "", device=None, depth: int = 2):
+        self.device = device if device is not None else _lib.require_gpu()
+        self.res_name, self.depth = res_name, depth
+        self._source = iter(source)
+        self._q = queue.Queue(maxsize=depth)
+        self._slots = _borrow_arenas(depth + 2)
+        self._slot_done = [None] * (depth + 2)
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._error = None
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="himo-eval-stage")
+        self._thread = threading.Thread(target=self._work, name="himo-eval-feeder", daemon=True)
+        self._thread.start()
+
+    def _work(self):
+        from .eval import EvalBatch
+        try:
+            torch.cuda.set_device(self.device)
+            slot = 0
+            for item in self._source:
+                frames, comp_dis = item if isinstance(item, tuple) else (item, None)
+                frames = list(frames)
+                if self._slot_done[slot] is not None:
+                    self._slot_done[slot].synchronize()
+                arena = self._slots[slot]
+                n = sum(len(f["pc0"]) for f in frames)
+                width = int(np.asarray(frames[0]["pc0"]).shape[1])
+                arena.reset(n * (4 * width + 12 + 12 + 4 + 1 + 8 + 1 + 1 + 16) + 4096 + 512 * len(frames))
+
+                jobs = []
+
+                def upload(parts, dtype):
+                    # concatenate (and convert) STRAIGHT into pinned memory on a pool thread -- numpy releases the GIL, the
+                    # arrays of a batch are staged in parallel -- and hand back the device tensor the copy will fill
+                    parts = [np.asarray(p) for p in parts]
+                    shape = (sum(p.shape[0] for p in parts),) + tuple(parts[0].shape[1:])
+                    tdt = torch.from_numpy(np.empty(0, dtype)).dtype
+                    pin = arena.take(shape, tdt)
+                    dst = torch.empty(shape, dtype=tdt, device=self.device)
+                    jobs.append((self._pool.submit(np.concatenate, parts, 0, pin.numpy(), casting="unsafe"), pin, dst))
+                    return dst
+
+                with torch.cuda.stream(self._stream):
+                    eb = EvalBatch.from_frames(frames, self.res_name, comp_dis, device=self.device, upload=upload)
+                    for job, pin, dst in jobs:
+                        job.result()
+                        dst.copy_(pin, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._stream)
+                self._slot_done[slot] = ev
+                self._q.put((eb, ev))
+                slot = (slot + 1) % len(self._slots)
+        except BaseException as e:
+            self._error = e
+        finally:
+            _return_arenas(self._slots, self._slot_done)
+            self._pool.shutdown(wait=False)
+            self._q.put(self._END)
+
+    def __iter__(self):
+        while True:
+            got = self._q.get()
+            if got is self._END:
+                if self._error is not None:
+                    raise self._error
+                return
+            eb, ev = got
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            b = eb.batch
+            for t in (b.offsets, b.pose0, b.pose1, b.pc0, b.lidar_dt, b.gm0, b.flow_is_valid, eb.gt, eb.category, eb.instance, eb.est):
+                if t is not None:
+                    t.record_stream(cur)
+            yield eb

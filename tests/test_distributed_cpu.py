@@ -284,13 +284,15 @@ def _worker_eval_cli(rank, world, port, data_dir, out_dir):
     import himo_oracle as oracle
     from himo_amd import eval as ev
 
-    def step_frames(self, frames, res_name="", comp_dis=None, keys=None):      # device double: the oracle scores the sweep
-        for f, key in zip(frames, keys):
-            ref = oracle.InstanceMetrics(self.data_name)
-            oracle.eval_frame(ref, f, res_name=res_name)
-            self._log.append((key, None))
-            self.frame_cnt += 1
-    ev.InstanceMetrics.step_frames = step_frames
+    def stream_batches(metrics, source, res_name=""):                        # device double: the oracle scores the sweep
+        for keys, frames, cds in source:
+            for f, key in zip(frames, keys):
+                ref = oracle.InstanceMetrics(metrics.data_name)
+                oracle.eval_frame(ref, f, res_name=res_name)
+                metrics._log.append((key, None))
+                metrics.frame_cnt += 1
+    ev.stream_batches = stream_batches
+    ev.InstanceMetrics.flush = lambda self: None
     ev.InstanceMetrics._apply = lambda self, fs: setattr(self, "frame_cnt", self.frame_cnt + 1)
     os.chdir(out_dir)
     m = ev.main(data_dir, res_name="seflowpp_best", batch_frames=2, file_name=str(Path(out_dir) / f"res-rank{rank}.json"))

@@ -155,3 +155,33 @@ def test_no_evaluated_points_is_a_noop(gpu):
     m = InstanceMetrics("av2")
     m.step_frames([f], res_name=RES)
     assert m.frame_cnt == 1 and m.summary() == {}
+
+
+def test_step_batch_pipeline_and_feeder_equal_the_serial_path(gpu, frames_av2, frames_scania):
+    """Device-resident batches with the records digested ``depth`` batches late (step_batch / flush), fed by
+    feeder.EvalFeeder (pinned staging, side-stream copies), must reproduce step_frames element for element -- including a
+    record buffer that is too small on the first try (the batch is run again with room for all)."""
+    import json
+    from himo_amd.eval import EvalBatch, InstanceMetrics
+    from himo_amd.feeder import EvalFeeder
+    for data_name, frames in (("av2", frames_av2), ("scania", frames_scania)):
+        want = InstanceMetrics(data_name)
+        for f in frames:
+            want.step_frames([f], res_name="seflowpp_best")
+        groups = [frames[i:i + 3] for i in range(0, len(frames), 3)]
+        got = InstanceMetrics(data_name)
+        for eb in EvalFeeder(iter(groups), res_name="seflowpp_best", device=gpu, depth=2):
+            got.step_batch(eb, depth=2)
+        assert got.frame_cnt < len(frames)                       # still in flight: nothing was waited for
+        got.flush()
+        tiny = InstanceMetrics(data_name)                         # record buffer of ONE entry: every batch overflows and reruns
+        ev = tiny.evaluator
+        launch = ev.launch
+        ev.launch = lambda *a, **k: launch(*a, **{**k, "max_records": k.get("max_records") or 1})
+        for g in groups:
+            tiny.step_batch(EvalBatch.from_frames(g, "seflowpp_best", device=gpu))
+        tiny.flush()
+        dump = lambda m: json.dumps(m.evaluate_data, default=float, sort_keys=True)
+        assert got.frame_cnt == tiny.frame_cnt == want.frame_cnt == len(frames)
+        assert dump(got) == dump(want) and dump(tiny) == dump(want)
+        assert [k for k, _ in got._log] == list(range(len(frames)))
