@@ -163,8 +163,27 @@ __device__ inline void store_block_vec(const ConvArgs& a, float* __restrict__ yo
         const int px = slot ^ ((slot >> 2) & 1);
         const uint4 d = *reinterpret_cast<const uint4*>(stg + q * 16);
         const int ch = ch0 + (OSPLIT ? (piece >> 2) * 16 : piece * 4);
-        if (px < n_valid_px && ch < a.Cout)
-            *reinterpret_cast<uint4*>(yout + (pix0 + px) * (int64_t)a.y_pitch + ch0 + piece * 4) = d;
+        if (px < n_valid_px && ch < a.Cout) {
+#ifdef HIMO_EXP_STORE_SCRATCH          // experiment: same store instructions, but into a 2 MB window (stays in L2: no HBM write traffic)
+            float* dst = a.y + ((((pix0 + px) * (int64_t)a.y_pitch + ch0 + piece * 4) & 0x7ffff) + (blockIdx.x & 7) * 0) ;
+#else
+            float* dst = yout + (pix0 + px) * (int64_t)a.y_pitch + ch0 + piece * 4;
+#endif
+#if defined(HIMO_EXP_STORE_NT)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(u32x4{d.x, d.y, d.z, d.w}, reinterpret_cast<u32x4*>(dst));
+#elif defined(HIMO_EXP_STORE_SC1)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 dv = {d.x, d.y, d.z, d.w};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(dv) : "memory");
+#elif defined(HIMO_EXP_STORE_SC01)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 dv = {d.x, d.y, d.z, d.w};
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(dv) : "memory");
+#else
+            *reinterpret_cast<uint4*>(dst) = d;
+#endif
+        }
     }
     __builtin_amdgcn_wave_barrier();
 }

@@ -115,6 +115,9 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int t = 0; t < NT; ++t)                  \
         ACC[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[rt][SA]),                    \
                                                            __builtin_bit_cast(f16x8, bcur[t][SB]), ACC[rt][t], 0, 0, 0);
+#ifdef HIMO_EXP_HNOMFMA                      // experiment: operand traffic without the matrix instructions
+        if (af[0][0][0] == (__bf16)12345.f)
+#endif
         if constexpr (FMT == 3) {
             HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
         } else {
@@ -139,6 +142,10 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
     }
 }
 
+#ifdef HIMO_EXP_HNOGATE                      // experiment: the gates without their exp / rcp (results are wrong)
+#define sigmoid_f(v) ((v) * 0.25f + 0.5f)
+#define tanh_f(v) ((v) * 0.5f)
+#endif
 template <int FMT>
 __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_head_kernel(GruHeadArgs a, GruHeadBatch batch) {
     __shared__ __attribute__((aligned(16))) unsigned char A[FMT * kGhPlane];

@@ -16,9 +16,13 @@ python bench.py --precision bf16x3 --no-cpu-baseline > $OUT/${RN}_bench_pipeline
 python bench.py --float32-activations --no-cpu-baseline > $OUT/${RN}_bench_pipeline_n1_float32_activations.json 2>> $OUT/pipeline.err
 python bench.py --workload compdis > $OUT/${RN}_bench_compdis_n1.json 2> $OUT/compdis.err
 python bench.py --workload train > $OUT/${RN}_bench_train_n1.json 2> $OUT/train.err
+python bench.py --cloud rings --no-cpu-baseline > $OUT/${RN}_bench_pipeline_n1_lidar_rings.json 2>> $OUT/pipeline.err
+python scripts/exp_layers.py 16 > $OUT/${RN}_conv3x3_per_layer.txt 2>&1
+python scripts/exp_eval.py > $OUT/${RN}_evaluator_throughput.txt 2>&1
+bash scripts/exp_clock_pmc.sh default > $OUT/${RN}_conv3x3_clock_and_mfma_busy.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 for wl in pipeline compdis train; do
-  ARGS="--workload $wl --no-cpu-baseline"
+  ARGS="--workload $wl --no-cpu-baseline --no-extra-precisions"
   [ $wl = train ] && ARGS="$ARGS --steps 3 --warmup 1"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$wl -o $wl -- python $R/bench.py $ARGS > $OUT/${RN}_bench_${wl}_n1_under_rocprof.json 2> $OUT/prof_$wl.err
   f=$(find $OUT/prof_$wl -name "*kernel_stats.csv" | head -1)
