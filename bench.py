@@ -12,6 +12,8 @@ Workloads (synthetic 120k-point sweeps already resident in HBM when the clock st
   compdis             only stages a1-a4 (the part of the path the reference tree contains) over a ragged batch of
                       B sweeps: the HBM-bound kernel on its own.
   train               BASELINE config 5: the self-supervised training step, data parallel (one flat all-reduce per step).
+  fastnsf             BASELINE config 4: optimisation-based flow -- a step fits the per-scene coordinate MLP to one 120k-point
+                      sweep pair (--fastnsf-iters Adam iterations); frames shard over the ranks like the pipeline's.
 ``--gpus N`` without a torchrun environment re-launches this file as N ranks (one per GPU) under
 ``python -m torch.distributed.run`` on 127.0.0.1; with one (WORLD_SIZE set) it must agree with WORLD_SIZE.
 ``--dry-run-cpu`` replaces ONLY the device work by a host stand-in (gloo instead of RCCL): it exists so that the launch,
@@ -46,7 +48,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "compdis", "train"])
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "compdis", "train", "fastnsf"])
+    ap.add_argument("--fastnsf-iters", type=int, default=100, help="fastnsf workload: optimiser iterations per frame")
     ap.add_argument("--frames-per-step", type=int, default=None, help="frames per rank per step")
     ap.add_argument("--points", type=int, default=POINTS_PER_FRAME)
     ap.add_argument("--precision", default="f16x2", choices=["bf16x3", "f16x2", "f32"],
@@ -71,7 +74,11 @@ def parse_args():
                     help="CPU test switch: host stand-in for the device work, gloo for RCCL; the reported numbers are meaningless")
     ap.add_argument("--traffic-json", default=str(REPO / "profiles" / "traffic_latest.json"))
     a = ap.parse_args()
-    if a.workload == "train":
+    if a.workload == "fastnsf":
+        a.steps = 5 if a.steps is None else a.steps
+        a.warmup = 1 if a.warmup is None else a.warmup
+        a.frames_per_step = 1
+    elif a.workload == "train":
         a.steps = 10 if a.steps is None else a.steps
         a.warmup = 2 if a.warmup is None else a.warmup
         a.frames_per_step = 1 if a.frames_per_step is None else a.frames_per_step
@@ -364,6 +371,16 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
 
         def step():
             eng.run(batch, sensor_dt=0.1, refined=args.refined, out=out)
+    elif args.workload == "fastnsf":
+        from himo_amd.fastnsf import FastNSF
+        from himo_amd.synthetic import make_frame
+        fr = [make_frame(100_000 * rank + 77 + i, n_points=P, cloud=args.cloud) for i in range(2)]
+        p0 = torch.from_numpy(np.ascontiguousarray(fr[0]["pc0"][:, :3])).to(device)
+        p1 = torch.from_numpy((fr[0]["pc0"][:, :3] + fr[0]["flow"]).astype(np.float32)).to(device)     # the sweep one step later
+        fitter = FastNSF(device=device, iters=args.fastnsf_iters)
+
+        def step():
+            result["flow"] = fitter.fit(p0, p1, fr[0]["pose0"], fr[0]["pose1"])
     elif args.workload == "train":
         # BASELINE config 5: self-supervised training, one sample per rank per optimiser step, ONE flat-gradient
         # all-reduce over RCCL, Adam.  Labels: ~10 % of the points in 30 dynamic clusters.
@@ -420,6 +437,12 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
             d = got.astype(np.float64) - ref
             parity = {"comp_dis_mean_epe_vs_ref": float(np.linalg.norm(d, axis=1).mean()),
                       "comp_dis_max_abs_vs_ref": float(np.abs(d).max()), "bit_exact_fraction": float((got == ref).mean())}
+        elif args.workload == "fastnsf":
+            gt = fr[0]["flow"]
+            got = result["flow"].cpu().numpy()
+            parity = {"loss_first_to_last_iteration": [fitter.loss_history[0][1], fitter.loss_history[-1][1]],
+                      "flow_mean_epe_vs_generating_flow": float(np.linalg.norm(got - gt, axis=1).mean()),
+                      "note": "gradient / trajectory parity vs the CPU restatement (oracle/fastnsf_oracle.py, unpinned): tests/test_fastnsf_gpu.py"}
         elif args.workload == "train":
             parity = {"loss_after_warmup": float(result["loss"].item()),
                       "note": "gradient parity vs CPU autograd through the oracle network: tests/test_train_gpu.py"}
@@ -439,7 +462,7 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     # The roofline kernel is timed live inside the timed region (HIP events around each of ITS launches, on the launch
     # stream); the other kernels are left alone there -- two event records per launch on ~45 launches per frame cost
     # ~12 % of the frame rate -- and get their table from one extra, untimed, fully profiled step afterwards.
-    dominant = {"compdis": "compdis_kernel", "train": "conv_wgrad_tiled_kernel"}.get(
+    dominant = {"compdis": "compdis_kernel", "train": "conv_wgrad_tiled_kernel", "fastnsf": "conv1x1_mfma_kernel"}.get(
         args.workload, {"bf16x3": "conv3x3_bf16x3_kernel", "f16x2": "conv3x3_f16x2_kernel"}.get(args.precision, "conv3x3_mfma_kernel"))
     if world > 1:
         dist.barrier()
@@ -501,6 +524,25 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
         workload = ("flow->comp_dis fused path only (a1-a4: ego-motion removal, dt0, flow2compDis; f64 chain, f32 I/O) "
                     "over a ragged HBM-resident batch; network forward NOT included")
         dtype = "f64"
+    elif args.workload == "fastnsf":
+        from himo_amd.fastnsf import HIDDEN, N_HIDDEN
+        # dominant kernel family of a fit: the MLP's row GEMMs (forward + input gradients) on float32 MFMA
+        k = prof.get("conv1x1_mfma_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
+        dims = [4] + [HIDDEN] * N_HIDDEN + [4]
+        fwd = sum(2.0 * P * ci * co for ci, co in zip(dims[:-1], dims[1:]))
+        dgrad = sum(2.0 * P * ci * co for ci, co in zip(dims[1:-1], dims[2:]))                     # every layer but the first
+        flops_fit = args.fastnsf_iters * (fwd + dgrad) + fwd                                        # + the final forward
+        alg_tf = flops_fit * args.steps / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
+        roofline = {"bound": "mfma", "kernel": "conv1x1_mfma_kernel (v_mfma_f32_32x32x2_f32; the MLP's forward / input-gradient row GEMMs)",
+                    "achieved": alg_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": alg_tf / MFMA_F32_PEAK_TF, "traffic": None,
+                    "avg_launch_ms": k["avg_ms"], "launches_timed": k["count"], "algorithmic_flops_per_frame": flops_fit,
+                    "share_of_step_time": k["total_ms"] / (elapsed * 1e3),
+                    "note": "an iteration is ~40 short launches (8-layer MLP forward / backward on 120k rows, two exact NN searches, "
+                            "truncated Chamfer, weight gradients, Adam); the row GEMMs are the largest family (K = 128: 64 matrix "
+                            "instructions per tile, so prologue / epilogue weigh a third)"}
+        workload = (f"FastNSF (BASELINE config 4): fit the per-scene coordinate MLP (3 -> 8 x 128 -> 3) to one pair of 120k-point sweeps, "
+                    f"{args.fastnsf_iters} Adam iterations per frame, exact NN correspondences every iteration")
+        dtype = "f32"
     elif args.workload == "train":
         from himo_amd.seflow import spec
         # dominant kernel of the step: the 3x3 weight gradients (float32 MFMA, LDS-tiled split-K), 19 launches per step
@@ -545,11 +587,14 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
         line["config"]["input"] = (f"himo_amd.synthetic.make_frame sweeps (SURVEY 8(d) seeded frames, cloud={args.cloud}); "
                                    f"{max(1, args.sample_sets)} distinct batches rotate through the steps, so the ragged batch "
                                    "container is rebuilt from different samples inside every timed step")
+    if args.workload == "fastnsf":
+        line["metric"] = "fastnsf_frames_per_sec_120k"
+        line["config"]["iterations_per_frame"] = args.fastnsf_iters
     if args.workload == "train":
         line["metric"] = "train_frames_per_sec_120k"
         line["config"]["parallelism"] = f"data parallel x{world}, one flat all-reduce per step"
         line["config"]["matrix_arithmetic"] = args.train_precision
-    if not dry and not args.no_cpu_baseline and args.workload != "train" and world == 1:     # CPU leg: rank 0 at N = 1 only
+    if not dry and not args.no_cpu_baseline and args.workload in ("pipeline", "compdis") and world == 1:     # CPU leg: rank 0 at N = 1 only
         if args.workload == "compdis":
             frames = [frame_to_host(batch, i) for i in range(min(8, B))]
             line["cpu_baseline"] = cpu_baseline_compdis(frames, args.cpu_seconds, args.cpu_frames)
