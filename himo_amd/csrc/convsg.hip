@@ -62,13 +62,13 @@ __device__ inline void glds16(const void* gsrc, unsigned lds_dst) {
 // 0 .. 32 (padded to 48), odd columns 1, 3, .. 63 in slots 48 .. 79 -- so that the 32 output pixels of a fragment (input
 // columns 2 li + kx) are again 32 consecutive slots for every tap (kx = 0: li, 1: 48 + li, 2: li + 1).  The gather costs
 // nothing: every DMA lane has its own source address anyway.
-template <int EPI, int PH, int MI, bool OSPLIT, int S>
-__global__ __launch_bounds__(256, (S == 2 || MI == 4) ? 3 : 4)
+template <int EPI, int PH, int MI, bool OSPLIT, int S, int NT = 1>
+__global__ __launch_bounds__(256, NT == 2 ? 2 : (S == 2 || MI == 4) ? 3 : 4)
 void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int TW = 32, TH = MI * PH, PHt = S == 1 ? TH + 2 : 2 * TH + 1, PWP = S == 1 ? 48 : 80, UPR = PWP / 16;
     constexpr int kRow = PWP * 64, kBuf = PHt * kRow;
     constexpr int kUnits = PHt * UPR, kUPW = (kUnits + 3) / 4;    // DMA units of 16 pixels; units per wave
-    constexpr int BN = (4 / PH) * 32;
+    constexpr int BN = (4 / PH) * 32 * NT;                       // NT column tiles of 32 channels per wave
     __shared__ __attribute__((aligned(1024))) unsigned char patch[2 * kBuf];
 
 #ifdef HIMO_EXP_STAGGER
@@ -91,7 +91,7 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int wp = wave % PH, wc = wave / PH;
     const int li = lane & 31, lh = lane >> 5;
-    const int co = tn * BN + wc * 32 + li;
+    const int co = tn * BN + wc * NT * 32 + li;                  // this lane's channel in column tile 0 (+ 32 per tile)
     const bool co_ok = co < a.Cout;
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(&patch[0]);
@@ -119,22 +119,32 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         }
     };
 
-    floatx16 acc[MI];
+    floatx16 acc[MI][NT];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][nt][r] = 0.f;
 
     // weight fragments: uniform base + 32-bit offsets (the packed weights are a few MB): one scalar multiply-add for the
     // (tap, slab) block and one vector add per load
     const int co_ld = co_ok ? co : a.Cout - 1;
     const unsigned char* __restrict__ wb = reinterpret_cast<const unsigned char*>(wpk);
-    const unsigned b_lane = (unsigned)co_ld * 32u + (unsigned)lh * 16u;
+    unsigned b_lane[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = co + nt * 32 < a.Cout ? co + nt * 32 : a.Cout - 1;
+        b_lane[nt] = (unsigned)c * 32u + (unsigned)lh * 16u;
+    }
     const unsigned b_plane = (unsigned)a.Cout * 32u, b_block = 2u * b_plane;          // bytes per plane, per (tap, slab)
-    auto load_b = [&](int tap, int slab, uint4 (&b)[2]) {
-        const unsigned off = (unsigned)(tap * slabs + slab) * b_block + b_lane;
-        b[0] = *reinterpret_cast<const uint4*>(wb + off);
-        b[1] = *reinterpret_cast<const uint4*>(wb + (off + b_plane));
+    auto load_b = [&](int tap, int slab, uint4 (&b)[NT][2]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const unsigned off = (unsigned)(tap * slabs + slab) * b_block + b_lane[nt];
+            b[nt][0] = *reinterpret_cast<const uint4*>(wb + off);
+            b[nt][1] = *reinterpret_cast<const uint4*>(wb + (off + b_plane));
+        }
     };
 
     // fragment read offsets (buffer 0, kernel row 0, this wave's first image row): [kx][plane]
@@ -146,7 +156,7 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         for (int s = 0; s < 2; ++s) rd[kx][s] = wp * MI * S * kRow + p * 64 + (((2 * s + lh) ^ f) << 4);
     }
 
-    uint4 bq[3][2];
+    uint4 bq[3][NT][2];
     stage(0, 0);
     load_b(0, 0, bq[0]);
     load_b(1, 0, bq[1]);
@@ -180,48 +190,58 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
                         af[mi][s] = *reinterpret_cast<const f16x8*>(&patch[rd[kx][s] + rowoff + mi * S * kRow]);
-                const uint4 (&bcur)[2] = bq[kx];
+                const uint4 (&bcur)[NT][2] = bq[kx];
 #define HIMO_TERM16(SA, SB)                                                                                        \
-    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                \
-        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][SA], __builtin_bit_cast(f16x8, bcur[SB]), acc[mi], 0, 0, 0);
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)              \
+        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][SA], __builtin_bit_cast(f16x8, bcur[nt][SB]), acc[mi][nt], 0, 0, 0);
                 HIMO_TERM16(1, 0) HIMO_TERM16(0, 1) HIMO_TERM16(0, 0)
 #undef HIMO_TERM16
 #ifndef HIMO_EXP_NOSCHED
                 // this tap's weight prefetch and ALL its activation-fragment reads before its matrix instructions (the
                 // compiler otherwise feeds each MFMA pair from a just-issued ds_read and sinks the prefetch next to its use)
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2 * NT, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, MI * 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MI * 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MI * NT * 3, 0);
 #endif
             }
         }
 #ifndef HIMO_EXP_NOBAR
         if (more) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // at most the next slab's first two weight fragments stay in flight
+            if (NT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // at most the next slab's first two weight fragments stay in flight
             __syncthreads();
         }
 #endif
     }
 
     float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
-    const float b = a.bias ? a.bias[co_ld] : 0.f;
-    float sc = 1.f, sh = 0.f;
-    if (EPI == kEpiBiasBnGelu) { sc = a.scale[co_ld]; sh = a.shift[co_ld]; }
+    float bs[NT], scs[NT], shs[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = co + nt * 32 < a.Cout ? co + nt * 32 : a.Cout - 1;
+        bs[nt] = a.bias ? a.bias[c] : 0.f;
+        scs[nt] = 1.f; shs[nt] = 0.f;
+        if (EPI == kEpiBiasBnGelu) { scs[nt] = a.scale[c]; shs[nt] = a.shift[c]; }
+    }
+    const float b = bs[0], sc = scs[0], sh = shs[0];
 #if !defined(HIMO_EXP_NOEPI) && !defined(HIMO_EXP_NOSTORE) && !defined(HIMO_EXP_DWORDSTORE)
-    if (a.act_flags & kActVecStore) {            // 16-byte stores through a wave-private LDS transpose (store_block_vec)
+    if (NT > 1 || (a.act_flags & kActVecStore)) {   // 16-byte stores through a wave-private LDS transpose (store_block_vec)
         __syncthreads();                         // every wave has read its last patch rows: the patch memory is free
         unsigned char* stg = patch + wave * 4096;
         const int n_px = a.Wo - ox0 < 32 ? a.Wo - ox0 : 32;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int oy = oy0 + wp * MI + mi;
-            unsigned word[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = epilogue_value<EPI>(acc[mi][r] * kF16AccScale + b, sc, sh);
-                word[r] = OSPLIT ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
+            for (int nt = 0; nt < NT; ++nt) {
+                unsigned word[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = epilogue_value<EPI>(acc[mi][nt][r] * kF16AccScale + bs[nt], scs[nt], shs[nt]);
+                    word[r] = OSPLIT ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
+                }
+                store_block_vec<OSPLIT>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, oy < a.Ho ? n_px : 0, tn * BN + (wc * NT + nt) * 32);
             }
-            store_block_vec<OSPLIT>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, oy < a.Ho ? n_px : 0, tn * BN + wc * 32);
         }
         return;
     }
@@ -233,7 +253,7 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float v = acc[mi][r] * kF16AccScale + b;
+            float v = acc[mi][0][r] * kF16AccScale + b;
 #if defined(HIMO_EXP_NOEPI)                    // experiment: no activation / split arithmetic, same stores (results are wrong)
             if (oy < a.Ho && ox < a.Wo) yout[((int64_t)oy * a.Wo + ox) * a.y_pitch + (OSPLIT ? (co & ~15) + ((co & 1) ? 8 : 0) + ((co & 15) >> 1) : co)] = v;
 #elif defined(HIMO_EXP_NOSTORE)                // experiment: full epilogue arithmetic, (almost) no stores
@@ -431,11 +451,11 @@ bool launch_conv1_presplit(const ConvArgs& a, int epilogue, const void* w_packed
     return true;
 }
 
-template <int PH, int MI, int S = 1>
+template <int PH, int MI, int S = 1, int NT = 1>
 static void launch_sg(const ConvArgs& a_in, int epi, bool osplit, const unsigned short* w, dim3 grid, hipStream_t s) {
     ConvArgs a = a_in;
     if (vec_store_ok(a)) a.act_flags |= kActVecStore;
-#define HIMO_SG(E, O) hipLaunchKernelGGL((conv3_presplit_kernel<E, PH, MI, O, S>), grid, dim3(256), 0, s, a, w)
+#define HIMO_SG(E, O) hipLaunchKernelGGL((conv3_presplit_kernel<E, PH, MI, O, S, NT>), grid, dim3(256), 0, s, a, w)
     if (epi == kEpiBias) { if (osplit) HIMO_SG(kEpiBias, true); else HIMO_SG(kEpiBias, false); }
     else { if (osplit) HIMO_SG(kEpiBiasBnGelu, true); else HIMO_SG(kEpiBiasBnGelu, false); }
 #undef HIMO_SG
@@ -453,6 +473,14 @@ bool launch_conv3_presplit(const ConvArgs& a, int epilogue, const void* w_packed
         ProfScope ps("conv3x3s2_f16x2_kernel", s);
         if (wide) launch_sg<1, 2, 2>(a, epilogue, out_split, (const unsigned short*)w_packed, dim3((unsigned)blocks), s);
         else launch_sg<2, 1, 2>(a, epilogue, out_split, (const unsigned short*)w_packed, dim3((unsigned)blocks), s);
+        return true;
+    }
+    // 64-channel layers, rows_hint 8: a wave owns 2 rows x 32 pixels x BOTH 32-channel column tiles (every activation fragment
+    // meets two weight fragments), four waves = an 8-row tile on a 10-row patch (1.25x halo instead of 1.5x), two blocks per CU
+    if (!wide && rows_hint == 8 && vec_store_ok(a)) {
+        const int64_t blocks = (int64_t)a.N * ((a.Ho + 7) / 8) * ((a.Wo + 31) / 32) * ((a.Cout + 63) / 64);
+        ProfScope ps("conv3x3_f16x2_kernel", s);
+        launch_sg<4, 2, 1, 2>(a, epilogue, out_split, (const unsigned short*)w_packed, dim3((unsigned)blocks), s);
         return true;
     }
     auto blocks_for = [&](int mi) -> int64_t {

@@ -36,7 +36,13 @@ for (name, n, h, w, ci, co, epi, reps) in shapes:
     ms = sorted(v["avg_ms"] for v in p.values())[0]
     fl = 2.0 * n * h * w * ci * co * 9
     total += ms * reps
-    print(f"{name:14s} N{n:3d} {h}x{w} {ci:3d}->{co:3d} epi{epi}: {ms*1e3:8.1f} us  {fl/ms/1e9:5.0f} TF f32-eq  x{reps}")
+    same = ""
+    if HINT:                                   # a pinned variant must reproduce the default variant's bits
+        ref = conv2d_nhwc(xin, wt, b, epilogue=epi, scale=sc, shift=sh, precision="f16x2", tile_hint=0, act_layout=lay)
+        got = conv2d_nhwc(xin, wt, b, epilogue=epi, scale=sc, shift=sh, precision="f16x2", tile_hint=HINT, act_layout=lay)
+        same = f"  bit-identical to hint 0: {torch.equal(ref, got)}"
+        del ref, got
+    print(f"{name:14s} N{n:3d} {h}x{w} {ci:3d}->{co:3d} epi{epi}: {ms*1e3:8.1f} us  {fl/ms/1e9:5.0f} TF f32-eq  x{reps}{same}")
     del xin
     torch.cuda.empty_cache()
 print(f"sum over the 20 layers of a forward: {total:.3f} ms per {BATCH} samples")
