@@ -483,6 +483,20 @@ bool launch_conv3_presplit(const ConvArgs& a, int epilogue, const void* w_packed
         launch_sg<4, 2, 1, 2>(a, epilogue, out_split, (const unsigned short*)w_packed, dim3((unsigned)blocks), s);
         return true;
     }
+    // wide layers, rows_hint 12: 4 rows x 64 channels per wave (128 accumulator registers, two waves per SIMD): half the
+    // fragment reads AND half the weight loads per matrix instruction; 3-4 % on the 256-channel decoder layers, slower on
+    // the 128-channel encoder ones (the autotune decides per layer)
+    if (wide && rows_hint == 12 && vec_store_ok(a)) {
+        ProfScope ps("conv3x3_f16x2_kernel", s);
+        if (a.Cout % 256 == 0) {
+            const int64_t blocks = (int64_t)a.N * ((a.Ho + 3) / 4) * ((a.Wo + 31) / 32) * (a.Cout / 256);
+            launch_sg<1, 4, 1, 2>(a, epilogue, out_split, (const unsigned short*)w_packed, dim3((unsigned)blocks), s);
+        } else {
+            const int64_t blocks = (int64_t)a.N * ((a.Ho + 7) / 8) * ((a.Wo + 31) / 32) * ((a.Cout + 127) / 128);
+            launch_sg<2, 4, 1, 2>(a, epilogue, out_split, (const unsigned short*)w_packed, dim3((unsigned)blocks), s);
+        }
+        return true;
+    }
     auto blocks_for = [&](int mi) -> int64_t {
         const int th = mi * ph;
         return (int64_t)a.N * ((a.Ho + th - 1) / th) * ((a.Wo + 31) / 32) * ((a.Cout + bn - 1) / bn);

@@ -272,8 +272,10 @@ class SeFlowNet:
             cands = [0x1000 | 4, 0x1000 | 2, 0x1000 | 1] if d.ksize == 1 else []
         if d.w_packed and d.ksize == 3:
             cands += [0x1000 | 4, 0x1000 | 2, 0x1000 | 1] if d.stride == 1 else [0x1000 | 2, 0x1000 | 1]   # weights-from-L2 structure (csrc/convsp.hip)
-            if d.stride == 1 and d.cout <= 64 and (d.act_layout & ACT_SPLIT_IN) and self.packed_format == 1:
-                cands.append(0x1000 | 8)     # 64-channel layers: 8-row tiles, a wave owns both 32-channel column tiles (convsg.hip)
+            if d.stride == 1 and (d.act_layout & ACT_SPLIT_IN) and self.packed_format == 1:
+                # two 32-channel column tiles per wave (convsg.hip): 8-row tiles for the 64-channel layers, 4 rows x 64 channels
+                # per wave for the wide ones
+                cands.append(0x1000 | (8 if d.cout <= 64 else 12))
         if len(cands) < 2:
             return cands[0] if cands else 0
         times = {hint: float("inf") for hint in cands}

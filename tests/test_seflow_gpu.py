@@ -186,7 +186,7 @@ def test_split_activation_format_is_bit_identical(gpu):
         s_0 = conv2d_nhwc(x, w0, b0, stride=s0, epilogue=1, act_layout=ACT_SPLIT_OUT, **kw)
         h0 = r0.half()
         assert torch.equal(_decode_split(s_0), h0.float() + (r0 - h0.float()).half().float())     # the format itself
-        for hint in (0, 0x1004, 0x1002, 0x1001, 0x1008):       # 0x1008: 8-row tiles, two column tiles per wave (<= 64 channels)
+        for hint in (0, 0x1004, 0x1002, 0x1001, 0x1008, 0x100c):   # 0x1008 / 0x100c: two column tiles per wave (<= 64 channels / wider)
             s_1 = conv2d_nhwc(s_0, w1, b1, epilogue=1, act_layout=ACT_SPLIT_IN | ACT_SPLIT_OUT, tile_hint=hint, **kw)
             assert torch.equal(conv2d_nhwc(s_0, w1, b1, epilogue=1, act_layout=ACT_SPLIT_IN, tile_hint=hint, **kw), r1)
             assert torch.equal(conv2d_nhwc(s_1, w2, b2, precision="f16x2", act_layout=ACT_SPLIT_IN, tile_hint=hint), r2), \
