@@ -48,10 +48,11 @@ def test_wgrad_and_masked_dgrad_kernels(gpu):
     assert (out - ref).abs().max().item() <= 1e-4
 
 
-def test_single_step_gradients_match_autograd(gpu):
+@pytest.mark.parametrize("n0,n1", [(6000, 5500), (120_000, 119_000)])      # incl. BASELINE size
+def test_single_step_gradients_match_autograd(gpu, n0, n1):
     import fastnsf_oracle as fo
     from himo_amd.fastnsf import FastNSF, init_mlp
-    pc0, pc1 = _scene(1, 6000, 5500)
+    pc0, pc1 = _scene(1, n0, n1)
     layers = init_mlp(3)
     eng = FastNSF(device=gpu, iters=1, lr=0.0, seed=3)
     eng.fit(pc0, pc1, layers=layers)

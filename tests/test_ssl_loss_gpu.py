@@ -51,7 +51,7 @@ def test_nn_grid_matches_brute_force_kernel_including_ties(gpu):
     assert torch.equal(idx, bi) and (idx < 3000).all()       # lowest index wins in both kernels
 
 
-@pytest.mark.parametrize("n0,n1", [(4000, 3500), (30_000, 32_000)])
+@pytest.mark.parametrize("n0,n1", [(4000, 3500), (30_000, 32_000), (120_000, 118_000)])      # incl. BASELINE size
 def test_loss_terms_and_gradient(gpu, n0, n1):
     import sslloss_oracle as so
     from himo_amd.ssl_loss import SeFlowLoss
