@@ -120,16 +120,17 @@ def _sample(n, seed=0):
     return pch, pc0, pc1, pose_h, pose0, pose1
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "mixed", "f32"])
-def test_full_network_gradients_match_autograd(gpu, precision):
+@pytest.mark.parametrize("precision,n_points", [("bf16x3", 6000), ("mixed", 6000), ("f32", 6000), ("mixed", 120_000)])
+def test_full_network_gradients_match_autograd(gpu, precision, n_points):
     """Every trainable tensor's gradient (pillar net, 16 encoder convs, decoder, head) against CPU autograd through the
-    oracle network, for the linear functional L = sum(res * G)."""
+    oracle network, for the linear functional L = sum(res * G) -- at test size in all three arithmetics and once at
+    BASELINE size (3 x 120k points) in the training default."""
     import oracle.seflow_oracle as so
     from himo_amd.seflow import spec
     from himo_amd.seflow.train import SeFlowTrainer
     params = spec.init_params(4)
-    pch, pc0, pc1, pose_h, pose0, pose1 = _sample(6000, seed=3)
-    tr = SeFlowTrainer(params, device=gpu, max_points=8000, precision=precision)
+    pch, pc0, pc1, pose_h, pose0, pose1 = _sample(n_points, seed=3)
+    tr = SeFlowTrainer(params, device=gpu, max_points=n_points + 2000, precision=precision)
     res = tr.forward(pch, pc0, pc1, pose_h, pose0, pose1)
     rng = np.random.default_rng(9)
     G = np.zeros((len(pc0), 4), np.float32)
