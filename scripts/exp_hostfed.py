@@ -13,7 +13,7 @@ from himo_amd.seflow.model import SeFlowNet
 from himo_amd.synthetic import make_frame
 
 dev = torch.device("cuda", 0)
-B, P, STEPS = 8, 120_000, int(sys.argv[1]) if len(sys.argv) > 1 else 20
+B, P, STEPS = 16, 120_000, int(sys.argv[1]) if len(sys.argv) > 1 else 20
 frames = [make_frame(i, n_points=P) for i in range(B + 2)]
 for f in frames:
     f["pc0"] = np.ascontiguousarray(f["pc0"], dtype=np.float32); f["lidar_dt"] = np.ascontiguousarray(f["lidar_dt"], dtype=np.float32)

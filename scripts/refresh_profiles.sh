@@ -19,6 +19,8 @@ python bench.py --workload train > $OUT/${RN}_bench_train_n1.json 2> $OUT/train.
 python bench.py --cloud rings --no-cpu-baseline > $OUT/${RN}_bench_pipeline_n1_lidar_rings.json 2>> $OUT/pipeline.err
 python scripts/exp_layers.py 16 > $OUT/${RN}_conv3x3_per_layer.txt 2>&1
 python scripts/exp_eval.py > $OUT/${RN}_evaluator_throughput.txt 2>&1
+python scripts/exp_hostfed.py > $OUT/${RN}_hostfed_pipeline.txt 2>&1
+python bench.py --workload fastnsf > $OUT/${RN}_bench_fastnsf_n1.json 2>> $OUT/pipeline.err
 bash scripts/exp_clock_pmc.sh default > $OUT/${RN}_conv3x3_clock_and_mfma_busy.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 for wl in pipeline compdis train; do
