@@ -53,7 +53,10 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     // double-buffered while two blocks still fit a CU's LDS; else single-buffered with a second barrier per slab
     using PL = PatchLayout<(PH == 2 || S == 2)>;
     constexpr int NB = 2 * FMT * NPIX * PL::kPitch <= 66 * 1024 ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) unsigned char patch[NB][FMT][NPIX * PL::kPitch];
+    // raw bytes, at least the 4 x 4 KB the vectorised epilogue stages through (store_block_vec, conv_common.h)
+    constexpr int kPatchBytes = NB * FMT * NPIX * PL::kPitch;
+    __shared__ __attribute__((aligned(16))) unsigned char patch_raw[kPatchBytes < 16384 ? 16384 : kPatchBytes];
+    auto& patch = *reinterpret_cast<unsigned char (*)[NB][FMT][NPIX * PL::kPitch]>(patch_raw);
 
     const int n_tiles_n = (a.Cout + BN - 1) / BN;
     int bid = xcd_block_id(blockIdx.x, gridDim.x);
@@ -218,11 +221,36 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     }
 
     float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
+    const bool osplit = (a.act_flags & kActSplitOut) != 0;       // output in the split activation format (convsg.hip)
+    if (EPI != kEpiReluMask && (a.act_flags & kActVecStore)) {   // 16-byte stores through a wave-private LDS transpose
+        const int cl = co_ok ? co : a.Cout - 1;
+        const float bv = a.bias ? a.bias[cl] : 0.f;
+        float scv = 1.f, shv = 0.f;
+        if (EPI == kEpiBiasBnGelu) { scv = a.scale[cl]; shv = a.shift[cl]; }
+        __syncthreads();                                          // every wave has read its last patch rows
+        unsigned char* stg = patch_raw + wave * 4096;
+        const int n_px = a.Wo - ox0 < 32 ? a.Wo - ox0 : 32;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int oy = oy0 + wp * MI + mi;
+            unsigned word[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mi][r];
+                if (XACC) v += acx[mi][r] * kF16LowInv;
+                if (FMT == 2) v *= kF16AccScale;
+                v = epilogue_value<EPI>(v + bv, scv, shv);
+                word[r] = (FMT == 2 && osplit) ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
+            }
+            if (FMT == 2 && osplit) store_block_vec<true>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, oy < a.Ho ? n_px : 0, tn * BN + wc * 32);
+            else store_block_vec<false>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, oy < a.Ho ? n_px : 0, tn * BN + wc * 32);
+        }
+        return;
+    }
     if (!co_ok) return;
     const float b = a.bias ? a.bias[co] : 0.f;
     float sc = 1.f, sh = 0.f;
     if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
-    const bool osplit = (a.act_flags & kActSplitOut) != 0;       // output in the split activation format (convsg.hip)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int oy = oy0 + wp * MI + mi;
@@ -241,7 +269,9 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 }
 
 template <int PH, int FMT, int MI, int S>
-static void launch_sp_epi(const ConvArgs& a, int epi, const unsigned short* w, dim3 grid, hipStream_t s) {
+static void launch_sp_epi(const ConvArgs& a_in, int epi, const unsigned short* w, dim3 grid, hipStream_t s) {
+    ConvArgs a = a_in;
+    if (vec_store_ok(a) && (!(a.act_flags & kActSplitOut) || !(a.Cout & 15))) a.act_flags |= kActVecStore;
     switch (epi) {
         case kEpiBias: hipLaunchKernelGGL((conv3_split_kernel<kEpiBias, PH, FMT, MI, S>), grid, dim3(256), 0, s, a, w); break;
         case kEpiBiasBnGelu: hipLaunchKernelGGL((conv3_split_kernel<kEpiBiasBnGelu, PH, FMT, MI, S>), grid, dim3(256), 0, s, a, w); break;
