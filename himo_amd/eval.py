@@ -226,6 +226,7 @@ class InstanceMetrics:
     # ---- a7: the reference's own entry point --------------------------------------------------------
     def step_eval(self, pc, gt_flow, pc_dt0, gt_category, gt_instance, est_flow=None, est_dis=None):
         """Same arguments as eval.py:64 (already masked, ego-motion-free arrays of ONE sweep)."""
+        self.flush()                                   # batches still in flight keep their place in the sweep order
         dev = self.evaluator.device
         n = len(pc)
         if est_flow is None and est_dis is None:
