@@ -51,23 +51,30 @@ struct GruHeadBatch {
     GruHeadSample s[kGhMaxSamples];
 };
 
-constexpr int kGhRows = 64, kGhSlabs = 12;              // 192 / 16
-constexpr int kGhPlane = kGhSlabs * kGhRows * 32;       // bytes per 16-bit plane
+// SLABS = 12: the GEMMs run over all 192 columns of [h | x].  SLABS = 9 ("folded", himo_gru_head_batch_folded): x =
+// Linear(3,64)(offset) is an AFFINE function of the point's 3-D offset o and never changes over the iterations, so its share
+// of every gate pre-activation is x W_x = [o, 1] [W_off W_x ; b_off W_x] -- a K = 4 product.  The host folds the 64 x-rows of
+// every weight matrix into those 4 rows (padded to one 16-row slab), the A operand's ninth slab holds (o0, o1, o2, 1, 0 ...)
+// for the whole kernel, and every GEMM of the head runs 9 slabs instead of 12: a quarter less matrix work, fragment reads,
+// weight stream and operand LDS, with no extra vector work.
+constexpr int kGhRows = 64;
 
+template <int SLABS>
 __device__ inline int a_slot(int s, int slab, int row, int half) {
-    return ((s * kGhSlabs + slab) * kGhRows + row) * 32 + ((half ^ ((row >> 4) & 1)) << 4);
+    return ((s * SLABS + slab) * kGhRows + row) * 32 + ((half ^ ((row >> 4) & 1)) << 4);
 }
 
 // one value of the A operand, column k of `row`, into the FMT planes (FMT = 3: bf16 h, m, l; FMT = 2: fp16 h, l')
-template <int FMT>
+template <int FMT, int SLABS>
 __device__ inline void a_store(unsigned char* A, int row, int k, float v) {
+    constexpr int kGhPlane = SLABS * kGhRows * 32;       // bytes per 16-bit plane
 #ifdef HIMO_EXP_HNOSTORE
     if (v != 12345.678f) return;
 #endif
     unsigned h, m = 0, l;
     if (FMT == 3) split3(v, h, m, l); else split2(v, h, l);
     const int slab = k >> 4, kk = k & 15;
-    const int off = a_slot(0, slab, row, kk >> 3) + (kk & 7) * 2;
+    const int off = a_slot<SLABS>(0, slab, row, kk >> 3) + (kk & 7) * 2;
     *reinterpret_cast<unsigned short*>(A + off) = (unsigned short)h;
     if (FMT == 3) *reinterpret_cast<unsigned short*>(A + off + kGhPlane) = (unsigned short)m;
     *reinterpret_cast<unsigned short*>(A + off + (FMT - 1) * kGhPlane) = (unsigned short)l;
@@ -75,7 +82,7 @@ __device__ inline void a_store(unsigned char* A, int row, int k, float v) {
 
 // acc[rt][t] += A[rows of tile rt][0..192) * W[:, col[t] + li] for the wave's NT column tiles; RT row tiles starting at rt0
 // FMT = 2: one accumulator (bf16x3.h); with -DHIMO_F16_SCALED acx collects the 2^11-scaled cross terms
-template <int RT, int NT, int FMT>
+template <int RT, int NT, int FMT, int SLABS>
 __device__ inline void gemm192(const unsigned char* A, const unsigned short* __restrict__ wpk, int cout, const int (&col)[NT],
                                floatx16 (&acc)[RT][NT], int rt0, int li, int lh) {
     constexpr bool XACC = FMT == 2 && kF16Scaled;
@@ -97,17 +104,18 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
                 b[t][s] = *reinterpret_cast<const uint4*>(wpk + (((int64_t)slab * FMT + s) * cout + col[t] + li) * 16 + lh * 8);
     };
     load_b(0, bcur);
-#pragma unroll 2
-    for (int slab = 0; slab < kGhSlabs; ++slab) {
+    constexpr int kUnroll = SLABS % 2 == 0 ? 2 : 3;      // a divisor of the trip count: no remainder loop, no full unroll
+#pragma unroll kUnroll
+    for (int slab = 0; slab < SLABS; ++slab) {
 #ifndef HIMO_EXP_HNOB
-        if (slab + 1 < kGhSlabs) load_b(slab + 1, bnxt);
+        if (slab + 1 < SLABS) load_b(slab + 1, bnxt);
 #endif
         bf16x8 af[RT][FMT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int s = 0; s < FMT; ++s)
-                af[rt][s] = *reinterpret_cast<const bf16x8*>(A + a_slot(s, slab, (rt0 + rt) * 32 + li, lh));
+                af[rt][s] = *reinterpret_cast<const bf16x8*>(A + a_slot<SLABS>(s, slab, (rt0 + rt) * 32 + li, lh));
 #define HIMO_TERM(SA, SB)                                                                                          \
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int t = 0; t < NT; ++t)                  \
         acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rt][SA], __builtin_bit_cast(bf16x8, bcur[t][SB]), acc[rt][t], 0, 0, 0);
@@ -146,8 +154,10 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
 #define sigmoid_f(v) ((v) * 0.25f + 0.5f)
 #define tanh_f(v) ((v) * 0.5f)
 #endif
-template <int FMT>
+template <int FMT, int SLABS>
 __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_head_kernel(GruHeadArgs a, GruHeadBatch batch) {
+    constexpr bool FOLD = SLABS == 9;
+    constexpr int kGhPlane = SLABS * kGhRows * 32;
     __shared__ __attribute__((aligned(16))) unsigned char A[FMT * kGhPlane];
     __shared__ int s_pid[kGhRows];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -167,8 +177,19 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
         const int64_t i = r0 + threadIdx.x;
         s_pid[threadIdx.x] = i < a.n ? a.pid[i] : -1;
     }
-    // x = Linear(3,64)(offset to the pillar centre): thread -> (row, 16-column slab), columns 128 + 16 q ..
-    {
+    if constexpr (FOLD) {
+        // ninth slab of the A operand, columns 128 .. 143 of every row: (o0, o1, o2, 1, 0, ..., 0); thread -> (row, 4 columns)
+        const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
+        const int64_t i = r0 + row;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (q == 0) {
+            if (i < a.n) { v[0] = a.offsets[i * 3]; v[1] = a.offsets[i * 3 + 1]; v[2] = a.offsets[i * 3 + 2]; }
+            v[3] = 1.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a_store<FMT, SLABS>(A, row, 128 + q * 4 + k, v[k]);
+    } else {
+        // x = Linear(3,64)(offset to the pillar centre): thread -> (row, 16-column slab), columns 128 + 16 q ..
         const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
         const int64_t i = r0 + row;
         float o0 = 0.f, o1 = 0.f, o2 = 0.f;
@@ -177,7 +198,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
         for (int k = 0; k < 16; ++k) {
             const int c = q * 16 + k;
             const float v = fmaf(o2, a.w_off[128 + c], fmaf(o1, a.w_off[64 + c], o0 * a.w_off[c])) + a.b_off[c];
-            a_store<FMT>(A, row, 128 + c, v);
+            a_store<FMT, SLABS>(A, row, 128 + c, v);
         }
     }
     __syncthreads();
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
                 }
             }
             h[rt][r] = v;
-            a_store<FMT>(A, row, wave * 32 + li, v);
+            a_store<FMT, SLABS>(A, row, wave * 32 + li, v);
         }
     __syncthreads();
 
@@ -227,7 +248,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
-        gemm192<2, 2, FMT>(A, a.wzr, 256, col_zr, acc, 0, li, lh);
+        gemm192<2, 2, FMT, SLABS>(A, a.wzr, 256, col_zr, acc, 0, li, lh);
         __syncthreads();                                        // every wave has read [h | x]
         float z[2][16];
 #pragma unroll
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
             for (int r = 0; r < 16; ++r) {
                 z[rt][r] = sigmoid_f(acc[rt][0][r] + bz);
                 const float rr = sigmoid_f(acc[rt][1][r] + br);
-                a_store<FMT>(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, rr * h[rt][r]);
+                a_store<FMT, SLABS>(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, rr * h[rt][r]);
             }
         __syncthreads();                                        // A = [r*h | x]
         floatx16 acq[2][1];
@@ -244,7 +265,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acq[rt][0][r] = 0.f;
-        gemm192<2, 1, FMT>(A, a.wq, 128, col_q, acq, 0, li, lh);
+        gemm192<2, 1, FMT, SLABS>(A, a.wq, 128, col_q, acq, 0, li, lh);
         __syncthreads();
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -253,7 +274,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
                 const float q = tanh_f(acq[rt][0][r] + bq);
                 const float hn = (1.0f - z[rt][r]) * h[rt][r] + z[rt][r] * q;
                 h[rt][r] = hn;
-                a_store<FMT>(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, hn);
+                a_store<FMT, SLABS>(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, hn);
             }
         __syncthreads();                                        // A = [h' | x]
     }
@@ -263,7 +284,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
 #pragma unroll
     for (int r = 0; r < 16; ++r) ac1[0][0][r] = 0.f;
     const int col_1[1] = {0};
-    if (wave < 2) gemm192<1, 1, FMT>(A, a.w1, 32, col_1, ac1, wave, li, lh);
+    if (wave < 2) gemm192<1, 1, FMT, SLABS>(A, a.w1, 32, col_1, ac1, wave, li, lh);
     __syncthreads();                                            // A is dead from here: reuse it for y1 [64][32] float32
     float* Y = reinterpret_cast<float*>(A);
     if (wave < 2) {
@@ -296,16 +317,17 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
 using namespace himo;
 
 // hidden 128 (= 32 + 32 + 64 gathered channels), x 64, dec1 width 32: the head of himo_amd/seflow/spec.py.  Packed
-// weights: himo_conv_pack_weights_ex(w, 1, 192, cout, packed_format) of zr [192][256], q [192][128], dec1 [192][32].
-extern "C" int himo_gru_head_batch(int n_samples, const himo_head_sample* h_samples, int img_pitch, int dec_pitch,
-                                   const float* d_w_off, const float* d_b_off,
-                                   const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
-                                   const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
-                                   int iters, int packed_format, int img_split, void* stream) {
+// weights: himo_conv_pack_weights_ex(w, 1, 192, cout, packed_format) of zr [192][256], q [192][128], dec1 [192][32]
+// -- or, folded: of [144][cout] matrices = the 128 hidden rows, then W_off W_x (3 rows), b_off W_x (1 row), 12 zero rows.
+static int gru_head_launch(int n_samples, const himo_head_sample* h_samples, int img_pitch, int dec_pitch,
+                           const float* d_w_off, const float* d_b_off, bool folded,
+                           const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
+                           const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
+                           int iters, int packed_format, int img_split, void* stream) {
     if (img_split && (packed_format != 1 || (img_pitch & 15))) return HIMO_ERR_INVALID_ARGUMENT;
     if (n_samples < 0 || n_samples > kGhMaxSamples || (n_samples && !h_samples)) return HIMO_ERR_INVALID_ARGUMENT;
     if (iters < 0 || !(packed_format == 0 || packed_format == 1) || img_pitch < 32 || dec_pitch < 64) return HIMO_ERR_INVALID_ARGUMENT;
-    if (!d_w_off || !d_b_off || !d_wzr_packed || !d_bzr || !d_wq_packed || !d_bq || !d_w1_packed || !d_b1 || !d_w2 || !d_b2)
+    if ((!folded && (!d_w_off || !d_b_off)) || !d_wzr_packed || !d_bzr || !d_wq_packed || !d_bq || !d_w1_packed || !d_b1 || !d_w2 || !d_b2)
         return HIMO_ERR_INVALID_ARGUMENT;
     if ((reinterpret_cast<uintptr_t>(d_wzr_packed) | reinterpret_cast<uintptr_t>(d_wq_packed) | reinterpret_cast<uintptr_t>(d_w1_packed)) & 15)
         return HIMO_ERR_INVALID_ARGUMENT;
@@ -333,10 +355,32 @@ extern "C" int himo_gru_head_batch(int n_samples, const himo_head_sample* h_samp
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("gru_head_kernel", s);
     const dim3 grid((unsigned)blocks);
-    if (packed_format == 1) hipLaunchKernelGGL(gru_head_kernel<2>, grid, dim3(256), 0, s, a, b);
-    else hipLaunchKernelGGL(gru_head_kernel<3>, grid, dim3(256), 0, s, a, b);
+    if (folded) {
+        if (packed_format == 1) hipLaunchKernelGGL((gru_head_kernel<2, 9>), grid, dim3(256), 0, s, a, b);
+        else hipLaunchKernelGGL((gru_head_kernel<3, 9>), grid, dim3(256), 0, s, a, b);
+    } else {
+        if (packed_format == 1) hipLaunchKernelGGL((gru_head_kernel<2, 12>), grid, dim3(256), 0, s, a, b);
+        else hipLaunchKernelGGL((gru_head_kernel<3, 12>), grid, dim3(256), 0, s, a, b);
+    }
     HIMO_LAUNCH_CHECK("gru_head_kernel");
     return HIMO_OK;
+}
+
+extern "C" int himo_gru_head_batch(int n_samples, const himo_head_sample* h_samples, int img_pitch, int dec_pitch,
+                                   const float* d_w_off, const float* d_b_off,
+                                   const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
+                                   const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
+                                   int iters, int packed_format, int img_split, void* stream) {
+    return gru_head_launch(n_samples, h_samples, img_pitch, dec_pitch, d_w_off, d_b_off, false, d_wzr_packed, d_bzr, d_wq_packed, d_bq,
+                           d_w1_packed, d_b1, d_w2, d_b2, iters, packed_format, img_split, stream);
+}
+
+extern "C" int himo_gru_head_batch_folded(int n_samples, const himo_head_sample* h_samples, int img_pitch, int dec_pitch,
+                                          const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
+                                          const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
+                                          int iters, int packed_format, int img_split, void* stream) {
+    return gru_head_launch(n_samples, h_samples, img_pitch, dec_pitch, nullptr, nullptr, true, d_wzr_packed, d_bzr, d_wq_packed, d_bq,
+                           d_w1_packed, d_b1, d_w2, d_b2, iters, packed_format, img_split, stream);
 }
 
 extern "C" int himo_gru_head(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0, const float* d_img1,

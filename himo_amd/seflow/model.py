@@ -62,6 +62,8 @@ _lib.register({
                       + [ctypes.c_void_p] * 12 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "himo_gru_head_batch": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 10
                             + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "himo_gru_head_batch_folded": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8
+                                   + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "himo_head_gather": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
@@ -172,6 +174,23 @@ class SeFlowNet:
                     _lib.check(self.lib.himo_conv_pack_weights_ex(w.contiguous().data_ptr(), ks, cin, cout, fmt, buf.data_ptr(),
                                                                   _lib.stream_handle()), "himo_conv_pack_weights_ex")
                     self.packed[k] = buf
+
+        # folded head (csrc/gruhead.hip, himo_gru_head_batch_folded): x = Linear(3,64)(offset) is affine in the offset and constant
+        # over the GRU iterations, so the 64 x-rows of every head matrix collapse (in float64, here) to 4 rows -- W_off W_x and
+        # b_off W_x -- that meet (o0, o1, o2, 1) in the A operand: [144][cout] matrices, 9 slabs per GEMM instead of 12
+        self.fold_head = precision != "f32"
+        if self.fold_head:
+            w_off, b_off = cpu["head.offset.weight"].double().numpy(), cpu["head.offset.bias"].double().numpy()
+            for name in ("head.gru.zr", "head.gru.q", "head.dec1"):
+                wfull = (derived if name.endswith("zr") else cpu)[f"{name}.weight"].double().numpy()
+                wh, wx = wfull[:spec.HIDDEN], wfull[spec.HIDDEN:]
+                folded = np.concatenate([wh, w_off @ wx, (b_off @ wx)[None], np.zeros((12, wfull.shape[1]))], axis=0)      # [144][cout]
+                wdev = torch.from_numpy(np.ascontiguousarray(folded, dtype=np.float32)).to(self.device)
+                buf = torch.empty(int(self.lib.himo_conv_packed_weight_bytes(1, 144, wdev.shape[1])), dtype=torch.uint8, device=self.device)
+                _lib.check(self.lib.himo_conv_pack_weights_ex(wdev.data_ptr(), 1, 144, wdev.shape[1], self.packed_format, buf.data_ptr(),
+                                                              _lib.stream_handle()), "himo_conv_pack_weights_ex")
+                torch.cuda.synchronize(self.device)                                          # wdev may be freed once packed
+                self.packed[f"{name}.weight.h"] = buf
 
         H, W = spec.GRID
         F = spec.NUM_FRAMES
@@ -472,13 +491,19 @@ class SeFlowNet:
                 h.d_img0, h.d_img1 = self.B0[k].data_ptr() + 4 * 32 * slot0, self.B0[k].data_ptr() + 4 * 32 * slot1
                 h.d_dec, h.d_xyz_t = self.DEC[k].data_ptr(), st["xyz_t"][slot0].data_ptr()
                 h.d_pts, h.pc_stride, h.d_flow = pc0.data_ptr(), pc0.shape[1], flow.data_ptr()
-            st = self.lib.himo_gru_head_batch(len(arr), ctypes.addressof(arr), 32 * F, 64,
-                                              p["head.offset.weight"].data_ptr(), p["head.offset.bias"].data_ptr(),
-                                              pk["head.gru.zr.weight"].data_ptr(), p["head.gru.zr.bias"].data_ptr(),
-                                              pk["head.gru.q.weight"].data_ptr(), p["head.gru.q.bias"].data_ptr(),
-                                              pk["head.dec1.weight"].data_ptr(), p["head.dec1.bias"].data_ptr(),
-                                              p["head.dec2.weight"].data_ptr(), p["head.dec2.bias"].data_ptr(),
-                                              spec.GRU_ITERS, self.packed_format, 1 if self.split_acts else 0, _lib.stream_handle())
+            tail = (p["head.dec2.weight"].data_ptr(), p["head.dec2.bias"].data_ptr(),
+                    spec.GRU_ITERS, self.packed_format, 1 if self.split_acts else 0, _lib.stream_handle())
+            if self.fold_head:
+                st = self.lib.himo_gru_head_batch_folded(len(arr), ctypes.addressof(arr), 32 * F, 64,
+                                                         pk["head.gru.zr.weight.h"].data_ptr(), p["head.gru.zr.bias"].data_ptr(),
+                                                         pk["head.gru.q.weight.h"].data_ptr(), p["head.gru.q.bias"].data_ptr(),
+                                                         pk["head.dec1.weight.h"].data_ptr(), p["head.dec1.bias"].data_ptr(), *tail)
+            else:
+                st = self.lib.himo_gru_head_batch(len(arr), ctypes.addressof(arr), 32 * F, 64,
+                                                  p["head.offset.weight"].data_ptr(), p["head.offset.bias"].data_ptr(),
+                                                  pk["head.gru.zr.weight"].data_ptr(), p["head.gru.zr.bias"].data_ptr(),
+                                                  pk["head.gru.q.weight"].data_ptr(), p["head.gru.q.bias"].data_ptr(),
+                                                  pk["head.dec1.weight"].data_ptr(), p["head.dec1.bias"].data_ptr(), *tail)
             _lib.check(st, "himo_gru_head_batch")
 
     def pillarize_all(self, sweeps, transforms):

@@ -336,6 +336,15 @@ int himo_gru_head_batch(int n_samples, const himo_head_sample* h_samples, int im
                         const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
                         const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
                         int iters, int packed_format, int img_split, void* stream);
+/* The same head with the 64 x-columns FOLDED: x = Linear(3,64)(offset) is an affine function of the point's offset o and
+ * constant over the GRU iterations, so x W_x = [o, 1] [W_off W_x ; b_off W_x] is a K = 4 product.  The packed weights are
+ * himo_conv_pack_weights_ex of [144][cout] matrices -- rows 0..127 the hidden rows of zr | q | dec1, rows 128..130
+ * W_off W_x, row 131 b_off W_x, rows 132..143 zero -- and every GEMM of the head runs 9 slabs of 16 instead of 12.  Results
+ * equal himo_gru_head_batch's up to float32 rounding of the folded rows. */
+int himo_gru_head_batch_folded(int n_samples, const himo_head_sample* h_samples, int img_pitch, int dec_pitch,
+                               const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
+                               const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
+                               int iters, int packed_format, int img_split, void* stream);
 /* per-point head glue: hx[i] = [img0[cell], img1[cell], dec[cell], Linear(3,64)(offset)] (192 floats; zeros for
  * dropped points), rhx[i][128:192] = the same Linear output */
 int himo_head_gather(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0,
