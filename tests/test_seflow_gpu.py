@@ -142,6 +142,28 @@ def test_fused_head_equals_the_multi_launch_head(gpu, params):
 
 
 @pytest.mark.parametrize("precision", ["f16x2", "bf16x3"])
+def test_folded_head_equals_the_unfolded_head(gpu, params, precision):
+    """himo_gru_head_batch_folded (the 64 x-columns of every head matrix folded into 4 rows that meet (o0, o1, o2, 1): 9 slabs
+    per GEMM) against himo_gru_head_batch (all 192 columns, 12 slabs): the same function up to float32 rounding of the
+    folded rows, for ragged row counts and dropped points."""
+    from himo_amd.seflow.model import SeFlowNet
+    from himo_amd.synthetic import make_frame
+    net = SeFlowNet(params, device=gpu, max_points=20_000, precision=precision, autotune=False)
+    assert net.fused_head and net.fold_head
+    for n0 in (12_345, 64, 1):
+        fh, f0, f1 = make_frame(30, n_points=15_000), make_frame(31, n_points=n0), make_frame(32, n_points=14_000)
+        f0["pc0"][: max(1, n0 // 50), 0] += 200.0                      # some points outside the range: pose flow only
+        args = (fh["pc0"], f0["pc0"], f1["pc0"], fh["pose0"], f0["pose0"], f0["pose1"])
+        net.fold_head = True
+        a = net.forward(*args).cpu().numpy()
+        net.fold_head = False
+        b = net.forward(*args).cpu().numpy()
+        net.fold_head = True
+        assert a.shape == b.shape == (n0, 3) and np.isfinite(a).all()
+        assert np.abs(a - b).max() <= 5e-6, (precision, n0, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3"])
 def test_every_tile_variant_gives_the_same_bits(gpu, precision):
     """The tile autotune may pick any structure / tile per layer: LDS-staged weights (convbf.hip, 4 tiles) or weights from
     L2 (convsp.hip, 4 | 2 | 1 rows per wave).  The summation order over K does not depend on the tile, so every variant
