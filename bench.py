@@ -70,6 +70,9 @@ def parse_args():
     ap.add_argument("--cloud", default="uniform", choices=["uniform", "rings"],
                     help="synthetic sweeps: SURVEY 8(d) uniform cloud with instances (default) or the LiDAR-like ring cloud")
     ap.add_argument("--sample-sets", type=int, default=3, help="distinct input batches rotated through the timed steps")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="join a process group even at N = 1 (a one-rank RCCL communicator): lets a single-GPU box execute the "
+                         "nccl branch -- init, barrier, max all-reduce, count all-gather -- that N > 1 runs use")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="CPU test switch: host stand-in for the device work, gloo for RCCL; the reported numbers are meaningless")
     ap.add_argument("--traffic-json", default=str(REPO / "profiles" / "traffic_latest.json"))
@@ -254,7 +257,7 @@ def reduce_job(elapsed: float, frames_done: int, device, world: int, rank: int):
     import torch.distributed as dist
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
     done = torch.tensor([frames_done], device=device, dtype=torch.int64)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         gathered = [torch.zeros_like(done) for _ in range(world)]
         dist.all_gather(gathered, done)                 # every backend implements all_gather; rank 0 reports
@@ -333,8 +336,11 @@ def main() -> int:
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
     sync = (lambda: None) if dry else torch.cuda.synchronize
-    if world > 1:
+    grouped = world > 1 or args.force_process_group
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver
         if dry:
             dist.init_process_group("gloo")
@@ -342,8 +348,10 @@ def main() -> int:
             dist.init_process_group("nccl", device_id=device)        # "nccl" IS RCCL on ROCm
     try:
         line = run_rank(args, rank, world, device, sync)
+        if line is not None:
+            line["config"]["collectives"] = (dist.get_backend() + f" x{dist.get_world_size()}") if grouped else "none (single process)"
     finally:
-        if world > 1:
+        if grouped:
             dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(line), flush=True)
@@ -464,7 +472,8 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     # ~12 % of the frame rate -- and get their table from one extra, untimed, fully profiled step afterwards.
     dominant = {"compdis": "compdis_kernel", "train": "conv_wgrad_tiled_kernel", "fastnsf": "conv1x1_mfma_kernel"}.get(
         args.workload, {"bf16x3": "conv3x3_bf16x3_kernel", "f16x2": "conv3x3_f16x2_kernel"}.get(args.precision, "conv3x3_mfma_kernel"))
-    if world > 1:
+    grouped = dist.is_available() and dist.is_initialized()
+    if grouped:
         dist.barrier()
     sync()
     import gc
@@ -484,7 +493,7 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     if pipe is not None:
         pipe.sync_check()                       # the last batch's finite-flow flag (fp16-split precision)
     sync()
-    if world > 1:
+    if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()

@@ -254,9 +254,10 @@ def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     """In-place mean over the ranks of the default process group (no-op without one): the data-parallel exchange of a
     training step is this single collective on the flat gradient buffer."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():          # also a one-rank group: the collective itself is exercised
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(dist.get_world_size())
+        if dist.get_world_size() > 1:
+            flat.div_(dist.get_world_size())
     return flat
 
 

@@ -179,3 +179,34 @@ def test_full_size_frames_against_oracle_and_invariants(gpu, oracle):
     # (4) batch == frame-by-frame
     one = eng.run(FrameBatch.from_frames(frames[1:2], RES))["comp_dis"]
     assert torch.equal(one, b.split(cd)[1])
+
+
+@pytest.mark.parametrize("workload", ["compdis", "train"])
+def test_bench_nccl_branch_runs_as_a_one_rank_communicator(gpu, workload):
+    """A single-GPU box cannot run N > 1, but it CAN execute the RCCL code path the multi-GPU runs use: bench.py
+    --force-process-group joins a one-rank "nccl" (= RCCL) communicator bound to cuda:0 and goes through the same barrier,
+    max all-reduce of the wall time and all-gather of the frame counts -- and, for the train workload, the all-reduce of the flat
+    gradient buffer inside every optimiser step.  (The N = 2 logic itself is covered on CPU over gloo:
+    tests/test_distributed_cpu.py.)"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parents[1]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    extra = ["--frames-per-step", "32", "--steps", "5"] if workload == "compdis" else ["--points", "20000", "--steps", "2"]
+    r = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "1", "--force-process-group", "--workload", workload,
+                        "--warmup", "1", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["collectives"] == "nccl x1" and line["value"] > 0
+    if workload == "compdis":
+        assert line["config"]["frames_per_rank"] == [5 * 32] and line["parity"]["comp_dis_max_abs_vs_ref"] <= 1e-6
+    else:                                   # the step's flat 28 MB gradient went through the RCCL all-reduce
+        assert line["config"]["frames_per_rank"] == [2] and np.isfinite(line["parity"]["loss_after_warmup"])
