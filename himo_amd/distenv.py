@@ -29,10 +29,11 @@ def process_group():
         yield dist.get_rank(), dist.get_world_size()
         return
     world = launched_world()
-    if world <= 1:
+    if world <= 1 and os.environ.get("HIMO_DIST_FORCE") != "1":      # HIMO_DIST_FORCE=1: a one-rank group (exercises RCCL on one GPU)
         yield 0, 1
         return
-    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_PORT", "29512")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this host driver
     backend = os.environ.get("HIMO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -57,7 +58,7 @@ def all_ranks_ok(ok: bool) -> bool:
     at a barrier for a process that has already died; afterwards the failing rank re-raises and the rest stop cleanly."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return ok
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)

@@ -343,7 +343,7 @@ class InstanceMetrics:
         the single-process lists element for element.  One small object all-gather; no per-sweep traffic."""
         import torch.distributed as dist
         self.flush()
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()):
             return
         gathered = [None] * dist.get_world_size()
         dist.all_gather_object(gathered, self._log)

@@ -308,3 +308,36 @@ def test_config2_shaped_run_over_the_reference_frame_list(gpu, tmp_path, monkeyp
             return x.keys() == y.keys() and all(close(x[k], y[k]) for k in x)
         return x == pytest.approx(y, rel=1e-6, abs=1e-9)
     assert close(a, b)
+
+
+def test_cli_entry_points_on_a_one_rank_rccl_group(gpu, tmp_path, monkeypatch):
+    """save_zip.main / eval.main with HIMO_DIST_FORCE=1: the entry points join a one-rank "nccl" (RCCL) group on cuda:0 and
+    run their rendezvous (int32 min all-reduce) and the metric gather (all_gather_object) through it -- the collectives of
+    the sharded runs, executed on the GPU box's RCCL."""
+    import json
+    import socket
+    import torch.distributed as dist
+    from himo_amd import eval as ev, save_zip
+    from himo_amd.dataset import NpzDataset
+    from himo_amd.synthetic import make_frame
+    root = tmp_path / "av2" / "demo"
+    frames = [make_frame(1200 + i, n_points=3_000, scene_id=f"scene{i // 3}") for i in range(6)]
+    NpzDataset.write(root, frames)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    for k, v in {"HIMO_DIST_FORCE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1",
+                 "LOCAL_RANK": "0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.chdir(tmp_path)
+    seen = []
+    real = dist.init_process_group
+    monkeypatch.setattr(dist, "init_process_group", lambda backend, **kw: (seen.append(backend), real(backend, **kw))[1])
+    save_zip.main(str(root), "seflowpp_best", batch_frames=4)
+    assert (root / "results" / "seflowpp_best-submit.zip").exists() and not dist.is_initialized()
+    m = ev.main(str(root), res_name="seflowpp_best", batch_frames=4, file_name=str(tmp_path / "res.json"))
+    assert m.frame_cnt == 6 and not dist.is_initialized()
+    assert seen == ["nccl", "nccl"]
+    single = ev.InstanceMetrics("av2")
+    single.step_frames(frames, res_name="seflowpp_best")
+    assert json.dumps(m.evaluate_data, default=float, sort_keys=True) == json.dumps(single.evaluate_data, default=float, sort_keys=True)
