@@ -53,6 +53,8 @@ struct PillarArgs {
     int* order2;              // [n] ascending order for cells too crowded for the LDS stage
     float* cell_xyz;          // [n][3] transformed points in cell-list (scatter) order: the feature kernel reads a cell's
                               //        indices AND coordinates as two contiguous runs instead of index -> point chains
+    unsigned long long* occ;  // incremental images (or NULL): bit c of word w = cell 64 w + c was non-empty the LAST time this
+                              //        workspace's image was written -- an empty cell that was empty then is already zero
 };
 
 // up to twelve sweeps per launch (blockIdx.y selects the sweep): the stage's kernels are latency chains on small grids,
@@ -175,19 +177,23 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarBatch m) {
     const int sub = threadIdx.x >> 5, c = threadIdx.x & 31;
     const int n_cells = a.g.W * a.g.H;
     const int cell0 = blockIdx.x * kFeatCells;
+    static_assert(kFeatCells == 64, "one 64-bit occupancy word per block");
+    // incremental images: the cells of this block that held data after the previous pass over this image (all of them the
+    // first time); read by every thread BEFORE the barrier, replaced by thread 0 after it
+    const unsigned long long was = a.occ ? a.occ[blockIdx.x] : ~0ull;
     if (threadIdx.x <= kFeatCells) s_beg[threadIdx.x] = cell_offset(a, min(cell0 + (int)threadIdx.x, n_cells));
     __syncthreads();
     if (threadIdx.x < 64) {                                   // wave 0 compacts the non-empty cells (ascending)
         const bool full = cell0 + (int)threadIdx.x < n_cells && s_beg[threadIdx.x + 1] > s_beg[threadIdx.x];
         const unsigned long long mask = __ballot(full);
         if (full) s_list[__popcll(mask & ((1ull << threadIdx.x) - 1ull))] = threadIdx.x;
-        if (threadIdx.x == 0) s_nlist = __popcll(mask);
+        if (threadIdx.x == 0) { s_nlist = __popcll(mask); if (a.occ) a.occ[blockIdx.x] = mask; }
     }
-    // zero rows of the empty cells: 16 bytes per lane, 8 lanes per 128-byte row, 32 rows per pass
+    // zero rows of the empty cells (those that are not zero already): 16 bytes per lane, 8 lanes per 128-byte row, 32 rows per pass
 #pragma unroll
     for (int i = 0; i < kFeatCells / 32; ++i) {
         const int lc = i * 32 + (threadIdx.x >> 3);
-        if (cell0 + lc < n_cells && s_beg[lc + 1] == s_beg[lc])
+        if (cell0 + lc < n_cells && s_beg[lc + 1] == s_beg[lc] && ((was >> lc) & 1ull))
             *reinterpret_cast<float4*>(a.image + (int64_t)(cell0 + lc) * a.image_pitch + (threadIdx.x & 7) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
@@ -264,23 +270,34 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarBatch m) {
                 if (have) a.order2[beg + rank] = idx;
             }
             __threadfence_block();
+            // the ascending list is walked in 32-point chunks: lane c fetches point j0 + c (one gather per chunk instead of a chain
+            // of dependent loads per point), the sequential -- order-deterministic -- sums then take the points by shuffle
             float sx = 0.f, sy = 0.f, sz = 0.f;
-            for (int j = 0; j < cnt; ++j) {
-                const float* p = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
-                sx += p[0]; sy += p[1]; sz += p[2];
+            for (int j0 = 0; j0 < cnt; j0 += 32) {
+                const bool have = j0 + c < cnt;
+                const float* p = a.xyz_t + (int64_t)(have ? a.order2[beg + j0 + c] : 0) * 3;
+                const float ux = have ? p[0] : 0.f, uy = have ? p[1] : 0.f, uz = have ? p[2] : 0.f;
+                const int lim = min(32, cnt - j0);
+                for (int j = 0; j < lim; ++j) { sx += shfl32(ux, j); sy += shfl32(uy, j); sz += shfl32(uz, j); }
             }
             const float mx = sx / fc, my = sy / fc, mz = sz / fc;
-            for (int j = 0; j < cnt; ++j) {
-                const int pj = a.order2[beg + j];
-                const float* p = a.xyz_t + (int64_t)pj * 3;
-                const float x = p[0], y = p[1], z = p[2];
-                const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
-                float v = f[0] * w[0];
+            for (int j0 = 0; j0 < cnt; j0 += 32) {
+                const bool have = j0 + c < cnt;
+                const int pidx = have ? a.order2[beg + j0 + c] : 0;
+                const float* p = a.xyz_t + (int64_t)pidx * 3;
+                const float ux = have ? p[0] : 0.f, uy = have ? p[1] : 0.f, uz = have ? p[2] : 0.f;
+                const int lim = min(32, cnt - j0);
+                for (int j = 0; j < lim; ++j) {
+                    const float x = shfl32(ux, j), y = shfl32(uy, j), z = shfl32(uz, j);
+                    const int pj = shfl32(pidx, j);
+                    const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
+                    float v = f[0] * w[0];
 #pragma unroll
-                for (int q = 1; q < 9; ++q) v = fmaf(f[q], w[q], v);
-                v = v * scale + shift;
-                acc += fmaxf(v, 0.f);
-                if (c < 3) a.offsets[(int64_t)pj * 3 + c] = f[6 + c];
+                    for (int q = 1; q < 9; ++q) v = fmaf(f[q], w[q], v);
+                    v = v * scale + shift;
+                    acc += fmaxf(v, 0.f);
+                    if (c < 3) a.offsets[(int64_t)pj * 3 + c] = f[6 + c];
+                }
             }
         }
         const float feat = acc / fc;
@@ -411,9 +428,19 @@ static size_t ws_cells(int cells) { return round_up((size_t)cells * 4, 16); }
 static size_t ws_blocks(int cells) { return round_up(((size_t)(cells + kScanBlock - 1) / kScanBlock + 1) * 4, 16); }
 static size_t ws_points(int64_t n) { return round_up((size_t)(n > 0 ? n : 1) * 4, 16); }
 static size_t pillar_ws(int64_t n, int cells) { return 2 * ws_cells(cells) + ws_blocks(cells) + 2 * ws_points(n) + 3 * ws_points(n); }
+// occupancy bitmap of the incremental images: one bit per cell, kept in the LAST bytes of the caller's per-sweep workspace
+// (a position that does not depend on the sweep's point count, unlike the lists in front of it)
+static size_t ws_occ(int cells) { return round_up(((size_t)cells + 63) / 64 * 8, 16); }
 
 extern "C" size_t himo_pillar_workspace_bytes(int64_t max_points, int grid_w, int grid_h) {
-    return pillar_ws(max_points, grid_w * grid_h) + 64;
+    return pillar_ws(max_points, grid_w * grid_h) + 64 + ws_occ(grid_w * grid_h);
+}
+
+extern "C" int himo_pillar_occupancy_reset(void* d_workspace, size_t workspace_bytes, int grid_w, int grid_h, void* stream) {
+    if (!d_workspace || grid_w < 1 || grid_h < 1 || workspace_bytes < ws_occ(grid_w * grid_h)) return HIMO_ERR_INVALID_ARGUMENT;
+    const size_t nb = ws_occ(grid_w * grid_h);
+    HIMO_HIP(hipMemsetAsync(reinterpret_cast<char*>(d_workspace) + (workspace_bytes - nb), 0xFF, nb, (hipStream_t)stream));
+    return HIMO_OK;
 }
 
 // validate one sweep's arguments and fill its kernel argument block
@@ -511,8 +538,11 @@ extern "C" int himo_pillarize_multi_ex(int n_sweeps, const himo_sweep* h_sweeps,
                                        const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight,
                                        const float* d_pfn_scale, const float* d_pfn_shift, int image_pitch, size_t workspace_bytes,
                                        int image_split, void* stream) {
+    const bool incremental = (image_split & 2) != 0;                  // HIMO_IMAGE_INCREMENTAL
+    image_split &= 1;
     if (image_split && (image_pitch & 15)) return HIMO_ERR_INVALID_ARGUMENT;
     if (n_sweeps < 1 || n_sweeps > kMaxSweeps || !h_sweeps) return HIMO_ERR_INVALID_ARGUMENT;
+    if (incremental && ((workspace_bytes & 15) || workspace_bytes < ws_occ(grid_w * grid_h))) return HIMO_ERR_WORKSPACE;
     PillarBatch m{};
     for (int i = 0; i < n_sweeps; ++i) {
         const himo_sweep& w = h_sweeps[i];
@@ -522,6 +552,11 @@ extern "C" int himo_pillarize_multi_ex(int n_sweeps, const himo_sweep* h_sweeps,
         if (st != HIMO_OK) return st;
         if (image_split && (reinterpret_cast<uintptr_t>(w.d_image) & 63)) return HIMO_ERR_INVALID_ARGUMENT;
         m.s[i].image_split = image_split ? 1 : 0;
+        if (incremental) {
+            const size_t nb = ws_occ(grid_w * grid_h);
+            if (workspace_bytes < pillar_ws(w.n, grid_w * grid_h) + nb) return HIMO_ERR_WORKSPACE;
+            m.s[i].occ = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(w.d_workspace) + (workspace_bytes - nb));
+        }
         for (int j = 0; j < i; ++j)
             if (h_sweeps[j].d_workspace == w.d_workspace) return HIMO_ERR_INVALID_ARGUMENT;     // one workspace per sweep
     }

@@ -40,6 +40,7 @@ ACT_SPLIT_IN, ACT_SPLIT_OUT = 1, 2      # himo_conv_desc.act_layout: x / y in th
 
 _lib.register({
     "himo_pillar_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "himo_pillar_occupancy_reset": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "himo_pillarize": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                       ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
                                       ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_int,
@@ -133,6 +134,7 @@ class SeFlowNet:
         self.autotune = autotune
         self.keep_cell_lists = False
         self.fused_head = precision != "f32"          # one kernel for gather + GRU + output (csrc/gruhead.hip)
+        self.incremental_images = True                # pillar images: write only the cells that changed since the last forward
         self.use_plan = True                          # replay the backbone's operator list from one call (csrc/plan.hip)
         self.use_graph = True                         # ... as a captured hipGraph
         self._plans = {}                              # samples per launch -> recorded operator list
@@ -234,11 +236,25 @@ class SeFlowNet:
                      "xyz_t": torch.empty((self.F, n, 3), dtype=torch.float32, device=dev),
                      "pid": torch.empty((self.F, n), dtype=torch.int32, device=dev),
                      "offsets": torch.empty((self.F, n, 3), dtype=torch.float32, device=dev)} for _ in range(self.max_batch)]
+        # incremental pillar images (csrc/pillar.hip, HIMO_IMAGE_INCREMENTAL): a sweep's image channels persist in B0 between
+        # forwards and only changed cells are written; fresh workspaces start with every cell marked dirty
+        for st in self._pt:
+            for ws in st["ws_slots"]:
+                _lib.check(self.lib.himo_pillar_occupancy_reset(ws.data_ptr(), ws.numel(), self.W, self.H, _lib.stream_handle()),
+                           "himo_pillar_occupancy_reset")
         self._use_sample(0)
         self.hx = torch.empty((n, 192), dtype=torch.float32, device=dev)
         self.rhx = torch.empty((n, 192), dtype=torch.float32, device=dev)
         self.zbuf = torch.empty((n, 128), dtype=torch.float32, device=dev)
         self.y1 = torch.empty((n, 32), dtype=torch.float32, device=dev)
+
+    def reset_images(self):
+        """Mark every pillar-image cell dirty (the next forward rewrites the whole image).  Needed only after something other
+        than this network's own pillar stage wrote into B0, or after switching ``incremental_images`` back on."""
+        for st in self._pt:
+            for ws in st["ws_slots"]:
+                _lib.check(self.lib.himo_pillar_occupancy_reset(ws.data_ptr(), ws.numel(), self.W, self.H, _lib.stream_handle()),
+                           "himo_pillar_occupancy_reset")
 
     def _use_sample(self, i: int):
         """bind the per-point buffers (and cell lists) of sample ``i`` of the batch"""
@@ -533,7 +549,7 @@ class SeFlowNet:
             status = self.lib.himo_pillarize_multi_ex(len(arr), ctypes.addressof(arr), self._range, self._voxel, self._centre, self.W, self.H,
                                                       self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
                                                       self.p["pfn.shift"].data_ptr(), 32 * self.F, self._pt[0]["ws_slots"][0].numel(),
-                                                      1 if self.split_acts else 0, _lib.stream_handle())
+                                                      (1 if self.split_acts else 0) | (2 if self.incremental_images else 0), _lib.stream_handle())
             _lib.check(status, "himo_pillarize_multi_ex")
 
     def pillarize_into(self, slot: int, pts: torch.Tensor, transform):
@@ -550,7 +566,7 @@ class SeFlowNet:
         st = self.lib.himo_pillarize_multi_ex(1, ctypes.addressof(arr), self._range, self._voxel, self._centre, self.W, self.H,
                                               self.p["pfn.weight"].data_ptr(), self.p["pfn.scale"].data_ptr(),
                                               self.p["pfn.shift"].data_ptr(), 32 * self.F, self.ws_slots[slot].numel(),
-                                              1 if self.split_acts else 0, _lib.stream_handle())
+                                              (1 if self.split_acts else 0) | (2 if self.incremental_images else 0), _lib.stream_handle())
         _lib.check(st, "himo_pillarize_multi_ex")
 
 

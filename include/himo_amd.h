@@ -228,8 +228,16 @@ int himo_pillarize_multi(int n_sweeps, const himo_sweep* h_sweeps, const float* 
                          const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight,
                          const float* d_pfn_scale, const float* d_pfn_shift, int image_pitch, size_t workspace_bytes,
                          void* stream);
-/* image_split != 0: each sweep's 32 image channels are written in the split activation format (himo_conv_desc.act_layout;
- * image_pitch a multiple of 16 floats, d_image 64-byte aligned); empty cells are zero either way */
+/* image_split bit 0 (HIMO_IMAGE_SPLIT): each sweep's 32 image channels are written in the split activation format
+ * (himo_conv_desc.act_layout; image_pitch a multiple of 16 floats, d_image 64-byte aligned); empty cells are zero either way.
+ * bit 1 (HIMO_IMAGE_INCREMENTAL): the image persists between calls and only changes are written.  The last bytes of each
+ * sweep's workspace (workspace_bytes a multiple of 16, constant per buffer) hold one bit per cell = "non-empty after the
+ * previous call"; an empty cell that was empty then is already zero and is skipped -- two thirds of the zero rows of a
+ * 120k-point sweep.  Contract: himo_pillar_occupancy_reset() once after allocating the workspace / image (marks every cell
+ * dirty), and nobody else writes this sweep's image channels in between. */
+#define HIMO_IMAGE_SPLIT 1
+#define HIMO_IMAGE_INCREMENTAL 2
+int himo_pillar_occupancy_reset(void* d_workspace, size_t workspace_bytes, int grid_w, int grid_h, void* stream);
 int himo_pillarize_multi_ex(int n_sweeps, const himo_sweep* h_sweeps, const float* h_range, const float* h_voxel,
                          const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight,
                          const float* d_pfn_scale, const float* d_pfn_shift, int image_pitch, size_t workspace_bytes, int image_split,

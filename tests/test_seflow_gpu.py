@@ -142,6 +142,47 @@ def test_fused_head_equals_the_multi_launch_head(gpu, params):
 
 
 @pytest.mark.parametrize("precision", ["f16x2", "bf16x3"])
+def test_incremental_pillar_images_leave_no_stale_cells(gpu, params, precision):
+    """HIMO_IMAGE_INCREMENTAL: a sweep's image persists between forwards and the pillar stage writes only what changed
+    (occupied cells, and zeros into cells that were occupied the last time).  A sequence of very different clouds through ONE
+    network -- uniform, LiDAR rings, a crowded square, an empty sweep, a single point, uniform again -- must leave exactly
+    the image a fresh network writing every cell produces, in both image formats."""
+    from himo_amd.seflow.model import SeFlowNet
+    from himo_amd.synthetic import make_frame
+    net = SeFlowNet(params, device=gpu, max_points=70_000, precision=precision, autotune=False)
+    assert net.incremental_images
+    rng = np.random.default_rng(3)
+    crowd = make_frame(7, n_points=5_000)["pc0"].copy()
+    crowd[:, :2] = rng.uniform(-1.0, 1.0, (5_000, 2)).astype(np.float32)
+    clouds = [make_frame(1, n_points=60_000)["pc0"], make_frame(2, n_points=40_000, cloud="rings")["pc0"], crowd,
+              np.zeros((0, 4), np.float32), make_frame(3, n_points=1)["pc0"], make_frame(4, n_points=65_000)["pc0"]]
+    T = np.eye(4)
+    T[0, 3], T[1, 3] = 0.37, -0.21
+    for slot in (1, 2):
+        for k, pc in enumerate(clouds):
+            pts = torch.from_numpy(np.ascontiguousarray(pc)).to(gpu)
+            net.pillarize_into(slot, pts, T)
+            fresh = SeFlowNet(params, device=gpu, max_points=70_000, precision=precision, autotune=False)
+            fresh.incremental_images = False
+            fresh.pillarize_into(slot, pts, T)
+            a = net.B0[0].view(512 * 512, 3, 32)[:, slot, :]
+            b = fresh.B0[0].view(512 * 512, 3, 32)[:, slot, :]
+            assert torch.equal(a, b), (precision, slot, k)
+            del fresh
+    # switching the mode off and on again needs reset_images(): afterwards the image is right again
+    net.incremental_images = False
+    net.pillarize_into(1, torch.from_numpy(np.ascontiguousarray(clouds[1])).to(gpu), T)
+    net.incremental_images = True
+    net.reset_images()
+    pts = torch.from_numpy(np.ascontiguousarray(clouds[0])).to(gpu)
+    net.pillarize_into(1, pts, T)
+    fresh = SeFlowNet(params, device=gpu, max_points=70_000, precision=precision, autotune=False)
+    fresh.incremental_images = False
+    fresh.pillarize_into(1, pts, T)
+    assert torch.equal(net.B0[0].view(512 * 512, 3, 32)[:, 1, :], fresh.B0[0].view(512 * 512, 3, 32)[:, 1, :])
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3"])
 def test_folded_head_equals_the_unfolded_head(gpu, params, precision):
     """himo_gru_head_batch_folded (the 64 x-columns of every head matrix folded into 4 rows that meet (o0, o1, o2, 1): 9 slabs
     per GEMM) against himo_gru_head_batch (all 192 columns, 12 slabs): the same function up to float32 rounding of the
