@@ -16,12 +16,17 @@
 // applied to each lane's SOURCE address: a permutation inside the pixel's 64 bytes -- coalescing is unchanged.
 // Pixels outside the image (and the 14 unused columns of a 48-pixel row) read a 64-byte zero page.
 //
-// Everything else as convsp.hip: a wave owns MI rows x 32 pixels x 32 output channels, weight fragments straight from
+// Everything else as convsp.hip: a wave owns MI rows x 32 pixels x NT column tiles of 32 output channels (NT = 2: every
+// activation fragment meets two weight fragments -- the 8-row tiles of the 64-channel layers and the 4-row x 64-channel
+// tiles of the wide decoder layers, both autotune candidates), weight fragments straight from
 // L2 two taps ahead in three statically rotated register sets, patch double-buffered, ONE barrier per 16-channel slab.
 // The DMA of slab + 1 is issued before the first tap of slab; the in-order vmcnt of the weight loads behind it has
 // retired it by tap 2, the explicit wait before the barrier only documents that.  Weight fragments are addressed as
 // uniform base + 32-bit lane offset (saddr loads), and each tap's loads and fragment reads are pinned ahead of its matrix
 // instructions (sched_group_barrier): DESIGN.md section 4 has the measurements and the variants that did not pay.
+// Epilogue: an accumulator block's 32 pixels x 128 bytes are transposed through a wave-private 4 KB corner of the (then free)
+// patch memory and leave as 16-byte stores, eight full 128-byte lines per instruction (store_block_vec, conv_common.h);
+// blocks walk the grid in an XCD-aware order (xcd_block_id).
 // Specification / oracle as conv.hip (reference network absent: PARITY UNPINNED).
 #include "conv_common.h"
 #include "bf16x3.h"
