@@ -36,6 +36,27 @@ class _PinnedArena:
         if self._buf.numel() < need_bytes:
             self._buf = torch.empty(int(need_bytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
         self._used = 0
+        if hasattr(self, "_extra"):
+            self._extra_used = [0] * len(self._extra)
+
+    def take_growing(self, shape, dtype=torch.float32) -> torch.Tensor:
+        """``take`` without a size known up front: when the block is exhausted a further pinned block is chained on (kept for
+        the following batches, so steady state allocates nothing)."""
+        nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        if not hasattr(self, "_extra"):
+            self._extra, self._extra_used = [], []
+        lo = (self._used + 63) & ~63
+        if lo + nbytes <= self._buf.numel():
+            self._used = lo + nbytes
+            return self._buf[lo:lo + nbytes].view(dtype).view(*shape)
+        for i, blk in enumerate(self._extra):
+            lo = (self._extra_used[i] + 63) & ~63
+            if lo + nbytes <= blk.numel():
+                self._extra_used[i] = lo + nbytes
+                return blk[lo:lo + nbytes].view(dtype).view(*shape)
+        blk = torch.empty(max(int(nbytes * 1.25) + 4096, 1 << 24), dtype=torch.uint8, pin_memory=True)
+        self._extra.append(blk); self._extra_used.append(nbytes)
+        return blk[:nbytes].view(dtype).view(*shape)
 
     def take(self, shape, dtype=torch.float32) -> torch.Tensor:
         nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
@@ -163,13 +184,22 @@ class ResultDrain:
         self._thread.start()
 
     def _pinned(self, like: torch.Tensor) -> torch.Tensor:
+        """a free pinned buffer that fits (ragged sweeps: capacities are rounded up to a power of two so they are reused)"""
+        fit, rest = None, []
         try:
-            while True:
+            while fit is None:
                 buf = self._free.get_nowait()
                 if buf.numel() >= like.numel() and buf.dtype == like.dtype:
-                    return buf
+                    fit = buf
+                else:
+                    rest.append(buf)
         except queue.Empty:
-            return torch.empty(like.numel(), dtype=like.dtype, pin_memory=True)
+            pass
+        for buf in rest:
+            self._free.put(buf)
+        if fit is None:
+            fit = torch.empty(1 << max(int(like.numel()) - 1, 1).bit_length(), dtype=like.dtype, pin_memory=True)
+        return fit
 
     def put(self, key, t: torch.Tensor) -> None:
         if self._error is not None:
@@ -202,74 +232,89 @@ class ResultDrain:
             raise self._error
 
 
-class EvalFeeder:
-    """Iterate device-resident ``eval.EvalBatch`` objects for the evaluator / scorer, prepared ``depth`` batches ahead.
+class BatchFeeder:
+    """Iterate device-resident batch objects prepared ``depth`` batches ahead of the consumer.
 
-    ``source`` yields lists of frame dicts (one list = one batch), or ``(frames, comp_dis_list)`` pairs for the zip mode
-    (eval.py:303-304).  A background thread concatenates the per-frame arrays straight into PINNED staging memory (numpy,
-    GIL released) and issues the host -> device copies on its own stream; the consumer's stream is ordered after them by an
-    event, so ``InstanceMetrics.step_batch`` never waits for a copy it did not need yet."""
+    ``source`` yields items (lists of host frame dicts, ...); ``build(item, upload)`` packs one item into a batch object whose
+    device tensors all come from ``upload(parts, dtype)`` and returns ``(object to yield, [its device tensors])``.  A background
+    thread runs ``build``: ``upload`` concatenates (and converts) the parts STRAIGHT into pinned staging memory on a small
+    thread pool (numpy releases the GIL: the arrays of a batch are staged in parallel) and issues the host -> device copies on
+    the feeder's own stream; the consumer's stream is ordered after them by an event, so it never waits for a copy it did not
+    need yet."""
 
     _END = object()
 
-    def __init__(self, source, res_name: str = "", device=None, depth: int = 2):
+    def __init__(self, source, build, device=None, depth: int = 2):
         self.device = device if device is not None else _lib.require_gpu()
-        self.res_name, self.depth = res_name, depth
+        self.depth, self._build = depth, build
         self._source = iter(source)
         self._q = queue.Queue(maxsize=depth)
         self._slots = _borrow_arenas(depth + 2)
         self._slot_done = [None] * (depth + 2)
         self._stream = torch.cuda.Stream(device=self.device)
         self._error = None
+        self._stop = False
         from concurrent.futures import ThreadPoolExecutor
-        self._pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="himo-eval-stage")
-        self._thread = threading.Thread(target=self._work, name="himo-eval-feeder", daemon=True)
+        self._pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="himo-stage")
+        self._thread = threading.Thread(target=self._work, name="himo-batch-feeder", daemon=True)
         self._thread.start()
 
     def _work(self):
-        from .eval import EvalBatch
         try:
             torch.cuda.set_device(self.device)
             slot = 0
             for item in self._source:
-                frames, comp_dis = item if isinstance(item, tuple) else (item, None)
-                frames = list(frames)
                 if self._slot_done[slot] is not None:
                     self._slot_done[slot].synchronize()
                 arena = self._slots[slot]
-                n = sum(len(f["pc0"]) for f in frames)
-                width = int(np.asarray(frames[0]["pc0"]).shape[1])
-                arena.reset(n * (4 * width + 12 + 12 + 4 + 1 + 8 + 1 + 1 + 16) + 4096 + 512 * len(frames))
-
+                arena.reset(0)
                 jobs = []
 
                 def upload(parts, dtype):
-                    # concatenate (and convert) STRAIGHT into pinned memory on a pool thread -- numpy releases the GIL, the
-                    # arrays of a batch are staged in parallel -- and hand back the device tensor the copy will fill
                     parts = [np.asarray(p) for p in parts]
                     shape = (sum(p.shape[0] for p in parts),) + tuple(parts[0].shape[1:])
                     tdt = torch.from_numpy(np.empty(0, dtype)).dtype
-                    pin = arena.take(shape, tdt)
+                    pin = arena.take_growing(shape, tdt)
                     dst = torch.empty(shape, dtype=tdt, device=self.device)
                     jobs.append((self._pool.submit(np.concatenate, parts, 0, pin.numpy(), casting="unsafe"), pin, dst))
                     return dst
 
                 with torch.cuda.stream(self._stream):
-                    eb = EvalBatch.from_frames(frames, self.res_name, comp_dis, device=self.device, upload=upload)
+                    obj, tensors = self._build(item, upload)
                     for job, pin, dst in jobs:
                         job.result()
                         dst.copy_(pin, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(self._stream)
                 self._slot_done[slot] = ev
-                self._q.put((eb, ev))
+                if not self._offer((obj, tensors, ev)):
+                    break
                 slot = (slot + 1) % len(self._slots)
         except BaseException as e:
             self._error = e
         finally:
             _return_arenas(self._slots, self._slot_done)
             self._pool.shutdown(wait=False)
-            self._q.put(self._END)
+            self._offer(self._END)
+
+    def _offer(self, item) -> bool:
+        while not self._stop:
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def close(self) -> None:
+        """Stop early (the consumer gave up): the worker returns its pinned arenas and exits."""
+        self._stop = True
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=10)
 
     def __iter__(self):
         while True:
@@ -278,11 +323,26 @@ class EvalFeeder:
                 if self._error is not None:
                     raise self._error
                 return
-            eb, ev = got
+            obj, tensors, ev = got
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(ev)
-            b = eb.batch
-            for t in (b.offsets, b.pose0, b.pose1, b.pc0, b.lidar_dt, b.gm0, b.flow_is_valid, eb.gt, eb.category, eb.instance, eb.est):
+            for t in tensors:
                 if t is not None:
                     t.record_stream(cur)
-            yield eb
+            yield obj
+
+
+class EvalFeeder(BatchFeeder):
+    """``eval.EvalBatch`` objects for the evaluator / scorer.  ``source`` yields lists of frame dicts (one list = one batch),
+    or ``(frames, comp_dis_list)`` pairs for the zip mode (eval.py:303-304)."""
+
+    def __init__(self, source, res_name: str = "", device=None, depth: int = 2):
+        from .eval import EvalBatch
+        dev = device if device is not None else _lib.require_gpu()
+
+        def build(item, upload):
+            frames, comp_dis = item if isinstance(item, tuple) else (item, None)
+            eb = EvalBatch.from_frames(list(frames), res_name, comp_dis, device=dev, upload=upload)
+            b = eb.batch
+            return eb, [b.offsets, b.pose0, b.pose1, b.pc0, b.lidar_dt, b.gm0, b.flow_is_valid, eb.gt, eb.category, eb.instance, eb.est]
+        super().__init__(source, build, device=dev, depth=depth)

@@ -96,28 +96,66 @@ def _dist():
     return 0, 1, None
 
 
-def run_dataset(dataset, res_name: str, output_dir: Path, batch_frames: int = 32, sensor_dt: float = 0.1) -> int:
-    """Shared body of ``main``: iterate ``dataset`` (frame i on rank i % world), batch sweeps into
-    HBM, run the fused path, write one Feather per sweep.  Returns the sweeps written by this rank."""
-    import torch
+OVERLAP = True          # read / stage / copy ahead and write behind on background threads (False: the reference's plain serial loop)
+
+
+def run_dataset(dataset, res_name: str, output_dir: Path, batch_frames: int = 32, sensor_dt: float = 0.1, overlap: bool | None = None) -> int:
+    """Shared body of ``main``: iterate ``dataset`` (frame i on rank i % world), batch sweeps into HBM, run the fused path,
+    write one Feather per sweep.  Returns the sweeps written by this rank.
+
+    With ``overlap`` (default) the reference's serial read -> compute -> write loop (save_zip.py:112-123) becomes three
+    overlapped stages: a feeder thread reads the frames, packs them into pinned memory and copies them to the device two
+    batches ahead (``feeder.BatchFeeder``), the launch thread only enqueues the fused kernel, and the compensation distances
+    leave through pinned buffers to a writer thread that encodes and writes the Feather files (``feeder.ResultDrain``)."""
     from .compdis import CompDisEngine, FrameBatch
 
+    overlap = OVERLAP if overlap is None else overlap
     rank, world, _ = _dist()
     eng = CompDisEngine(max_frames=batch_frames)
     mine = list(range(rank, len(dataset), world))
+
+    def batches():
+        for lo in range(0, len(mine), batch_frames):
+            frames = [dataset[i] for i in mine[lo:lo + batch_frames]]
+            for f in frames:
+                if len(f["lidar_dt"]) == 0:
+                    raise ValueError("max() arg is an empty sequence")       # save_zip.py:120
+            yield frames
+
     written = 0
-    for lo in range(0, len(mine), batch_frames):
-        frames = [dataset[i] for i in mine[lo:lo + batch_frames]]
-        for f in frames:
-            if len(f["lidar_dt"]) == 0:
-                raise ValueError("max() arg is an empty sequence")       # save_zip.py:120
-        batch = FrameBatch.from_frames(frames, res_name)
-        cd = eng.run(batch, sensor_dt=sensor_dt)["comp_dis"]
-        host = cd.cpu().numpy()                                          # one D2H copy per batch
-        o = batch.offsets_host
-        for k, f in enumerate(frames):
-            write_output_file(host[o[k]:o[k + 1]], (f["scene_id"], str(f["timestamp"])), output_dir)
-            written += 1
+    if not overlap:
+        for frames in batches():
+            batch = FrameBatch.from_frames(frames, res_name)
+            host = eng.run(batch, sensor_dt=sensor_dt)["comp_dis"].cpu().numpy()      # one D2H copy per batch
+            o = batch.offsets_host
+            for k, f in enumerate(frames):
+                write_output_file(host[o[k]:o[k + 1]], (f["scene_id"], str(f["timestamp"])), output_dir)
+                written += 1
+        return written
+
+    from .feeder import BatchFeeder, ResultDrain
+    dev = eng.device
+
+    def build(frames, upload):
+        b = FrameBatch.from_frames(frames, res_name, device=dev, upload=upload)
+        return (frames, b), [b.offsets, b.pose0, b.pose1, b.pc0, b.lidar_dt, b.flow]
+    drain = ResultDrain(lambda key, arr: write_output_file(arr, key, output_dir), device=dev)
+    feed = BatchFeeder(batches(), build, device=dev)
+    try:
+        for frames, batch in feed:
+            cd = eng.run(batch, sensor_dt=sensor_dt)["comp_dis"]
+            o = batch.offsets_host
+            for k, f in enumerate(frames):
+                drain.put((f["scene_id"], str(f["timestamp"])), cd[int(o[k]):int(o[k + 1])])
+                written += 1
+    except BaseException:
+        feed.close()
+        try:
+            drain.close()                       # the sweeps already computed still reach the disk, as in the serial loop
+        except BaseException:
+            pass
+        raise
+    drain.close()
     return written
 
 

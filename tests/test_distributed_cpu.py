@@ -96,6 +96,7 @@ def _worker_save_zip(rank, world, port, data_dir):
 
     compdis.CompDisEngine = CpuEngine
     compdis.FrameBatch.from_frames = classmethod(from_frames)
+    save_zip.OVERLAP = False                                   # the feeder / drain threads need HIP streams and pinned memory
     ds = SyntheticDataset(7, n_points=500, ragged=True)
     out = Path(data_dir) / "results"
     out.mkdir(exist_ok=True, parents=True)
@@ -224,6 +225,8 @@ def _cpu_compdis_double():
 
     compdis.CompDisEngine = CpuEngine
     compdis.FrameBatch.from_frames = classmethod(from_frames)
+    from himo_amd import save_zip
+    save_zip.OVERLAP = False                                   # the feeder / drain threads need HIP streams and pinned memory
 
 
 def _worker_save_zip_cli(rank, world, port, data_dir, fail_rank):

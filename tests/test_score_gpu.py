@@ -90,6 +90,46 @@ def test_save_zip_program_round_trip_on_gpu_box(gpu, gold, tmp_path):
         assert cd.dtype == np.float32 and np.abs(cd.astype(np.float64) - ref).max() <= 1e-9
 
 
+def test_overlapped_save_zip_writes_the_serial_loops_files(gpu, tmp_path):
+    """run_dataset's feeder -> kernel -> drain form writes byte-identical Feather files to the plain serial loop, over ragged
+    sweeps and a last short batch; a sweep without points / without the result key fails as save_zip.py:117,120 would, with
+    the files of the earlier batches on disk."""
+    from himo_amd import save_zip
+    from himo_amd.synthetic import SyntheticDataset
+    ds = SyntheticDataset(11, n_points=20_000, ragged=True)
+    outs = []
+    for overlap in (False, True):
+        out = tmp_path / f"o{int(overlap)}"
+        out.mkdir()
+        assert save_zip.run_dataset(ds, "seflowpp_best", out, batch_frames=4, overlap=overlap) == 11
+        outs.append(out)
+    names = sorted(p.relative_to(outs[0]) for p in outs[0].rglob("*.feather"))
+    assert len(names) == 11 and names == sorted(p.relative_to(outs[1]) for p in outs[1].rglob("*.feather"))
+    for n in names:
+        assert (outs[0] / n).read_bytes() == (outs[1] / n).read_bytes(), n
+
+    class Broken:
+        def __init__(self, bad, how):
+            self.bad, self.how = bad, how
+
+        def __len__(self):
+            return len(ds)
+
+        def __getitem__(self, i):
+            f = dict(ds[i])
+            if i == self.bad and self.how == "empty":
+                f["lidar_dt"] = f["lidar_dt"][:0]
+            if i == self.bad and self.how == "key":
+                del f["seflowpp_best"]
+            return f
+    for how, exc in (("empty", ValueError), ("key", KeyError)):
+        out = tmp_path / how
+        out.mkdir()
+        with pytest.raises(exc):
+            save_zip.run_dataset(Broken(9, how), "seflowpp_best", out, batch_frames=4)
+        assert len(list(out.rglob("*.feather"))) == 8                # batches 0 and 1 were complete
+
+
 def test_mixed_sweep_kinds_in_one_batch_are_decided_per_sweep(gpu, gold, oracle):
     """score.py:270-296 tests ``gt_flow_norm is not None`` / ``pc0 is not None`` for EACH sweep: a batch that mixes sweeps
     with and without them must score every sweep as it would be scored alone (one sweep without gt_flow_norm must not
