@@ -162,6 +162,16 @@ class SeFlowNet:
         derived["pfn.scale"], derived["pfn.shift"] = fold("pfn.bn", spec.BN_EPS_PFN)
         for name, *_ in spec.ENCODER:
             derived[f"{name}.scale"], derived[f"{name}.shift"] = fold(f"{name}.bn", spec.BN_EPS)
+        # folded decoder joints: a block's last 3x3 conv (u5) feeds ONLY the next block's 1x1 conv (u1) and nothing stands between
+        # them (spec step 4: no activations), so the pair is one 3x3 conv with W = W_u5 W_u1, b = b_u5 W_u1 + b_u1 (formed in
+        # float64): half the output channels of u5, and the 1x1 launch with its float32 round trip disappears.  Exact at the
+        # borders too (the 1x1 is pointwise).  The training pass keeps the layers apart (it needs u5's output).
+        self.fold_decoder = True
+        for a, b in (("dec1", "dec2"), ("dec2", "dec3")):
+            w5, b5 = cpu[f"{a}.u5.weight"].double().numpy(), cpu[f"{a}.u5.bias"].double().numpy()
+            w1, b1 = cpu[f"{b}.u1.weight"].double().numpy()[0, 0], cpu[f"{b}.u1.bias"].double().numpy()
+            derived[f"{a}.u5>{b}.u1.weight"] = torch.from_numpy(np.ascontiguousarray(w5 @ w1, dtype=np.float32))
+            derived[f"{a}.u5>{b}.u1.bias"] = torch.from_numpy(np.ascontiguousarray(b5 @ w1 + b1, dtype=np.float32))
         derived["head.gru.zr.weight"] = torch.cat([cpu["head.gru.z.weight"], cpu["head.gru.r.weight"]], dim=1).contiguous()
         derived["head.gru.zr.bias"] = torch.cat([cpu["head.gru.z.bias"], cpu["head.gru.r.bias"]]).contiguous()
         self.p = {k: v.to(self.device) for k, v in {**cpu, **derived}.items()}
@@ -403,17 +413,24 @@ class SeFlowNet:
         """B0, F1, F2, F3 -> DEC; every intermediate keeps its own buffer (the training backward pass reads them)."""
         H, W, F = self.H, self.W, self.F
         IN, IO = ACT_SPLIT_IN, ACT_SPLIT_IN | ACT_SPLIT_OUT
-        def block(name, coarse, c_in, ch, cw, tmp, cat, skip, skip_c, lat, out, work):
+        fold = self.fold_decoder
+        def block(name, coarse, c_in, ch, cw, tmp, cat, skip, skip_c, lat, out, work, nxt=None):
             # the 1x1 output that feeds the bilinear upsampling stays float32 (the interpolation reads float32); its result
             # and everything else is written split
-            self._conv(coarse, 0, c_in, f"{name}.u1", tmp, 0, lat, 1, 1, ch * cw, c_in, lat, 1, 1, EPI_BIAS, act=IN)
+            if coarse is not None:
+                self._conv(coarse, 0, c_in, f"{name}.u1", tmp, 0, lat, 1, 1, ch * cw, c_in, lat, 1, 1, EPI_BIAS, act=IN)
             self._up(tmp, lat, ch, cw, lat, cat, 2 * lat, out_split=True)
             self._conv(skip, 0, skip_c, f"{name}.u3", cat, 0, 2 * lat, 1, 1, 4 * ch * cw, skip_c, lat, 1, 1, EPI_BIAS, y_off=lat, act=IO)
             self._conv(cat, 0, 2 * lat, f"{name}.u4", work[0], 0, out, 1, 2 * ch, 2 * cw, 2 * lat, out, 3, 1, EPI_BIAS, act=IO)
+            if fold and nxt is not None:
+                # u5 and the next block's u1 as one 3x3 conv straight into that block's (float32) upsampling source
+                nname, ntmp, nlat = nxt
+                self._conv(work[0], 0, out, f"{name}.u5>{nname}.u1", ntmp, 0, nlat, 1, 2 * ch, 2 * cw, out, nlat, 3, 1, EPI_BIAS, act=IN)
+                return None
             self._conv(work[0], 0, out, f"{name}.u5", work[1], 0, out, 1, 2 * ch, 2 * cw, out, out, 3, 1, EPI_BIAS, act=IO)
             return work[1]
-        s = block("dec1", self.F3, 256 * F, H // 8, W // 8, self.T1, self.CAT1, self.F2, 128 * F, 256, 256, self.S)
-        t = block("dec2", s, 256, H // 4, W // 4, self.T2, self.CAT2, self.F1, 64 * F, 128, 128, self.T)
+        s = block("dec1", self.F3, 256 * F, H // 8, W // 8, self.T1, self.CAT1, self.F2, 128 * F, 256, 256, self.S, ("dec2", self.T2, 128))
+        t = block("dec2", s, 256, H // 4, W // 4, self.T2, self.CAT2, self.F1, 64 * F, 128, 128, self.T, ("dec3", self.T3, 64))
         u = block("dec3", t, 128, H // 2, W // 2, self.T3, self.CAT3, self.B0, 32 * F, 64, 64, self.U)
         self._conv(u, 0, 64, "dec4", self.DEC, 0, 64, 1, H, W, 64, 64, 3, 1, EPI_BIAS, act=IN)      # DEC stays float32: the head gathers it
         return self.DEC

@@ -129,9 +129,11 @@ def conv_flops() -> float:
     return total
 
 
-def conv3x3_flops() -> float:
+def conv3x3_flops(folded: bool = False) -> float:
     """Flops (2*M*N*K) of the 20 stride-1 3x3 convolutions of one forward: 13 encoder layers x 3 frames, the two
-    3x3 convs of each decoder block and the final 3x3 conv -- the launches named conv3x3_mfma_kernel."""
+    3x3 convs of each decoder block and the final 3x3 conv -- the launches named conv3x3_mfma_kernel.
+    ``folded``: the graph the inference engine executes, where dec1.u5 / dec2.u5 absorb the next block's 1x1 conv and
+    produce that block's latent width (half their own)."""
     H, W = GRID
     total = 0.0
     h, w = H, W
@@ -141,9 +143,10 @@ def conv3x3_flops() -> float:
         else:
             total += NUM_FRAMES * 2.0 * h * w * cin * cout * 9
     size = {"dec1": (H // 4, W // 4), "dec2": (H // 2, W // 2), "dec3": (H, W)}
-    for name, cin, skip, lat, out in DECODER:
+    for i, (name, cin, skip, lat, out) in enumerate(DECODER):
         oh, ow = size[name]
-        total += 2.0 * oh * ow * (2 * lat) * out * 9 + 2.0 * oh * ow * out * out * 9
+        u5_out = DECODER[i + 1][3] if folded and i + 1 < len(DECODER) else out
+        total += 2.0 * oh * ow * (2 * lat) * out * 9 + 2.0 * oh * ow * out * u5_out * 9
     total += 2.0 * H * W * DEC_OUT * DEC_OUT * 9
     return total
 

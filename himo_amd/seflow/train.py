@@ -287,6 +287,7 @@ class SeFlowTrainer:
         self.device = dev = device if device is not None else _lib.require_gpu()
         params = spec.init_params(seed) if params is None else params
         net = self.net = SeFlowNet(params, device=dev, max_points=1, precision="f32", autotune=False)
+        net.fold_decoder = False                          # the backward pass reads every decoder layer's own output
         net.keep_cell_lists = True
         net.use_plan = False
         net.max_points = 0

@@ -122,6 +122,30 @@ def test_full_forward_matches_cpu_restatement(gpu, so, params, precision):
     assert np.abs(inter["res"]).mean() > 0.05       # the network output is not trivially zero
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2", "f32"])
+def test_folded_decoder_joints_equal_the_layer_by_layer_decoder(gpu, so, params, precision):
+    """dec1.u5 + dec2.u1 and dec2.u5 + dec3.u1 run as one 3x3 convolution each (weights composed in float64, model.py): the same
+    linear map, so the decoder output differs from the layer-by-layer graph by rounding only, and the layer-by-layer graph
+    (the one the training pass differentiates) stays within the contract of the CPU restatement too."""
+    from himo_amd.seflow.model import SeFlowNet
+    from himo_amd.synthetic import make_frame
+    net = SeFlowNet(params, device=gpu, max_points=50_000, precision=precision)
+    assert net.fold_decoder
+    fh, f0, f1 = make_frame(40, n_points=30_000), make_frame(41, n_points=40_000), make_frame(42, n_points=35_000)
+    args = (fh["pc0"], f0["pc0"], f1["pc0"], fh["pose0"], f0["pose0"], f0["pose1"])
+    folded = net.forward(*args).clone()
+    dec_folded = net.DEC.clone()
+    net.fold_decoder = False
+    net._plans.clear()
+    plain = net.forward(*args).clone()
+    torch.cuda.synchronize()
+    scale = max(1.0, net.DEC.abs().max().item())
+    assert (dec_folded - net.DEC).abs().max().item() <= 2e-5 * scale
+    assert (folded - plain).abs().max().item() <= 2e-5
+    ref = so.forward(params, *args)
+    assert np.abs(plain.cpu().numpy() - ref).max() <= 1e-4 and np.abs(folded.cpu().numpy() - ref).max() <= 1e-4
+
+
 def test_fused_head_equals_the_multi_launch_head(gpu, params):
     """gruhead.hip (one kernel: gather, 4 GRU iterations, MLP, output) against the same network run as head_gather + 8
     row-GEMMs with gate epilogues + dec1 + head_final; ragged row counts exercise the partial last block."""
