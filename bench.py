@@ -571,6 +571,18 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
         dtype = "f32 weight gradients / optimiser; bf16x3 (split bf16, float32-class) forward + data-gradient convolutions"
     else:
         roofline, dtype = conv_roofline(args.precision, prof, B, args.steps, elapsed, traffic, folded=pipe.net.fold_decoder)
+        if rank == 0 and _lib is not None:
+            # what the matrix pipes of THIS box sustain on their own (register-resident chains, no memory traffic; ~0.4 s per
+            # leg, outside the timed region): the clock is power-managed and the power of a matrix instruction depends on its
+            # operand bits, so the nameplate `peak` is a zero-operand figure
+            kind = {"f16x2": "f16", "bf16x3": "bf16", "f32": "f32"}[args.precision]
+            rnd, zer = _lib.mfma_sustained_tflops(kind, False), _lib.mfma_sustained_tflops(kind, True)
+            issued = roofline["issued_matrix_tflops"]
+            roofline["sustained_matrix_rate"] = {
+                "random_operands_tflops": rnd, "zero_operands_tflops": zer, "issued_over_random_operand_rate": issued / rnd,
+                "note": "himo_mfma_sustained_tflops on this device right after the timed region: independent v_mfma chains from "
+                        "registers on every SIMD; `issued_matrix_tflops` / random-operand rate = the share of the chip's "
+                        "data-carrying matrix rate the convolution kernels reach while also moving their operands"}
         workload = ("per-frame pipeline: pillarise 3 sweeps (512x512 grid) -> SeFlow++-style encoder/decoder + GRU head "
                     "(random-init, self-specified: reference network source absent) -> per-point flow -> ego-motion "
                     "removal + dt0 + flow2compDis -> comp_dis")

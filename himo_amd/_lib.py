@@ -24,6 +24,7 @@ SIGNATURES = {
     "himo_prof_filter": (None, [ctypes.c_char_p]),
     "himo_prof_reset": (None, []),
     "himo_prof_summary": (c_size_t, [ctypes.c_char_p, c_size_t]),
+    "himo_mfma_sustained_tflops": (c_int, [c_int, c_int, c_double, ctypes.POINTER(c_double), c_void_p]),
     "himo_compdis_workspace_bytes": (c_size_t, [c_int]),
     "himo_compdis_batch": (c_int, [c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                    c_double, c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -152,3 +153,12 @@ def prof_stop() -> dict:
         out[name] = {"count": int(n), "total_ms": float(tot), "avg_ms": float(tot) / max(int(n), 1),
                      "min_ms": float(mn), "max_ms": float(mx)}
     return out
+
+
+def mfma_sustained_tflops(kind: str = "f16", zero_operands: bool = False, seconds: float = 0.4) -> float:
+    """himo_mfma_sustained_tflops: the rate the chip's matrix pipes sustain on their own (register-resident independent chains
+    on every SIMD) for ``kind`` "f16" | "bf16" | "f32", with random or all-zero operand bits.  Synchronous; ~``seconds``."""
+    out = ctypes.c_double(0.0)
+    check(load().himo_mfma_sustained_tflops({"f16": 0, "bf16": 1, "f32": 2}[kind], int(bool(zero_operands)), float(seconds),
+                                           ctypes.byref(out), stream_handle()), "himo_mfma_sustained_tflops")
+    return out.value

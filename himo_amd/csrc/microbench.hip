@@ -1,0 +1,103 @@
+// microbench.hip -- himo_mfma_sustained_tflops: what the matrix pipes of the chip this library runs on sustain with nothing
+// else going on.  Four independent v_mfma chains per wave, operands in registers, no memory traffic in the loop, one or two
+// waves per SIMD on every CU.  The MI355X manages its clock by power, and matrix-instruction power depends on the operand
+// bits: with random fp16 operands a box of this pool sustains ~1.58 PFLOP/s (the pipes 100 % busy at ~1.5 GHz), with all-zero
+// operands ~2.45 PFLOP/s (2.35 GHz) -- the 2.5 PFLOP/s nameplate is a zero-operand figure.  bench.py reports both next to the
+// roofline fraction so that the fraction can be read against what the silicon delivers on data.
+#include "himo_common.h"
+
+namespace himo {
+
+typedef _Float16 mb_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float mb_floatx16 __attribute__((ext_vector_type(16)));
+
+// deterministic operand bits: sign + 10-bit mantissa from a hash, exponents 12 .. 17 (values ~2^-3 .. 2^2): no inf / nan
+__device__ inline unsigned mb_bits(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    const unsigned lo = (x & 0x83ffu) | ((12u + (x >> 10) % 6u) << 10);
+    const unsigned y = x * 0x9e3779b9u + 0x85ebca6bu;
+    const unsigned hi = ((y >> 3) & 0x83ffu) | ((12u + (y >> 20) % 6u) << 10);
+    return lo | (hi << 16);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void mfma_chain_kernel(float* __restrict__ sink, int iters, int zero) {
+    uint4 a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const unsigned s = (threadIdx.x * 8u + i * 4u) * 2654435761u;
+        a[i] = zero ? make_uint4(0, 0, 0, 0) : make_uint4(mb_bits(s), mb_bits(s + 1), mb_bits(s + 2), mb_bits(s + 3));
+        b[i] = zero ? make_uint4(0, 0, 0, 0) : make_uint4(mb_bits(~s), mb_bits(~s + 1), mb_bits(~s + 2), mb_bits(~s + 3));
+    }
+    mb_floatx16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (KIND == 0) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mb_f16x8, a[c & 1]), __builtin_bit_cast(mb_f16x8, b[c >> 1]), acc[c], 0, 0, 0);
+                if (KIND == 1) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mb_bf16x8, a[c & 1]), __builtin_bit_cast(mb_bf16x8, b[c >> 1]), acc[c], 0, 0, 0);
+                if (KIND == 2) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[c & 1].x), __builtin_bit_cast(float, b[c >> 1].x), acc[c], 0, 0, 0);
+            }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[c][r];
+    if (s == 12345.678f) sink[threadIdx.x] = s;       // keeps the chains alive; never true in practice
+}
+
+}  // namespace himo
+
+using namespace himo;
+
+int himo_mfma_sustained_tflops(int kind, int zero_operands, double min_seconds, double* tflops, void* stream) {
+    if (kind < 0 || kind > 2 || !tflops || !(min_seconds >= 0.0) || min_seconds > 10.0) return HIMO_ERR_INVALID_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0, cus = 0;
+    HIMO_HIP(hipGetDevice(&dev));
+    HIMO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    float* sink = nullptr;
+    HIMO_HIP(hipMalloc((void**)&sink, 1024));
+    const int blocks = cus * 2, iters = 4000;                  // two waves per SIMD; ~2 ms per launch
+    const double flops_per_instr = kind == 2 ? 2.0 * 32 * 32 * 2 : 2.0 * 32 * 32 * 16;
+    auto launch = [&]() {
+        if (kind == 0) hipLaunchKernelGGL((mfma_chain_kernel<0>), dim3(blocks), dim3(256), 0, s, sink, iters, zero_operands);
+        else if (kind == 1) hipLaunchKernelGGL((mfma_chain_kernel<1>), dim3(blocks), dim3(256), 0, s, sink, iters, zero_operands);
+        else hipLaunchKernelGGL((mfma_chain_kernel<2>), dim3(blocks), dim3(256), 0, s, sink, iters, zero_operands);
+    };
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int st = HIMO_OK;
+    do {
+        if ((st = check_hip(hipEventCreate(&e0), "hipEventCreate")) != HIMO_OK) break;
+        if ((st = check_hip(hipEventCreate(&e1), "hipEventCreate")) != HIMO_OK) break;
+        // the first half of the budget brings the chip to its power-managed clock, the second half is timed
+        double warmed = 0.0, timed_ms = 0.0; long timed_launches = 0;
+        for (int phase = 0; phase < 2 && st == HIMO_OK; ++phase) {
+            const double budget_ms = min_seconds * 500.0;
+            double spent = 0.0; long n = 0;
+            do {
+                hipEventRecord(e0, s);
+                for (int k = 0; k < 8; ++k) launch();
+                hipEventRecord(e1, s);
+                if ((st = check_hip(hipEventSynchronize(e1), "mfma_chain_kernel")) != HIMO_OK) break;
+                float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+                spent += ms; n += 8;
+            } while (spent < budget_ms);
+            if (phase == 0) warmed = spent; else { timed_ms = spent; timed_launches = n; }
+        }
+        (void)warmed;
+        if (st == HIMO_OK) *tflops = (double)timed_launches * blocks * 4 * iters * 16 * flops_per_instr / (timed_ms * 1e-3) / 1e12;
+    } while (0);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    hipFree(sink);
+    return st;
+}

@@ -67,6 +67,11 @@ void himo_prof_enable(int on);
 void himo_prof_filter(const char* substr);
 void himo_prof_reset(void);
 size_t himo_prof_summary(char* buf, size_t cap);
+/* Diagnostic: the matrix-instruction rate the device sustains on its own -- independent v_mfma chains from registers on every
+ * SIMD, no memory traffic, for about `min_seconds` (half of it untimed, to reach the power-managed clock).  kind 0: fp16
+ * 32x32x16, 1: bf16 32x32x16, 2: float32 32x32x2; `zero_operands` != 0 feeds all-zero operands (the clock, hence the rate,
+ * depends on the operand bits).  Synchronous.  Writes TFLOP/s to *tflops. */
+int himo_mfma_sustained_tflops(int kind, int zero_operands, double min_seconds, double* tflops, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a1-a4 (+a5/a6): flow -> per-point de-distortion offsets, batched over ragged frames.
