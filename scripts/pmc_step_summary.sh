@@ -18,7 +18,7 @@ cd $R
 python - <<PY
 import csv, glob, re, collections
 FAM = [("conv3x3 (stride 1)", r"conv3_presplit_kernel<\d+, \d+, \d+, \w+, 1, \d+>", 20), ("conv3x3 (stride 2)", r"conv3_presplit_kernel<\d+, \d+, \d+, \w+, 2, \d+>", 3),
-       ("conv1x1", r"conv1_presplit_kernel<", 6), ("gru_head", r"gru_head_kernel<", 1), ("upsample2x", r"upsample2x_kernel<", 3),
+       ("conv1x1", r"conv1_presplit_kernel<", 4), ("gru_head", r"gru_head_kernel<", 1), ("upsample2x", r"upsample2x_kernel<", 3),
        ("pillar_feature", r"pillar_feature_kernel", 4), ("pillar_fill", r"pillar_fill_kernel", 4), ("pillar_assign", r"pillar_assign_kernel", 4),
        ("compdis", r"compdis_kernel<", 1)]
 vals = collections.defaultdict(lambda: collections.defaultdict(list))      # family -> counter -> [(dispatch, value, ns)]

@@ -22,6 +22,9 @@ python scripts/exp_eval.py > $OUT/${RN}_evaluator_throughput.txt 2>&1
 python scripts/exp_hostfed.py > $OUT/${RN}_hostfed_pipeline.txt 2>&1
 python bench.py --workload fastnsf > $OUT/${RN}_bench_fastnsf_n1.json 2>> $OUT/pipeline.err
 bash scripts/exp_clock_pmc.sh default > $OUT/${RN}_conv3x3_clock_and_mfma_busy.txt 2>&1
+bash scripts/pmc_step_summary.sh > $OUT/${RN}_pmc_step_summary.txt 2>&1
+python scripts/exp_savezip.py > $OUT/${RN}_exp_savezip.log 2>&1
+hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_peak scripts/micro/mfma_peak.hip && /tmp/mfma_peak > $OUT/${RN}_mfma_sustained_peak.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 for wl in pipeline compdis train; do
   ARGS="--workload $wl --no-cpu-baseline --no-extra-precisions"
