@@ -470,7 +470,10 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     # The roofline kernel is timed live inside the timed region (HIP events around each of ITS launches, on the launch
     # stream); the other kernels are left alone there -- two event records per launch on ~45 launches per frame cost
     # ~12 % of the frame rate -- and get their table from one extra, untimed, fully profiled step afterwards.
-    dominant = {"compdis": "compdis_kernel", "train": "conv_wgrad_tiled_kernel", "fastnsf": "conv1x1_mfma_kernel"}.get(
+    # train: with split-bf16 weight gradients (the default, --train-precision mixed) the largest family of the step is the 3x3
+    # DATA-gradient convolutions (split bf16, six matrix products per float32 product); in float32 it is the weight gradients
+    train_dominant = "conv_wgrad_tiled_kernel" if args.train_precision == "f32" else "conv3x3_bf16x3_kernel"
+    dominant = {"compdis": "compdis_kernel", "train": train_dominant, "fastnsf": "conv1x1_mfma_kernel"}.get(
         args.workload, {"bf16x3": "conv3x3_bf16x3_kernel", "f16x2": "conv3x3_f16x2_kernel"}.get(args.precision, "conv3x3_mfma_kernel"))
     grouped = dist.is_available() and dist.is_initialized()
     if grouped:
@@ -554,21 +557,32 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
         dtype = "f32"
     elif args.workload == "train":
         from himo_amd.seflow import spec
-        # dominant kernel of the step: the 3x3 weight gradients (float32 MFMA, LDS-tiled split-K), 19 launches per step
-        k = prof.get("conv_wgrad_tiled_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
         n_steps = B * args.steps
         H, W = spec.GRID
+        # 2*M*N*K of the 23 3x3 layers of one sample (20 stride-1 + the 3 stride-2 ones at their output resolution): the
+        # algorithmic work of the weight gradients AND of the data gradients (a transposed convolution of the same size)
         flops_w = spec.conv3x3_flops() + sum(spec.NUM_FRAMES * 2.0 * (H // d) * (W // d) * ci * co * 9
                                              for d, ci, co in ((2, 32, 64), (4, 64, 128), (8, 128, 256)))
+        k = prof.get(train_dominant, {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
         alg_tf = flops_w * n_steps / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
-        roofline = {"bound": "mfma", "kernel": "conv_wgrad_tiled_kernel (v_mfma_f32_32x32x2_f32; 3x3 weight gradients)",
-                    "achieved": alg_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": alg_tf / MFMA_F32_PEAK_TF,
-                    "traffic": None, "avg_launch_ms": k["avg_ms"], "launches_timed": k["count"],
-                    "algorithmic_flops_per_step": flops_w, "share_of_step_time": k["total_ms"] / (elapsed * 1e3)}
+        if train_dominant == "conv_wgrad_tiled_kernel":
+            kdesc, peak, pnote = "conv_wgrad_tiled_kernel (v_mfma_f32_32x32x2_f32; 3x3 weight gradients)", MFMA_F32_PEAK_TF, "dense float32 MFMA peak"
+        else:
+            kdesc = ("conv3x3_bf16x3_kernel (v_mfma_f32_32x32x16_bf16, 6 per float32 product block; the 3x3 DATA-gradient convolutions: "
+                     "flipped weights, stride-2 layers through a zero-stuffed dY)")
+            peak, pnote = MFMA_BF16_PEAK_TF / 6.0, f"{MFMA_BF16_PEAK_TF:.0f} TFLOP/s dense bf16 MFMA peak / 6 matrix products per float32 product"
+        roofline = {"bound": "mfma", "kernel": kdesc, "achieved": alg_tf, "peak": peak, "peak_note": pnote, "unit": "TFLOP/s",
+                    "frac": alg_tf / peak, "traffic": None, "avg_launch_ms": k["avg_ms"], "launches_timed": k["count"],
+                    "algorithmic_flops_per_step": flops_w, "share_of_step_time": k["total_ms"] / (elapsed * 1e3),
+                    "note": "the stride-2 layers' data gradients run at the INPUT resolution on a zero-stuffed dY (4x their algorithmic "
+                            "flops), which this figure does not credit"}
         workload = ("self-supervised TRAINING step (BASELINE config 5): pillarise 3 sweeps -> network forward with saved "
                     "activations -> 4-term NN/Chamfer loss -> full backward -> flat-gradient all-reduce -> Adam; "
                     "one 120k-point sample per GPU per step")
-        dtype = "f32 weight gradients / optimiser; bf16x3 (split bf16, float32-class) forward + data-gradient convolutions"
+        dtype = {"mixed": "forward f16x2 (two-term fp16 split); data-gradient convolutions bf16x3 (three-term bf16 split, float32-class); stride-1 3x3 "
+                          "weight gradients two-term bf16 split (16-bit operands, float32 sums); everything else and the optimiser f32",
+                 "bf16x3": "forward + data-gradient convolutions bf16x3 (split bf16, float32-class); weight gradients / optimiser f32",
+                 "f32": "f32"}[args.train_precision]
     else:
         roofline, dtype = conv_roofline(args.precision, prof, B, args.steps, elapsed, traffic, folded=pipe.net.fold_decoder)
         if rank == 0 and _lib is not None:

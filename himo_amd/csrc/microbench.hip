@@ -84,11 +84,11 @@ int himo_mfma_sustained_tflops(int kind, int zero_operands, double min_seconds, 
             const double budget_ms = min_seconds * 500.0;
             double spent = 0.0; long n = 0;
             do {
-                hipEventRecord(e0, s);
+                (void)hipEventRecord(e0, s);
                 for (int k = 0; k < 8; ++k) launch();
-                hipEventRecord(e1, s);
+                (void)hipEventRecord(e1, s);
                 if ((st = check_hip(hipEventSynchronize(e1), "mfma_chain_kernel")) != HIMO_OK) break;
-                float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+                float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
                 spent += ms; n += 8;
             } while (spent < budget_ms);
             if (phase == 0) warmed = spent; else { timed_ms = spent; timed_launches = n; }
@@ -96,8 +96,8 @@ int himo_mfma_sustained_tflops(int kind, int zero_operands, double min_seconds, 
         (void)warmed;
         if (st == HIMO_OK) *tflops = (double)timed_launches * blocks * 4 * iters * 16 * flops_per_instr / (timed_ms * 1e-3) / 1e12;
     } while (0);
-    if (e0) hipEventDestroy(e0);
-    if (e1) hipEventDestroy(e1);
-    hipFree(sink);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
     return st;
 }

@@ -10,6 +10,7 @@
 // atomics anywhere in the backward pass.
 #include "himo_common.h"
 #include <math.h>
+#include "bf16x3.h"
 
 namespace himo {
 
@@ -373,6 +374,147 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(ConvWgradTiled
             out[t * 4096 + (wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + wn * 32 + li] = acc[t][r];
 }
 
+// ---- the same weight gradient with SPLIT-bf16 operands on the 16-bit matrix instructions (himo_conv3x3_wgrad_batch flag 2) ----
+// x = h + m (two bf16, 16 significant bits), products h*h + h*m + m*h into one float32 accumulator: THREE
+// v_mfma_f32_32x32x16_bf16 per 16 pixels of a tap instead of EIGHT v_mfma_f32_32x32x2_f32 -- 5.3x less matrix time.  The sum
+// runs over hundreds of thousands of pixels with unbiased operand roundings, and the training step's gradients are compared
+// at 2e-3 of the tensor's max-abs (tests/test_train_gpu.py); the float32 kernel above stays the default of the ABI.
+// The reduction dimension is the PIXEL index, so the operands are staged TRANSPOSED: Xt[plane][halo row][ci][px],
+// Yt[plane][row][co][px], 8 consecutive pixels = one 16-byte fragment read.  A tap's kx shifts the pixel window by 0, 1, 2
+// elements: every (row, ky) reads ONE aligned fragment + the following 32-bit word and forms the three windows in registers
+// (kx = 1: four v_alignbit; kx = 2: a register rename).  Rows are padded to 40 pixels = 80 bytes: consecutive channels sit 20
+// banks apart, so the 16 lanes of a ds_read_b128 phase cover the 64 banks exactly once, and so do the transposed stores.
+// Stride 1 only (the stride-2 layers keep the float32 kernel); same tile, partial layout and reduce kernel as above.
+constexpr int kWsPxp = 40;
+
+__device__ inline void split2_bf16_pair(float a, float b, unsigned& hw, unsigned& mw) {
+    typedef float wg_f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 wg_b2 __attribute__((ext_vector_type(2)));
+    wg_f2 v; v[0] = a; v[1] = b;
+    hw = __builtin_bit_cast(unsigned, __builtin_convertvector(v, wg_b2));          // v_cvt_pk_bf16_f32 (round to nearest even)
+    wg_f2 r;
+    r[0] = a - __builtin_bit_cast(float, hw << 16);
+    r[1] = b - __builtin_bit_cast(float, hw & 0xffff0000u);
+    mw = __builtin_bit_cast(unsigned, __builtin_convertvector(r, wg_b2));
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(ConvWgradTiledArgs a) {
+    constexpr int TR = 2, HR = 4, HC = 34;
+    __shared__ __attribute__((aligned(16))) unsigned short Xt[2][HR][64][kWsPxp];
+    __shared__ __attribute__((aligned(16))) unsigned short Yt[2][TR][64][kWsPxp];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int co_tiles = a.cout / 64;
+    const int ci0 = ((int)blockIdx.y / co_tiles) * 64, co0 = ((int)blockIdx.y % co_tiles) * 64;
+    const int col_blocks = a.Wo / 32, row_groups = a.Ho / TR;
+    const int tiles_per_img = col_blocks * row_groups;
+    const int n_tiles = a.n_img * tiles_per_img;
+    const int t0 = (int)blockIdx.x * a.tiles_per_chunk;
+    const int t1 = min(t0 + a.tiles_per_chunk, n_tiles);
+    const int sc = threadIdx.x & 63, sg = threadIdx.x >> 6;      // staging: this thread's channel, its group of items
+
+    floatx16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // a tile's operands travel global -> registers one tile AHEAD (issued before the previous tile's matrix loop, which hides
+    // their latency), then registers -> split -> transposed LDS between two barriers
+    constexpr int kXItems = HR * 5 / 4, kYItems = TR * 4 / 4;
+    float vx[kXItems][8], vy[kYItems][8];
+    auto fetch = [&](int t) {
+        const int img = t / tiles_per_img;
+        const int rem = t - img * tiles_per_img;
+        const int y0 = (rem / col_blocks) * TR, x0 = (rem % col_blocks) * 32;
+        const float* xi = a.x + img * a.x_bs + ci0 + sc;
+        const float* di = a.dy + img * a.dy_bs + co0 + sc;
+        // X halo: item = (halo row, 8-pixel chunk) of this thread's channel: 8 coalesced loads (64 lanes = 64 consecutive
+        // channels of one pixel)
+#pragma unroll
+        for (int it = 0; it < kXItems; ++it) {
+            const int item = sg + 4 * it, hr = item / 5, ch = item % 5;
+            const int iy = y0 - 1 + hr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int hx = ch * 8 + j, ix = x0 - 1 + hx;
+                vx[it][j] = (hx < HC && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? xi[((int64_t)iy * a.W + ix) * a.x_pitch] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kYItems; ++it) {
+            const int item = sg + 4 * it, r = item >> 2, ch = item & 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vy[it][j] = di[((int64_t)(y0 + r) * a.Wo + x0 + ch * 8 + j) * a.dy_pitch];
+        }
+    };
+    if (t0 < t1) fetch(t0);
+    for (int t = t0; t < t1; ++t) {
+        __syncthreads();                                   // the previous tile's fragment reads are done
+#pragma unroll
+        for (int it = 0; it < kXItems; ++it) {
+            const int item = sg + 4 * it, hr = item / 5, ch = item % 5;
+            uint4 h, m;
+            split2_bf16_pair(vx[it][0], vx[it][1], h.x, m.x); split2_bf16_pair(vx[it][2], vx[it][3], h.y, m.y);
+            split2_bf16_pair(vx[it][4], vx[it][5], h.z, m.z); split2_bf16_pair(vx[it][6], vx[it][7], h.w, m.w);
+            *reinterpret_cast<uint4*>(&Xt[0][hr][sc][ch * 8]) = h;
+            *reinterpret_cast<uint4*>(&Xt[1][hr][sc][ch * 8]) = m;
+        }
+#pragma unroll
+        for (int it = 0; it < kYItems; ++it) {
+            const int item = sg + 4 * it, r = item >> 2, ch = item & 3;
+            uint4 h, m;
+            split2_bf16_pair(vy[it][0], vy[it][1], h.x, m.x); split2_bf16_pair(vy[it][2], vy[it][3], h.y, m.y);
+            split2_bf16_pair(vy[it][4], vy[it][5], h.z, m.z); split2_bf16_pair(vy[it][6], vy[it][7], h.w, m.w);
+            *reinterpret_cast<uint4*>(&Yt[0][r][sc][ch * 8]) = h;
+            *reinterpret_cast<uint4*>(&Yt[1][r][sc][ch * 8]) = m;
+        }
+        if (t + 1 < t1) fetch(t + 1);
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < TR; ++r)
+#pragma unroll 1
+            for (int s = 0; s < 2; ++s) {
+                const int px = 16 * s + 8 * lh;
+                bf16x8 bfr[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bfr[p] = *reinterpret_cast<const bf16x8*>(&Yt[p][r][wn * 32 + li][px]);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    uint4 q[2]; unsigned q4[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        q[p] = *reinterpret_cast<const uint4*>(&Xt[p][r + ky][wm * 32 + li][px]);
+                        q4[p] = *reinterpret_cast<const unsigned*>(&Xt[p][r + ky][wm * 32 + li][px + 8]);
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        bf16x8 af[2];
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            uint4 w = q[p];
+                            if (kx == 1) w = make_uint4(__builtin_amdgcn_alignbit(q[p].y, q[p].x, 16), __builtin_amdgcn_alignbit(q[p].z, q[p].y, 16),
+                                                        __builtin_amdgcn_alignbit(q[p].w, q[p].z, 16), __builtin_amdgcn_alignbit(q4[p], q[p].w, 16));
+                            if (kx == 2) w = make_uint4(q[p].y, q[p].z, q[p].w, q4[p]);
+                            af[p] = __builtin_bit_cast(bf16x8, w);
+                        }
+                        floatx16& c = acc[ky * 3 + kx];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], c, 0, 0, 0);
+                    }
+                }
+            }
+    }
+    float* out = a.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 * 64 * 64;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            out[t * 4096 + (wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + wn * 32 + li] = acc[t][r];
+}
+
 __global__ __launch_bounds__(256) void conv_wgrad_tiled_reduce_kernel(const float* __restrict__ partial, int chunks, int cin, int cout,
                                                                       float* __restrict__ dW, int accumulate) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -599,7 +741,8 @@ extern "C" int himo_conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_b
     hipStream_t s = (hipStream_t)stream;
     {
         ProfScope ps("conv_wgrad_tiled_kernel", s);
-        if (stride == 1) hipLaunchKernelGGL(conv_wgrad_tiled_kernel<1>, dim3(grid_x, tiles_xy), dim3(256), 0, s, a);
+        if (stride == 1 && (flags & 2u)) hipLaunchKernelGGL(conv_wgrad_split_kernel, dim3(grid_x, tiles_xy), dim3(256), 0, s, a);
+        else if (stride == 1) hipLaunchKernelGGL(conv_wgrad_tiled_kernel<1>, dim3(grid_x, tiles_xy), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(conv_wgrad_tiled_kernel<2>, dim3(grid_x, tiles_xy), dim3(256), 0, s, a);
     }
     hipLaunchKernelGGL(conv_wgrad_tiled_reduce_kernel, dim3((unsigned)((9ll * cin * cout + 255) / 256)), dim3(256), 0, s, a.partial, grid_x,

@@ -44,9 +44,9 @@ _lib.register({
 
 
 # ---- stand-alone backward operators (tests): the kernels the trainer strings together ---------------------------------
-def conv3x3_backward_nhwc(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, stride: int = 1):
+def conv3x3_backward_nhwc(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, stride: int = 1, wgrad_flags: int = 0):
     """x [N,H,W,Cin], weight [3,3,Cin,Cout], dy [N,Ho,Wo,Cout] -> (dx [N,H,W,Cin], dw [3,3,Cin,Cout], db [Cout]) of
-    y = conv3x3(x, weight, pad 1, stride) + b."""
+    y = conv3x3(x, weight, pad 1, stride) + b.  ``wgrad_flags`` 2: split-bf16 operands in the weight-gradient kernel."""
     from .model import conv2d_nhwc
     lib = _lib.load()
     n, h, w, cin = x.shape
@@ -68,7 +68,7 @@ def conv3x3_backward_nhwc(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tenso
     if need:                                                                                    # LDS-tiled batch kernel
         ws = torch.empty(need, dtype=torch.uint8, device=x.device)
         _lib.check(lib.himo_conv3x3_wgrad_batch(n, x.data_ptr(), h * w * cin, cin, h, w, cin, dy.data_ptr(), ho * wo * cout, cout, cout,
-                                                stride, dw.data_ptr(), 0, ws.data_ptr(), ws.numel(), s()), "himo_conv3x3_wgrad_batch")
+                                                stride, dw.data_ptr(), wgrad_flags, ws.data_ptr(), ws.numel(), s()), "himo_conv3x3_wgrad_batch")
         return dx, dw, dy.sum((0, 1, 2))
     ws = torch.empty(int(lib.himo_conv_wgrad_workspace_bytes(ho, wo, cin, cout)), dtype=torch.uint8, device=x.device)
     for i in range(n):
@@ -283,6 +283,9 @@ class SeFlowTrainer:
             raise ValueError(precision)
         self.precision = precision
         self.fwd_format = 1 if precision == "mixed" else 0          # HIMO_PACK_F16X2 / HIMO_PACK_BF16X3
+        # mixed: the stride-1 3x3 weight gradients multiply split-bf16 operands (16 significant bits, float32 sums) on the
+        # 16-bit matrix instructions (csrc/train.hip conv_wgrad_split_kernel); the other modes keep float32 matrix instructions
+        self.wgrad_flags = 2 if precision == "mixed" else 0
         self.lib = _lib.load()
         self.device = dev = device if device is not None else _lib.require_gpu()
         params = spec.init_params(seed) if params is None else params
@@ -405,7 +408,7 @@ class SeFlowTrainer:
     def _wgrad3_batch(self, n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, gname, stride=1):
         """weight gradient over n images in one launch (LDS-tiled kernel)"""
         _lib.check(self.lib.himo_conv3x3_wgrad_batch(n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, stride,
-                                                     self.g[gname].data_ptr(), 0, self.ws.data_ptr(), self.ws.numel(),
+                                                     self.g[gname].data_ptr(), self.wgrad_flags, self.ws.data_ptr(), self.ws.numel(),
                                                      _lib.stream_handle()), "conv3x3_wgrad_batch")
 
     def _wgrad3(self, x, x_pitch, h, w, cin, dy, dy_pitch, cout, stride, gname, acc):

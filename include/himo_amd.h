@@ -468,7 +468,9 @@ int himo_head_scatter(int64_t n, int grid_w, int grid_h, const void* d_pillar_wo
                       void* stream);
 /* the 3x3 weight gradient over a batch of images, LDS-tiled (dY tile + X halo staged once, all 9 taps read them);
  * h, w = INPUT image size.  stride 1: h even, w % 32 == 0, cin % 64 == 0; stride 2: h even, w % 64 == 0, cin == 32 or
- * cin % 64 == 0; cout % 64 == 0 -- HIMO_ERR_UNSUPPORTED otherwise (workspace_bytes returns 0) */
+ * cin % 64 == 0; cout % 64 == 0 -- HIMO_ERR_UNSUPPORTED otherwise (workspace_bytes returns 0).
+ * flags bit 0: accumulate into d_dw; bit 1 (2): stride-1 layers multiply split-bf16 operands (x = h + m, 16 significant bits,
+ * float32 accumulation) on the 16-bit matrix instructions instead of float32 ones */
 size_t himo_conv_wgrad_batch_workspace_bytes(int n_img, int h, int w, int cin, int cout, int stride);
 int himo_conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int cin,
                              const float* d_dy, int64_t dy_batch_stride, int dy_pitch, int cout, int stride, float* d_dw,
