@@ -470,9 +470,9 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     # The roofline kernel is timed live inside the timed region (HIP events around each of ITS launches, on the launch
     # stream); the other kernels are left alone there -- two event records per launch on ~45 launches per frame cost
     # ~12 % of the frame rate -- and get their table from one extra, untimed, fully profiled step afterwards.
-    # train: with split-bf16 weight gradients (the default, --train-precision mixed) the largest family of the step is the 3x3
-    # DATA-gradient convolutions (split bf16, six matrix products per float32 product); in float32 it is the weight gradients
-    train_dominant = "conv_wgrad_tiled_kernel" if args.train_precision == "f32" else "conv3x3_bf16x3_kernel"
+    # train: the 3x3 weight gradients are the largest kernel family of the step in every precision mode (mixed: split-bf16
+    # operands on the stride-1 layers; bf16x3 / f32: float32 matrix instructions)
+    train_dominant = "conv_wgrad_tiled_kernel"
     dominant = {"compdis": "compdis_kernel", "train": train_dominant, "fastnsf": "conv1x1_mfma_kernel"}.get(
         args.workload, {"bf16x3": "conv3x3_bf16x3_kernel", "f16x2": "conv3x3_f16x2_kernel"}.get(args.precision, "conv3x3_mfma_kernel"))
     grouped = dist.is_available() and dist.is_initialized()
@@ -565,22 +565,22 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
                                              for d, ci, co in ((2, 32, 64), (4, 64, 128), (8, 128, 256)))
         k = prof.get(train_dominant, {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
         alg_tf = flops_w * n_steps / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
-        if train_dominant == "conv_wgrad_tiled_kernel":
-            kdesc, peak, pnote = "conv_wgrad_tiled_kernel (v_mfma_f32_32x32x2_f32; 3x3 weight gradients)", MFMA_F32_PEAK_TF, "dense float32 MFMA peak"
+        if args.train_precision == "mixed":
+            kdesc = ("conv_wgrad_tiled_kernel family: 3x3 weight gradients -- the 20 stride-1 layers on v_mfma_f32_32x32x16_bf16 with two-term "
+                     "split-bf16 operands (3 per float32 product block), the 3 stride-2 layers on v_mfma_f32_32x32x2_f32")
+            peak, pnote = MFMA_BF16_PEAK_TF / 3.0, (f"{MFMA_BF16_PEAK_TF:.0f} TFLOP/s dense bf16 MFMA peak / 3 matrix products per float32 product "
+                                                    "(the stride-2 launches, 10 % of the family's flops, run float32 matrix instructions)")
         else:
-            kdesc = ("conv3x3_bf16x3_kernel (v_mfma_f32_32x32x16_bf16, 6 per float32 product block; the 3x3 DATA-gradient convolutions: "
-                     "flipped weights, stride-2 layers through a zero-stuffed dY)")
-            peak, pnote = MFMA_BF16_PEAK_TF / 6.0, f"{MFMA_BF16_PEAK_TF:.0f} TFLOP/s dense bf16 MFMA peak / 6 matrix products per float32 product"
+            kdesc, peak, pnote = "conv_wgrad_tiled_kernel (v_mfma_f32_32x32x2_f32; 3x3 weight gradients)", MFMA_F32_PEAK_TF, "dense float32 MFMA peak"
         roofline = {"bound": "mfma", "kernel": kdesc, "achieved": alg_tf, "peak": peak, "peak_note": pnote, "unit": "TFLOP/s",
                     "frac": alg_tf / peak, "traffic": None, "avg_launch_ms": k["avg_ms"], "launches_timed": k["count"],
                     "algorithmic_flops_per_step": flops_w, "share_of_step_time": k["total_ms"] / (elapsed * 1e3),
-                    "note": "the stride-2 layers' data gradients run at the INPUT resolution on a zero-stuffed dY (4x their algorithmic "
-                            "flops), which this figure does not credit"}
+                    "note": "split-K over pixel tiles; the fixed-order reduction of the partials is a separate (small) kernel"}
         workload = ("self-supervised TRAINING step (BASELINE config 5): pillarise 3 sweeps -> network forward with saved "
                     "activations -> 4-term NN/Chamfer loss -> full backward -> flat-gradient all-reduce -> Adam; "
                     "one 120k-point sample per GPU per step")
-        dtype = {"mixed": "forward f16x2 (two-term fp16 split); data-gradient convolutions bf16x3 (three-term bf16 split, float32-class); stride-1 3x3 "
-                          "weight gradients two-term bf16 split (16-bit operands, float32 sums); everything else and the optimiser f32",
+        dtype = {"mixed": "forward f16x2 (two-term fp16 split); 3x3 data-gradient convolutions and stride-1 3x3 weight gradients two-term bf16 split "
+                          "(16-bit operands, float32 range and sums); 1x1 / head data gradients bf16x3; everything else and the optimiser f32",
                  "bf16x3": "forward + data-gradient convolutions bf16x3 (split bf16, float32-class); weight gradients / optimiser f32",
                  "f32": "f32"}[args.train_precision]
     else:

@@ -45,8 +45,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     const int ci = slab * 16 + k;
     const float x = ci < Cin ? w[((int64_t)tap * Cin + ci) * Cout + co] : 0.f;
     unsigned h, m = 0, l;
-    if (FMT == 3) split3(x, h, m, l); else split2(x * kF16WeightScale, h, l);
-    const int64_t base = (((int64_t)tap * slabs + slab) * FMT) * Cout * 16 + (int64_t)co * 16 + k;
+    constexpr int NP = FMT == 3 ? 3 : 2;               // FMT = 4: two bf16 planes (h, m), see convsp.hip
+    if (FMT == 3) split3(x, h, m, l);
+    else if (FMT == 4) { h = bf16_rne_bits(x); l = bf16_rne_bits(x - bf16_bits_to_float(h)); }
+    else split2(x * kF16WeightScale, h, l);
+    const int64_t base = (((int64_t)tap * slabs + slab) * NP) * Cout * 16 + (int64_t)co * 16 + k;
     out[base] = (unsigned short)h;
     if (FMT == 3) {
         out[base + (int64_t)Cout * 16] = (unsigned short)m;
@@ -330,7 +333,7 @@ int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w
         HIMO_LAUNCH_CHECK("conv3_split_kernel");
         return HIMO_OK;
     }
-    if (stride != 1) return HIMO_ERR_UNSUPPORTED;
+    if (stride != 1 || format == 2) return HIMO_ERR_UNSUPPORTED;       // (format 2 lives in convsp.hip only)
     auto blocks_for = [&](int bn, int mi) -> int64_t {
         const int bm = 64 * mi, th = 2 * mi;
         const int64_t tm = ksize == 1 ? (int64_t)a.N * (((int64_t)a.Ho * a.Wo + bm - 1) / bm)
@@ -368,11 +371,13 @@ extern "C" size_t himo_conv_packed_weight_bytes(int ksize, int cin, int cout) {
 }
 
 extern "C" int himo_conv_pack_weights_ex(const float* d_w, int ksize, int cin, int cout, int format, void* d_packed, void* stream) {
-    if (!d_w || !d_packed || cin < 1 || cout < 1 || !(ksize == 1 || ksize == 3) || !(format == 0 || format == 1)) return HIMO_ERR_INVALID_ARGUMENT;
+    if (!d_w || !d_packed || cin < 1 || cout < 1 || !(ksize == 1 || ksize == 3) || format < 0 || format > 2) return HIMO_ERR_INVALID_ARGUMENT;
+    if (format == 2 && ksize != 3) return HIMO_ERR_UNSUPPORTED;          // the two-term bf16 split exists for 3x3 layers only
     const int T = ksize * ksize;
     const int64_t total = (int64_t)T * ((cin + 15) / 16) * cout * 16;
     const dim3 grid((unsigned)((total + 255) / 256));
     if (format == 1) hipLaunchKernelGGL(pack_weights_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, d_w, T, cin, cout, (unsigned short*)d_packed);
+    else if (format == 2) hipLaunchKernelGGL(pack_weights_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, d_w, T, cin, cout, (unsigned short*)d_packed);
     else hipLaunchKernelGGL(pack_weights_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, d_w, T, cin, cout, (unsigned short*)d_packed);
     HIMO_LAUNCH_CHECK("pack_weights_kernel");
     return HIMO_OK;

@@ -42,9 +42,12 @@ template <> struct PatchLayout<true> {
 // S = 2 (the three stride-2 layers): the halo patch is (2 TH + 1) x 65 input pixels, stored with even and odd
 // columns de-interleaved ([33 even | 32 odd] per row) so that the 32 output pixels of a fragment -- input columns
 // 2 li + kx -- are again 32 CONSECUTIVE patch pixels for every tap.
+// FMT = 4: the two-term bf16 split x = h + m (16 significant bits, float32 range; three products h*h + h*m + m*h) -- the data-gradient
+// convolutions of the mixed-precision training step (himo_conv_pack_weights_ex format 2); NP = planes of the format.
 template <int EPI, int PH, int FMT, int MI, int S>
-__global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled && S == 1) ? 3 : 2)
+__global__ __launch_bounds__(256, (FMT != 3 && !kF16Scaled && S == 1) ? 3 : 2)
 void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
+    constexpr int NP = FMT == 3 ? 3 : 2;
     constexpr int TW = 32, TH = MI * PH;
     constexpr int PW = S == 1 ? TW + 2 : 2 * TW + 1, PHt = S == 1 ? TH + 2 : 2 * TH + 1, NPIX = PHt * PW;
     constexpr int BN = (4 / PH) * 32;
@@ -52,11 +55,11 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int kPatchPerThread = (kPatchItems + 255) / 256;
     // double-buffered while two blocks still fit a CU's LDS; else single-buffered with a second barrier per slab
     using PL = PatchLayout<(PH == 2 || S == 2)>;
-    constexpr int NB = 2 * FMT * NPIX * PL::kPitch <= 66 * 1024 ? 2 : 1;
+    constexpr int NB = 2 * NP * NPIX * PL::kPitch <= 66 * 1024 ? 2 : 1;
     // raw bytes, at least the 4 x 4 KB the vectorised epilogue stages through (store_block_vec, conv_common.h)
-    constexpr int kPatchBytes = NB * FMT * NPIX * PL::kPitch;
+    constexpr int kPatchBytes = NB * NP * NPIX * PL::kPitch;
     __shared__ __attribute__((aligned(16))) unsigned char patch_raw[kPatchBytes < 16384 ? 16384 : kPatchBytes];
-    auto& patch = *reinterpret_cast<unsigned char (*)[NB][FMT][NPIX * PL::kPitch]>(patch_raw);
+    auto& patch = *reinterpret_cast<unsigned char (*)[NB][NP][NPIX * PL::kPitch]>(patch_raw);
 
     const int n_tiles_n = (a.Cout + BN - 1) / BN;
     int bid = xcd_block_id(blockIdx.x, gridDim.x);
@@ -117,21 +120,25 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
                     split3(r[it].x, h[0], m[0], l[0]); split3(r[it].y, h[1], m[1], l[1]);
                     split3(r[it].z, h[2], m[2], l[2]); split3(r[it].w, h[3], m[3], l[3]);
                     *reinterpret_cast<uint2*>(&patch[buf][1][off]) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+                } else if (FMT == 4) {
+                    const float xv[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { h[e] = bf16_rne_bits(xv[e]); l[e] = bf16_rne_bits(xv[e] - bf16_bits_to_float(h[e])); }
                 } else {
                     split2(r[it].x, h[0], l[0]); split2(r[it].y, h[1], l[1]);
                     split2(r[it].z, h[2], l[2]); split2(r[it].w, h[3], l[3]);
                 }
                 *reinterpret_cast<uint2*>(&patch[buf][0][off]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                *reinterpret_cast<uint2*>(&patch[buf][FMT - 1][off]) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                *reinterpret_cast<uint2*>(&patch[buf][NP - 1][off]) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
             }
         }
     };
     // this wave's weight fragments of one (tap, slab): FMT x 16 bytes per lane
     const int co_ld = co_ok ? co : a.Cout - 1;        // out-of-range lanes read a valid column; their results are never stored
-    auto load_b = [&](int tap, int slab, uint4 (&b)[FMT]) {
-        const unsigned short* base = wpk + (((int64_t)tap * slabs + slab) * FMT) * a.Cout * 16 + (int64_t)co_ld * 16 + lh * 8;
+    auto load_b = [&](int tap, int slab, uint4 (&b)[NP]) {
+        const unsigned short* base = wpk + (((int64_t)tap * slabs + slab) * NP) * a.Cout * 16 + (int64_t)co_ld * 16 + lh * 8;
 #pragma unroll
-        for (int s = 0; s < FMT; ++s) b[s] = *reinterpret_cast<const uint4*>(base + (int64_t)s * a.Cout * 16);
+        for (int s = 0; s < NP; ++s) b[s] = *reinterpret_cast<const uint4*>(base + (int64_t)s * a.Cout * 16);
     };
 
     // Weight fragments run TWO taps ahead of their use (an L2 round trip outlasts one tap's matrix work) in three
@@ -139,7 +146,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     // so no copy ever forces a wait on a load issued in the same tap; 9 taps = 3 kernel rows keep the rotation aligned
     // across slabs.  The loads are unconditional (clamped indices) to keep the loop body free of branches.
     float4 pr[kPatchPerThread];
-    uint4 bq[3][FMT];
+    uint4 bq[3][NP];
     load_patch(0, pr);
     load_b(0, 0, bq[0]);
     load_b(1, 0, bq[1]);
@@ -166,9 +173,9 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #endif
                 }
                 const int tapoff = S == 1 ? ky * PW + kx : ky * PW + (kx & 1) * 33 + (kx >> 1);
-                bf16x8 af[MI][FMT];
+                bf16x8 af[MI][NP];
 #pragma unroll
-                for (int s = 0; s < FMT; ++s)
+                for (int s = 0; s < NP; ++s)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
 #ifdef HIMO_EXP_NOA
@@ -176,7 +183,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #else
                         af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[buf][s][PL::slot((wp * MI + mi) * S * PW + li + tapoff, lh)]);
 #endif
-                const uint4 (&bcur)[FMT] = bq[kx];
+                const uint4 (&bcur)[NP] = bq[kx];
 #define HIMO_TERM(SA, SB)                                                                                          \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                \
         acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][SA], __builtin_bit_cast(bf16x8, bcur[SB]), acc[mi], 0, 0, 0);
@@ -186,6 +193,8 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
                                                         __builtin_bit_cast(f16x8, bcur[SB]), ACC[mi], 0, 0, 0);
                 if constexpr (FMT == 3) {
                     HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
+                } else if constexpr (FMT == 4) {
+                    HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
                 } else {
                     if constexpr (XACC) { HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1) }
                     else { HIMO_TERM16(acc, 1, 0) HIMO_TERM16(acc, 0, 1) HIMO_TERM16(acc, 0, 0) }
@@ -272,6 +281,10 @@ template <int PH, int FMT, int MI, int S>
 static void launch_sp_epi(const ConvArgs& a_in, int epi, const unsigned short* w, dim3 grid, hipStream_t s) {
     ConvArgs a = a_in;
     if (vec_store_ok(a) && (!(a.act_flags & kActSplitOut) || !(a.Cout & 15))) a.act_flags |= kActVecStore;
+    if constexpr (FMT == 4) {          // the data-gradient format: bias epilogue only (launch_conv3_split has checked)
+        hipLaunchKernelGGL((conv3_split_kernel<kEpiBias, PH, FMT, MI, S>), grid, dim3(256), 0, s, a, w);
+        return;
+    }
     switch (epi) {
         case kEpiBias: hipLaunchKernelGGL((conv3_split_kernel<kEpiBias, PH, FMT, MI, S>), grid, dim3(256), 0, s, a, w); break;
         case kEpiBiasBnGelu: hipLaunchKernelGGL((conv3_split_kernel<kEpiBiasBnGelu, PH, FMT, MI, S>), grid, dim3(256), 0, s, a, w); break;
@@ -296,6 +309,7 @@ static void launch_sp_mi(const ConvArgs& a, int epi, int mi, int stride, const u
 // rows_hint: 0 = heuristic, else image rows per wave (4 | 2 | 1; stride 2 always uses 2).
 bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, int format, int rows_hint, int stride, hipStream_t s) {
     if (epilogue == kEpiGruZR || epilogue == kEpiGruQ) return false;
+    if (format == 2 && (epilogue != kEpiBias || a.act_flags)) return false;        // two-term bf16: float32 maps, bias epilogue
     const bool wide = a.Cout > 64;                     // PH = 1: 128-channel tiles; PH = 2: 64-channel tiles
     const int bn = wide ? 128 : 64, ph = wide ? 1 : 2;
     auto blocks_for = [&](int mi) -> int64_t {
@@ -307,10 +321,11 @@ bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, i
     if (stride == 2) mi = (rows_hint == 1 || rows_hint == 2) ? rows_hint : (wide ? 2 : 1);
     const dim3 grid((unsigned)blocks_for(mi));
     const unsigned short* w = (const unsigned short*)w_packed;
-    const char* name = stride == 2 ? (format == 1 ? "conv3x3s2_f16x2_kernel" : "conv3x3s2_bf16x3_kernel")
-                                   : (format == 1 ? "conv3x3_f16x2_kernel" : "conv3x3_bf16x3_kernel");
+    const char* name = stride == 2 ? (format == 1 ? "conv3x3s2_f16x2_kernel" : format == 2 ? "conv3x3s2_bf16x2_kernel" : "conv3x3s2_bf16x3_kernel")
+                                   : (format == 1 ? "conv3x3_f16x2_kernel" : format == 2 ? "conv3x3_bf16x2_kernel" : "conv3x3_bf16x3_kernel");
     ProfScope ps(name, s);
-    if (format == 1) { if (wide) launch_sp_mi<1, 2>(a, epilogue, mi, stride, w, grid, s); else launch_sp_mi<2, 2>(a, epilogue, mi, stride, w, grid, s); }
+    if (format == 2) { if (wide) launch_sp_mi<1, 4>(a, epilogue, mi, stride, w, grid, s); else launch_sp_mi<2, 4>(a, epilogue, mi, stride, w, grid, s); }
+    else if (format == 1) { if (wide) launch_sp_mi<1, 2>(a, epilogue, mi, stride, w, grid, s); else launch_sp_mi<2, 2>(a, epilogue, mi, stride, w, grid, s); }
     else { if (wide) launch_sp_mi<1, 3>(a, epilogue, mi, stride, w, grid, s); else launch_sp_mi<2, 3>(a, epilogue, mi, stride, w, grid, s); }
     return true;
 }

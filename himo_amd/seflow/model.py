@@ -610,8 +610,8 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, strid
     d.cin, d.cout, d.ksize, d.stride, d.epilogue = cin, cout, k, stride, epilogue
     d.tile_hint = tile_hint
     d.act_layout = act_layout
-    if precision in ("bf16x3", "f16x2") and (stride == 1 or k == 3):
-        fmt = 1 if precision == "f16x2" else 0
+    if precision in ("bf16x3", "f16x2", "bf16x2") and (stride == 1 or k == 3):
+        fmt = {"bf16x3": 0, "f16x2": 1, "bf16x2": 2}[precision]       # bf16x2: 3x3 layers only (the training data gradients)
         pk = torch.empty(int(lib.himo_conv_packed_weight_bytes(k, cin, cout)), dtype=torch.uint8, device=x.device)
         _lib.check(lib.himo_conv_pack_weights_ex(weight.contiguous().data_ptr(), k, cin, cout, fmt, pk.data_ptr(), _lib.stream_handle()),
                    "himo_conv_pack_weights_ex")

@@ -286,6 +286,10 @@ class SeFlowTrainer:
         # mixed: the stride-1 3x3 weight gradients multiply split-bf16 operands (16 significant bits, float32 sums) on the
         # 16-bit matrix instructions (csrc/train.hip conv_wgrad_split_kernel); the other modes keep float32 matrix instructions
         self.wgrad_flags = 2 if precision == "mixed" else 0
+        # mixed: the 3x3 data-gradient convolutions run the two-term bf16 split (HIMO_PACK_BF16X2: 16 significant bits, float32
+        # range, three matrix products per block) instead of the three-term one (six)
+        self.bwd3_format = 2 if precision == "mixed" else 0
+        self._wp_fmt = 0
         self.lib = _lib.load()
         self.device = dev = device if device is not None else _lib.require_gpu()
         params = spec.init_params(seed) if params is None else params
@@ -391,6 +395,8 @@ class SeFlowTrainer:
 
     # ---- launch helpers (raw device addresses: most operands are channel groups of wider buffers) --------------
     def _conv(self, x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride=1, packed=None, fmt=0):
+        if packed is not None and self.precision != "f32" and packed == self.WFP.data_ptr():
+            fmt = self._wp_fmt                        # the scratch copy _flip just packed
         key = (x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride, packed, fmt)
         d = self._descs.get(key)                 # cached per call site: see HeadTrainer._gemm
         if d is None:
@@ -431,7 +437,8 @@ class SeFlowTrainer:
         _lib.check(self.lib.himo_weight_flip(self.p[f"{name}.weight"].data_ptr(), ks, cin, cout, self.WF.data_ptr(), _lib.stream_handle()), "flip")
         if self.precision == "f32":
             return self.WF.data_ptr(), None
-        _lib.check(self.lib.himo_conv_pack_weights(self.WF.data_ptr(), ks, cout, cin, self.WFP.data_ptr(), _lib.stream_handle()), "pack")
+        self._wp_fmt = self.bwd3_format if ks == 3 else 0
+        _lib.check(self.lib.himo_conv_pack_weights_ex(self.WF.data_ptr(), ks, cout, cin, self._wp_fmt, self.WFP.data_ptr(), _lib.stream_handle()), "pack")
         return self.WF.data_ptr(), self.WFP.data_ptr()
 
     def _add2d(self, rows, cols, b, b_pitch, y, y_pitch):

@@ -119,6 +119,25 @@ def test_split_bf16_weight_gradient_matches_autograd(gpu, h, w, cin, cout, n):
     assert err_f32 <= 1e-4 and err_split <= 1e-4, (err_f32, err_split)
 
 
+@pytest.mark.parametrize("stride,h,w,cin,cout,n", [(1, 24, 40, 64, 64, 2), (1, 16, 64, 128, 256, 1), (1, 64, 96, 256, 64, 1), (2, 32, 64, 64, 128, 2),
+                                                   (2, 16, 128, 128, 32, 1)])
+def test_two_term_bf16_convolution_for_the_data_gradients(gpu, stride, h, w, cin, cout, n):
+    """HIMO_PACK_BF16X2 (x = h + m in bf16, three matrix products per block): the arithmetic of the mixed-precision training
+    step's 3x3 data-gradient convolutions.  Inputs span eight decades (gradients do): relative to each output's own scale the
+    error stays at the 2^-16 of the operands, where the fp16 split would have flushed most of the input to zero."""
+    from himo_amd.seflow.model import conv2d_nhwc
+    rng = np.random.default_rng(h * 7 + cin)
+    x = (rng.normal(size=(n, h, w, cin)) * 10.0 ** rng.uniform(-8, 0, size=(n, h, w, 1))).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = np.zeros(cout, np.float32)
+    y = conv2d_nhwc(*(torch.from_numpy(a).to(gpu) for a in (x, wt, b)), stride=stride, precision="bf16x2").cpu().numpy()
+    tx, tw = torch.from_numpy(x).permute(0, 3, 1, 2).double(), torch.from_numpy(wt).permute(3, 2, 0, 1).double()
+    ref = F.conv2d(tx, tw, None, stride=stride, padding=1).permute(0, 2, 3, 1).numpy()
+    # scale of an output = sum of |x| |w| over its window (what the rounding errors are relative to)
+    mag = F.conv2d(tx.abs(), tw.abs(), None, stride=stride, padding=1).permute(0, 2, 3, 1).numpy()
+    assert (np.abs(y - ref) / mag).max() <= 2.0 ** -15
+
+
 def test_upsample2x_backward_is_the_adjoint(gpu):
     from himo_amd.seflow.train import upsample2x_backward_nhwc
     rng = np.random.default_rng(5)
