@@ -73,6 +73,10 @@ def parse_args():
     ap.add_argument("--force-process-group", action="store_true",
                     help="join a process group even at N = 1 (a one-rank RCCL communicator): lets a single-GPU box execute the "
                          "nccl branch -- init, barrier, max all-reduce, count all-gather -- that N > 1 runs use")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="test switch for boxes with fewer GPUs than ranks: rank r drives device r %% device_count and the collectives "
+                         "run over gloo (RCCL refuses two ranks on one device); the N > 1 code path with real device work, "
+                         "the rate itself is meaningless and the line says so")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="CPU test switch: host stand-in for the device work, gloo for RCCL; the reported numbers are meaningless")
     ap.add_argument("--traffic-json", default=str(REPO / "profiles" / "traffic_latest.json"))
@@ -255,6 +259,8 @@ def reduce_job(elapsed: float, frames_done: int, device, world: int, rank: int):
     exchange, the final gather to rank 0 (RCCL on GPUs; gloo in the CPU tests)."""
     import torch
     import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo":
+        device = torch.device("cpu")                    # gloo gathers host tensors (CPU tests, --share-gpu)
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
     done = torch.tensor([frames_done], device=device, dtype=torch.int64)
     if dist.is_available() and dist.is_initialized():
@@ -278,7 +284,7 @@ def self_launch(args) -> int:
     on.  Rank 0's JSON line goes to this process's stdout unchanged."""
     import socket
     import subprocess
-    if not args.dry_run_cpu:
+    if not args.dry_run_cpu and not args.share_gpu:
         import torch
         have = torch.cuda.device_count()
         if have < args.gpus:
@@ -331,6 +337,8 @@ def main() -> int:
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a HIP device; there is no CPU path to benchmark")
+        if args.share_gpu:
+            local_rank %= torch.cuda.device_count()
         if torch.cuda.device_count() <= local_rank:
             raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} HIP device(s) visible")
         torch.cuda.set_device(local_rank)
@@ -342,7 +350,7 @@ def main() -> int:
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver
-        if dry:
+        if dry or args.share_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)        # "nccl" IS RCCL on ROCm
@@ -350,6 +358,8 @@ def main() -> int:
         line = run_rank(args, rank, world, device, sync)
         if line is not None:
             line["config"]["collectives"] = (dist.get_backend() + f" x{dist.get_world_size()}") if grouped else "none (single process)"
+            if args.share_gpu:
+                line["config"]["shared_gpu"] = "TEST MODE: the ranks share HIP devices and exchange over gloo; `value` is not a scaling figure"
     finally:
         if grouped:
             dist.destroy_process_group()
@@ -503,11 +513,15 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     torch.set_num_threads(n_threads)
     prof = _lib.prof_stop() if _lib is not None else {}
     all_kernels = {}
-    if rank == 0 and _lib is not None:
-        _lib.prof_start()
+    if _lib is not None:
+        # one extra, untimed step with every kernel timed (rank 0's table).  EVERY rank runs it: the train workload's step
+        # contains the gradient all-reduce, and a collective only rank 0 entered would never complete
+        if rank == 0:
+            _lib.prof_start()
         step()
         sync()
-        all_kernels = _lib.prof_stop()
+        if rank == 0:
+            all_kernels = _lib.prof_stop()
 
     elapsed, total_frames, per_rank = reduce_job(elapsed, B * args.steps, device, world, rank)
     if rank != 0:

@@ -255,7 +255,14 @@ def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     training step is this single collective on the flat gradient buffer."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():          # also a one-rank group: the collective itself is exercised
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if flat.is_cuda and dist.get_backend() == "gloo":
+            # gloo (HIMO_DIST_BACKEND=gloo, bench.py --share-gpu: ranks sharing a device, where RCCL cannot be used) reduces host
+            # memory: stage through the host; RCCL reduces the device buffer in place
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         if dist.get_world_size() > 1:
             flat.div_(dist.get_world_size())
     return flat

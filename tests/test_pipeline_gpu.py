@@ -341,3 +341,27 @@ def test_cli_entry_points_on_a_one_rank_rccl_group(gpu, tmp_path, monkeypatch):
     single = ev.InstanceMetrics("av2")
     single.step_frames(frames, res_name="seflowpp_best")
     assert json.dumps(m.evaluate_data, default=float, sort_keys=True) == json.dumps(single.evaluate_data, default=float, sort_keys=True)
+
+
+@pytest.mark.parametrize("workload", ["pipeline", "train"])
+def test_bench_two_ranks_on_this_box(gpu, workload):
+    """`python bench.py --gpus 2 --share-gpu`: the driver's command line for N = 2 on a one-GPU box -- bench.py re-launches itself
+    as two ranks under torch.distributed.run, both do REAL device work (on the one device; collectives over gloo because RCCL
+    refuses two ranks per device), barrier, max-over-ranks time, per-rank frame counts gathered, one JSON line from rank 0.
+    Everything the 8-GPU run does except RCCL itself (which the one-rank `--force-process-group` tests exercise)."""
+    import json, os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--share-gpu", "--workload", workload, "--steps", "2", "--warmup", "1",
+           "--points", "20000", "--no-cpu-baseline", "--no-extra-precisions"] + (["--frames-per-step", "2"] if workload == "pipeline" else [])
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                     # rank 0 alone prints
+    line = json.loads(lines[0])
+    per_step = 2 if workload == "pipeline" else 1
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["collectives"] == "gloo x2"
+    assert line["config"]["frames_per_rank"] == [2 * per_step, 2 * per_step] and "shared_gpu" in line["config"]
+    assert line["value"] > 0 and np.isfinite(line["value"])
