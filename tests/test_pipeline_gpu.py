@@ -1,5 +1,6 @@
 """End-to-end per-frame pipeline on the GPU (network flow -> comp_dis) against the CPU restatements."""
 import numpy as np
+from pathlib import Path
 import pytest
 import torch
 
@@ -365,3 +366,65 @@ def test_bench_two_ranks_on_this_box(gpu, workload):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["collectives"] == "gloo x2"
     assert line["config"]["frames_per_rank"] == [2 * per_step, 2 * per_step] and "shared_gpu" in line["config"]
     assert line["value"] > 0 and np.isfinite(line["value"])
+
+
+def test_cli_programs_as_two_ranks_on_this_box(gpu, tmp_path):
+    """The reference's job shape (assets/slurm/ssl-train-av2.sh:3: one process per GPU under a launcher) for the four programs,
+    with REAL device work on the one-GPU box: `python -m torch.distributed.run --nproc-per-node 2 -m himo_amd.{save, save_zip,
+    eval, seflow.fit}` with HIMO_DIST_BACKEND=gloo (both ranks drive cuda:0; RCCL refuses two ranks per device).  The sharded
+    runs must leave exactly what the single-process programs leave."""
+    import json, os, pickle, socket, subprocess, sys
+    from zipfile import ZipFile
+    from himo_amd import eval as ev, save, save_zip
+    from himo_amd.dataset import NpzDataset
+    from himo_amd.synthetic import make_frame
+    repo = Path(__file__).resolve().parents[1]
+
+    def dataset(root):
+        frames = [make_frame(4100 + i, n_points=3_000 + 100 * (i % 3), scene_id=f"scene{i // 4}") for i in range(8)]
+        for i, f in enumerate(frames):
+            f["timestamp"] = 1000 + i
+            f.pop("seflowpp_best")
+        NpzDataset.write(root, frames)
+        with open(root / "index_eval.pkl", "wb") as fh:             # save_zip / eval walk the frames that have a successor
+            pickle.dump([[f["scene_id"], f["timestamp"]] for i, f in enumerate(frames) if i % 4 != 3], fh)
+
+    def torchrun(module, *args, cwd):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HIMO_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=str(repo))
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HIMO_DIST_FORCE"):
+            env.pop(k, None)
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port), "-m", module, *args], env=env, cwd=cwd, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (module, out.stderr[-3000:])
+        return out
+
+    two, one = tmp_path / "two" / "av2" / "demo", tmp_path / "one" / "av2" / "demo"
+    dataset(two); dataset(one)
+    # single-process programs
+    save.main(dataset_path=str(one), res_name="seflowpp_best")
+    save_zip.main(str(one), "seflowpp_best", batch_frames=4)
+    ref = ev.main(str(one), res_name="seflowpp_best", batch_frames=4, file_name=str(tmp_path / "one" / "res.json"))
+    # the same three as two ranks each
+    torchrun("himo_amd.save", "--dataset_path", str(two), "--res_name", "seflowpp_best", cwd=tmp_path / "two")
+    a, b = NpzDataset(one), NpzDataset(two)
+    assert len(a) == len(b)
+    for i in range(len(a)):
+        assert ("seflowpp_best" in a[i]) == ("seflowpp_best" in b[i])
+        if "seflowpp_best" in a[i]:
+            assert np.array_equal(a[i]["seflowpp_best"], b[i]["seflowpp_best"]), i      # frame i came from rank i % 2: same bits
+    torchrun("himo_amd.save_zip", "--data_dir", str(two), "--res_name", "seflowpp_best", "--batch_frames", "4", cwd=tmp_path / "two")
+    with ZipFile(one / "results" / "seflowpp_best-submit.zip") as z1, ZipFile(two / "results" / "seflowpp_best-submit.zip") as z2:
+        assert sorted(z1.namelist()) == sorted(z2.namelist()) and len(z1.namelist()) > 0
+        for n in z1.namelist():
+            assert z1.read(n) == z2.read(n), n
+    torchrun("himo_amd.eval", "--data_dir", str(two), "--res_name", "seflowpp_best", cwd=tmp_path / "two")
+    got = json.loads((tmp_path / "two" / "res-av2.json").read_text())
+    want = json.loads((tmp_path / "one" / "res.json").read_text())
+    assert ref.frame_cnt > 0 and got == want
+    # the training loop: 2 ranks x 1 sample per optimiser step, one epoch; rank 0 leaves the checkpoints
+    torchrun("himo_amd.seflow.fit", "--dataset_path", str(two), "--out_dir", str(tmp_path / "ckpt"), "--epochs", "1", "--batch_size", "2",
+             cwd=tmp_path / "two")
+    assert list((tmp_path / "ckpt").glob("*.npz"))
