@@ -356,3 +356,17 @@ def test_network_with_split_activations_gives_the_same_flow_bits(gpu, params):
     fb = b.forward(*args)
     assert torch.equal(fa, fb) and torch.equal(fa2, fb)
     assert torch.equal(a.DEC, b.DEC)
+
+
+def test_sustained_matrix_rate_diagnostic(gpu):
+    """himo_mfma_sustained_tflops (what bench.py prints next to the roofline fraction): register-resident matrix chains on every
+    SIMD.  The rate depends on the operand bits -- the clock is power-managed -- so all-zero operands must beat random ones,
+    and neither can exceed the nameplate; the float32 instruction is not power-limited and sits near its 157 TFLOP/s peak."""
+    from himo_amd import _lib
+    rnd = _lib.mfma_sustained_tflops("f16", False, 0.2)
+    zer = _lib.mfma_sustained_tflops("f16", True, 0.2)
+    f32 = _lib.mfma_sustained_tflops("f32", False, 0.2)
+    assert 800.0 < rnd < zer <= 2600.0, (rnd, zer)
+    assert 100.0 < f32 <= 165.0, f32
+    with pytest.raises(ValueError):
+        _lib.check(_lib.load().himo_mfma_sustained_tflops(7, 0, 0.1, None, None), "bad kind")
