@@ -90,7 +90,8 @@ def parse_args():
         a.warmup = 2 if a.warmup is None else a.warmup
         a.frames_per_step = 1 if a.frames_per_step is None else a.frames_per_step
     elif a.workload == "pipeline":
-        a.steps = 20 if a.steps is None else a.steps            # 320 frames: ~0.55 s timed, host hiccups average out
+        a.steps = 100 if a.steps is None else a.steps           # 1600 frames: ~2.4 s timed -- long enough for an outside observer's
+                                                                # utilisation samples to see the region; 20 steps give the same rate
         a.warmup = 3 if a.warmup is None else a.warmup
         # 16 samples per backbone launch (16 GB of activation buffers of the 288): +3 % over 8 -- the low-resolution
         # layers and the batched head get whole rounds of blocks; 24 / 32 add under 1 % more
