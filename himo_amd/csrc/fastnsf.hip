@@ -175,7 +175,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int ci = e / cout, co = e % cout;
         const int tile = (ci / 128) * ((cout + 127) / 128) + co / 128;
         const float* p = partial + (int64_t)tile * n_blocks * 128 * 128 + (ci % 128) * 128 + (co % 128);
-        for (int b = grp; b < n_blocks; b += 4) s += p[(int64_t)b * 128 * 128];
+        // four independent chains per thread (16 loads in flight per element over the four groups): the sum of ~500 partials
+        // as ONE chain costs a memory latency per term, not a byte rate
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = grp;
+        for (; b + 12 < n_blocks; b += 16) {
+            s0 += p[(int64_t)b * 128 * 128]; s1 += p[(int64_t)(b + 4) * 128 * 128];
+            s2 += p[(int64_t)(b + 8) * 128 * 128]; s3 += p[(int64_t)(b + 12) * 128 * 128];
+        }
+        for (; b < n_blocks; b += 4) s0 += p[(int64_t)b * 128 * 128];
+        s = (s0 + s1) + (s2 + s3);
     }
     sh[grp][o] = s;
     __syncthreads();
@@ -235,8 +244,16 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
     const int lc = threadIdx.x & 127, grp = threadIdx.x >> 7;
     const int col = (int)blockIdx.x * 128 + lc;
     float s = 0.f;
-    if (col < cout)
-        for (int b = grp; b < n_blocks; b += 8) s += partial[((int64_t)blockIdx.x * n_blocks + b) * 128 + lc];
+    if (col < cout) {
+        const float* p = partial + (int64_t)blockIdx.x * n_blocks * 128 + lc;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four chains per thread, fixed order (see wgrad_reduce_kernel)
+        int b = grp;
+        for (; b + 24 < n_blocks; b += 32) {
+            s0 += p[(int64_t)b * 128]; s1 += p[(int64_t)(b + 8) * 128]; s2 += p[(int64_t)(b + 16) * 128]; s3 += p[(int64_t)(b + 24) * 128];
+        }
+        for (; b < n_blocks; b += 8) s0 += p[(int64_t)b * 128];
+        s = (s0 + s1) + (s2 + s3);
+    }
     sh[grp][lc] = s;
     __syncthreads();
     if (grp == 0 && col < cout) {

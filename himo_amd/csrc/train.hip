@@ -517,22 +517,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(ConvWgradTiled
 
 __global__ __launch_bounds__(256) void conv_wgrad_tiled_reduce_kernel(const float* __restrict__ partial, int chunks, int cin, int cout,
                                                                       float* __restrict__ dW, int accumulate) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= 9ll * cin * cout) return;
-    const int co = (int)(e % cout);
-    const int ci = (int)((e / cout) % cin);
-    const int tap = (int)(e / ((int64_t)cout * cin));
-    const int tile = (ci / 64) * (cout / 64) + co / 64;
-    const float* p = partial + ((int64_t)tile * chunks) * 9 * 4096 + tap * 4096 + (ci % 64) * 64 + (co % 64);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four independent chains: more loads in flight, fixed order
-    int b = 0;
-    for (; b + 3 < chunks; b += 4) {
-        s0 += p[(int64_t)b * 9 * 4096]; s1 += p[(int64_t)(b + 1) * 9 * 4096];
-        s2 += p[(int64_t)(b + 2) * 9 * 4096]; s3 += p[(int64_t)(b + 3) * 9 * 4096];
+    // a block owns 64 consecutive elements; its four thread groups take every fourth chunk, four independent chains each
+    // (16 loads in flight per element: a sum of hundreds of partials as one chain costs a memory latency per term), combined in a
+    // fixed order -- deterministic
+    __shared__ float sh[4][64];
+    const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + o;
+    const bool ok = e < 9ll * cin * cout;
+    float s = 0.f;
+    if (ok) {
+        const int co = (int)(e % cout);
+        const int ci = (int)((e / cout) % cin);
+        const int tap = (int)(e / ((int64_t)cout * cin));
+        const int tile = (ci / 64) * (cout / 64) + co / 64;
+        const float* p = partial + ((int64_t)tile * chunks) * 9 * 4096 + tap * 4096 + (ci % 64) * 64 + (co % 64);
+        constexpr int64_t kStride = 9 * 4096;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = grp;
+        for (; b + 12 < chunks; b += 16) {
+            s0 += p[(int64_t)b * kStride]; s1 += p[(int64_t)(b + 4) * kStride];
+            s2 += p[(int64_t)(b + 8) * kStride]; s3 += p[(int64_t)(b + 12) * kStride];
+        }
+        for (; b < chunks; b += 4) s0 += p[(int64_t)b * kStride];
+        s = (s0 + s1) + (s2 + s3);
     }
-    for (; b < chunks; ++b) s0 += p[(int64_t)b * 9 * 4096];
-    const float s = (s0 + s1) + (s2 + s3);
-    dW[e] = accumulate ? dW[e] + s : s;
+    sh[grp][o] = s;
+    __syncthreads();
+    if (grp == 0 && ok) {
+        const float t = (sh[0][o] + sh[1][o]) + (sh[2][o] + sh[3][o]);
+        dW[e] = accumulate ? dW[e] + t : t;
+    }
 }
 
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int cin, int cout,
@@ -745,7 +759,7 @@ extern "C" int himo_conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_b
         else if (stride == 1) hipLaunchKernelGGL(conv_wgrad_tiled_kernel<1>, dim3(grid_x, tiles_xy), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(conv_wgrad_tiled_kernel<2>, dim3(grid_x, tiles_xy), dim3(256), 0, s, a);
     }
-    hipLaunchKernelGGL(conv_wgrad_tiled_reduce_kernel, dim3((unsigned)((9ll * cin * cout + 255) / 256)), dim3(256), 0, s, a.partial, grid_x,
+    hipLaunchKernelGGL(conv_wgrad_tiled_reduce_kernel, dim3((unsigned)((9ll * cin * cout + 63) / 64)), dim3(256), 0, s, a.partial, grid_x,
                        cin, cout, d_dw, (flags & 1u) ? 1 : 0);
     HIMO_LAUNCH_CHECK("conv_wgrad_tiled kernels");
     return HIMO_OK;
