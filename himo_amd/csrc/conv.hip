@@ -38,8 +38,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     constexpr int kPatchItems = PH * PW * (BK / 4);
     constexpr int kPatchPerThread = (kPatchItems + 255) / 256;
     constexpr int kWPerThread = BK * (BN / 4) / 256;
-    __shared__ float patchT[kPatchBufs][BK * PP];
-    __shared__ float wt[2][BK * BN];
+    // one raw block (patch planes, then weight slabs): the row-GEMM epilogue reuses its first 16 KB as the four waves' store
+    // staging areas (store_block_vec)
+    constexpr int kPatchFloats = kPatchBufs * BK * PP, kWFloats = 2 * BK * BN;
+    static_assert(kPatchFloats % 4 == 0, "weight slabs stay 16-byte aligned");
+    __shared__ __attribute__((aligned(16))) float smem[kPatchFloats + kWFloats < 4096 ? 4096 : kPatchFloats + kWFloats];
+    auto& patchT = *reinterpret_cast<float (*)[kPatchBufs][BK * PP]>(smem);
+    auto& wt = *reinterpret_cast<float (*)[2][BK * BN]>(smem + kPatchFloats);
 
     // ---- block -> (image, spatial tile, channel tile) ----
     const int n_tiles_n = (a.Cout + BN - 1) / BN;
@@ -209,6 +214,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     // ---- epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] ----
     float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
     const int64_t out_rows = (int64_t)a.Ho * a.Wo;
+    if constexpr (KS == 1 && EPI != kEpiGruZR && EPI != kEpiGruQ) {
+        // row GEMMs (the FastNSF MLP, 1x1 layers): an accumulator block's 32 rows are consecutive output rows, so it leaves as
+        // 16-byte stores through the wave's LDS staging area -- and the ReLU mask of the input-gradient GEMMs is read with the
+        // same 16-byte pattern instead of one 4-byte load per element (FastNSF fit: its row GEMMs 130 -> 94 ms per 100 iterations)
+        if (a.act_flags & kActVecStore) {
+            __syncthreads();                       // every wave is done with the patch / weight slabs
+            unsigned char* stg = reinterpret_cast<unsigned char*>(smem) + wave * 4096;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int ch0 = n0 + wn * WN + ni * 32;
+                const int co = ch0 + li < a.Cout ? ch0 + li : a.Cout - 1;
+                const float b = a.bias ? a.bias[co] : 0.f;
+                float sc = 1.f, sh = 0.f;
+                if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    unsigned word[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) word[r] = __builtin_bit_cast(unsigned, epilogue_value<EPI>(acc[mi][ni][r] + b, sc, sh));
+                    const int64_t pix0 = row0 + wm * (32 * MI) + mi * 32;
+                    const int64_t left = out_rows - pix0;
+                    store_block_vec<false, EPI == kEpiReluMask>(a, yout, stg, word, lane, pix0, left < 0 ? 0 : left > 32 ? 32 : (int)left, ch0);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int co = n0 + wn * WN + ni * 32 + li;
@@ -287,7 +319,12 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(UpArgs a) {
 }
 
 template <int KS, int S, int BN, int MI>
-static void launch_epi(const ConvArgs& a, int epi, dim3 grid, hipStream_t s) {
+static void launch_epi(const ConvArgs& a_in, int epi, dim3 grid, hipStream_t s) {
+    ConvArgs a = a_in;
+    // row GEMMs: 16-byte epilogue stores when the output (and, for the ReLU-mask epilogue, the mask source) admits them
+    if (KS == 1 && vec_store_ok(a) && !(a.Cout & 31) &&
+        (epi != kEpiReluMask || (!(reinterpret_cast<uintptr_t>(a.aux_in) & 15u) && !(a.aux_in_pitch & 3))))
+        a.act_flags |= kActVecStore;
     switch (epi) {
         case kEpiBias: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBias, MI>), grid, dim3(256), 0, s, a); break;
         case kEpiBiasBnGelu: hipLaunchKernelGGL((conv_mfma_kernel<KS, S, BN, kEpiBiasBnGelu, MI>), grid, dim3(256), 0, s, a); break;

@@ -144,7 +144,9 @@ inline bool vec_store_ok(const ConvArgs& a) {
 // the two half-waves write pixels 4 apart (512 bytes: the same banks) in the same instruction, the swap moves one of them
 // 128 bytes on.  DS operations of a wave execute in order, so no barrier is needed between its writes and reads.
 // word = this lane's 32-bit output for pixel r (float bits, or the paired split word of split_word()).
-template <bool OSPLIT>
+// MASK (float32 outputs only): the kEpiReluMask epilogue -- an output is kept where aux_in (same pixel, same channel) is positive,
+// read with the same 16-byte pattern as the store.
+template <bool OSPLIT, bool MASK = false>
 __device__ inline void store_block_vec(const ConvArgs& a, float* __restrict__ yout, unsigned char* stg, const unsigned (&word)[16],
                                        int lane, int64_t pix0, int n_valid_px, int ch0) {
     const int li = lane & 31, lh = lane >> 5;
@@ -161,9 +163,13 @@ __device__ inline void store_block_vec(const ConvArgs& a, float* __restrict__ yo
         const int q = t * 64 + lane;
         const int slot = q >> 3, piece = q & 7;
         const int px = slot ^ ((slot >> 2) & 1);
-        const uint4 d = *reinterpret_cast<const uint4*>(stg + q * 16);
+        uint4 d = *reinterpret_cast<const uint4*>(stg + q * 16);
         const int ch = ch0 + (OSPLIT ? (piece >> 2) * 16 : piece * 4);
         if (px < n_valid_px && ch < a.Cout) {
+            if (MASK) {
+                const float4 m = *reinterpret_cast<const float4*>(a.aux_in + (pix0 + px) * (int64_t)a.aux_in_pitch + ch0 + piece * 4);
+                d.x = m.x > 0.f ? d.x : 0u; d.y = m.y > 0.f ? d.y : 0u; d.z = m.z > 0.f ? d.z : 0u; d.w = m.w > 0.f ? d.w : 0u;
+            }
 #ifdef HIMO_EXP_STORE_SCRATCH          // experiment: same store instructions, but into a 2 MB window (stays in L2: no HBM write traffic)
             float* dst = a.y + ((((pix0 + px) * (int64_t)a.y_pitch + ch0 + piece * 4) & 0x7ffff) + (blockIdx.x & 7) * 0) ;
 #else
