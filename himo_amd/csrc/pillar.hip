@@ -50,10 +50,10 @@ struct PillarArgs {
     int* cell_count;          // [H*W] -> block-local exclusive offsets after the scan
     int* block_sum;           // [H*W/1024 + 1] exclusive offsets of the 1024-cell blocks
     int* cell_cursor;         // [H*W]
-    int* order;               // [n] point indices grouped by cell (scatter order)
     int* order2;              // [n] ascending order for cells too crowded for the LDS stage
-    float* cell_xyz;          // [n][3] transformed points in cell-list (scatter) order: the feature kernel reads a cell's
-                              //        indices AND coordinates as two contiguous runs instead of index -> point chains
+    float4* cell_rec;         // [n] (x, y, z, point index as bits) of the transformed points grouped by cell (scatter order): ONE
+                              //        16-byte scattered store per point in the fill kernel (four 4-byte ones cost 8.5x their bytes
+                              //        in HBM sector writes), one 16-byte load per point in the feature kernel
     unsigned long long* occ;  // incremental images (or NULL): bit c of word w = cell 64 w + c was non-empty the LAST time this
                               //        workspace's image was written -- an empty cell that was empty then is already zero
 };
@@ -160,8 +160,7 @@ __global__ __launch_bounds__(256) void pillar_fill_kernel(PillarBatch m) {
     if (cell < 0) return;
     const int slot = atomicAdd(&a.cell_cursor[cell], 1);
     const int at = cell_offset(a, cell) + slot;
-    a.order[at] = (int)i;
-    a.cell_xyz[(int64_t)at * 3] = a.xyz_t[i * 3]; a.cell_xyz[(int64_t)at * 3 + 1] = a.xyz_t[i * 3 + 1]; a.cell_xyz[(int64_t)at * 3 + 2] = a.xyz_t[i * 3 + 2];
+    a.cell_rec[at] = make_float4(a.xyz_t[i * 3], a.xyz_t[i * 3 + 1], a.xyz_t[i * 3 + 2], __int_as_float((int)i));
 }
 
 constexpr int kCellsPerBlock = 8;     // 8 cells x 32 lanes = 256 threads
@@ -223,9 +222,9 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarBatch m) {
         if (cnt == 1) {
             // a single point (the common case on sparse sweeps): no ordering, the mean IS the point, so the three
             // offset-to-mean features are exactly zero and their products drop out of the sum (fma(0, w, v) == v)
-            const int pj = a.order[beg];
-            const float* p = a.cell_xyz + (int64_t)beg * 3;
-            const float x = p[0], y = p[1], z = p[2];
+            const float4 rc = a.cell_rec[beg];
+            const int pj = __float_as_int(rc.w);
+            const float x = rc.x, y = rc.y, z = rc.z;
             if (c == 0) a.order2[beg] = pj;
             const float f6[3] = {x - ccx, y - ccy, z - ccz};
             float v = x * w[0];
@@ -238,9 +237,9 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarBatch m) {
         } else if (cnt <= 32) {
             // lane j holds point j of the cell's (scatter-ordered) list; rank by point index, permute into ascending order
             const bool have = c < cnt;
-            const int idx = have ? a.order[beg + c] : 0x7fffffff;
-            const float* p = a.cell_xyz + (int64_t)(beg + (have ? c : 0)) * 3;
-            const float ux = p[0], uy = p[1], uz = p[2];
+            const float4 rc = a.cell_rec[beg + (have ? c : 0)];
+            const int idx = have ? __float_as_int(rc.w) : 0x7fffffff;
+            const float ux = rc.x, uy = rc.y, uz = rc.z;
             int rank = 0;
             for (int j = 0; j < cnt; ++j) rank += shfl32(idx, j) < idx;
             int src = 0;
@@ -268,10 +267,10 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarBatch m) {
             // through order2 in global memory
             for (int j0 = 0; j0 < cnt; j0 += 32) {
                 const bool have = j0 + c < cnt;
-                const int idx = have ? a.order[beg + j0 + c] : 0x7fffffff;
+                const int idx = have ? __float_as_int(a.cell_rec[beg + j0 + c].w) : 0x7fffffff;
                 int rank = 0;
                 for (int k0 = 0; k0 < cnt; k0 += 32) {
-                    const int other = k0 + c < cnt ? a.order[beg + k0 + c] : 0x7fffffff;
+                    const int other = k0 + c < cnt ? __float_as_int(a.cell_rec[beg + k0 + c].w) : 0x7fffffff;
                     const int lim = min(32, cnt - k0);
                     for (int j = 0; j < lim; ++j) rank += shfl32(other, j) < idx;
                 }
@@ -479,9 +478,8 @@ static int pillar_args(PillarArgs& a, int64_t n, const float* d_pts, int pc_stri
     a.cell_count = reinterpret_cast<int*>(ws);
     a.cell_cursor = reinterpret_cast<int*>(ws + ws_cells(cells));
     a.block_sum = reinterpret_cast<int*>(ws + 2 * ws_cells(cells));
-    a.order = reinterpret_cast<int*>(ws + 2 * ws_cells(cells) + ws_blocks(cells));
-    a.order2 = a.order + ws_points(n) / 4;
-    a.cell_xyz = reinterpret_cast<float*>(a.order2 + ws_points(n) / 4);
+    a.cell_rec = reinterpret_cast<float4*>(ws + 2 * ws_cells(cells) + ws_blocks(cells));
+    a.order2 = reinterpret_cast<int*>(ws + 2 * ws_cells(cells) + ws_blocks(cells) + 4 * ws_points(n));
     return HIMO_OK;
 }
 
@@ -578,7 +576,7 @@ static void carve_bwd(PillarBwdArgs& a, int64_t n, int cells, void* d_workspace)
     char* ws = reinterpret_cast<char*>(d_workspace);
     a.cell_count = reinterpret_cast<const int*>(ws);
     a.block_sum = reinterpret_cast<const int*>(ws + 2 * ws_cells(cells));
-    a.order2 = reinterpret_cast<const int*>(ws + 2 * ws_cells(cells) + ws_blocks(cells)) + ws_points(n) / 4;
+    a.order2 = reinterpret_cast<const int*>(ws + 2 * ws_cells(cells) + ws_blocks(cells) + 4 * ws_points(n));
 }
 
 constexpr int kPfnBwdBlocks = 1024;
