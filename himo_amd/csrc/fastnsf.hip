@@ -162,6 +162,113 @@ __global__ __launch_bounds__(256, 2) void wgrad_partial_lds_kernel(int64_t n, co
                 out[(wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wn * 64 + b * 32 + li] = acc[a][b][r];
 }
 
+// The same partial tiles with SPLIT-bf16 operands (himo_linear_wgrad_ex flag 2; the mixed-precision training step): x = h + m
+// in bf16 (16 significant bits, float32 range), products h*h + h*m + m*h on v_mfma_f32_32x32x16_bf16 -- 3 instructions per 16
+// rows where the float32 kernel issues 8 -- which leaves the kernel bound by its operand stream.  The reduction index is the
+// ROW, so both operands are staged transposed ([plane][column][row], 8 rows = one 16-byte fragment; rows padded to 40 = 80
+// bytes so that consecutive columns sit 20 banks apart: conflict-free 16-byte stores and fragment reads), 32 rows per stage,
+// the next stage's 32 coalesced 4-byte loads per lane in flight during the current stage's matrix instructions.  Needs
+// cin, cout multiples of 4 and 16-byte aligned rows like the float32 LDS kernel; same partial layout and reduction.
+constexpr int kWsRowsPad = 40;
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline void wg_split_pair(float a, float b, unsigned& hw, unsigned& mw) {
+    typedef float wg_f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 wg_b2 __attribute__((ext_vector_type(2)));
+    wg_f2 v; v[0] = a; v[1] = b;
+    hw = __builtin_bit_cast(unsigned, __builtin_convertvector(v, wg_b2));
+    wg_f2 r;
+    r[0] = a - __builtin_bit_cast(float, hw << 16);
+    r[1] = b - __builtin_bit_cast(float, hw & 0xffff0000u);
+    mw = __builtin_bit_cast(unsigned, __builtin_convertvector(r, wg_b2));
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_partial_split_kernel(int64_t n, const float* __restrict__ X, int x_pitch, int cin,
+                                                                     const float* __restrict__ dZ, int z_pitch, int cout,
+                                                                     float* __restrict__ partial, int rows_pb) {
+    __shared__ __attribute__((aligned(16))) unsigned short Xt[2][128][kWsRowsPad];
+    __shared__ __attribute__((aligned(16))) unsigned short Zt[2][128][kWsRowsPad];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int co_tiles = (cout + 127) / 128;
+    const int ci0 = ((int)blockIdx.y / co_tiles) * 128, co0 = ((int)blockIdx.y % co_tiles) * 128;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_pb;
+    const int64_t r1 = r0 + rows_pb < n ? r0 + rows_pb : n;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // staging: this thread's column of the tile, its two 8-row chunks of the 32-row stage (chunk = sg + 2 it)
+    const int sc = threadIdx.x & 127, sg = threadIdx.x >> 7;
+    const bool x_ok = ci0 + sc < cin, z_ok = co0 + sc < cout;
+    float vx[2][8], vz[2][8];
+    auto fetch = [&](int64_t base) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t row = base + (sg + 2 * it) * 8 + j;
+                const bool ok = row < r1;
+                vx[it][j] = (ok && x_ok) ? X[row * x_pitch + ci0 + sc] : 0.f;
+                vz[it][j] = (ok && z_ok) ? dZ[row * z_pitch + co0 + sc] : 0.f;
+            }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int ch = sg + 2 * it;
+            uint4 h, m;
+            wg_split_pair(vx[it][0], vx[it][1], h.x, m.x); wg_split_pair(vx[it][2], vx[it][3], h.y, m.y);
+            wg_split_pair(vx[it][4], vx[it][5], h.z, m.z); wg_split_pair(vx[it][6], vx[it][7], h.w, m.w);
+            *reinterpret_cast<uint4*>(&Xt[0][sc][ch * 8]) = h;
+            *reinterpret_cast<uint4*>(&Xt[1][sc][ch * 8]) = m;
+            wg_split_pair(vz[it][0], vz[it][1], h.x, m.x); wg_split_pair(vz[it][2], vz[it][3], h.y, m.y);
+            wg_split_pair(vz[it][4], vz[it][5], h.z, m.z); wg_split_pair(vz[it][6], vz[it][7], h.w, m.w);
+            *reinterpret_cast<uint4*>(&Zt[0][sc][ch * 8]) = h;
+            *reinterpret_cast<uint4*>(&Zt[1][sc][ch * 8]) = m;
+        }
+    };
+    if (r0 < r1) fetch(r0);
+    for (int64_t base = r0; base < r1; base += 32) {
+        __syncthreads();                                   // the previous stage's fragment reads are done
+        stage();
+        __syncthreads();
+        if (base + 32 < r1) fetch(base + 32);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            wg_bf16x8 af[2][2], bf[2][2];                  // [tile][plane]
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    af[t][pl] = *reinterpret_cast<const wg_bf16x8*>(&Xt[pl][wm * 64 + t * 32 + li][ks * 16 + lh * 8]);
+                    bf[t][pl] = *reinterpret_cast<const wg_bf16x8*>(&Zt[pl][wn * 64 + t * 32 + li][ks * 16 + lh * 8]);
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], acc[a][b], 0, 0, 0);
+                }
+        }
+    }
+    float* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 * 128;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wn * 64 + b * 32 + li] = acc[a][b][r];
+}
+
 // dW[ci][co] (+)= sum_b partial[tile][b][ci % 128][co % 128], deterministic: a block owns 64 consecutive elements, its
 // four thread groups sum every fourth chunk (four loads in flight per element instead of one serial chain), and the
 // groups are combined in a fixed order
@@ -400,7 +507,7 @@ static size_t wgrad_ws(int64_t n_rows, int cin, int cout) {
 extern "C" size_t himo_wgrad_workspace_bytes(int64_t n_rows) { return wgrad_ws(n_rows, 128, 128); }
 extern "C" size_t himo_wgrad_workspace_bytes_ex(int64_t n_rows, int cin, int cout) { return wgrad_ws(n_rows, cin, cout); }
 
-// flags bit 0: accumulate into dW / db instead of overwriting
+// flags bit 0: accumulate into dW / db instead of overwriting; bit 1 (2): split-bf16 operands (wgrad_partial_split_kernel)
 extern "C" int himo_linear_wgrad_ex(int64_t n, const float* d_x, int x_pitch, int cin, const float* d_dz, int z_pitch, int cout,
                                     float* d_dw, float* d_db, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (n < 1 || cin < 1 || cout < 1 || !d_x || !d_dz || !d_dw || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
@@ -418,7 +525,10 @@ extern "C" int himo_linear_wgrad_ex(int64_t n, const float* d_x, int x_pitch, in
         ProfScope ps("wgrad_partial_kernel", s);
         const bool vec = !(x_pitch & 3) && !(z_pitch & 3) && !(cin & 3) && !(cout & 3) &&
                          !((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_dz)) & 15);
-        if (vec)
+        if (flags & 2u)
+            hipLaunchKernelGGL(wgrad_partial_split_kernel, dim3(nb, ci_tiles * co_tiles), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch,
+                               cout, partial, rows_pb);
+        else if (vec)
             hipLaunchKernelGGL(wgrad_partial_lds_kernel, dim3(nb, ci_tiles * co_tiles), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch,
                                cout, partial, rows_pb);
         else

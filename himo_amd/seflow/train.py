@@ -113,6 +113,7 @@ class HeadTrainer:
         if precision not in ("f32", "bf16x3", "mixed"):
             raise ValueError(precision)
         self.fmt_fwd = {"f32": None, "bf16x3": 0, "mixed": 1}[precision]
+        self.wgrad_flags = 2 if precision == "mixed" else 0           # split-bf16 operands in the weight-gradient GEMMs (csrc/fastnsf.hip)
         self.fmt_bwd = None if precision == "f32" else 0
         self.lib = _lib.load()
         self.device = device if device is not None else _lib.require_gpu()
@@ -196,7 +197,7 @@ class HeadTrainer:
     def _wgrad(self, x, cin, dz, cout, name, accumulate=False):
         _lib.check(self.lib.himo_linear_wgrad_ex(x.shape[0], x.data_ptr(), x.shape[1], cin, dz.data_ptr(), dz.shape[1], cout,
                                                  self.g[f"{name}.weight"].data_ptr(), self.g[f"{name}.bias"].data_ptr(),
-                                                 1 if accumulate else 0, self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle()), "wgrad")
+                                                 (1 if accumulate else 0) | self.wgrad_flags, self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle()), "wgrad")
 
     def _transposed(self, name):
         w = self.p[f"{name}.weight"]
@@ -436,7 +437,7 @@ class SeFlowTrainer:
 
     def _wgrad1(self, rows, x, x_pitch, cin, dz, z_pitch, cout, name):
         _lib.check(self.lib.himo_linear_wgrad_ex(rows, x, x_pitch, cin, dz, z_pitch, cout, self.g[f"{name}.weight"].data_ptr(),
-                                                 self.g[f"{name}.bias"].data_ptr(), 0, self.ws.data_ptr(), self.ws.numel(),
+                                                 self.g[f"{name}.bias"].data_ptr(), self.wgrad_flags, self.ws.data_ptr(), self.ws.numel(),
                                                  _lib.stream_handle()), "linear_wgrad")
 
     def _flip(self, name, ks, cin, cout):

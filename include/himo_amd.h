@@ -401,7 +401,8 @@ int himo_ssl_loss(int n0, int n1, const float* d_pc0, const float* d_pc1, const 
 size_t himo_wgrad_workspace_bytes(int64_t n_rows);
 int himo_linear_wgrad(int64_t n, const float* d_x, int x_pitch, int cin, const float* d_dz, int z_pitch, int cout,
                       float* d_dw, float* d_db, void* d_workspace, size_t workspace_bytes, void* stream);
-/* the same for any cin / cout (tiled 128 x 128); flags bit 0: accumulate into d_dw / d_db (BPTT over GRU iterations) */
+/* the same for any cin / cout (tiled 128 x 128); flags bit 0: accumulate into d_dw / d_db (BPTT over GRU iterations); bit 1 (2):
+ * multiply split-bf16 operands (x = h + m, 16 significant bits, float32 sums) on the 16-bit matrix instructions */
 size_t himo_wgrad_workspace_bytes_ex(int64_t n_rows, int cin, int cout);
 int himo_linear_wgrad_ex(int64_t n, const float* d_x, int x_pitch, int cin, const float* d_dz, int z_pitch, int cout,
                          float* d_dw, float* d_db, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);

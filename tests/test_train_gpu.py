@@ -138,6 +138,29 @@ def test_two_term_bf16_convolution_for_the_data_gradients(gpu, stride, h, w, cin
     assert (np.abs(y - ref) / mag).max() <= 2.0 ** -15
 
 
+@pytest.mark.parametrize("n,cin,cout", [(5000, 128, 128), (70_001, 192, 256), (33_333, 384, 64), (4096, 3, 64)])
+def test_split_bf16_linear_weight_gradient(gpu, n, cin, cout):
+    """himo_linear_wgrad_ex with flag 2 (split-bf16 operands, the mixed training default for the 1x1 layers and the head):
+    dW = X^T dZ and the column sums against float64, with the columns of dZ spanning six decades and an accumulate pass."""
+    from himo_amd import _lib
+    import himo_amd.seflow.train  # noqa: F401  (registers the entry points)
+    lib = _lib.load()
+    rng = np.random.default_rng(n)
+    x = torch.from_numpy((rng.normal(size=(n, cin)) * rng.uniform(0.1, 3.0, size=(1, cin))).astype(np.float32)).to(gpu)
+    dz = torch.from_numpy((rng.normal(size=(n, cout)) * 10.0 ** rng.uniform(-6, 0, size=(1, cout))).astype(np.float32)).to(gpu)
+    dw = torch.zeros((cin, cout), dtype=torch.float32, device=gpu)
+    db = torch.zeros(cout, dtype=torch.float32, device=gpu)
+    ws = torch.empty(int(lib.himo_wgrad_workspace_bytes_ex(n, cin, cout)), dtype=torch.uint8, device=gpu)
+    for flag in (2, 3):                                                      # overwrite, then accumulate on top
+        _lib.check(lib.himo_linear_wgrad_ex(n, x.data_ptr(), cin, cin, dz.data_ptr(), cout, cout, dw.data_ptr(), db.data_ptr(), flag,
+                                            ws.data_ptr(), ws.numel(), _lib.stream_handle()))
+    ref = (x.double().T @ dz.double()).cpu().numpy() * 2
+    scale = np.abs(ref).max(axis=0)
+    assert (np.abs(dw.cpu().numpy() - ref) / scale).max() <= 1e-4
+    ref_b = dz.double().sum(0).cpu().numpy() * 2
+    assert np.abs(db.cpu().numpy() - ref_b).max() <= 1e-4 * np.abs(ref_b).max() + 1e-3 * np.abs(dz.cpu().numpy()).max() * n ** 0.5 * 1e-3
+
+
 def test_upsample2x_backward_is_the_adjoint(gpu):
     from himo_amd.seflow.train import upsample2x_backward_nhwc
     rng = np.random.default_rng(5)
