@@ -59,6 +59,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
+// FMT = 4: the two-term bf16 split (planes h, m; products h*h + h*m + m*h): float32 range at 16 significant bits -- the data-gradient
+// GEMMs of the mixed-precision training step (himo_conv_pack_weights_ex format 2; see convsp.hip).  NP = planes of the format.
 template <int KS, int BN, int EPI, int MI, int FMT>
 __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int TW = 32, TH = 2 * MI, BM = 64 * MI;
@@ -72,12 +74,13 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
     // taps whose weights are staged together (one barrier per group): the whole kernel row for the fp16 split, whose
     // two planes leave the LDS room; one tap for the three-plane bf16 split
     constexpr int G = (KS == 3 && FMT == 2) ? 3 : 1;
-    constexpr int kWItemsTap = FMT * BN * 2;                    // 16-byte half rows of one tap
+    constexpr int NP = FMT == 3 ? 3 : 2;
+    constexpr int kWItemsTap = NP * BN * 2;                     // 16-byte half rows of one tap
     constexpr int kWItems = G * kWItemsTap;
     constexpr int kWPerThread = (kWItems + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char patch[FMT][NPIX * kRowBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char patch[NP][NPIX * kRowBytes];
     constexpr int WB = G == 1 ? 2 : 1;      // a staged kernel row is single-buffered (the register prefetch hides the loads)
-    __shared__ __attribute__((aligned(16))) unsigned char wts[WB][G][FMT][BN * kRowBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char wts[WB][G][NP][BN * kRowBytes];
 
     const int n_tiles_n = (a.Cout + BN - 1) / BN;
     int bid = xcd_block_id(blockIdx.x, gridDim.x);
@@ -155,12 +158,16 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
                     split3(r[it].x, h[0], m[0], l[0]); split3(r[it].y, h[1], m[1], l[1]);
                     split3(r[it].z, h[2], m[2], l[2]); split3(r[it].w, h[3], m[3], l[3]);
                     *reinterpret_cast<uint2*>(&patch[1][off]) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+                } else if (FMT == 4) {
+                    const float xv[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { h[e] = bf16_rne_bits(xv[e]); l[e] = bf16_rne_bits(xv[e] - bf16_bits_to_float(h[e])); }
                 } else {
                     split2(r[it].x, h[0], l[0]); split2(r[it].y, h[1], l[1]);
                     split2(r[it].z, h[2], l[2]); split2(r[it].w, h[3], l[3]);
                 }
                 *reinterpret_cast<uint2*>(&patch[0][off]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                *reinterpret_cast<uint2*>(&patch[FMT - 1][off]) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                *reinterpret_cast<uint2*>(&patch[NP - 1][off]) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
             }
         }
     };
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
                 const int t = item / kWItemsTap, rest = item % kWItemsTap;
                 const int s = rest / (BN * 2), rem = rest % (BN * 2);
                 const int co = n0 + (rem >> 1), half = rem & 1;
-                const unsigned short* base = wpk + (((int64_t)(tap0 + t) * slabs + slab) * FMT) * a.Cout * 16;
+                const unsigned short* base = wpk + (((int64_t)(tap0 + t) * slabs + slab) * NP) * a.Cout * 16;
                 if (co < a.Cout) v = *reinterpret_cast<const uint4*>(base + ((int64_t)s * a.Cout + co) * 16 + half * 8);
             }
             r[it] = v;
@@ -215,9 +222,9 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
             for (int t = 0; t < G; ++t) {
                 const int tap = tap0 + t;
                 const int tapoff = KS == 1 ? 0 : (tap / KS) * PW + (tap % KS);
-                bf16x8 af[MI][FMT], bf[NI][FMT];
+                bf16x8 af[MI][NP], bf[NI][NP];
 #pragma unroll
-                for (int s = 0; s < FMT; ++s) {
+                for (int s = 0; s < NP; ++s) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
                         af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[s][(ppA[mi] + tapoff) * kRowBytes + lh * 16]);
@@ -235,6 +242,8 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
                                                             __builtin_bit_cast(f16x8, bf[ni][SB]), ACC[mi][ni], 0, 0, 0);
                 if constexpr (FMT == 3) {
                     HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
+                } else if constexpr (FMT == 4) {
+                    HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
                 } else {
                     if constexpr (XACC) { HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1) }
                     else { HIMO_TERM16(acc, 1, 0) HIMO_TERM16(acc, 0, 1) HIMO_TERM16(acc, 0, 0) }
@@ -292,6 +301,10 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
 
 template <int KS, int BN, int MI, int FMT>
 static void launch_bf_epi(const ConvArgs& a, int epi, const unsigned short* w, dim3 grid, hipStream_t s) {
+    if constexpr (FMT == 4) {              // the data-gradient format: plain bias epilogue only (launch_conv_bf16x3 has checked)
+        hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBias, MI, FMT>), grid, dim3(256), 0, s, a, w);
+        return;
+    }
     switch (epi) {
         case kEpiBias: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBias, MI, FMT>), grid, dim3(256), 0, s, a, w); break;
         case kEpiBiasBnGelu: hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBiasBnGelu, MI, FMT>), grid, dim3(256), 0, s, a, w); break;
@@ -333,7 +346,8 @@ int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w
         HIMO_LAUNCH_CHECK("conv3_split_kernel");
         return HIMO_OK;
     }
-    if (stride != 1 || format == 2) return HIMO_ERR_UNSUPPORTED;       // (format 2 lives in convsp.hip only)
+    if (stride != 1) return HIMO_ERR_UNSUPPORTED;
+    if (format == 2 && (ksize != 1 || epilogue != kEpiBias || a.act_flags)) return HIMO_ERR_UNSUPPORTED;     // two-term bf16: 3x3 in convsp.hip, row GEMMs here
     auto blocks_for = [&](int bn, int mi) -> int64_t {
         const int bm = 64 * mi, th = 2 * mi;
         const int64_t tm = ksize == 1 ? (int64_t)a.N * (((int64_t)a.Ho * a.Wo + bm - 1) / bm)
@@ -351,11 +365,16 @@ int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w
     }
     const dim3 grid((unsigned)blocks_for(bn, mi));
     const bool f16 = format == 1;
-    const char* name = ksize == 1 ? (f16 ? "conv1x1_f16x2_kernel" : "conv1x1_bf16x3_kernel") : (f16 ? "conv3x3_f16x2_kernel" : "conv3x3_bf16x3_kernel");
+    const char* name = ksize == 1 ? (f16 ? "conv1x1_f16x2_kernel" : format == 2 ? "conv1x1_bf16x2_kernel" : "conv1x1_bf16x3_kernel")
+                                  : (f16 ? "conv3x3_f16x2_kernel" : "conv3x3_bf16x3_kernel");
     {
         ProfScope ps(name, s);
         const unsigned short* w = (const unsigned short*)w_packed;
-        if (ksize == 1) { if (f16) launch_bf_tile<1, 2>(a, epilogue, bn, mi, w, grid, s); else launch_bf_tile<1, 3>(a, epilogue, bn, mi, w, grid, s); }
+        if (ksize == 1) {
+            if (f16) launch_bf_tile<1, 2>(a, epilogue, bn, mi, w, grid, s);
+            else if (format == 2) launch_bf_tile<1, 4>(a, epilogue, bn, mi, w, grid, s);
+            else launch_bf_tile<1, 3>(a, epilogue, bn, mi, w, grid, s);
+        }
         else { if (f16) launch_bf_tile<3, 2>(a, epilogue, bn, mi, w, grid, s); else launch_bf_tile<3, 3>(a, epilogue, bn, mi, w, grid, s); }
     }
     HIMO_LAUNCH_CHECK("conv_bf16x3_kernel");
@@ -372,7 +391,6 @@ extern "C" size_t himo_conv_packed_weight_bytes(int ksize, int cin, int cout) {
 
 extern "C" int himo_conv_pack_weights_ex(const float* d_w, int ksize, int cin, int cout, int format, void* d_packed, void* stream) {
     if (!d_w || !d_packed || cin < 1 || cout < 1 || !(ksize == 1 || ksize == 3) || format < 0 || format > 2) return HIMO_ERR_INVALID_ARGUMENT;
-    if (format == 2 && ksize != 3) return HIMO_ERR_UNSUPPORTED;          // the two-term bf16 split exists for 3x3 layers only
     const int T = ksize * ksize;
     const int64_t total = (int64_t)T * ((cin + 15) / 16) * cout * 16;
     const dim3 grid((unsigned)((total + 255) / 256));

@@ -114,7 +114,7 @@ class HeadTrainer:
             raise ValueError(precision)
         self.fmt_fwd = {"f32": None, "bf16x3": 0, "mixed": 1}[precision]
         self.wgrad_flags = 2 if precision == "mixed" else 0           # split-bf16 operands in the weight-gradient GEMMs (csrc/fastnsf.hip)
-        self.fmt_bwd = None if precision == "f32" else 0
+        self.fmt_bwd = {"f32": None, "bf16x3": 0, "mixed": 2}[precision]      # mixed: two-term bf16 split (HIMO_PACK_BF16X2) for dX = dZ W^T
         self.lib = _lib.load()
         self.device = device if device is not None else _lib.require_gpu()
         dev = self.device
@@ -219,7 +219,7 @@ class HeadTrainer:
         _lib.check(lib.himo_affine_gelu_bwd(n, 32, self.DY1.data_ptr(), 32, self.PRE1.data_ptr(), 32, None, self.DY1.data_ptr(), 32, s()), "gelu_bwd")
         self._wgrad(self.HX[-1], 192, self.DY1, 32, "dec1")
         w1_t, w1_p = self._transposed_packed("dec1")
-        self._gemm(self.DY1, w1_t, None, self.DHX, 32, 192, packed=w1_p)
+        self._gemm(self.DY1, w1_t, None, self.DHX, 32, 192, packed=w1_p, fmt=self.fmt_bwd or 0)
         # split d[h | x] of the last state
         self.DH.copy_(self.DHX[:, :128])
         self.DX.copy_(self.DHX[:, 128:])
@@ -229,11 +229,11 @@ class HeadTrainer:
             _lib.check(lib.himo_gru_bwd1(n, self.DH.data_ptr(), self.Z[t].data_ptr(), self.Q[t].data_ptr(), self.HX[t].data_ptr(),
                                          self.DAQ.data_ptr(), self.DZ.data_ptr(), self.DHP.data_ptr(), s()), "gru_bwd1")
             self._wgrad(self.RHX[t], 192, self.DAQ, 128, "q", accumulate=acc)
-            self._gemm(self.DAQ, wq_t, None, self.DRHX, 128, 192, packed=wq_p)
+            self._gemm(self.DAQ, wq_t, None, self.DRHX, 128, 192, packed=wq_p, fmt=self.fmt_bwd or 0)
             _lib.check(lib.himo_gru_bwd2(n, self.DRHX.data_ptr(), self.HX[t].data_ptr(), self.Z[t].data_ptr(), self.R[t].data_ptr(),
                                          self.DZ.data_ptr(), self.DHP.data_ptr(), self.DAZR.data_ptr(), self.DX.data_ptr(), s()), "gru_bwd2")
             self._wgrad(self.HX[t], 192, self.DAZR, 256, "zr", accumulate=acc)
-            self._gemm(self.DAZR, wzr_t, None, self.DHX, 256, 192, packed=wzr_p)
+            self._gemm(self.DAZR, wzr_t, None, self.DHX, 256, 192, packed=wzr_p, fmt=self.fmt_bwd or 0)
             _lib.check(lib.himo_gru_bwd3(n, self.DHX.data_ptr(), self.DHP.data_ptr(), self.DH.data_ptr(), self.DX.data_ptr(), s()), "gru_bwd3")
         out = torch.empty((n, 192), dtype=torch.float32, device=self.device)
         out[:, :128].copy_(self.DH)
@@ -294,7 +294,7 @@ class SeFlowTrainer:
         # mixed: the stride-1 3x3 weight gradients multiply split-bf16 operands (16 significant bits, float32 sums) on the
         # 16-bit matrix instructions (csrc/train.hip conv_wgrad_split_kernel); the other modes keep float32 matrix instructions
         self.wgrad_flags = 2 if precision == "mixed" else 0
-        # mixed: the 3x3 data-gradient convolutions run the two-term bf16 split (HIMO_PACK_BF16X2: 16 significant bits, float32
+        # mixed: the data-gradient convolutions (3x3 and 1x1) run the two-term bf16 split (HIMO_PACK_BF16X2: 16 significant bits, float32
         # range, three matrix products per block) instead of the three-term one (six)
         self.bwd3_format = 2 if precision == "mixed" else 0
         self._wp_fmt = 0
@@ -445,7 +445,7 @@ class SeFlowTrainer:
         _lib.check(self.lib.himo_weight_flip(self.p[f"{name}.weight"].data_ptr(), ks, cin, cout, self.WF.data_ptr(), _lib.stream_handle()), "flip")
         if self.precision == "f32":
             return self.WF.data_ptr(), None
-        self._wp_fmt = self.bwd3_format if ks == 3 else 0
+        self._wp_fmt = self.bwd3_format                   # 3x3 and 1x1 data gradients alike
         _lib.check(self.lib.himo_conv_pack_weights_ex(self.WF.data_ptr(), ks, cout, cin, self._wp_fmt, self.WFP.data_ptr(), _lib.stream_handle()), "pack")
         return self.WF.data_ptr(), self.WFP.data_ptr()
 

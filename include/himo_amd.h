@@ -295,8 +295,9 @@ size_t himo_conv_packed_weight_bytes(int ksize, int cin, int cout);
 int himo_conv_pack_weights(const float* d_w, int ksize, int cin, int cout, void* d_packed, void* stream);
 #define HIMO_PACK_BF16X3 0
 #define HIMO_PACK_F16X2 1
-#define HIMO_PACK_BF16X2 2   /* two bf16 planes, x = h + m (16 significant bits, float32 range, three products per block): 3x3 layers with float32
-                                activation maps and the bias epilogue only -- the data-gradient convolutions of the mixed-precision training step */
+#define HIMO_PACK_BF16X2 2   /* two bf16 planes, x = h + m (16 significant bits, float32 range, three products per block): 3x3 layers and row GEMMs
+                                (1x1) with float32 activation maps and the bias epilogue only -- the data gradients of the mixed-precision
+                                training step */
 int himo_conv_pack_weights_ex(const float* d_w, int ksize, int cin, int cout, int format, void* d_packed, void* stream);
 
 /* bilinear x2 upsampling, align_corners = true; c channels of every pixel, NHWC with pitches */

@@ -161,6 +161,19 @@ def test_split_bf16_linear_weight_gradient(gpu, n, cin, cout):
     assert np.abs(db.cpu().numpy() - ref_b).max() <= 1e-4 * np.abs(ref_b).max() + 1e-3 * np.abs(dz.cpu().numpy()).max() * n ** 0.5 * 1e-3
 
 
+def test_two_term_bf16_row_gemm(gpu):
+    """HIMO_PACK_BF16X2 for 1x1 layers / row GEMMs (dX = dZ W^T of the head and the 1x1 convolutions in the mixed training step)."""
+    from himo_amd.seflow.model import conv2d_nhwc
+    rng = np.random.default_rng(17)
+    for n, cin, cout in ((70_001, 256, 192), (4097, 32, 192), (9000, 128, 384)):
+        x = (rng.normal(size=(1, 1, n, cin)) * 10.0 ** rng.uniform(-8, 0, size=(1, 1, n, 1))).astype(np.float32)
+        wt = (rng.normal(size=(1, 1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+        y = conv2d_nhwc(*(torch.from_numpy(a).to(gpu) for a in (x, wt, np.zeros(cout, np.float32))), precision="bf16x2").cpu().numpy()[0, 0]
+        ref = x[0, 0].astype(np.float64) @ wt[0, 0].astype(np.float64)
+        mag = np.abs(x[0, 0]).astype(np.float64) @ np.abs(wt[0, 0]).astype(np.float64)
+        assert (np.abs(y - ref) / mag).max() <= 2.0 ** -15, (n, cin, cout)
+
+
 def test_upsample2x_backward_is_the_adjoint(gpu):
     from himo_amd.seflow.train import upsample2x_backward_nhwc
     rng = np.random.default_rng(5)
