@@ -85,7 +85,7 @@ def test_bench_cli_contract(monkeypatch):
     """bench.py's command line: --gpus/--steps/--warmup exist, no flags means N=1 and minutes-scale defaults per workload."""
     import sys
     import bench
-    for argv, steps, warmup, frames in (([], 20, 3, 16), (["--workload", "compdis"], 50, 5, 256), (["--workload", "train"], 10, 2, 1),
+    for argv, steps, warmup, frames in (([], 100, 3, 16), (["--workload", "compdis"], 50, 5, 256), (["--workload", "train"], 10, 2, 1),
                                         (["--gpus", "8", "--steps", "7", "--warmup", "1"], 7, 1, 16)):
         monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
         a = bench.parse_args()
