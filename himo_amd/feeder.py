@@ -31,20 +31,18 @@ class _PinnedArena:
     def __init__(self):
         self._buf = torch.empty(0, dtype=torch.uint8)
         self._used = 0
+        self._extra, self._extra_used = [], []        # further pinned blocks chained on by take_growing
 
     def reset(self, need_bytes: int):
         if self._buf.numel() < need_bytes:
             self._buf = torch.empty(int(need_bytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
         self._used = 0
-        if hasattr(self, "_extra"):
-            self._extra_used = [0] * len(self._extra)
+        self._extra_used = [0] * len(self._extra)
 
     def take_growing(self, shape, dtype=torch.float32) -> torch.Tensor:
         """``take`` without a size known up front: when the block is exhausted a further pinned block is chained on (kept for
         the following batches, so steady state allocates nothing)."""
         nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
-        if not hasattr(self, "_extra"):
-            self._extra, self._extra_used = [], []
         lo = (self._used + 63) & ~63
         if lo + nbytes <= self._buf.numel():
             self._used = lo + nbytes
@@ -55,7 +53,8 @@ class _PinnedArena:
                 self._extra_used[i] = lo + nbytes
                 return blk[lo:lo + nbytes].view(dtype).view(*shape)
         blk = torch.empty(max(int(nbytes * 1.25) + 4096, 1 << 24), dtype=torch.uint8, pin_memory=True)
-        self._extra.append(blk); self._extra_used.append(nbytes)
+        self._extra.append(blk)
+        self._extra_used.append(nbytes)
         return blk[:nbytes].view(dtype).view(*shape)
 
     def take(self, shape, dtype=torch.float32) -> torch.Tensor:
