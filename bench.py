@@ -60,13 +60,19 @@ def parse_args():
                     help="pipeline, f16x2: keep the backbone's maps float32 in HBM instead of the split activation format (A/B switch)")
     ap.add_argument("--refined", action="store_true", help="also write refined points (+12 B/pt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=40.0,
-                    help="CPU work budget PER LEG (all cores / 1 thread) of the baseline; at least 3 frames are timed per leg")
+    ap.add_argument("--cpu-seconds", type=float, default=110.0,
+                    help="CPU work budget of the all-cores leg of the baseline: BASELINE.md section 3's protocol (5 warm-ups + 50 frames, "
+                         "median) runs in full when 55 frames fit this budget at the probed per-frame time, otherwise as many frames as "
+                         "fit (at least 3) and `cpu_baseline.sample` states the shortfall; the 1-thread leg gets a third of it")
     ap.add_argument("--cpu-frames", type=int, default=0,
-                    help="time exactly this many frames per CPU leg after 5 warm-ups (BASELINE.md section 3 asks for >= 50), ignoring --cpu-seconds")
+                    help="time exactly this many frames per CPU leg (both legs) after 5 warm-ups, ignoring --cpu-seconds")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0 = torch's default)")
     ap.add_argument("--no-extra-precisions", action="store_true",
                     help="pipeline, N=1: skip the bf16x3 / f32 legs that follow the timed f16x2 region")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="pipeline, N=1: skip the short training-step (config 5) and FastNSF (config 4) legs that follow the timed region")
+    ap.add_argument("--leg-train-steps", type=int, default=6, help="timed optimiser steps of the `leg_train` leg (after 2 warm-ups)")
+    ap.add_argument("--leg-fastnsf-fits", type=int, default=3, help="timed fits of the `leg_fastnsf` leg (after 1 warm-up)")
     ap.add_argument("--cloud", default="uniform", choices=["uniform", "rings"],
                     help="synthetic sweeps: SURVEY 8(d) uniform cloud with instances (default) or the LiDAR-like ring cloud")
     ap.add_argument("--sample-sets", type=int, default=3, help="distinct input batches rotated through the timed steps")
@@ -174,11 +180,11 @@ def cpu_baseline_compdis(frames: list[dict], budget_s: float, exact_frames: int 
     sys.path.insert(0, str(REPO / "oracle"))
     import himo_oracle as oracle
     run_one = lambda i: oracle.comp_dis_frame_f32(frames[i], "seflowpp_best")
-    legs = {"all_cores": _median_rate(run_one, len(frames), budget_s / 2, exact_frames)}
+    legs = {"all_cores": _median_rate(run_one, len(frames), budget_s / 2, exact_frames, est_s_per_frame=0.02)}
     try:
         from threadpoolctl import threadpool_limits
         with threadpool_limits(limits=1):
-            legs["one_thread"] = _median_rate(run_one, len(frames), budget_s / 2, exact_frames)
+            legs["one_thread"] = _median_rate(run_one, len(frames), budget_s / 2, exact_frames, est_s_per_frame=0.02)
     except ImportError:                                   # pragma: no cover
         legs["one_thread"] = legs["all_cores"]
     a, o = legs["all_cores"], legs["one_thread"]
@@ -189,10 +195,17 @@ def cpu_baseline_compdis(frames: list[dict], budget_s: float, exact_frames: int 
                       f"(the arithmetic is element-wise numpy: the thread count barely matters)"}
 
 
-def _median_rate(run_one, n_frames_avail: int, budget_s: float, exact_frames: int):
+PROTOCOL_WARMUPS, PROTOCOL_FRAMES = 5, 50
+
+
+def _median_rate(run_one, n_frames_avail: int, budget_s: float, exact_frames: int, est_s_per_frame: float | None = None):
     """warm-up frames, then the MEDIAN per-frame time of the measured ones.  ``exact_frames`` > 0:
-    5 warm-ups + exactly that many frames; otherwise 1 warm-up + as many frames as fit in ``budget_s`` (at least 3)."""
-    warm = 5 if exact_frames > 0 else 1
+    5 warm-ups + exactly that many frames.  Otherwise the full protocol (5 + 50) when ``est_s_per_frame`` says it fits into
+    ``budget_s``; else 1 warm-up + as many frames as fit (at least 3) -- the returned dict says which."""
+    full = exact_frames > 0 or (est_s_per_frame is not None and
+                                est_s_per_frame * (PROTOCOL_WARMUPS + PROTOCOL_FRAMES) <= budget_s)
+    n_exact = exact_frames if exact_frames > 0 else (PROTOCOL_FRAMES if full else 0)
+    warm = PROTOCOL_WARMUPS if full else 1
     for i in range(warm):
         run_one(i % n_frames_avail)
     times, t_start = [], time.perf_counter()
@@ -200,14 +213,17 @@ def _median_rate(run_one, n_frames_avail: int, budget_s: float, exact_frames: in
         t0 = time.perf_counter()
         run_one((warm + len(times)) % n_frames_avail)
         times.append(time.perf_counter() - t0)
-        if exact_frames > 0:
-            if len(times) >= exact_frames:
+        if n_exact > 0:
+            if len(times) >= n_exact:
                 break
-        elif len(times) >= 3 and (time.perf_counter() - t_start + times[-1] > budget_s or len(times) >= 50):
+        elif len(times) >= 3 and (time.perf_counter() - t_start + times[-1] > budget_s or len(times) >= PROTOCOL_FRAMES):
             break
     med = float(np.median(times))
     return {"frames_per_s": 1.0 / med, "ms_per_frame": med * 1e3, "frames_timed": len(times), "warmup_frames": warm,
-            "ms_min": float(np.min(times)) * 1e3, "ms_max": float(np.max(times)) * 1e3}
+            "ms_min": float(np.min(times)) * 1e3, "ms_max": float(np.max(times)) * 1e3,
+            "protocol": ("BASELINE.md section 3 in full (5 warm-ups, median of >= 50 frames)" if warm >= PROTOCOL_WARMUPS and len(times) >= PROTOCOL_FRAMES
+                         else f"SHORT of BASELINE.md section 3 (asks 5 warm-ups + 50 frames): {warm} warm-up(s) + {len(times)} frames fitted the "
+                              f"{budget_s:.0f} s budget of this leg")}
 
 
 def cpu_baseline_pipeline(host_samples, params, budget_s: float, exact_frames: int = 0, threads_all: int = 0) -> dict:
@@ -239,9 +255,10 @@ def cpu_baseline_pipeline(host_samples, params, budget_s: float, exact_frames: i
                 run_one(1 % len(host_samples))
                 probe[thr] = time.perf_counter() - t0
             threads_all = min(probe, key=probe.get)
-        for name, thr in (("all_cores", threads_all), ("one_thread", 1)):
+        est = probe.get(threads_all)
+        for name, thr, budget in (("all_cores", threads_all, budget_s), ("one_thread", 1, budget_s / 3.0)):
             torch.set_num_threads(thr)
-            legs[name] = dict(_median_rate(run_one, len(host_samples), budget_s, exact_frames), threads=thr)
+            legs[name] = dict(_median_rate(run_one, len(host_samples), budget, exact_frames, est if thr == threads_all else None), threads=thr)
     finally:
         torch.set_num_threads(default_threads)
     a, o = legs["all_cores"], legs["one_thread"]
@@ -252,7 +269,8 @@ def cpu_baseline_pipeline(host_samples, params, budget_s: float, exact_frames: i
                       f"(the fastest of {sorted(probe) or [a['threads']]} on this host) "
                       f"({a['ms_per_frame']:.0f} ms/frame) and of {o['frames_timed']} at 1 thread ({o['ms_per_frame']:.0f} ms/frame); "
                       f"a frame = 3 x {len(host_samples[0][1]['pc0'])}-point sweeps through the PyTorch-CPU fp32 restatement "
-                      f"(oracle/seflow_oracle.py) + numpy comp_dis; host has {os.cpu_count()} logical cores"}
+                      f"(oracle/seflow_oracle.py) + numpy comp_dis; host has {os.cpu_count()} logical cores.  All-cores leg: {a['protocol']}; "
+                      f"1-thread leg: {o['protocol']}"}
 
 
 def reduce_job(elapsed: float, frames_done: int, device, world: int, rank: int):
@@ -369,6 +387,51 @@ def main() -> int:
     return 0
 
 
+def make_fastnsf_step(args, rank: int, device, result: dict):
+    """BASELINE config 4: a step fits the per-scene coordinate MLP to one 120k-point sweep pair."""
+    import torch
+    from himo_amd.fastnsf import FastNSF
+    from himo_amd.synthetic import make_frame
+    P = args.points
+    fr = [make_frame(100_000 * rank + 77 + i, n_points=P, cloud=args.cloud) for i in range(2)]
+    p0 = torch.from_numpy(np.ascontiguousarray(fr[0]["pc0"][:, :3])).to(device)
+    p1 = torch.from_numpy((fr[0]["pc0"][:, :3] + fr[0]["flow"]).astype(np.float32)).to(device)     # the sweep one step later
+    fitter = FastNSF(device=device, iters=args.fastnsf_iters)
+
+    def step():
+        result["flow"] = fitter.fit(p0, p1, fr[0]["pose0"], fr[0]["pose1"])
+    return step, fitter, fr
+
+
+def make_train_step(args, rank: int, device, result: dict, n_sets: int = 2):
+    """BASELINE config 5: self-supervised training, ``frames_per_step`` samples per rank per step (one optimiser step each), ONE
+    flat-gradient all-reduce over RCCL per optimiser step, Adam.  Labels: ~10 % of the points in 30 dynamic clusters.
+    ``n_sets`` distinct sample sets rotate through the steps, so the incremental pillar images meet cells that emptied
+    and cells that filled (a single repeated sample would skip every empty cell: a best case)."""
+    import torch
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.train import SeFlowTrainer
+    B, P = args.frames_per_step, args.points
+    params = spec.init_params(0)
+    trainer = SeFlowTrainer(params, device=device, max_points=P, precision=args.train_precision)
+    sets, _ = synthetic_sample_sets(n_sets, B, P, device, seed=rank, cloud=args.cloud)
+    g = torch.Generator(device=device); g.manual_seed(99 + rank)
+    labels = []
+    for _ in range(B):
+        pick = torch.rand(P, generator=g, device=device) < 0.1
+        lab = torch.randint(1, 31, (P,), generator=g, device=device, dtype=torch.int32) * pick.to(torch.int32)
+        labels.append((lab, lab.clone()))
+    turn = [0]
+
+    def step():
+        samples = sets[turn[0] % len(sets)]
+        turn[0] += 1
+        for smp, (l0, l1) in zip(samples, labels):
+            _, total = trainer.train_step(smp.pch1, smp.pc0, smp.pc1, smp.pose_h1, smp.pose0, smp.pose1, l0, l1, n_labels=31)
+            result["loss"] = total
+    return step, trainer
+
+
 def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     import torch
     import torch.distributed as dist
@@ -391,35 +454,9 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
         def step():
             eng.run(batch, sensor_dt=0.1, refined=args.refined, out=out)
     elif args.workload == "fastnsf":
-        from himo_amd.fastnsf import FastNSF
-        from himo_amd.synthetic import make_frame
-        fr = [make_frame(100_000 * rank + 77 + i, n_points=P, cloud=args.cloud) for i in range(2)]
-        p0 = torch.from_numpy(np.ascontiguousarray(fr[0]["pc0"][:, :3])).to(device)
-        p1 = torch.from_numpy((fr[0]["pc0"][:, :3] + fr[0]["flow"]).astype(np.float32)).to(device)     # the sweep one step later
-        fitter = FastNSF(device=device, iters=args.fastnsf_iters)
-
-        def step():
-            result["flow"] = fitter.fit(p0, p1, fr[0]["pose0"], fr[0]["pose1"])
+        step, fitter, fr = make_fastnsf_step(args, rank, device, result)
     elif args.workload == "train":
-        # BASELINE config 5: self-supervised training, one sample per rank per optimiser step, ONE flat-gradient
-        # all-reduce over RCCL, Adam.  Labels: ~10 % of the points in 30 dynamic clusters.
-        from himo_amd.seflow import spec
-        from himo_amd.seflow.train import SeFlowTrainer
-        params = spec.init_params(0)
-        trainer = SeFlowTrainer(params, device=device, max_points=P, precision=args.train_precision)
-        sets, host_frames = synthetic_sample_sets(1, B, P, device, seed=rank, cloud=args.cloud)
-        samples = sets[0]
-        g = torch.Generator(device=device); g.manual_seed(99 + rank)
-        labels = []
-        for _ in range(B):
-            pick = torch.rand(P, generator=g, device=device) < 0.1
-            lab = torch.randint(1, 31, (P,), generator=g, device=device, dtype=torch.int32) * pick.to(torch.int32)
-            labels.append((lab, lab.clone()))
-
-        def step():
-            for smp, (l0, l1) in zip(samples, labels):
-                _, total = trainer.train_step(smp.pch1, smp.pc0, smp.pc1, smp.pose_h1, smp.pose0, smp.pose1, l0, l1, n_labels=31)
-                result["loss"] = total
+        step, trainer = make_train_step(args, rank, device, result)
     else:
         from himo_amd.pipeline import HiMoPipeline
         from himo_amd.seflow import spec
@@ -483,8 +520,7 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     # ~12 % of the frame rate -- and get their table from one extra, untimed, fully profiled step afterwards.
     # train: the 3x3 weight gradients are the largest kernel family of the step in every precision mode (mixed: split-bf16
     # operands on the stride-1 layers; bf16x3 / f32: float32 matrix instructions)
-    train_dominant = "conv_wgrad_tiled_kernel"
-    dominant = {"compdis": "compdis_kernel", "train": train_dominant, "fastnsf": "conv1x1_mfma_kernel"}.get(
+    dominant = {"compdis": "compdis_kernel", "train": TRAIN_DOMINANT, "fastnsf": "conv1x1_mfma_kernel"}.get(
         args.workload, {"bf16x3": "conv3x3_bf16x3_kernel", "f16x2": "conv3x3_f16x2_kernel"}.get(args.precision, "conv3x3_mfma_kernel"))
     grouped = dist.is_available() and dist.is_initialized()
     if grouped:
@@ -552,52 +588,9 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
                     "over a ragged HBM-resident batch; network forward NOT included")
         dtype = "f64"
     elif args.workload == "fastnsf":
-        from himo_amd.fastnsf import HIDDEN, N_HIDDEN
-        # dominant kernel family of a fit: the MLP's row GEMMs (forward + input gradients) on float32 MFMA
-        k = prof.get("conv1x1_mfma_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
-        dims = [4] + [HIDDEN] * N_HIDDEN + [4]
-        fwd = sum(2.0 * P * ci * co for ci, co in zip(dims[:-1], dims[1:]))
-        dgrad = sum(2.0 * P * ci * co for ci, co in zip(dims[1:-1], dims[2:]))                     # every layer but the first
-        flops_fit = args.fastnsf_iters * (fwd + dgrad) + fwd                                        # + the final forward
-        alg_tf = flops_fit * args.steps / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
-        roofline = {"bound": "mfma", "kernel": "conv1x1_mfma_kernel (v_mfma_f32_32x32x2_f32; the MLP's forward / input-gradient row GEMMs)",
-                    "achieved": alg_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": alg_tf / MFMA_F32_PEAK_TF, "traffic": None,
-                    "avg_launch_ms": k["avg_ms"], "launches_timed": k["count"], "algorithmic_flops_per_frame": flops_fit,
-                    "share_of_step_time": k["total_ms"] / (elapsed * 1e3),
-                    "note": "an iteration is ~40 short launches (8-layer MLP forward / backward on 120k rows, two exact NN searches, "
-                            "truncated Chamfer, weight gradients, Adam); the row GEMMs are the largest family (K = 128: 64 matrix "
-                            "instructions per tile, so prologue / epilogue weigh a third)"}
-        workload = (f"FastNSF (BASELINE config 4): fit the per-scene coordinate MLP (3 -> 8 x 128 -> 3) to one pair of 120k-point sweeps, "
-                    f"{args.fastnsf_iters} Adam iterations per frame, exact NN correspondences every iteration")
-        dtype = "f32"
+        roofline, workload, dtype = fastnsf_roofline(args, prof, args.steps, elapsed)
     elif args.workload == "train":
-        from himo_amd.seflow import spec
-        n_steps = B * args.steps
-        H, W = spec.GRID
-        # 2*M*N*K of the 23 3x3 layers of one sample (20 stride-1 + the 3 stride-2 ones at their output resolution): the
-        # algorithmic work of the weight gradients AND of the data gradients (a transposed convolution of the same size)
-        flops_w = spec.conv3x3_flops() + sum(spec.NUM_FRAMES * 2.0 * (H // d) * (W // d) * ci * co * 9
-                                             for d, ci, co in ((2, 32, 64), (4, 64, 128), (8, 128, 256)))
-        k = prof.get(train_dominant, {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
-        alg_tf = flops_w * n_steps / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
-        if args.train_precision == "mixed":
-            kdesc = ("conv_wgrad_tiled_kernel family: 3x3 weight gradients -- the 20 stride-1 layers on v_mfma_f32_32x32x16_bf16 with two-term "
-                     "split-bf16 operands (3 per float32 product block), the 3 stride-2 layers on v_mfma_f32_32x32x2_f32")
-            peak, pnote = MFMA_BF16_PEAK_TF / 3.0, (f"{MFMA_BF16_PEAK_TF:.0f} TFLOP/s dense bf16 MFMA peak / 3 matrix products per float32 product "
-                                                    "(the stride-2 launches, 10 % of the family's flops, run float32 matrix instructions)")
-        else:
-            kdesc, peak, pnote = "conv_wgrad_tiled_kernel (v_mfma_f32_32x32x2_f32; 3x3 weight gradients)", MFMA_F32_PEAK_TF, "dense float32 MFMA peak"
-        roofline = {"bound": "mfma", "kernel": kdesc, "achieved": alg_tf, "peak": peak, "peak_note": pnote, "unit": "TFLOP/s",
-                    "frac": alg_tf / peak, "traffic": None, "avg_launch_ms": k["avg_ms"], "launches_timed": k["count"],
-                    "algorithmic_flops_per_step": flops_w, "share_of_step_time": k["total_ms"] / (elapsed * 1e3),
-                    "note": "split-K over pixel tiles; the fixed-order reduction of the partials is a separate (small) kernel"}
-        workload = ("self-supervised TRAINING step (BASELINE config 5): pillarise 3 sweeps -> network forward with saved "
-                    "activations -> 4-term NN/Chamfer loss -> full backward -> flat-gradient all-reduce -> Adam; "
-                    "one 120k-point sample per GPU per step")
-        dtype = {"mixed": "forward f16x2 (two-term fp16 split); 3x3 data-gradient convolutions and stride-1 3x3 weight gradients two-term bf16 split "
-                          "(16-bit operands, float32 range and sums); 1x1 / head data gradients bf16x3; everything else and the optimiser f32",
-                 "bf16x3": "forward + data-gradient convolutions bf16x3 (split bf16, float32-class); weight gradients / optimiser f32",
-                 "f32": "f32"}[args.train_precision]
+        roofline, workload, dtype = train_roofline(args, prof, B * args.steps, elapsed)
     else:
         roofline, dtype = conv_roofline(args.precision, prof, B, args.steps, elapsed, traffic, folded=pipe.net.fold_decoder)
         if rank == 0 and _lib is not None:
@@ -615,8 +608,26 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
         workload = ("per-frame pipeline: pillarise 3 sweeps (512x512 grid) -> SeFlow++-style encoder/decoder + GRU head "
                     "(random-init, self-specified: reference network source absent) -> per-point flow -> ego-motion "
                     "removal + dt0 + flow2compDis -> comp_dis")
+        # the whole step against the HBM roofline (BASELINE.json's metric asks for the achieved fraction): bytes every operator
+        # of the executed graph must move once (himo_amd/seflow/spec.py algorithmic_bytes_per_frame) / measured step time
+        from himo_amd.seflow import spec as _spec
+        parts = _spec.algorithmic_bytes_per_frame(P, folded=pipe.net.fold_decoder)
+        step_s = elapsed / args.steps
+        gbs = parts["total"] * B / step_s / 1e9
+        roofline["step_hbm"] = {"algorithmic_bytes_per_step": parts["total"] * B, "achieved": gbs, "GB/s": gbs, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                "algorithmic_MB_per_frame": {k: round(v / 1e6, 1) for k, v in parts.items()},
+                                "note": "every operator of the executed graph reads its inputs and writes its outputs once, 4 B per feature-map "
+                                        "value, weights L2-resident; the step is bound by the matrix rate of the 3x3 convolutions (`roofline`), "
+                                        "not by HBM: at 8 TB/s these bytes would take "
+                                        f"{parts['total'] * B / HBM_PEAK_GBS / 1e6:.1f} ms of the {step_s * 1e3:.1f} ms step"}
+        roofline["traffic_source"] = (f"{Path(args.traffic_json).name}: builder-run rocprofv3 PMC passes of this workload (scripts/collect_traffic.sh: "
+                                      "FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, separate passes, per launch of the tuned kernels) -- "
+                                      "a cross-reference read from profiles/, NOT measured in this run") if roofline.get("traffic") else None
         if world == 1 and not args.no_extra_precisions:
             extra = extra_precision_legs(args, params, sets, device, ref_flow, exclude=args.precision)
+        if world == 1 and not args.no_extra_workloads:
+            extra.update(extra_workload_legs(args, device))
     line = {
         "metric": "lidar_frames_per_sec_120k", "value": total_frames / elapsed, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -653,6 +664,62 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
             line["cpu_baseline"] = cpu_baseline_pipeline(host_samples, params, args.cpu_seconds, args.cpu_frames, args.cpu_threads)
         line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
     return line
+
+
+def fastnsf_roofline(args, prof: dict, n_fits: int, elapsed: float):
+    """roofline object / workload / dtype of the FastNSF fit: the MLP's row GEMMs are the largest kernel family."""
+    from himo_amd.fastnsf import HIDDEN, N_HIDDEN
+    P = args.points
+    k = prof.get("conv1x1_mfma_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
+    dims = [4] + [HIDDEN] * N_HIDDEN + [4]
+    fwd = sum(2.0 * P * ci * co for ci, co in zip(dims[:-1], dims[1:]))
+    dgrad = sum(2.0 * P * ci * co for ci, co in zip(dims[1:-1], dims[2:]))                     # every layer but the first
+    flops_fit = args.fastnsf_iters * (fwd + dgrad) + fwd                                        # + the final forward
+    alg_tf = flops_fit * n_fits / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
+    roofline = {"bound": "mfma", "kernel": "conv1x1_mfma_kernel (v_mfma_f32_32x32x2_f32; the MLP's forward / input-gradient row GEMMs)",
+                "achieved": alg_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": alg_tf / MFMA_F32_PEAK_TF, "traffic": None,
+                "avg_launch_ms": k["avg_ms"], "launches_timed": k["count"], "algorithmic_flops_per_frame": flops_fit,
+                "share_of_step_time": k["total_ms"] / (elapsed * 1e3),
+                "note": "an iteration is ~40 short launches (8-layer MLP forward / backward on 120k rows, two exact NN searches, "
+                        "truncated Chamfer, weight gradients, Adam); the row GEMMs are the largest family (K = 128: 64 matrix "
+                        "instructions per tile, so prologue / epilogue weigh a third)"}
+    workload = (f"FastNSF (BASELINE config 4): fit the per-scene coordinate MLP (3 -> 8 x 128 -> 3) to one pair of {P}-point sweeps, "
+                f"{args.fastnsf_iters} Adam iterations per frame, exact NN correspondences every iteration")
+    return roofline, workload, "f32"
+
+
+TRAIN_DOMINANT = "conv_wgrad_tiled_kernel"       # the 3x3 weight gradients: largest kernel family of the step in every precision mode
+
+
+def train_roofline(args, prof: dict, n_steps: int, elapsed: float):
+    """roofline object / workload / dtype of the training step (``n_steps`` optimiser steps inside ``elapsed`` seconds)."""
+    from himo_amd.seflow import spec
+    H, W = spec.GRID
+    # 2*M*N*K of the 23 3x3 layers of one sample (20 stride-1 + the 3 stride-2 ones at their output resolution): the
+    # algorithmic work of the weight gradients AND of the data gradients (a transposed convolution of the same size)
+    flops_w = spec.conv3x3_flops() + sum(spec.NUM_FRAMES * 2.0 * (H // d) * (W // d) * ci * co * 9
+                                         for d, ci, co in ((2, 32, 64), (4, 64, 128), (8, 128, 256)))
+    k = prof.get(TRAIN_DOMINANT, {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
+    alg_tf = flops_w * n_steps / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
+    if args.train_precision == "mixed":
+        kdesc = ("conv_wgrad_tiled_kernel family: 3x3 weight gradients -- the 20 stride-1 layers on v_mfma_f32_32x32x16_bf16 with two-term "
+                 "split-bf16 operands (3 per float32 product block), the 3 stride-2 layers on v_mfma_f32_32x32x2_f32")
+        peak, pnote = MFMA_BF16_PEAK_TF / 3.0, (f"{MFMA_BF16_PEAK_TF:.0f} TFLOP/s dense bf16 MFMA peak / 3 matrix products per float32 product "
+                                                "(the stride-2 launches, 10 % of the family's flops, run float32 matrix instructions)")
+    else:
+        kdesc, peak, pnote = "conv_wgrad_tiled_kernel (v_mfma_f32_32x32x2_f32; 3x3 weight gradients)", MFMA_F32_PEAK_TF, "dense float32 MFMA peak"
+    roofline = {"bound": "mfma", "kernel": kdesc, "achieved": alg_tf, "peak": peak, "peak_note": pnote, "unit": "TFLOP/s",
+                "frac": alg_tf / peak, "traffic": None, "avg_launch_ms": k["avg_ms"], "launches_timed": k["count"],
+                "algorithmic_flops_per_step": flops_w, "share_of_step_time": k["total_ms"] / (elapsed * 1e3),
+                "note": "split-K over pixel tiles; the fixed-order reduction of the partials is a separate (small) kernel"}
+    workload = ("self-supervised TRAINING step (BASELINE config 5): pillarise 3 sweeps -> network forward with saved "
+                "activations -> 4-term NN/Chamfer loss -> full backward -> flat-gradient all-reduce -> Adam; "
+                f"one {args.points}-point sample per GPU per step")
+    dtype = {"mixed": "forward f16x2 (two-term fp16 split); 3x3 data-gradient convolutions and stride-1 3x3 weight gradients two-term bf16 split "
+                      "(16-bit operands, float32 range and sums); 1x1 / head data gradients bf16x3; everything else and the optimiser f32",
+             "bf16x3": "forward + data-gradient convolutions bf16x3 (split bf16, float32-class); weight gradients / optimiser f32",
+             "f32": "f32"}[args.train_precision]
+    return roofline, workload, dtype
 
 
 def conv_roofline(precision: str, prof: dict, B: int, steps: int, elapsed: float, traffic: dict, folded: bool = True):
@@ -694,6 +761,62 @@ def conv_roofline(precision: str, prof: dict, B: int, steps: int, elapsed: float
              "f16x2 (two-term split fp16, x = h + l with exact subnormals, on the matrix cores; float32 accumulate; ~22-bit products)"
              if f16 else "f32")
     return roofline, dtype
+
+
+def extra_workload_legs(args, device) -> dict:
+    """N = 1 only, after the timed pipeline region: SHORT legs of BASELINE configs 5 (training step) and 4 (FastNSF fit) at the
+    same 120k points, each with the protocol of its own workload (priming pass, warm-up, K timed steps between
+    synchronisations, the leg's dominant kernel timed live by HIP events) and its own `roofline` object, so the driver-run
+    line carries figures for them too: ``leg_train`` / ``leg_fastnsf`` (+ ``value_train`` / ``value_fastnsf`` frames/s).
+    `python bench.py --workload train|fastnsf` runs the same code as the main workload."""
+    import copy
+    import torch
+    from himo_amd import _lib
+    out = {}
+    for name, steps, warm in (("train", args.leg_train_steps, 2), ("fastnsf", args.leg_fastnsf_fits, 1)):
+        if steps <= 0:
+            continue
+        a = copy.copy(args)
+        a.workload, a.frames_per_step = name, 1
+        result = {}
+        try:
+            if name == "train":
+                step, obj = make_train_step(a, 0, device, result)
+                dominant = TRAIN_DOMINANT
+            else:
+                step, obj, fr = make_fastnsf_step(a, 0, device, result)
+                dominant = "conv1x1_mfma_kernel"
+            step()                                                  # priming pass (workspace growth, one-off autotune)
+            for _ in range(warm):
+                step()
+            torch.cuda.synchronize()
+            _lib.prof_start(only=dominant)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            prof = _lib.prof_stop()
+            if name == "train":
+                roof, workload, dtype = train_roofline(a, prof, steps, el)
+                parity = {"loss_after_leg": float(result["loss"].item()),
+                          "note": "gradient parity vs CPU autograd through the oracle network (unpinned): tests/test_train_gpu.py"}
+            else:
+                roof, workload, dtype = fastnsf_roofline(a, prof, steps, el)
+                got = result["flow"].cpu().numpy()
+                parity = {"loss_first_to_last_iteration": [obj.loss_history[0][1], obj.loss_history[-1][1]],
+                          "flow_mean_epe_vs_generating_flow": float(np.linalg.norm(got - fr[0]["flow"], axis=1).mean()),
+                          "note": "gradient / trajectory parity vs the CPU restatement (oracle/fastnsf_oracle.py, unpinned): tests/test_fastnsf_gpu.py"}
+            leg = {"frames_per_s": steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warm,
+                   "points_per_frame": a.points, "workload": workload, "dtype": dtype, "roofline": roof, "parity": parity}
+        except Exception as e:                                      # a leg must never cost the main line
+            leg = {"error": f"{type(e).__name__}: {e}"}
+        out[f"leg_{name}"] = leg
+        if "frames_per_s" in leg:
+            out[f"value_{name}"] = leg["frames_per_s"]
+        step = obj = result = None
+        torch.cuda.empty_cache()
+    return out
 
 
 def extra_precision_legs(args, params, sets, device, ref_flow, exclude: str) -> dict:

@@ -154,3 +154,38 @@ def conv3x3_flops(folded: bool = False) -> float:
 def head_flops_per_point() -> float:
     per_iter = 3 * 2.0 * (HIDDEN + XDIM) * HIDDEN
     return GRU_ITERS * per_iter + 2.0 * 3 * XDIM + 2.0 * (HIDDEN + XDIM) * 32 + 2.0 * 32 * 3
+
+
+def algorithmic_bytes_per_frame(n_points: int, folded: bool = True) -> dict:
+    """HBM bytes one frame (3 sweeps -> flow -> comp_dis) has to move when every operator reads its inputs and writes its
+    outputs exactly once, 4 bytes per feature-map value (float32 or the fp16 split pair), weights not counted (L2-resident).
+    The whole-step HBM roofline of bench.py (``roofline.step_hbm``) prices the measured step time against this figure.
+    ``folded``: the executed inference graph (dec1.u5 / dec2.u5 absorb the next block's 1x1 convolution)."""
+    H, W = GRID
+    px = lambda d: (H // d) * (W // d) * 4.0
+    parts = {"point_io": n_points * (NUM_FRAMES * 16.0 + 12.0),                   # xyzi rows of 3 sweeps in, flow out
+             "comp_dis": n_points * 44.0,                                          # SURVEY 8(d): xyzi 16 + flow 12 + dt 4 + comp_dis 12
+             "pillar_images": NUM_FRAMES * px(1) * PILLAR_CH}
+    enc, d = 0.0, 1
+    for name, cin, cout, stride in ENCODER:
+        enc += px(d) * cin                                                         # input at the input resolution
+        if stride == 2:
+            d *= 2
+        enc += px(d) * cout
+    parts["encoder"] = NUM_FRAMES * enc
+    dec = 0.0
+    res = {"dec1": 8, "dec2": 4, "dec3": 2}
+    for i, (name, cin, skip, lat, out) in enumerate(DECODER):
+        dc = res[name]                                                              # coarse resolution divisor; output at dc // 2
+        if not (folded and i > 0):
+            dec += px(dc) * (cin + lat)                                             # u1 (folded into the previous u5 otherwise)
+        dec += px(dc) * lat + px(dc // 2) * lat                                     # bilinear x2
+        dec += px(dc // 2) * (skip + lat)                                           # u3
+        dec += px(dc // 2) * (2 * lat + out)                                        # u4 on the concat
+        u5_out = DECODER[i + 1][3] if folded and i + 1 < len(DECODER) else out
+        dec += px(dc // 2) * (out + u5_out)                                         # u5
+    dec += px(1) * 2 * DEC_OUT                                                      # dec4
+    parts["decoder"] = dec
+    parts["head_gather"] = n_points * HIDDEN * 4.0
+    parts["total"] = sum(parts.values())
+    return parts

@@ -254,12 +254,15 @@ def test_flows_never_returns_an_overflowed_batch(gpu):
         HiMoPipeline(device=gpu, max_points=9_000, max_batch=1, params=big, precision="f16x2").flows(samples)
 
 
-def test_config2_shaped_run_over_the_reference_frame_list(gpu, tmp_path, monkeypatch):
-    """BASELINE config 2 in shape (the data itself is absent): the reference's own frame lists -- 70 eval frames of 13 scenes
-    (index_eval.pkl) inside their index_total.pkl neighbourhood -- filled with small synthetic sweeps, then the three
-    programs in a row through their command-line mains: save (network flow under <res_name> for every frame with a
-    successor) -> save_zip (the eval list only -> one Feather member per distinct sweep, stored zip) -> eval, once from the stored flow
-    and once from the zip: the same table (to the float32 rounding of the zip's payload)."""
+@pytest.mark.parametrize("n_points", [2_000, 120_000])
+def test_config2_run_over_the_reference_frame_list(gpu, oracle, tmp_path, monkeypatch, n_points):
+    """BASELINE config 2 (the data itself is absent): the reference's own frame lists -- 70 eval frames of 13 scenes
+    (index_eval.pkl) inside their index_total.pkl neighbourhood -- filled with synthetic sweeps (small ones, and BASELINE-size
+    120k-point ones), then the three programs in a row through their command-line mains: save (network flow under <res_name>
+    for every frame with a successor) -> save_zip (the eval list only -> one Feather member per distinct sweep, stored zip)
+    -> eval, once from the stored flow and once from the zip.  Both tables are checked against the pinned oracle's
+    ``InstanceMetrics`` (eval.py:64-149 restated) fed the SAME stored flow / the SAME zip payload, sweep by sweep in the
+    list's order -- not only against each other."""
     import json
     import pickle
     from pathlib import Path
@@ -276,11 +279,15 @@ def test_config2_shaped_run_over_the_reference_frame_list(gpu, tmp_path, monkeyp
         keep.update(j for j in (i - 1, i, i + 1) if 0 <= j < len(total) and total[j][0] == s)
     sub = [total[i] for i in sorted(keep)]
     root = tmp_path / "av2" / "himo"
-    frames = [make_frame(9000 + k, n_points=2_000 + (k % 7) * 100, scene_id=s) for k, (s, t) in enumerate(sub)]
-    for f, (s, t) in zip(frames, sub):
+    frames = []
+    for k, (s, t) in enumerate(sub):                               # ragged: 120k, 119k, ... (2000, 2100, ... in the small run)
+        f = make_frame(9000 + k, n_points=n_points - (k % 7) * (n_points // 120) if n_points > 10_000 else n_points + (k % 7) * 100,
+                       scene_id=s)
         f["timestamp"] = int(t)
         f.pop("seflowpp_best")
+        frames.append(f)
     NpzDataset.write(root, frames)
+    del frames
     with open(root / "index_eval.pkl", "wb") as fh:
         pickle.dump(evl, fh)
     assert len(NpzDataset(root, eval=True)) == 70 and len({s for s, _ in evl}) == 13
@@ -304,11 +311,25 @@ def test_config2_shaped_run_over_the_reference_frame_list(gpu, tmp_path, monkeyp
     a, b = (json.loads(json.dumps(m.summary(), default=float)) for m in (direct, via_zip))
     assert "Total" in a and a["Total"]["num_obj"] > 0
 
-    def close(x, y):                                            # the zip carries comp_dis rounded to float32 (save_zip.py:70-72),
-        if isinstance(x, dict):                                   # the direct mode keeps the float64 chain: same table to ~1e-7
-            return x.keys() == y.keys() and all(close(x[k], y[k]) for k in x)
-        return x == pytest.approx(y, rel=1e-6, abs=1e-9)
-    assert close(a, b)
+    def close(x, y, rel, path=""):
+        if isinstance(x, dict):
+            assert x.keys() == y.keys(), (path, sorted(x), sorted(y))
+            return all(close(x[k], y[k], rel, f"{path}/{k}") for k in x)
+        assert x == pytest.approx(y, rel=rel, abs=1e-9, nan_ok=True), (path, x, y)
+        return True
+    # the zip carries comp_dis rounded to float32 (save_zip.py:70-72), the direct mode keeps the float64 chain: same table to ~1e-7
+    assert close(a, b, 1e-6)
+    # ... and against the pinned oracle: eval.py's loop over the same 70 entries, on the flow `save` stored / the zip `save_zip` wrote
+    from himo_amd.save_zip import read_output_zip
+    ref_direct, ref_zip = oracle.InstanceMetrics("av2"), oracle.InstanceMetrics("av2")
+    for i in range(len(ds)):
+        f = ds[i]
+        oracle.eval_frame(ref_direct, f, res_name="seflowpp_best")
+        oracle.eval_frame(ref_zip, f, comp_dis=read_output_zip(z, (f["scene_id"], f["timestamp"])))
+    assert ref_direct.frame_cnt == ref_zip.frame_cnt == 70
+    for mine, ref in ((direct, ref_direct), (via_zip, ref_zip)):
+        close(json.loads(json.dumps(mine.evaluate_data, default=float)), json.loads(json.dumps(ref.evaluate_data, default=float)), 1e-9)
+        close(json.loads(json.dumps(mine.summary(), default=float)), json.loads(json.dumps(ref.summary(), default=float)), 1e-9)
 
 
 def test_cli_entry_points_on_a_one_rank_rccl_group(gpu, tmp_path, monkeypatch):
