@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import os
 from contextlib import contextmanager
+from datetime import timedelta
 
 
 def launched_world() -> int:
@@ -37,30 +38,61 @@ def process_group():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this host driver
     backend = os.environ.get("HIMO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    # these are batch tools: a peer that was hard-killed must not leave the rest parked for RCCL's default 10 minutes
+    timeout = timedelta(seconds=float(os.environ.get("HIMO_DIST_TIMEOUT_S", "300")))
+    global _FLAG_GROUP
     if backend == "nccl":
         if torch.cuda.device_count() <= local:
             raise RuntimeError(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} HIP device(s) visible")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=timeout)
+        # the "did every rank get through" flag travels over a host-side gloo group: a rank whose GPU faulted would fail again
+        # inside an RCCL collective and bury the original error; data (the metric gather, gradients) stays on RCCL
+        _FLAG_GROUP = dist.new_group(backend="gloo", timeout=timeout)
     else:
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
     try:
         yield rank, world
     finally:
+        _FLAG_GROUP = None
         dist.destroy_process_group()
 
 
+_FLAG_GROUP = None
+
+
 def all_ranks_ok(ok: bool) -> bool:
-    """The job's rendezvous after the sharded loop: True only if EVERY rank got through its share.  A rank that failed
-    still arrives here (callers wrap their loop in try/except and pass ok=False) so the others are never left waiting
-    at a barrier for a process that has already died; afterwards the failing rank re-raises and the rest stop cleanly."""
+    """The job's rendezvous after the sharded loop: True only if EVERY rank got through its share.  A rank whose loop raised
+    an ``Exception`` still arrives here (callers pass ok=False) so the others are never left waiting for a process that has
+    already given up; afterwards the failing rank re-raises and the rest stop cleanly."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return ok
+    if _FLAG_GROUP is not None:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=_FLAG_GROUP)
+        return bool(flag.item())
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     return bool(flag.item())
+
+
+def rendezvous(err: Exception | None, what: str = "its share of the frames") -> None:
+    """``all_ranks_ok`` + the raising that follows it in every entry point.  ``err``: the ``Exception`` this rank's loop
+    raised, or None.  KeyboardInterrupt / SystemExit are never routed here (the mains catch ``Exception`` only): an
+    interrupted rank leaves at once and the launcher takes the job down.  If the rendezvous collective itself fails on a
+    rank that already carries an error, the ORIGINAL error is raised, with the collective's failure as its cause."""
+    try:
+        everyone = all_ranks_ok(err is None)
+    except Exception as coll:
+        if err is not None:
+            raise err from coll
+        raise
+    if err is not None:
+        raise err
+    if not everyone:
+        raise RuntimeError(f"another rank failed; this rank finished {what}")

@@ -489,13 +489,9 @@ def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo", res_name: str = 
                         cds = [read_output_zip(comp_dis_zip, (f["scene_id"], str(f["timestamp"]))) for f in frames]
                     yield mine[lo:lo + batch_frames], frames, cds
             stream_batches(metrics, batches(), res_name)
-        except BaseException as e:
+        except Exception as e:
             err = e
-        everyone = distenv.all_ranks_ok(err is None)
-        if err is not None:
-            raise err
-        if not everyone:
-            raise RuntimeError("another rank failed; no result file was written")
+        distenv.rendezvous(err, "its sweeps, but no result file was written")
         metrics.gather()
         if rank == 0:
             metrics.print(res_name=res_name, file_name=file_name or f"res-{data_name}.json")

@@ -160,9 +160,15 @@ class HiMoPipeline:
         """Network only: (N0,3) flow including ego motion (the h5 ``<res_name>`` payload)."""
         return self.net.forward_device(s.pch1, s.pc0, s.pc1, s.pose_h1, s.pose0, s.pose1, out=out)
 
-    def run(self, samples, sensor_dt: float = 0.1, refined: bool = False) -> dict:
+    def run(self, samples, sensor_dt: float = 0.1, refined: bool = False, copy: bool = False) -> dict:
         """flow + comp_dis for a list of samples; asynchronous on the current stream.
-        Returns {"flow", "comp_dis"[, "refined"]} as (T,3) tensors plus "batch" for splitting per frame."""
+        Returns {"flow", "comp_dis"[, "refined"]} as (T,3) tensors plus "batch" for splitting per frame.
+
+        LIFETIME of the returned tensors: they are views of two alternating grow-only buffer sets, valid until the
+        NEXT-BUT-ONE ``run`` overwrites them (batch k's results survive batch k+1 -- a caller draining on a side stream --
+        and are gone after batch k+2 is launched).  A caller that collects results over many batches
+        (``outs = [pipe.run(b) for b in batches]``) must pass ``copy=True`` (fresh tensors, one device copy per output) or
+        clone what it keeps."""
         batch = self._batch_for(samples)
         o = batch.offsets_host
         self.sync_check()                                    # the PREVIOUS batch's flag: no stall on this one
@@ -181,4 +187,7 @@ class HiMoPipeline:
         if refined:
             out["refined"] = self._rows("refined", T, 3)
         res = self.compdis.run(batch, sensor_dt=sensor_dt, refined=refined, out=out)
-        return {"flow": batch.flow, "comp_dis": res["comp_dis"], "refined": res.get("refined"), "batch": batch}
+        out = {"flow": batch.flow, "comp_dis": res["comp_dis"], "refined": res.get("refined"), "batch": batch}
+        if copy:
+            out.update({k: out[k].clone() for k in ("flow", "comp_dis", "refined") if out[k] is not None})
+        return out

@@ -21,6 +21,25 @@ import numpy as np
 from .pipeline import HiMoPipeline, Sample
 
 
+class _FrameCache:
+    """``dataset[i]`` with the last few frames kept: the walk below touches frame i as "next" of i-1, as itself, and as
+    "history" of i+1 -- one file read instead of three (h5 / npz reads are the slow part of ``save``)."""
+
+    def __init__(self, dataset, keep: int = 4):
+        self.dataset, self.keep, self._frames = dataset, keep, {}
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, i):
+        f = self._frames.get(i)
+        if f is None:
+            f = self._frames[i] = self.dataset[i]
+            while len(self._frames) > self.keep:
+                self._frames.pop(min(self._frames))               # the walk is ascending: the lowest index is the stale one
+        return f
+
+
 def history_of(dataset, i: int):
     """The history sweep of frame i: the previous frame of the same scene, else the frame itself."""
     f = dataset[i]
@@ -85,6 +104,7 @@ def frame_source(dataset, rank: int = 0, world: int = 1, by_scene: bool = False)
     """(index, history frame, frame, next frame | None) for every frame of this rank that has a next sweep to flow into.
     ``by_scene``: shard whole scenes (scene k of the walk -> rank k % world) instead of frames."""
     index = getattr(dataset, "index", None)
+    dataset = _FrameCache(dataset)
     if by_scene and index is not None:
         scenes = {}
         for s, _ in index:
@@ -154,13 +174,9 @@ def main(checkpoint: str = "", dataset_path: str = "", res_name: str = ""):
         done, err = 0, None
         try:
             done = run(ds, name, params, sink=sink, by_scene=not npz)
-        except BaseException as e:                              # arrive at the rendezvous anyway, then re-raise
+        except Exception as e:                                  # arrive at the rendezvous anyway, then re-raise
             err = e
-        everyone = distenv.all_ranks_ok(err is None)
-        if err is not None:
-            raise err
-        if not everyone:
-            raise RuntimeError("another rank failed while writing flow results; this rank's share is complete")
+        distenv.rendezvous(err, "writing its share of the flow results")
         return done
 
 

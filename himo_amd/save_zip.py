@@ -175,13 +175,9 @@ def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo/demo", res_name: s
         try:
             dataset = open_dataset(data_dir, vis_name=res_name, eval=True)
             run_dataset(dataset, res_name, output_dir, batch_frames=batch_frames)
-        except BaseException as e:
+        except Exception as e:                                   # (an interrupt leaves at once; the launcher ends the job)
             err = e
-        everyone = distenv.all_ranks_ok(err is None)            # every rank's files are on disk -- or somebody failed
-        if err is not None:
-            raise err
-        if not everyone:
-            raise RuntimeError("another rank failed; no submit zip was written")
+        distenv.rendezvous(err, "its Feather files, but no submit zip was written")   # every rank's files are on disk -- or somebody failed
         if rank == 0:
             zip_res(output_dir, output_file=f"{output_dir}/{res_name}-submit.zip")
         if world > 1:

@@ -92,13 +92,30 @@ class TopK:
         self.directory, self.k, self.prefix = Path(directory), int(k), prefix
         self.directory.mkdir(parents=True, exist_ok=True)
         self.kept = []                                       # (val, path)
+        # a resumed run continues the ranking of the files already in the directory (else more than k accumulate)
+        for path in sorted(self.directory.glob(f"{self.prefix}-epoch*-val*.npz")):
+            try:
+                with np.load(path) as z:
+                    val = float(z["__val__"])
+            except Exception:
+                continue
+            if np.isfinite(val):
+                self.kept.append((val, path))
+        self.kept.sort(key=lambda t: t[0])
+        for _, old in self.kept[self.k:]:
+            old.unlink(missing_ok=True)
+        self.kept = self.kept[:self.k]
 
     def offer(self, val: float, epoch: int, params: dict, **extra):
-        """Returns the path written, or None when ``val`` does not make the top k."""
+        """Returns the path written, or None when ``val`` does not make the top k (a non-finite figure never does)."""
+        val = float(val)
+        if not np.isfinite(val):
+            return None
         if len(self.kept) >= self.k and val >= max(v for v, _ in self.kept):
             return None
         path = save_params(self.directory / f"{self.prefix}-epoch{epoch:02d}-val{val:.4f}.npz", params, epoch=epoch, val=val, **extra)
-        self.kept.append((float(val), path))
+        self.kept = [(v, p) for v, p in self.kept if p != path]          # re-offering an epoch replaces its file
+        self.kept.append((val, path))
         self.kept.sort(key=lambda t: t[0])
         for _, old in self.kept[self.k:]:
             old.unlink(missing_ok=True)

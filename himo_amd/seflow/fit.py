@@ -3,8 +3,9 @@
 +optimizer.scheduler.name=StepLR +...step_size=3 +...gamma=0.5``, assets/slurm/ssl-train-av2.sh:31-34, on 4 GPUs :3).
 
 PARITY UNPINNED: ``OpenSceneFlow/train.py`` is absent, so only the launcher's numbers are mirrored: epochs over the
-dataset, ``batch_size`` samples per optimiser step (spread over the ranks: every rank averages the gradients of ITS
-samples, then ONE flat all-reduce averages the ranks), Adam at ``lr`` with StepLR(step_size, gamma) per epoch, the
+dataset, ``batch_size`` samples per optimiser step (spread over the ranks: every rank sums the gradients of ITS
+samples, ONE flat all-reduce adds the ranks' sums and sample counts, and the sum is divided by the global count: every
+sample of a batch weighs the same however it splits over the ranks), Adam at ``lr`` with StepLR(step_size, gamma) per epoch, the
 ``save_top`` best checkpoints kept by the epoch's validation (or mean training) loss, and resuming from a checkpoint.
 Conventions of this build: BatchNorm stays FROZEN -- running statistics and affine folded into
 constants, the usual fine-tuning convention -- so there is no batch-statistics pass and no BN backward; labels are the
@@ -24,25 +25,40 @@ from .train import SeFlowTrainer
 
 def triplets(dataset):
     """(history, current, next) frame indices of every frame that has a successor in its scene (the history frame is the
-    previous sweep of the scene, else the frame itself -- ``num_frames=3``, ssl-train-av2.sh:32)."""
+    previous sweep of the scene, else the frame itself -- ``num_frames=3``, ssl-train-av2.sh:32).  A dataset whose frames
+    carry their successor themselves (``HDF5Dataset``: ``pc1`` / ``pose1`` come from the next timestamp, and successor-less
+    sweeps are not in its index at all) yields ``next = None`` for EVERY entry -- the last usable sweep of a scene included."""
+    index = getattr(dataset, "index", None)
+    scene = (lambda i: index[i][0]) if index is not None else (lambda i: dataset[i].get("scene_id"))
+    n = len(dataset)
+    carries_next = n > 0 and "pc1" in dataset[0]
     out = []
-    for i in range(len(dataset) - 1):
-        f0, f1 = dataset[i], dataset[i + 1]
-        if f0.get("scene_id") != f1.get("scene_id"):
-            continue
-        ih = i - 1 if i > 0 and dataset[i - 1].get("scene_id") == f0.get("scene_id") else i
-        out.append((ih, i, i + 1))
+    for i in range(n):
+        ih = i - 1 if i > 0 and scene(i - 1) == scene(i) else i
+        if carries_next:
+            out.append((ih, i, None))
+        elif i + 1 < n and scene(i + 1) == scene(i):
+            out.append((ih, i, i + 1))
     return out
 
 
 def make_sample(dataset, trip, device, label_key: str = "flow_instance_id"):
     """(pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels) on ``device`` for one triplet."""
-    fh, f0, f1 = (dataset[i] for i in trip)
+    ih, i0, i1 = trip
+    f0 = dataset[i0]
+    fh = dataset[ih] if ih != i0 else f0
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
-    lab = lambda f: torch.from_numpy(np.ascontiguousarray(f[label_key]).astype(np.int32)).to(device)
-    l0, l1 = lab(f0), lab(f1)
-    n_labels = int(max(int(f0[label_key].max(initial=0)), int(f1[label_key].max(initial=0)))) + 1
-    return (up(fh["pc0"]), up(f0["pc0"]), up(f1["pc0"]), np.asarray(fh["pose0"], np.float64), np.asarray(f0["pose0"], np.float64),
+    lab = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).to(device)
+    if i1 is None:                                            # the frame carries its successor (HDF5Dataset)
+        pc1, lab1 = f0["pc1"], f0.get(label_key + "_next")
+        if lab1 is None:
+            raise KeyError(f"{label_key}_next: the frame carries pc1 but not its labels")
+    else:
+        f1 = dataset[i1]
+        pc1, lab1 = f1["pc0"], f1[label_key]
+    l0, l1 = lab(f0[label_key]), lab(lab1)
+    n_labels = int(max(int(np.max(f0[label_key], initial=0)), int(np.max(lab1, initial=0)))) + 1
+    return (up(fh["pc0"]), up(f0["pc0"]), up(pc1), np.asarray(fh["pose0"], np.float64), np.asarray(f0["pose0"], np.float64),
             np.asarray(f0["pose1"], np.float64), l0, l1, n_labels)
 
 
@@ -78,10 +94,8 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
             if max_steps is not None and steps_done >= max_steps:
                 break
             batch = order[s * batch_size:(s + 1) * batch_size]
-            mine = [trips[j] for j in batch[rank::world]]
-            if not mine:                                     # fewer samples than ranks in a last partial batch: an extra copy keeps
-                mine = [trips[batch[0]]]                     # every rank in the collective (weights it slightly more)
-            loss = tr.train_batch((make_sample(dataset, t, dev) for t in mine), lr=lr_e)
+            mine = [trips[j] for j in batch[rank::world]]    # may be empty in a partial last batch: the rank still joins the
+            loss = tr.train_batch((make_sample(dataset, t, dev) for t in mine), lr=lr_e)      # all-reduce, with zeros
             losses.append(loss)
             steps_done += 1
         train_loss = float(torch.stack(losses).mean().item()) if losses else float("nan")

@@ -134,7 +134,7 @@ class SeFlowNet:
         self.autotune = autotune
         self.keep_cell_lists = False
         self.fused_head = precision != "f32"          # one kernel for gather + GRU + output (csrc/gruhead.hip)
-        self.incremental_images = True                # pillar images: write only the cells that changed since the last forward
+        self._incremental_images = True               # pillar images: write only the cells that changed since the last forward
         self.use_plan = True                          # replay the backbone's operator list from one call (csrc/plan.hip)
         self.use_graph = True                         # ... as a captured hipGraph
         self._plans = {}                              # samples per launch -> recorded operator list
@@ -144,7 +144,7 @@ class SeFlowNet:
         # fp16 split: every map of the backbone (pillar images, encoder / decoder maps; not the decoder output the head
         # gathers) is stored already split -- fp16 pairs in place of floats, csrc/convsg.hip -- and staged by LDS-DMA;
         # results are bit-identical either way.  False keeps every activation buffer float32 (the training pass reads them)
-        self.split_acts = precision == "f16x2"
+        self._split_acts = precision == "f16x2"
         self.tiles = {}
         self.lib = _lib.load()
         self.device = device if device is not None else _lib.require_gpu()
@@ -210,7 +210,7 @@ class SeFlowNet:
         dev = self.device
         B = self.max_batch
         buf = lambda *shape: torch.empty((B, *shape), dtype=torch.float32, device=dev)      # [sample][...]
-        self.B0 = buf(H * W, 32 * F)                                   # 3 pillar images as channel groups
+        self._B0 = buf(H * W, 32 * F)                                  # 3 pillar images as channel groups
         self.E1 = [buf(F, (H // 2) * (W // 2), 64) for _ in range(2)]
         self.F1 = buf((H // 2) * (W // 2), 64 * F)
         self.E2 = [buf(F, (H // 4) * (W // 4), 128) for _ in range(2)]
@@ -258,10 +258,46 @@ class SeFlowNet:
         self.zbuf = torch.empty((n, 128), dtype=torch.float32, device=dev)
         self.y1 = torch.empty((n, 32), dtype=torch.float32, device=dev)
 
+    # The incremental pillar images rest on one invariant: the occupancy bits at the tail of every sweep workspace describe
+    # what B0's slot of that sweep holds RIGHT NOW, in the current activation format.  Everything that can break it goes
+    # through a setter that marks all cells dirty again (the next forward then rewrites the whole image).
+    @property
+    def incremental_images(self) -> bool:
+        return self._incremental_images
+
+    @incremental_images.setter
+    def incremental_images(self, on: bool):
+        on = bool(on)
+        if on != self._incremental_images:
+            self._incremental_images = on
+            self.reset_images()                        # whatever was written while it was off is not in the bitmap
+
+    @property
+    def split_acts(self) -> bool:
+        return self._split_acts
+
+    @split_acts.setter
+    def split_acts(self, on: bool):
+        on = bool(on)
+        if on != self._split_acts:
+            self._split_acts = on
+            self.drop_plan()                           # recorded operator lists carry the old layout flags
+            self.reset_images()                        # the persisted image bytes are in the other format
+
+    @property
+    def B0(self):
+        return self._B0
+
+    @B0.setter
+    def B0(self, buf):
+        self._B0 = buf                                 # a rebound / reallocated image buffer holds arbitrary bytes
+        self.drop_plan()
+        self.reset_images()
+
     def reset_images(self):
         """Mark every pillar-image cell dirty (the next forward rewrites the whole image).  Needed only after something other
         than this network's own pillar stage wrote into B0, or after switching ``incremental_images`` back on."""
-        for st in self._pt:
+        for st in getattr(self, "_pt", ()):
             for ws in st["ws_slots"]:
                 _lib.check(self.lib.himo_pillar_occupancy_reset(ws.data_ptr(), ws.numel(), self.W, self.H, _lib.stream_handle()),
                            "himo_pillar_occupancy_reset")

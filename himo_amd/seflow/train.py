@@ -269,6 +269,32 @@ def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
+    """In-place SUM over the ranks of the default process group (no-op without one)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        if flat.is_cuda and dist.get_backend() == "gloo":         # see allreduce_mean_
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def combine_batch_(flat_acc: torch.Tensor, flat_g: torch.Tensor) -> torch.Tensor:
+    """The data-parallel exchange of ``train_batch``: ``flat_acc`` = [this rank's gradient SUM | its sample count | its loss
+    sum] -> ONE all-reduce (sum over ranks) -> ``flat_g`` = global gradient sum / global count.  Returns the global mean loss.
+    Every sample of the global batch gets weight 1 / count whatever the split over the ranks (2,1,1,1 or an empty rank)."""
+    n = flat_g.numel()
+    allreduce_sum_(flat_acc)
+    count = flat_acc[n]
+    if float(count.item()) <= 0.0:
+        raise ValueError("train_batch needs at least one sample on some rank")
+    torch.div(flat_acc[:n], count, out=flat_g)
+    return (flat_acc[n + 1] / count).clone()
+
+
 class SeFlowTrainer:
     """Whole-network training step.  Conventions (PARITY UNPINNED, this build's own): float32 MFMA kernels, BatchNorm
     fully frozen (running statistics AND affine folded into constant scale / shift), trainable = every weight and bias.
@@ -642,23 +668,24 @@ class SeFlowTrainer:
 
     def train_batch(self, samples, lr: float = 6e-5):
         """One optimisation step on SEVERAL samples per rank (the launcher's ``batch_size=8`` on fewer than 8 GPUs):
-        ``samples`` = iterable of (pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels); the per-sample
-        gradients are averaged in a second flat buffer, then one all-reduce and one Adam step.  Returns the mean loss."""
-        if not hasattr(self, "flat_acc"):
-            self.flat_acc = torch.zeros_like(self.flat_g)
+        ``samples`` = iterable of (pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels).  Every sample of the
+        GLOBAL batch weighs the same whatever the split over the ranks: each rank sums its per-sample gradients (and its
+        sample count and loss) in one flat buffer, ONE all-reduce adds the ranks, and the sum is divided by the global
+        count once.  A rank may hold no sample of a partial last batch -- it still enters the collective with zeros.
+        Returns the mean loss over the global batch (the same number on every rank)."""
+        n = self.flat_g.numel()
+        if not hasattr(self, "flat_acc") or self.flat_acc.numel() != n + 2:
+            self.flat_acc = torch.zeros(n + 2, dtype=self.flat_g.dtype, device=self.flat_g.device)   # [gradient sum | count | loss sum]
         self.flat_acc.zero_()
-        mean, count = None, 0
+        acc = self.flat_acc[:n]
         for smp in samples:
             _, total = self.loss_and_grad(*smp)
-            self.flat_acc.add_(self.flat_g)
-            mean = total if mean is None else mean + total
-            count += 1
-        if count == 0:
-            raise ValueError("train_batch needs at least one sample")
-        torch.mul(self.flat_acc, 1.0 / count, out=self.flat_g)
-        self.allreduce()
+            acc.add_(self.flat_g)
+            self.flat_acc[n] += 1.0
+            self.flat_acc[n + 1] += total.to(self.flat_acc.dtype)
+        loss = combine_batch_(self.flat_acc, self.flat_g)
         self.adam_step(lr)
-        return mean / count
+        return loss
 
     @staticmethod
     def step_lr(epoch: int, base_lr: float = 6e-5, step_size: int = 3, gamma: float = 0.5) -> float:

@@ -44,3 +44,15 @@ def test_top_k_keeps_the_best_three(tmp_path):
     kept = sorted(float(ck.load_params(p, with_extra=True)[1]["val"]) for p in tmp_path.glob("*.npz"))
     assert kept == [0.3, 0.5, 0.7]
     assert float(ck.load_params(top.best(), with_extra=True)[1]["val"]) == 0.3
+
+
+def test_top_k_resumes_its_ranking_and_rejects_non_finite_figures(tmp_path):
+    params = spec.init_params(8)
+    first = ck.TopK(tmp_path, k=2)
+    for e, v in enumerate([0.6, 0.4, 0.5]):
+        first.offer(v, e, params)
+    resumed = ck.TopK(tmp_path, k=2)                               # --resume: a fresh object over the same directory
+    assert sorted(v for v, _ in resumed.kept) == [0.4, 0.5]
+    assert resumed.offer(float("nan"), 3, params) is None and resumed.offer(float("inf"), 3, params) is None
+    assert resumed.offer(0.45, 4, params) is not None
+    assert sorted(float(ck.load_params(p, with_extra=True)[1]["val"]) for p in tmp_path.glob("*.npz")) == [0.4, 0.45]   # never more than k

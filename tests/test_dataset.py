@@ -59,7 +59,7 @@ def test_reference_frame_lists_load_and_every_eval_frame_has_a_successor(tmp_pat
     assert len(ev) == 70 and len({s for s, _ in ev}) == 13 and len(total) == 2040
     assert all(isinstance(s, str) and isinstance(t, str) for s, t in ev)
     ds = HDF5Dataset(tmp_path, vis_name="seflowpp_best", eval=True, opener=_memory_opener({}))
-    assert len(ds) == 70 and ds.index == ev
+    assert len(ds) == 70 and ds.index == ev and ds.dropped == []     # every entry of the shipped eval list survives the loader
     full = HDF5Dataset(tmp_path, opener=_memory_opener({}))
     assert len(full) == 2040 - 13                                  # the last sweep of each scene cannot be compensated
     nxt = {(s, t): t1 for (s, t), (s1, t1) in zip(total[:-1], total[1:]) if s == s1}
@@ -85,8 +85,14 @@ def test_hdf5_dataset_logic_through_the_opener_hook(tmp_path):
     assert np.array_equal(d[flow_name], frames[1][flow_name]) and d["lidar_dt"].dtype == np.float32
     for k in ("flow", "flow_is_valid", "flow_category_indices", "flow_instance_id", "lidar_id"):
         assert np.array_equal(d[k], frames[1][k]), k
-    ev = HDF5Dataset(tmp_path, vis_name=flow_name, eval=True, opener=_memory_opener(scenes))
-    assert [t for _, t in ev.index] == [str(frames[0]["timestamp"]), str(frames[4]["timestamp"])]      # frame 2 has no successor
+    # frame 2 of the eval list has no successor: a sweep the leaderboard expects would silently go missing -> loud by default
+    with pytest.raises(KeyError, match="pose1"):
+        HDF5Dataset(tmp_path, vis_name=flow_name, eval=True, opener=_memory_opener(scenes))
+    with pytest.warns(UserWarning, match="no successor"):
+        ev = HDF5Dataset(tmp_path, vis_name=flow_name, eval=True, opener=_memory_opener(scenes), allow_dropped_eval=True)
+    assert [t for _, t in ev.index] == [str(frames[0]["timestamp"]), str(frames[4]["timestamp"])]
+    assert ev.dropped == [("scene0", str(frames[2]["timestamp"]))]
+    assert len(ds.dropped) == 2                                     # the scene ends of index_total.pkl: noted, not an error
     raw = HDF5Dataset(tmp_path, vis_name="raw", opener=_memory_opener(scenes))[0]
     assert flow_name not in raw
     # the frames it yields are exactly what the comp_dis path consumes
@@ -94,6 +100,20 @@ def test_hdf5_dataset_logic_through_the_opener_hook(tmp_path):
     import torch
     b = FrameBatch.from_frames([ds[0], ds[1]], flow_name, device=torch.device("cpu"), with_masks=True)
     assert b.total_points == 50 + 51
+
+
+def test_training_triplets_use_the_successor_a_frame_carries(tmp_path):
+    """the last usable sweep of every h5 scene was lost to the training loop, because its successor is not in
+    the index although the frame itself carries pc1 (and now the successor's cluster labels)."""
+    from himo_amd.seflow.fit import triplets
+    frames = [make_frame(i, n_points=40 + i, scene_id=f"scene{i // 3}") for i in range(6)]
+    _dataset_dir(tmp_path, frames)
+    ds = HDF5Dataset(tmp_path, opener=_memory_opener(_scene_groups(frames)))
+    assert triplets(ds) == [(0, 0, None), (0, 1, None), (2, 2, None), (2, 3, None)]      # 4 usable sweeps, all of them
+    d = ds[1]
+    assert np.array_equal(d["flow_instance_id_next"], frames[2]["flow_instance_id"]) and len(d["pc1"]) == len(frames[2]["pc0"])
+    from himo_amd.dataset import ListDataset
+    assert triplets(ListDataset(frames)) == [(0, 0, 1), (0, 1, 2), (3, 3, 4), (3, 4, 5)]
 
 
 def test_h5_result_sink_writes_res_name_per_timestamp_and_only_after_the_scene(tmp_path):

@@ -311,3 +311,34 @@ def test_eval_cli_under_torchrun_env_shards_the_sweeps(tmp_path):
     mp.spawn(_worker_eval_cli, args=(2, _free_port(), str(root), str(out)), nprocs=2, join=True)
     for r in range(2):                                           # after the gather every rank holds all 7 sweeps, once each
         assert (out / f"cnt{r}").read_text() == "7 [0, 1, 2, 3, 4, 5, 6]"
+
+
+def _worker_combine(rank, world, port, out_dir):
+    _init(rank, world, port)
+    from himo_amd.seflow.train import combine_batch_
+    # a partial last batch of 3 samples on 2 ranks: rank 0 holds samples 0 and 2, rank 1 holds sample 1
+    grads = [torch.tensor([1.0, 2.0, 3.0]), torch.tensor([10.0, 20.0, 30.0]), torch.tensor([100.0, 200.0, 300.0])]
+    losses = [1.0, 2.0, 6.0]
+    out = {}
+    for name, split in (("2+1", [[0, 2], [1]]), ("3+0", [[0, 1, 2], []])):
+        mine = split[rank]
+        acc = torch.zeros(5)
+        for j in mine:
+            acc[:3] += grads[j]; acc[3] += 1.0; acc[4] += losses[j]
+        g = torch.zeros(3)
+        loss = combine_batch_(acc, g)
+        out[name] = {"g": g.tolist(), "loss": float(loss)}
+    Path(out_dir, f"rank{rank}.json").write_text(json.dumps(out))
+    dist.destroy_process_group()
+
+
+def test_train_batch_exchange_weighs_every_sample_of_the_global_batch_alike(tmp_path):
+    """'each rank averages its own samples and the ranks are then averaged' gave the samples of an uneven split
+    unequal weight, and an empty rank re-used a sample.  Now: gradient sums + counts all-reduced, divided once."""
+    port = _free_port()
+    mp.spawn(_worker_combine, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    want_g, want_loss = [37.0, 74.0, 111.0], 3.0
+    for r in range(2):
+        got = json.loads(Path(tmp_path, f"rank{r}.json").read_text())
+        for name in ("2+1", "3+0"):
+            assert got[name]["g"] == pytest.approx(want_g) and got[name]["loss"] == pytest.approx(want_loss), (r, name)

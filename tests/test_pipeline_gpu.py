@@ -232,6 +232,11 @@ def test_streaming_temporaries_never_see_a_previous_batch(gpu, oracle):
     assert torch.equal(a["comp_dis"], keep)
     # refined is only handed out when asked for
     assert a["refined"] is None
+    # ... and are overwritten by batch k+2 unless the caller asked for copies (the lifetime is part of run()'s contract)
+    kept = [pipe.run([Sample.from_frames(frames[i], frames[i + 1], frames[i + 2], device=gpu)], copy=True) for i in range(4)]
+    for i, r in enumerate(kept):
+        alone = HiMoPipeline(net=pipe.net, device=gpu).flow(Sample.from_frames(frames[i], frames[i + 1], frames[i + 2], device=gpu))
+        assert torch.equal(r["flow"], alone), i
 
 
 def test_flows_never_returns_an_overflowed_batch(gpu):

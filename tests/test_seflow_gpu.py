@@ -99,6 +99,31 @@ def test_pillar_front_end_is_deterministic_and_handles_out_of_range(gpu, net):
     assert torch.equal(a, net.B0)                              # every cell rewritten: no stale data
 
 
+def test_incremental_images_survive_every_way_of_invalidating_them(gpu, net):
+    """The occupancy bitmap must describe B0's current bytes: switching ``incremental_images`` off and on again, rebinding
+    B0, or changing the activation format all mark every cell dirty, so no stale row survives (the invariant
+    used to be the caller's job)."""
+    a_pts = torch.rand(20_000, 4, device=gpu) * 60 - 30
+    b_pts = torch.rand(5_000, 4, device=gpu) * 20 - 10
+    was = net.incremental_images
+    try:
+        net.incremental_images = True
+        net.pillarize_into(0, b_pts, np.eye(4))
+        want = net.B0.clone()                                      # image of b_pts alone
+        net.incremental_images = False
+        net.pillarize_into(0, a_pts, np.eye(4))                    # written while the bitmap is not maintained
+        net.incremental_images = True                              # -> everything dirty again
+        net.pillarize_into(0, b_pts, np.eye(4))
+        assert torch.equal(net.B0, want)
+        net.pillarize_into(0, a_pts, np.eye(4))
+        net.B0 = torch.full_like(net.B0, 7.0)                      # a rebound buffer full of foreign bytes
+        net.pillarize_into(0, b_pts, np.eye(4))
+        assert torch.equal(net.B0[..., :32], want[..., :32])       # slot 0 fully rewritten (the other slots were never pillarised)
+    finally:
+        net.incremental_images = was
+        net.reset_images()
+
+
 @pytest.mark.parametrize("precision", ["bf16x3", "f16x2", "f32"])
 def test_full_forward_matches_cpu_restatement(gpu, so, params, precision):
     from himo_amd.seflow.model import SeFlowNet
