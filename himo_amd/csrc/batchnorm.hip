@@ -1,0 +1,295 @@
+// batchnorm.hip -- stage a11, BatchNorm in TRAINING mode for the encoder's conv -> BN -> GELU layers (BASELINE config 5).
+//
+// Why it exists: the reference's job trains from scratch (assets/slurm/ssl-train-av2.sh:31-34 passes no checkpoint=,
+// 12 epochs, batch_size=8), so its BatchNorm layers normalise with BATCH statistics, learn gamma / beta and update their
+// running statistics.  PARITY UNPINNED: the network source (OpenSceneFlow) is absent; the semantics below are
+// torch.nn.BatchNorm2d's (biased variance for the normalisation, unbiased for the running estimate, momentum 0.1) applied
+// to this build's own specification (himo_amd/seflow/spec.py: the statistics of a layer are taken over the images of ONE
+// forward call -- the F frames of a sample, frames as the batch); oracle: oracle/seflow_oracle.py forward_train(training=True).
+//
+// All three stages are HBM-bound streams over an [n_img][rows][ch] NHWC map with a per-channel reduction:
+//   forward   stats (read x once, float64 sums)  ->  finalize  ->  normalise + GELU (read x, write xhat and y)
+//   backward  g = dy * gelu'(gamma xhat + beta) written to dx, float64 sums of g and g xhat  ->  finalize  ->
+//             dx = gamma invstd (g - mean(g) - xhat mean(g xhat))            (in place on dx)
+// Every reduction is a fixed two-level tree (block partials -> one block per 128 channels): bit-deterministic, no atomics.
+// Algorithmic bytes per element: forward 4 + 4 + 8 = 16 B, backward 8 + 4 + 8 + 4 = 24 B.
+#include "himo_common.h"
+#include <math.h>
+
+namespace himo {
+
+struct BnMap {                 // [n_img][rows][ch] view: element (i, r, c) at p + i * img_stride + r * pitch + c
+    const float* p; int64_t img_stride; int pitch;
+};
+struct BnMapW { float* p; int64_t img_stride; int pitch; };
+
+__device__ inline float bn_gelu(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ inline float bn_gelu_grad(float v) {
+    return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.39894228040143267794f * expf(-0.5f * v * v);
+}
+
+// block = 8 row groups x 32 float4 columns (a 128-channel tile, blockIdx.y) over `rows_pb` consecutive global rows
+__device__ inline int64_t bn_addr(int64_t r, int64_t rows, int64_t img_stride, int pitch) {
+    const int64_t img = r / rows;
+    return img * img_stride + (r - img * rows) * pitch;
+}
+
+// ---- forward: per-channel sum and sum of squares (float64) -------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(int64_t total, int64_t rows, int ch, BnMap x, double* __restrict__ partial,
+                                                               int rows_pb) {
+    const int q = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int col = (int)blockIdx.y * 128 + q * 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_pb;
+    const int64_t r1 = r0 + rows_pb < total ? r0 + rows_pb : total;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    if (col < ch) {
+#pragma unroll 4
+        for (int64_t r = r0 + grp; r < r1; r += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(x.p + bn_addr(r, rows, x.img_stride, x.pitch) + col);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
+        }
+    }
+    __shared__ double sh[2][8][128];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sh[0][grp][q * 4 + k] = s[k]; sh[1][grp][q * 4 + k] = ss[k]; }
+    __syncthreads();
+    const int which = threadIdx.x >> 7, lc = threadIdx.x & 127;
+    double t = sh[which][0][lc];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += sh[which][g][lc];
+    partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + which) * 128 + lc] = t;
+}
+
+// one block per 128-channel tile: fixed-order sum of the block partials, then the layer's constants.
+// consts [4][ch]: mean, invstd (forward) -- the backward reuses the buffer for its own three coefficient rows.
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const double* __restrict__ partial, int n_blocks, int ch, double count,
+                                                                float eps, float momentum, float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var, float* __restrict__ mean_out,
+                                                                float* __restrict__ invstd_out) {
+    __shared__ double sh[2][4][128];
+    const int lc = threadIdx.x & 127, which = (threadIdx.x >> 7) & 1, grp = threadIdx.x >> 8;     // 4 groups x 2 sums x 128 channels
+    const int col = (int)blockIdx.x * 128 + lc;
+    double t = 0.0;
+    if (col < ch)
+        for (int b = grp; b < n_blocks; b += 4) t += partial[(((int64_t)blockIdx.x * n_blocks + b) * 2 + which) * 128 + lc];
+    sh[which][grp][lc] = t;
+    __syncthreads();
+    if (threadIdx.x < 128 && col < ch) {
+        const double s = (sh[0][0][lc] + sh[0][1][lc]) + (sh[0][2][lc] + sh[0][3][lc]);
+        const double ss = (sh[1][0][lc] + sh[1][1][lc]) + (sh[1][2][lc] + sh[1][3][lc]);
+        const double mean = s / count;
+        double var = ss / count - mean * mean;            // biased: what the normalisation uses
+        if (var < 0.0) var = 0.0;
+        mean_out[col] = (float)mean;
+        invstd_out[col] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {                               // torch: running estimate uses the UNBIASED variance
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[col] = (float)((1.0 - (double)momentum) * (double)running_mean[col] + (double)momentum * mean);
+            running_var[col] = (float)((1.0 - (double)momentum) * (double)running_var[col] + (double)momentum * unbiased);
+        }
+    }
+}
+
+// xhat = (x - mean) * invstd; y = gelu(gamma * xhat + beta)
+__global__ __launch_bounds__(256) void bn_normalize_gelu_kernel(int64_t total, int64_t rows, int ch, BnMap x, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, BnMapW xhat, BnMapW y) {
+    const int c4 = ch >> 2;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total * c4) return;
+    const int64_t r = e / c4;
+    const int col = (int)(e - r * c4) * 4;
+    const int64_t img = r / rows, rr = r - img * rows;
+    const float4 v = *reinterpret_cast<const float4*>(x.p + img * x.img_stride + rr * x.pitch + col);
+    const float4 m = *reinterpret_cast<const float4*>(mean + col), is = *reinterpret_cast<const float4*>(invstd + col);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + col), be = *reinterpret_cast<const float4*>(beta + col);
+    float4 h, o;
+    h.x = (v.x - m.x) * is.x; h.y = (v.y - m.y) * is.y; h.z = (v.z - m.z) * is.z; h.w = (v.w - m.w) * is.w;
+    o.x = bn_gelu(ga.x * h.x + be.x); o.y = bn_gelu(ga.y * h.y + be.y); o.z = bn_gelu(ga.z * h.z + be.z); o.w = bn_gelu(ga.w * h.w + be.w);
+    *reinterpret_cast<float4*>(xhat.p + img * xhat.img_stride + rr * xhat.pitch + col) = h;
+    *reinterpret_cast<float4*>(y.p + img * y.img_stride + rr * y.pitch + col) = o;
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------------------------
+// g = dy * gelu'(gamma * xhat + beta) -> dx; partial float64 sums of g and g * xhat per channel
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(int64_t total, int64_t rows, int ch, BnMap dy, BnMap xhat,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, BnMapW dx,
+                                                             double* __restrict__ partial, int rows_pb) {
+    const int q = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int col = (int)blockIdx.y * 128 + q * 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_pb;
+    const int64_t r1 = r0 + rows_pb < total ? r0 + rows_pb : total;
+    double s[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
+    if (col < ch) {
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + col), be = *reinterpret_cast<const float4*>(beta + col);
+#pragma unroll 2
+        for (int64_t r = r0 + grp; r < r1; r += 8) {
+            const int64_t img = r / rows, rr = r - img * rows;
+            const float4 d = *reinterpret_cast<const float4*>(dy.p + img * dy.img_stride + rr * dy.pitch + col);
+            const float4 h = *reinterpret_cast<const float4*>(xhat.p + img * xhat.img_stride + rr * xhat.pitch + col);
+            float4 g;
+            g.x = d.x * bn_gelu_grad(ga.x * h.x + be.x); g.y = d.y * bn_gelu_grad(ga.y * h.y + be.y);
+            g.z = d.z * bn_gelu_grad(ga.z * h.z + be.z); g.w = d.w * bn_gelu_grad(ga.w * h.w + be.w);
+            *reinterpret_cast<float4*>(dx.p + img * dx.img_stride + rr * dx.pitch + col) = g;
+            s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+            sx[0] += (double)g.x * h.x; sx[1] += (double)g.y * h.y; sx[2] += (double)g.z * h.z; sx[3] += (double)g.w * h.w;
+        }
+    }
+    __shared__ double sh[2][8][128];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sh[0][grp][q * 4 + k] = s[k]; sh[1][grp][q * 4 + k] = sx[k]; }
+    __syncthreads();
+    const int which = threadIdx.x >> 7, lc = threadIdx.x & 127;
+    double t = sh[which][0][lc];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += sh[which][g][lc];
+    partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + which) * 128 + lc] = t;
+}
+
+// dbeta = sum g, dgamma = sum g xhat; coefficient rows for the element-wise pass: k1 = gamma invstd, k2 = dbeta / N, k3 = dgamma / N
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int n_blocks, int ch, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                              float* __restrict__ coef) {
+    __shared__ double sh[2][4][128];
+    const int lc = threadIdx.x & 127, which = (threadIdx.x >> 7) & 1, grp = threadIdx.x >> 8;
+    const int col = (int)blockIdx.x * 128 + lc;
+    double t = 0.0;
+    if (col < ch)
+        for (int b = grp; b < n_blocks; b += 4) t += partial[(((int64_t)blockIdx.x * n_blocks + b) * 2 + which) * 128 + lc];
+    sh[which][grp][lc] = t;
+    __syncthreads();
+    if (threadIdx.x < 128 && col < ch) {
+        const double sg = (sh[0][0][lc] + sh[0][1][lc]) + (sh[0][2][lc] + sh[0][3][lc]);
+        const double sgx = (sh[1][0][lc] + sh[1][1][lc]) + (sh[1][2][lc] + sh[1][3][lc]);
+        dbeta[col] = accumulate ? dbeta[col] + (float)sg : (float)sg;
+        dgamma[col] = accumulate ? dgamma[col] + (float)sgx : (float)sgx;
+        coef[col] = gamma[col] * invstd[col];
+        coef[ch + col] = (float)(sg / count);
+        coef[2 * ch + col] = (float)(sgx / count);
+    }
+}
+
+// dx = k1 * (g - k2 - xhat * k3), in place on dx (which holds g)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int64_t total, int64_t rows, int ch, BnMap xhat, const float* __restrict__ coef,
+                                                           BnMapW dx) {
+    const int c4 = ch >> 2;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total * c4) return;
+    const int64_t r = e / c4;
+    const int col = (int)(e - r * c4) * 4;
+    const int64_t img = r / rows, rr = r - img * rows;
+    float* p = dx.p + img * dx.img_stride + rr * dx.pitch + col;
+    const float4 g = *reinterpret_cast<const float4*>(p);
+    const float4 h = *reinterpret_cast<const float4*>(xhat.p + img * xhat.img_stride + rr * xhat.pitch + col);
+    const float4 k1 = *reinterpret_cast<const float4*>(coef + col), k2 = *reinterpret_cast<const float4*>(coef + ch + col),
+                 k3 = *reinterpret_cast<const float4*>(coef + 2 * ch + col);
+    float4 o;
+    o.x = k1.x * ((g.x - k2.x) - h.x * k3.x); o.y = k1.y * ((g.y - k2.y) - h.y * k3.y);
+    o.z = k1.z * ((g.z - k2.z) - h.z * k3.z); o.w = k1.w * ((g.w - k2.w) - h.w * k3.w);
+    *reinterpret_cast<float4*>(p) = o;
+}
+
+// eval-mode constants from the current running statistics: scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+__global__ __launch_bounds__(256) void bn_fold_kernel(int ch, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                      float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ch) return;
+    const float s = gamma[c] / sqrtf(var[c] + eps);
+    scale[c] = s;
+    shift[c] = beta[c] - mean[c] * s;
+}
+
+static int bn_rows_per_block(int64_t total) {
+    int64_t r = (total + 1023) / 1024;                    // ~1024 blocks of partials at most
+    r = (r + 7) / 8 * 8;
+    return (int)(r < 64 ? 64 : r);
+}
+static size_t bn_ws(int64_t total, int ch) {
+    const size_t nb = (size_t)((total + 63) / 64) < 1025 ? (size_t)((total + 63) / 64) + 1 : 1025;
+    const size_t tiles = (size_t)(ch + 127) / 128;
+    return tiles * nb * 2 * 128 * sizeof(double) + (size_t)4 * ch * sizeof(float) + 64;
+}
+static bool bn_map_ok(const void* p, int64_t img_stride, int pitch, int ch) {
+    return p && !(reinterpret_cast<uintptr_t>(p) & 15) && !(img_stride & 3) && !(pitch & 3) && pitch >= ch;
+}
+
+}  // namespace himo
+
+using namespace himo;
+
+extern "C" size_t himo_bn_workspace_bytes(int64_t total_rows, int ch) { return total_rows > 0 && ch > 0 ? bn_ws(total_rows, ch) : 0; }
+
+extern "C" int himo_bn_train_fwd(int n_img, int64_t rows, int ch, const float* d_x, int64_t x_img_stride, int x_pitch,
+                                 const float* d_gamma, const float* d_beta, float eps, float momentum, float* d_running_mean,
+                                 float* d_running_var, float* d_mean, float* d_invstd, float* d_xhat, int64_t xhat_img_stride, int xhat_pitch,
+                                 float* d_y, int64_t y_img_stride, int y_pitch, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (n_img < 1 || rows < 1 || ch < 4 || (ch & 3) || !d_gamma || !d_beta || !d_mean || !d_invstd || !d_workspace)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    if (!bn_map_ok(d_x, x_img_stride, x_pitch, ch) || !bn_map_ok(d_xhat, xhat_img_stride, xhat_pitch, ch) || !bn_map_ok(d_y, y_img_stride, y_pitch, ch))
+        return HIMO_ERR_UNSUPPORTED;                        // 16-byte accesses: aligned bases, strides multiples of 4 floats
+    if ((d_running_mean == nullptr) != (d_running_var == nullptr)) return HIMO_ERR_INVALID_ARGUMENT;
+    const int64_t total = (int64_t)n_img * rows;
+    if (workspace_bytes < bn_ws(total, ch) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int rows_pb = bn_rows_per_block(total);
+    const int nb = (int)((total + rows_pb - 1) / rows_pb), tiles = (ch + 127) / 128;
+    double* partial = reinterpret_cast<double*>(d_workspace);
+    const BnMap x{d_x, x_img_stride, x_pitch};
+    {
+        ProfScope ps("bn_stats_kernel", s);
+        hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb, tiles), dim3(256), 0, s, total, rows, ch, x, partial, rows_pb);
+        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(tiles), dim3(1024), 0, s, partial, nb, ch, (double)total, eps, momentum, d_running_mean,
+                           d_running_var, d_mean, d_invstd);
+    }
+    HIMO_LAUNCH_CHECK("bn_stats kernels");
+    {
+        ProfScope ps("bn_normalize_gelu_kernel", s);
+        const int64_t n4 = total * (ch >> 2);
+        hipLaunchKernelGGL(bn_normalize_gelu_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, total, rows, ch, x, d_mean, d_invstd,
+                           d_gamma, d_beta, BnMapW{d_xhat, xhat_img_stride, xhat_pitch}, BnMapW{d_y, y_img_stride, y_pitch});
+    }
+    HIMO_LAUNCH_CHECK("bn_normalize_gelu_kernel");
+    return HIMO_OK;
+}
+
+extern "C" int himo_bn_train_bwd(int n_img, int64_t rows, int ch, const float* d_dy, int64_t dy_img_stride, int dy_pitch,
+                                 const float* d_xhat, int64_t xhat_img_stride, int xhat_pitch, const float* d_gamma, const float* d_beta,
+                                 const float* d_invstd, float* d_dx, int64_t dx_img_stride, int dx_pitch, float* d_dgamma, float* d_dbeta,
+                                 unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (n_img < 1 || rows < 1 || ch < 4 || (ch & 3) || !d_gamma || !d_beta || !d_invstd || !d_dgamma || !d_dbeta || !d_workspace)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    if (!bn_map_ok(d_dy, dy_img_stride, dy_pitch, ch) || !bn_map_ok(d_xhat, xhat_img_stride, xhat_pitch, ch) || !bn_map_ok(d_dx, dx_img_stride, dx_pitch, ch))
+        return HIMO_ERR_UNSUPPORTED;
+    const int64_t total = (int64_t)n_img * rows;
+    if (workspace_bytes < bn_ws(total, ch) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int rows_pb = bn_rows_per_block(total);
+    const int nb = (int)((total + rows_pb - 1) / rows_pb), tiles = (ch + 127) / 128;
+    double* partial = reinterpret_cast<double*>(d_workspace);
+    float* coef = reinterpret_cast<float*>(partial + (size_t)tiles * nb * 2 * 128);
+    const BnMap xh{d_xhat, xhat_img_stride, xhat_pitch};
+    const BnMapW dx{d_dx, dx_img_stride, dx_pitch};
+    {
+        ProfScope ps("bn_bwd_kernel", s);
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb, tiles), dim3(256), 0, s, total, rows, ch, BnMap{d_dy, dy_img_stride, dy_pitch}, xh,
+                           d_gamma, d_beta, dx, partial, rows_pb);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tiles), dim3(1024), 0, s, partial, nb, ch, (double)total, d_gamma, d_invstd, d_dgamma,
+                           d_dbeta, (flags & 1u) ? 1 : 0, coef);
+        const int64_t n4 = total * (ch >> 2);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, total, rows, ch, xh, coef, dx);
+    }
+    HIMO_LAUNCH_CHECK("bn_bwd kernels");
+    return HIMO_OK;
+}
+
+extern "C" int himo_bn_fold(int ch, const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_var, float eps,
+                            float* d_scale, float* d_shift, void* stream) {
+    if (ch < 1 || !d_gamma || !d_beta || !d_mean || !d_var || !d_scale || !d_shift) return HIMO_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((ch + 255) / 256), dim3(256), 0, (hipStream_t)stream, ch, d_gamma, d_beta, d_mean, d_var, eps,
+                       d_scale, d_shift);
+    HIMO_LAUNCH_CHECK("bn_fold_kernel");
+    return HIMO_OK;
+}

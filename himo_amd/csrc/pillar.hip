@@ -416,6 +416,168 @@ __global__ __launch_bounds__(256) void pfn_backward_reduce_kernel(const float* _
     }
 }
 
+// ---- BatchNorm of the pillar feature net in TRAINING mode (BASELINE config 5; semantics of torch.nn.BatchNorm1d over the
+// in-range points of ONE sweep -- each sweep is one call of the embedder, oracle/seflow_oracle.py pillar_image(training=True)) ----
+// y = feats W for every point of every cell (the forward's fma chain, the forward's ascending order); per-channel float64
+// sum / sum of squares as block partials [2][32]
+struct PfnBnArgs {
+    PillarBwdArgs b;
+    double* partial;                 // [gridDim.x][2][32]
+    const float* mean; const float* invstd;      // [32] batch statistics (backward)
+    const float* coef;               // [2][32]: mean(g), mean(g * xhat) (backward, pass B)
+};
+
+template <int MODE>                  // 0: statistics of y; 1: sums of g and g * xhat (g = d_image / cnt * [v > 0])
+__global__ __launch_bounds__(256) void pfn_bn_reduce_kernel(PfnBnArgs p) {
+    const PillarBwdArgs& a = p.b;
+    __shared__ double red[2][kCellsPerBlock][32];
+    const int sub = threadIdx.x >> 5, c = threadIdx.x & 31;
+    const int n_cells = a.g.W * a.g.H;
+    float w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = a.pfn_w[k * 32 + c];
+    const float scale = MODE ? a.pfn_scale[c] : 0.f, shift = MODE ? a.pfn_shift[c] : 0.f;
+    const float mean = MODE ? p.mean[c] : 0.f, invstd = MODE ? p.invstd[c] : 0.f;
+    double s0 = 0.0, s1 = 0.0;
+    for (int cell = blockIdx.x * kCellsPerBlock + sub; cell < n_cells; cell += gridDim.x * kCellsPerBlock) {
+        const int beg = cell_offset_b(a, cell);
+        const int cnt = cell_offset_b(a, cell + 1) - beg;
+        if (cnt == 0) continue;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int j = 0; j < cnt; ++j) {
+            const float* q = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
+            sx += q[0]; sy += q[1]; sz += q[2];
+        }
+        const float fc = (float)cnt;
+        const float mx = sx / fc, my = sy / fc, mz = sz / fc;
+        const int iy = cell / a.g.W, ix = cell - iy * a.g.W;
+        const float ccx = (float)ix * a.g.vx + a.g.cx0, ccy = (float)iy * a.g.vy + a.g.cy0, ccz = 0.f * a.g.vz + a.g.cz0;
+        const float gi = MODE ? a.d_image[(int64_t)cell * a.image_pitch + c] / fc : 0.f;
+        for (int j = 0; j < cnt; ++j) {
+            const float* q = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
+            const float x = q[0], y = q[1], z = q[2];
+            const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
+            float v = f[0] * w[0];
+#pragma unroll
+            for (int k = 1; k < 9; ++k) v = fmaf(f[k], w[k], v);
+            if (MODE == 0) {
+                s0 += v; s1 += (double)v * v;
+            } else {
+                const float g = (v * scale + shift) > 0.f ? gi : 0.f;
+                s0 += g; s1 += (double)g * ((v - mean) * invstd);
+            }
+        }
+    }
+    red[0][sub][c] = s0; red[1][sub][c] = s1;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int which = threadIdx.x >> 5;
+        double t = red[which][0][c];
+#pragma unroll
+        for (int q = 1; q < kCellsPerBlock; ++q) t += red[which][q][c];
+        p.partial[((int64_t)blockIdx.x * 2 + which) * 32 + c] = t;
+    }
+}
+
+// one block of 256 threads: 4 groups x 2 sums x 32 channels over the block partials in fixed order, then the constants.
+// MODE 0 (forward): batch mean / invstd, the feature kernel's scale / shift, running-statistics update (unbiased variance).
+// MODE 1 (backward): dgamma / dbeta (accumulated when asked) and the two means the weight-gradient pass needs.
+template <int MODE>
+__global__ __launch_bounds__(256) void pfn_bn_finalize_kernel(const double* __restrict__ partial, int n_blocks, const int* __restrict__ cell_count,
+                                                              const int* __restrict__ block_sum, int n_cells, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, float momentum,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2,
+                                                              float* __restrict__ out3, int accumulate) {
+    __shared__ double sh[2][4][32];
+    const int c = threadIdx.x & 31, which = (threadIdx.x >> 5) & 1, grp = threadIdx.x >> 6;
+    double t = 0.0;
+    for (int b = grp; b < n_blocks; b += 4) t += partial[((int64_t)b * 2 + which) * 32 + c];
+    sh[which][grp][c] = t;
+    __syncthreads();
+    if (threadIdx.x >= 32) return;
+    const double count = (double)block_sum[(n_cells + kScanBlock - 1) / kScanBlock];        // in-range points of the sweep
+    const double a0 = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
+    const double a1 = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
+    (void)cell_count;
+    if (MODE == 0) {
+        if (count < 1.0) {                                   // an empty sweep: nothing to normalise, statistics untouched
+            const float sc = gamma[c] / sqrtf((running_var ? running_var[c] : 1.f) + eps);
+            out0[c] = sc; out1[c] = beta[c] - (running_mean ? running_mean[c] : 0.f) * sc; out2[c] = 0.f; out3[c] = 0.f;
+            return;
+        }
+        const double mean = a0 / count;
+        double var = a1 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        out0[c] = sc;                                        // scale
+        out1[c] = beta[c] - (float)mean * sc;                // shift
+        out2[c] = (float)mean;
+        out3[c] = invstd;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+        }
+    } else {
+        out0[c] = accumulate ? out0[c] + (float)a1 : (float)a1;      // dgamma = sum g xhat
+        out1[c] = accumulate ? out1[c] + (float)a0 : (float)a0;      // dbeta  = sum g
+        out2[c] = count > 0.0 ? (float)(a0 / count) : 0.f;           // coef[0]: mean g
+        out3[c] = count > 0.0 ? (float)(a1 / count) : 0.f;           // coef[1]: mean g xhat
+    }
+}
+
+// weight gradient with batch statistics: dy = scale * (g - mean(g) - xhat * mean(g xhat)) for EVERY in-range point (the two mean
+// terms reach the points the ReLU masked as well), dW[k][c] = sum f_k dy
+__global__ __launch_bounds__(256) void pfn_backward_bn_kernel(PfnBnArgs p) {
+    const PillarBwdArgs& a = p.b;
+    __shared__ float red[kCellsPerBlock][9][32];
+    const int sub = threadIdx.x >> 5, c = threadIdx.x & 31;
+    const int n_cells = a.g.W * a.g.H;
+    float w[9], dw[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { w[k] = a.pfn_w[k * 32 + c]; dw[k] = 0.f; }
+    const float scale = a.pfn_scale[c], shift = a.pfn_shift[c], mean = p.mean[c], invstd = p.invstd[c];
+    const float k2 = p.coef[c], k3 = p.coef[32 + c];
+    for (int cell = blockIdx.x * kCellsPerBlock + sub; cell < n_cells; cell += gridDim.x * kCellsPerBlock) {
+        const int beg = cell_offset_b(a, cell);
+        const int cnt = cell_offset_b(a, cell + 1) - beg;
+        if (cnt == 0) continue;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int j = 0; j < cnt; ++j) {
+            const float* q = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
+            sx += q[0]; sy += q[1]; sz += q[2];
+        }
+        const float fc = (float)cnt;
+        const float mx = sx / fc, my = sy / fc, mz = sz / fc;
+        const int iy = cell / a.g.W, ix = cell - iy * a.g.W;
+        const float ccx = (float)ix * a.g.vx + a.g.cx0, ccy = (float)iy * a.g.vy + a.g.cy0, ccz = 0.f * a.g.vz + a.g.cz0;
+        const float gi = a.d_image[(int64_t)cell * a.image_pitch + c] / fc;
+        for (int j = 0; j < cnt; ++j) {
+            const float* q = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
+            const float x = q[0], y = q[1], z = q[2];
+            const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
+            float v = f[0] * w[0];
+#pragma unroll
+            for (int k = 1; k < 9; ++k) v = fmaf(f[k], w[k], v);
+            const float g = (v * scale + shift) > 0.f ? gi : 0.f;
+            const float dy = scale * ((g - k2) - ((v - mean) * invstd) * k3);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dw[k] += f[k] * dy;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[sub][k][c] = dw[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 9 * 32; e += 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < kCellsPerBlock; ++q) t += red[q][e / 32][e % 32];
+        a.partial[(int64_t)blockIdx.x * 288 + e] = t;
+    }
+}
+
 // adjoint of head_gather_kernel: the per-point gradient rows are summed per cell (ascending point order) into the
 // image gradients; the cells of groups that are not gathered from, and empty cells, are written as zeros
 __global__ __launch_bounds__(256) void head_scatter_kernel(PillarBwdArgs a) {
@@ -616,6 +778,121 @@ extern "C" int himo_pfn_backward(int64_t n, const float* h_voxel, const float* h
     }
     hipLaunchKernelGGL(pfn_backward_reduce_kernel, dim3(9), dim3(256), 0, s, a.partial, kPfnBwdBlocks, d_dweight, (flags & 1u) ? 1 : 0);
     HIMO_LAUNCH_CHECK("pfn_backward kernels");
+    return HIMO_OK;
+}
+
+// ---- training-mode BatchNorm of the pillar feature net: host side ---------------------------------------------------------
+// workspace: the 1024 x 288 floats of himo_pfn_backward + block partials of the two reductions + 64 floats of coefficients
+extern "C" size_t himo_pfn_bn_workspace_bytes(void) {
+    return round_up((size_t)kPfnBwdBlocks * 288 * 4, 64) + (size_t)kPfnBwdBlocks * 2 * 32 * sizeof(double) + 64 * sizeof(float) + 64;
+}
+
+static int pfn_bn_args(PfnBnArgs& p, int64_t n, const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
+                       const float* d_pfn_weight, const float* d_xyz_t, const void* d_pillar_workspace, void* d_workspace,
+                       size_t workspace_bytes) {
+    if (n < 0 || !h_voxel || !h_centre_offset || grid_w < 1 || grid_h < 1 || !d_pfn_weight || !d_pillar_workspace || !d_workspace)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    if (n > 0 && !d_xyz_t) return HIMO_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < himo_pfn_bn_workspace_bytes() || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
+    p = PfnBnArgs{};
+    PillarBwdArgs& a = p.b;
+    a.g.vx = h_voxel[0]; a.g.vy = h_voxel[1]; a.g.vz = h_voxel[2];
+    a.g.cx0 = h_centre_offset[0]; a.g.cy0 = h_centre_offset[1]; a.g.cz0 = h_centre_offset[2];
+    a.g.W = grid_w; a.g.H = grid_h;
+    carve_bwd(a, n, grid_w * grid_h, const_cast<void*>(d_pillar_workspace));
+    a.xyz_t = d_xyz_t; a.pfn_w = d_pfn_weight;
+    a.partial = reinterpret_cast<float*>(d_workspace);
+    p.partial = reinterpret_cast<double*>(reinterpret_cast<char*>(d_workspace) + round_up((size_t)kPfnBwdBlocks * 288 * 4, 64));
+    return HIMO_OK;
+}
+
+// Batch statistics of y = feats W over the in-range points of the sweep whose cell lists himo_pillarize* left in
+// d_pillar_workspace -> d_scale / d_shift (what the feature kernel and the backward pass consume: gamma invstd,
+// beta - mean gamma invstd), d_mean / d_invstd (saved for the backward pass); running statistics updated in place
+// (momentum, unbiased variance; NULL: not tracked).
+extern "C" int himo_pfn_bn_stats(int64_t n, const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
+                                 const float* d_pfn_weight, const float* d_xyz_t, const void* d_pillar_workspace, const float* d_gamma,
+                                 const float* d_beta, float eps, float momentum, float* d_running_mean, float* d_running_var,
+                                 float* d_scale, float* d_shift, float* d_mean, float* d_invstd, void* d_workspace, size_t workspace_bytes,
+                                 void* stream) {
+    if (!d_gamma || !d_beta || !d_scale || !d_shift || !d_mean || !d_invstd || (d_running_mean == nullptr) != (d_running_var == nullptr))
+        return HIMO_ERR_INVALID_ARGUMENT;
+    PfnBnArgs p;
+    const int st = pfn_bn_args(p, n, h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight, d_xyz_t, d_pillar_workspace, d_workspace,
+                               workspace_bytes);
+    if (st != HIMO_OK) return st;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("pfn_bn_stats_kernel", s);
+    hipLaunchKernelGGL(pfn_bn_reduce_kernel<0>, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(pfn_bn_finalize_kernel<0>, dim3(1), dim3(256), 0, s, p.partial, kPfnBwdBlocks, p.b.cell_count, p.b.block_sum,
+                       grid_w * grid_h, d_gamma, d_beta, eps, momentum, d_running_mean, d_running_var, d_scale, d_shift, d_mean, d_invstd, 0);
+    HIMO_LAUNCH_CHECK("pfn_bn_stats kernels");
+    return HIMO_OK;
+}
+
+// The feature kernel alone, with PER-SWEEP BatchNorm constants (d_scale / d_shift: [n_sweeps][32]): the second half of a
+// training-mode pillar stage -- himo_pillarize_multi_ex built the cell lists (its images, written with stale constants, are
+// overwritten here), himo_pfn_bn_stats turned them into each sweep's constants.
+extern "C" int himo_pillar_features_multi(int n_sweeps, const himo_sweep* h_sweeps, const float* h_range, const float* h_voxel,
+                                          const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight,
+                                          const float* d_scale, const float* d_shift, int image_pitch, size_t workspace_bytes,
+                                          int image_split, void* stream) {
+    const bool incremental = (image_split & 2) != 0;
+    image_split &= 1;
+    if (image_split && (image_pitch & 15)) return HIMO_ERR_INVALID_ARGUMENT;
+    if (n_sweeps < 1 || n_sweeps > kMaxSweeps || !h_sweeps || !d_scale || !d_shift) return HIMO_ERR_INVALID_ARGUMENT;
+    if (incremental && ((workspace_bytes & 15) || workspace_bytes < ws_occ(grid_w * grid_h))) return HIMO_ERR_WORKSPACE;
+    PillarBatch m{};
+    for (int i = 0; i < n_sweeps; ++i) {
+        const himo_sweep& w = h_sweeps[i];
+        const int st = pillar_args(m.s[i], w.n, w.d_pts, w.pc_stride, w.transform, h_range, h_voxel, h_centre_offset, grid_w, grid_h,
+                                   d_pfn_weight, d_scale + 32 * i, d_shift + 32 * i, w.d_xyz_t, w.d_pid, w.d_offsets, w.d_image, image_pitch,
+                                   w.d_workspace, workspace_bytes);
+        if (st != HIMO_OK) return st;
+        if (image_split && (reinterpret_cast<uintptr_t>(w.d_image) & 63)) return HIMO_ERR_INVALID_ARGUMENT;
+        m.s[i].image_split = image_split ? 1 : 0;
+        if (incremental) {
+            const size_t nb = ws_occ(grid_w * grid_h);
+            if (workspace_bytes < pillar_ws(w.n, grid_w * grid_h) + nb) return HIMO_ERR_WORKSPACE;
+            m.s[i].occ = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(w.d_workspace) + (workspace_bytes - nb));
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int cells = grid_w * grid_h;
+    {
+        ProfScope ps("pillar_feature_kernel", s);
+        hipLaunchKernelGGL(pillar_feature_kernel, dim3((cells + kFeatCells - 1) / kFeatCells, n_sweeps), dim3(256), 0, s, m);
+    }
+    HIMO_LAUNCH_CHECK("pillar_feature_kernel");
+    return HIMO_OK;
+}
+
+// himo_pfn_backward with batch statistics: also yields d loss / d gamma, d loss / d beta [32] (flags bit 0: accumulate all three)
+extern "C" int himo_pfn_backward_bn(int64_t n, const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
+                                    const float* d_pfn_weight, const float* d_scale, const float* d_shift, const float* d_mean,
+                                    const float* d_invstd, const float* d_xyz_t, const void* d_pillar_workspace, const float* d_dimage,
+                                    int image_pitch, float* d_dweight, float* d_dgamma, float* d_dbeta, unsigned flags, void* d_workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (!d_scale || !d_shift || !d_mean || !d_invstd || !d_dimage || !d_dweight || !d_dgamma || !d_dbeta || image_pitch < 32)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    PfnBnArgs p;
+    const int st = pfn_bn_args(p, n, h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight, d_xyz_t, d_pillar_workspace, d_workspace,
+                               workspace_bytes);
+    if (st != HIMO_OK) return st;
+    p.b.pfn_scale = d_scale; p.b.pfn_shift = d_shift; p.b.d_image = d_dimage; p.b.image_pitch = image_pitch;
+    p.mean = d_mean; p.invstd = d_invstd;
+    float* coef = reinterpret_cast<float*>(p.partial + (size_t)kPfnBwdBlocks * 2 * 32);
+    p.coef = coef;
+    hipStream_t s = (hipStream_t)stream;
+    const int acc = (flags & 1u) ? 1 : 0;
+    ProfScope ps("pfn_backward_kernel", s);
+    hipLaunchKernelGGL(pfn_bn_reduce_kernel<1>, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(pfn_bn_finalize_kernel<1>, dim3(1), dim3(256), 0, s, p.partial, kPfnBwdBlocks, p.b.cell_count, p.b.block_sum,
+                       grid_w * grid_h, (const float*)nullptr, (const float*)nullptr, 0.f, 0.f, (float*)nullptr, (float*)nullptr, d_dgamma,
+                       d_dbeta, coef, coef + 32, acc);
+    hipLaunchKernelGGL(pfn_backward_bn_kernel, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(pfn_backward_reduce_kernel, dim3(9), dim3(256), 0, s, p.b.partial, kPfnBwdBlocks, d_dweight, acc);
+    HIMO_LAUNCH_CHECK("pfn_backward_bn kernels");
     return HIMO_OK;
 }
 

@@ -248,7 +248,22 @@ _lib.register({
     "himo_pfn_backward": (c_i, [c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
     "himo_head_scatter": (c_i, [c_l, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p]),
     "himo_adam_step": (c_i, [c_l, c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_p]),
+    # BatchNorm in training mode (csrc/batchnorm.hip, csrc/pillar.hip)
+    "himo_bn_workspace_bytes": (ctypes.c_size_t, [c_l, c_i]),
+    "himo_bn_train_fwd": (c_i, [c_i, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_l, c_i,
+                                c_p, ctypes.c_size_t, c_p]),
+    "himo_bn_train_bwd": (c_i, [c_i, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_p, ctypes.c_uint,
+                                c_p, ctypes.c_size_t, c_p]),
+    "himo_bn_fold": (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]),
+    "himo_pfn_bn_workspace_bytes": (ctypes.c_size_t, []),
+    "himo_pfn_bn_stats": (c_i, [c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                ctypes.c_size_t, c_p]),
+    "himo_pillar_features_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, ctypes.c_size_t, c_i, c_p]),
+    "himo_pfn_backward_bn": (c_i, [c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, ctypes.c_uint,
+                                   c_p, ctypes.c_size_t, c_p]),
 })
+
+BN_MOMENTUM = 0.1                 # torch.nn.BatchNorm's default; the reference's launcher sets none (ssl-train-av2.sh:31-34)
 
 
 def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
@@ -296,8 +311,13 @@ def combine_batch_(flat_acc: torch.Tensor, flat_g: torch.Tensor) -> torch.Tensor
 
 
 class SeFlowTrainer:
-    """Whole-network training step.  Conventions (PARITY UNPINNED, this build's own): float32 MFMA kernels, BatchNorm
-    fully frozen (running statistics AND affine folded into constant scale / shift), trainable = every weight and bias.
+    """Whole-network training step.  PARITY UNPINNED (``OpenSceneFlow/train.py`` is absent); conventions of this build:
+    ``batchnorm="batch"`` (default) is what a from-scratch job runs (assets/slurm/ssl-train-av2.sh:31-34 passes no
+    checkpoint): every BatchNorm normalises with the statistics of the current forward (pillar net: the in-range points of
+    each sweep; encoder layers: the sample's F frames as the batch), gamma / beta are trained and the running statistics
+    follow with momentum 0.1 -- torch.nn.BatchNorm semantics; ``forward(training=False)`` (validation) uses the running
+    statistics.  ``batchnorm="frozen"`` is the fine-tuning convention: running statistics AND affine folded into constant
+    scale / shift, trainable = every weight and bias.
 
         tr = SeFlowTrainer(params)                       # spec parameter dict
         res = tr.forward(pch1, pc0, pc1, pose_h1, pose0, pose1)     # [n0, 4] network flow of pc0 rows (col 3 = 0)
@@ -306,7 +326,7 @@ class SeFlowTrainer:
     """
 
     def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, seed: int = 0,
-                 precision: str = "bf16x3"):
+                 precision: str = "bf16x3", batchnorm: str = "batch"):
         """``precision``: "bf16x3" runs every stride-1 convolution of the forward and data-gradient passes as split-bf16
         on the matrix cores (float32-class accuracy, csrc/convbf.hip; weights are re-packed after every optimiser step);
         "mixed" runs the FORWARD convolutions as the two-term fp16 split (activations are O(1): inside fp16's range) and
@@ -315,7 +335,10 @@ class SeFlowTrainer:
         from .model import SeFlowNet
         if precision not in ("bf16x3", "mixed", "f32"):
             raise ValueError(precision)
+        if batchnorm not in ("batch", "frozen"):
+            raise ValueError(batchnorm)
         self.precision = precision
+        self.bn_batch = batchnorm == "batch"
         self.fwd_format = 1 if precision == "mixed" else 0          # HIMO_PACK_F16X2 / HIMO_PACK_BF16X3
         # mixed: the stride-1 3x3 weight gradients multiply split-bf16 operands (16 significant bits, float32 sums) on the
         # 16-bit matrix instructions (csrc/train.hip conv_wgrad_split_kernel); the other modes keep float32 matrix instructions
@@ -345,6 +368,10 @@ class SeFlowTrainer:
         host["head.offset.weight"], host["head.offset.bias"] = params["head.offset.weight"], params["head.offset.bias"]
         for k, v in HeadTrainer.host_params(params).items():
             host[f"head.{k}"] = v
+        self.bn_layers = [("pfn.bn", spec.BN_EPS_PFN, "pfn")] + [(f"{n}.bn", spec.BN_EPS, n) for n, *_ in spec.ENCODER]
+        if self.bn_batch:                                        # gamma / beta join the trainable set (at the end: the layout of
+            for prefix, _, _ in self.bn_layers:                  # everything else is the frozen mode's)
+                host[f"{prefix}.gamma"], host[f"{prefix}.beta"] = params[f"{prefix}.gamma"], params[f"{prefix}.beta"]
         self.names = list(host)
         sizes = [int(np.prod(host[k].shape)) for k in self.names]
         pad = lambda n: (n + 3) // 4 * 4                                   # 16-byte aligned views
@@ -363,7 +390,7 @@ class SeFlowTrainer:
             o += pad(n)
         for k in self.names:
             if not k.startswith("head.") or k.startswith("head.offset"):
-                net.p[k] = self.p[k]
+                net.p[k] = self.p[k]                              # incl. the BatchNorm gamma / beta views in batch mode
         hp = {k[5:]: v for k, v in self.p.items() if k.startswith("head.") and not k.startswith("head.offset")}
         hg = {k[5:]: v for k, v in self.g.items() if k.startswith("head.") and not k.startswith("head.offset")}
         self.head = HeadTrainer(device=dev, p=hp, g=hg, precision=precision)
@@ -405,8 +432,15 @@ class SeFlowTrainer:
                  int(self.lib.himo_wgrad_workspace_bytes_ex(H * W // 16, 384, 256)),
                  int(self.lib.himo_wgrad_workspace_bytes_ex(max_points, 192, 256)),
                  int(self.lib.himo_pfn_backward_workspace_bytes()))
+        ws = max(ws, int(self.lib.himo_pfn_bn_workspace_bytes()),
+                 max(int(self.lib.himo_bn_workspace_bytes(F * L[6] * L[7], L[2])) for L in self.layers))
         self.ws = torch.empty(ws + 64, dtype=torch.uint8, device=dev)
         self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
+        # BatchNorm in training mode: per-layer batch statistics kept for the backward pass; the pillar net has one set per sweep
+        self.bn_mean = torch.zeros((len(self.layers), 256), dtype=torch.float32, device=dev)
+        self.bn_invstd = torch.zeros((len(self.layers), 256), dtype=torch.float32, device=dev)
+        self.pfn_scale, self.pfn_shift, self.pfn_mean, self.pfn_invstd = (torch.zeros((F, 32), dtype=torch.float32, device=dev) for _ in range(4))
+        self._bn_folded = True                                   # net.p[*.scale / *.shift] match the running statistics
         # split-bf16 copies of the convolution weights (forward) and a scratch for the flipped ones (data gradient)
         self.packed = {}
         if precision != "f32":
@@ -479,15 +513,47 @@ class SeFlowTrainer:
         _lib.check(self.lib.himo_add2d(rows, cols, b, b_pitch, y, y_pitch, _lib.stream_handle()), "add2d")
 
     # ---- forward -------------------------------------------------------------------------------------------------
-    def forward(self, pch1, pc0, pc1, pose_h1, pose0, pose1) -> torch.Tensor:
+    def fold_batchnorm(self):
+        """eval-mode constants (net.p[*.scale / *.shift]) from the CURRENT gamma / beta / running statistics"""
+        net = self.net
+        for prefix, eps, out in self.bn_layers:
+            ch = net.p[f"{prefix}.gamma"].numel()
+            _lib.check(self.lib.himo_bn_fold(ch, net.p[f"{prefix}.gamma"].data_ptr(), net.p[f"{prefix}.beta"].data_ptr(),
+                                             net.p[f"{prefix}.mean"].data_ptr(), net.p[f"{prefix}.var"].data_ptr(), eps,
+                                             net.p[f"{out}.scale"].data_ptr(), net.p[f"{out}.shift"].data_ptr(), _lib.stream_handle()), "bn_fold")
+        self._bn_folded = True
+
+    def forward(self, pch1, pc0, pc1, pose_h1, pose0, pose1, training: bool = True) -> torch.Tensor:
+        """``training`` (only meaningful with batchnorm="batch"): True normalises with batch statistics, saves them for
+        ``backward`` and moves the running statistics; False (validation) uses the running statistics."""
         net, lib, s = self.net, self.lib, _lib.stream_handle
         dev = self.device
+        batch = self.bn_batch and training
+        self._fwd_batch = batch
+        if self.bn_batch and not training and not self._bn_folded:
+            self.fold_batchnorm()
         to_dev = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(dev, torch.float32).contiguous()
         pch1, pc0, pc1 = to_dev(pch1), to_dev(pc0), to_dev(pc1)
         inv1 = np.linalg.inv(np.asarray(pose1, np.float64))
         self.n_pts = [pch1.shape[0], pc0.shape[0], pc1.shape[0]]
-        net.pillarize_all((pch1, pc0, pc1), (inv1 @ np.asarray(pose_h1, np.float64), inv1 @ np.asarray(pose0, np.float64), np.eye(4)))
+        sweeps = (pch1, pc0, pc1)
+        transforms = (inv1 @ np.asarray(pose_h1, np.float64), inv1 @ np.asarray(pose0, np.float64), np.eye(4))
+        net.pillarize_all(sweeps, transforms)
         F = net.F
+        if batch:
+            # the pass above left every sweep's cell lists (its images were written with stale constants): batch statistics of
+            # each sweep -- one call of the embedder each, in call order for the running estimate -- then the feature kernel
+            # again with per-sweep constants
+            self._bn_folded = False
+            g, b = net.p["pfn.bn.gamma"].data_ptr(), net.p["pfn.bn.beta"].data_ptr()
+            rm, rv = net.p["pfn.bn.mean"].data_ptr(), net.p["pfn.bn.var"].data_ptr()
+            for slot in range(F):
+                _lib.check(lib.himo_pfn_bn_stats(self.n_pts[slot], net._voxel, net._centre, net.W, net.H, self.p["pfn.weight"].data_ptr(),
+                                                 net.xyz_t[slot].data_ptr(), net.ws_slots[slot].data_ptr(), g, b, spec.BN_EPS_PFN, BN_MOMENTUM,
+                                                 rm, rv, self.pfn_scale[slot].data_ptr(), self.pfn_shift[slot].data_ptr(),
+                                                 self.pfn_mean[slot].data_ptr(), self.pfn_invstd[slot].data_ptr(), self.ws.data_ptr(),
+                                                 self.ws.numel(), s()), "pfn_bn_stats")
+            net.pillar_features(sweeps, transforms, self.pfn_scale, self.pfn_shift)
         # encoder with saved activations
         src, src_bs, src_pitch = net.B0.data_ptr(), 32, 32 * F
         cat = {64: net.F1, 128: net.F2, 256: net.F3}
@@ -499,18 +565,28 @@ class SeFlowTrainer:
             self._conv(src, src_bs, src_pitch, self.p[f"{name}.weight"].data_ptr(), self.p[f"{name}.bias"].data_ptr(),
                        pre.data_ptr(), ho * wo * cout, cout, F, h, w, cin, cout, 3, stride, packed=None if pk is None else pk.data_ptr(),
                        fmt=self.fwd_format)
-            sc, sh = net.p[f"{name}.scale"].data_ptr(), net.p[f"{name}.shift"].data_ptr()
             if last:
                 dst = cat[cout]
-                for f in range(F):
-                    _lib.check(lib.himo_affine_gelu_fwd(ho * wo, cout, pre[f].data_ptr(), cout, sc, sh, pre[f].data_ptr(), cout,
-                                                        dst.data_ptr() + 4 * cout * f, cout * F, s()), "affine_gelu_fwd")
-                src, src_bs, src_pitch = dst.data_ptr(), cout, cout * F
+                y_ptr, y_bs, y_pitch = dst.data_ptr(), cout, cout * F          # frames as channel groups of the concat buffer
             else:
-                y = self.Y[li]
-                _lib.check(lib.himo_affine_gelu_fwd(F * ho * wo, cout, pre.data_ptr(), cout, sc, sh, pre.data_ptr(), cout,
-                                                    y.data_ptr(), cout, s()), "affine_gelu_fwd")
-                src, src_bs, src_pitch = y.data_ptr(), ho * wo * cout, cout
+                y_ptr, y_bs, y_pitch = self.Y[li].data_ptr(), ho * wo * cout, cout
+            if batch:                                            # PRE keeps xhat (normalised, before gamma / beta)
+                pfx = f"{name}.bn"
+                _lib.check(lib.himo_bn_train_fwd(F, ho * wo, cout, pre.data_ptr(), ho * wo * cout, cout, net.p[f"{pfx}.gamma"].data_ptr(),
+                                                 net.p[f"{pfx}.beta"].data_ptr(), spec.BN_EPS, BN_MOMENTUM, net.p[f"{pfx}.mean"].data_ptr(),
+                                                 net.p[f"{pfx}.var"].data_ptr(), self.bn_mean[li].data_ptr(), self.bn_invstd[li].data_ptr(),
+                                                 pre.data_ptr(), ho * wo * cout, cout, y_ptr, y_bs, y_pitch, self.ws.data_ptr(),
+                                                 self.ws.numel(), s()), "bn_train_fwd")
+            else:                                                # PRE keeps the affine pre-activation
+                sc, sh = net.p[f"{name}.scale"].data_ptr(), net.p[f"{name}.shift"].data_ptr()
+                if last:
+                    for f in range(F):
+                        _lib.check(lib.himo_affine_gelu_fwd(ho * wo, cout, pre[f].data_ptr(), cout, sc, sh, pre[f].data_ptr(), cout,
+                                                            y_ptr + 4 * cout * f, y_pitch, s()), "affine_gelu_fwd")
+                else:
+                    _lib.check(lib.himo_affine_gelu_fwd(F * ho * wo, cout, pre.data_ptr(), cout, sc, sh, pre.data_ptr(), cout,
+                                                        y_ptr, cout, s()), "affine_gelu_fwd")
+            src, src_bs, src_pitch = y_ptr, y_bs, y_pitch
         net.decoder()
         # head: gather -> GRU with saved states
         n0 = pc0.shape[0]
@@ -597,7 +673,14 @@ class SeFlowTrainer:
             pre = self.PRE[li]
             sc = net.p[f"{name}.scale"].data_ptr()
             dp = self.DP.data_ptr()
-            if last:                                             # gradient arrives in the concat layout
+            if self._fwd_batch:                                  # through GELU and the batch statistics; also d gamma / d beta
+                pfx = f"{name}.bn"
+                dy_ptr, dy_bs, dy_pitch = (dcat[cout].data_ptr(), cout, cout * F) if last else (dy, ho * wo * cout, cout)
+                _lib.check(lib.himo_bn_train_bwd(F, ho * wo, cout, dy_ptr, dy_bs, dy_pitch, pre.data_ptr(), ho * wo * cout, cout,
+                                                 net.p[f"{pfx}.gamma"].data_ptr(), net.p[f"{pfx}.beta"].data_ptr(), self.bn_invstd[li].data_ptr(),
+                                                 dp, ho * wo * cout, cout, self.g[f"{pfx}.gamma"].data_ptr(), self.g[f"{pfx}.beta"].data_ptr(),
+                                                 0, self.ws.data_ptr(), self.ws.numel(), s()), "bn_train_bwd")
+            elif last:                                           # gradient arrives in the concat layout
                 src = dcat[cout]
                 for f in range(F):
                     _lib.check(lib.himo_affine_gelu_bwd(ho * wo, cout, src.data_ptr() + 4 * cout * f, cout * F, pre[f].data_ptr(), cout, sc,
@@ -622,6 +705,15 @@ class SeFlowTrainer:
                 dy = nxt
         # pillar feature net
         for slot in range(F):
+            if self._fwd_batch:
+                _lib.check(lib.himo_pfn_backward_bn(self.n_pts[slot], net._voxel, net._centre, W, H, self.p["pfn.weight"].data_ptr(),
+                                                    self.pfn_scale[slot].data_ptr(), self.pfn_shift[slot].data_ptr(),
+                                                    self.pfn_mean[slot].data_ptr(), self.pfn_invstd[slot].data_ptr(),
+                                                    net.xyz_t[slot].data_ptr(), net.ws_slots[slot].data_ptr(),
+                                                    self.dB0.data_ptr() + 4 * 32 * slot, 32 * F, self.g["pfn.weight"].data_ptr(),
+                                                    self.g["pfn.bn.gamma"].data_ptr(), self.g["pfn.bn.beta"].data_ptr(), 1 if slot else 0,
+                                                    self.ws.data_ptr(), self.ws.numel(), s()), "pfn_backward_bn")
+                continue
             _lib.check(lib.himo_pfn_backward(self.n_pts[slot], net._voxel, net._centre, W, H, self.p["pfn.weight"].data_ptr(),
                                              net.p["pfn.scale"].data_ptr(), net.p["pfn.shift"].data_ptr(), net.xyz_t[slot].data_ptr(),
                                              net.ws_slots[slot].data_ptr(), self.dB0.data_ptr() + 4 * 32 * slot, 32 * F,
@@ -652,7 +744,7 @@ class SeFlowTrainer:
         from ..ssl_loss import SeFlowLoss
         if not hasattr(self, "loss"):
             self.loss = SeFlowLoss(device=self.device)
-        res = self.forward(pch1, pc0, pc1, pose_h1, pose0, pose1)
+        res = self.forward(pch1, pc0, pc1, pose_h1, pose0, pose1, training=False)
         n0, n1 = self.n_pts[1], self.n_pts[2]
         _, total, _ = self.loss(self.net.xyz_t[1][:n0], self.net.xyz_t[2][:n1], res[:, :3].contiguous(), label0, label1, n_labels)
         return total
@@ -734,6 +826,7 @@ class SeFlowTrainer:
             self.net.p[f"{out}.shift"].copy_(shift)
             for k in ("gamma", "beta", "mean", "var"):
                 self.net.p[f"{prefix}.{k}"].copy_(t(f"{prefix}.{k}"))
+        self._bn_folded = True
         self._repack()
 
     def export_params(self) -> dict:

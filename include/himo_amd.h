@@ -470,6 +470,50 @@ int himo_pfn_backward(int64_t n, const float* h_voxel, const float* h_centre_off
 int himo_head_scatter(int64_t n, int grid_w, int grid_h, const void* d_pillar_workspace, const float* d_dhx, int dhx_pitch,
                       float* d_db0, int b0_pitch, int group0, int group1, int n_groups, float* d_ddec, int dec_pitch,
                       void* stream);
+
+/* ---- BatchNorm in TRAINING mode (BASELINE config 5).  Replaces: the torch.nn.BatchNorm layers of the model the reference's
+ * training job builds from scratch (assets/slurm/ssl-train-av2.sh:31-34: no checkpoint=, 12 epochs, batch_size=8; the model
+ * source, OpenSceneFlow/, is absent -- PARITY UNPINNED, semantics = torch's: biased variance normalises, the unbiased one
+ * feeds the running estimate, momentum 0.1).  Maps are NHWC float32 views [n_img][rows][ch]: element (i, r, c) at
+ * p + i * img_stride + r * pitch + c (16-byte aligned bases, strides multiples of 4 floats, ch % 4 == 0).
+ * himo_bn_train_fwd: batch mean / invstd over all n_img * rows rows -> d_mean, d_invstd [ch] (kept for the backward pass);
+ *   d_xhat = (x - mean) * invstd (may alias d_x); d_y = gelu(gamma * xhat + beta); running statistics updated in place when
+ *   given.  himo_bn_train_bwd: d_dy = d loss / d y -> d_dx = d loss / d x (the three-term BatchNorm gradient through the
+ *   exact-erf GELU; may alias d_dy), d_dgamma / d_dbeta [ch] (flags bit 0: accumulate).  Every reduction is a fixed tree.
+ * himo_bn_fold: eval-mode constants scale = gamma / sqrt(var + eps), shift = beta - mean * scale from the running statistics. */
+size_t himo_bn_workspace_bytes(int64_t total_rows, int ch);
+int himo_bn_train_fwd(int n_img, int64_t rows, int ch, const float* d_x, int64_t x_img_stride, int x_pitch,
+                      const float* d_gamma, const float* d_beta, float eps, float momentum, float* d_running_mean,
+                      float* d_running_var, float* d_mean, float* d_invstd, float* d_xhat, int64_t xhat_img_stride, int xhat_pitch,
+                      float* d_y, int64_t y_img_stride, int y_pitch, void* d_workspace, size_t workspace_bytes, void* stream);
+int himo_bn_train_bwd(int n_img, int64_t rows, int ch, const float* d_dy, int64_t dy_img_stride, int dy_pitch,
+                      const float* d_xhat, int64_t xhat_img_stride, int xhat_pitch, const float* d_gamma, const float* d_beta,
+                      const float* d_invstd, float* d_dx, int64_t dx_img_stride, int dx_pitch, float* d_dgamma, float* d_dbeta,
+                      unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);
+int himo_bn_fold(int ch, const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_var, float eps,
+                 float* d_scale, float* d_shift, void* stream);
+/* The same for the pillar feature net's BatchNorm1d (statistics over the in-range points of ONE sweep; y = feats W):
+ * himo_pfn_bn_stats reads the cell lists himo_pillarize* left in d_pillar_workspace and yields the sweep's constants
+ *   d_scale = gamma invstd, d_shift = beta - mean gamma invstd [32] (+ d_mean, d_invstd for the backward pass; running
+ *   statistics updated in place when given);
+ * himo_pillar_features_multi re-runs ONLY the feature kernel of himo_pillarize_multi_ex with per-sweep constants
+ *   (d_scale / d_shift: [n_sweeps][32]);
+ * himo_pfn_backward_bn = himo_pfn_backward through the batch statistics, also yielding d gamma / d beta [32]. */
+size_t himo_pfn_bn_workspace_bytes(void);
+int himo_pfn_bn_stats(int64_t n, const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
+                      const float* d_pfn_weight, const float* d_xyz_t, const void* d_pillar_workspace, const float* d_gamma,
+                      const float* d_beta, float eps, float momentum, float* d_running_mean, float* d_running_var,
+                      float* d_scale, float* d_shift, float* d_mean, float* d_invstd, void* d_workspace, size_t workspace_bytes,
+                      void* stream);
+int himo_pillar_features_multi(int n_sweeps, const himo_sweep* h_sweeps, const float* h_range, const float* h_voxel,
+                               const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight,
+                               const float* d_scale, const float* d_shift, int image_pitch, size_t workspace_bytes,
+                               int image_split, void* stream);
+int himo_pfn_backward_bn(int64_t n, const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
+                         const float* d_pfn_weight, const float* d_scale, const float* d_shift, const float* d_mean,
+                         const float* d_invstd, const float* d_xyz_t, const void* d_pillar_workspace, const float* d_dimage,
+                         int image_pitch, float* d_dweight, float* d_dgamma, float* d_dbeta, unsigned flags, void* d_workspace,
+                         size_t workspace_bytes, void* stream);
 /* the 3x3 weight gradient over a batch of images, LDS-tiled (dY tile + X halo staged once, all 9 taps read them);
  * h, w = INPUT image size.  stride 1: h even, w % 32 == 0, cin % 64 == 0; stride 2: h even, w % 64 == 0, cin == 32 or
  * cin % 64 == 0; cout % 64 == 0 -- HIMO_ERR_UNSUPPORTED otherwise (workspace_bytes returns 0).

@@ -20,6 +20,7 @@ VOXEL_SIZE = (0.2, 0.2, 6.0)
 PC_RANGE = (-51.2, -51.2, -3.0, 51.2, 51.2, 3.0)
 GRID_H, GRID_W = 512, 512
 BN_EPS_PFN, BN_EPS = 1e-3, 1e-5
+BN_MOMENTUM = 0.1
 GRU_ITERS = 4
 
 
@@ -52,8 +53,22 @@ def voxelize(xyz: torch.Tensor):
     return valid, c[:, 1].long(), c[:, 0].long()
 
 
-def pillar_image(params, xyz: torch.Tensor):
-    """(32, H, W) pseudo-image + per-point (valid, pillar id, offset-to-centre)."""
+def _batch_norm(params, prefix, y, eps, training):
+    """BatchNorm over dim 0 (and the spatial dims) of y.  Eval: the running statistics folded to scale / shift exactly as the
+    product folds them.  Training: torch's own F.batch_norm -- batch statistics normalise, the tensors under
+    ``<prefix>.mean`` / ``<prefix>.var`` are updated IN PLACE (momentum 0.1, unbiased variance)."""
+    if training:
+        return F.batch_norm(y, _t(params[f"{prefix}.mean"]), _t(params[f"{prefix}.var"]), _t(params[f"{prefix}.gamma"]),
+                            _t(params[f"{prefix}.beta"]), training=True, momentum=BN_MOMENTUM, eps=eps)
+    scale = _t(params[f"{prefix}.gamma"]) / torch.sqrt(_t(params[f"{prefix}.var"]) + eps)
+    shift = _t(params[f"{prefix}.beta"]) - _t(params[f"{prefix}.mean"]) * scale
+    shape = (1, -1) + (1,) * (y.dim() - 2)
+    return y * scale.reshape(shape) + shift.reshape(shape)
+
+
+def pillar_image(params, xyz: torch.Tensor, training: bool = False):
+    """(32, H, W) pseudo-image + per-point (valid, pillar id, offset-to-centre).  ``training``: the pillar net's BatchNorm
+    uses the statistics of THIS sweep's in-range points (one call of the embedder per sweep)."""
     valid, iy, ix = voxelize(xyz)
     pid = iy * GRID_W + ix
     pts = xyz[valid]
@@ -69,9 +84,7 @@ def pillar_image(params, xyz: torch.Tensor):
     centre = cell * vs + off
     feats = torch.cat([pts, pts - mean, pts - centre], dim=1)                        # (n, 9)
     y = feats @ _t(params["pfn.weight"])
-    scale = _t(params["pfn.bn.gamma"]) / torch.sqrt(_t(params["pfn.bn.var"]) + BN_EPS_PFN)
-    shift = _t(params["pfn.bn.beta"]) - _t(params["pfn.bn.mean"]) * scale
-    y = torch.relu(y * scale + shift)
+    y = torch.relu(_batch_norm(params, "pfn.bn", y, BN_EPS_PFN, training and len(pv) > 0))
     acc = torch.zeros(n_cells, y.shape[1], dtype=torch.float32).index_add_(0, pv, y)
     img = acc / cnt.clamp(min=1.0)[:, None]
     img = img.T.reshape(-1, GRID_H, GRID_W).contiguous()
@@ -85,22 +98,21 @@ def _conv(params, name, x, stride=1, pad=1):
     return F.conv2d(x, w, _t(params[f"{name}.bias"]), stride=stride, padding=pad)
 
 
-def conv_bn_gelu(params, name, x, stride):
+def conv_bn_gelu(params, name, x, stride, training: bool = False):
     y = _conv(params, name, x, stride=stride)
-    scale = _t(params[f"{name}.bn.gamma"]) / torch.sqrt(_t(params[f"{name}.bn.var"]) + BN_EPS)
-    shift = _t(params[f"{name}.bn.beta"]) - _t(params[f"{name}.bn.mean"]) * scale
-    return F.gelu(y * scale[None, :, None, None] + shift[None, :, None, None])
+    return F.gelu(_batch_norm(params, f"{name}.bn", y, BN_EPS, training))
 
 
 ENC_STAGES = (("enc1", 4), ("enc2", 6), ("enc3", 6))
 
 
-def encoder(params, imgs: torch.Tensor):
-    """imgs (F,32,H,W) -> [(F,64,H/2,..), (F,128,H/4,..), (F,256,H/8,..)]"""
+def encoder(params, imgs: torch.Tensor, training: bool = False):
+    """imgs (F,32,H,W) -> [(F,64,H/2,..), (F,128,H/4,..), (F,256,H/8,..)].  The F frames of the sample are the batch: in
+    training mode a layer's BatchNorm statistics are taken over all of them."""
     outs, x = [], imgs
     for stage, n in ENC_STAGES:
         for i in range(n):
-            x = conv_bn_gelu(params, f"{stage}.{i}", x, stride=2 if i == 0 else 1)
+            x = conv_bn_gelu(params, f"{stage}.{i}", x, stride=2 if i == 0 else 1, training=training)
         outs.append(x)
     return outs
 
@@ -113,9 +125,9 @@ def upsample_skip(params, name, coarse, skip):
     return _conv(params, f"{name}.u5", y)
 
 
-def backbone(params, imgs: torch.Tensor):
+def backbone(params, imgs: torch.Tensor, training: bool = False):
     """imgs (F,32,H,W) -> (64,H,W) decoder map."""
-    f1, f2, f3 = encoder(params, imgs)
+    f1, f2, f3 = encoder(params, imgs, training)
     cat = lambda t: t.reshape(1, -1, t.shape[2], t.shape[3])                          # frames stacked on channels
     s = upsample_skip(params, "dec1", cat(f3), cat(f2))
     t = upsample_skip(params, "dec2", s, cat(f1))
@@ -164,19 +176,22 @@ def forward(params, pch1, pc0, pc1, pose_h1, pose0, pose1, return_intermediates:
     return out
 
 
-def forward_train(params, pch1, pc0, pc1, pose_h1, pose0, pose1):
+def forward_train(params, pch1, pc0, pc1, pose_h1, pose0, pose1, training: bool = False):
     """Differentiable restatement for the training tests: ``params`` maps names to torch tensors (leaves that require
-    grad for the trainable ones; BatchNorm tensors are constants = frozen BN).  Returns (res (n_valid,3) with graph,
-    valid0 (N0,) bool, pc0 in pc1's frame (N0,3))."""
+    grad for the trainable ones).  ``training`` False: BatchNorm frozen (its tensors are constants).  True: BatchNorm in
+    training mode as torch defines it -- batch statistics (per sweep in the pillar net, over the sample's F frames in the
+    encoder), gamma / beta trainable leaves, and the ``*.bn.mean`` / ``*.bn.var`` tensors of ``params`` updated in place in
+    call order (pillar net: history sweep, pc0, pc1).  Returns (res (n_valid,3) with graph, valid0 (N0,) bool, pc0 in
+    pc1's frame (N0,3))."""
     p0 = _t(pc0)[:, :3].float()
     T0, Th = ego_transform(pose0, pose1), ego_transform(pose_h1, pose1)
     p0t = transform_points(p0, T0)
     pht = transform_points(pch1, Th)
     p1 = _t(pc1)[:, :3].float()
-    img_h, *_ = pillar_image(params, pht)
-    img0, valid0, pid0, off0 = pillar_image(params, p0t)
-    img1, *_ = pillar_image(params, p1)
+    img_h, *_ = pillar_image(params, pht, training)
+    img0, valid0, pid0, off0 = pillar_image(params, p0t, training)
+    img1, *_ = pillar_image(params, p1, training)
     imgs = torch.stack([img_h, img0, img1])
-    dec = backbone(params, imgs)
+    dec = backbone(params, imgs, training)
     res = head(params, img0, img1, dec, pid0[valid0], off0[valid0])
     return res, valid0, p0t
