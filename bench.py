@@ -56,6 +56,9 @@ def parse_args():
                     help="network matrix arithmetic: split-bf16 (float32-class accuracy) or float32 MFMA")
     ap.add_argument("--train-precision", default="mixed", choices=["mixed", "bf16x3", "f32"],
                     help="train workload: forward fp16-split + data-gradient split-bf16 (mixed), all split-bf16, or float32 MFMA")
+    ap.add_argument("--train-batchnorm", default="batch", choices=["batch", "frozen"],
+                    help="train workload / leg: BatchNorm in training mode (batch statistics, gamma / beta trained, running statistics "
+                         "updated: the reference's from-scratch job) or frozen (fine-tuning convention)")
     ap.add_argument("--float32-activations", action="store_true",
                     help="pipeline, f16x2: keep the backbone's maps float32 in HBM instead of the split activation format (A/B switch)")
     ap.add_argument("--refined", action="store_true", help="also write refined points (+12 B/pt)")
@@ -413,7 +416,7 @@ def make_train_step(args, rank: int, device, result: dict, n_sets: int = 2):
     from himo_amd.seflow.train import SeFlowTrainer
     B, P = args.frames_per_step, args.points
     params = spec.init_params(0)
-    trainer = SeFlowTrainer(params, device=device, max_points=P, precision=args.train_precision)
+    trainer = SeFlowTrainer(params, device=device, max_points=P, precision=args.train_precision, batchnorm=args.train_batchnorm)
     sets, _ = synthetic_sample_sets(n_sets, B, P, device, seed=rank, cloud=args.cloud)
     g = torch.Generator(device=device); g.manual_seed(99 + rank)
     labels = []
@@ -655,6 +658,7 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
         line["metric"] = "train_frames_per_sec_120k"
         line["config"]["parallelism"] = f"data parallel x{world}, one flat all-reduce per step"
         line["config"]["matrix_arithmetic"] = args.train_precision
+        line["config"]["batchnorm"] = args.train_batchnorm
     if not dry and not args.no_cpu_baseline and args.workload in ("pipeline", "compdis") and world == 1:     # CPU leg: rank 0 at N = 1 only
         if args.workload == "compdis":
             frames = [frame_to_host(batch, i) for i in range(min(8, B))]
@@ -712,9 +716,11 @@ def train_roofline(args, prof: dict, n_steps: int, elapsed: float):
                 "frac": alg_tf / peak, "traffic": None, "avg_launch_ms": k["avg_ms"], "launches_timed": k["count"],
                 "algorithmic_flops_per_step": flops_w, "share_of_step_time": k["total_ms"] / (elapsed * 1e3),
                 "note": "split-K over pixel tiles; the fixed-order reduction of the partials is a separate (small) kernel"}
+    bn = ("BatchNorm in training mode (batch statistics per forward, gamma / beta trained, running statistics updated)"
+          if args.train_batchnorm == "batch" else "BatchNorm frozen (fine-tuning convention)")
     workload = ("self-supervised TRAINING step (BASELINE config 5): pillarise 3 sweeps -> network forward with saved "
                 "activations -> 4-term NN/Chamfer loss -> full backward -> flat-gradient all-reduce -> Adam; "
-                f"one {args.points}-point sample per GPU per step")
+                f"one {args.points}-point sample per GPU per step; {bn}")
     dtype = {"mixed": "forward f16x2 (two-term fp16 split); 3x3 data-gradient convolutions and stride-1 3x3 weight gradients two-term bf16 split "
                       "(16-bit operands, float32 range and sums); 1x1 / head data gradients bf16x3; everything else and the optimiser f32",
              "bf16x3": "forward + data-gradient convolutions bf16x3 (split bf16, float32-class); weight gradients / optimiser f32",

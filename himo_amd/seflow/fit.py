@@ -7,8 +7,11 @@ dataset, ``batch_size`` samples per optimiser step (spread over the ranks: every
 samples, ONE flat all-reduce adds the ranks' sums and sample counts, and the sum is divided by the global count: every
 sample of a batch weighs the same however it splits over the ranks), Adam at ``lr`` with StepLR(step_size, gamma) per epoch, the
 ``save_top`` best checkpoints kept by the epoch's validation (or mean training) loss, and resuming from a checkpoint.
-Conventions of this build: BatchNorm stays FROZEN -- running statistics and affine folded into
-constants, the usual fine-tuning convention -- so there is no batch-statistics pass and no BN backward; labels are the
+Conventions of this build: BatchNorm runs in TRAINING mode by default (``batchnorm="batch"``: batch statistics, trainable
+gamma / beta, running statistics with momentum 0.1 -- the launcher passes no checkpoint, so the reference's job trains from
+scratch; statistics are per forward call = per sample on a rank, un-synchronised across ranks like DDP's default, and rank
+0's running statistics go into the checkpoints); ``batchnorm="frozen"`` is the fine-tuning convention (running statistics
+and affine folded into constants); validation always uses the running statistics; labels are the
 frame's dynamic-cluster ids (``flow_instance_id`` here; the reference's ``ssl_label=seflow_auto`` files are absent).
 """
 from __future__ import annotations
@@ -65,7 +68,7 @@ def make_sample(dataset, trip, device, label_key: str = "flow_instance_id"):
 def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, batch_size: int = 8, lr: float = 6e-5,
         step_size: int = 3, gamma: float = 0.5, save_top: int = 3, val_dataset=None, resume=None, precision: str = "mixed",
         max_points: int = 140_000, device=None, seed: int = 0, max_steps: int | None = None, log=print,
-        trainer: SeFlowTrainer | None = None) -> dict:
+        trainer: SeFlowTrainer | None = None, batchnorm: str = "batch") -> dict:
     """Train for ``epochs`` passes over ``dataset``; returns {"trainer", "history", "best"}.
 
     Ranks (torch.distributed, initialised by the caller / ``distenv.process_group``): step s of an epoch takes the global
@@ -73,7 +76,8 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
     ``max_steps`` bounds the optimiser steps of the whole run (tests)."""
     import torch.distributed as dist
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
-    tr = trainer if trainer is not None else SeFlowTrainer(params, device=device, max_points=max_points, seed=seed, precision=precision)
+    tr = trainer if trainer is not None else SeFlowTrainer(params, device=device, max_points=max_points, seed=seed, precision=precision,
+                                                           batchnorm=batchnorm)
     dev = tr.device
     start_epoch = 0
     if resume is not None:
@@ -99,6 +103,7 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
             losses.append(loss)
             steps_done += 1
         train_loss = float(torch.stack(losses).mean().item()) if losses else float("nan")
+        tr.sync_running_stats()                              # validation and the checkpoint use rank 0's running statistics
         val_loss = None
         if val_trips:
             vals = [tr.loss_only(*make_sample(val_dataset, t, dev)) for t in val_trips[rank::world]]
@@ -137,13 +142,15 @@ def main(argv=None):
     ap.add_argument("--batch_size", type=int, default=8)
     ap.add_argument("--lr", type=float, default=6e-5)
     ap.add_argument("--save_top_model", type=int, default=3)
+    ap.add_argument("--batchnorm", default="batch", choices=["batch", "frozen"],
+                    help="batch: BatchNorm in training mode (from-scratch training, the reference job); frozen: fine-tuning convention")
     a = ap.parse_args(argv)
     with distenv.process_group():
         ds = open_dataset(Path(a.dataset_path))
         val = open_dataset(Path(a.val_path)) if a.val_path else None
         params = load_params(a.checkpoint) if a.checkpoint else None
         return fit(ds, params, out_dir=a.out_dir, epochs=a.epochs, batch_size=a.batch_size, lr=a.lr, save_top=a.save_top_model,
-                   val_dataset=val, resume=a.resume or None)
+                   val_dataset=val, resume=a.resume or None, batchnorm=a.batchnorm)
 
 
 if __name__ == "__main__":

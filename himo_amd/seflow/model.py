@@ -605,6 +605,25 @@ class SeFlowNet:
                                                       (1 if self.split_acts else 0) | (2 if self.incremental_images else 0), _lib.stream_handle())
             _lib.check(status, "himo_pillarize_multi_ex")
 
+    def pillar_features(self, sweeps, transforms, scale: torch.Tensor, shift: torch.Tensor):
+        """Training mode (csrc/pillar.hip himo_pillar_features_multi): the feature kernel ALONE for the F sweeps of the current
+        sample, with per-sweep BatchNorm constants ``scale`` / ``shift`` [F][32] -- ``pillarize_all`` has just built the cell
+        lists of exactly these sweeps (same tensors, same transforms)."""
+        arr = (HimoSweep * self.F)()
+        st = self._pt[self._sample]
+        for slot, (pts, T) in enumerate(zip(sweeps, transforms)):
+            w = arr[slot]
+            w.n, w.d_pts, w.pc_stride = pts.shape[0], pts.data_ptr(), pts.shape[1]
+            w.transform = _f32x(np.asarray(T, dtype=np.float32).reshape(-1))
+            w.d_xyz_t, w.d_pid, w.d_offsets = st["xyz_t"][slot].data_ptr(), st["pid"][slot].data_ptr(), st["offsets"][slot].data_ptr()
+            w.d_image = self.B0[self._sample].data_ptr() + 4 * 32 * slot
+            w.d_workspace = st["ws_slots"][slot].data_ptr()
+        status = self.lib.himo_pillar_features_multi(self.F, ctypes.addressof(arr), self._range, self._voxel, self._centre, self.W, self.H,
+                                                     self.p["pfn.weight"].data_ptr(), scale.data_ptr(), shift.data_ptr(), 32 * self.F,
+                                                     st["ws_slots"][0].numel(),
+                                                     (1 if self.split_acts else 0) | (2 if self.incremental_images else 0), _lib.stream_handle())
+        _lib.check(status, "himo_pillar_features_multi")
+
     def pillarize_into(self, slot: int, pts: torch.Tensor, transform):
         """Sweep -> channel group ``slot`` of B0 (pitch 96)."""
         n = pts.shape[0]

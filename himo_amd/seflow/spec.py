@@ -26,6 +26,14 @@ Data flow for one sample (pch1 = one history sweep, pc0, pc1; all float32 xyz):
      x = Linear(3,64)(point - pillar centre); 4 iterations of a GRU cell (1x1 convs == per-point
      linears); flow = Linear(192,32) -> GELU -> Linear(32,3) on [h, x],
   6. output: flow_out = pose_flow + network flow for in-range points, pose_flow alone otherwise.
+
+Training mode (BASELINE config 5; the reference's job trains from scratch, assets/slurm/ssl-train-av2.sh:31-34): every
+BatchNorm follows torch.nn.BatchNorm -- batch statistics normalise (biased variance), gamma / beta are trainable, the running
+mean / variance follow with momentum 0.1 (unbiased variance).  The batch of a layer is what ONE forward call puts through
+it: the pillar net is called once per sweep (statistics over that sweep's in-range points; three running-statistics updates
+per sample, in the order history, pc0, pc1), the encoder once per sample on its F = 3 images stacked as the batch
+(statistics over 3 x H x W positions).  A rank processes its samples one at a time and accumulates their gradients
+(himo_amd/seflow/train.py train_batch): per-GPU statistics, un-synchronised across ranks like DDP's default.
 """
 from __future__ import annotations
 
@@ -83,9 +91,10 @@ def param_shapes() -> dict:
     return s
 
 
-def init_params(seed: int = 0) -> dict:
+def init_params(seed: int = 0, fresh_bn: bool = False) -> dict:
     """Random-init float32 parameters (He-uniform fan-in bounds like torch's defaults; BN with
-    non-trivial running statistics so that the BN arithmetic is exercised)."""
+    non-trivial running statistics so that the BN arithmetic is exercised).  ``fresh_bn``: BatchNorm as a
+    from-scratch training job starts it (torch.nn.BatchNorm's reset: gamma 1, beta 0, running mean 0, running var 1)."""
     rng = np.random.default_rng(seed)
     out = {}
     for name, shape in param_shapes().items():
@@ -106,6 +115,10 @@ def init_params(seed: int = 0) -> dict:
             out[name] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
         else:  # pragma: no cover
             raise KeyError(name)
+    if fresh_bn:
+        for name, a in out.items():
+            if ".bn." in name:
+                a[...] = 1.0 if name.endswith((".gamma", ".var")) else 0.0
     return out
 
 

@@ -349,7 +349,7 @@ class SeFlowTrainer:
         self._wp_fmt = 0
         self.lib = _lib.load()
         self.device = dev = device if device is not None else _lib.require_gpu()
-        params = spec.init_params(seed) if params is None else params
+        params = spec.init_params(seed, fresh_bn=self.bn_batch) if params is None else params      # from scratch: BatchNorm reset
         net = self.net = SeFlowNet(params, device=dev, max_points=1, precision="f32", autotune=False)
         net.fold_decoder = False                          # the backward pass reads every decoder layer's own output
         net.keep_cell_lists = True
@@ -687,7 +687,12 @@ class SeFlowTrainer:
                                                         dp + 4 * f * ho * wo * cout, cout, s()), "affine_gelu_bwd")
             else:
                 _lib.check(lib.himo_affine_gelu_bwd(F * ho * wo, cout, dy, cout, pre.data_ptr(), cout, sc, dp, cout, s()), "affine_gelu_bwd")
-            self._colsum(F * ho * wo, dp, cout, cout, f"{name}.bias")
+            if self._fwd_batch:
+                # a bias in front of a training-mode BatchNorm has exactly zero gradient (the batch mean absorbs it); the column
+                # sums of dp would be rounding noise that Adam's normalisation turns into full-size random steps
+                self.g[f"{name}.bias"].zero_()
+            else:
+                self._colsum(F * ho * wo, dp, cout, cout, f"{name}.bias")
             x, x_bs, x_pitch = self.inputs[li]
             self._wgrad3_batch(F, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride)
             wf, wp = self._flip(name, 3, cin, cout)
@@ -721,6 +726,27 @@ class SeFlowTrainer:
                        "pfn_backward")
 
     # ---- optimiser / data parallel -----------------------------------------------------------------------------
+    def sync_running_stats(self, src: int = 0):
+        """Every rank adopts rank ``src``'s BatchNorm running statistics (one small broadcast; what DDP's default
+        ``broadcast_buffers`` does before each forward, done here once per epoch: batch statistics -- not these -- drive the
+        training forward, so only validation and the checkpoints see them)."""
+        import torch.distributed as dist
+        if not (self.bn_batch and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        stats = [self.net.p[f"{prefix}.{k}"] for prefix, _, _ in self.bn_layers for k in ("mean", "var")]
+        flat = torch.cat([t.reshape(-1) for t in stats])
+        if flat.is_cuda and dist.get_backend() == "gloo":
+            host = flat.cpu()
+            dist.broadcast(host, src=src)
+            flat = host.to(self.device)
+        else:
+            dist.broadcast(flat, src=src)
+        o = 0
+        for t in stats:
+            t.copy_(flat[o:o + t.numel()].view_as(t))
+            o += t.numel()
+        self._bn_folded = False
+
     def allreduce(self):
         """Mean of the flat gradient over ranks: ONE collective per step (RCCL over xGMI)."""
         allreduce_mean_(self.flat_g)

@@ -52,17 +52,44 @@ def test_fit_runs_epochs_batches_schedule_and_keeps_the_top_checkpoints(gpu, tmp
     trips = triplets(ds)
     assert len(trips) == 10 and trips[0] == (0, 0, 1) and trips[1] == (0, 1, 2) and trips[5] == (6, 6, 7)      # no pair across scenes
     logs = []
-    out = fit(ds, spec.init_params(9), out_dir=tmp_path, epochs=5, batch_size=4, lr=1e-3, step_size=2, gamma=0.5, save_top=2,
+    out = fit(ds, spec.init_params(9), out_dir=tmp_path, epochs=5, batch_size=4, lr=2e-4, step_size=2, gamma=0.5, save_top=2,
               max_points=6_000, device=gpu, log=logs.append)
     hist = out["history"]
     assert [h["epoch"] for h in hist] == [0, 1, 2, 3, 4] and all(h["steps"] == 3 for h in hist)            # ceil(10 / 4) steps per epoch
-    assert [h["lr"] for h in hist] == [1e-3, 1e-3, 5e-4, 5e-4, 2.5e-4]                                       # StepLR(2, 0.5)
+    assert [h["lr"] for h in hist] == [2e-4, 2e-4, 1e-4, 1e-4, 5e-5]                                         # StepLR(2, 0.5)
     assert all(np.isfinite(h["train_loss"]) for h in hist) and hist[-1]["train_loss"] < hist[0]["train_loss"]
     assert out["trainer"].step_count == 15 and len(logs) == 5
     kept = sorted(tmp_path.glob("*.npz"))
     assert len(kept) == 2                                                                                  # save_top_model
     best_val = float(ck.load_params(out["best"], with_extra=True)[1]["val"])
     assert best_val == pytest.approx(min(h["train_loss"] for h in hist), rel=1e-4, abs=1e-4)   # file name carries 4 decimals; the array is exact
+
+
+def test_fit_trains_from_scratch_with_batchnorm_in_training_mode(gpu, tmp_path):
+    """The reference's job shape (ssl-train-av2.sh:31-34: no checkpoint=): random weights, BatchNorm freshly reset (gamma 1,
+    beta 0, running statistics 0 / 1) and in TRAINING mode; the loss falls, gamma / beta and the running statistics move,
+    validation (running statistics) is finite, and the checkpoint drives the inference network."""
+    from himo_amd.dataset import ListDataset
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.checkpoint import load_params
+    from himo_amd.seflow.fit import fit
+    from himo_amd.seflow.model import SeFlowNet
+    from himo_amd.synthetic import make_frame
+    frames = [make_frame(760 + i, n_points=5_000, scene_id=f"scene{i // 5}") for i in range(10)]
+    start = spec.init_params(12, fresh_bn=True)
+    assert np.all(start["enc2.3.bn.gamma"] == 1) and np.all(start["pfn.bn.var"] == 1) and np.all(start["enc1.0.bn.mean"] == 0)
+    out = fit(ListDataset(frames), start, out_dir=tmp_path, epochs=4, batch_size=4, lr=2e-4, save_top=1, max_points=6_000, device=gpu,
+              val_dataset=ListDataset(frames[:5]), log=None)
+    hist = out["history"]
+    assert all(np.isfinite(h["train_loss"]) and np.isfinite(h["val_loss"]) for h in hist), hist
+    assert hist[-1]["train_loss"] < 0.9 * hist[0]["train_loss"], hist
+    trained = load_params(out["best"])
+    for k in ("pfn.bn.gamma", "enc1.0.bn.beta", "enc3.5.bn.gamma", "enc2.0.bn.mean", "pfn.bn.var"):
+        assert not np.array_equal(trained[k], start[k]), k
+    assert np.all(trained["enc1.1.bn.var"] > 0)
+    net = SeFlowNet(trained, device=gpu, max_points=6_000, precision="f16x2", autotune=False)
+    flow = net.forward(frames[0]["pc0"], frames[1]["pc0"], frames[2]["pc0"], frames[0]["pose0"], frames[1]["pose0"], frames[1]["pose1"])
+    assert torch.isfinite(flow).all()
 
 
 def test_checkpoint_resume_continues_bit_for_bit(gpu, tmp_path):
@@ -75,17 +102,21 @@ def test_checkpoint_resume_continues_bit_for_bit(gpu, tmp_path):
     frames = [make_frame(740 + i, n_points=6_000, scene_id="s") for i in range(4)]
     a, b = make_sample(frames, (0, 1, 2), gpu), make_sample(frames, (1, 2, 3), gpu)
     tr = SeFlowTrainer(spec.init_params(10), device=gpu, max_points=7_000, precision="bf16x3")
-    tr.train_step(*a, lr=1e-3); tr.train_step(*b, lr=1e-3)
+    tr.train_step(*a, lr=1e-4); tr.train_step(*b, lr=1e-4)
     path = tr.save_checkpoint(tmp_path / "ck.npz", epoch=0)
-    tr.train_step(*a, lr=1e-3); tr.train_step(*b, lr=1e-3)
+    tr.train_step(*a, lr=1e-4); tr.train_step(*b, lr=1e-4)
     other = SeFlowTrainer(spec.init_params(11), device=gpu, max_points=7_000, precision="bf16x3")       # different initial weights
     extra = other.load_checkpoint(path)
     assert int(extra["epoch"]) == 0 and other.step_count == 2
-    other.train_step(*a, lr=1e-3); other.train_step(*b, lr=1e-3)
+    other.train_step(*a, lr=1e-4); other.train_step(*b, lr=1e-4)
     # the loss's scatter-add half may differ in the last bits between runs: compare to float32 round-off, moments included
     for x, y in ((tr.flat_p, other.flat_p), (tr.flat_m, other.flat_m), (tr.flat_v, other.flat_v)):
         assert (x - y).abs().max().item() <= 1e-6 * max(x.abs().max().item(), 1e-30)
     assert other.step_count == tr.step_count == 4
+    for k in ("pfn.bn.mean", "pfn.bn.var", "enc1.0.bn.mean", "enc3.5.bn.var"):          # BatchNorm running statistics travel with the file
+        x, y = tr.net.p[k], other.net.p[k]
+        assert (x - y).abs().max().item() <= 1e-6 * max(x.abs().max().item(), 1e-30), k
+        assert not np.array_equal(x.cpu().numpy(), spec.init_params(10)[k]), k                # ... and have moved since initialisation
     # the file is also an inference checkpoint: save.main's loader -> SeFlowNet
     from himo_amd.seflow.checkpoint import load_params
     net = SeFlowNet(load_params(path), device=gpu, max_points=7_000, precision="bf16x3", autotune=False)

@@ -199,17 +199,21 @@ def _sample(n, seed=0):
     return pch, pc0, pc1, pose_h, pose0, pose1
 
 
-@pytest.mark.parametrize("precision,n_points", [("bf16x3", 6000), ("mixed", 6000), ("f32", 6000), ("mixed", 120_000)])
-def test_full_network_gradients_match_autograd(gpu, precision, n_points):
+@pytest.mark.parametrize("precision,n_points,batchnorm", [
+    ("bf16x3", 6000, "frozen"), ("mixed", 6000, "frozen"), ("f32", 6000, "frozen"), ("mixed", 120_000, "frozen"),
+    ("f32", 6000, "batch"), ("mixed", 6000, "batch"), ("bf16x3", 6000, "batch"), ("mixed", 120_000, "batch")])
+def test_full_network_gradients_match_autograd(gpu, precision, n_points, batchnorm):
     """Every trainable tensor's gradient (pillar net, 16 encoder convs, decoder, head) against CPU autograd through the
     oracle network, for the linear functional L = sum(res * G) -- at test size in all three arithmetics and once at
-    BASELINE size (3 x 120k points) in the training default."""
+    BASELINE size (3 x 120k points) in the training default.  ``batchnorm="batch"`` (BASELINE config 5: the reference's job
+    trains from scratch): BatchNorm in training mode on both sides -- batch statistics, gamma / beta gradients, and the
+    running statistics after the forward pass equal to torch's."""
     import oracle.seflow_oracle as so
     from himo_amd.seflow import spec
     from himo_amd.seflow.train import SeFlowTrainer
     params = spec.init_params(4)
     pch, pc0, pc1, pose_h, pose0, pose1 = _sample(n_points, seed=3)
-    tr = SeFlowTrainer(params, device=gpu, max_points=n_points + 2000, precision=precision)
+    tr = SeFlowTrainer(params, device=gpu, max_points=n_points + 2000, precision=precision, batchnorm=batchnorm)
     res = tr.forward(pch, pc0, pc1, pose_h, pose0, pose1)
     rng = np.random.default_rng(9)
     G = np.zeros((len(pc0), 4), np.float32)
@@ -218,13 +222,15 @@ def test_full_network_gradients_match_autograd(gpu, precision, n_points):
     torch.cuda.synchronize()
     got = {k: v.cpu().numpy() for k, v in tr.g.items()}
     res_gpu = res.cpu().numpy()
+    batch = batchnorm == "batch"
+    assert any(k.endswith(".bn.gamma") for k in got) == batch
 
     torch.set_num_threads(max(1, torch.get_num_threads()))
     P = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
     for k in P:
-        if k.endswith(".weight") or k.endswith(".bias"):
+        if k.endswith(".weight") or k.endswith(".bias") or (batch and (k.endswith(".gamma") or k.endswith(".beta"))):
             P[k].requires_grad_(True)
-    ref_res, valid, _ = so.forward_train(P, pch, pc0, pc1, pose_h, pose0, pose1)
+    ref_res, valid, _ = so.forward_train(P, pch, pc0, pc1, pose_h, pose0, pose1, training=batch)
     v = valid.numpy()
     assert np.abs(res_gpu[v][:, :3] - ref_res.detach().numpy()).max() <= 1e-4
     assert np.all(res_gpu[~v] == 0)
@@ -240,10 +246,24 @@ def test_full_network_gradients_match_autograd(gpu, precision, n_points):
         g = got[k]
         if k.startswith("head.dec2"):
             g = g[..., :3]
+        if batch and k.startswith("enc") and k.endswith(".bias") and ".bn." not in k:
+            # a bias in front of a training-mode BatchNorm has NO gradient (the batch mean absorbs it): both sides hold
+            # rounding noise around zero, far below the layer's weight gradient
+            floor = 1e-4 * np.abs(pairs[k[:-4] + "weight"]).max()
+            assert np.abs(g).max() <= floor and np.abs(r).max() <= floor, (k, np.abs(g).max(), np.abs(r).max(), floor)
+            continue
         scale = max(np.abs(r).max(), 1e-12)
         worst[k] = np.abs(g - r).max() / scale
     bad = {k: e for k, e in worst.items() if not e <= 2e-3}
     assert not bad, bad
+    if batch:
+        # running statistics after ONE training-mode forward (momentum 0.1, unbiased variance; the pillar net's moved three
+        # times, once per sweep in call order) against torch's in-place updates of the oracle's tensors
+        for prefix in ["pfn.bn"] + [f"{n}.bn" for n, *_ in spec.ENCODER]:
+            for stat in ("mean", "var"):
+                mine, theirs = tr.net.p[f"{prefix}.{stat}"].cpu().numpy(), P[f"{prefix}.{stat}"].numpy()
+                assert not np.array_equal(theirs, params[f"{prefix}.{stat}"]), prefix          # it did move
+                assert np.abs(mine - theirs).max() <= 2e-5 * max(np.abs(theirs).max(), 1.0), (prefix, stat, np.abs(mine - theirs).max())
 
 
 def _labelled_sample(n, seed):
@@ -262,21 +282,24 @@ def _labelled_sample(n, seed):
     return (pch, pc0, pc1, pose_h, pose0, pose1), lab0, lab1
 
 
-def test_train_steps_reduce_the_loss(gpu):
+@pytest.mark.parametrize("batchnorm,lr,steps", [("frozen", 1e-3, 6), ("batch", 1e-4, 8)])
+def test_train_steps_reduce_the_loss(gpu, batchnorm, lr, steps):
+    """(learning rates from scripts/exp_bn_lr.py: with BatchNorm in training mode Adam at 1e-3 overshoots on the first steps --
+    the loss spikes 5.8 -> 96 before it recovers -- while 1e-4, next to the launcher's 6e-5, falls monotonically)"""
     from himo_amd.seflow import spec
     from himo_amd.seflow.train import SeFlowTrainer
     (pch, pc0, pc1, pose_h, pose0, pose1), lab0, lab1 = _labelled_sample(8000, 11)
-    tr = SeFlowTrainer(spec.init_params(5), device=gpu, max_points=8000)
+    tr = SeFlowTrainer(spec.init_params(5), device=gpu, max_points=8000, batchnorm=batchnorm)
     l0, l1 = torch.from_numpy(lab0).to(gpu), torch.from_numpy(lab1).to(gpu)
     totals = []
-    for _ in range(6):
-        _, total = tr.train_step(pch, pc0, pc1, pose_h, pose0, pose1, l0, l1, n_labels=int(lab0.max()) + 1, lr=1e-3)
+    for _ in range(steps):
+        _, total = tr.train_step(pch, pc0, pc1, pose_h, pose0, pose1, l0, l1, n_labels=int(lab0.max()) + 1, lr=lr)
         totals.append(float(total.item()))
     assert all(np.isfinite(totals)), totals
     assert totals[-1] < 0.9 * totals[0], totals
     # the exported parameters drive the inference network to the trainer's own forward result
     from himo_amd.seflow.model import SeFlowNet
-    res = tr.forward(pch, pc0, pc1, pose_h, pose0, pose1)[:, :3].cpu().numpy()
+    res = tr.forward(pch, pc0, pc1, pose_h, pose0, pose1, training=False)[:, :3].cpu().numpy()      # eval mode: running statistics
     net = SeFlowNet(tr.export_params(), device=gpu, max_points=8000, precision="f32")
     flow = net.forward(pch, pc0, pc1, pose_h, pose0, pose1).cpu().numpy()
     ego = np.linalg.inv(pose1) @ pose0
@@ -285,10 +308,12 @@ def test_train_steps_reduce_the_loss(gpu):
     assert np.abs((flow - pose_flow)[valid] - res[valid]).max() <= 2e-4
 
 
-def test_train_batch_averages_the_per_sample_gradients(gpu):
+@pytest.mark.parametrize("batchnorm", ["frozen", "batch"])
+def test_train_batch_averages_the_per_sample_gradients(gpu, batchnorm):
+    """(batch mode: the statistics are per forward call, i.e. per sample, so the batch gradient is still the plain average)"""
     from himo_amd.seflow import spec
     from himo_amd.seflow.train import SeFlowTrainer
-    tr = SeFlowTrainer(spec.init_params(6), device=gpu, max_points=6000)
+    tr = SeFlowTrainer(spec.init_params(6), device=gpu, max_points=6000, batchnorm=batchnorm)
     batch, grads = [], []
     for seed in (21, 22):
         args, lab0, lab1 = _labelled_sample(5000, seed)
