@@ -35,6 +35,7 @@ struct GruHeadArgs {
     float* flow;
     int iters;
     int img_split;                                      // img0 / img1 rows in the split activation format (convsg.hip)
+    unsigned* nonfinite;                                // or NULL: set to 1 when any flow value written is NaN / inf (fp16-range guard)
 };
 
 // several samples in one launch (himo_gru_head_batch): a block finds its sample from the running block counts -- one
@@ -154,13 +155,16 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
 #define sigmoid_f(v) ((v) * 0.25f + 0.5f)
 #define tanh_f(v) ((v) * 0.5f)
 #endif
+// (Round 3, measured and dropped -- profiles/r03_exp_head_gate_pipelining.txt: the z | r product as two products with the r
+// gate issued slab by slab under the z product's matrix instructions and the z gate under the q product's.  The unrolled slab
+// loop it needs costs 20 spilled registers at the 168 budget; 204-208 us per 120k points against 200.7.)
 template <int FMT, int SLABS>
 __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_head_kernel(GruHeadArgs a, GruHeadBatch batch) {
     constexpr bool FOLD = SLABS == 9;
     constexpr int kGhPlane = SLABS * kGhRows * 32;
     __shared__ __attribute__((aligned(16))) unsigned char A[FMT * kGhPlane];
     __shared__ int s_pid[kGhRows];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;     // wave id in an SGPR: uniform branches
     const int li = lane & 31, lh = lane >> 5;
     int bid = blockIdx.x;
     {   // this block's sample (uniform: scalar loads from the argument block)
@@ -203,36 +207,60 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
     }
     __syncthreads();
 
-    // h0: wave w gathers its 32 hidden columns (0: pc0 image, 1: pc1 image, 2,3: decoder map) in accumulator layout
+    // h0: wave w gathers its 32 hidden columns (0: pc0 image, 1: pc1 image, 2,3: decoder map) in accumulator layout.
+    // BRANCH-FREE: every lane issues all of its 32 row loads (dropped points read cell 0 and discard it) and waits ONCE.
+    // Written as `if (cell >= 0) v = src[...]` the compiler branched around each load and waited vmcnt(0) per element:
+    // 32 serialized memory round trips per block, ~26 us of the block's life (the 64 us "fixed cost" of the r02 breakdown).
     const float* src = wave == 0 ? a.img0 : wave == 1 ? a.img1 : a.dec + (wave - 2) * 32;
     const int src_pitch = wave < 2 ? a.img_pitch : a.dec_pitch;
     float h[2][16];
+    {
+        int cell[2][16];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int cell = s_pid[row];
-            float v = 0.f;
-            if (cell >= 0) {
-                if (FMT == 2 && wave < 2) {
-                    // fp16 split: an image feature IS its two-term value h + l -- read as stored when the pillar stage wrote
-                    // the image split, rounded here when it wrote float32 -- so both layouts give the same bits
-                    unsigned hh, ll;
-                    if (a.img_split) {
-                        const unsigned short* rec = reinterpret_cast<const unsigned short*>(src + (int64_t)cell * src_pitch + (li & ~15));
-                        hh = rec[li & 15]; ll = rec[16 + (li & 15)];
-                    } else {
-                        split2(src[(int64_t)cell * src_pitch + li], hh, ll);
-                    }
-                    v = (float)__builtin_bit_cast(_Float16, (unsigned short)hh) + (float)__builtin_bit_cast(_Float16, (unsigned short)ll) * kF16LowInv;
-                } else {
-                    v = src[(int64_t)cell * src_pitch + li];
+            for (int r = 0; r < 16; ++r) cell[rt][r] = s_pid[rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        if (FMT == 2 && wave < 2 && a.img_split) {
+            // fp16 split image rows: the value IS its two-term pair (h at half-word li & 15, l 32 bytes further) of the 16-channel record
+            unsigned short hh[2][16], ll[2][16];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned short* rec = reinterpret_cast<const unsigned short*>(src + (int64_t)max(cell[rt][r], 0) * src_pitch + (li & ~15));
+                    hh[rt][r] = rec[li & 15]; ll[rt][r] = rec[16 + (li & 15)];
                 }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    h[rt][r] = cell[rt][r] >= 0 ? (float)__builtin_bit_cast(_Float16, hh[rt][r]) + (float)__builtin_bit_cast(_Float16, ll[rt][r]) * kF16LowInv : 0.f;
+        } else {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h[rt][r] = src[(int64_t)max(cell[rt][r], 0) * src_pitch + li];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h[rt][r] = cell[rt][r] >= 0 ? h[rt][r] : 0.f;
+            if (FMT == 2 && wave < 2) {
+                // float32 image rows in the fp16-split network: rounded to the two-term value here, so both layouts give the same bits
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        unsigned hh, ll;
+                        split2(h[rt][r], hh, ll);
+                        h[rt][r] = (float)__builtin_bit_cast(_Float16, (unsigned short)hh) + (float)__builtin_bit_cast(_Float16, (unsigned short)ll) * kF16LowInv;
+                    }
             }
-            h[rt][r] = v;
-            a_store<FMT, SLABS>(A, row, wave * 32 + li, v);
         }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a_store<FMT, SLABS>(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, h[rt][r]);
+    }
     __syncthreads();
 
     const int col_zr[2] = {wave * 32, 128 + wave * 32};
@@ -249,13 +277,14 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
         gemm192<2, 2, FMT, SLABS>(A, a.wzr, 256, col_zr, acc, 0, li, lh);
-        __syncthreads();                                        // every wave has read [h | x]
-        float z[2][16];
+#ifndef HIMO_EXP_HNOWAR                                         // experiment (results are wrong): the two write-after-read barriers gone --
+        __syncthreads();                                        // every wave has read [h | x]      the bound on what a second operand buffer could buy
+#endif
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                z[rt][r] = sigmoid_f(acc[rt][0][r] + bz);
+                acc[rt][0][r] = sigmoid_f(acc[rt][0][r] + bz);                      // z replaces its accumulator element
                 const float rr = sigmoid_f(acc[rt][1][r] + br);
                 a_store<FMT, SLABS>(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, rr * h[rt][r]);
             }
@@ -266,13 +295,16 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
 #pragma unroll
             for (int r = 0; r < 16; ++r) acq[rt][0][r] = 0.f;
         gemm192<2, 1, FMT, SLABS>(A, a.wq, 128, col_q, acq, 0, li, lh);
+#ifndef HIMO_EXP_HNOWAR
         __syncthreads();
+#endif
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float q = tanh_f(acq[rt][0][r] + bq);
-                const float hn = (1.0f - z[rt][r]) * h[rt][r] + z[rt][r] * q;
+                const float zz = acc[rt][0][r];
+                const float hn = (1.0f - zz) * h[rt][r] + zz * q;
                 h[rt][r] = hn;
                 a_store<FMT, SLABS>(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, hn);
             }
@@ -308,6 +340,9 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
                 out = pose_flow + (s + a.b2[c]);
             }
             a.flow[i * 3 + c] = out;
+            // the finite-flow guard of the fp16-split arithmetic, at the only place a flow value is born (an overflowed activation
+            // is inf -> NaN at the next split and reaches every output it feeds): taken only when something IS wrong
+            if (a.nonfinite && !(fabsf(out) <= 3.4028234664e38f)) atomicOr(a.nonfinite, 1u);
         }
     }
 }
@@ -323,7 +358,7 @@ static int gru_head_launch(int n_samples, const himo_head_sample* h_samples, int
                            const float* d_w_off, const float* d_b_off, bool folded,
                            const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
                            const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
-                           int iters, int packed_format, int img_split, void* stream) {
+                           int iters, int packed_format, int img_split, unsigned* d_nonfinite, void* stream) {
     if (img_split && (packed_format != 1 || (img_pitch & 15))) return HIMO_ERR_INVALID_ARGUMENT;
     if (n_samples < 0 || n_samples > kGhMaxSamples || (n_samples && !h_samples)) return HIMO_ERR_INVALID_ARGUMENT;
     if (iters < 0 || !(packed_format == 0 || packed_format == 1) || img_pitch < 32 || dec_pitch < 64) return HIMO_ERR_INVALID_ARGUMENT;
@@ -352,6 +387,7 @@ static int gru_head_launch(int n_samples, const himo_head_sample* h_samples, int
     a.wzr = (const unsigned short*)d_wzr_packed; a.bzr = d_bzr; a.wq = (const unsigned short*)d_wq_packed; a.bq = d_bq;
     a.w1 = (const unsigned short*)d_w1_packed; a.b1 = d_b1; a.w2 = d_w2; a.b2 = d_b2; a.iters = iters;
     a.img_split = img_split ? 1 : 0;
+    a.nonfinite = d_nonfinite;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("gru_head_kernel", s);
     const dim3 grid((unsigned)blocks);
@@ -372,7 +408,7 @@ extern "C" int himo_gru_head_batch(int n_samples, const himo_head_sample* h_samp
                                    const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
                                    int iters, int packed_format, int img_split, void* stream) {
     return gru_head_launch(n_samples, h_samples, img_pitch, dec_pitch, d_w_off, d_b_off, false, d_wzr_packed, d_bzr, d_wq_packed, d_bq,
-                           d_w1_packed, d_b1, d_w2, d_b2, iters, packed_format, img_split, stream);
+                           d_w1_packed, d_b1, d_w2, d_b2, iters, packed_format, img_split, nullptr, stream);
 }
 
 extern "C" int himo_gru_head_batch_folded(int n_samples, const himo_head_sample* h_samples, int img_pitch, int dec_pitch,
@@ -380,7 +416,26 @@ extern "C" int himo_gru_head_batch_folded(int n_samples, const himo_head_sample*
                                           const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
                                           int iters, int packed_format, int img_split, void* stream) {
     return gru_head_launch(n_samples, h_samples, img_pitch, dec_pitch, nullptr, nullptr, true, d_wzr_packed, d_bzr, d_wq_packed, d_bq,
-                           d_w1_packed, d_b1, d_w2, d_b2, iters, packed_format, img_split, stream);
+                           d_w1_packed, d_b1, d_w2, d_b2, iters, packed_format, img_split, nullptr, stream);
+}
+
+// Both forms above plus the finite-flow guard: d_w_off / d_b_off NULL selects the folded weights ([144][cout] matrices);
+// d_nonfinite (device uint32, or NULL) is OR-ed with 1 when any flow value this launch writes is NaN or infinite -- the caller
+// clears it (himo_clear_u32) before the launches it wants to cover and reads it back when it needs the verdict.
+extern "C" int himo_gru_head_batch_guarded(int n_samples, const himo_head_sample* h_samples, int img_pitch, int dec_pitch,
+                                           const float* d_w_off, const float* d_b_off,
+                                           const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
+                                           const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
+                                           int iters, int packed_format, int img_split, uint32_t* d_nonfinite, void* stream) {
+    if ((d_w_off == nullptr) != (d_b_off == nullptr)) return HIMO_ERR_INVALID_ARGUMENT;
+    return gru_head_launch(n_samples, h_samples, img_pitch, dec_pitch, d_w_off, d_b_off, d_w_off == nullptr, d_wzr_packed, d_bzr, d_wq_packed,
+                           d_bq, d_w1_packed, d_b1, d_w2, d_b2, iters, packed_format, img_split, d_nonfinite, stream);
+}
+
+extern "C" int himo_clear_u32(uint32_t* d_words, int n, void* stream) {
+    if (!d_words || n < 1) return HIMO_ERR_INVALID_ARGUMENT;
+    HIMO_HIP(hipMemsetAsync(d_words, 0, (size_t)n * 4, (hipStream_t)stream));
+    return HIMO_OK;
 }
 
 extern "C" int himo_gru_head(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0, const float* d_img1,

@@ -129,6 +129,31 @@ class HiMoPipeline:
         """precision="auto": leave the fp16 split for the bf16 split (float32 range) for good"""
         self.net = SeFlowNet(precision="bf16x3", **self._net_args)
 
+    def _guard_begin(self):
+        """fp16 split: zero the network's finite-flow word (the fused head ORs 1 into it when it writes a NaN / inf flow value,
+        csrc/gruhead.hip) -- stream-ordered, no framework kernel, no host sync"""
+        if self.net.precision == "f16x2":
+            if not self.net.fused_head:
+                raise RuntimeError("precision='f16x2' needs the fused head: its output stage carries the finite-flow guard")
+            self.net.clear_nonfinite()
+
+    def _guard_now(self) -> bool:
+        """True when the launches since ``_guard_begin`` wrote only finite flow values (one 4-byte read back: a host sync)"""
+        return self.net.precision != "f16x2" or int(self.net.nonfinite.item()) == 0
+
+    def _guard_later(self):
+        """queue the read-back of the guard word (4 bytes into pinned memory + an event) for ``sync_check`` one batch later"""
+        if self.net.precision != "f16x2":
+            return
+        if not hasattr(self, "_flag_ring"):
+            self._flag_ring, self._flag_next = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)], 0
+        host = self._flag_ring[self._flag_next]
+        self._flag_next ^= 1
+        host.copy_(self.net.nonfinite, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._finite = (host, ev)
+
     def flows(self, samples) -> list:
         """Network only, for a list of samples: [(N0_k,3) flow incl. ego motion] -- the h5 ``<res_name>`` payload that
         ``save.run`` writes.  In the fp16 split every call checks its flows for non-finite values BEFORE returning them (one
@@ -137,8 +162,9 @@ class HiMoPipeline:
         counts = [int(s.pc0.shape[0]) for s in samples]
         flat = torch.empty((sum(counts), 3), dtype=torch.float32, device=self.device)
         outs = list(torch.split(flat, counts)) if counts else []
+        self._guard_begin()
         self._forward(samples, outs)
-        if self.net.precision == "f16x2" and not bool(torch.isfinite(flat).all().item()):
+        if not self._guard_now():
             if not self.auto:
                 raise FloatingPointError("non-finite flow: activations left the fp16 range of precision='f16x2'; "
                                          "use precision='bf16x3' (or 'auto') for these weights")
@@ -151,8 +177,9 @@ class HiMoPipeline:
         split and reaches the flow; this raises instead of handing such a batch on.  Checked one batch late by
         ``run`` (so it never stalls the stream) and by the caller after the last batch."""
         if self._finite is not None:
-            ok, self._finite = bool(self._finite.item()), None
-            if not ok:
+            (host, ev), self._finite = self._finite, None
+            ev.synchronize()
+            if int(host.item()) != 0:
                 raise FloatingPointError("non-finite flow: activations left the fp16 range of precision='f16x2'; "
                                          "use SeFlowNet(precision='bf16x3') for these weights")
 
@@ -174,14 +201,13 @@ class HiMoPipeline:
         self.sync_check()                                    # the PREVIOUS batch's flag: no stall on this one
 
         outs = [batch.flow[int(o[k]):int(o[k + 1])] for k in range(len(samples))]
+        self._guard_begin()
         self._forward(samples, outs)
-        if self.net.precision == "f16x2":
-            finite = torch.isfinite(batch.flow).all()
-            if not self.auto:
-                self._finite = finite                            # checked one batch late (sync_check)
-            elif not bool(finite.item()):                        # auto: checked now (one host sync per batch)
-                self._fall_back()
-                self._forward(samples, outs)
+        if not self.auto:
+            self._guard_later()                                  # checked one batch late (sync_check)
+        elif not self._guard_now():                              # auto: checked now (one host sync per batch)
+            self._fall_back()
+            self._forward(samples, outs)
         T = batch.total_points
         out = {"comp_dis": self._rows("comp_dis", T, 3)}
         if refined:

@@ -65,6 +65,9 @@ _lib.register({
                             + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "himo_gru_head_batch_folded": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 8
                                    + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "himo_gru_head_batch_guarded": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 10
+                                    + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "himo_clear_u32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "himo_head_gather": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
@@ -229,6 +232,8 @@ class SeFlowNet:
         self.DEC = buf(H * W, 64)
         self.max_points = 0
         self._reserve_points(max_points)
+        # finite-flow guard: the fused head ORs 1 into this word when it writes a NaN / inf flow value (csrc/gruhead.hip)
+        self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
         self._range = _f32x(spec.POINT_CLOUD_RANGE[:3])
         self._voxel = _f32x(spec.VOXEL_SIZE)
         r, v = spec.POINT_CLOUD_RANGE, spec.VOXEL_SIZE
@@ -293,6 +298,10 @@ class SeFlowNet:
         self._B0 = buf                                 # a rebound / reallocated image buffer holds arbitrary bytes
         self.drop_plan()
         self.reset_images()
+
+    def clear_nonfinite(self):
+        """zero the finite-flow guard word (stream-ordered; no host sync)"""
+        _lib.check(self.lib.himo_clear_u32(self.nonfinite.data_ptr(), 1, _lib.stream_handle()), "himo_clear_u32")
 
     def reset_images(self):
         """Mark every pillar-image cell dirty (the next forward rewrites the whole image).  Needed only after something other
@@ -561,18 +570,18 @@ class SeFlowNet:
                 h.d_dec, h.d_xyz_t = self.DEC[k].data_ptr(), st["xyz_t"][slot0].data_ptr()
                 h.d_pts, h.pc_stride, h.d_flow = pc0.data_ptr(), pc0.shape[1], flow.data_ptr()
             tail = (p["head.dec2.weight"].data_ptr(), p["head.dec2.bias"].data_ptr(),
-                    spec.GRU_ITERS, self.packed_format, 1 if self.split_acts else 0, _lib.stream_handle())
+                    spec.GRU_ITERS, self.packed_format, 1 if self.split_acts else 0, self.nonfinite.data_ptr(), _lib.stream_handle())
             if self.fold_head:
-                st = self.lib.himo_gru_head_batch_folded(len(arr), ctypes.addressof(arr), 32 * F, 64,
-                                                         pk["head.gru.zr.weight.h"].data_ptr(), p["head.gru.zr.bias"].data_ptr(),
-                                                         pk["head.gru.q.weight.h"].data_ptr(), p["head.gru.q.bias"].data_ptr(),
-                                                         pk["head.dec1.weight.h"].data_ptr(), p["head.dec1.bias"].data_ptr(), *tail)
+                st = self.lib.himo_gru_head_batch_guarded(len(arr), ctypes.addressof(arr), 32 * F, 64, None, None,
+                                                          pk["head.gru.zr.weight.h"].data_ptr(), p["head.gru.zr.bias"].data_ptr(),
+                                                          pk["head.gru.q.weight.h"].data_ptr(), p["head.gru.q.bias"].data_ptr(),
+                                                          pk["head.dec1.weight.h"].data_ptr(), p["head.dec1.bias"].data_ptr(), *tail)
             else:
-                st = self.lib.himo_gru_head_batch(len(arr), ctypes.addressof(arr), 32 * F, 64,
-                                                  p["head.offset.weight"].data_ptr(), p["head.offset.bias"].data_ptr(),
-                                                  pk["head.gru.zr.weight"].data_ptr(), p["head.gru.zr.bias"].data_ptr(),
-                                                  pk["head.gru.q.weight"].data_ptr(), p["head.gru.q.bias"].data_ptr(),
-                                                  pk["head.dec1.weight"].data_ptr(), p["head.dec1.bias"].data_ptr(), *tail)
+                st = self.lib.himo_gru_head_batch_guarded(len(arr), ctypes.addressof(arr), 32 * F, 64,
+                                                          p["head.offset.weight"].data_ptr(), p["head.offset.bias"].data_ptr(),
+                                                          pk["head.gru.zr.weight"].data_ptr(), p["head.gru.zr.bias"].data_ptr(),
+                                                          pk["head.gru.q.weight"].data_ptr(), p["head.gru.q.bias"].data_ptr(),
+                                                          pk["head.dec1.weight"].data_ptr(), p["head.dec1.bias"].data_ptr(), *tail)
             _lib.check(st, "himo_gru_head_batch")
 
     def pillarize_all(self, sweeps, transforms):

@@ -361,6 +361,17 @@ int himo_gru_head_batch_folded(int n_samples, const himo_head_sample* h_samples,
                                const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
                                const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
                                int iters, int packed_format, int img_split, void* stream);
+/* himo_gru_head_batch (d_w_off / d_b_off given) or himo_gru_head_batch_folded (both NULL: folded [144][cout] weights) with the
+ * finite-flow guard of the fp16-split arithmetic built into the output stage: *d_nonfinite (device uint32, may be NULL) is
+ * OR-ed with 1 when any flow value this launch writes is NaN or infinite.  The caller clears the word (himo_clear_u32) before
+ * the launches it wants covered.  Replaces the host framework's isfinite reduction over the flow buffer. */
+int himo_gru_head_batch_guarded(int n_samples, const himo_head_sample* h_samples, int img_pitch, int dec_pitch,
+                                const float* d_w_off, const float* d_b_off,
+                                const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
+                                const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
+                                int iters, int packed_format, int img_split, uint32_t* d_nonfinite, void* stream);
+int himo_clear_u32(uint32_t* d_words, int n, void* stream);
+
 /* per-point head glue: hx[i] = [img0[cell], img1[cell], dec[cell], Linear(3,64)(offset)] (192 floats; zeros for
  * dropped points), rhx[i][128:192] = the same Linear output */
 int himo_head_gather(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0,
