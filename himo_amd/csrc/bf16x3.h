@@ -66,4 +66,14 @@ __device__ inline void split2_rounded(float x, unsigned& h, unsigned& l) {
     split2(x, h, l);
 }
 
+// the same split as ONE 32-bit word h | l << 16 (epilogues): v_cvt_f16_f32 for h; x - h is exact in float32, so the low part
+// is a single rounding however the compiler forms it (cvt / sub / cvt, or one v_fma_mix); the empty asm pins x's own rounding
+typedef _Float16 himo_half2 __attribute__((ext_vector_type(2)));
+__device__ inline unsigned split2_packed(float x) {
+    asm("" : "+v"(x));
+    const _Float16 hh = (_Float16)x;
+    const _Float16 ll = (_Float16)((x - (float)hh) * kF16LowScale);
+    return __builtin_bit_cast(unsigned, himo_half2{hh, ll});
+}
+
 }  // namespace himo

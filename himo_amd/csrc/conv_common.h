@@ -59,15 +59,21 @@ __device__ inline int xcd_block_id(int bid, int n_blocks) {
 #endif
 }
 
+// GELU through erf(|v| / sqrt 2) = 1 - p(t) t exp(-v^2 / 2), t = 1 / (1 + 0.3275911 |v| / sqrt 2) (Abramowitz & Stegun 7.1.26, 1.5e-7
+// absolute).  Arranged for instruction count -- the convolutions' epilogues run beside other waves' matrix instructions, where
+// a SIMD issues only ~5 vector instructions per matrix instruction (scripts/micro/mfma_filler_cost.hip), so every one counts:
+// 11 vector + 2 transcendental instructions (17 + 2 in the textbook arrangement): the constants of |v| / sqrt 2 are folded into
+// the polynomial argument and the exponent, and v / 2 (1 + sign(v) erf) = v / 2 + |v / 2| erf is ONE fused multiply-add.
 __device__ inline float gelu_exact(float v) {
-    const float x = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    const float hv = 0.5f * v;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(v), 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
     p = fmaf(p, t, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-x * x);            // erf(|v| / sqrt 2)
-    return v * 0.5f * (1.0f + copysignf(e, v));
+    const float ex = __builtin_amdgcn_exp2f((v * v) * (-0.5f * 1.44269504088896340736f));      // exp(-v^2 / 2)
+    const float e = fmaf(-(p * t), ex, 1.0f);                 // erf(|v| / sqrt 2)
+    return fmaf(fabsf(hv), e, hv);
 }
 // GRU gates: hardware exp2 / rcp (~1 ulp each); the gate outputs are O(1) and feed a 1e-4 abs budget
 __device__ inline float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -77,6 +83,20 @@ __device__ inline float tanh_f(float v) {
     return copysignf(t, v);
 }
 
+
+// ---- the two epilogues of the backbone (bias; bias + BatchNorm + GELU) with the fewest vector instructions ------------------------
+// value = fma(acc, A, B) with per-channel constants A = k (* scale), B = bias (* scale + shift): the accumulator's packing scale k
+// (a power of two, so A is exact), the bias and the folded BatchNorm in ONE instruction instead of mul + add + mul + add.
+template <int EPI> constexpr bool kEpiAffine = EPI == kEpiBias || EPI == kEpiBiasBnGelu || EPI == kEpiBiasGelu;
+template <int EPI>
+__device__ inline void epi_affine(float k, float bias, float sc, float sh, float& A, float& B) {
+    if (EPI == kEpiBiasBnGelu) { A = k * sc; B = fmaf(bias, sc, sh); } else { A = k; B = bias; }
+}
+template <int EPI>
+__device__ inline float epi_activate(float acc, float A, float B) {
+    const float v = fmaf(acc, A, B);
+    return EPI == kEpiBias ? v : gelu_exact(v);
+}
 
 // one output element: bias -> (BatchNorm scale/shift) -> activation / GRU gate math -> store
 template <int EPI>
@@ -110,19 +130,21 @@ __device__ inline void epilogue_store(const ConvArgs& a, float* __restrict__ you
 // PAIRED (accumulator layouts where lane parity = channel parity and both lanes of a pair hold the same pixel): the even
 // lane takes its neighbour's high part, the odd lane its neighbour's low part, and each stores ONE 32-bit word -- a
 // wave's 32 channels of a pixel leave as one full 128-byte line per store instruction, as the float32 epilogue does.
+__device__ inline unsigned split_word(float v, bool odd);
 template <int EPI, bool PAIRED>
 __device__ inline void split_store(const ConvArgs& a, float* __restrict__ yout, int64_t pix, int co, float v, float sc, float sh) {
     if (EPI == kEpiBiasBnGelu) v = gelu_exact(v * sc + sh);
     else if (EPI == kEpiBiasGelu) v = gelu_exact(v);
     else if (EPI == kEpiBiasRelu) v = fmaxf(v, 0.f);
-    unsigned h, l;
-    split2_rounded(v, h, l);
     if (PAIRED) {
         const bool odd = co & 1;
-        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? h : l), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
         unsigned* rec = reinterpret_cast<unsigned*>(yout + pix * a.y_pitch + (co & ~15));
-        rec[(odd ? 8 : 0) + ((co & 15) >> 1)] = odd ? (recv | (l << 16)) : (h | (recv << 16));
-    } else {
+        rec[(odd ? 8 : 0) + ((co & 15) >> 1)] = split_word(v, odd);
+        return;
+    }
+    unsigned h, l;
+    split2_rounded(v, h, l);
+    {
         unsigned short* rec = reinterpret_cast<unsigned short*>(yout + pix * a.y_pitch + (co & ~15));
         rec[co & 15] = (unsigned short)h;
         rec[16 + (co & 15)] = (unsigned short)l;
@@ -131,7 +153,8 @@ __device__ inline void split_store(const ConvArgs& a, float* __restrict__ yout, 
 
 // the output admits 16-byte stores: base, pitches and strides multiples of four floats, whole 4-channel groups
 inline bool vec_store_ok(const ConvArgs& a) {
-    return (reinterpret_cast<uintptr_t>(a.y) & 15u) == 0 && !(a.y_pitch & 3) && !(a.y_batch_stride & 3) && !(a.y_outer_stride & 3) && !(a.Cout & 3);
+    return (reinterpret_cast<uintptr_t>(a.y) & 15u) == 0 && !(a.y_pitch & 3) && !(a.y_batch_stride & 3) && !(a.y_outer_stride & 3) && !(a.Cout & 3) &&
+           (int64_t)a.Ho * a.Wo * a.y_pitch < ((int64_t)1 << 29);            // 32-bit byte offsets inside an output image
 }
 
 // Epilogue of one accumulator block (v_mfma 32x32 layout: lane (li, lh) holds output channel ch0 + li of the 16 pixels
@@ -173,7 +196,9 @@ __device__ inline void store_block_vec(const ConvArgs& a, float* __restrict__ yo
 #ifdef HIMO_EXP_STORE_SCRATCH          // experiment: same store instructions, but into a 2 MB window (stays in L2: no HBM write traffic)
             float* dst = a.y + ((((pix0 + px) * (int64_t)a.y_pitch + ch0 + piece * 4) & 0x7ffff) + (blockIdx.x & 7) * 0) ;
 #else
-            float* dst = yout + (pix0 + px) * (int64_t)a.y_pitch + ch0 + piece * 4;
+            // 32-bit offset from the (uniform) image base: vec_store_ok() admits only images below 2 GB, and a 64-bit multiply-add per
+            // store was ~8 vector instructions of the block's ~60
+            float* dst = yout + (((unsigned)pix0 + (unsigned)px) * (unsigned)a.y_pitch + (unsigned)(ch0 + piece * 4));
 #endif
 #if defined(HIMO_EXP_STORE_NT)
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -203,12 +228,14 @@ __device__ inline float epilogue_value(float v, float sc, float sh) {
     return v;
 }
 // split x = h + l and pair up with the neighbouring lane (channel parity = lane parity, same pixel): the even lane ends up
-// with (h_even, h_odd), the odd lane with (l_even, l_odd) -- the 32-bit words of the split record (see split_store)
+// with (h_even, h_odd), the odd lane with (l_even, l_odd) -- the 32-bit words of the split record (see split_store).
+// Both lanes form p = h | l << 16, fetch the neighbour's p by DPP and pick their two half-words with one byte permute
+// (selector per lane parity): pack + mov_dpp + perm instead of two selects, a shift-or pair and the DPP move.
 __device__ inline unsigned split_word(float v, bool odd) {
-    unsigned h, l;
-    split2_rounded(v, h, l);
-    const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)(odd ? h : l), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-    return odd ? (recv | (l << 16)) : (h | (recv << 16));
+    const unsigned p = split2_packed(v);
+    const unsigned q = (unsigned)__builtin_amdgcn_mov_dpp((int)p, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+    // v_perm_b32: selector bytes 0-3 pick from the SECOND operand (p), 4-7 from the first (q)
+    return __builtin_amdgcn_perm(q, p, odd ? 0x03020706u : 0x05040100u);
 }
 
 // implemented in convbf.hip: stride-1 convolutions / row GEMMs on split-bf16 matrix instructions

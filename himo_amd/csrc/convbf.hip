@@ -277,6 +277,8 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
         const float b = a.bias ? a.bias[co] : 0.f;
         float sc = 1.f, sh = 0.f;
         if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
+        float eA = 1.f, eB = 0.f;                                 // fused bias / BatchNorm affine (conv_common.h): same bits as convsg / convsp
+        if (kEpiAffine<EPI>) epi_affine<EPI>(FMT == 2 ? kF16AccScale : 1.f, b, sc, sh, eA, eB);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -292,8 +294,12 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
                 }
                 float v = acc[mi][ni][r];
                 if (XACC) v += acx[mi][ni][r] * kF16LowInv;
-                if (FMT == 2) v *= kF16AccScale;
-                if (ok) epilogue_store<EPI>(a, yout, pix, co, v + b, sc, sh);
+                if (kEpiAffine<EPI>) {
+                    if (ok) yout[pix * a.y_pitch + co] = epi_activate<EPI>(v, eA, eB);
+                } else {
+                    if (FMT == 2) v *= kF16AccScale;
+                    if (ok) epilogue_store<EPI>(a, yout, pix, co, v + b, sc, sh);
+                }
             }
         }
     }

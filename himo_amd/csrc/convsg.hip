@@ -8,13 +8,14 @@
 // upsampling -- so a value is split ONCE instead of once per consuming block and halo overlap; the numbers that reach the
 // matrix instructions are bit-identical to the float32-activation kernels' (convsp.hip / convbf.hip).
 //
-// LDS image of a slab's halo patch: (TH + 2) rows x 48 pixels (34 used) x 64 bytes; the four 16-byte pieces of a pixel
-// (plane s, k-half lh) sit at slot (2 s + lh) ^ ((px >> 2) & 3).  Rows start on 16-pixel boundaries, so the XOR term
-// depends on the column alone and a fragment read is `ds_read_b128 v[kx][s] offset:row` with six per-lane offsets
-// computed once; every 16-lane group of a ds_read_b128 covers the 256-byte bank row exactly once ({0,12,20,24} and
-// {4,8,16,28} give four different (px >> 2) & 3).  LDS-DMA writes lane-linearly (M0 base + lane * 16), so the same XOR is
-// applied to each lane's SOURCE address: a permutation inside the pixel's 64 bytes -- coalescing is unchanged.
-// Pixels outside the image (and the 14 unused columns of a 48-pixel row) read a 64-byte zero page.
+// LDS image of a slab's halo patch: (TH + 2) rows x 40 pixel slots (34 used) x 64 bytes; the four 16-byte pieces of a pixel
+// (plane s, k-half lh) sit at slot (2 s + lh) ^ ((px >> 2) & 3), px = the pixel's column in its row.  A row is 2560 bytes = ten
+// 256-byte bank rows, so the bank of a piece depends on its column alone: a fragment read is `ds_read_b128 v[kx][s] offset:row`
+// with six per-lane offsets computed once, and every 16-lane group of a ds_read_b128 covers the 256-byte bank row exactly once
+// ({0,12,20,24} and {4,8,16,28} give four different (px >> 2) & 3).  LDS-DMA writes lane-linearly (M0 base + lane * 16) in
+// units of 16 pixels that run linearly over the patch (a unit may straddle two rows); the same XOR is applied to each lane's
+// SOURCE address: a permutation inside the pixel's 64 bytes -- coalescing is unchanged.  Pixels outside the image (and the 6
+// unused slots of a row) read a 64-byte zero page.
 //
 // Everything else as convsp.hip: a wave owns MI rows x 32 pixels x NT column tiles of 32 output channels (NT = 2: every
 // activation fragment meets two weight fragments -- the 8-row tiles of the 64-channel layers and the 4-row x 64-channel
@@ -68,11 +69,15 @@ __device__ inline void glds16(const void* gsrc, unsigned lds_dst) {
 // columns 2 li + kx) are again 32 consecutive slots for every tap (kx = 0: li, 1: 48 + li, 2: li + 1).  The gather costs
 // nothing: every DMA lane has its own source address anyway.
 template <int EPI, int PH, int MI, bool OSPLIT, int S, int NT = 1>
-__global__ __launch_bounds__(256, NT == 2 ? 2 : (S == 2 || MI == 4) ? 3 : 4)
+__global__ __launch_bounds__(256, NT == 2 ? (MI == 2 ? 3 : 2) : (S == 2 || MI == 4) ? 3 : 4)
 void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
-    constexpr int TW = 32, TH = MI * PH, PHt = S == 1 ? TH + 2 : 2 * TH + 1, PWP = S == 1 ? 48 : 80, UPR = PWP / 16;
-    constexpr int kRow = PWP * 64, kBuf = PHt * kRow;
-    constexpr int kUnits = PHt * UPR, kUPW = (kUnits + 3) / 4;    // DMA units of 16 pixels; units per wave
+    // S = 1: patch rows of 40 pixel slots (34 used; 2560 bytes = ten 256-byte bank rows, so the bank of a piece depends on its
+    // column alone and the swizzle term can be taken from the column whatever the row), DMA units of 16 pixels run LINEARLY
+    // over the patch and may straddle rows.  (48-slot rows until round 3: 61 KB for the 8-row tiles = two blocks per CU;
+    // 51 KB = three.)  S = 2: 80-slot rows, five whole units per row.
+    constexpr int TW = 32, TH = MI * PH, PHt = S == 1 ? TH + 2 : 2 * TH + 1, PWP = S == 1 ? 40 : 80, UPR = PWP / 16;
+    constexpr int kRow = PWP * 64, kBuf = (PHt * kRow + 1023) / 1024 * 1024;
+    constexpr int kUnits = S == 1 ? (PHt * PWP + 15) / 16 : PHt * UPR, kUPW = (kUnits + 3) / 4;    // DMA units of 16 pixels; units per wave
     constexpr int BN = (4 / PH) * 32 * NT;                       // NT column tiles of 32 channels per wave
     __shared__ __attribute__((aligned(1024))) unsigned char patch[2 * kBuf];
 
@@ -107,10 +112,11 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #pragma unroll
     for (int k = 0; k < kUPW; ++k) {
         const int u = wave + 4 * k;
-        const int row = u / UPR, px = (u % UPR) * 16 + (lane >> 2);         // slot within the patch row
+        const int q = u * 16 + (lane >> 2);                                  // S = 1: linear pixel slot of the patch
+        const int row = S == 1 ? q / PWP : u / UPR, px = S == 1 ? q - row * PWP : (u % UPR) * 16 + (lane >> 2);   // slot within the patch row
         const int col = S == 1 ? px : px < 48 ? 2 * px : 2 * (px - 48) + 1;   // input column it holds
         const int iy = iy0 + row, ix = ix0 + col;
-        const bool ok = u < kUnits && (S == 1 ? px < TW + 2 : px <= 32 || px >= 48) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const bool ok = u < kUnits && row < PHt && (S == 1 ? px < TW + 2 : px <= 32 || px >= 48) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         const int sl = (lane & 3) ^ ((px >> 2) & 3);
         src[k] = ok ? (int)((((int64_t)iy * a.W + ix) * a.x_pitch) * 4 + sl * 16) : -1;
     }
@@ -120,7 +126,8 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         for (int k = 0; k < kUPW; ++k) {
             const int u = wave + 4 * k;
             if (u < kUnits)
-                glds16(src[k] >= 0 ? xin + (unsigned)(src[k] + slab * 64) : zero, lds_base + buf * kBuf + ((u / UPR) * PWP + (u % UPR) * 16) * 64);
+                glds16(src[k] >= 0 ? xin + (unsigned)(src[k] + slab * 64) : zero,
+                       lds_base + buf * kBuf + (S == 1 ? u * 1024 : ((u / UPR) * PWP + (u % UPR) * 16) * 64));
         }
     };
 
@@ -134,7 +141,6 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 
     // weight fragments: uniform base + 32-bit offsets (the packed weights are a few MB): one scalar multiply-add for the
     // (tap, slab) block and one vector add per load
-    const int co_ld = co_ok ? co : a.Cout - 1;
     const unsigned char* __restrict__ wb = reinterpret_cast<const unsigned char*>(wpk);
     unsigned b_lane[NT];
 #pragma unroll
@@ -220,15 +226,13 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     }
 
     float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
-    float bs[NT], scs[NT], shs[NT];
+    float eA[NT], eB[NT];                            // value = fma(acc, A, B): packing scale, bias and folded BatchNorm (conv_common.h)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int c = co + nt * 32 < a.Cout ? co + nt * 32 : a.Cout - 1;
-        bs[nt] = a.bias ? a.bias[c] : 0.f;
-        scs[nt] = 1.f; shs[nt] = 0.f;
-        if (EPI == kEpiBiasBnGelu) { scs[nt] = a.scale[c]; shs[nt] = a.shift[c]; }
+        epi_affine<EPI>(kF16AccScale, a.bias ? a.bias[c] : 0.f, EPI == kEpiBiasBnGelu ? a.scale[c] : 1.f, EPI == kEpiBiasBnGelu ? a.shift[c] : 0.f,
+                        eA[nt], eB[nt]);
     }
-    const float b = bs[0], sc = scs[0], sh = shs[0];
 #if !defined(HIMO_EXP_NOEPI) && !defined(HIMO_EXP_NOSTORE) && !defined(HIMO_EXP_DWORDSTORE)
     if (NT > 1 || (a.act_flags & kActVecStore)) {   // 16-byte stores through a wave-private LDS transpose (store_block_vec)
         __syncthreads();                         // every wave has read its last patch rows: the patch memory is free
@@ -242,7 +246,7 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
                 unsigned word[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = epilogue_value<EPI>(acc[mi][nt][r] * kF16AccScale + bs[nt], scs[nt], shs[nt]);
+                    const float v = epi_activate<EPI>(acc[mi][nt][r], eA[nt], eB[nt]);
                     word[r] = OSPLIT ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
                 }
                 store_block_vec<OSPLIT>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, oy < a.Ho ? n_px : 0, tn * BN + (wc * NT + nt) * 32);
@@ -258,19 +262,20 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float v = acc[mi][0][r] * kF16AccScale + b;
 #if defined(HIMO_EXP_NOEPI)                    // experiment: no activation / split arithmetic, same stores (results are wrong)
+            const float v = fmaf(acc[mi][0][r], eA[0], eB[0]);
             if (oy < a.Ho && ox < a.Wo) yout[((int64_t)oy * a.Wo + ox) * a.y_pitch + (OSPLIT ? (co & ~15) + ((co & 1) ? 8 : 0) + ((co & 15) >> 1) : co)] = v;
 #elif defined(HIMO_EXP_NOSTORE)                // experiment: full epilogue arithmetic, (almost) no stores
             if (oy < a.Ho && ox < a.Wo) {
-                if (EPI == kEpiBiasBnGelu) v = gelu_exact(v * sc + sh);
-                unsigned hh, ll; split2_rounded(v, hh, ll);
-                if ((hh ^ ll) == 0x12345u) yout[((int64_t)oy * a.Wo + ox) * a.y_pitch + co] = v;
+                const float v = epi_activate<EPI>(acc[mi][0][r], eA[0], eB[0]);
+                const unsigned w = split2_packed(v);
+                if (w == 0x12345u) yout[((int64_t)oy * a.Wo + ox) * a.y_pitch + co] = v;
             }
 #else
-            if (oy < a.Ho && ox < a.Wo) {
-                if (OSPLIT) split_store<EPI, true>(a, yout, (int64_t)oy * a.Wo + ox, co, v, sc, sh);
-                else epilogue_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v, sc, sh);
+            if (oy < a.Ho && ox < a.Wo) {                       // (scalar-store fallback: outputs that do not admit 16-byte stores)
+                const float v = epi_activate<EPI>(acc[mi][0][r], eA[0], eB[0]);
+                if (OSPLIT) split_store<kEpiBias, true>(a, yout, (int64_t)oy * a.Wo + ox, co, v, 1.f, 0.f);
+                else yout[((int64_t)oy * a.Wo + ox) * a.y_pitch + co] = v;
             }
 #endif
         }
@@ -382,9 +387,8 @@ void conv1_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     }
 
     float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
-    const float b = a.bias ? a.bias[co_ld] : 0.f;
-    float sc = 1.f, sh = 0.f;
-    if (EPI == kEpiBiasBnGelu) { sc = a.scale[co_ld]; sh = a.shift[co_ld]; }
+    float eA, eB;
+    epi_affine<EPI>(kF16AccScale, a.bias ? a.bias[co_ld] : 0.f, EPI == kEpiBiasBnGelu ? a.scale[co_ld] : 1.f, EPI == kEpiBiasBnGelu ? a.shift[co_ld] : 0.f, eA, eB);
 #if !defined(HIMO_EXP_DWORDSTORE)
     if (a.act_flags & kActVecStore) {            // 16-byte stores through a wave-private LDS transpose (store_block_vec)
         __syncthreads();
@@ -396,7 +400,7 @@ void conv1_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
             unsigned word[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = epilogue_value<EPI>(acc[mi][r] * kF16AccScale + b, sc, sh);
+                const float v = epi_activate<EPI>(acc[mi][r], eA, eB);
                 word[r] = OSPLIT ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
             }
             store_block_vec<OSPLIT>(a, yout, stg, word, lane, pix0, left < 0 ? 0 : left > 32 ? 32 : (int)left, tn * BN + wc * 32);
@@ -410,10 +414,10 @@ void conv1_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t pix = row0 + (wp * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float v = acc[mi][r] * kF16AccScale + b;
             if (pix < rows) {
-                if (OSPLIT) split_store<EPI, true>(a, yout, pix, co, v, sc, sh);
-                else epilogue_store<EPI>(a, yout, pix, co, v, sc, sh);
+                const float v = epi_activate<EPI>(acc[mi][r], eA, eB);
+                if (OSPLIT) split_store<kEpiBias, true>(a, yout, pix, co, v, 1.f, 0.f);
+                else yout[pix * a.y_pitch + co] = v;
             }
         }
     }
@@ -481,7 +485,7 @@ bool launch_conv3_presplit(const ConvArgs& a, int epilogue, const void* w_packed
         return true;
     }
     // 64-channel layers, rows_hint 8: a wave owns 2 rows x 32 pixels x BOTH 32-channel column tiles (every activation fragment
-    // meets two weight fragments), four waves = an 8-row tile on a 10-row patch (1.25x halo instead of 1.5x), two blocks per CU
+    // meets two weight fragments), four waves = an 8-row tile on a 10-row patch (1.25x halo instead of 1.5x; 51 KB: three blocks per CU)
     if (!wide && rows_hint == 8 && vec_store_ok(a)) {
         const int64_t blocks = (int64_t)a.N * ((a.Ho + 7) / 8) * ((a.Wo + 31) / 32) * ((a.Cout + 63) / 64);
         ProfScope ps("conv3x3_f16x2_kernel", s);

@@ -236,6 +236,8 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         const float bv = a.bias ? a.bias[cl] : 0.f;
         float scv = 1.f, shv = 0.f;
         if (EPI == kEpiBiasBnGelu) { scv = a.scale[cl]; shv = a.shift[cl]; }
+        float eA = 1.f, eB = 0.f;                                 // fused bias / BatchNorm affine of the backbone's epilogues (conv_common.h)
+        if (kEpiAffine<EPI>) epi_affine<EPI>(FMT == 2 ? kF16AccScale : 1.f, bv, scv, shv, eA, eB);
         __syncthreads();                                          // every wave has read its last patch rows
         unsigned char* stg = patch_raw + wave * 4096;
         const int n_px = a.Wo - ox0 < 32 ? a.Wo - ox0 : 32;
@@ -247,8 +249,12 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
             for (int r = 0; r < 16; ++r) {
                 float v = acc[mi][r];
                 if (XACC) v += acx[mi][r] * kF16LowInv;
-                if (FMT == 2) v *= kF16AccScale;
-                v = epilogue_value<EPI>(v + bv, scv, shv);
+                if (kEpiAffine<EPI>) {
+                    v = epi_activate<EPI>(v, eA, eB);
+                } else {
+                    if (FMT == 2) v *= kF16AccScale;
+                    v = epilogue_value<EPI>(v + bv, scv, shv);
+                }
                 word[r] = (FMT == 2 && osplit) ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
             }
             if (FMT == 2 && osplit) store_block_vec<true>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, oy < a.Ho ? n_px : 0, tn * BN + wc * 32);
@@ -260,6 +266,8 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     const float b = a.bias ? a.bias[co] : 0.f;
     float sc = 1.f, sh = 0.f;
     if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
+    float eA = 1.f, eB = 0.f;
+    if (kEpiAffine<EPI>) epi_affine<EPI>(FMT == 2 ? kF16AccScale : 1.f, b, sc, sh, eA, eB);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int oy = oy0 + wp * MI + mi;
@@ -268,10 +276,17 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
             const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             float v = acc[mi][r];
             if (XACC) v += acx[mi][r] * kF16LowInv;
-            if (FMT == 2) v *= kF16AccScale;
             if (oy < a.Ho && ox < a.Wo) {
-                if (FMT == 2 && osplit) split_store<EPI, true>(a, yout, (int64_t)oy * a.Wo + ox, co, v + b, sc, sh);
-                else epilogue_store<EPI>(a, yout, (int64_t)oy * a.Wo + ox, co, v + b, sc, sh);
+                const int64_t pix = (int64_t)oy * a.Wo + ox;
+                if (kEpiAffine<EPI>) {
+                    v = epi_activate<EPI>(v, eA, eB);
+                    if (FMT == 2 && osplit) split_store<kEpiBias, true>(a, yout, pix, co, v, 1.f, 0.f);
+                    else yout[pix * a.y_pitch + co] = v;
+                } else {
+                    if (FMT == 2) v *= kF16AccScale;
+                    if (FMT == 2 && osplit) split_store<EPI, true>(a, yout, pix, co, v + b, sc, sh);
+                    else epilogue_store<EPI>(a, yout, pix, co, v + b, sc, sh);
+                }
             }
         }
     }
