@@ -523,7 +523,7 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     # ~12 % of the frame rate -- and get their table from one extra, untimed, fully profiled step afterwards.
     # train: the 3x3 weight gradients are the largest kernel family of the step in every precision mode (mixed: split-bf16
     # operands on the stride-1 layers; bf16x3 / f32: float32 matrix instructions)
-    dominant = {"compdis": "compdis_kernel", "train": TRAIN_DOMINANT, "fastnsf": "conv1x1_mfma_kernel"}.get(
+    dominant = {"compdis": "compdis_kernel", "train": TRAIN_DOMINANT, "fastnsf": FASTNSF_DOMINANT}.get(
         args.workload, {"bf16x3": "conv3x3_bf16x3_kernel", "f16x2": "conv3x3_f16x2_kernel"}.get(args.precision, "conv3x3_mfma_kernel"))
     grouped = dist.is_available() and dist.is_initialized()
     if grouped:
@@ -670,26 +670,39 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     return line
 
 
+FASTNSF_DOMINANT = "mlp_"          # mlp_forward_kernel + mlp_backward_kernel (csrc/mlpfused.hip): substring filter of himo_prof_filter
+
+
 def fastnsf_roofline(args, prof: dict, n_fits: int, elapsed: float):
-    """roofline object / workload / dtype of the FastNSF fit: the MLP's row GEMMs are the largest kernel family."""
+    """roofline object / workload / dtype of the FastNSF fit.  Dominant kernels: the two fused MLP kernels (whole forward pass;
+    whole chain of input gradients), which are HBM-bound streams: what leaves / enters the chip per iteration is the eight
+    128-wide activation maps written by the forward pass and read (mask) + the eight gradient maps written by the backward pass."""
     from himo_amd.fastnsf import HIDDEN, N_HIDDEN
     P = args.points
-    k = prof.get("conv1x1_mfma_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
-    dims = [4] + [HIDDEN] * N_HIDDEN + [4]
-    fwd = sum(2.0 * P * ci * co for ci, co in zip(dims[:-1], dims[1:]))
-    dgrad = sum(2.0 * P * ci * co for ci, co in zip(dims[1:-1], dims[2:]))                     # every layer but the first
-    flops_fit = args.fastnsf_iters * (fwd + dgrad) + fwd                                        # + the final forward
-    alg_tf = flops_fit * n_fits / (k["total_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
-    roofline = {"bound": "mfma", "kernel": "conv1x1_mfma_kernel (v_mfma_f32_32x32x2_f32; the MLP's forward / input-gradient row GEMMs)",
-                "achieved": alg_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": alg_tf / MFMA_F32_PEAK_TF, "traffic": None,
-                "avg_launch_ms": k["avg_ms"], "launches_timed": k["count"], "algorithmic_flops_per_frame": flops_fit,
-                "share_of_step_time": k["total_ms"] / (elapsed * 1e3),
-                "note": "an iteration is ~40 short launches (8-layer MLP forward / backward on 120k rows, two exact NN searches, "
-                        "truncated Chamfer, weight gradients, Adam); the row GEMMs are the largest family (K = 128: 64 matrix "
-                        "instructions per tile, so prologue / epilogue weigh a third)"}
+    f = prof.get("mlp_forward_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
+    b = prof.get("mlp_backward_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
+    map_bytes = 4.0 * P * HIDDEN
+    bytes_fwd = N_HIDDEN * map_bytes + 16.0 * P + 16.0 * P                                 # H_k written; x0 read, output written
+    bytes_bwd = 2 * N_HIDDEN * map_bytes + 16.0 * P                                        # H_k read (ReLU mask), dZ_k written; d out read
+    total_ms = f["total_ms"] + b["total_ms"]
+    total_bytes = f["count"] * bytes_fwd + b["count"] * bytes_bwd
+    gbs = total_bytes / (total_ms * 1e-3) / 1e9 if f["count"] and b["count"] else float("nan")
+    flops = 2.0 * P * HIDDEN * HIDDEN * (N_HIDDEN - 1) * (f["count"] + b["count"])           # the 128 x 128 products of both directions
+    roofline = {"bound": "hbm", "kernel": "mlp_forward_kernel + mlp_backward_kernel (csrc/mlpfused.hip: the MLP's whole forward pass / whole chain of "
+                                          "input gradients, activations on chip between layers; v_mfma_f32_32x32x16_f16 / _bf16, 3 per float32 product block)",
+                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": {"forward": bytes_fwd, "backward": bytes_bwd},
+                "avg_launch_ms": {"forward": f["avg_ms"], "backward": b["avg_ms"]}, "launches_timed": f["count"] + b["count"],
+                "matrix_tflops_f32_equivalent": flops / (total_ms * 1e-3) / 1e12 if total_ms == total_ms else float("nan"),
+                "share_of_step_time": total_ms / (elapsed * 1e3),
+                "note": "an iteration = fused forward, distance-transform lookup (loss + gradient), fused backward, 9 split-K weight-gradient "
+                        "products (the largest remaining family), Adam, one re-pack launch; the distance transform of pc1 is built once per pair"}
     workload = (f"FastNSF (BASELINE config 4): fit the per-scene coordinate MLP (3 -> 8 x 128 -> 3) to one pair of {P}-point sweeps, "
-                f"{args.fastnsf_iters} Adam iterations per frame, exact NN correspondences every iteration")
-    return roofline, workload, "f32"
+                f"{args.fastnsf_iters} Adam iterations per frame, distance-transform objective (pc1 -> 0.1 m distance volume once per pair, "
+                "trilinear lookup per iteration)")
+    dtype = ("mixed: forward fp16 split (two-term, 22-bit products), input / weight gradients two-term bf16 (16 significant bits, float32 range), "
+             "float32 sums and optimiser")
+    return roofline, workload, dtype
 
 
 TRAIN_DOMINANT = "conv_wgrad_tiled_kernel"       # the 3x3 weight gradients: largest kernel family of the step in every precision mode
@@ -791,7 +804,7 @@ def extra_workload_legs(args, device) -> dict:
                 dominant = TRAIN_DOMINANT
             else:
                 step, obj, fr = make_fastnsf_step(a, 0, device, result)
-                dominant = "conv1x1_mfma_kernel"
+                dominant = FASTNSF_DOMINANT
             step()                                                  # priming pass (workspace growth, one-off autotune)
             for _ in range(warm):
                 step()

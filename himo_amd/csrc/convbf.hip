@@ -25,6 +25,7 @@
 // GEMMs (1x1 layers, GRU epilogues) and remains selectable per layer through himo_conv_desc.tile_hint.
 #include "conv_common.h"
 #include "bf16x3.h"
+#include <algorithm>
 
 namespace himo {
 
@@ -307,8 +308,9 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
 
 template <int KS, int BN, int MI, int FMT>
 static void launch_bf_epi(const ConvArgs& a, int epi, const unsigned short* w, dim3 grid, hipStream_t s) {
-    if constexpr (FMT == 4) {              // the data-gradient format: plain bias epilogue only (launch_conv_bf16x3 has checked)
-        hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBias, MI, FMT>), grid, dim3(256), 0, s, a, w);
+    if constexpr (FMT == 4) {              // the data-gradient format: bias, or bias + ReLU mask of the layer's input (launch_conv_bf16x3 has checked)
+        if (epi == kEpiReluMask) hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiReluMask, MI, FMT>), grid, dim3(256), 0, s, a, w);
+        else hipLaunchKernelGGL((conv_bf16x3_kernel<KS, BN, kEpiBias, MI, FMT>), grid, dim3(256), 0, s, a, w);
         return;
     }
     switch (epi) {
@@ -353,7 +355,7 @@ int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w
         return HIMO_OK;
     }
     if (stride != 1) return HIMO_ERR_UNSUPPORTED;
-    if (format == 2 && (ksize != 1 || epilogue != kEpiBias || a.act_flags)) return HIMO_ERR_UNSUPPORTED;     // two-term bf16: 3x3 in convsp.hip, row GEMMs here
+    if (format == 2 && (ksize != 1 || (epilogue != kEpiBias && epilogue != kEpiReluMask) || a.act_flags)) return HIMO_ERR_UNSUPPORTED;     // two-term bf16: 3x3 in convsp.hip, row GEMMs here
     auto blocks_for = [&](int bn, int mi) -> int64_t {
         const int bm = 64 * mi, th = 2 * mi;
         const int64_t tm = ksize == 1 ? (int64_t)a.N * (((int64_t)a.Ho * a.Wo + bm - 1) / bm)
@@ -404,6 +406,64 @@ extern "C" int himo_conv_pack_weights_ex(const float* d_w, int ksize, int cin, i
     else if (format == 2) hipLaunchKernelGGL(pack_weights_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, d_w, T, cin, cout, (unsigned short*)d_packed);
     else hipLaunchKernelGGL(pack_weights_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, d_w, T, cin, cout, (unsigned short*)d_packed);
     HIMO_LAUNCH_CHECK("pack_weights_kernel");
+    return HIMO_OK;
+}
+
+// All layers of a small MLP in ONE launch (FastNSF re-packs after every optimiser step): per layer W [cin][cout] float32 ->
+// its fp16-split copy for the forward product (format 1) and the two-term bf16 copy of W^T for the input-gradient product
+// (format 2).  blockIdx.y = layer; a thread packs one forward item and one backward item.
+namespace himo {
+constexpr int kMlpMaxLayers = 16;
+struct MlpPackBatch {
+    int n;
+    const float* w[kMlpMaxLayers]; int cin[kMlpMaxLayers], cout[kMlpMaxLayers];
+    unsigned short* fwd[kMlpMaxLayers]; unsigned short* bwd[kMlpMaxLayers];
+};
+__global__ __launch_bounds__(256) void mlp_repack_kernel(MlpPackBatch b) {
+    const int L = blockIdx.y;
+    const float* __restrict__ w = b.w[L];
+    const int cin = b.cin[L], cout = b.cout[L];
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    {   // forward: rows = cin (slabs of 16), columns = cout; fp16 split with the weight packing scale
+        const int slabs = (cin + 15) / 16;
+        if (b.fwd[L] && item < (int64_t)slabs * cout * 16) {
+            const int k = (int)(item % 16), co = (int)((item / 16) % cout), slab = (int)(item / (16 * (int64_t)cout));
+            const int ci = slab * 16 + k;
+            unsigned h, l;
+            split2((ci < cin ? w[(int64_t)ci * cout + co] : 0.f) * kF16WeightScale, h, l);
+            const int64_t base = ((int64_t)slab * 2) * cout * 16 + (int64_t)co * 16 + k;
+            b.fwd[L][base] = (unsigned short)h; b.fwd[L][base + (int64_t)cout * 16] = (unsigned short)l;
+        }
+    }
+    {   // backward: W^T [cout][cin]: rows = cout (slabs), columns = cin; two-term bf16
+        const int slabs = (cout + 15) / 16;
+        if (b.bwd[L] && item < (int64_t)slabs * cin * 16) {
+            const int k = (int)(item % 16), ci = (int)((item / 16) % cin), slab = (int)(item / (16 * (int64_t)cin));
+            const int co = slab * 16 + k;
+            const float x = co < cout ? w[(int64_t)ci * cout + co] : 0.f;
+            const unsigned h = bf16_rne_bits(x), l = bf16_rne_bits(x - bf16_bits_to_float(h));
+            const int64_t base = ((int64_t)slab * 2) * cin * 16 + (int64_t)ci * 16 + k;
+            b.bwd[L][base] = (unsigned short)h; b.bwd[L][base + (int64_t)cin * 16] = (unsigned short)l;
+        }
+    }
+}
+}  // namespace himo
+
+extern "C" int himo_mlp_repack(int n_layers, const float* const* h_w, const int* h_cin, const int* h_cout, void* const* h_fwd_packed,
+                               void* const* h_bwd_packed, void* stream) {
+    if (n_layers < 1 || n_layers > kMlpMaxLayers || !h_w || !h_cin || !h_cout || !h_fwd_packed || !h_bwd_packed) return HIMO_ERR_INVALID_ARGUMENT;
+    MlpPackBatch b{};
+    b.n = n_layers;
+    int64_t most = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        if (!h_w[i] || h_cin[i] < 1 || h_cout[i] < 1) return HIMO_ERR_INVALID_ARGUMENT;
+        b.w[i] = h_w[i]; b.cin[i] = h_cin[i]; b.cout[i] = h_cout[i];
+        b.fwd[i] = (unsigned short*)h_fwd_packed[i]; b.bwd[i] = (unsigned short*)h_bwd_packed[i];
+        const int64_t f = (int64_t)((h_cin[i] + 15) / 16) * h_cout[i] * 16, r = (int64_t)((h_cout[i] + 15) / 16) * h_cin[i] * 16;
+        most = std::max(most, std::max(f, r));
+    }
+    hipLaunchKernelGGL(mlp_repack_kernel, dim3((unsigned)((most + 255) / 256), n_layers), dim3(256), 0, (hipStream_t)stream, b);
+    HIMO_LAUNCH_CHECK("mlp_repack_kernel");
     return HIMO_OK;
 }
 

@@ -6,9 +6,14 @@ This build's own specification, after the published Neural Scene Flow Prior fami
 
   * flow field  f_theta: R^3 -> R^3, an MLP 3 -> 128 (x8 hidden layers, ReLU) -> 3, weights U(-1/sqrt(fan_in), ..);
   * pc0 is first brought into pc1's frame (p' = R p + t with inv(pose1) @ pose0, float32 -- as seflow/spec.py step 0);
-  * objective   L = mean_i [d_i <= tau^2] d_i + mean_j [e_j <= tau^2] e_j, with d_i the squared distance from
-                p'_i + f(p'_i) to its nearest pc1 point, e_j the squared distance from pc1_j to its nearest moved
-                point, tau = 2 m; correspondences are exact (csrc/nngrid.hip) and constant within an iteration;
+  * objective   ``objective="dt"`` (default; what makes FastNSF fast): ONCE per pair pc1 becomes a distance-transform volume --
+                cells of 0.1 m over the network range grown by tau, D[c] = distance from cell c to the nearest cell holding a
+                pc1 point, exact up to tau (csrc/dtloss.hip) -- and L = mean_i [D(m_i) <= tau] D(m_i) with m_i = p'_i + f(p'_i)
+                and D(.) the trilinear interpolation of the volume: one lookup kernel per iteration, no search.
+                ``objective="nn"`` (the NSFP objective, kept for the parity tests of round 1-2):
+                L = mean_i [d_i <= tau^2] d_i + mean_j [e_j <= tau^2] e_j, with d_i the squared distance from
+                m_i to its nearest pc1 point, e_j the squared distance from pc1_j to its nearest moved
+                point; correspondences are exact (csrc/nngrid.hip) and constant within an iteration; tau = 2 m in both;
   * optimiser   Adam(lr 1e-3, betas (0.9, 0.999), eps 1e-8), ``iters`` steps, optional early stop on the loss;
   * output      (N,3) float32 flow INCLUDING ego motion, row-aligned with pc0 -- the h5 ``<res_name>`` payload.
 
@@ -36,6 +41,9 @@ _lib.register({
     "himo_linear_wgrad": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "himo_transpose": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "himo_wgrad_workspace_bytes_ex": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "himo_linear_wgrad_ex": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "himo_adam_step": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]),
     "himo_chamfer_trunc_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
@@ -46,7 +54,35 @@ _lib.register({
                                      ctypes.c_float, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "himo_rigid_transform": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_int, ctypes.c_void_p]),
+    "himo_mlp_repack": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "himo_mlp_forward_fused": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "himo_mlp_backward_fused": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_void_p]),
+    "himo_dt_volume_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
+    "himo_dt_build": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "himo_dt_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "himo_dt_loss": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_int,
+                                    ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                    ctypes.c_void_p]),
 })
+
+DT_CELL = 0.1                       # metres per cell of the distance-transform volume
+
+
+def dt_grid(trunc: float = TRUNC, cell: float = DT_CELL, box=None):
+    """(origin float32[3], dims int32[3], window) of the distance-transform volume: ``box`` = (xmin, ymin, zmin, xmax, ymax, zmax),
+    default the network range (seflow/spec.py POINT_CLOUD_RANGE) grown by ``trunc`` on every side; the window -- the distance in
+    cells up to which the transform is exact -- covers ``trunc`` plus one cell of interpolation margin."""
+    from .seflow import spec
+    if box is None:
+        r = spec.POINT_CLOUD_RANGE
+        box = (r[0] - trunc, r[1] - trunc, r[2] - trunc, r[3] + trunc, r[4] + trunc, r[5] + trunc)
+    origin = np.asarray(box[:3], np.float32)
+    dims = np.asarray([max(1, int(math.ceil((box[3 + k] - box[k]) / cell - 1e-6))) for k in range(3)], np.int32)
+    return origin, dims, int(math.ceil(trunc / cell)) + 1
+
 
 
 def init_mlp(seed: int = 0) -> list:
@@ -62,10 +98,25 @@ def init_mlp(seed: int = 0) -> list:
 
 class FastNSF:
     def __init__(self, device=None, lr: float = 1e-3, iters: int = 100, seed: int = 0, trunc: float = TRUNC,
-                 early_patience: int = 0, early_min_delta: float = 1e-4):
+                 early_patience: int = 0, early_min_delta: float = 1e-4, objective: str = "dt", dt_cell: float = DT_CELL, dt_box=None,
+                 precision: str = "mixed", fused: bool = True):
+        """``fused`` (mixed precision only): the whole forward pass and the whole chain of input gradients as ONE kernel each
+        (csrc/mlpfused.hip) instead of a row GEMM per layer and direction.
+        ``precision``: "mixed" (default) runs the MLP's products on the 16-bit matrix instructions with split operands -- forward
+        fp16 split (x = h + l: 22-bit products; activations are O(1) and coordinates < 64 m), input gradients and weight gradients
+        two-term bf16 (16 significant bits at float32's range: gradients sit far below fp16's subnormal floor), float32 sums
+        throughout -- as the training step does (seflow/train.py); "f32": float32 matrix instructions everywhere."""
+        if objective not in ("dt", "nn"):
+            raise ValueError(objective)
+        if precision not in ("mixed", "f32"):
+            raise ValueError(precision)
+        self.mixed = precision == "mixed"
+        self.fused = bool(fused) and self.mixed
         self.lib = _lib.load()
         self.device = device if device is not None else _lib.require_gpu()
         self.lr, self.iters, self.seed, self.trunc = lr, iters, seed, trunc
+        self.objective, self.dt_cell, self.dt_box = objective, dt_cell, dt_box
+        self._dt_vol = None                                   # the volume buffer is kept between fits (0.45 GB at the default box)
         self.early_patience, self.early_min_delta = early_patience, early_min_delta
         self.loss_history = []
         self._descs = {}
@@ -96,8 +147,24 @@ class FastNSF:
             self.Wt.append(torch.empty((pout, pin), dtype=torch.float32, device=dev))
         self.flat_p.copy_(torch.from_numpy(host))
         self._descs = {}
+        self.pk_fwd, self.pk_bwd, self._repack_args = [], [], None
+        if self.mixed:
+            for k, (pin, pout) in enumerate(shapes):
+                nb = lambda ci, co: int(self.lib.himo_conv_packed_weight_bytes(1, ci, co))
+                self.pk_fwd.append(torch.empty(nb(pin, pout), dtype=torch.uint8, device=dev))
+                self.pk_bwd.append(torch.empty(nb(pout, pin), dtype=torch.uint8, device=dev) if k > 0 else None)
+            L = len(shapes)
+            P, I = ctypes.c_void_p * L, ctypes.c_int * L
+            self._repack_args = (L, P(*[w.data_ptr() for w in self.W]), I(*[p for p, _ in shapes]), I(*[q for _, q in shapes]),
+                                 P(*[b.data_ptr() for b in self.pk_fwd]), P(*[None if b is None else b.data_ptr() for b in self.pk_bwd]))
+            self._repack()
 
-    def _gemm(self, x, w, bias, y, n, cin, cout, epi, aux=None):
+    def _repack(self):
+        """refresh the split copies of every layer's W (forward) and W^T (input gradient): one launch (csrc/convbf.hip)"""
+        if self._repack_args is not None:
+            _lib.check(self.lib.himo_mlp_repack(*self._repack_args, _lib.stream_handle()), "himo_mlp_repack")
+
+    def _gemm(self, x, w, bias, y, n, cin, cout, epi, aux=None, packed=None, fmt=0):
         key = (x.data_ptr(), w.data_ptr(), y.data_ptr(), epi)          # descriptors are cached per call site
         d = self._descs.get(key)
         if d is None:
@@ -108,15 +175,32 @@ class FastNSF:
             d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = 1, 1, n, cin, cout, 1, 1, epi
             if aux is not None:
                 d.aux_in = aux.data_ptr(); d.aux_in_pitch = aux.shape[1]
+            if packed is not None:
+                d.w_packed, d.packed_format = packed.data_ptr(), fmt
             self._descs[key] = d
         _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), "himo_conv2d(mlp)")
 
+    def _fused_args(self):
+        """pointer tables of the fused kernels (buffers are fixed for the duration of a fit)"""
+        L = len(self.W)                                         # 1 + (N_HIDDEN - 1) + 1 layers
+        P = ctypes.c_void_p * N_HIDDEN
+        hid = lambda bufs: P(*([None] + [bufs[k].data_ptr() for k in range(1, L - 1)]))
+        self._fz = dict(wf=hid(self.pk_fwd), wb=hid(self.pk_bwd), bias=hid(self.b), H=P(*[h.data_ptr() for h in self.H]),
+                        dZ=P(*[z.data_ptr() for z in self.dZ]))
+
     def _forward(self, n):
         L = len(self.W)
+        if self.fused:
+            f = self._fz
+            _lib.check(self.lib.himo_mlp_forward_fused(n, self.X0.data_ptr(), N_HIDDEN, self.W[0].data_ptr(), self.b[0].data_ptr(), f["wf"], f["bias"],
+                                                       self.W[L - 1].data_ptr(), self.b[L - 1].data_ptr(), f["H"], self.OUT.data_ptr(),
+                                                       _lib.stream_handle()), "himo_mlp_forward_fused")
+            return
         for k in range(L):
             x = self.X0 if k == 0 else self.H[k - 1]
             y = self.OUT if k == L - 1 else self.H[k]
-            self._gemm(x, self.W[k], self.b[k], y, n, self.W[k].shape[0], self.W[k].shape[1], EPI_BIAS if k == L - 1 else EPI_BIAS_RELU)
+            self._gemm(x, self.W[k], self.b[k], y, n, self.W[k].shape[0], self.W[k].shape[1], EPI_BIAS if k == L - 1 else EPI_BIAS_RELU,
+                       packed=self.pk_fwd[k] if self.mixed else None, fmt=1)
 
     def fit(self, pc0, pc1, pose0=None, pose1=None, layers=None) -> torch.Tensor:
         """-> (N0,3) float32 device tensor: flow of every pc0 row including ego motion."""
@@ -127,20 +211,37 @@ class FastNSF:
         # ego transform (host 4x4, float32 like seflow/spec.py step 0), applied by the pillar front end's rule
         T = np.eye(4) if pose0 is None else np.linalg.inv(np.asarray(pose1, np.float64)) @ np.asarray(pose0, np.float64)
         T32 = torch.from_numpy(np.ascontiguousarray(T, dtype=np.float32)).to(dev)
-        self.X0 = torch.empty((n, 4), dtype=torch.float32, device=dev)                          # [x', y', z', 0]
+        n_pad = (n + 63) // 64 * 64                            # the fused kernels work on whole 64-row blocks (csrc/mlpfused.hip)
+        self.X0 = torch.zeros((n_pad, 4), dtype=torch.float32, device=dev)[:n]                  # [x', y', z', 0]
         _lib.check(lib.himo_rigid_transform(n, p0_raw.data_ptr(), 3, T32.data_ptr(), self.X0.data_ptr(), 4, s()), "rigid")
         self._load(init_mlp(self.seed) if layers is None else layers)
-        buf = lambda c: torch.empty((n, c), dtype=torch.float32, device=dev)
+        buf = lambda c: torch.zeros((n_pad, c), dtype=torch.float32, device=dev)[:n]
         self.H = [buf(HIDDEN) for _ in range(N_HIDDEN)]
         self.dH = [buf(HIDDEN) for _ in range(2)]
         self.OUT, self.dOUT = buf(4), buf(4)
+        if self.fused:
+            self.dZ = [buf(HIDDEN) for _ in range(N_HIDDEN)]    # masked gradients at every hidden layer's output (weight-gradient operands)
+            self._fused_args()
         moved, gmoved = torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty((n, 3), dtype=torch.float32, device=dev)
-        d_a, i_a = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
-        d_b, i_b = torch.empty(n1, dtype=torch.float32, device=dev), torch.empty(n1, dtype=torch.int32, device=dev)
-        nn_ws = torch.empty(int(lib.himo_nn_grid_workspace_bytes(max(n, n1), GRID_W, GRID_H)), dtype=torch.uint8, device=dev)
-        ch_ws = torch.empty(int(lib.himo_chamfer_trunc_workspace_bytes(n, n1)), dtype=torch.uint8, device=dev)
-        wg_ws = torch.empty(int(lib.himo_wgrad_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        dt = self.objective == "dt"
+        if dt:
+            # the target sweep as a distance-transform volume, built once for this pair
+            origin, dims, window = dt_grid(self.trunc, self.dt_cell, self.dt_box)
+            o_c, d_c = (ctypes.c_float * 3)(*origin.tolist()), (ctypes.c_int * 3)(*dims.tolist())
+            need = int(lib.himo_dt_volume_bytes(d_c))
+            if self._dt_vol is None or self._dt_vol.numel() < need:
+                self._dt_vol = torch.empty(need, dtype=torch.uint8, device=dev)
+            _lib.check(lib.himo_dt_build(n1, p1.data_ptr(), o_c, self.dt_cell, d_c, window, self._dt_vol.data_ptr(), self._dt_vol.numel(), s()),
+                       "himo_dt_build")
+            ch_ws = torch.empty(int(lib.himo_dt_loss_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        else:
+            d_a, i_a = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
+            d_b, i_b = torch.empty(n1, dtype=torch.float32, device=dev), torch.empty(n1, dtype=torch.int32, device=dev)
+            nn_ws = torch.empty(int(lib.himo_nn_grid_workspace_bytes(max(n, n1), GRID_W, GRID_H)), dtype=torch.uint8, device=dev)
+            ch_ws = torch.empty(int(lib.himo_chamfer_trunc_workspace_bytes(n, n1)), dtype=torch.uint8, device=dev)
+        wg_ws = torch.empty(int(lib.himo_wgrad_workspace_bytes_ex(n, HIDDEN, HIDDEN)), dtype=torch.uint8, device=dev)
         loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._moved, self._gmoved = moved, gmoved             # (tests read the objective's gradient)
         self.loss_history, best, stale = [], float("inf"), 0
         L = len(self.W)
 
@@ -151,26 +252,45 @@ class FastNSF:
         for it in range(1, self.iters + 1):
             self._forward(n)
             _lib.check(lib.himo_rows_add(n, 3, self.X0.data_ptr(), 4, self.OUT.data_ptr(), 4, 1.0, moved.data_ptr(), 3, 0, s()), "rows_add")
-            nn(moved, n, p1, n1, d_a, i_a)
-            nn(p1, n1, moved, n, d_b, i_b)
-            _lib.check(lib.himo_chamfer_trunc(n, n1, moved.data_ptr(), p1.data_ptr(), d_a.data_ptr(), i_a.data_ptr(), d_b.data_ptr(),
-                                              i_b.data_ptr(), self.trunc, loss.data_ptr(), gmoved.data_ptr(), ch_ws.data_ptr(),
-                                              ch_ws.numel(), s()), "himo_chamfer_trunc")
+            if dt:
+                _lib.check(lib.himo_dt_loss(n, moved.data_ptr(), o_c, self.dt_cell, d_c, window, self._dt_vol.data_ptr(), self.trunc,
+                                            loss.data_ptr(), gmoved.data_ptr(), ch_ws.data_ptr(), ch_ws.numel(), s()), "himo_dt_loss")
+            else:
+                nn(moved, n, p1, n1, d_a, i_a)
+                nn(p1, n1, moved, n, d_b, i_b)
+                _lib.check(lib.himo_chamfer_trunc(n, n1, moved.data_ptr(), p1.data_ptr(), d_a.data_ptr(), i_a.data_ptr(), d_b.data_ptr(),
+                                                  i_b.data_ptr(), self.trunc, loss.data_ptr(), gmoved.data_ptr(), ch_ws.data_ptr(),
+                                                  ch_ws.numel(), s()), "himo_chamfer_trunc")
             _lib.check(lib.himo_rows_add(n, 3, gmoved.data_ptr(), 3, None, 0, 0.0, self.dOUT.data_ptr(), 4, 1, s()), "rows_add")
             # backward: dZ_k is the gradient at layer k's output (post-mask for hidden layers)
+            if self.fused:
+                f = self._fz
+                _lib.check(lib.himo_mlp_backward_fused(n, self.dOUT.data_ptr(), N_HIDDEN, f["wb"], self.W[L - 1].data_ptr(), f["H"], f["dZ"], s()),
+                           "himo_mlp_backward_fused")
+                for k in range(L):
+                    xk = self.X0 if k == 0 else self.H[k - 1]
+                    dz = self.dOUT if k == L - 1 else self.dZ[k]
+                    cin, cout = self.W[k].shape
+                    _lib.check(lib.himo_linear_wgrad_ex(n, xk.data_ptr(), xk.shape[1], cin, dz.data_ptr(), dz.shape[1], cout,
+                                                        self.gW[k].data_ptr(), self.gb[k].data_ptr(), 2, wg_ws.data_ptr(), wg_ws.numel(), s()), "wgrad")
             dz = self.dOUT
-            for k in range(L - 1, -1, -1):
+            for k in (range(L - 1, -1, -1) if not self.fused else ()):
                 xk = self.X0 if k == 0 else self.H[k - 1]
                 cin, cout = self.W[k].shape
-                _lib.check(lib.himo_linear_wgrad(n, xk.data_ptr(), xk.shape[1], cin, dz.data_ptr(), dz.shape[1], cout,
-                                                 self.gW[k].data_ptr(), self.gb[k].data_ptr(), wg_ws.data_ptr(), wg_ws.numel(), s()), "wgrad")
+                _lib.check(lib.himo_linear_wgrad_ex(n, xk.data_ptr(), xk.shape[1], cin, dz.data_ptr(), dz.shape[1], cout,
+                                                    self.gW[k].data_ptr(), self.gb[k].data_ptr(), 2 if self.mixed else 0, wg_ws.data_ptr(),
+                                                    wg_ws.numel(), s()), "wgrad")
                 if k > 0:
-                    _lib.check(lib.himo_transpose(self.W[k].data_ptr(), cin, cout, self.Wt[k].data_ptr(), s()), "transpose")
                     nxt = self.dH[k % 2]
-                    self._gemm(dz, self.Wt[k], None, nxt, n, cout, cin, EPI_RELU_MASK, aux=self.H[k - 1])
+                    if self.mixed:                              # W^T's two-term bf16 copy was refreshed by _repack
+                        self._gemm(dz, self.Wt[k], None, nxt, n, cout, cin, EPI_RELU_MASK, aux=self.H[k - 1], packed=self.pk_bwd[k], fmt=2)
+                    else:
+                        _lib.check(lib.himo_transpose(self.W[k].data_ptr(), cin, cout, self.Wt[k].data_ptr(), s()), "transpose")
+                        self._gemm(dz, self.Wt[k], None, nxt, n, cout, cin, EPI_RELU_MASK, aux=self.H[k - 1])
                     dz = nxt
             _lib.check(lib.himo_adam_step(self.flat_p.numel(), self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                           self.flat_v.data_ptr(), self.lr, 0.9, 0.999, 1e-8, it, s()), "adam")
+            self._repack()
             if self.early_patience > 0 or it == self.iters or it <= 3:
                 lv = float(loss.item())
                 self.loss_history.append((it, lv))

@@ -482,6 +482,37 @@ int himo_head_scatter(int64_t n, int grid_w, int grid_h, const void* d_pillar_wo
                       float* d_db0, int b0_pitch, int group0, int group1, int n_groups, float* d_ddec, int dec_pitch,
                       void* stream);
 
+/* FastNSF's MLP after an optimiser step, ONE launch for all layers: every W [cin][cout] -> its fp16-split copy (format 1, forward
+ * products) and the two-term bf16 copy of its transpose (format 2, input-gradient products); either destination may be NULL. */
+int himo_mlp_repack(int n_layers, const float* const* h_w, const int* h_cin, const int* h_cout, void* const* h_fwd_packed,
+                    void* const* h_bwd_packed, void* stream);
+
+/* FastNSF's coordinate MLP (3 -> 128 x n_hidden, ReLU -> 3; himo_amd/fastnsf.py) over all n points as ONE kernel per direction
+ * (csrc/mlpfused.hip): the forward pass writes the post-ReLU activations h_H[k] [n][128] and d_out [n][4]; the backward pass turns
+ * d_dout [n][4] into the masked gradients h_dZ[k] [n][128] at every hidden layer's output.  Hidden layer k = 1 .. n_hidden - 1 is
+ * given by himo_mlp_repack's copies of W_k (forward: fp16 split) / W_k^T (backward: two-term bf16); entry 0 of those arrays is
+ * ignored.  First layer W [4][128] and last layer W [128][4] are float32 (padded with zeros).  Replaces 17 row-GEMM launches.
+ * EVERY [n][.] buffer must hold ceil(n / 64) * 64 rows (whole 64-row blocks, no bounds checks; pad d_x0 / d_dout with zeros). */
+int himo_mlp_forward_fused(int64_t n, const float* d_x0, int n_hidden, const float* d_w_first, const float* d_b_first,
+                           const void* const* h_w_hidden_packed, const float* const* h_b_hidden, const float* d_w_last,
+                           const float* d_b_last, float* const* h_H, float* d_out, void* stream);
+int himo_mlp_backward_fused(int64_t n, const float* d_dout, int n_hidden, const void* const* h_wT_hidden_packed,
+                            const float* d_w_last, float* const* h_H, float* const* h_dZ, void* stream);
+
+/* ---- FastNSF's distance-transform objective (BASELINE config 4, `model=fastnsf`, README.md:53; implementation absent from the
+ * reference tree: PARITY UNPINNED, specification in csrc/dtloss.hip / himo_amd/fastnsf.py).  himo_dt_build: ONCE per sweep pair, the
+ * target sweep d_pc1 [n1][3] -> a volume of squared cell distances to the nearest occupied cell (uint16, x fastest, exact up to
+ * `window` cells; h_dims = {nx, ny, nz}); d_volume holds himo_dt_volume_bytes() (two volumes: the passes ping-pong, the result is
+ * the first).  himo_dt_loss: per optimiser iteration, loss = (1/n) sum [D <= trunc] D(moved_i) by trilinear lookup and its gradient
+ * with respect to the moved points [n][3] -- what replaces the two exact NN searches + himo_chamfer_trunc of the NN objective. */
+size_t himo_dt_volume_bytes(const int* h_dims);
+int himo_dt_build(int n1, const float* d_pc1, const float* h_origin, float cell, const int* h_dims, int window,
+                  void* d_volume, size_t volume_bytes, void* stream);
+size_t himo_dt_loss_workspace_bytes(int n);
+int himo_dt_loss(int n, const float* d_moved, const float* h_origin, float cell, const int* h_dims, int window,
+                 const void* d_volume, float trunc_dist, double* d_loss, float* d_grad_moved, void* d_workspace,
+                 size_t workspace_bytes, void* stream);
+
 /* ---- BatchNorm in TRAINING mode (BASELINE config 5).  Replaces: the torch.nn.BatchNorm layers of the model the reference's
  * training job builds from scratch (assets/slurm/ssl-train-av2.sh:31-34: no checkpoint=, 12 epochs, batch_size=8; the model
  * source, OpenSceneFlow/, is absent -- PARITY UNPINNED, semantics = torch's: biased variance normalises, the unbiased one

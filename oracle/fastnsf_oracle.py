@@ -58,3 +58,78 @@ def fit(layers_np, pc0, pc1, iters, lr=1e-3, trunc=2.0):
     with torch.no_grad():
         flow = mlp(layers, p0).numpy()
     return hist, flow
+
+
+# ---- the distance-transform objective (csrc/dtloss.hip; himo_amd/fastnsf.py objective="dt") -----------------------------------
+def dt_volume(pc1, origin, dims, cell, window):
+    """(nz, ny, nx) float32 volume D: distance in metres from every cell to the nearest cell that holds a pc1 point, capped at
+    ``window`` cells -- scipy's exact Euclidean distance transform of the occupancy grid."""
+    from scipy.ndimage import distance_transform_edt
+    nx, ny, nz = (int(d) for d in dims)
+    c = np.floor((pc1[:, :3].astype(np.float32) - np.asarray(origin, np.float32)) / np.float32(cell))
+    ok = (c[:, 0] >= 0) & (c[:, 0] < nx) & (c[:, 1] >= 0) & (c[:, 1] < ny) & (c[:, 2] >= 0) & (c[:, 2] < nz)
+    c = c[ok].astype(np.int64)
+    occ = np.zeros((nz, ny, nx), bool)
+    occ[c[:, 2], c[:, 1], c[:, 0]] = True
+    if not occ.any():
+        return np.full((nz, ny, nx), np.float32(window) * np.float32(cell), np.float32)
+    d = distance_transform_edt(~occ)                                   # in cells
+    # the product's passes are windowed: a cell further than `window` cells from every occupied cell ALONG SOME AXIS of the
+    # minimising offset is reported as `window`; capping at `window` makes both agree (any distance < window is within the window)
+    return (np.minimum(d, float(window)).astype(np.float32) * np.float32(cell)).astype(np.float32)
+
+
+def dt_lookup(vol, moved, origin, cell):
+    """Trilinear interpolation of ``vol`` (torch float32 (nz, ny, nx)) at ``moved`` (torch (n, 3), may require grad) in cell-centre
+    coordinates, clamped to the volume -- the rule of csrc/dtloss.hip, with autograd supplying the gradient."""
+    nz, ny, nx = vol.shape
+    dims = (nx, ny, nz)
+    idx, frac = [], []
+    for k in range(3):
+        u = (moved[:, k] - float(np.float32(origin[k]))) / float(np.float32(cell)) - 0.5
+        uc = u.clamp(0.0, float(dims[k] - 1))
+        b = uc.detach().floor().clamp(max=float(max(dims[k] - 2, 0))).long()
+        idx.append(b); frac.append(uc - b.to(uc.dtype))
+    def at(dx, dy, dz):
+        x = (idx[0] + dx).clamp(max=nx - 1); y = (idx[1] + dy).clamp(max=ny - 1); z = (idx[2] + dz).clamp(max=nz - 1)
+        return vol[z, y, x]
+    fx, fy, fz = frac
+    c00 = at(0, 0, 0) * (1 - fx) + at(1, 0, 0) * fx
+    c10 = at(0, 1, 0) * (1 - fx) + at(1, 1, 0) * fx
+    c01 = at(0, 0, 1) * (1 - fx) + at(1, 0, 1) * fx
+    c11 = at(0, 1, 1) * (1 - fx) + at(1, 1, 1) * fx
+    c0 = c00 * (1 - fy) + c10 * fy
+    c1 = c01 * (1 - fy) + c11 * fy
+    return c0 * (1 - fz) + c1 * fz
+
+
+def dt_loss_and_grads(layers_np, pc0, pc1, origin, dims, cell, window, trunc=2.0):
+    """(loss, [(dW, db)], flow, d loss / d moved) of the distance-transform objective for the given parameters."""
+    layers = [(torch.from_numpy(w.copy()).requires_grad_(True), torch.from_numpy(b.copy()).requires_grad_(True)) for w, b in layers_np]
+    vol = torch.from_numpy(dt_volume(pc1, origin, dims, cell, window))
+    p0 = torch.from_numpy(pc0.astype(np.float32))
+    f = mlp(layers, p0)
+    moved = p0 + f
+    moved.retain_grad()
+    D = dt_lookup(vol, moved, origin, cell)
+    loss = (D * (D.detach() <= trunc)).double().sum() / len(p0)
+    loss.backward()
+    return float(loss), [(w.grad.numpy(), b.grad.numpy()) for w, b in layers], f.detach().numpy(), moved.grad.numpy()
+
+
+def dt_fit(layers_np, pc0, pc1, origin, dims, cell, window, iters, lr=1e-3, trunc=2.0):
+    layers = [(torch.from_numpy(w.copy()).requires_grad_(True), torch.from_numpy(b.copy()).requires_grad_(True)) for w, b in layers_np]
+    opt = torch.optim.Adam([t for wb in layers for t in wb], lr=lr, betas=(0.9, 0.999), eps=1e-8)
+    vol = torch.from_numpy(dt_volume(pc1, origin, dims, cell, window))
+    p0 = torch.from_numpy(pc0.astype(np.float32))
+    hist = []
+    for _ in range(iters):
+        opt.zero_grad()
+        D = dt_lookup(vol, p0 + mlp(layers, p0), origin, cell)
+        loss = (D * (D.detach() <= trunc)).double().sum() / len(p0)
+        loss.backward()
+        opt.step()
+        hist.append(float(loss))
+    with torch.no_grad():
+        flow = mlp(layers, p0).numpy()
+    return hist, flow

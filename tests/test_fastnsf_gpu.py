@@ -48,22 +48,23 @@ def test_wgrad_and_masked_dgrad_kernels(gpu):
     assert (out - ref).abs().max().item() <= 1e-4
 
 
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-4), ("mixed", 1e-3)])
 @pytest.mark.parametrize("n0,n1", [(6000, 5500), (120_000, 119_000)])      # incl. BASELINE size
-def test_single_step_gradients_match_autograd(gpu, n0, n1):
+def test_single_step_gradients_match_autograd(gpu, n0, n1, precision, tol):
     import fastnsf_oracle as fo
     from himo_amd.fastnsf import FastNSF, init_mlp
     pc0, pc1 = _scene(1, n0, n1)
     layers = init_mlp(3)
-    eng = FastNSF(device=gpu, iters=1, lr=0.0, seed=3)
+    eng = FastNSF(device=gpu, iters=1, lr=0.0, seed=3, objective="nn", precision=precision)
     eng.fit(pc0, pc1, layers=layers)
     ref_loss, ref_grads, _ = fo.loss_and_grads(layers, pc0, pc1)
-    assert eng.loss_history[0][1] == pytest.approx(ref_loss, rel=1e-5)
+    assert eng.loss_history[0][1] == pytest.approx(ref_loss, rel=1e-5 if precision == "f32" else 1e-4)
     for k, (gw, gb) in enumerate(ref_grads):
         cin, cout = gw.shape
         got_w, got_b = eng.gW[k].cpu().numpy()[:cin, :cout], eng.gb[k].cpu().numpy()[:cout]
         scale = max(np.abs(gw).max(), 1e-8)
-        assert np.abs(got_w - gw).max() <= 2e-4 * scale, k
-        assert np.abs(got_b - gb).max() <= 2e-4 * max(np.abs(gb).max(), 1e-8), k
+        assert np.abs(got_w - gw).max() <= tol * scale, k
+        assert np.abs(got_b - gb).max() <= tol * max(np.abs(gb).max(), 1e-8), k
 
 
 def test_fit_follows_the_cpu_restatement_and_recovers_the_motion(gpu):
@@ -72,7 +73,7 @@ def test_fit_follows_the_cpu_restatement_and_recovers_the_motion(gpu):
     pc0, pc1 = _scene(2, 8000, 8000)
     layers = init_mlp(5)
     iters = 25
-    eng = FastNSF(device=gpu, iters=iters, lr=1e-3, early_patience=10_000)     # patience on => loss logged every step
+    eng = FastNSF(device=gpu, iters=iters, lr=1e-3, early_patience=10_000, objective="nn")     # patience on => loss logged every step
     flow = eng.fit(pc0, pc1, layers=layers).cpu().numpy()
     hist, ref_flow = fo.fit(layers, pc0, pc1, iters)
     got_hist = [v for _, v in eng.loss_history]
@@ -97,10 +98,12 @@ def test_flow_includes_ego_motion(gpu):
     assert np.abs((flow - f) - np.array([-1.5, 0, 0], np.float32)).max() < 1e-5
 
 
-def test_full_size_fit_is_finite_reproducible_and_reduces_the_objective(gpu):
+@pytest.mark.parametrize("objective", ["nn", "dt"])
+def test_full_size_fit_is_finite_reproducible_and_reduces_the_objective(gpu, objective):
     """BASELINE config 4 at BASELINE size: one 120k-point sweep pair, 30 iterations.  The objective falls, the flow is
     finite and row-aligned with pc0, and a second fit from the same seed reproduces it (exact NN correspondences and
-    fixed-order weight-gradient reductions; the Chamfer gradient's scatter half may differ in the last bits)."""
+    fixed-order weight-gradient reductions; the Chamfer gradient's scatter half may differ in the last bits -- the
+    distance-transform objective has no scatter at all and reproduces bit for bit)."""
     from himo_amd.fastnsf import FastNSF
     from himo_amd.synthetic import make_frame
     f = make_frame(805, n_points=120_000)
@@ -108,7 +111,7 @@ def test_full_size_fit_is_finite_reproducible_and_reduces_the_objective(gpu):
     pc1 = torch.from_numpy((f["pc0"][:, :3] + f["flow"]).astype(np.float32)).to(gpu)
     runs = []
     for _ in range(2):
-        m = FastNSF(device=gpu, iters=30, seed=3)
+        m = FastNSF(device=gpu, iters=30, seed=3, objective=objective)
         flow = m.fit(pc0, pc1, f["pose0"], f["pose1"])
         assert flow.shape == (120_000, 3) and torch.isfinite(flow).all()
         first, last = m.loss_history[0][1], m.loss_history[-1][1]
@@ -116,3 +119,104 @@ def test_full_size_fit_is_finite_reproducible_and_reduces_the_objective(gpu):
         runs.append((flow.clone(), last))
     assert runs[0][1] == pytest.approx(runs[1][1], rel=1e-4)
     assert (runs[0][0] - runs[1][0]).abs().max().item() <= 1e-3
+    if objective == "dt":
+        assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+
+
+# ---- the distance-transform objective (csrc/dtloss.hip): what the config's `model=fastnsf` names ---------------------------------
+DT_BOX = (-12.0, -10.0, -2.0, 12.0, 10.0, 2.0)
+
+
+def _dt_scene(seed, n0, n1):
+    rng = np.random.default_rng(seed)
+    lo, hi = np.array([-9, -7, -1.5], np.float32), np.array([9, 7, 1.5], np.float32)
+    pc1 = rng.uniform(lo, hi, (n1, 3)).astype(np.float32)
+    pc0 = (pc1[rng.integers(0, n1, n0)] - np.array([0.5, 0.15, 0.0], np.float32) + rng.normal(0, 0.03, (n0, 3))).astype(np.float32)
+    pc0[:20] += np.array([40.0, 0, 0], np.float32)               # a few points far outside the volume: clamped, no gradient
+    return pc0, pc1
+
+
+@pytest.mark.parametrize("n1,cell", [(3_000, 0.1), (40, 0.1), (0, 0.2), (20_000, 0.25)])
+def test_distance_transform_volume_equals_scipy_edt(gpu, n1, cell):
+    """The three windowed min-plus passes against scipy's exact Euclidean distance transform of the same occupancy grid, capped
+    at the window: sparse targets (large distances: the cap / INF handling), an empty target, a dense one."""
+    import ctypes
+    import fastnsf_oracle as fo
+    from himo_amd import _lib
+    from himo_amd.fastnsf import dt_grid
+    lib = _lib.load()
+    _, pc1 = _dt_scene(7, 10, max(n1, 1))
+    pc1 = pc1[:n1]
+    origin, dims, window = dt_grid(2.0, cell, DT_BOX)
+    o_c, d_c = (ctypes.c_float * 3)(*origin.tolist()), (ctypes.c_int * 3)(*dims.tolist())
+    vol = torch.empty(int(lib.himo_dt_volume_bytes(d_c)), dtype=torch.uint8, device=gpu)
+    p1 = torch.from_numpy(pc1.reshape(-1, 3).copy()).to(gpu)
+    _lib.check(lib.himo_dt_build(n1, p1.data_ptr() if n1 else None, o_c, cell, d_c, window, vol.data_ptr(), vol.numel(), _lib.stream_handle()))
+    nx, ny, nz = (int(d) for d in dims)
+    g = vol[: nx * ny * nz * 2].view(torch.int16).cpu().numpy().view(np.uint16).reshape(nz, ny, nx)
+    got = np.minimum(np.sqrt(g.astype(np.float32)), np.float32(window)) * np.float32(cell)
+    got[g == 0xFFFF] = np.float32(window) * np.float32(cell)
+    ref = fo.dt_volume(pc1.reshape(-1, 3), origin, dims, cell, window)
+    assert np.abs(got - ref).max() <= 1e-6 * max(ref.max(), 1.0)
+    if n1:
+        assert (g == 0).sum() > 0 and got.min() == 0.0
+
+
+def test_fused_mlp_kernels_equal_the_layer_by_layer_products(gpu):
+    """csrc/mlpfused.hip against the row-GEMM path it replaces (same split arithmetic, same packed weights): activations, output,
+    loss and every gradient of one evaluation -- at a point count that is not a multiple of the 64-row block."""
+    from himo_amd.fastnsf import FastNSF, init_mlp
+    pc0, pc1 = _dt_scene(21, 10_037, 9_000)
+    layers = init_mlp(9)
+    runs = {}
+    for fused in (False, True):
+        eng = FastNSF(device=gpu, iters=1, lr=0.0, seed=3, objective="dt", dt_box=DT_BOX, precision="mixed", fused=fused)
+        eng.fit(pc0, pc1, layers=layers)
+        runs[fused] = ([h.clone() for h in eng.H], eng.OUT.clone(), eng.loss_history[0][1], eng.flat_g.clone())
+    (H0, out0, loss0, g0), (H1, out1, loss1, g1) = runs[False], runs[True]
+    for k, (a, b) in enumerate(zip(H0, H1)):
+        assert (a - b).abs().max().item() <= 2e-5 * max(a.abs().max().item(), 1.0), k       # same 22-bit products, different summation grouping
+    assert (out0 - out1).abs().max().item() <= 1e-5 * max(out0.abs().max().item(), 1.0)
+    assert loss1 == pytest.approx(loss0, rel=1e-5)
+    assert (g0 - g1).abs().max().item() <= 5e-4 * g0.abs().max().item()
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-4), ("mixed", 1e-3)])
+@pytest.mark.parametrize("n0,n1", [(6_000, 5_500), (50_000, 60_000)])
+def test_dt_objective_loss_and_gradients_match_autograd(gpu, n0, n1, precision, tol):
+    import fastnsf_oracle as fo
+    from himo_amd.fastnsf import FastNSF, dt_grid, init_mlp
+    pc0, pc1 = _dt_scene(11, n0, n1)
+    layers = init_mlp(3)
+    eng = FastNSF(device=gpu, iters=1, lr=0.0, seed=3, objective="dt", dt_box=DT_BOX, precision=precision)
+    eng.fit(pc0, pc1, layers=layers)
+    origin, dims, window = dt_grid(2.0, 0.1, DT_BOX)
+    ref_loss, ref_grads, _, ref_gm = fo.dt_loss_and_grads(layers, pc0, pc1, origin, dims, 0.1, window)
+    assert eng.loss_history[0][1] == pytest.approx(ref_loss, rel=1e-5 if precision == "f32" else 1e-4)
+    gm = eng._gmoved.cpu().numpy()
+    assert np.abs(gm - ref_gm).max() <= (1e-4 if precision == "f32" else 2e-3) * np.abs(ref_gm).max()
+    assert np.all(gm[:20] == 0)                                   # the points far outside the volume
+    for k, (gw, gb) in enumerate(ref_grads):
+        cin, cout = gw.shape
+        got_w, got_b = eng.gW[k].cpu().numpy()[:cin, :cout], eng.gb[k].cpu().numpy()[:cout]
+        assert np.abs(got_w - gw).max() <= tol * max(np.abs(gw).max(), 1e-8), k
+        assert np.abs(got_b - gb).max() <= tol * max(np.abs(gb).max(), 1e-8), k
+
+
+def test_dt_fit_follows_the_cpu_restatement_and_recovers_the_motion(gpu):
+    import fastnsf_oracle as fo
+    from himo_amd.fastnsf import FastNSF, dt_grid, init_mlp
+    pc0, pc1 = _dt_scene(12, 8_000, 8_000)
+    layers = init_mlp(5)
+    iters = 25
+    eng = FastNSF(device=gpu, iters=iters, lr=1e-3, early_patience=10_000, objective="dt", dt_box=DT_BOX)
+    flow = eng.fit(pc0, pc1, layers=layers).cpu().numpy()
+    origin, dims, window = dt_grid(2.0, 0.1, DT_BOX)
+    hist, ref_flow = fo.dt_fit(layers, pc0, pc1, origin, dims, 0.1, window, iters)
+    got_hist = [v for _, v in eng.loss_history]
+    assert len(got_hist) == iters
+    for a, b in zip(got_hist[:10], hist[:10]):
+        assert a == pytest.approx(b, rel=2e-3)
+    assert got_hist[-1] < 0.7 * got_hist[0] and hist[-1] < 0.7 * hist[0]
+    assert got_hist[-1] == pytest.approx(hist[-1], rel=0.1)
+    assert np.abs(np.median(flow[20:], axis=0) - np.median(ref_flow[20:], axis=0)).max() < 0.05
