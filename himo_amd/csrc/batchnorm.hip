@@ -61,23 +61,44 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(int64_t total, in
     partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + which) * 128 + lc] = t;
 }
 
+// the two per-channel sums of a 128-channel tile (blockIdx.x) over the block partials, by a 1024-thread block: 8 groups x 128
+// channels, each thread four independent chains over every 8th partial (the loads of a chain step are all in flight: a single
+// serial chain of 256 dependent float64 loads per thread made this 40 us), fixed-order combine -- valid in threads 0..127
+__device__ inline void bn_sum_partials(const double* __restrict__ partial, int n_blocks, int ch, double& s0, double& s1) {
+    __shared__ double sh[2][8][128];
+    const int lc = threadIdx.x & 127, grp = threadIdx.x >> 7;
+    const int col = (int)blockIdx.x * 128 + lc;
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (col < ch) {
+        const double* p = partial + (int64_t)blockIdx.x * n_blocks * 256 + lc;
+        int i = grp;
+        for (; i + 24 < n_blocks; i += 32) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[k] += p[(int64_t)(i + 8 * k) * 256]; b[k] += p[(int64_t)(i + 8 * k) * 256 + 128]; }
+        }
+        for (; i < n_blocks; i += 8) { a[0] += p[(int64_t)i * 256]; b[0] += p[(int64_t)i * 256 + 128]; }
+    }
+    sh[0][grp][lc] = (a[0] + a[1]) + (a[2] + a[3]);
+    sh[1][grp][lc] = (b[0] + b[1]) + (b[2] + b[3]);
+    __syncthreads();
+    s0 = 0.0; s1 = 0.0;
+    if (threadIdx.x < 128) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { s0 += sh[0][g][lc]; s1 += sh[1][g][lc]; }
+    }
+}
+
 // one block per 128-channel tile: fixed-order sum of the block partials, then the layer's constants.
 // consts [4][ch]: mean, invstd (forward) -- the backward reuses the buffer for its own three coefficient rows.
 __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const double* __restrict__ partial, int n_blocks, int ch, double count,
                                                                 float eps, float momentum, float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var, float* __restrict__ mean_out,
                                                                 float* __restrict__ invstd_out) {
-    __shared__ double sh[2][4][128];
-    const int lc = threadIdx.x & 127, which = (threadIdx.x >> 7) & 1, grp = threadIdx.x >> 8;     // 4 groups x 2 sums x 128 channels
+    double s, ss;
+    bn_sum_partials(partial, n_blocks, ch, s, ss);
+    const int lc = threadIdx.x & 127;
     const int col = (int)blockIdx.x * 128 + lc;
-    double t = 0.0;
-    if (col < ch)
-        for (int b = grp; b < n_blocks; b += 4) t += partial[(((int64_t)blockIdx.x * n_blocks + b) * 2 + which) * 128 + lc];
-    sh[which][grp][lc] = t;
-    __syncthreads();
     if (threadIdx.x < 128 && col < ch) {
-        const double s = (sh[0][0][lc] + sh[0][1][lc]) + (sh[0][2][lc] + sh[0][3][lc]);
-        const double ss = (sh[1][0][lc] + sh[1][1][lc]) + (sh[1][2][lc] + sh[1][3][lc]);
         const double mean = s / count;
         double var = ss / count - mean * mean;            // biased: what the normalisation uses
         if (var < 0.0) var = 0.0;
@@ -152,17 +173,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double* __r
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
                                                               float* __restrict__ coef) {
-    __shared__ double sh[2][4][128];
-    const int lc = threadIdx.x & 127, which = (threadIdx.x >> 7) & 1, grp = threadIdx.x >> 8;
+    double sg, sgx;
+    bn_sum_partials(partial, n_blocks, ch, sg, sgx);
+    const int lc = threadIdx.x & 127;
     const int col = (int)blockIdx.x * 128 + lc;
-    double t = 0.0;
-    if (col < ch)
-        for (int b = grp; b < n_blocks; b += 4) t += partial[(((int64_t)blockIdx.x * n_blocks + b) * 2 + which) * 128 + lc];
-    sh[which][grp][lc] = t;
-    __syncthreads();
     if (threadIdx.x < 128 && col < ch) {
-        const double sg = (sh[0][0][lc] + sh[0][1][lc]) + (sh[0][2][lc] + sh[0][3][lc]);
-        const double sgx = (sh[1][0][lc] + sh[1][1][lc]) + (sh[1][2][lc] + sh[1][3][lc]);
         dbeta[col] = accumulate ? dbeta[col] + (float)sg : (float)sg;
         dgamma[col] = accumulate ? dgamma[col] + (float)sgx : (float)sgx;
         coef[col] = gamma[col] * invstd[col];
@@ -203,12 +218,12 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(int ch, const float* __res
 }
 
 static int bn_rows_per_block(int64_t total) {
-    int64_t r = (total + 1023) / 1024;                    // ~1024 blocks of partials at most
+    int64_t r = (total + 255) / 256;                      // at most 256 blocks of partials: one per CU, and a short finalize
     r = (r + 7) / 8 * 8;
     return (int)(r < 64 ? 64 : r);
 }
 static size_t bn_ws(int64_t total, int ch) {
-    const size_t nb = (size_t)((total + 63) / 64) < 1025 ? (size_t)((total + 63) / 64) + 1 : 1025;
+    const size_t nb = (size_t)((total + 63) / 64) < 257 ? (size_t)((total + 63) / 64) + 1 : 257;
     const size_t tiles = (size_t)(ch + 127) / 128;
     return tiles * nb * 2 * 128 * sizeof(double) + (size_t)4 * ch * sizeof(float) + 64;
 }
