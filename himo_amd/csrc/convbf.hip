@@ -467,6 +467,55 @@ extern "C" int himo_mlp_repack(int n_layers, const float* const* h_w, const int*
     return HIMO_OK;
 }
 
+// Every packed weight copy a training step needs, in ONE launch (himo_weight_prepare_batch): a device-resident table of jobs, each a
+// himo_conv_pack_weights_ex of one tensor, optionally of its data-gradient form (taps mirrored, cin <-> cout: what weight_flip_kernel
+// + pack_weights_kernel produced in two launches per layer -- ~100 launches of 4-6 us per step before).  A block finds its job by
+// bisection over the jobs' first-block numbers.
+namespace himo {
+__device__ __forceinline__ void pack_store(float x, int format, unsigned short* __restrict__ out, int64_t base, int64_t plane) {
+    unsigned h, m = 0, l;
+    if (format == 0) { split3(x, h, m, l); out[base] = (unsigned short)h; out[base + plane] = (unsigned short)m; out[base + 2 * plane] = (unsigned short)l; }
+    else if (format == 2) { h = bf16_rne_bits(x); l = bf16_rne_bits(x - bf16_bits_to_float(h)); out[base] = (unsigned short)h; out[base + plane] = (unsigned short)l; }
+    else { split2(x * kF16WeightScale, h, l); out[base] = (unsigned short)h; out[base + plane] = (unsigned short)l; }
+}
+__global__ __launch_bounds__(256) void weight_prepare_kernel(const himo_weight_job* __restrict__ jobs, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {                                   // last job whose first block is <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const himo_weight_job j = jobs[lo];
+    const int T = j.ksize * j.ksize;
+    const int Cin = j.flip ? j.cout : j.cin, Cout = j.flip ? j.cin : j.cout;       // of the packed (logical) tensor
+    const int slabs = (Cin + 15) / 16;
+    const int64_t item = (int64_t)((int)blockIdx.x - j.first_block) * 256 + threadIdx.x;
+    if (item >= (int64_t)T * slabs * Cout * 16) return;
+    const int k = (int)(item % 16);
+    const int co = (int)((item / 16) % Cout);
+    const int slab = (int)((item / (16 * (int64_t)Cout)) % slabs);
+    const int tap = (int)(item / (16 * (int64_t)Cout * slabs));
+    const int ci = slab * 16 + k;
+    float x = 0.f;
+    if (ci < Cin) x = j.flip ? j.w[((int64_t)(T - 1 - tap) * j.cin + co) * j.cout + ci]          // wf[tap][ci][co] = w[T-1-tap][co][ci]
+                             : j.w[((int64_t)tap * Cin + ci) * Cout + co];
+    const int NP = j.format == 0 ? 3 : 2;
+    pack_store(x, j.format, (unsigned short*)j.packed, (((int64_t)tap * slabs + slab) * NP) * Cout * 16 + (int64_t)co * 16 + k, (int64_t)Cout * 16);
+}
+}  // namespace himo
+
+extern "C" int himo_weight_job_blocks(int ksize, int cin, int cout, int flip) {
+    if (cin < 1 || cout < 1 || !(ksize == 1 || ksize == 3)) return -1;
+    const int64_t items = (int64_t)ksize * ksize * (((flip ? cout : cin) + 15) / 16) * (flip ? cin : cout) * 16;
+    return (int)((items + 255) / 256);
+}
+
+extern "C" int himo_weight_prepare_batch(const himo_weight_job* d_jobs, int n_jobs, int total_blocks, void* stream) {
+    if (!d_jobs || n_jobs < 1 || total_blocks < 1) return HIMO_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(weight_prepare_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, d_jobs, n_jobs);
+    HIMO_LAUNCH_CHECK("weight_prepare_kernel");
+    return HIMO_OK;
+}
+
 extern "C" int himo_conv_pack_weights(const float* d_w, int ksize, int cin, int cout, void* d_packed, void* stream) {
     return himo_conv_pack_weights_ex(d_w, ksize, cin, cout, 0, d_packed, stream);
 }

@@ -126,6 +126,24 @@ class HeadTrainer:
             self.p, self.g = p, g
         self.n = 0
         self._descs = {}
+        self.WT = {k: torch.empty((v.shape[1], v.shape[0]), dtype=torch.float32, device=dev) for k, v in self.p.items() if v.dim() == 2}
+        pk = lambda cin, cout: torch.empty(int(self.lib.himo_conv_packed_weight_bytes(1, cin, cout)), dtype=torch.uint8, device=dev)
+        # split copies of the three wide matrices and of their transposes (dec2 is 32 x 4: stays float32)
+        self.PK = {k: pk(*self.p[f"{k}.weight"].shape) for k in ("zr", "q", "dec1")} if self.fmt_fwd is not None else {}
+        self.PKT = {k: pk(*self.p[f"{k}.weight"].shape[::-1]) for k in ("zr", "q", "dec1")} if self.fmt_bwd is not None else {}
+        # True: the owner refreshes PK / PKT itself after every parameter update (SeFlowTrainer: one launch for the whole network)
+        self.external_pack = False
+
+    def weight_jobs(self):
+        """(weight, ksize, cin, cout, format, flip, destination) per packed copy, for himo_weight_prepare_batch"""
+        jobs = []
+        for k in self.PK:
+            cin, cout = self.p[f"{k}.weight"].shape
+            jobs.append((self.p[f"{k}.weight"], 1, cin, cout, self.fmt_fwd, 0, self.PK[k]))
+        for k in self.PKT:
+            cin, cout = self.p[f"{k}.weight"].shape
+            jobs.append((self.p[f"{k}.weight"], 1, cin, cout, self.fmt_bwd, 1, self.PKT[k]))
+        return jobs
 
     def _reserve(self, n):
         if n == self.n:
@@ -143,11 +161,6 @@ class HeadTrainer:
         self.DY1, self.DHX, self.DRHX = buf(n, 32), buf(n, 192), buf(n, 192)
         self.DH, self.DHP, self.DZ, self.DAQ, self.DAZR = buf(n, 128), buf(n, 128), buf(n, 128), buf(n, 128), buf(n, 256)
         self.DX = buf(n, 64)
-        self.WT = {k: torch.empty((v.shape[1], v.shape[0]), dtype=torch.float32, device=dev) for k, v in self.p.items() if v.dim() == 2}
-        pk = lambda cin, cout: torch.empty(int(self.lib.himo_conv_packed_weight_bytes(1, cin, cout)), dtype=torch.uint8, device=dev)
-        # split copies of the three wide matrices and of their transposes (dec2 is 32 x 4: stays float32)
-        self.PK = {k: pk(*self.p[f"{k}.weight"].shape) for k in ("zr", "q", "dec1")} if self.fmt_fwd is not None else {}
-        self.PKT = {k: pk(*self.p[f"{k}.weight"].shape[::-1]) for k in ("zr", "q", "dec1")} if self.fmt_bwd is not None else {}
         need = int(self.lib.himo_wgrad_workspace_bytes_ex(n, 192, 256))
         self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
 
@@ -180,7 +193,7 @@ class HeadTrainer:
         self._reserve(n)
         lib, s, p = self.lib, _lib.stream_handle, self.p
         ff = self.fmt_fwd
-        pk = {k: self._pack(p[f"{k}.weight"], self.PK[k], ff) for k in self.PK}
+        pk = self.PK if self.external_pack else {k: self._pack(p[f"{k}.weight"], self.PK[k], ff) for k in self.PK}
         self.HX[0].copy_(hx0)
         for t in range(spec.GRU_ITERS):
             self._gemm(self.HX[t], p["zr.weight"], p["zr.bias"], self.AZR, 192, 256, packed=pk.get("zr"), fmt=ff or 0)
@@ -206,6 +219,8 @@ class HeadTrainer:
 
     def _transposed_packed(self, name):
         """(transposed float32 weights, their split-bf16 copy or None) for a data gradient dX = dZ W^T"""
+        if self.external_pack and name in self.PKT:          # the product reads only the packed copy; the float32 address must just be valid
+            return self.p[f"{name}.weight"], self.PKT[name]
         wt = self._transposed(name)
         return wt, (self._pack(wt, self.PKT[name], self.fmt_bwd) if name in self.PKT else None)
 
@@ -242,6 +257,8 @@ class HeadTrainer:
 
 
 _lib.register({
+    "himo_weight_job_blocks": (c_i, [c_i, c_i, c_i, c_i]),
+    "himo_weight_prepare_batch": (c_i, [c_p, c_i, c_i, c_p]),
     "himo_add2d": (c_i, [c_l, c_i, c_p, c_i, c_p, c_i, c_p]),
     "himo_colsum": (c_i, [c_l, c_p, c_i, c_i, c_p, ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
     "himo_pfn_backward_workspace_bytes": (ctypes.c_size_t, []),
@@ -346,7 +363,6 @@ class SeFlowTrainer:
         # mixed: the data-gradient convolutions (3x3 and 1x1) run the two-term bf16 split (HIMO_PACK_BF16X2: 16 significant bits, float32
         # range, three matrix products per block) instead of the three-term one (six)
         self.bwd3_format = 2 if precision == "mixed" else 0
-        self._wp_fmt = 0
         self.lib = _lib.load()
         self.device = dev = device if device is not None else _lib.require_gpu()
         params = spec.init_params(seed, fresh_bn=self.bn_batch) if params is None else params      # from scratch: BatchNorm reset
@@ -418,7 +434,7 @@ class SeFlowTrainer:
         self.dCAT = buf(H * W * 128)
         self.dTMPc = buf((H // 2) * (W // 2) * 64)               # gradient of the 1x1-projected coarse map
         self.dCO = [buf((H // 2) * (W // 2) * 128) for _ in range(2)]   # d coarse of dec3 / dec2
-        self.WF = buf(3 * 3 * 512 * 256)                         # flipped / transposed weights of the layer being differentiated
+        self.WF = buf(3 * 3 * 512 * 256) if precision == "f32" else None      # flipped weights of the layer being differentiated
         ws = max(int(self.lib.himo_conv_wgrad_workspace_bytes(H // 4, W // 4, 512, 256)),
                  max(int(self.lib.himo_conv_wgrad_batch_workspace_bytes(n, h_, w_, ci, co, st)) for n, h_, w_, ci, co, st in
                      [(F, H // 2, W // 2, 64, 64, 1), (F, H // 4, W // 4, 128, 128, 1), (F, H // 8, W // 8, 256, 256, 1),
@@ -449,22 +465,43 @@ class SeFlowTrainer:
                 if k.endswith(".weight") and v.dim() == 4:
                     ks, _, cin, cout = v.shape
                     self.packed[k] = torch.empty(int(self.lib.himo_conv_packed_weight_bytes(ks, cin, cout)), dtype=torch.uint8, device=dev)
-            self.WFP = torch.empty(int(self.lib.himo_conv_packed_weight_bytes(3, 512, 256)), dtype=torch.uint8, device=dev)
+            # ... and of every layer's DATA-GRADIENT weights (taps mirrored, channel roles swapped), same byte count
+            self.packed_flip = {k: torch.empty_like(v) for k, v in self.packed.items()}
+            self._flip_ptrs = {v.data_ptr() for v in self.packed_flip.values()}
             net.packed = self.packed                      # the decoder forward runs through net._conv
             net.packed_format = self.fwd_format
+            jobs = []
+            for k, buf in self.packed.items():
+                ks, _, cin, cout = self.p[k].shape
+                jobs.append((self.p[k], ks, cin, cout, self.fwd_format, 0, buf))
+                jobs.append((self.p[k], ks, cin, cout, self.bwd3_format, 1, self.packed_flip[k]))
+            jobs += self.head.weight_jobs()
+            self.head.external_pack = True
+            table = np.zeros(len(jobs), dtype=np.dtype([("w", "<u8"), ("packed", "<u8"), ("ksize", "<i4"), ("cin", "<i4"), ("cout", "<i4"),
+                                                        ("format", "<i4"), ("flip", "<i4"), ("first_block", "<i4")]))   # himo_weight_job
+            blocks = 0
+            for i, (w, ks, cin, cout, fmt, flip, dst) in enumerate(jobs):
+                nb = int(self.lib.himo_weight_job_blocks(ks, cin, cout, flip))
+                if nb < 1:
+                    raise ValueError(f"weight job {i}: {ks}x{ks} {cin}->{cout}")
+                table[i] = (w.data_ptr(), dst.data_ptr(), ks, cin, cout, fmt, flip, blocks)
+                blocks += nb
+            self._jobs = torch.from_numpy(table.view(np.uint8).copy()).to(dev)
+            self._n_jobs, self._job_blocks = len(jobs), blocks
         self._repack()
 
     def _repack(self):
-        """refresh the split-bf16 weight copies (after construction and after every optimiser step)"""
-        for k, buf in self.packed.items():
-            ks, _, cin, cout = self.p[k].shape
-            _lib.check(self.lib.himo_conv_pack_weights_ex(self.p[k].data_ptr(), ks, cin, cout, self.fwd_format, buf.data_ptr(),
-                                                          _lib.stream_handle()), "pack")
+        """refresh EVERY packed weight copy -- forward, data-gradient (flipped) and the head's -- in one launch: after construction,
+        after every optimiser step and after loading parameters.  Code that edits ``self.p`` by hand must call it too."""
+        if self.precision == "f32":
+            return
+        _lib.check(self.lib.himo_weight_prepare_batch(self._jobs.data_ptr(), self._n_jobs, self._job_blocks, _lib.stream_handle()),
+                   "weight_prepare_batch")
 
     # ---- launch helpers (raw device addresses: most operands are channel groups of wider buffers) --------------
     def _conv(self, x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride=1, packed=None, fmt=0):
-        if packed is not None and self.precision != "f32" and packed == self.WFP.data_ptr():
-            fmt = self._wp_fmt                        # the scratch copy _flip just packed
+        if packed is not None and self.precision != "f32" and packed in self._flip_ptrs:
+            fmt = self.bwd3_format                    # a data-gradient copy (_flip)
         key = (x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride, packed, fmt)
         d = self._descs.get(key)                 # cached per call site: see HeadTrainer._gemm
         if d is None:
@@ -502,12 +539,10 @@ class SeFlowTrainer:
 
     def _flip(self, name, ks, cin, cout):
         """flipped / transposed weights of one layer for its data gradient: (float32 address, split-bf16 address or None)"""
+        if self.precision != "f32":      # prepared by _repack; the product reads only the packed copy, the float32 address must just be valid
+            return self.p[f"{name}.weight"].data_ptr(), self.packed_flip[f"{name}.weight"].data_ptr()
         _lib.check(self.lib.himo_weight_flip(self.p[f"{name}.weight"].data_ptr(), ks, cin, cout, self.WF.data_ptr(), _lib.stream_handle()), "flip")
-        if self.precision == "f32":
-            return self.WF.data_ptr(), None
-        self._wp_fmt = self.bwd3_format                   # 3x3 and 1x1 data gradients alike
-        _lib.check(self.lib.himo_conv_pack_weights_ex(self.WF.data_ptr(), ks, cout, cin, self._wp_fmt, self.WFP.data_ptr(), _lib.stream_handle()), "pack")
-        return self.WF.data_ptr(), self.WFP.data_ptr()
+        return self.WF.data_ptr(), None
 
     def _add2d(self, rows, cols, b, b_pitch, y, y_pitch):
         _lib.check(self.lib.himo_add2d(rows, cols, b, b_pitch, y, y_pitch, _lib.stream_handle()), "add2d")
@@ -687,11 +722,10 @@ class SeFlowTrainer:
                                                         dp + 4 * f * ho * wo * cout, cout, s()), "affine_gelu_bwd")
             else:
                 _lib.check(lib.himo_affine_gelu_bwd(F * ho * wo, cout, dy, cout, pre.data_ptr(), cout, sc, dp, cout, s()), "affine_gelu_bwd")
-            if self._fwd_batch:
-                # a bias in front of a training-mode BatchNorm has exactly zero gradient (the batch mean absorbs it); the column
-                # sums of dp would be rounding noise that Adam's normalisation turns into full-size random steps
-                self.g[f"{name}.bias"].zero_()
-            else:
+            # a bias in front of a training-mode BatchNorm has exactly zero gradient (the batch mean absorbs it); the column sums
+            # of dp would be rounding noise that Adam's normalisation turns into full-size random steps.  Nothing ever writes
+            # these entries of flat_g in batch mode: they keep the zeros they were created with.
+            if not self._fwd_batch:
                 self._colsum(F * ho * wo, dp, cout, cout, f"{name}.bias")
             x, x_bs, x_pitch = self.inputs[li]
             self._wgrad3_batch(F, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride)

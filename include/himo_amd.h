@@ -482,6 +482,23 @@ int himo_head_scatter(int64_t n, int grid_w, int grid_h, const void* d_pillar_wo
                       float* d_db0, int b0_pitch, int group0, int group1, int n_groups, float* d_ddec, int dec_pitch,
                       void* stream);
 
+/* Every packed weight copy of a training step in ONE launch.  A job = himo_conv_pack_weights_ex(w, ksize, cin, cout, format) into
+ * `packed`; with flip != 0 the copy is of the layer's DATA-GRADIENT weights instead -- taps mirrored and the channel roles swapped,
+ * i.e. pack(wf, ksize, cout, cin) with wf[t][co][ci] = w[k*k-1-t][ci][co] (for ksize 1: the transpose).  The job table lives in DEVICE
+ * memory (the caller uploads it once; the tensors it names are updated in place by the optimiser); first_block = the running sum
+ * of himo_weight_job_blocks over the jobs before it, total_blocks the sum over all.  Spec: himo_amd/seflow/train.py (reference
+ * absent: its training loop packs nothing). */
+typedef struct himo_weight_job {
+    const float* w;           /* [k][k][cin][cout] float32 */
+    void* packed;             /* himo_conv_packed_weight_bytes(ksize, cin, cout) bytes (the same for the flipped form) */
+    int ksize, cin, cout;
+    int format;               /* HIMO_PACK_* */
+    int flip;
+    int first_block;
+} himo_weight_job;
+int himo_weight_job_blocks(int ksize, int cin, int cout, int flip);
+int himo_weight_prepare_batch(const himo_weight_job* d_jobs, int n_jobs, int total_blocks, void* stream);
+
 /* FastNSF's MLP after an optimiser step, ONE launch for all layers: every W [cin][cout] -> its fp16-split copy (format 1, forward
  * products) and the two-term bf16 copy of its transpose (format 2, input-gradient products); either destination may be NULL. */
 int himo_mlp_repack(int n_layers, const float* const* h_w, const int* h_cin, const int* h_cout, void* const* h_fwd_packed,
