@@ -34,71 +34,81 @@ __device__ inline int64_t bn_addr(int64_t r, int64_t rows, int64_t img_stride, i
     return img * img_stride + (r - img * rows) * pitch;
 }
 
+// narrow layers keep every lane busy: a block covers 2^qs float4 columns (32 for > 64 channels, 16 for > 32, else 8) x 256 >> qs row groups
+__device__ __host__ inline int bn_quad_shift(int ch) { return ch > 64 ? 5 : (ch > 32 ? 4 : 3); }
+
+// the block's two per-channel partial sums -> partial[tile][block][2][128], groups combined in fixed order
+__device__ inline void bn_block_partials(const double (&s0)[4], const double (&s1)[4], int qs, int q, int grp, int G, double* __restrict__ partial) {
+    __shared__ double sh[2][1024];                       // [which][grp][4 << qs]
+    const int w = 4 << qs;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sh[0][grp * w + q * 4 + k] = s0[k]; sh[1][grp * w + q * 4 + k] = s1[k]; }
+    __syncthreads();
+    const int which = threadIdx.x >> 7, lc = threadIdx.x & 127;
+    double t = 0.0;
+    if (lc < w) {
+        t = sh[which][lc];
+        for (int g = 1; g < G; ++g) t += sh[which][g * w + lc];
+    }
+    partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + which) * 128 + lc] = t;
+}
+
 // ---- forward: per-channel sum and sum of squares (float64) -------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(int64_t total, int64_t rows, int ch, BnMap x, double* __restrict__ partial,
                                                                int rows_pb) {
-    const int q = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int qs = bn_quad_shift(ch), q = threadIdx.x & ((1 << qs) - 1), grp = threadIdx.x >> qs, G = 256 >> qs;
     const int col = (int)blockIdx.y * 128 + q * 4;
     const int64_t r0 = (int64_t)blockIdx.x * rows_pb;
     const int64_t r1 = r0 + rows_pb < total ? r0 + rows_pb : total;
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     if (col < ch) {
 #pragma unroll 4
-        for (int64_t r = r0 + grp; r < r1; r += 8) {
+        for (int64_t r = r0 + grp; r < r1; r += G) {
             const float4 v = *reinterpret_cast<const float4*>(x.p + bn_addr(r, rows, x.img_stride, x.pitch) + col);
             s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
             ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
         }
     }
-    __shared__ double sh[2][8][128];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { sh[0][grp][q * 4 + k] = s[k]; sh[1][grp][q * 4 + k] = ss[k]; }
-    __syncthreads();
-    const int which = threadIdx.x >> 7, lc = threadIdx.x & 127;
-    double t = sh[which][0][lc];
-#pragma unroll
-    for (int g = 1; g < 8; ++g) t += sh[which][g][lc];
-    partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + which) * 128 + lc] = t;
+    bn_block_partials(s, ss, qs, q, grp, G, partial);
 }
 
-// the two per-channel sums of a 128-channel tile (blockIdx.x) over the block partials, by a 1024-thread block: 8 groups x 128
-// channels, each thread four independent chains over every 8th partial (the loads of a chain step are all in flight: a single
-// serial chain of 256 dependent float64 loads per thread made this 40 us), fixed-order combine -- valid in threads 0..127
-__device__ inline void bn_sum_partials(const double* __restrict__ partial, int n_blocks, int ch, double& s0, double& s1) {
-    __shared__ double sh[2][8][128];
-    const int lc = threadIdx.x & 127, grp = threadIdx.x >> 7;
-    const int col = (int)blockIdx.x * 128 + lc;
+// the two per-channel sums over the block partials.  One 1024-thread block per 16 channels (blockIdx.x = tile * 8 + chunk): 64 groups x
+// 16 channels, each thread four independent chains over every 64th partial, fixed-order combine -- a single serial chain of dependent
+// float64 loads per thread made this 40 us.  Result valid in threads 0..15; returns the thread's channel.
+__device__ inline int bn_sum_partials(const double* __restrict__ partial, int n_blocks, int ch, double& s0, double& s1) {
+    __shared__ double sh[2][64][16];
+    const int lc = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int tile = (int)blockIdx.x >> 3, chunk = (int)blockIdx.x & 7;
+    const int col = tile * 128 + chunk * 16 + lc;
     double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
     if (col < ch) {
-        const double* p = partial + (int64_t)blockIdx.x * n_blocks * 256 + lc;
+        const double* p = partial + (int64_t)tile * n_blocks * 256 + chunk * 16 + lc;
         int i = grp;
-        for (; i + 24 < n_blocks; i += 32) {
+        for (; i + 192 < n_blocks; i += 256) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { a[k] += p[(int64_t)(i + 8 * k) * 256]; b[k] += p[(int64_t)(i + 8 * k) * 256 + 128]; }
+            for (int k = 0; k < 4; ++k) { a[k] += p[(int64_t)(i + 64 * k) * 256]; b[k] += p[(int64_t)(i + 64 * k) * 256 + 128]; }
         }
-        for (; i < n_blocks; i += 8) { a[0] += p[(int64_t)i * 256]; b[0] += p[(int64_t)i * 256 + 128]; }
+        for (; i < n_blocks; i += 64) { a[0] += p[(int64_t)i * 256]; b[0] += p[(int64_t)i * 256 + 128]; }
     }
     sh[0][grp][lc] = (a[0] + a[1]) + (a[2] + a[3]);
     sh[1][grp][lc] = (b[0] + b[1]) + (b[2] + b[3]);
     __syncthreads();
     s0 = 0.0; s1 = 0.0;
-    if (threadIdx.x < 128) {
-#pragma unroll
-        for (int g = 0; g < 8; ++g) { s0 += sh[0][g][lc]; s1 += sh[1][g][lc]; }
+    if (threadIdx.x < 16) {
+        for (int g = 0; g < 64; ++g) { s0 += sh[0][g][lc]; s1 += sh[1][g][lc]; }
     }
+    return col;
 }
 
-// one block per 128-channel tile: fixed-order sum of the block partials, then the layer's constants.
+// fixed-order sum of the block partials, then the layer's constants.
 // consts [4][ch]: mean, invstd (forward) -- the backward reuses the buffer for its own three coefficient rows.
 __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const double* __restrict__ partial, int n_blocks, int ch, double count,
                                                                 float eps, float momentum, float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var, float* __restrict__ mean_out,
                                                                 float* __restrict__ invstd_out) {
     double s, ss;
-    bn_sum_partials(partial, n_blocks, ch, s, ss);
-    const int lc = threadIdx.x & 127;
-    const int col = (int)blockIdx.x * 128 + lc;
-    if (threadIdx.x < 128 && col < ch) {
+    const int col = bn_sum_partials(partial, n_blocks, ch, s, ss);
+    if (threadIdx.x < 16 && col < ch) {
         const double mean = s / count;
         double var = ss / count - mean * mean;            // biased: what the normalisation uses
         if (var < 0.0) var = 0.0;
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(256) void bn_normalize_gelu_kernel(int64_t total, i
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(int64_t total, int64_t rows, int ch, BnMap dy, BnMap xhat,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, BnMapW dx,
                                                              double* __restrict__ partial, int rows_pb) {
-    const int q = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int qs = bn_quad_shift(ch), q = threadIdx.x & ((1 << qs) - 1), grp = threadIdx.x >> qs, G = 256 >> qs;
     const int col = (int)blockIdx.y * 128 + q * 4;
     const int64_t r0 = (int64_t)blockIdx.x * rows_pb;
     const int64_t r1 = r0 + rows_pb < total ? r0 + rows_pb : total;
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(int64_t total, int6
     if (col < ch) {
         const float4 ga = *reinterpret_cast<const float4*>(gamma + col), be = *reinterpret_cast<const float4*>(beta + col);
 #pragma unroll 2
-        for (int64_t r = r0 + grp; r < r1; r += 8) {
+        for (int64_t r = r0 + grp; r < r1; r += G) {
             const int64_t img = r / rows, rr = r - img * rows;
             const float4 d = *reinterpret_cast<const float4*>(dy.p + img * dy.img_stride + rr * dy.pitch + col);
             const float4 h = *reinterpret_cast<const float4*>(xhat.p + img * xhat.img_stride + rr * xhat.pitch + col);
@@ -157,15 +167,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(int64_t total, int6
             sx[0] += (double)g.x * h.x; sx[1] += (double)g.y * h.y; sx[2] += (double)g.z * h.z; sx[3] += (double)g.w * h.w;
         }
     }
-    __shared__ double sh[2][8][128];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { sh[0][grp][q * 4 + k] = s[k]; sh[1][grp][q * 4 + k] = sx[k]; }
-    __syncthreads();
-    const int which = threadIdx.x >> 7, lc = threadIdx.x & 127;
-    double t = sh[which][0][lc];
-#pragma unroll
-    for (int g = 1; g < 8; ++g) t += sh[which][g][lc];
-    partial[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + which) * 128 + lc] = t;
+    bn_block_partials(s, sx, qs, q, grp, G, partial);
 }
 
 // dbeta = sum g, dgamma = sum g xhat; coefficient rows for the element-wise pass: k1 = gamma invstd, k2 = dbeta / N, k3 = dgamma / N
@@ -174,10 +176,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double* __r
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
                                                               float* __restrict__ coef) {
     double sg, sgx;
-    bn_sum_partials(partial, n_blocks, ch, sg, sgx);
-    const int lc = threadIdx.x & 127;
-    const int col = (int)blockIdx.x * 128 + lc;
-    if (threadIdx.x < 128 && col < ch) {
+    const int col = bn_sum_partials(partial, n_blocks, ch, sg, sgx);
+    if (threadIdx.x < 16 && col < ch) {
         dbeta[col] = accumulate ? dbeta[col] + (float)sg : (float)sg;
         dgamma[col] = accumulate ? dgamma[col] + (float)sgx : (float)sgx;
         coef[col] = gamma[col] * invstd[col];
@@ -218,12 +218,12 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(int ch, const float* __res
 }
 
 static int bn_rows_per_block(int64_t total) {
-    int64_t r = (total + 255) / 256;                      // at most 256 blocks of partials: one per CU, and a short finalize
-    r = (r + 7) / 8 * 8;
+    int64_t r = (total + 1023) / 1024;                    // at most 1024 blocks of partials (4 per CU)
+    r = (r + 31) / 32 * 32;
     return (int)(r < 64 ? 64 : r);
 }
 static size_t bn_ws(int64_t total, int ch) {
-    const size_t nb = (size_t)((total + 63) / 64) < 257 ? (size_t)((total + 63) / 64) + 1 : 257;
+    const size_t nb = (size_t)((total + 63) / 64) < 1025 ? (size_t)((total + 63) / 64) + 1 : 1025;
     const size_t tiles = (size_t)(ch + 127) / 128;
     return tiles * nb * 2 * 128 * sizeof(double) + (size_t)4 * ch * sizeof(float) + 64;
 }
@@ -256,7 +256,7 @@ extern "C" int himo_bn_train_fwd(int n_img, int64_t rows, int ch, const float* d
     {
         ProfScope ps("bn_stats_kernel", s);
         hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb, tiles), dim3(256), 0, s, total, rows, ch, x, partial, rows_pb);
-        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(tiles), dim3(1024), 0, s, partial, nb, ch, (double)total, eps, momentum, d_running_mean,
+        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(tiles * 8), dim3(1024), 0, s, partial, nb, ch, (double)total, eps, momentum, d_running_mean,
                            d_running_var, d_mean, d_invstd);
     }
     HIMO_LAUNCH_CHECK("bn_stats kernels");
@@ -291,7 +291,7 @@ extern "C" int himo_bn_train_bwd(int n_img, int64_t rows, int ch, const float* d
         ProfScope ps("bn_bwd_kernel", s);
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb, tiles), dim3(256), 0, s, total, rows, ch, BnMap{d_dy, dy_img_stride, dy_pitch}, xh,
                            d_gamma, d_beta, dx, partial, rows_pb);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tiles), dim3(1024), 0, s, partial, nb, ch, (double)total, d_gamma, d_invstd, d_dgamma,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tiles * 8), dim3(1024), 0, s, partial, nb, ch, (double)total, d_gamma, d_invstd, d_dgamma,
                            d_dbeta, (flags & 1u) ? 1 : 0, coef);
         const int64_t n4 = total * (ch >> 2);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, total, rows, ch, xh, coef, dx);

@@ -328,3 +328,57 @@ def test_train_batch_averages_the_per_sample_gradients(gpu, batchnorm):
     want = (grads[0] + grads[1]) * 0.5
     assert (tr.flat_g - want).abs().max().item() <= 1e-6 * max(want.abs().max().item(), 1e-12)
     assert SeFlowTrainer.step_lr(0) == 6e-5 and SeFlowTrainer.step_lr(3) == 3e-5 and SeFlowTrainer.step_lr(7) == 1.5e-5
+
+
+@pytest.mark.parametrize("n_img,rows,ch,pad", [(3, 4097, 64, 0), (1, 300, 32, 32), (2, 70_001, 128, 0), (3, 1024, 256, 256), (2, 5000, 48, 16),
+                                               (1, 9, 8, 0)])
+def test_batchnorm_training_kernels_match_autograd(gpu, n_img, rows, ch, pad):
+    """himo_bn_train_fwd / himo_bn_train_bwd (csrc/batchnorm.hip) against float64 autograd of torch's batch_norm + GELU: statistics,
+    running estimates, xhat, y, dx, dgamma, dbeta -- over narrow (every lane busy), wide and pitched maps and ragged row counts."""
+    from himo_amd import _lib
+    from himo_amd.seflow import train  # noqa: F401  (registers the signatures)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(7 + ch + rows)
+    pitch = ch + pad
+    x = torch.randn((n_img, rows, pitch), generator=g) * 1.7 + 0.4
+    dy = torch.randn((n_img, rows, pitch), generator=g)
+    gamma, beta = torch.rand(ch, generator=g) + 0.5, torch.randn(ch, generator=g) * 0.2
+    rm, rv = torch.randn(ch, generator=g) * 0.1, torch.rand(ch, generator=g) + 0.5
+    eps, mom = 1e-3, 0.1
+    # float64 reference
+    xr = x[:, :, :ch].double().reshape(-1, ch).clone().requires_grad_(True)
+    gr, br = gamma.double().clone().requires_grad_(True), beta.double().clone().requires_grad_(True)
+    rm_r, rv_r = rm.double().clone(), rv.double().clone()
+    pre = F.batch_norm(xr, rm_r, rv_r, gr, br, training=True, momentum=mom, eps=eps)
+    y_ref = F.gelu(pre)
+    (y_ref * dy[:, :, :ch].double().reshape(-1, ch)).sum().backward()
+    mean = xr.detach().mean(0); var = xr.detach().var(0, unbiased=False)
+    xhat_ref = (xr.detach() - mean) / torch.sqrt(var + eps)
+    # device
+    dev = gpu
+    X, DY = x.to(dev), dy.to(dev)
+    XH, Y, DX = torch.zeros_like(X), torch.zeros_like(X), torch.zeros_like(X)
+    G, B, RM, RV = gamma.to(dev), beta.to(dev), rm.to(dev), rv.to(dev)
+    M, IS, DG, DB = (torch.zeros(ch, device=dev) for _ in range(4))
+    ws = torch.empty(int(lib.himo_bn_workspace_bytes(n_img * rows, ch)), dtype=torch.uint8, device=dev)
+    s = _lib.stream_handle()
+    _lib.check(lib.himo_bn_train_fwd(n_img, rows, ch, X.data_ptr(), rows * pitch, pitch, G.data_ptr(), B.data_ptr(), eps, mom, RM.data_ptr(),
+                                     RV.data_ptr(), M.data_ptr(), IS.data_ptr(), XH.data_ptr(), rows * pitch, pitch, Y.data_ptr(), rows * pitch,
+                                     pitch, ws.data_ptr(), ws.numel(), s), "bn_train_fwd")
+    _lib.check(lib.himo_bn_train_bwd(n_img, rows, ch, DY.data_ptr(), rows * pitch, pitch, XH.data_ptr(), rows * pitch, pitch, G.data_ptr(),
+                                     B.data_ptr(), IS.data_ptr(), DX.data_ptr(), rows * pitch, pitch, DG.data_ptr(), DB.data_ptr(), 0,
+                                     ws.data_ptr(), ws.numel(), s), "bn_train_bwd")
+    torch.cuda.synchronize()
+    flat = lambda t: t.cpu()[:, :, :ch].reshape(-1, ch).double()
+    np.testing.assert_allclose(M.cpu().double(), mean, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(IS.cpu().double(), 1.0 / torch.sqrt(var + eps), rtol=2e-6, atol=0)
+    np.testing.assert_allclose(RM.cpu().double(), rm_r, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(RV.cpu().double(), rv_r, rtol=3e-6, atol=0)
+    np.testing.assert_allclose(flat(XH), xhat_ref, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(flat(Y), y_ref.detach(), rtol=0, atol=1e-5)
+    scale = float(xr.grad.abs().max())
+    np.testing.assert_allclose(flat(DX), xr.grad, rtol=0, atol=2e-5 * max(scale, 1.0))
+    np.testing.assert_allclose(DG.cpu().double(), gr.grad, rtol=2e-5, atol=2e-5 * float(gr.grad.abs().max()))
+    np.testing.assert_allclose(DB.cpu().double(), br.grad, rtol=2e-5, atol=2e-5 * float(br.grad.abs().max()))
+    if pad:                                              # the padding columns of the pitched maps stay untouched
+        assert float(Y.cpu()[:, :, ch:].abs().max()) == 0.0 and float(DX.cpu()[:, :, ch:].abs().max()) == 0.0
