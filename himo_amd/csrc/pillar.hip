@@ -335,6 +335,7 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarBatch m) {
 struct PillarBwdArgs {
     GridSpec g;
     const int* cell_count; const int* block_sum; const int* order2;
+    const float4* cell_rec;                     // (x, y, z, index) grouped by cell, scatter order (PillarArgs::cell_rec)
     const float* xyz_t;
     const float* pfn_w; const float* pfn_scale; const float* pfn_shift;
     const float* d_image; int image_pitch;      // gradient w.r.t. this sweep's 32 image channels
@@ -351,55 +352,7 @@ __device__ inline int cell_offset_b(const PillarBwdArgs& a, int cell) {
                            : a.cell_count[cell] + a.block_sum[cell / kScanBlock];
 }
 
-// d loss / d pfn.weight[k][c] = sum over points of f_k * (d_image[cell][c] / cnt) * [v > 0] * scale[c]
-__global__ __launch_bounds__(256) void pfn_backward_kernel(PillarBwdArgs a) {
-    __shared__ float red[kCellsPerBlock][9][32];
-    const int sub = threadIdx.x >> 5, c = threadIdx.x & 31;
-    const int n_cells = a.g.W * a.g.H;
-    float w[9], dw[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { w[k] = a.pfn_w[k * 32 + c]; dw[k] = 0.f; }
-    const float scale = a.pfn_scale[c], shift = a.pfn_shift[c];
-    for (int cell = blockIdx.x * kCellsPerBlock + sub; cell < n_cells; cell += gridDim.x * kCellsPerBlock) {
-        const int beg = cell_offset_b(a, cell);
-        const int cnt = cell_offset_b(a, cell + 1) - beg;
-        if (cnt == 0) continue;
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        for (int j = 0; j < cnt; ++j) {
-            const float* p = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
-            sx += p[0]; sy += p[1]; sz += p[2];
-        }
-        const float fc = (float)cnt;
-        const float mx = sx / fc, my = sy / fc, mz = sz / fc;
-        const int iy = cell / a.g.W, ix = cell - iy * a.g.W;
-        const float ccx = (float)ix * a.g.vx + a.g.cx0, ccy = (float)iy * a.g.vy + a.g.cy0, ccz = 0.f * a.g.vz + a.g.cz0;
-        const float g = a.d_image[(int64_t)cell * a.image_pitch + c] / fc * scale;
-        for (int j = 0; j < cnt; ++j) {
-            const float* p = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
-            const float x = p[0], y = p[1], z = p[2];
-            const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
-            float v = f[0] * w[0];
-#pragma unroll
-            for (int k = 1; k < 9; ++k) v = fmaf(f[k], w[k], v);
-            v = v * scale + shift;
-            if (v > 0.f) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) dw[k] += f[k] * g;
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) red[sub][k][c] = dw[k];
-    __syncthreads();
-    for (int e = threadIdx.x; e < 9 * 32; e += 256) {
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < kCellsPerBlock; ++q) t += red[q][e / 32][e % 32];
-        a.partial[(int64_t)blockIdx.x * 288 + e] = t;
-    }
-}
-
-// one block per feature k: 8 groups x 32 channels, each group sums every 8th partial, fixed-order combine
+// one block per feature k: 32 groups x 32 channels, each group sums every 32nd partial, fixed-order combine
 __global__ __launch_bounds__(1024) void pfn_backward_reduce_kernel(const float* __restrict__ partial, int n_blocks, float* __restrict__ dw,
                                                                    int accumulate) {
     __shared__ float sh[32][32];
@@ -434,55 +387,127 @@ struct PfnBnArgs {
     const float* coef;               // [2][32]: mean(g), mean(g * xhat) (backward, pass B)
 };
 
-template <int MODE>                  // 0: statistics of y; 1: sums of g and g * xhat (g = d_image / cnt * [v > 0])
-__global__ __launch_bounds__(256) void pfn_bn_reduce_kernel(PfnBnArgs p) {
+// ONE walk over the sweep's cell lists serves the four per-point reductions of the training step (KIND):
+//   0  statistics of y (float64 sum, sum of squares)                         -> p.partial [block][2][32]
+//   1  sums of g and g * xhat, g = d_image / cnt * [v > 0]                   -> p.partial
+//   2  weight gradient with batch statistics: dy = scale * (g - mean(g) - xhat * mean(g xhat)) for EVERY in-range point (the two
+//      mean terms reach the points the ReLU masked as well), dW[k][c] = sum f_k dy            -> a.partial [block][9][32]
+//   3  weight gradient with frozen statistics: dW[k][c] = sum f_k * g * scale                 -> a.partial
+// A block takes 256 consecutive cells at a time: their offsets are fetched by one load per thread and the non-empty ones compacted
+// into a list (ascending) that the eight half-waves (32 lanes = 32 channels) work through -- most cells are empty, and walking them
+// one dependent load chain at a time made each of these kernels 60-75 us per sweep.  A cell's points are taken in ascending point
+// order (order2, written by the forward pass), 32 per gather, and broadcast by shuffle: the per-cell sums have the forward's order;
+// no float atomics anywhere.
+template <int KIND>
+__global__ __launch_bounds__(256) void pfn_walk_kernel(PfnBnArgs p) {
     const PillarBwdArgs& a = p.b;
-    __shared__ double red[2][kCellsPerBlock][32];
-    const int sub = threadIdx.x >> 5, c = threadIdx.x & 31;
+    constexpr int kChunk = 256;
+    __shared__ int s_beg[kChunk + 1];
+    __shared__ int s_list[kChunk];
+    __shared__ int s_wn[4];
+    constexpr bool kStats = KIND < 2;
+    __shared__ double red_d[kStats ? 2 : 1][kStats ? kCellsPerBlock : 1][32];
+    __shared__ float red_f[kStats ? 1 : kCellsPerBlock][kStats ? 1 : 9][32];
+    const int sub = threadIdx.x >> 5, c = threadIdx.x & 31, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n_cells = a.g.W * a.g.H;
-    float w[9];
+    float w[9], dw[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w[k] = a.pfn_w[k * 32 + c];
-    const float scale = MODE ? a.pfn_scale[c] : 0.f, shift = MODE ? a.pfn_shift[c] : 0.f;
-    const float mean = MODE ? p.mean[c] : 0.f, invstd = MODE ? p.invstd[c] : 0.f;
+    for (int k = 0; k < 9; ++k) { w[k] = a.pfn_w[k * 32 + c]; dw[k] = 0.f; }
+    const float scale = KIND ? a.pfn_scale[c] : 0.f, shift = KIND ? a.pfn_shift[c] : 0.f;
+    const float mean = (KIND == 1 || KIND == 2) ? p.mean[c] : 0.f, invstd = (KIND == 1 || KIND == 2) ? p.invstd[c] : 0.f;
+    const float k2 = KIND == 2 ? p.coef[c] : 0.f, k3 = KIND == 2 ? p.coef[32 + c] : 0.f;
     double s0 = 0.0, s1 = 0.0;
-    for (int cell = blockIdx.x * kCellsPerBlock + sub; cell < n_cells; cell += gridDim.x * kCellsPerBlock) {
-        const int beg = cell_offset_b(a, cell);
-        const int cnt = cell_offset_b(a, cell + 1) - beg;
-        if (cnt == 0) continue;
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        for (int j = 0; j < cnt; ++j) {
-            const float* q = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
-            sx += q[0]; sy += q[1]; sz += q[2];
-        }
-        const float fc = (float)cnt;
-        const float mx = sx / fc, my = sy / fc, mz = sz / fc;
-        const int iy = cell / a.g.W, ix = cell - iy * a.g.W;
-        const float ccx = (float)ix * a.g.vx + a.g.cx0, ccy = (float)iy * a.g.vy + a.g.cy0, ccz = 0.f * a.g.vz + a.g.cz0;
-        const float gi = MODE ? a.d_image[(int64_t)cell * a.image_pitch + c] / fc : 0.f;
-        for (int j = 0; j < cnt; ++j) {
-            const float* q = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
-            const float x = q[0], y = q[1], z = q[2];
-            const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
-            float v = f[0] * w[0];
+    for (int cell0 = blockIdx.x * kChunk; cell0 < n_cells; cell0 += gridDim.x * kChunk) {
+        s_beg[threadIdx.x] = cell_offset_b(a, min(cell0 + (int)threadIdx.x, n_cells));
+        if (threadIdx.x == 0) s_beg[kChunk] = cell_offset_b(a, min(cell0 + kChunk, n_cells));
+        __syncthreads();
+        const int my_cnt = cell0 + (int)threadIdx.x < n_cells ? s_beg[threadIdx.x + 1] - s_beg[threadIdx.x] : 0;
+        const unsigned long long occ = __ballot(my_cnt > 0);
+        if (lane == 0) s_wn[wv] = __popcll(occ);
+        __syncthreads();
+        int base = 0, nlist = 0;
 #pragma unroll
-            for (int k = 1; k < 9; ++k) v = fmaf(f[k], w[k], v);
-            if (MODE == 0) {
-                s0 += v; s1 += (double)v * v;
-            } else {
-                const float g = (v * scale + shift) > 0.f ? gi : 0.f;
-                s0 += g; s1 += (double)g * ((v - mean) * invstd);
+        for (int u = 0; u < 4; ++u) { if (u < wv) base += s_wn[u]; nlist += s_wn[u]; }
+        if (my_cnt > 0) s_list[base + __popcll(occ & ((1ull << lane) - 1ull))] = threadIdx.x;
+        __syncthreads();
+        for (int k = sub; k < nlist; k += kCellsPerBlock) {
+            const int lc = s_list[k];
+            const int cell = cell0 + lc;
+            const int beg = s_beg[lc], cnt = s_beg[lc + 1] - beg;
+            const float fc = (float)cnt;
+            const float gi = KIND ? a.d_image[(int64_t)cell * a.image_pitch + c] / fc : 0.f;
+            const int iy = cell / a.g.W, ix = cell - iy * a.g.W;
+            const float ccx = (float)ix * a.g.vx + a.g.cx0, ccy = (float)iy * a.g.vy + a.g.cy0, ccz = 0.f * a.g.vz + a.g.cz0;
+            auto point = [&](float x, float y, float z, float mx, float my, float mz) {
+                const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
+                float v = f[0] * w[0];
+#pragma unroll
+                for (int q = 1; q < 9; ++q) v = fmaf(f[q], w[q], v);
+                if (KIND == 0) {
+                    s0 += v; s1 += (double)v * v;
+                } else if (KIND == 1) {
+                    const float g = (v * scale + shift) > 0.f ? gi : 0.f;
+                    s0 += g; s1 += (double)g * ((v - mean) * invstd);
+                } else if (KIND == 2) {
+                    const float g = (v * scale + shift) > 0.f ? gi : 0.f;
+                    const float dy = scale * ((g - k2) - ((v - mean) * invstd) * k3);
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) dw[q] += f[q] * dy;
+                } else {
+                    if ((v * scale + shift) > 0.f) {
+                        const float g = gi * scale;
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) dw[q] += f[q] * g;
+                    }
+                }
+            };
+            if (cnt == 1) {                      // the mean IS the point (x / 1.0f == x)
+                const float4 rc = a.cell_rec[beg];
+                point(rc.x, rc.y, rc.z, rc.x, rc.y, rc.z);
+                continue;
+            }
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            float ux = 0.f, uy = 0.f, uz = 0.f;
+            for (int j0 = 0; j0 < cnt; j0 += 32) {
+                const bool have = j0 + c < cnt;
+                const float* q = a.xyz_t + (int64_t)(have ? a.order2[beg + j0 + c] : 0) * 3;
+                ux = have ? q[0] : 0.f; uy = have ? q[1] : 0.f; uz = have ? q[2] : 0.f;
+                const int lim = min(32, cnt - j0);
+                for (int j = 0; j < lim; ++j) { sx += shfl32(ux, j); sy += shfl32(uy, j); sz += shfl32(uz, j); }
+            }
+            const float mx = sx / fc, my = sy / fc, mz = sz / fc;
+            for (int j0 = 0; j0 < cnt; j0 += 32) {
+                if (cnt > 32) {                  // (a cell of <= 32 points still holds its only chunk)
+                    const bool have = j0 + c < cnt;
+                    const float* q = a.xyz_t + (int64_t)(have ? a.order2[beg + j0 + c] : 0) * 3;
+                    ux = have ? q[0] : 0.f; uy = have ? q[1] : 0.f; uz = have ? q[2] : 0.f;
+                }
+                const int lim = min(32, cnt - j0);
+                for (int j = 0; j < lim; ++j) point(shfl32(ux, j), shfl32(uy, j), shfl32(uz, j), mx, my, mz);
             }
         }
+        __syncthreads();                         // s_beg / s_list are rewritten by the next chunk
     }
-    red[0][sub][c] = s0; red[1][sub][c] = s1;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int which = threadIdx.x >> 5;
-        double t = red[which][0][c];
+    if (kStats) {
+        red_d[0][sub][c] = s0; red_d[1][sub][c] = s1;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int which = threadIdx.x >> 5;
+            double t = red_d[which][0][c];
 #pragma unroll
-        for (int q = 1; q < kCellsPerBlock; ++q) t += red[which][q][c];
-        p.partial[((int64_t)blockIdx.x * 2 + which) * 32 + c] = t;
+            for (int q = 1; q < kCellsPerBlock; ++q) t += red_d[which][q][c];
+            p.partial[((int64_t)blockIdx.x * 2 + which) * 32 + c] = t;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) red_f[sub][k][c] = dw[k];
+        __syncthreads();
+        for (int e = threadIdx.x; e < 9 * 32; e += 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < kCellsPerBlock; ++q) t += red_f[q][e / 32][e % 32];
+            a.partial[(int64_t)blockIdx.x * 288 + e] = t;
+        }
     }
 }
 
@@ -542,56 +567,6 @@ __global__ __launch_bounds__(1024) void pfn_bn_finalize_kernel(const double* __r
         out1[c] = accumulate ? out1[c] + (float)a0 : (float)a0;      // dbeta  = sum g
         out2[c] = count > 0.0 ? (float)(a0 / count) : 0.f;           // coef[0]: mean g
         out3[c] = count > 0.0 ? (float)(a1 / count) : 0.f;           // coef[1]: mean g xhat
-    }
-}
-
-// weight gradient with batch statistics: dy = scale * (g - mean(g) - xhat * mean(g xhat)) for EVERY in-range point (the two mean
-// terms reach the points the ReLU masked as well), dW[k][c] = sum f_k dy
-__global__ __launch_bounds__(256) void pfn_backward_bn_kernel(PfnBnArgs p) {
-    const PillarBwdArgs& a = p.b;
-    __shared__ float red[kCellsPerBlock][9][32];
-    const int sub = threadIdx.x >> 5, c = threadIdx.x & 31;
-    const int n_cells = a.g.W * a.g.H;
-    float w[9], dw[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { w[k] = a.pfn_w[k * 32 + c]; dw[k] = 0.f; }
-    const float scale = a.pfn_scale[c], shift = a.pfn_shift[c], mean = p.mean[c], invstd = p.invstd[c];
-    const float k2 = p.coef[c], k3 = p.coef[32 + c];
-    for (int cell = blockIdx.x * kCellsPerBlock + sub; cell < n_cells; cell += gridDim.x * kCellsPerBlock) {
-        const int beg = cell_offset_b(a, cell);
-        const int cnt = cell_offset_b(a, cell + 1) - beg;
-        if (cnt == 0) continue;
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        for (int j = 0; j < cnt; ++j) {
-            const float* q = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
-            sx += q[0]; sy += q[1]; sz += q[2];
-        }
-        const float fc = (float)cnt;
-        const float mx = sx / fc, my = sy / fc, mz = sz / fc;
-        const int iy = cell / a.g.W, ix = cell - iy * a.g.W;
-        const float ccx = (float)ix * a.g.vx + a.g.cx0, ccy = (float)iy * a.g.vy + a.g.cy0, ccz = 0.f * a.g.vz + a.g.cz0;
-        const float gi = a.d_image[(int64_t)cell * a.image_pitch + c] / fc;
-        for (int j = 0; j < cnt; ++j) {
-            const float* q = a.xyz_t + (int64_t)a.order2[beg + j] * 3;
-            const float x = q[0], y = q[1], z = q[2];
-            const float f[9] = {x, y, z, x - mx, y - my, z - mz, x - ccx, y - ccy, z - ccz};
-            float v = f[0] * w[0];
-#pragma unroll
-            for (int k = 1; k < 9; ++k) v = fmaf(f[k], w[k], v);
-            const float g = (v * scale + shift) > 0.f ? gi : 0.f;
-            const float dy = scale * ((g - k2) - ((v - mean) * invstd) * k3);
-#pragma unroll
-            for (int k = 0; k < 9; ++k) dw[k] += f[k] * dy;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) red[sub][k][c] = dw[k];
-    __syncthreads();
-    for (int e = threadIdx.x; e < 9 * 32; e += 256) {
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < kCellsPerBlock; ++q) t += red[q][e / 32][e % 32];
-        a.partial[(int64_t)blockIdx.x * 288 + e] = t;
     }
 }
 
@@ -763,6 +738,7 @@ static void carve_bwd(PillarBwdArgs& a, int64_t n, int cells, void* d_workspace)
     char* ws = reinterpret_cast<char*>(d_workspace);
     a.cell_count = reinterpret_cast<const int*>(ws);
     a.block_sum = reinterpret_cast<const int*>(ws + 2 * ws_cells(cells));
+    a.cell_rec = reinterpret_cast<const float4*>(ws + 2 * ws_cells(cells) + ws_blocks(cells));
     a.order2 = reinterpret_cast<const int*>(ws + 2 * ws_cells(cells) + ws_blocks(cells) + 4 * ws_points(n));
 }
 
@@ -791,7 +767,9 @@ extern "C" int himo_pfn_backward(int64_t n, const float* h_voxel, const float* h
     hipStream_t s = (hipStream_t)stream;
     {
         ProfScope ps("pfn_backward_kernel", s);
-        hipLaunchKernelGGL(pfn_backward_kernel, dim3(kPfnBwdBlocks), dim3(256), 0, s, a);
+        PfnBnArgs p{};
+        p.b = a;
+        hipLaunchKernelGGL(pfn_walk_kernel<3>, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
     }
     hipLaunchKernelGGL(pfn_backward_reduce_kernel, dim3(9), dim3(1024), 0, s, a.partial, kPfnBwdBlocks, d_dweight, (flags & 1u) ? 1 : 0);
     HIMO_LAUNCH_CHECK("pfn_backward kernels");
@@ -840,7 +818,7 @@ extern "C" int himo_pfn_bn_stats(int64_t n, const float* h_voxel, const float* h
     if (st != HIMO_OK) return st;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("pfn_bn_stats_kernel", s);
-    hipLaunchKernelGGL(pfn_bn_reduce_kernel<0>, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(pfn_walk_kernel<0>, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
     hipLaunchKernelGGL(pfn_bn_finalize_kernel<0>, dim3(1), dim3(1024), 0, s, p.partial, kPfnBwdBlocks, p.b.cell_count, p.b.block_sum,
                        grid_w * grid_h, d_gamma, d_beta, eps, momentum, d_running_mean, d_running_var, d_scale, d_shift, d_mean, d_invstd, 0);
     HIMO_LAUNCH_CHECK("pfn_bn_stats kernels");
@@ -903,11 +881,11 @@ extern "C" int himo_pfn_backward_bn(int64_t n, const float* h_voxel, const float
     hipStream_t s = (hipStream_t)stream;
     const int acc = (flags & 1u) ? 1 : 0;
     ProfScope ps("pfn_backward_kernel", s);
-    hipLaunchKernelGGL(pfn_bn_reduce_kernel<1>, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(pfn_walk_kernel<1>, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
     hipLaunchKernelGGL(pfn_bn_finalize_kernel<1>, dim3(1), dim3(1024), 0, s, p.partial, kPfnBwdBlocks, p.b.cell_count, p.b.block_sum,
                        grid_w * grid_h, (const float*)nullptr, (const float*)nullptr, 0.f, 0.f, (float*)nullptr, (float*)nullptr, d_dgamma,
                        d_dbeta, coef, coef + 32, acc);
-    hipLaunchKernelGGL(pfn_backward_bn_kernel, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(pfn_walk_kernel<2>, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
     hipLaunchKernelGGL(pfn_backward_reduce_kernel, dim3(9), dim3(1024), 0, s, p.b.partial, kPfnBwdBlocks, d_dweight, acc);
     HIMO_LAUNCH_CHECK("pfn_backward_bn kernels");
     return HIMO_OK;
