@@ -36,6 +36,20 @@ struct GruHeadArgs {
     int iters;
     int img_split;                                      // img0 / img1 rows in the split activation format (convsg.hip)
     unsigned* nonfinite;                                // or NULL: set to 1 when any flow value written is NaN / inf (fp16-range guard)
+    int w2_pitch;                                       // row pitch of w2: 3 (inference) or 4 (the trainer's zero-padded copy)
+};
+
+// TRAINING forward (himo_gru_head_train, SAVE = true): the same kernel also leaves every tensor the backward pass reads -- the GRU
+// operands and gates of each iteration, the decoder's pre-activation -- and writes the network's residual flow [n][4] instead of the
+// final flow.  All buffers have ceil(n / 64) * 64 rows, so no store needs a row guard.
+constexpr int kGhMaxIters = 4;
+struct GruHeadSave {                 // tensors of successive iterations are stacked: element (t, row, c) at base + (t * rows + row) * pitch + c
+    float* hx;                       // [iters + 1][rows][192]  [h_t | x]: the z|r product's operand (hx[iters] feeds the decoder)
+    float* rhx;                      // [iters][rows][192]      [r_t h_t | x]: the q product's operand
+    float* z; float* r; float* q;    // [iters][rows][128]
+    float* pre1; float* y1;          // [rows][32]  decoder pre-activation and its GELU
+    float* res;                      // [rows][4]   Linear(32,3)(y1) for in-range points, zeros otherwise; column 3 = 0
+    int64_t rows;                    // ceil(n / 64) * 64
 };
 
 // several samples in one launch (himo_gru_head_batch): a block finds its sample from the running block counts -- one
@@ -158,9 +172,16 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
 // (Round 3, measured and dropped -- profiles/r03_exp_head_gate_pipelining.txt: the z | r product as two products with the r
 // gate issued slab by slab under the z product's matrix instructions and the z gate under the q product's.  The unrolled slab
 // loop it needs costs 20 spilled registers at the 168 budget; 204-208 us per 120k points against 200.7.)
-template <int FMT, int SLABS>
-__global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_head_kernel(GruHeadArgs a, GruHeadBatch batch) {
+// a saved value: uniform tensor base (scalar registers) + a 32-bit per-lane byte offset -- written as 64-bit pointers per element the
+// compiler hoists ~160 loop-invariant address registers out of the iteration loop and spills them
+__device__ inline void sv_store(float* base, unsigned byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+template <int FMT, int SLABS, bool SAVE = false>
+__global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_head_kernel(GruHeadArgs a, GruHeadBatch batch, GruHeadSave sv) {
     constexpr bool FOLD = SLABS == 9;
+    static_assert(!(SAVE && FOLD), "the training forward keeps x explicit");
     constexpr int kGhPlane = SLABS * kGhRows * 32;
     __shared__ __attribute__((aligned(16))) unsigned char A[FMT * kGhPlane];
     __shared__ int s_pid[kGhRows];
@@ -203,6 +224,11 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
             const int c = q * 16 + k;
             const float v = fmaf(o2, a.w_off[128 + c], fmaf(o1, a.w_off[64 + c], o0 * a.w_off[c])) + a.b_off[c];
             a_store<FMT, SLABS>(A, row, 128 + c, v);
+            if constexpr (SAVE) {                           // x is the same in every operand of every iteration
+                const unsigned at = ((unsigned)i * 192u + 128u + (unsigned)c) * 4u;
+                for (int t = 0; t <= a.iters; ++t) sv_store(sv.hx + t * sv.rows * 192, at, v);
+                for (int t = 0; t < a.iters; ++t) sv_store(sv.rhx + t * sv.rows * 192, at, v);
+            }
         }
     }
     __syncthreads();
@@ -259,9 +285,16 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a_store<FMT, SLABS>(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, h[rt][r]);
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                a_store<FMT, SLABS>(A, row, wave * 32 + li, h[rt][r]);
+                if constexpr (SAVE) sv_store(sv.hx, (((unsigned)r0 + row) * 192u + wave * 32 + li) * 4u, h[rt][r]);
+            }
     }
     __syncthreads();
+    // byte offsets of (row r0 + 4 lh, column 32 wave + li) in a [rows][128] / [rows][192] saved tensor; accumulator element r of row
+    // tile rt sits kGhRowOf(rt, r) rows further
+    unsigned o128 = (((unsigned)r0 + 4 * lh) * 128u + wave * 32 + li) * 4u, o192 = (((unsigned)r0 + 4 * lh) * 192u + wave * 32 + li) * 4u;
 
     const int col_zr[2] = {wave * 32, 128 + wave * 32};
     const int col_q[1] = {wave * 32};
@@ -269,6 +302,11 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
 
 #pragma unroll 1
     for (int it = 0; it < a.iters; ++it) {
+        int sli = li, slh = lh;               // lane coordinates of the gate stages' LDS / global stores
+        if constexpr (SAVE) asm volatile("" : "+v"(o128), "+v"(o192), "+v"(sli), "+v"(slh));      // keep the ~100 per-element addresses out of the loop-invariant set
+        float* const sz = SAVE ? sv.z + it * sv.rows * 128 : nullptr; float* const sr = SAVE ? sv.r + it * sv.rows * 128 : nullptr;
+        float* const sq = SAVE ? sv.q + it * sv.rows * 128 : nullptr; float* const srhx = SAVE ? sv.rhx + it * sv.rows * 192 : nullptr;
+        float* const shx = SAVE ? sv.hx + (it + 1) * sv.rows * 192 : nullptr;
         floatx16 acc[2][2];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -286,9 +324,17 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
             for (int r = 0; r < 16; ++r) {
                 acc[rt][0][r] = sigmoid_f(acc[rt][0][r] + bz);                      // z replaces its accumulator element
                 const float rr = sigmoid_f(acc[rt][1][r] + br);
-                a_store<FMT, SLABS>(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, rr * h[rt][r]);
+                const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * slh;
+                a_store<FMT, SLABS>(A, row, wave * 32 + sli, rr * h[rt][r]);
+                if constexpr (SAVE) {
+                    const unsigned dr = rt * 32 + (r & 3) + 8 * (r >> 2);
+                    sv_store(sz, o128 + dr * 512u, acc[rt][0][r]); sv_store(sr, o128 + dr * 512u, rr);
+                    sv_store(srhx, o192 + dr * 768u, rr * h[rt][r]);
+                }
             }
         __syncthreads();                                        // A = [r*h | x]
+        // (again: the two gate stages address the same elements, and common addresses would stay live across the q product)
+        if constexpr (SAVE) asm volatile("" : "+v"(o128), "+v"(o192), "+v"(sli), "+v"(slh));
         floatx16 acq[2][1];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -306,7 +352,13 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
                 const float zz = acc[rt][0][r];
                 const float hn = (1.0f - zz) * h[rt][r] + zz * q;
                 h[rt][r] = hn;
-                a_store<FMT, SLABS>(A, rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, wave * 32 + li, hn);
+                const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * slh;
+                a_store<FMT, SLABS>(A, row, wave * 32 + sli, hn);
+                if constexpr (SAVE) {
+                    const unsigned dr = rt * 32 + (r & 3) + 8 * (r >> 2);
+                    sv_store(sq, o128 + dr * 512u, q);
+                    sv_store(shx, o192 + dr * 768u, hn);
+                }
             }
         __syncthreads();                                        // A = [h' | x]
     }
@@ -322,9 +374,33 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
     if (wave < 2) {
         const float b1 = a.b1[li];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Y[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = gelu_exact(ac1[0][0][r] + b1);
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float pre = ac1[0][0][r] + b1, y = gelu_exact(pre);
+            Y[row * 32 + li] = y;
+            if constexpr (SAVE) {
+                const unsigned at = (((unsigned)r0 + row) * 32u + li) * 4u;
+                sv_store(sv.pre1, at, pre); sv_store(sv.y1, at, y);
+            }
+        }
     }
     __syncthreads();
+    if constexpr (SAVE) {
+        // residual flow rows [n][4]: Linear(32,3)(y1) for in-range points, zeros for the dropped ones (himo_mask_rows) and in column 3
+        const int row = threadIdx.x >> 2, c = threadIdx.x & 3;
+        const int64_t i = r0 + row;
+        float out = 0.f;
+        if (c < 3 && s_pid[row] >= 0) {
+            const float* y = Y + row * 32;
+            float s = y[0] * a.w2[c];
+#pragma unroll
+            for (int k = 1; k < 32; ++k) s = fmaf(y[k], a.w2[k * a.w2_pitch + c], s);
+            out = s + a.b2[c];
+        }
+        sv.res[i * 4 + c] = out;
+        if (a.nonfinite && !(fabsf(out) <= 3.4028234664e38f)) atomicOr(a.nonfinite, 1u);
+        return;
+    }
     // flow = pose_flow (+ Linear(32,3)(y1) for in-range points): head_final_kernel's arithmetic
     if (threadIdx.x < 3 * kGhRows) {
         const int row = threadIdx.x / 3, c = threadIdx.x % 3;
@@ -336,7 +412,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
                 const float* y = Y + row * 32;
                 float s = y[0] * a.w2[c];
 #pragma unroll
-                for (int k = 1; k < 32; ++k) s = fmaf(y[k], a.w2[k * 3 + c], s);
+                for (int k = 1; k < 32; ++k) s = fmaf(y[k], a.w2[k * a.w2_pitch + c], s);
                 out = pose_flow + (s + a.b2[c]);
             }
             a.flow[i * 3 + c] = out;
@@ -388,15 +464,17 @@ static int gru_head_launch(int n_samples, const himo_head_sample* h_samples, int
     a.w1 = (const unsigned short*)d_w1_packed; a.b1 = d_b1; a.w2 = d_w2; a.b2 = d_b2; a.iters = iters;
     a.img_split = img_split ? 1 : 0;
     a.nonfinite = d_nonfinite;
+    a.w2_pitch = 3;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("gru_head_kernel", s);
     const dim3 grid((unsigned)blocks);
+    const GruHeadSave none{};
     if (folded) {
-        if (packed_format == 1) hipLaunchKernelGGL((gru_head_kernel<2, 9>), grid, dim3(256), 0, s, a, b);
-        else hipLaunchKernelGGL((gru_head_kernel<3, 9>), grid, dim3(256), 0, s, a, b);
+        if (packed_format == 1) hipLaunchKernelGGL((gru_head_kernel<2, 9>), grid, dim3(256), 0, s, a, b, none);
+        else hipLaunchKernelGGL((gru_head_kernel<3, 9>), grid, dim3(256), 0, s, a, b, none);
     } else {
-        if (packed_format == 1) hipLaunchKernelGGL((gru_head_kernel<2, 12>), grid, dim3(256), 0, s, a, b);
-        else hipLaunchKernelGGL((gru_head_kernel<3, 12>), grid, dim3(256), 0, s, a, b);
+        if (packed_format == 1) hipLaunchKernelGGL((gru_head_kernel<2, 12>), grid, dim3(256), 0, s, a, b, none);
+        else hipLaunchKernelGGL((gru_head_kernel<3, 12>), grid, dim3(256), 0, s, a, b, none);
     }
     HIMO_LAUNCH_CHECK("gru_head_kernel");
     return HIMO_OK;
@@ -430,6 +508,48 @@ extern "C" int himo_gru_head_batch_guarded(int n_samples, const himo_head_sample
     if ((d_w_off == nullptr) != (d_b_off == nullptr)) return HIMO_ERR_INVALID_ARGUMENT;
     return gru_head_launch(n_samples, h_samples, img_pitch, dec_pitch, d_w_off, d_b_off, d_w_off == nullptr, d_wzr_packed, d_bzr, d_wq_packed,
                            d_bq, d_w1_packed, d_b1, d_w2, d_b2, iters, packed_format, img_split, d_nonfinite, stream);
+}
+
+// The head's TRAINING forward: one launch = himo_head_gather + the GRU row products with their gate kernels + the decoder of the
+// unfused trainer path (himo_amd/seflow/train.py HeadTrainer.forward), leaving every tensor its backward pass reads.
+extern "C" int himo_gru_head_train(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0, const float* d_img1,
+                                   int img_pitch, const float* d_dec, int dec_pitch, const float* d_w_off, const float* d_b_off,
+                                   const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
+                                   const void* d_w1_packed, const float* d_b1, const float* d_w2, int w2_pitch, const float* d_b2,
+                                   int iters, int packed_format, const himo_head_saved* h_saved, uint32_t* d_nonfinite, void* stream) {
+    if (n < 0 || iters < 1 || iters > kGhMaxIters || !(packed_format == 0 || packed_format == 1) || img_pitch < 32 || dec_pitch < 64 ||
+        !(w2_pitch == 3 || w2_pitch == 4) || !h_saved)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    if (!d_w_off || !d_b_off || !d_wzr_packed || !d_bzr || !d_wq_packed || !d_bq || !d_w1_packed || !d_b1 || !d_w2 || !d_b2)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    if ((reinterpret_cast<uintptr_t>(d_wzr_packed) | reinterpret_cast<uintptr_t>(d_wq_packed) | reinterpret_cast<uintptr_t>(d_w1_packed)) & 15)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    if (n == 0) return HIMO_OK;
+    if (!d_pid || !d_offsets || !d_img0 || !d_img1 || !d_dec) return HIMO_ERR_INVALID_ARGUMENT;
+    if ((n + 63) / 64 * 64 * 768 >= ((int64_t)1 << 32)) return HIMO_ERR_UNSUPPORTED;      // 32-bit byte offsets inside a saved tensor
+    GruHeadSave sv{};
+    sv.hx = h_saved->d_hx; sv.rhx = h_saved->d_rhx; sv.z = h_saved->d_z; sv.r = h_saved->d_r; sv.q = h_saved->d_q;
+    sv.pre1 = h_saved->d_pre1; sv.y1 = h_saved->d_y1; sv.res = h_saved->d_res;
+    sv.rows = (n + 63) / 64 * 64;
+    if (!sv.hx || !sv.rhx || !sv.z || !sv.r || !sv.q || !sv.pre1 || !sv.y1 || !sv.res || h_saved->rows != sv.rows) return HIMO_ERR_INVALID_ARGUMENT;
+    GruHeadBatch b{};
+    b.n_samples = 1;
+    GruHeadSample& g = b.s[0];
+    g.n = n; g.pid = d_pid; g.offsets = d_offsets; g.img0 = d_img0; g.img1 = d_img1; g.dec = d_dec;
+    const int64_t blocks = (n + kGhRows - 1) / kGhRows;
+    if (blocks > 0x7fffffff) return HIMO_ERR_INVALID_ARGUMENT;
+    b.block_start[0] = 0; b.block_start[1] = (int)blocks;
+    GruHeadArgs a{};
+    a.img_pitch = img_pitch; a.dec_pitch = dec_pitch; a.w_off = d_w_off; a.b_off = d_b_off;
+    a.wzr = (const unsigned short*)d_wzr_packed; a.bzr = d_bzr; a.wq = (const unsigned short*)d_wq_packed; a.bq = d_bq;
+    a.w1 = (const unsigned short*)d_w1_packed; a.b1 = d_b1; a.w2 = d_w2; a.b2 = d_b2; a.iters = iters; a.w2_pitch = w2_pitch;
+    a.nonfinite = d_nonfinite;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("gru_head_train_kernel", s);
+    if (packed_format == 1) hipLaunchKernelGGL((gru_head_kernel<2, 12, true>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, sv);
+    else hipLaunchKernelGGL((gru_head_kernel<3, 12, true>), dim3((unsigned)blocks), dim3(256), 0, s, a, b, sv);
+    HIMO_LAUNCH_CHECK("gru_head_kernel<train>");
+    return HIMO_OK;
 }
 
 extern "C" int himo_clear_u32(uint32_t* d_words, int n, void* stream) {

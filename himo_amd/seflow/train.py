@@ -86,6 +86,13 @@ def upsample2x_backward_nhwc(dy: torch.Tensor) -> torch.Tensor:
     return dx
 
 
+class HeadSaved(ctypes.Structure):
+    """himo_head_saved (include/himo_amd.h)"""
+    _fields_ = [("rows", ctypes.c_int64), ("d_hx", ctypes.c_void_p), ("d_rhx", ctypes.c_void_p), ("d_z", ctypes.c_void_p),
+                ("d_r", ctypes.c_void_p), ("d_q", ctypes.c_void_p), ("d_pre1", ctypes.c_void_p), ("d_y1", ctypes.c_void_p),
+                ("d_res", ctypes.c_void_p)]
+
+
 class HeadTrainer:
     """GRU head with saved states.  Parameters (device float32): ``zr.weight`` [192,256], ``zr.bias`` [256], ``q.weight``
     [192,128], ``q.bias`` [128], ``dec1.weight`` [192,32], ``dec1.bias`` [32], ``dec2.weight`` [32,4] (column 3 zero),
@@ -151,11 +158,17 @@ class HeadTrainer:
         dev, T = self.device, spec.GRU_ITERS
         buf = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         self.n = n
-        self.HX = [buf(n, 192) for _ in range(T + 1)]
-        self.RHX = [buf(n, 192) for _ in range(T)]
-        self.Z, self.R, self.Q = ([buf(n, 128) for _ in range(T)] for _ in range(3))
+        # saved states: iterations stacked, rows padded to whole 64-row blocks (the fused forward writes whole blocks:
+        # himo_gru_head_train); the lists are views of the first n rows
+        rows = self.rows = (n + 63) // 64 * 64
+        self._HX, self._RHX = buf(T + 1, rows, 192), buf(T, rows, 192)
+        self._Z, self._R, self._Q = buf(T, rows, 128), buf(T, rows, 128), buf(T, rows, 128)
+        self._PRE1, self._Y1, self._RES = buf(rows, 32), buf(rows, 32), buf(rows, 4)
+        self.HX = [self._HX[t, :n] for t in range(T + 1)]
+        self.RHX = [self._RHX[t, :n] for t in range(T)]
+        self.Z, self.R, self.Q = ([x[t, :n] for t in range(T)] for x in (self._Z, self._R, self._Q))
         self.AZR, self.AQ = buf(n, 256), buf(n, 128)
-        self.PRE1, self.Y1, self.RES = buf(n, 32), buf(n, 32), buf(n, 4)
+        self.PRE1, self.Y1, self.RES = self._PRE1[:n], self._Y1[:n], self._RES[:n]
         self.A1 = buf(n, 32)
         # backward scratch
         self.DY1, self.DHX, self.DRHX = buf(n, 32), buf(n, 192), buf(n, 192)
@@ -205,6 +218,28 @@ class HeadTrainer:
         self._gemm(self.HX[-1], p["dec1.weight"], p["dec1.bias"], self.A1, 192, 32, packed=pk.get("dec1"), fmt=ff or 0)
         _lib.check(lib.himo_affine_gelu_fwd(n, 32, self.A1.data_ptr(), 32, None, None, self.PRE1.data_ptr(), 32, self.Y1.data_ptr(), 32, s()), "gelu_fwd")
         self._gemm(self.Y1, p["dec2.weight"], p["dec2.bias"], self.RES, 32, 4)
+        return self.RES
+
+    def forward_fused(self, n, pid, offsets, img0, img1, img_pitch, dec, dec_pitch, w_off, b_off, nonfinite=None) -> torch.Tensor:
+        """The same forward as ``himo_head_gather`` + ``forward`` + the row mask, as ONE launch (csrc/gruhead.hip with its saves
+        enabled): device addresses of the point's cell ids / offsets, the two 32-channel image groups and the decoder map in;
+        res [n,4] out (zeros for dropped points), every state the backward pass reads saved.  Split precisions only."""
+        if self.fmt_fwd is None:
+            raise ValueError("the fused training forward needs precision 'bf16x3' or 'mixed'")
+        self._reserve(n)
+        if not self.external_pack:
+            for k in self.PK:
+                self._pack(self.p[f"{k}.weight"], self.PK[k], self.fmt_fwd)
+        sv = HeadSaved()
+        sv.rows = self.rows
+        sv.d_hx, sv.d_rhx, sv.d_z, sv.d_r, sv.d_q = (t.data_ptr() for t in (self._HX, self._RHX, self._Z, self._R, self._Q))
+        sv.d_pre1, sv.d_y1, sv.d_res = self._PRE1.data_ptr(), self._Y1.data_ptr(), self._RES.data_ptr()
+        p = self.p
+        _lib.check(self.lib.himo_gru_head_train(n, pid, offsets, img0, img1, img_pitch, dec, dec_pitch, w_off, b_off,
+                                                self.PK["zr"].data_ptr(), p["zr.bias"].data_ptr(), self.PK["q"].data_ptr(), p["q.bias"].data_ptr(),
+                                                self.PK["dec1"].data_ptr(), p["dec1.bias"].data_ptr(), p["dec2.weight"].data_ptr(), 4,
+                                                p["dec2.bias"].data_ptr(), spec.GRU_ITERS, self.fmt_fwd, ctypes.byref(sv),
+                                                None if nonfinite is None else nonfinite.data_ptr(), _lib.stream_handle()), "himo_gru_head_train")
         return self.RES
 
     def _wgrad(self, x, cin, dz, cout, name, accumulate=False):
@@ -257,6 +292,8 @@ class HeadTrainer:
 
 
 _lib.register({
+    "himo_gru_head_train": (c_i, [c_l, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p,
+                                  c_i, c_i, c_p, c_p, c_p]),
     "himo_weight_job_blocks": (c_i, [c_i, c_i, c_i, c_i]),
     "himo_weight_prepare_batch": (c_i, [c_p, c_i, c_i, c_p]),
     "himo_add2d": (c_i, [c_l, c_i, c_p, c_i, c_p, c_i, c_p]),
@@ -626,6 +663,10 @@ class SeFlowTrainer:
         # head: gather -> GRU with saved states
         n0 = pc0.shape[0]
         self.n0 = n0
+        if self.precision != "f32" and n0 > 0:        # gather + GRU + decoder + row mask as one launch, states saved for backward
+            return self.head.forward_fused(n0, net.pid[1].data_ptr(), net.offsets[1].data_ptr(), net.B0.data_ptr() + 4 * 32,
+                                           net.B0.data_ptr() + 4 * 64, 32 * F, net.DEC.data_ptr(), 64,
+                                           self.p["head.offset.weight"].data_ptr(), self.p["head.offset.bias"].data_ptr())
         hx0 = torch.empty((n0, 192), dtype=torch.float32, device=dev)
         rhx = torch.empty((n0, 192), dtype=torch.float32, device=dev)
         _lib.check(lib.himo_head_gather(n0, net.pid[1].data_ptr(), net.offsets[1].data_ptr(), net.B0.data_ptr() + 4 * 32,

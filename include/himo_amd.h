@@ -370,6 +370,25 @@ int himo_gru_head_batch_guarded(int n_samples, const himo_head_sample* h_samples
                                 const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
                                 const void* d_w1_packed, const float* d_b1, const float* d_w2, const float* d_b2,
                                 int iters, int packed_format, int img_split, uint32_t* d_nonfinite, void* stream);
+/* The head's TRAINING forward in one launch (BASELINE config 5; csrc/gruhead.hip with its saves enabled): gather -> `iters` (<= 4) GRU
+ * iterations -> Linear(192,32) + GELU -> Linear(32,3), the explicit-x form of himo_gru_head_batch, writing the network's RESIDUAL flow
+ * d_res [rows][4] (zeros for dropped points and in column 3) and every tensor the backward pass reads.  All saved buffers have
+ * rows = ceil(n / 64) * 64 rows per iteration.  d_w2 is [32][w2_pitch], w2_pitch 3 or 4.  Replaces, in the trainer, himo_head_gather + 2 * iters row
+ * products (himo_conv2d) + 2 * iters gate kernels (himo_gru_gates_fwd) + the decoder.  Spec: himo_amd/seflow/spec.py steps 5-6
+ * (reference model source absent: PARITY UNPINNED). */
+typedef struct himo_head_saved {
+    int64_t rows;              /* ceil(n / 64) * 64: the row count of every buffer below; iterations are stacked */
+    float* d_hx;               /* [iters + 1][rows][192]  [h_t | x], t = 0 .. iters */
+    float* d_rhx;              /* [iters][rows][192]      [r_t h_t | x] */
+    float* d_z; float* d_r; float* d_q;               /* [iters][rows][128] */
+    float* d_pre1; float* d_y1;                       /* [rows][32] */
+    float* d_res;                                     /* [rows][4] */
+} himo_head_saved;
+int himo_gru_head_train(int64_t n, const int32_t* d_pid, const float* d_offsets, const float* d_img0, const float* d_img1,
+                        int img_pitch, const float* d_dec, int dec_pitch, const float* d_w_off, const float* d_b_off,
+                        const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
+                        const void* d_w1_packed, const float* d_b1, const float* d_w2, int w2_pitch, const float* d_b2,
+                        int iters, int packed_format, const himo_head_saved* h_saved, uint32_t* d_nonfinite, void* stream);
 int himo_clear_u32(uint32_t* d_words, int n, void* stream);
 
 /* per-point head glue: hx[i] = [img0[cell], img1[cell], dec[cell], Linear(3,64)(offset)] (192 floats; zeros for

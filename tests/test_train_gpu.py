@@ -382,3 +382,68 @@ def test_batchnorm_training_kernels_match_autograd(gpu, n_img, rows, ch, pad):
     np.testing.assert_allclose(DB.cpu().double(), br.grad, rtol=2e-5, atol=2e-5 * float(br.grad.abs().max()))
     if pad:                                              # the padding columns of the pitched maps stay untouched
         assert float(Y.cpu()[:, :, ch:].abs().max()) == 0.0 and float(DX.cpu()[:, :, ch:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("precision,n", [("mixed", 5000), ("bf16x3", 777), ("mixed", 64)])
+def test_fused_training_head_matches_the_unfused_path(gpu, precision, n):
+    """himo_gru_head_train (one launch) against himo_head_gather + HeadTrainer.forward + the row mask: the residual flow and every
+    saved state of every iteration; then the backward pass from either set of states gives the same gradients."""
+    from himo_amd import _lib
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.train import HeadTrainer
+    lib = _lib.load()
+    params = spec.init_params(3)
+    rng = np.random.default_rng(11)
+    H = W = 32
+    F_ = 3
+    dev = gpu
+    B0 = torch.from_numpy(rng.standard_normal((H * W, 32 * F_)).astype(np.float32)).to(dev)
+    DEC = torch.from_numpy(rng.standard_normal((H * W, 64)).astype(np.float32)).to(dev)
+    pid = rng.integers(0, H * W, n).astype(np.int32)
+    pid[rng.random(n) < 0.1] = -1                                   # dropped points
+    off = (rng.standard_normal((n, 3)) * 0.1).astype(np.float32)
+    off[pid < 0] = 0
+    PID, OFF = torch.from_numpy(pid).to(dev), torch.from_numpy(off).to(dev)
+    w_off = torch.from_numpy(params["head.offset.weight"]).to(dev)
+    b_off = torch.from_numpy(params["head.offset.bias"]).to(dev)
+    s = _lib.stream_handle
+
+    def run(fused):
+        ht = HeadTrainer(params, device=dev, precision=precision)
+        if fused:
+            res = ht.forward_fused(n, PID.data_ptr(), OFF.data_ptr(), B0.data_ptr() + 4 * 32, B0.data_ptr() + 4 * 64, 32 * F_,
+                                   DEC.data_ptr(), 64, w_off.data_ptr(), b_off.data_ptr())
+        else:
+            hx0 = torch.empty((n, 192), dtype=torch.float32, device=dev)
+            rhx = torch.empty((n, 192), dtype=torch.float32, device=dev)
+            _lib.check(lib.himo_head_gather(n, PID.data_ptr(), OFF.data_ptr(), B0.data_ptr() + 4 * 32, B0.data_ptr() + 4 * 64, 32 * F_,
+                                            DEC.data_ptr(), 64, w_off.data_ptr(), b_off.data_ptr(), hx0.data_ptr(), rhx.data_ptr(), 192, s()),
+                       "head_gather")
+            res = ht.forward(hx0)
+            _lib.check(lib.himo_mask_rows(n, 4, PID.data_ptr(), res.data_ptr(), 4, s()), "mask_rows")
+        torch.cuda.synchronize()
+        saved = {"res": res.cpu().numpy().copy(), "pre1": ht.PRE1.cpu().numpy().copy(), "y1": ht.Y1.cpu().numpy().copy()}
+        for t in range(spec.GRU_ITERS):
+            for k, v in (("hx", ht.HX), ("rhx", ht.RHX), ("z", ht.Z), ("r", ht.R), ("q", ht.Q)):
+                saved[f"{k}{t}"] = v[t].cpu().numpy().copy()
+        saved["hxT"] = ht.HX[-1].cpu().numpy().copy()
+        dres = torch.from_numpy(np.random.default_rng(5).standard_normal((n, 4)).astype(np.float32)).to(dev)
+        dres[:, 3] = 0
+        dres[PID < 0] = 0
+        dhx0 = ht.backward(dres)
+        torch.cuda.synchronize()
+        return saved, dhx0.cpu().numpy(), {k: v.cpu().numpy().copy() for k, v in ht.g.items()}
+
+    sa, da, ga = run(False)
+    sb, db, gb = run(True)
+    tol = 3e-5 if precision == "mixed" else 1e-5
+    inr = pid >= 0
+    for k in sa:
+        a, b = sa[k], sb[k]
+        if k in ("pre1", "y1"):                 # the unfused path leaves the dropped rows' decoder values unmasked; res is masked in both
+            a, b = a[inr], b[inr]
+        np.testing.assert_allclose(b, a, rtol=0, atol=tol, err_msg=k)
+    assert np.all(sb["res"][~inr] == 0) and np.all(sb["res"][:, 3] == 0)
+    np.testing.assert_allclose(db, da, rtol=0, atol=2e-4 * max(1.0, float(np.abs(da).max())))
+    for k in ga:
+        np.testing.assert_allclose(gb[k], ga[k], rtol=0, atol=2e-4 * max(1.0, float(np.abs(ga[k]).max())), err_msg=k)
