@@ -174,8 +174,12 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
 // loop it needs costs 20 spilled registers at the 168 budget; 204-208 us per 120k points against 200.7.)
 // a saved value: uniform tensor base (scalar registers) + a 32-bit per-lane byte offset -- written as 64-bit pointers per element the
 // compiler hoists ~160 loop-invariant address registers out of the iteration loop and spills them
+#ifndef HIMO_EXP_SVMASK                  // experiment: bit k = keep the saves of group k (0 x, 1 h0, 2 z r, 3 r h, 4 q, 5 h', 6 decoder)
+#define HIMO_EXP_SVMASK 0xff
+#endif
+template <int GROUP>
 __device__ inline void sv_store(float* base, unsigned byte_off, float v) {
-    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+    if ((HIMO_EXP_SVMASK >> GROUP) & 1) *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
 template <int FMT, int SLABS, bool SAVE = false>
@@ -213,6 +217,24 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) a_store<FMT, SLABS>(A, row, 128 + q * 4 + k, v[k]);
+    } else if constexpr (SAVE) {
+        // x = Linear(3,64)(offset to the pillar centre), also copied into every saved operand: thread -> (column, every 4th row), so a
+        // wave's stores cover one row's 64 columns = 256 contiguous bytes (in the 16-columns-per-thread arrangement below a store
+        // instruction touched 64 separate 64-byte segments and the copies cost 670 us per 120k points)
+        const int c = threadIdx.x & 63;
+        const float w0 = a.w_off[c], w1 = a.w_off[64 + c], w2 = a.w_off[128 + c], bc = a.b_off[c];
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            const int row = wave + 4 * j;                   // wave-uniform: the offsets arrive by scalar loads
+            const int64_t i = r0 + row;
+            const int64_t ic = i < a.n ? i : a.n - 1;       // (padding rows repeat the last point: their values are never read)
+            const float o0 = a.offsets[ic * 3], o1 = a.offsets[ic * 3 + 1], o2 = a.offsets[ic * 3 + 2];
+            const float v = fmaf(o2, w2, fmaf(o1, w1, o0 * w0)) + bc;
+            a_store<FMT, SLABS>(A, row, 128 + c, v);
+            const unsigned at = ((unsigned)i * 192u + 128u + (unsigned)c) * 4u;
+            for (int t = 0; t <= a.iters; ++t) sv_store<0>(sv.hx + t * sv.rows * 192, at, v);
+            for (int t = 0; t < a.iters; ++t) sv_store<0>(sv.rhx + t * sv.rows * 192, at, v);
+        }
     } else {
         // x = Linear(3,64)(offset to the pillar centre): thread -> (row, 16-column slab), columns 128 + 16 q ..
         const int row = threadIdx.x >> 2, q = threadIdx.x & 3;
@@ -224,11 +246,6 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
             const int c = q * 16 + k;
             const float v = fmaf(o2, a.w_off[128 + c], fmaf(o1, a.w_off[64 + c], o0 * a.w_off[c])) + a.b_off[c];
             a_store<FMT, SLABS>(A, row, 128 + c, v);
-            if constexpr (SAVE) {                           // x is the same in every operand of every iteration
-                const unsigned at = ((unsigned)i * 192u + 128u + (unsigned)c) * 4u;
-                for (int t = 0; t <= a.iters; ++t) sv_store(sv.hx + t * sv.rows * 192, at, v);
-                for (int t = 0; t < a.iters; ++t) sv_store(sv.rhx + t * sv.rows * 192, at, v);
-            }
         }
     }
     __syncthreads();
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 a_store<FMT, SLABS>(A, row, wave * 32 + li, h[rt][r]);
-                if constexpr (SAVE) sv_store(sv.hx, (((unsigned)r0 + row) * 192u + wave * 32 + li) * 4u, h[rt][r]);
+                if constexpr (SAVE) sv_store<1>(sv.hx, (((unsigned)r0 + row) * 192u + wave * 32 + li) * 4u, h[rt][r]);
             }
     }
     __syncthreads();
@@ -328,8 +345,8 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
                 a_store<FMT, SLABS>(A, row, wave * 32 + sli, rr * h[rt][r]);
                 if constexpr (SAVE) {
                     const unsigned dr = rt * 32 + (r & 3) + 8 * (r >> 2);
-                    sv_store(sz, o128 + dr * 512u, acc[rt][0][r]); sv_store(sr, o128 + dr * 512u, rr);
-                    sv_store(srhx, o192 + dr * 768u, rr * h[rt][r]);
+                    sv_store<2>(sz, o128 + dr * 512u, acc[rt][0][r]); sv_store<2>(sr, o128 + dr * 512u, rr);
+                    sv_store<3>(srhx, o192 + dr * 768u, rr * h[rt][r]);
                 }
             }
         __syncthreads();                                        // A = [r*h | x]
@@ -356,8 +373,8 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
                 a_store<FMT, SLABS>(A, row, wave * 32 + sli, hn);
                 if constexpr (SAVE) {
                     const unsigned dr = rt * 32 + (r & 3) + 8 * (r >> 2);
-                    sv_store(sq, o128 + dr * 512u, q);
-                    sv_store(shx, o192 + dr * 768u, hn);
+                    sv_store<4>(sq, o128 + dr * 512u, q);
+                    sv_store<5>(shx, o192 + dr * 768u, hn);
                 }
             }
         __syncthreads();                                        // A = [h' | x]
@@ -380,7 +397,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
             Y[row * 32 + li] = y;
             if constexpr (SAVE) {
                 const unsigned at = (((unsigned)r0 + row) * 32u + li) * 4u;
-                sv_store(sv.pre1, at, pre); sv_store(sv.y1, at, y);
+                sv_store<6>(sv.pre1, at, pre); sv_store<6>(sv.y1, at, y);
             }
         }
     }
