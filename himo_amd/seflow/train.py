@@ -140,6 +140,8 @@ class HeadTrainer:
         self.PKT = {k: pk(*self.p[f"{k}.weight"].shape[::-1]) for k in ("zr", "q", "dec1")} if self.fmt_bwd is not None else {}
         # True: the owner refreshes PK / PKT itself after every parameter update (SeFlowTrainer: one launch for the whole network)
         self.external_pack = False
+        self.fused_backward = True     # split precisions: the GRU iterations' backward sweep as one kernel (False: three element-wise
+                                       # kernels around two row products per iteration -- kept as the statement the fused sweep is tested against)
 
     def weight_jobs(self):
         """(weight, ksize, cin, cout, format, flip, destination) per packed copy, for himo_weight_prepare_batch"""
@@ -161,8 +163,9 @@ class HeadTrainer:
         # saved states: iterations stacked, rows padded to whole 64-row blocks (the fused forward writes whole blocks:
         # himo_gru_head_train); the lists are views of the first n rows
         rows = self.rows = (n + 63) // 64 * 64
-        self._HX, self._RHX = buf(T + 1, rows, 192), buf(T, rows, 192)
-        self._Z, self._R, self._Q = buf(T, rows, 128), buf(T, rows, 128), buf(T, rows, 128)
+        zbuf = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)      # (the unfused forward never writes the padding rows)
+        self._HX, self._RHX = zbuf(T + 1, rows, 192), zbuf(T, rows, 192)
+        self._Z, self._R, self._Q = zbuf(T, rows, 128), zbuf(T, rows, 128), zbuf(T, rows, 128)
         self._PRE1, self._Y1, self._RES = buf(rows, 32), buf(rows, 32), buf(rows, 4)
         self.HX = [self._HX[t, :n] for t in range(T + 1)]
         self.RHX = [self._RHX[t, :n] for t in range(T)]
@@ -170,11 +173,13 @@ class HeadTrainer:
         self.AZR, self.AQ = buf(n, 256), buf(n, 128)
         self.PRE1, self.Y1, self.RES = self._PRE1[:n], self._Y1[:n], self._RES[:n]
         self.A1 = buf(n, 32)
-        # backward scratch
-        self.DY1, self.DHX, self.DRHX = buf(n, 32), buf(n, 192), buf(n, 192)
+        # backward scratch (the fused sweep's buffers are padded like the saved states; zeros in the padding of its input)
+        self._DHX = torch.zeros((rows, 192), dtype=torch.float32, device=dev)
+        self._DAQ, self._DAZR, self._DHX0 = buf(T, rows, 128), buf(T, rows, 256), buf(rows, 192)
+        self.DY1, self.DHX, self.DRHX = buf(n, 32), self._DHX[:n], buf(n, 192)
         self.DH, self.DHP, self.DZ, self.DAQ, self.DAZR = buf(n, 128), buf(n, 128), buf(n, 128), buf(n, 128), buf(n, 256)
         self.DX = buf(n, 64)
-        need = int(self.lib.himo_wgrad_workspace_bytes_ex(n, 192, 256))
+        need = int(self.lib.himo_wgrad_workspace_bytes_ex(T * rows, 192, 256))
         self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
 
     def _pack(self, w, buf, fmt):
@@ -230,10 +235,7 @@ class HeadTrainer:
         if not self.external_pack:
             for k in self.PK:
                 self._pack(self.p[f"{k}.weight"], self.PK[k], self.fmt_fwd)
-        sv = HeadSaved()
-        sv.rows = self.rows
-        sv.d_hx, sv.d_rhx, sv.d_z, sv.d_r, sv.d_q = (t.data_ptr() for t in (self._HX, self._RHX, self._Z, self._R, self._Q))
-        sv.d_pre1, sv.d_y1, sv.d_res = self._PRE1.data_ptr(), self._Y1.data_ptr(), self._RES.data_ptr()
+        sv = self._saved()
         p = self.p
         _lib.check(self.lib.himo_gru_head_train(n, pid, offsets, img0, img1, img_pitch, dec, dec_pitch, w_off, b_off,
                                                 self.PK["zr"].data_ptr(), p["zr.bias"].data_ptr(), self.PK["q"].data_ptr(), p["q.bias"].data_ptr(),
@@ -241,6 +243,31 @@ class HeadTrainer:
                                                 p["dec2.bias"].data_ptr(), spec.GRU_ITERS, self.fmt_fwd, ctypes.byref(sv),
                                                 None if nonfinite is None else nonfinite.data_ptr(), _lib.stream_handle()), "himo_gru_head_train")
         return self.RES
+
+    def _backward_fused(self) -> torch.Tensor:
+        """The GRU iterations' backward sweep as one launch (csrc/gruheadbwd.hip) + ONE weight-gradient product per matrix over the
+        stacked iterations (rows of all T iterations; the sweep leaves zeros in the padding rows of the gate gradients)."""
+        T, n = spec.GRU_ITERS, self.n
+        sv = self._saved()
+        if not self.external_pack:
+            for k in ("q", "zr"):
+                self._transposed_packed(k)
+        _lib.check(self.lib.himo_gru_head_backward(n, T, self._DHX.data_ptr(), ctypes.byref(sv), self.PKT["q"].data_ptr(),
+                                                   self.PKT["zr"].data_ptr(), self.fmt_bwd, self._DAQ.data_ptr(), self._DAZR.data_ptr(),
+                                                   self._DHX0.data_ptr(), _lib.stream_handle()), "himo_gru_head_backward")
+        rows = T * self.rows
+        for name, x, dz, cout in (("q", self._RHX, self._DAQ, 128), ("zr", self._HX, self._DAZR, 256)):
+            _lib.check(self.lib.himo_linear_wgrad_ex(rows, x.data_ptr(), 192, 192, dz.data_ptr(), cout, cout, self.g[f"{name}.weight"].data_ptr(),
+                                                     self.g[f"{name}.bias"].data_ptr(), self.wgrad_flags, self.ws.data_ptr(), self.ws.numel(),
+                                                     _lib.stream_handle()), "wgrad")
+        return self._DHX0[:n]
+
+    def _saved(self):
+        sv = HeadSaved()
+        sv.rows = self.rows
+        sv.d_hx, sv.d_rhx, sv.d_z, sv.d_r, sv.d_q = (t.data_ptr() for t in (self._HX, self._RHX, self._Z, self._R, self._Q))
+        sv.d_pre1, sv.d_y1, sv.d_res = self._PRE1.data_ptr(), self._Y1.data_ptr(), self._RES.data_ptr()
+        return sv
 
     def _wgrad(self, x, cin, dz, cout, name, accumulate=False):
         _lib.check(self.lib.himo_linear_wgrad_ex(x.shape[0], x.data_ptr(), x.shape[1], cin, dz.data_ptr(), dz.shape[1], cout,
@@ -270,6 +297,8 @@ class HeadTrainer:
         self._wgrad(self.HX[-1], 192, self.DY1, 32, "dec1")
         w1_t, w1_p = self._transposed_packed("dec1")
         self._gemm(self.DY1, w1_t, None, self.DHX, 32, 192, packed=w1_p, fmt=self.fmt_bwd or 0)
+        if self.fmt_bwd is not None and self.fused_backward:
+            return self._backward_fused()
         # split d[h | x] of the last state
         self.DH.copy_(self.DHX[:, :128])
         self.DX.copy_(self.DHX[:, 128:])
@@ -294,6 +323,7 @@ class HeadTrainer:
 _lib.register({
     "himo_gru_head_train": (c_i, [c_l, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p,
                                   c_i, c_i, c_p, c_p, c_p]),
+    "himo_gru_head_backward": (c_i, [c_l, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
     "himo_weight_job_blocks": (c_i, [c_i, c_i, c_i, c_i]),
     "himo_weight_prepare_batch": (c_i, [c_p, c_i, c_i, c_p]),
     "himo_add2d": (c_i, [c_l, c_i, c_p, c_i, c_p, c_i, c_p]),

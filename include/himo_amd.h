@@ -389,6 +389,15 @@ int himo_gru_head_train(int64_t n, const int32_t* d_pid, const float* d_offsets,
                         const void* d_wzr_packed, const float* d_bzr, const void* d_wq_packed, const float* d_bq,
                         const void* d_w1_packed, const float* d_b1, const float* d_w2, int w2_pitch, const float* d_b2,
                         int iters, int packed_format, const himo_head_saved* h_saved, uint32_t* d_nonfinite, void* stream);
+/* Backpropagation through the head's GRU iterations in one launch (csrc/gruheadbwd.hip): d_dhx_last [rows][192] = d loss / d [h_T | x]
+ * (from the decoder's backward) and the states himo_gru_head_train saved -> d_daq [iters][rows][128], d_dazr [iters][rows][256] (the gate
+ * pre-activation gradients: the dz operands of the q / z|r weight-gradient products, zero in the padding rows) and d_dhx0 [rows][192] =
+ * d loss / d [h_0 | x].  rows = h_saved->rows = ceil(n / 64) * 64 for every buffer.  d_wq_t_packed / d_wzr_t_packed =
+ * himo_weight_prepare_batch's flipped copies (ksize 1: the transposes) of q [192][128] and zr [192][256], packed_format
+ * HIMO_PACK_BF16X3 or HIMO_PACK_BF16X2.  Replaces gru_bwd1/2/3 + two himo_conv2d row products per iteration. */
+int himo_gru_head_backward(int64_t n, int iters, const float* d_dhx_last, const himo_head_saved* h_saved,
+                           const void* d_wq_t_packed, const void* d_wzr_t_packed, int packed_format, float* d_daq,
+                           float* d_dazr, float* d_dhx0, void* stream);
 int himo_clear_u32(uint32_t* d_words, int n, void* stream);
 
 /* per-point head glue: hx[i] = [img0[cell], img1[cell], dec[cell], Linear(3,64)(offset)] (192 floats; zeros for

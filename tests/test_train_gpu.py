@@ -387,7 +387,8 @@ def test_batchnorm_training_kernels_match_autograd(gpu, n_img, rows, ch, pad):
 @pytest.mark.parametrize("precision,n", [("mixed", 5000), ("bf16x3", 777), ("mixed", 64)])
 def test_fused_training_head_matches_the_unfused_path(gpu, precision, n):
     """himo_gru_head_train (one launch) against himo_head_gather + HeadTrainer.forward + the row mask: the residual flow and every
-    saved state of every iteration; then the backward pass from either set of states gives the same gradients."""
+    saved state of every iteration; then himo_gru_head_backward (one launch + one weight-gradient product per matrix) against the
+    unfused backward pass: the same d loss / d [h0 | x] and parameter gradients."""
     from himo_amd import _lib
     from himo_amd.seflow import spec
     from himo_amd.seflow.train import HeadTrainer
@@ -410,6 +411,7 @@ def test_fused_training_head_matches_the_unfused_path(gpu, precision, n):
 
     def run(fused):
         ht = HeadTrainer(params, device=dev, precision=precision)
+        ht.fused_backward = fused               # csrc/gruheadbwd.hip against the three element-wise kernels + two row products per iteration
         if fused:
             res = ht.forward_fused(n, PID.data_ptr(), OFF.data_ptr(), B0.data_ptr() + 4 * 32, B0.data_ptr() + 4 * 64, 32 * F_,
                                    DEC.data_ptr(), 64, w_off.data_ptr(), b_off.data_ptr())
