@@ -734,8 +734,8 @@ def train_roofline(args, prof: dict, n_steps: int, elapsed: float):
     workload = ("self-supervised TRAINING step (BASELINE config 5): pillarise 3 sweeps -> network forward with saved "
                 "activations -> 4-term NN/Chamfer loss -> full backward -> flat-gradient all-reduce -> Adam; "
                 f"one {args.points}-point sample per GPU per step; {bn}")
-    dtype = {"mixed": "forward f16x2 (two-term fp16 split); 3x3 data-gradient convolutions and stride-1 3x3 weight gradients two-term bf16 split "
-                      "(16-bit operands, float32 range and sums); 1x1 / head data gradients bf16x3; everything else and the optimiser f32",
+    dtype = {"mixed": "forward f16x2 (two-term fp16 split); every data-gradient product (3x3, 1x1, the head's GRU sweep) and every weight-gradient "
+                      "product two-term bf16 split (16-bit operands, float32 range and sums); everything else and the optimiser f32",
              "bf16x3": "forward + data-gradient convolutions bf16x3 (split bf16, float32-class); weight gradients / optimiser f32",
              "f32": "f32"}[args.train_precision]
     return roofline, workload, dtype

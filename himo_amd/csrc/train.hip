@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tiled_kernel(ConvWgradTiled
 // elements: every (row, ky) reads ONE aligned fragment + the following 32-bit word and forms the three windows in registers
 // (kx = 1: four v_alignbit; kx = 2: a register rename).  Rows are padded to 40 pixels = 80 bytes: consecutive channels sit 20
 // banks apart, so the 16 lanes of a ds_read_b128 phase cover the 64 banks exactly once, and so do the transposed stores.
-// Stride 1 only (the stride-2 layers keep the float32 kernel); same tile, partial layout and reduce kernel as above.
+// This kernel: stride 1 (stride 2: conv_wgrad_split2_kernel below); same tile, partial layout and reduce kernel as above.
 constexpr int kWsPxp = 40;
 
 __device__ inline void split2_bf16_pair(float a, float b, unsigned& hw, unsigned& mw) {
@@ -506,6 +506,131 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(ConvWgradTiled
                     }
                 }
             }
+    }
+    float* out = a.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 * 64 * 64;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            out[t * 4096 + (wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + wn * 32 + li] = acc[t][r];
+}
+
+// STRIDE 2 with split-bf16 operands (himo_conv3x3_wgrad_batch flag 2).  The tap windows of 8 consecutive OUTPUT pixels are every other
+// input pixel, so the halo (3 rows x 65 columns) is staged DE-INTERLEAVED: Xo[..][j] = x[2 (x0 + j) - 1] (j = 0 .. 32) and
+// Xe[..][j] = x[2 (x0 + j)] (j = 0 .. 31); kx = 0 reads Xo[px ..], kx = 1 Xe[px ..], kx = 2 Xo[px + 1 ..] (one v_alignbit per word).
+// One output row x 32 output columns per tile; same block tile, partial layout and reduce kernel as the stride-1 kernel.
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split2_kernel(ConvWgradTiledArgs a) {
+    constexpr int HR = 3;
+    __shared__ __attribute__((aligned(16))) unsigned short Xo[2][HR][64][kWsPxp];
+    __shared__ __attribute__((aligned(16))) unsigned short Xe[2][HR][64][kWsPxp];
+    __shared__ __attribute__((aligned(16))) unsigned short Yt[2][64][kWsPxp];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int co_tiles = a.cout / 64;
+    const int ci0 = ((int)blockIdx.y / co_tiles) * 64, co0 = ((int)blockIdx.y % co_tiles) * 64;
+    const int col_blocks = a.Wo / 32;
+    const int tiles_per_img = col_blocks * a.Ho;
+    const int n_tiles = a.n_img * tiles_per_img;
+    const int t0 = (int)blockIdx.x * a.tiles_per_chunk;
+    const int t1 = min(t0 + a.tiles_per_chunk, n_tiles);
+    const int sc = threadIdx.x & 63, sg = threadIdx.x >> 6;      // staging: this thread's channel, its group of items
+    const bool ci_ok = ci0 + sc < a.cin;                         // a 32-channel input (enc1.0) fills half the tile
+
+    floatx16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // item = (halo row, 16 input pixels) of this thread's channel: 12 items over the 4 thread groups; the 65th column (odd plane,
+    // index 32) of halo row sg is one more load for groups 0 .. 2
+    float vx[3][16], vlast, vy[8];
+    auto fetch = [&](int t) {
+        const int img = t / tiles_per_img;
+        const int rem = t - img * tiles_per_img;
+        const int y0 = rem / col_blocks, x0 = (rem % col_blocks) * 32;
+        const float* xi = a.x + img * a.x_bs + ci0 + (ci_ok ? sc : 0);
+        const float* di = a.dy + img * a.dy_bs + co0 + sc;
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int item = sg + 4 * it, hr = item >> 2, ch = item & 3;
+            const int iy = 2 * y0 - 1 + hr;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int ix = 2 * x0 - 1 + 16 * ch + j;
+                vx[it][j] = (ci_ok && iy >= 0 && ix >= 0) ? xi[((int64_t)iy * a.W + ix) * a.x_pitch] : 0.f;
+            }
+        }
+        {
+            const int iy = 2 * y0 - 1 + sg;
+            vlast = (ci_ok && sg < 3 && iy >= 0) ? xi[((int64_t)iy * a.W + 2 * x0 + 63) * a.x_pitch] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vy[j] = di[((int64_t)y0 * a.Wo + x0 + sg * 8 + j) * a.dy_pitch];
+    };
+    if (t0 < t1) fetch(t0);
+    for (int t = t0; t < t1; ++t) {
+        __syncthreads();                                   // the previous tile's fragment reads are done
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int item = sg + 4 * it, hr = item >> 2, ch = item & 3;
+            uint4 h, m;                                    // j even -> odd input columns, j odd -> even input columns
+            split2_bf16_pair(vx[it][0], vx[it][2], h.x, m.x); split2_bf16_pair(vx[it][4], vx[it][6], h.y, m.y);
+            split2_bf16_pair(vx[it][8], vx[it][10], h.z, m.z); split2_bf16_pair(vx[it][12], vx[it][14], h.w, m.w);
+            *reinterpret_cast<uint4*>(&Xo[0][hr][sc][ch * 8]) = h;
+            *reinterpret_cast<uint4*>(&Xo[1][hr][sc][ch * 8]) = m;
+            split2_bf16_pair(vx[it][1], vx[it][3], h.x, m.x); split2_bf16_pair(vx[it][5], vx[it][7], h.y, m.y);
+            split2_bf16_pair(vx[it][9], vx[it][11], h.z, m.z); split2_bf16_pair(vx[it][13], vx[it][15], h.w, m.w);
+            *reinterpret_cast<uint4*>(&Xe[0][hr][sc][ch * 8]) = h;
+            *reinterpret_cast<uint4*>(&Xe[1][hr][sc][ch * 8]) = m;
+        }
+        if (sg < 3) {
+            unsigned hw, mw;
+            split2_bf16_pair(vlast, 0.f, hw, mw);
+            Xo[0][sg][sc][32] = (unsigned short)hw; Xo[1][sg][sc][32] = (unsigned short)mw;
+        }
+        {
+            uint4 h, m;
+            split2_bf16_pair(vy[0], vy[1], h.x, m.x); split2_bf16_pair(vy[2], vy[3], h.y, m.y);
+            split2_bf16_pair(vy[4], vy[5], h.z, m.z); split2_bf16_pair(vy[6], vy[7], h.w, m.w);
+            *reinterpret_cast<uint4*>(&Yt[0][sc][sg * 8]) = h;
+            *reinterpret_cast<uint4*>(&Yt[1][sc][sg * 8]) = m;
+        }
+        if (t + 1 < t1) fetch(t + 1);
+        __syncthreads();
+#pragma unroll 1
+        for (int s = 0; s < 2; ++s) {
+            const int px = 16 * s + 8 * lh;
+            bf16x8 bfr[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bfr[p] = *reinterpret_cast<const bf16x8*>(&Yt[p][wn * 32 + li][px]);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                uint4 qo[2], qe[2]; unsigned q4[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    qo[p] = *reinterpret_cast<const uint4*>(&Xo[p][ky][wm * 32 + li][px]);
+                    q4[p] = *reinterpret_cast<const unsigned*>(&Xo[p][ky][wm * 32 + li][px + 8]);
+                    qe[p] = *reinterpret_cast<const uint4*>(&Xe[p][ky][wm * 32 + li][px]);
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    bf16x8 af[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        uint4 w = kx == 1 ? qe[p] : qo[p];
+                        if (kx == 2) w = make_uint4(__builtin_amdgcn_alignbit(qo[p].y, qo[p].x, 16), __builtin_amdgcn_alignbit(qo[p].z, qo[p].y, 16),
+                                                    __builtin_amdgcn_alignbit(qo[p].w, qo[p].z, 16), __builtin_amdgcn_alignbit(q4[p], qo[p].w, 16));
+                        af[p] = __builtin_bit_cast(bf16x8, w);
+                    }
+                    floatx16& c = acc[ky * 3 + kx];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bfr[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bfr[0], c, 0, 0, 0);
+                }
+            }
+        }
     }
     float* out = a.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 * 64 * 64;
 #pragma unroll
@@ -756,6 +881,7 @@ extern "C" int himo_conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_b
     {
         ProfScope ps("conv_wgrad_tiled_kernel", s);
         if (stride == 1 && (flags & 2u)) hipLaunchKernelGGL(conv_wgrad_split_kernel, dim3(grid_x, tiles_xy), dim3(256), 0, s, a);
+        else if (flags & 2u) hipLaunchKernelGGL(conv_wgrad_split2_kernel, dim3(grid_x, tiles_xy), dim3(256), 0, s, a);
         else if (stride == 1) hipLaunchKernelGGL(conv_wgrad_tiled_kernel<1>, dim3(grid_x, tiles_xy), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(conv_wgrad_tiled_kernel<2>, dim3(grid_x, tiles_xy), dim3(256), 0, s, a);
     }

@@ -424,8 +424,8 @@ class SeFlowTrainer:
         self.precision = precision
         self.bn_batch = batchnorm == "batch"
         self.fwd_format = 1 if precision == "mixed" else 0          # HIMO_PACK_F16X2 / HIMO_PACK_BF16X3
-        # mixed: the stride-1 3x3 weight gradients multiply split-bf16 operands (16 significant bits, float32 sums) on the
-        # 16-bit matrix instructions (csrc/train.hip conv_wgrad_split_kernel); the other modes keep float32 matrix instructions
+        # mixed: the 3x3 weight gradients multiply split-bf16 operands (16 significant bits, float32 sums) on the 16-bit matrix
+        # instructions (csrc/train.hip conv_wgrad_split_kernel / conv_wgrad_split2_kernel); the other modes keep float32 ones
         self.wgrad_flags = 2 if precision == "mixed" else 0
         # mixed: the data-gradient convolutions (3x3 and 1x1) run the two-term bf16 split (HIMO_PACK_BF16X2: 16 significant bits, float32
         # range, three matrix products per block) instead of the three-term one (six)

@@ -95,8 +95,9 @@ def test_conv3x3_backward_matches_autograd(gpu, stride, h, w, cin, cout, n):
     assert np.abs(db.cpu().numpy() - dy.sum((0, 1, 2))).max() <= 1e-3
 
 
-@pytest.mark.parametrize("h,w,cin,cout,n", [(24, 64, 64, 64, 2), (16, 32, 192, 128, 1), (64, 96, 64, 128, 3), (128, 128, 128, 64, 2)])
-def test_split_bf16_weight_gradient_matches_autograd(gpu, h, w, cin, cout, n):
+@pytest.mark.parametrize("h,w,cin,cout,n,stride", [(24, 64, 64, 64, 2, 1), (16, 32, 192, 128, 1, 1), (64, 96, 64, 128, 3, 1), (128, 128, 128, 64, 2, 1),
+                                                   (32, 64, 32, 64, 3, 2), (16, 128, 64, 128, 2, 2), (64, 192, 128, 256, 1, 2), (2, 64, 32, 64, 1, 2)])
+def test_split_bf16_weight_gradient_matches_autograd(gpu, h, w, cin, cout, n, stride):
     """himo_conv3x3_wgrad_batch with flag 2 (the training default, precision "mixed"): operands x = h + m in bf16 (16 significant
     bits) on the 16-bit matrix instructions, float32 accumulation -- against float64 autograd, and against the float32-MFMA
     kernel of the same entry point.  Image borders, several images and ragged tile runs per block are all in the shapes."""
@@ -104,13 +105,13 @@ def test_split_bf16_weight_gradient_matches_autograd(gpu, h, w, cin, cout, n):
     rng = np.random.default_rng(h + cin)
     x = (rng.normal(size=(n, h, w, cin)) * rng.uniform(0.1, 3.0, size=(1, 1, 1, cin))).astype(np.float32)
     wt = (rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
-    dy = (rng.normal(size=(n, h, w, cout)) * 10.0 ** rng.uniform(-6, 0, size=(1, 1, 1, cout))).astype(np.float32)   # gradients span decades
+    dy = (rng.normal(size=(n, h // stride, w // stride, cout)) * 10.0 ** rng.uniform(-6, 0, size=(1, 1, 1, cout))).astype(np.float32)   # gradients span decades
     args = [torch.from_numpy(a).to(gpu) for a in (x, wt, dy)]
-    _, dw_split, _ = conv3x3_backward_nhwc(*args, 1, wgrad_flags=2)
-    _, dw_f32, _ = conv3x3_backward_nhwc(*args, 1, wgrad_flags=0)
+    _, dw_split, _ = conv3x3_backward_nhwc(*args, stride, wgrad_flags=2)       # stride 2: the de-interleaved halo (conv_wgrad_split2_kernel)
+    _, dw_f32, _ = conv3x3_backward_nhwc(*args, stride, wgrad_flags=0)
     tx = torch.from_numpy(x).permute(0, 3, 1, 2).double()
     tw = torch.from_numpy(wt).permute(3, 2, 0, 1).double().requires_grad_(True)
-    (F.conv2d(tx, tw, None, padding=1) * torch.from_numpy(dy).permute(0, 3, 1, 2).double()).sum().backward()
+    (F.conv2d(tx, tw, None, stride=stride, padding=1) * torch.from_numpy(dy).permute(0, 3, 1, 2).double()).sum().backward()
     ref = tw.grad.permute(2, 3, 1, 0).numpy()
     # per output channel (the columns' scales differ by six decades): error against that channel's largest gradient
     scale = np.abs(ref).max(axis=(0, 1, 2))
