@@ -296,6 +296,7 @@ struct ConvWgradTiledArgs {
     int n_img, H, W, Ho, Wo, cin, cout;   // H, W: input image; Ho, Wo: output-gradient image
     int tiles_per_chunk;           // pixel tiles per block
     float* partial;                // [ci_tile][co_tile][chunk][9][64][64]
+    float* db_partial;             // or NULL: [co_tile][chunk][64] column sums of dY (the bias gradient), written by the ci_tile 0 blocks
 };
 
 template <int S> struct WgTile {
@@ -419,6 +420,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(ConvWgradTiled
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // the bias gradient rides along (dY passes through this block's registers anyway): this thread's share of the column sum of
+    // channel co0 + sc lives in LDS between tiles -- as a register it cost 29 spills in a kernel that sits at 256
+    __shared__ float bacc[256];
+    const bool want_db = a.db_partial != nullptr && ci0 == 0;
+    bacc[threadIdx.x] = 0.f;
 
     // a tile's operands travel global -> registers one tile AHEAD (issued before the previous tile's matrix loop, which hides
     // their latency), then registers -> split -> transposed LDS between two barriers
@@ -452,6 +458,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(ConvWgradTiled
     if (t0 < t1) fetch(t0);
     for (int t = t0; t < t1; ++t) {
         __syncthreads();                                   // the previous tile's fragment reads are done
+        if (want_db) {
+            float bs = 0.f;
+#pragma unroll
+            for (int it = 0; it < kYItems; ++it)
+                bs += ((vy[it][0] + vy[it][1]) + (vy[it][2] + vy[it][3])) + ((vy[it][4] + vy[it][5]) + (vy[it][6] + vy[it][7]));
+            bacc[threadIdx.x] += bs;
+        }
 #pragma unroll
         for (int it = 0; it < kXItems; ++it) {
             const int item = sg + 4 * it, hr = item / 5, ch = item % 5;
@@ -506,6 +519,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(ConvWgradTiled
                     }
                 }
             }
+    }
+    if (want_db) {                                         // thread = sg * 64 + sc: the four groups' shares, fixed order
+        __syncthreads();
+        if (threadIdx.x < 64)
+            a.db_partial[((int64_t)(co0 / 64) * gridDim.x + blockIdx.x) * 64 + sc] = (bacc[sc] + bacc[64 + sc]) + (bacc[128 + sc] + bacc[192 + sc]);
     }
     float* out = a.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 9 * 64 * 64;
 #pragma unroll
@@ -638,6 +656,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split2_kernel(ConvWgradTile
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             out[t * 4096 + (wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + wn * 32 + li] = acc[t][r];
+}
+
+// the bias gradient's chunk partials -> db [cout]: block = 64 channels, four thread groups over every fourth chunk, fixed-order combine
+__global__ __launch_bounds__(256) void conv_wgrad_db_reduce_kernel(const float* __restrict__ db_partial, int chunks, float* __restrict__ db,
+                                                                   int accumulate) {
+    __shared__ float sh[4][64];
+    const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const float* p = db_partial + (int64_t)blockIdx.x * chunks * 64 + o;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = grp;
+    for (; b + 12 < chunks; b += 16) { s0 += p[(int64_t)b * 64]; s1 += p[(int64_t)(b + 4) * 64]; s2 += p[(int64_t)(b + 8) * 64]; s3 += p[(int64_t)(b + 12) * 64]; }
+    for (; b < chunks; b += 4) s0 += p[(int64_t)b * 64];
+    sh[grp][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0) {
+        const float t = (sh[0][o] + sh[1][o]) + (sh[2][o] + sh[3][o]);
+        const int c = blockIdx.x * 64 + o;
+        db[c] = accumulate ? db[c] + t : t;
+    }
 }
 
 __global__ __launch_bounds__(256) void conv_wgrad_tiled_reduce_kernel(const float* __restrict__ partial, int chunks, int cin, int cout,
@@ -857,15 +894,38 @@ extern "C" size_t himo_conv_wgrad_batch_workspace_bytes(int n_img, int h, int w,
     if (!wgrad_tiled_ok(h, w, cin, cout, stride)) return 0;
     const int ho = h / stride, wo = w / stride;
     const int n_tiles = n_img * (ho / (stride == 1 ? 2 : 1)) * (wo / 32), tiles_xy = ((cin + 63) / 64) * (cout / 64);
-    return (size_t)tiles_xy * wgrad_tiled_chunks(n_tiles, tiles_xy) * 9 * 4096 * 4 + 64;
+    const size_t chunks = wgrad_tiled_chunks(n_tiles, tiles_xy);
+    return (size_t)tiles_xy * chunks * 9 * 4096 * 4 + (size_t)(cout / 64) * chunks * 64 * 4 + 64;      // weight partials + bias partials
 }
 
 // 3x3 (pad 1) weight gradient over a batch of images (frames), LDS-tiled.  stride 1: h even, w % 32 == 0, cin % 64 == 0;
 // stride 2: h even, w % 64 == 0, cin == 32 or cin % 64 == 0; cout % 64 == 0, pitches % 4 == 0
 // (HIMO_ERR_UNSUPPORTED otherwise: use himo_conv3x3_wgrad)
+static int conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int cin,
+                               const float* d_dy, int64_t dy_batch_stride, int dy_pitch, int cout, int stride, float* d_dw, float* d_db,
+                               unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int himo_conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int cin,
                                         const float* d_dy, int64_t dy_batch_stride, int dy_pitch, int cout, int stride, float* d_dw,
                                         unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
+    return conv3x3_wgrad_batch(n_img, d_x, x_batch_stride, x_pitch, h, w, cin, d_dy, dy_batch_stride, dy_pitch, cout, stride, d_dw, nullptr,
+                               flags, d_workspace, workspace_bytes, stream);
+}
+
+// ... and the bias gradient d_db [cout] = column sums of dY from the same pass over dY (flags bit 0 accumulates it too).  Stride 1 with
+// split-bf16 operands (flags bit 1) only: HIMO_ERR_UNSUPPORTED otherwise (himo_colsum is the stand-alone form).
+extern "C" int himo_conv3x3_wgrad_batch_bias(int n_img, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int cin,
+                                             const float* d_dy, int64_t dy_batch_stride, int dy_pitch, int cout, int stride, float* d_dw,
+                                             float* d_db, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!d_db) return HIMO_ERR_INVALID_ARGUMENT;
+    if (stride != 1 || !(flags & 2u)) return HIMO_ERR_UNSUPPORTED;
+    return conv3x3_wgrad_batch(n_img, d_x, x_batch_stride, x_pitch, h, w, cin, d_dy, dy_batch_stride, dy_pitch, cout, stride, d_dw, d_db,
+                               flags, d_workspace, workspace_bytes, stream);
+}
+
+static int conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int cin,
+                               const float* d_dy, int64_t dy_batch_stride, int dy_pitch, int cout, int stride, float* d_dw, float* d_db,
+                               unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (!d_x || !d_dy || !d_dw || !d_workspace || n_img < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return HIMO_ERR_INVALID_ARGUMENT;
     if (!wgrad_tiled_ok(h, w, cin, cout, stride) || (x_pitch & 3) || (dy_pitch & 3) || (x_batch_stride & 3) || (dy_batch_stride & 3))
         return HIMO_ERR_UNSUPPORTED;
@@ -875,8 +935,9 @@ extern "C" int himo_conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_b
     const int n_tiles = n_img * (ho / (stride == 1 ? 2 : 1)) * (wo / 32), tiles_xy = ((cin + 63) / 64) * (cout / 64);
     const int chunks = wgrad_tiled_chunks(n_tiles, tiles_xy);
     ConvWgradTiledArgs a{d_x, x_batch_stride, x_pitch, d_dy, dy_batch_stride, dy_pitch, n_img, h, w, ho, wo, cin, cout,
-                         (n_tiles + chunks - 1) / chunks, reinterpret_cast<float*>(d_workspace)};
+                         (n_tiles + chunks - 1) / chunks, reinterpret_cast<float*>(d_workspace), nullptr};
     const int grid_x = (n_tiles + a.tiles_per_chunk - 1) / a.tiles_per_chunk;
+    if (d_db) a.db_partial = a.partial + (size_t)tiles_xy * chunks * 9 * 4096;        // behind the weight partials (grid_x <= chunks)
     hipStream_t s = (hipStream_t)stream;
     {
         ProfScope ps("conv_wgrad_tiled_kernel", s);
@@ -887,6 +948,7 @@ extern "C" int himo_conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_b
     }
     hipLaunchKernelGGL(conv_wgrad_tiled_reduce_kernel, dim3((unsigned)((9ll * cin * cout + 63) / 64)), dim3(256), 0, s, a.partial, grid_x,
                        cin, cout, d_dw, (flags & 1u) ? 1 : 0);
+    if (d_db) hipLaunchKernelGGL(conv_wgrad_db_reduce_kernel, dim3(cout / 64), dim3(256), 0, s, a.db_partial, grid_x, d_db, (flags & 1u) ? 1 : 0);
     HIMO_LAUNCH_CHECK("conv_wgrad_tiled kernels");
     return HIMO_OK;
 }

@@ -39,6 +39,7 @@ _lib.register({
     "himo_conv_wgrad_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i, c_i]),
     "himo_conv_wgrad_batch_workspace_bytes": (ctypes.c_size_t, [c_i, c_i, c_i, c_i, c_i, c_i]),
     "himo_conv3x3_wgrad_batch": (c_i, [c_i, c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_i, c_i, c_p, ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
+    "himo_conv3x3_wgrad_batch_bias": (c_i, [c_i, c_p, c_l, c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_i, c_i, c_p, c_p, ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
     "himo_conv3x3_wgrad": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
 })
 
@@ -595,6 +596,18 @@ class SeFlowTrainer:
         _lib.check(self.lib.himo_conv3x3_wgrad(x, x_pitch, h, w, cin, dy, dy_pitch, cout, stride, self.g[gname].data_ptr(),
                                                1 if acc else 0, self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle()), "conv3x3_wgrad")
 
+    def _wgrad3_bias(self, x, x_pitch, h, w, cin, dy, dy_pitch, cout, wname, bname):
+        """stride-1 3x3 weight gradient AND the bias gradient (column sums of dY) of one image: one pass over dY in the split-bf16
+        kernel (mixed precision); the float32 kernels keep the separate column-sum launch"""
+        if self.wgrad_flags & 2:
+            st = self.lib.himo_conv3x3_wgrad_batch_bias(1, x, 0, x_pitch, h, w, cin, dy, 0, dy_pitch, cout, 1, self.g[wname].data_ptr(),
+                                                        self.g[bname].data_ptr(), self.wgrad_flags, self.ws.data_ptr(), self.ws.numel(),
+                                                        _lib.stream_handle())
+            if st == 0:
+                return
+        self._wgrad3(x, x_pitch, h, w, cin, dy, dy_pitch, cout, 1, wname, False)
+        self._colsum(h * w, dy, dy_pitch, cout, bname)
+
     def _colsum(self, rows, z, pitch, cout, gname, acc=False):
         _lib.check(self.lib.himo_colsum(rows, z, pitch, cout, self.g[gname].data_ptr(), 1 if acc else 0, self.ws.data_ptr(),
                                         self.ws.numel(), _lib.stream_handle()), "colsum")
@@ -716,13 +729,11 @@ class SeFlowTrainer:
         P = h2 * w2
         zb = self.zero_bias.data_ptr()
         # u5
-        self._wgrad3(work0.data_ptr(), out, h2, w2, out, d_out, out, out, 1, f"{name}.u5.weight", False)
-        self._colsum(P, d_out, out, out, f"{name}.u5.bias")
+        self._wgrad3_bias(work0.data_ptr(), out, h2, w2, out, d_out, out, out, f"{name}.u5.weight", f"{name}.u5.bias")
         wf, wp = self._flip(f"{name}.u5", 3, out, out)
         self._conv(d_out, 0, out, wf, zb, d_in, 0, out, 1, h2, w2, out, out, 3, packed=wp)
         # u4
-        self._wgrad3(cat.data_ptr(), 2 * lat, h2, w2, 2 * lat, d_in, out, out, 1, f"{name}.u4.weight", False)
-        self._colsum(P, d_in, out, out, f"{name}.u4.bias")
+        self._wgrad3_bias(cat.data_ptr(), 2 * lat, h2, w2, 2 * lat, d_in, out, out, f"{name}.u4.weight", f"{name}.u4.bias")
         dcat = self.dCAT.data_ptr()
         wf, wp = self._flip(f"{name}.u4", 3, 2 * lat, out)
         self._conv(d_in, 0, out, wf, zb, dcat, 0, 2 * lat, 1, h2, w2, out, 2 * lat, 3, packed=wp)
@@ -758,8 +769,7 @@ class SeFlowTrainer:
         zb = self.zero_bias.data_ptr()
         # dec4
         u = net.U[1]
-        self._wgrad3(u.data_ptr(), 64, H, W, 64, self.dDEC.data_ptr(), 64, 64, 1, "dec4.weight", False)
-        self._colsum(H * W, self.dDEC.data_ptr(), 64, 64, "dec4.bias")
+        self._wgrad3_bias(u.data_ptr(), 64, H, W, 64, self.dDEC.data_ptr(), 64, 64, "dec4.weight", "dec4.bias")
         d_u = self.dWORK[0].data_ptr()
         wf, wp = self._flip("dec4", 3, 64, 64)
         self._conv(self.dDEC.data_ptr(), 0, 64, wf, zb, d_u, 0, 64, 1, H, W, 64, 64, 3, packed=wp)

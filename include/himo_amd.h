@@ -610,6 +610,11 @@ size_t himo_conv_wgrad_batch_workspace_bytes(int n_img, int h, int w, int cin, i
 int himo_conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int cin,
                              const float* d_dy, int64_t dy_batch_stride, int dy_pitch, int cout, int stride, float* d_dw,
                              unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);
+/* the same with the layer's BIAS gradient d_db [cout] (column sums of dY) from the same pass over dY: stride 1 with flags bit 1 only
+ * (HIMO_ERR_UNSUPPORTED otherwise; himo_colsum is the stand-alone form); flags bit 0 accumulates into both.  Same workspace. */
+int himo_conv3x3_wgrad_batch_bias(int n_img, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int cin,
+                                  const float* d_dy, int64_t dy_batch_stride, int dy_pitch, int cout, int stride, float* d_dw,
+                                  float* d_db, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);
 size_t himo_conv_wgrad_workspace_bytes(int ho, int wo, int cin, int cout);
 int himo_conv3x3_wgrad(const float* d_x, int x_pitch, int h, int w, int cin, const float* d_dy, int dy_pitch, int cout,
                        int stride, float* d_dw, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);

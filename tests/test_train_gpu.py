@@ -118,6 +118,17 @@ def test_split_bf16_weight_gradient_matches_autograd(gpu, h, w, cin, cout, n, st
     err_split = (np.abs(dw_split.cpu().numpy() - ref) / scale).max()
     err_f32 = (np.abs(dw_f32.cpu().numpy() - ref) / scale).max()
     assert err_f32 <= 1e-4 and err_split <= 1e-4, (err_f32, err_split)
+    if stride == 1:                      # the bias gradient from the same pass over dY (himo_conv3x3_wgrad_batch_bias)
+        from himo_amd import _lib
+        lib = _lib.load()
+        X, _, DY = args
+        dw2, db2 = torch.empty_like(dw_split), torch.empty(cout, device=gpu)
+        ws = torch.empty(int(lib.himo_conv_wgrad_batch_workspace_bytes(n, h, w, cin, cout, 1)), dtype=torch.uint8, device=gpu)
+        _lib.check(lib.himo_conv3x3_wgrad_batch_bias(n, X.data_ptr(), h * w * cin, cin, h, w, cin, DY.data_ptr(), h * w * cout, cout, cout, 1,
+                                                     dw2.data_ptr(), db2.data_ptr(), 2, ws.data_ptr(), ws.numel(), _lib.stream_handle()), "wgrad_bias")
+        assert torch.equal(dw2, dw_split)
+        ref_db = dy.astype(np.float64).sum((0, 1, 2))
+        assert (np.abs(db2.cpu().numpy() - ref_db) / np.abs(dy).sum((0, 1, 2))).max() <= 1e-6
 
 
 @pytest.mark.parametrize("stride,h,w,cin,cout,n", [(1, 24, 40, 64, 64, 2), (1, 16, 64, 128, 256, 1), (1, 64, 96, 256, 64, 1), (2, 32, 64, 64, 128, 2),
