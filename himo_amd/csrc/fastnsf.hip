@@ -504,6 +504,64 @@ static size_t wgrad_ws(int64_t n_rows, int cin, int cout) {
     return tiles * nb * 128 * 128 * 4 + ctiles * nb * 128 * 4 + 64;
 }
 
+// dW = X^T dZ and db = column sums of dZ for a THIN input (cin <= 4: the head's Linear(3, 64) on the point offsets).  As a matrix-core
+// product the 3-row operand filled 3 of 128 tile rows (83 us per 120k points); here it is what it is, a column reduction of dZ with cin + 1
+// weights per row: block = 4 row groups x 64 columns, partials [block][cin + 1][cout], fixed-order reductions.
+namespace himo {
+__global__ __launch_bounds__(256) void wgrad_thin_partial_kernel(int64_t n, const float* __restrict__ X, int x_pitch, int cin,
+                                                                 const float* __restrict__ dZ, int z_pitch, int cout,
+                                                                 float* __restrict__ partial, int rows_pb) {
+    __shared__ float sh[4][5][64];
+    const int c = (int)blockIdx.y * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_pb;
+    const int64_t r1 = r0 + rows_pb < n ? r0 + rows_pb : n;
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    int kk[4];                                             // rows >= cin re-read row 0 (their sums are never written): no conditional loads,
+#pragma unroll                                             // which the compiler would serialise one by one
+    for (int k = 0; k < 4; ++k) kk[k] = k < cin ? k : 0;
+    const int cc = c < cout ? c : cout - 1;
+#pragma unroll 4
+    for (int64_t r = r0 + grp; r < r1; r += 4) {
+        const float g = dZ[r * z_pitch + cc];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += X[r * x_pitch + kk[k]] * g;
+        a[4] += g;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sh[grp][k][threadIdx.x & 63] = a[k];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 5 * 64; e += 256) {
+        const int k = e >> 6, cc = e & 63;
+        const int col = (int)blockIdx.y * 64 + cc;
+        if (col < cout) partial[((int64_t)blockIdx.x * 5 + k) * cout + col] = (sh[0][k][cc] + sh[1][k][cc]) + (sh[2][k][cc] + sh[3][k][cc]);
+    }
+}
+// element e of [5][cout] (rows 0 .. cin - 1: dW, row 4: db): four thread groups over every fourth block partial, four chains each
+__global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const float* __restrict__ partial, int nb, int cin, int cout,
+                                                                float* __restrict__ dW, float* __restrict__ db, int accumulate) {
+    __shared__ float sh[4][64];
+    const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = (int)blockIdx.x * 64 + o;
+    const bool ok = e < 5 * cout;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (ok) {
+        const float* p = partial + e;
+        const int64_t st = 5ll * cout;
+        int b = grp;
+        for (; b + 12 < nb; b += 16) { s0 += p[b * st]; s1 += p[(b + 4) * st]; s2 += p[(b + 8) * st]; s3 += p[(b + 12) * st]; }
+        for (; b < nb; b += 4) s0 += p[b * st];
+    }
+    sh[grp][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && ok) {
+        const float t = (sh[0][o] + sh[1][o]) + (sh[2][o] + sh[3][o]);
+        const int k = e / cout, col = e - k * cout;
+        if (k < cin) dW[k * cout + col] = accumulate ? dW[k * cout + col] + t : t;
+        else if (k == 4 && db) db[col] = accumulate ? db[col] + t : t;
+    }
+}
+}  // namespace himo
+
 extern "C" size_t himo_wgrad_workspace_bytes(int64_t n_rows) { return wgrad_ws(n_rows, 128, 128); }
 extern "C" size_t himo_wgrad_workspace_bytes_ex(int64_t n_rows, int cin, int cout) { return wgrad_ws(n_rows, cin, cout); }
 
@@ -513,6 +571,21 @@ extern "C" int himo_linear_wgrad_ex(int64_t n, const float* d_x, int x_pitch, in
     if (n < 1 || cin < 1 || cout < 1 || !d_x || !d_dz || !d_dw || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
     if (workspace_bytes < wgrad_ws(n, cin, cout) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    if (cin <= 4) {                                        // thin input: a column reduction, not a matrix product (wgrad_thin_*)
+        const int64_t want = (n + 63) / 64;
+        const int nb = (int)(want < 512 ? want : 512);
+        const int rows_pb = (int)((n + nb - 1) / nb);
+        if ((size_t)nb * 5 * cout * 4 <= workspace_bytes) {
+            float* partial = reinterpret_cast<float*>(d_workspace);
+            ProfScope ps("wgrad_partial_kernel", s);
+            hipLaunchKernelGGL(wgrad_thin_partial_kernel, dim3(nb, (cout + 63) / 64), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch, cout,
+                               partial, rows_pb);
+            hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((5 * cout + 63) / 64), dim3(256), 0, s, partial, nb, cin, cout, d_dw, d_db,
+                               (flags & 1u) ? 1 : 0);
+            HIMO_LAUNCH_CHECK("wgrad_thin kernels");
+            return HIMO_OK;
+        }
+    }
     const int ci_tiles = (cin + 127) / 128, co_tiles = (cout + 127) / 128;
     // rows per block: 256 for short inputs, longer runs when that would mean > ~512 blocks (the partial tiles, 64 KB
     // each, are written and read back: fewer, longer blocks keep that traffic below the operand traffic)
