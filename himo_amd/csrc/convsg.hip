@@ -205,7 +205,10 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #define HIMO_TERM16(SA, SB)                                                                                        \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)              \
         acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][SA], __builtin_bit_cast(f16x8, bcur[nt][SB]), acc[mi][nt], 0, 0, 0);
-                HIMO_TERM16(1, 0) HIMO_TERM16(0, 1) HIMO_TERM16(0, 0)
+#ifdef HIMO_EXP_NOMFMA                       // experiment: everything but the matrix instructions
+                if (af[0][0][0] == (_Float16)12345.f)
+#endif
+                { HIMO_TERM16(1, 0) HIMO_TERM16(0, 1) HIMO_TERM16(0, 0) }
 #undef HIMO_TERM16
 #ifndef HIMO_EXP_NOSCHED
                 // this tap's weight prefetch and ALL its activation-fragment reads before its matrix instructions (the
