@@ -300,7 +300,11 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(UpArgs a) {
 #pragma unroll
     for (int part = 0; part < CPT / 4; ++part) {
         auto ld = [&](int yy, int xx) { return *reinterpret_cast<const float4*>(a.x + ((int64_t)yy * a.W + xx) * a.x_pitch + q * CPT + part * 4); };
+#ifdef HIMO_EXP_UPNOLOAD                     // experiment: stores only
+        const float4 v00 = make_float4(lx0, ly0, lx1, ly1), v01 = v00, v10 = v00, v11 = v00;
+#else
         const float4 v00 = ld(y0, x0), v01 = ld(y0, x1), v10 = ld(y1, x0), v11 = ld(y1, x1);
+#endif
         o[part * 4 + 0] = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
         o[part * 4 + 1] = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
         o[part * 4 + 2] = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
@@ -315,6 +319,108 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(UpArgs a) {
         *reinterpret_cast<uint4*>(rec + 32) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
     } else {
         *reinterpret_cast<float4*>(a.y + pix * a.y_pitch + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// Split output, round 3: the same 8 channels per thread and the same arithmetic (identical bits) as upsample2x_kernel<true>, with the
+// index arithmetic taken out of the lanes: a block works inside ONE output row (blockIdx.y; the row's source rows and weights are
+// scalars) and a thread's pixel / channel group come from one 32-bit division instead of three 64-bit divisions and remainders.
+// Measured (scripts/exp_upsample.py): the 8-channel kernel ran at 2.4-2.6 TB/s of output where its stores alone sustain 5.8 -- neither
+// the bytes nor the load pattern (a 4-channel variant with fully contiguous loads and DPP-paired stores was 30 % SLOWER: twice the
+// threads, twice the index arithmetic) but the integer work per lane.
+__global__ __launch_bounds__(256) void upsample2x_split_row_kernel(UpArgs a) {
+    a.x += (int64_t)blockIdx.z * a.x_bs;
+    a.y += (int64_t)blockIdx.z * a.y_bs;
+    const unsigned cq = (unsigned)a.C >> 3;
+    const unsigned item = blockIdx.x * 256u + threadIdx.x;           // within the row: pixel * cq + group
+    const unsigned ox = item / cq, q = item - ox * cq;
+    if (ox >= 2u * (unsigned)a.W) return;
+    const int oy = (int)blockIdx.y;
+    const float sy = a.ry * (float)oy, sx = a.rx * (float)ox;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < a.H - 1 ? 1 : 0), x1 = x0 + (x0 < a.W - 1 ? 1 : 0);
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float* row0 = a.x + (int64_t)y0 * a.W * a.x_pitch + q * 8;
+    const float* row1 = a.x + (int64_t)y1 * a.W * a.x_pitch + q * 8;
+    const unsigned c0 = (unsigned)x0 * (unsigned)a.x_pitch, c1 = (unsigned)x1 * (unsigned)a.x_pitch;
+    float o[8];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const float4 v00 = *reinterpret_cast<const float4*>(row0 + c0 + part * 4), v01 = *reinterpret_cast<const float4*>(row0 + c1 + part * 4);
+        const float4 v10 = *reinterpret_cast<const float4*>(row1 + c0 + part * 4), v11 = *reinterpret_cast<const float4*>(row1 + c1 + part * 4);
+        o[part * 4 + 0] = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+        o[part * 4 + 1] = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+        o[part * 4 + 2] = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+        o[part * 4 + 3] = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+    }
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) split2_rounded(o[k], h[k], l[k]);
+    unsigned char* rec = reinterpret_cast<unsigned char*>(a.y + ((int64_t)oy * (2 * a.W) + ox) * a.y_pitch + (q >> 1) * 16) + (q & 1) * 16;
+    *reinterpret_cast<uint4*>(rec) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    *reinterpret_cast<uint4*>(rec + 32) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+// Split output, the decoder's channel counts (C = 8 CQ, CQ = 8 | 16 | 32): the source pixels of a tile through LDS.  Every output
+// value needs four source values; read from global memory that is four 16-byte load instructions per 4 channels, and the kernels above
+// are bound by exactly that count (a wave's dwordx4 load occupies the CU's vector-memory path for ~40-60 cycles: 8 of them per 2 KB of
+// output = 2.4-2.6 TB/s, while the same stores without the loads sustain 5.8).  Here a block owns kUpRows output rows x 256 / CQ output
+// columns: the (kUpRows / 2 + 2) x (PX / 2 + 2) source pixels they can touch are loaded ONCE, coalesced, into LDS (1.1 global loads per
+// 8 output channels instead of 8) and the four corners come from ds_read_b128.  Same arithmetic per value: identical bits.
+#ifndef HIMO_EXP_UPROWS
+#define HIMO_EXP_UPROWS 8
+#endif
+constexpr int kUpRows = HIMO_EXP_UPROWS;
+template <int CQ>
+__global__ __launch_bounds__(256) void upsample2x_split_lds_kernel(UpArgs a) {
+    constexpr int PX = 256 / CQ, NC = PX / 2 + 2, NR = kUpRows / 2 + 2, C = CQ * 8, C4 = C / 4;
+    constexpr int CP = C + 4;        // pixel pitch in LDS: + 16 bytes, so the two source pixels of a 16-lane read phase interleave in the banks
+    __shared__ __attribute__((aligned(16))) float tile[NR * NC * CP];
+    a.x += (int64_t)blockIdx.z * a.x_bs;
+    a.y += (int64_t)blockIdx.z * a.y_bs;
+    const int ox0 = (int)blockIdx.x * PX, oy0 = (int)blockIdx.y * kUpRows;
+    const int cy0 = (int)(a.ry * (float)oy0), cx0 = (int)(a.rx * (float)ox0);       // first source row / column of the tile
+    for (int e = threadIdx.x; e < NR * NC * C4; e += 256) {
+        const int px = e / C4, j = e - px * C4;
+        const int r = px / NC, c = px - r * NC;
+        const int yy = min(cy0 + r, a.H - 1), xx = min(cx0 + c, a.W - 1);          // (clamped duplicates past the border are never selected)
+        *reinterpret_cast<float4*>(&tile[px * CP + j * 4]) = *reinterpret_cast<const float4*>(a.x + ((int64_t)yy * a.W + xx) * a.x_pitch + j * 4);
+    }
+    __syncthreads();
+    const int q = threadIdx.x % CQ, p = threadIdx.x / CQ;
+    const int ox = ox0 + p;
+    if (ox >= 2 * a.W) return;
+    const float sx = a.rx * (float)ox;
+    const int x0 = (int)sx;
+    const int x1 = x0 + (x0 < a.W - 1 ? 1 : 0);
+    const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+    const int t0 = (x0 - cx0) * CP + q * 8, t1 = (x1 - cx0) * CP + q * 8;
+#pragma unroll
+    for (int r = 0; r < kUpRows; ++r) {
+        const int oy = oy0 + r;
+        if (oy >= 2 * a.H) break;
+        const float sy = a.ry * (float)oy;
+        const int y0 = (int)sy;
+        const int y1 = y0 + (y0 < a.H - 1 ? 1 : 0);
+        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+        const float* r0 = &tile[(y0 - cy0) * NC * CP], * r1 = &tile[(y1 - cy0) * NC * CP];
+        float o[8];
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const float4 v00 = *reinterpret_cast<const float4*>(r0 + t0 + part * 4), v01 = *reinterpret_cast<const float4*>(r0 + t1 + part * 4);
+            const float4 v10 = *reinterpret_cast<const float4*>(r1 + t0 + part * 4), v11 = *reinterpret_cast<const float4*>(r1 + t1 + part * 4);
+            o[part * 4 + 0] = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+            o[part * 4 + 1] = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+            o[part * 4 + 2] = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+            o[part * 4 + 3] = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+        }
+        unsigned h[8], l[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) split2_rounded(o[k], h[k], l[k]);
+        unsigned char* rec = reinterpret_cast<unsigned char*>(a.y + ((int64_t)oy * (2 * a.W) + ox) * a.y_pitch + (q >> 1) * 16) + (q & 1) * 16;
+        *reinterpret_cast<uint4*>(rec) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        *reinterpret_cast<uint4*>(rec + 32) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
     }
 }
 
@@ -432,8 +538,27 @@ extern "C" int himo_upsample2x_batch_ex(int n, const float* d_x, int64_t x_batch
     a.x_bs = x_batch_stride; a.y_bs = y_batch_stride; a.out_split = out_split ? 1 : 0;
     a.ry = h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     a.rx = w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
-    const int64_t total = (int64_t)(2 * h) * (2 * w) * (c / (out_split ? 8 : 4));
     ProfScope ps("upsample2x_kernel", (hipStream_t)stream);
+#if !defined(HIMO_EXP_UP8) && !defined(HIMO_EXP_UPROW)
+    if (out_split && (c == 64 || c == 128 || c == 256) && (2 * h + kUpRows - 1) / kUpRows <= 65535 && n <= 65535) {
+        const int cq = c / 8, px = 256 / cq;
+        const dim3 grid((2 * w + px - 1) / px, (2 * h + kUpRows - 1) / kUpRows, n);
+        if (cq == 8) hipLaunchKernelGGL(upsample2x_split_lds_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        else if (cq == 16) hipLaunchKernelGGL(upsample2x_split_lds_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(upsample2x_split_lds_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        HIMO_LAUNCH_CHECK("upsample2x_split_lds_kernel");
+        return HIMO_OK;
+    }
+#endif
+#ifndef HIMO_EXP_UP8                         // (experiment switch: the flat-index kernel of rounds 1-2 for the split output as well)
+    if (out_split && 2 * h <= 65535 && n <= 65535 && (int64_t)w * x_pitch < ((int64_t)1 << 31)) {
+        const unsigned row_items = (unsigned)(2 * w) * (unsigned)(c / 8);
+        hipLaunchKernelGGL(upsample2x_split_row_kernel, dim3((row_items + 255) / 256, 2 * h, n), dim3(256), 0, (hipStream_t)stream, a);
+        HIMO_LAUNCH_CHECK("upsample2x_split_row_kernel");
+        return HIMO_OK;
+    }
+#endif
+    const int64_t total = (int64_t)(2 * h) * (2 * w) * (c / (out_split ? 8 : 4));
     const dim3 grid((unsigned)((total + 255) / 256), n);
     if (out_split) hipLaunchKernelGGL(upsample2x_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(upsample2x_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);

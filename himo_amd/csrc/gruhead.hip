@@ -73,6 +73,11 @@ struct GruHeadBatch {
 // for the whole kernel, and every GEMM of the head runs 9 slabs instead of 12: a quarter less matrix work, fragment reads,
 // weight stream and operand LDS, with no extra vector work.
 constexpr int kGhRows = 64;
+#ifdef HIMO_EXP_HLAUNDER                     // experiment: the inference kernel also recomputes its gate-stage LDS addresses per stage
+constexpr bool kGhLaunder = true;
+#else
+constexpr bool kGhLaunder = false;
+#endif
 
 template <int SLABS>
 __device__ inline int a_slot(int s, int slab, int row, int half) {
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
 #pragma unroll 1
     for (int it = 0; it < a.iters; ++it) {
         int sli = li, slh = lh;               // lane coordinates of the gate stages' LDS / global stores
-        if constexpr (SAVE) asm volatile("" : "+v"(o128), "+v"(o192), "+v"(sli), "+v"(slh));      // keep the ~100 per-element addresses out of the loop-invariant set
+        if constexpr (SAVE || kGhLaunder) asm volatile("" : "+v"(o128), "+v"(o192), "+v"(sli), "+v"(slh));      // keep the ~100 per-element addresses out of the loop-invariant set
         float* const sz = SAVE ? sv.z + it * sv.rows * 128 : nullptr; float* const sr = SAVE ? sv.r + it * sv.rows * 128 : nullptr;
         float* const sq = SAVE ? sv.q + it * sv.rows * 128 : nullptr; float* const srhx = SAVE ? sv.rhx + it * sv.rows * 192 : nullptr;
         float* const shx = SAVE ? sv.hx + (it + 1) * sv.rows * 192 : nullptr;
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
             }
         __syncthreads();                                        // A = [r*h | x]
         // (again: the two gate stages address the same elements, and common addresses would stay live across the q product)
-        if constexpr (SAVE) asm volatile("" : "+v"(o128), "+v"(o192), "+v"(sli), "+v"(slh));
+        if constexpr (SAVE || kGhLaunder) asm volatile("" : "+v"(o128), "+v"(o192), "+v"(sli), "+v"(slh));
         floatx16 acq[2][1];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
