@@ -2,7 +2,7 @@
 # One table for a whole pipeline bench step: per kernel family the launches per step, time, effective shader clock
 # (GRBM_GUI_ACTIVE / 8 XCDs / duration), matrix-pipe busy share (SQ_VALU_MFMA_BUSY_CYCLES per SIMD / cycles) and the fabric-side
 # bytes (FETCH_SIZE x 2 per the gfx950 note, WRITE_SIZE) -> achieved GB/s.  Three rocprofv3 --pmc passes over
-# `bench.py --no-cpu-baseline --no-extra-precisions --steps 2 --warmup 1`; only the launches of the last two steps are averaged.
+# `bench.py --no-cpu-baseline --no-extra-precisions --no-extra-workloads --steps 2 --warmup 1`; only the launches of the last two steps are averaged.
 # usage (GPU box, repo root): bash scripts/pmc_step_summary.sh > gpurun_out/pmc_step_summary.txt
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python $R/bench.py --no-cpu-baseline --no-extra-precisions --steps 2 --warmup 1 > $OUT/p$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o pmc -- python $R/bench.py --no-cpu-baseline --no-extra-precisions --no-extra-workloads --steps 2 --warmup 1 > $OUT/p$i.log 2>&1
 done
 cd $R
 python - <<PY

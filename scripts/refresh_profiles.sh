@@ -16,6 +16,7 @@ python bench.py --precision bf16x3 --no-cpu-baseline > $OUT/${RN}_bench_pipeline
 python bench.py --float32-activations --no-cpu-baseline > $OUT/${RN}_bench_pipeline_n1_float32_activations.json 2>> $OUT/pipeline.err
 python bench.py --workload compdis > $OUT/${RN}_bench_compdis_n1.json 2> $OUT/compdis.err
 python bench.py --workload train > $OUT/${RN}_bench_train_n1.json 2> $OUT/train.err
+python bench.py --workload train --train-batchnorm frozen --no-extra-workloads > $OUT/${RN}_bench_train_n1_frozen_bn.json 2>> $OUT/train.err
 python bench.py --cloud rings --no-cpu-baseline > $OUT/${RN}_bench_pipeline_n1_lidar_rings.json 2>> $OUT/pipeline.err
 python scripts/exp_layers.py 16 > $OUT/${RN}_conv3x3_per_layer.txt 2>&1
 python scripts/exp_eval.py > $OUT/${RN}_evaluator_throughput.txt 2>&1
@@ -26,9 +27,13 @@ bash scripts/pmc_step_summary.sh > $OUT/${RN}_pmc_step_summary.txt 2>&1
 python scripts/exp_savezip.py > $OUT/${RN}_exp_savezip.log 2>&1
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_peak scripts/micro/mfma_peak.hip && /tmp/mfma_peak > $OUT/${RN}_mfma_sustained_peak.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-for wl in pipeline compdis train; do
+python scripts/exp_hbm_layers.py > $OUT/${RN}_hbm_side_layers.txt 2>&1
+python scripts/exp_upsample.py > $OUT/${RN}_upsample.txt 2>&1
+for wl in pipeline compdis train fastnsf; do
   ARGS="--workload $wl --no-cpu-baseline --no-extra-precisions"
-  [ $wl = train ] && ARGS="$ARGS --steps 3 --warmup 1"
+  [ $wl = train ] && ARGS="$ARGS --steps 5 --warmup 2 --no-extra-workloads"
+  [ $wl = fastnsf ] && ARGS="$ARGS --steps 2 --warmup 1 --no-extra-workloads"
+  [ $wl = pipeline ] && ARGS="$ARGS --no-extra-workloads"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$wl -o $wl -- python $R/bench.py $ARGS > $OUT/${RN}_bench_${wl}_n1_under_rocprof.json 2> $OUT/prof_$wl.err
   f=$(find $OUT/prof_$wl -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${RN}_${wl}_rocprofv3_kernel_stats.csv
