@@ -27,8 +27,8 @@ bash scripts/pmc_step_summary.sh > $OUT/${RN}_pmc_step_summary.txt 2>&1
 python scripts/exp_savezip.py > $OUT/${RN}_exp_savezip.log 2>&1
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_peak scripts/micro/mfma_peak.hip && /tmp/mfma_peak > $OUT/${RN}_mfma_sustained_peak.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-python scripts/exp_hbm_layers.py > $OUT/${RN}_hbm_side_layers.txt 2>&1
-python scripts/exp_upsample.py > $OUT/${RN}_upsample.txt 2>&1
+python $R/scripts/exp_hbm_layers.py > $OUT/${RN}_hbm_side_layers.txt 2>&1
+python $R/scripts/exp_upsample.py > $OUT/${RN}_upsample.txt 2>&1
 for wl in pipeline compdis train fastnsf; do
   ARGS="--workload $wl --no-cpu-baseline --no-extra-precisions"
   [ $wl = train ] && ARGS="$ARGS --steps 5 --warmup 2 --no-extra-workloads"
