@@ -32,7 +32,9 @@ struct ConvArgs {
     float* aux_out; int aux_out_pitch;                        // r*h (kEpiGruZR) / h in place (kEpiGruQ)
     int act_flags;                                            // kActSplitIn | kActSplitOut: split activation format (convsg.hip)
 };
-enum ActFlags { kActSplitIn = 1, kActSplitOut = 2, kActVecStore = 4 };     // kActVecStore: set by the launchers (vec_store_ok)
+enum ActFlags { kActSplitIn = 1, kActSplitOut = 2, kActVecStore = 4, kActAccumulate = 8 };
+// kActVecStore: set by the launchers (vec_store_ok).  kActAccumulate (HIMO_ACT_ACCUMULATE): y += result -- float32 output of the
+// two-term bf16 3x3 kernels only (the training step's stride-2 data gradients add into the decoder's skip gradient in place)
 
 // GELU (erf form).  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, below float32 resolution of the 1 + erf sum)
 // with the hardware exp2 / rcp: a dozen instructions where the library erff takes three times that -- the epilogue of
@@ -169,7 +171,7 @@ inline bool vec_store_ok(const ConvArgs& a) {
 // word = this lane's 32-bit output for pixel r (float bits, or the paired split word of split_word()).
 // MASK (float32 outputs only): the kEpiReluMask epilogue -- an output is kept where aux_in (same pixel, same channel) is positive,
 // read with the same 16-byte pattern as the store.
-template <bool OSPLIT, bool MASK = false>
+template <bool OSPLIT, bool MASK = false, bool ACC = false>
 __device__ inline void store_block_vec(const ConvArgs& a, float* __restrict__ yout, unsigned char* stg, const unsigned (&word)[16],
                                        int lane, int64_t pix0, int n_valid_px, int ch0) {
     const int li = lane & 31, lh = lane >> 5;
@@ -200,6 +202,11 @@ __device__ inline void store_block_vec(const ConvArgs& a, float* __restrict__ yo
             // store was ~8 vector instructions of the block's ~60
             float* dst = yout + (((unsigned)pix0 + (unsigned)px) * (unsigned)a.y_pitch + (unsigned)(ch0 + piece * 4));
 #endif
+            if (ACC) {                                     // y += result (float32 words)
+                const float4 o = *reinterpret_cast<const float4*>(dst);
+                d.x = __builtin_bit_cast(unsigned, o.x + __builtin_bit_cast(float, d.x)); d.y = __builtin_bit_cast(unsigned, o.y + __builtin_bit_cast(float, d.y));
+                d.z = __builtin_bit_cast(unsigned, o.z + __builtin_bit_cast(float, d.z)); d.w = __builtin_bit_cast(unsigned, o.w + __builtin_bit_cast(float, d.w));
+            }
 #if defined(HIMO_EXP_STORE_NT)
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             __builtin_nontemporal_store(u32x4{d.x, d.y, d.z, d.w}, reinterpret_cast<u32x4*>(dst));

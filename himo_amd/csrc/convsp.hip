@@ -258,6 +258,8 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
                 word[r] = (FMT == 2 && osplit) ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
             }
             if (FMT == 2 && osplit) store_block_vec<true>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, oy < a.Ho ? n_px : 0, tn * BN + wc * 32);
+            else if (FMT == 4 && (a.act_flags & kActAccumulate))
+                store_block_vec<false, false, true>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, oy < a.Ho ? n_px : 0, tn * BN + wc * 32);
             else store_block_vec<false>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, oy < a.Ho ? n_px : 0, tn * BN + wc * 32);
         }
         return;
@@ -324,7 +326,8 @@ static void launch_sp_mi(const ConvArgs& a, int epi, int mi, int stride, const u
 // rows_hint: 0 = heuristic, else image rows per wave (4 | 2 | 1; stride 2 always uses 2).
 bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, int format, int rows_hint, int stride, hipStream_t s) {
     if (epilogue == kEpiGruZR || epilogue == kEpiGruQ) return false;
-    if (format == 2 && (epilogue != kEpiBias || a.act_flags)) return false;        // two-term bf16: float32 maps, bias epilogue
+    if (format == 2 && (epilogue != kEpiBias || (a.act_flags & ~kActAccumulate))) return false;        // two-term bf16: float32 maps, bias epilogue
+    if ((a.act_flags & kActAccumulate) && (format != 2 || !vec_store_ok(a))) return false;              // y += result: that kernel's 16-byte store path only
     const bool wide = a.Cout > 64;                     // PH = 1: 128-channel tiles; PH = 2: 64-channel tiles
     const int bn = wide ? 128 : 64, ph = wide ? 1 : 2;
     auto blocks_for = [&](int mi) -> int64_t {

@@ -64,10 +64,10 @@ struct PillarArgs {
 constexpr int kMaxSweeps = 12;
 struct PillarBatch { PillarArgs s[kMaxSweeps]; };
 
-// cell_count and cell_cursor of every sweep of the launch group cleared in ONE launch (16 bytes per lane): as per-sweep
+// cell_count of every sweep of the launch group cleared in ONE launch (16 bytes per lane): as per-sweep
 // hipMemsetAsync calls they were 12 serialized ~5 us fill kernels per group, a quarter millisecond per 16-sample step
 __global__ __launch_bounds__(256) void pillar_clear_kernel(PillarBatch m, int n_vec4) {
-    int4* p = reinterpret_cast<int4*>(m.s[blockIdx.y].cell_count);        // cell_cursor follows cell_count (pillar_args)
+    int4* p = reinterpret_cast<int4*>(m.s[blockIdx.y].cell_count);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n_vec4; i += gridDim.x * 256) p[i] = make_int4(0, 0, 0, 0);
 }
 
@@ -91,7 +91,9 @@ __global__ __launch_bounds__(256) void pillar_assign_kernel(PillarBatch m) {
     int cell = -1;
     if (ok) {
         cell = (int)fy * a.g.W + (int)fx;
-        atomicAdd(&a.cell_count[cell], 1);
+        // the histogram's returned count IS the point's slot in its cell's list: the scatter below needs no second round of atomics
+        // (kept in order2 until the feature kernel, which runs after the scatter, writes the ascending order there)
+        a.order2[i] = atomicAdd(&a.cell_count[cell], 1);
     } else {
         a.offsets[i * 3] = 0.f; a.offsets[i * 3 + 1] = 0.f; a.offsets[i * 3 + 2] = 0.f;
     }
@@ -158,8 +160,7 @@ __global__ __launch_bounds__(256) void pillar_fill_kernel(PillarBatch m) {
     if (i >= a.n) return;
     const int cell = a.pid[i];
     if (cell < 0) return;
-    const int slot = atomicAdd(&a.cell_cursor[cell], 1);
-    const int at = cell_offset(a, cell) + slot;
+    const int at = cell_offset(a, cell) + a.order2[i];
     a.cell_rec[at] = make_float4(a.xyz_t[i * 3], a.xyz_t[i * 3 + 1], a.xyz_t[i * 3 + 2], __int_as_float((int)i));
 }
 
@@ -398,8 +399,11 @@ struct PfnBnArgs {
 // one dependent load chain at a time made each of these kernels 60-75 us per sweep.  A cell's points are taken in ascending point
 // order (order2, written by the forward pass), 32 per gather, and broadcast by shuffle: the per-cell sums have the forward's order;
 // no float atomics anywhere.
+struct PfnBnBatch { PfnBnArgs s[kMaxSweeps]; };     // blockIdx.y = sweep: the walks of a sample's sweeps share a launch (latency chains on
+                                                    // small grids, like the forward stage's kernels)
 template <int KIND>
-__global__ __launch_bounds__(256) void pfn_walk_kernel(PfnBnArgs p) {
+__global__ __launch_bounds__(256) void pfn_walk_kernel(PfnBnBatch m) {
+    const PfnBnArgs& p = m.s[blockIdx.y];
     const PillarBwdArgs& a = p.b;
     constexpr int kChunk = 256;
     __shared__ int s_beg[kChunk + 1];
@@ -653,7 +657,7 @@ static int pillar_launch(const PillarBatch& m, int count, hipStream_t s) {
     for (int i = 0; i < count; ++i)
         if (m.s[i].n > nmax) nmax = m.s[i].n;
     {
-        const int n_vec4 = (int)(2 * ws_cells(cells) / 16);
+        const int n_vec4 = (int)(ws_cells(cells) / 16);            // the histogram only: the cursor array behind it is no longer used
         hipLaunchKernelGGL(pillar_clear_kernel, dim3(std::min((n_vec4 + 255) / 256, 512), count), dim3(256), 0, s, m, n_vec4);
     }
     HIMO_LAUNCH_CHECK("pillar_clear_kernel");
@@ -767,9 +771,9 @@ extern "C" int himo_pfn_backward(int64_t n, const float* h_voxel, const float* h
     hipStream_t s = (hipStream_t)stream;
     {
         ProfScope ps("pfn_backward_kernel", s);
-        PfnBnArgs p{};
-        p.b = a;
-        hipLaunchKernelGGL(pfn_walk_kernel<3>, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
+        PfnBnBatch m{};
+        m.s[0].b = a;
+        hipLaunchKernelGGL(pfn_walk_kernel<3>, dim3(kPfnBwdBlocks), dim3(256), 0, s, m);
     }
     hipLaunchKernelGGL(pfn_backward_reduce_kernel, dim3(9), dim3(1024), 0, s, a.partial, kPfnBwdBlocks, d_dweight, (flags & 1u) ? 1 : 0);
     HIMO_LAUNCH_CHECK("pfn_backward kernels");
@@ -801,28 +805,46 @@ static int pfn_bn_args(PfnBnArgs& p, int64_t n, const float* h_voxel, const floa
     return HIMO_OK;
 }
 
-// Batch statistics of y = feats W over the in-range points of the sweep whose cell lists himo_pillarize* left in
+// Batch statistics of y = feats W over the in-range points of each sweep whose cell lists himo_pillarize* left in its
 // d_pillar_workspace -> d_scale / d_shift (what the feature kernel and the backward pass consume: gamma invstd,
-// beta - mean gamma invstd), d_mean / d_invstd (saved for the backward pass); running statistics updated in place
-// (momentum, unbiased variance; NULL: not tracked).
+// beta - mean gamma invstd), d_mean / d_invstd (saved for the backward pass), rows of [n_sweeps][32] arrays; running statistics
+// updated in place sweep after sweep (momentum, unbiased variance; NULL: not tracked).  ONE walk launch for all sweeps; the
+// per-sweep finalize kernels follow in order.  Workspace: n_sweeps x himo_pfn_bn_workspace_bytes().
+extern "C" int himo_pfn_bn_stats_multi(int n_sweeps, const int64_t* h_n, const float* const* h_xyz_t, const void* const* h_pillar_workspace,
+                                       const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
+                                       const float* d_pfn_weight, const float* d_gamma, const float* d_beta, float eps, float momentum,
+                                       float* d_running_mean, float* d_running_var, float* d_scale, float* d_shift, float* d_mean,
+                                       float* d_invstd, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (n_sweeps < 1 || n_sweeps > kMaxSweeps || !h_n || !h_xyz_t || !h_pillar_workspace) return HIMO_ERR_INVALID_ARGUMENT;
+    if (!d_gamma || !d_beta || !d_scale || !d_shift || !d_mean || !d_invstd || (d_running_mean == nullptr) != (d_running_var == nullptr))
+        return HIMO_ERR_INVALID_ARGUMENT;
+    const size_t one = himo_pfn_bn_workspace_bytes();
+    if (workspace_bytes < one * n_sweeps) return HIMO_ERR_WORKSPACE;
+    PfnBnBatch m{};
+    for (int i = 0; i < n_sweeps; ++i) {
+        const int st = pfn_bn_args(m.s[i], h_n[i], h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight, h_xyz_t[i], h_pillar_workspace[i],
+                                   reinterpret_cast<char*>(d_workspace) + one * i, one);
+        if (st != HIMO_OK) return st;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("pfn_bn_stats_kernel", s);
+    hipLaunchKernelGGL(pfn_walk_kernel<0>, dim3(kPfnBwdBlocks, n_sweeps), dim3(256), 0, s, m);
+    for (int i = 0; i < n_sweeps; ++i)
+        hipLaunchKernelGGL(pfn_bn_finalize_kernel<0>, dim3(1), dim3(1024), 0, s, m.s[i].partial, kPfnBwdBlocks, m.s[i].b.cell_count,
+                           m.s[i].b.block_sum, grid_w * grid_h, d_gamma, d_beta, eps, momentum, d_running_mean, d_running_var,
+                           d_scale + 32 * i, d_shift + 32 * i, d_mean + 32 * i, d_invstd + 32 * i, 0);
+    HIMO_LAUNCH_CHECK("pfn_bn_stats kernels");
+    return HIMO_OK;
+}
+
 extern "C" int himo_pfn_bn_stats(int64_t n, const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
                                  const float* d_pfn_weight, const float* d_xyz_t, const void* d_pillar_workspace, const float* d_gamma,
                                  const float* d_beta, float eps, float momentum, float* d_running_mean, float* d_running_var,
                                  float* d_scale, float* d_shift, float* d_mean, float* d_invstd, void* d_workspace, size_t workspace_bytes,
                                  void* stream) {
-    if (!d_gamma || !d_beta || !d_scale || !d_shift || !d_mean || !d_invstd || (d_running_mean == nullptr) != (d_running_var == nullptr))
-        return HIMO_ERR_INVALID_ARGUMENT;
-    PfnBnArgs p;
-    const int st = pfn_bn_args(p, n, h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight, d_xyz_t, d_pillar_workspace, d_workspace,
-                               workspace_bytes);
-    if (st != HIMO_OK) return st;
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope ps("pfn_bn_stats_kernel", s);
-    hipLaunchKernelGGL(pfn_walk_kernel<0>, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(pfn_bn_finalize_kernel<0>, dim3(1), dim3(1024), 0, s, p.partial, kPfnBwdBlocks, p.b.cell_count, p.b.block_sum,
-                       grid_w * grid_h, d_gamma, d_beta, eps, momentum, d_running_mean, d_running_var, d_scale, d_shift, d_mean, d_invstd, 0);
-    HIMO_LAUNCH_CHECK("pfn_bn_stats kernels");
-    return HIMO_OK;
+    return himo_pfn_bn_stats_multi(1, &n, &d_xyz_t, &d_pillar_workspace, h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight, d_gamma,
+                                   d_beta, eps, momentum, d_running_mean, d_running_var, d_scale, d_shift, d_mean, d_invstd, d_workspace,
+                                   workspace_bytes, stream);
 }
 
 // The feature kernel alone, with PER-SWEEP BatchNorm constants (d_scale / d_shift: [n_sweeps][32]): the second half of a
@@ -862,33 +884,55 @@ extern "C" int himo_pillar_features_multi(int n_sweeps, const himo_sweep* h_swee
     return HIMO_OK;
 }
 
-// himo_pfn_backward with batch statistics: also yields d loss / d gamma, d loss / d beta [32] (flags bit 0: accumulate all three)
+// himo_pfn_backward with batch statistics, for the sweeps of a sample at once: d loss / d pfn.weight, d gamma, d beta [32] SUMMED over the
+// sweeps in order (flags bit 0: added to what the three hold).  d_scale / d_shift / d_mean / d_invstd: rows of [n_sweeps][32] arrays as
+// himo_pfn_bn_stats_multi left them.  Two walk launches for all sweeps; the per-sweep finalize / reduce kernels follow in order, so the
+// result has the bits of n_sweeps single calls.
+extern "C" int himo_pfn_backward_bn_multi(int n_sweeps, const int64_t* h_n, const float* const* h_xyz_t, const void* const* h_pillar_workspace,
+                                          const float* const* h_dimage, int image_pitch, const float* h_voxel, const float* h_centre_offset,
+                                          int grid_w, int grid_h, const float* d_pfn_weight, const float* d_scale, const float* d_shift,
+                                          const float* d_mean, const float* d_invstd, float* d_dweight, float* d_dgamma, float* d_dbeta,
+                                          unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (n_sweeps < 1 || n_sweeps > kMaxSweeps || !h_n || !h_xyz_t || !h_pillar_workspace || !h_dimage) return HIMO_ERR_INVALID_ARGUMENT;
+    if (!d_scale || !d_shift || !d_mean || !d_invstd || !d_dweight || !d_dgamma || !d_dbeta || image_pitch < 32) return HIMO_ERR_INVALID_ARGUMENT;
+    const size_t one = himo_pfn_bn_workspace_bytes();
+    if (workspace_bytes < one * n_sweeps) return HIMO_ERR_WORKSPACE;
+    PfnBnBatch m{};
+    for (int i = 0; i < n_sweeps; ++i) {
+        if (!h_dimage[i]) return HIMO_ERR_INVALID_ARGUMENT;
+        PfnBnArgs& p = m.s[i];
+        const int st = pfn_bn_args(p, h_n[i], h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight, h_xyz_t[i], h_pillar_workspace[i],
+                                   reinterpret_cast<char*>(d_workspace) + one * i, one);
+        if (st != HIMO_OK) return st;
+        p.b.pfn_scale = d_scale + 32 * i; p.b.pfn_shift = d_shift + 32 * i; p.b.d_image = h_dimage[i]; p.b.image_pitch = image_pitch;
+        p.mean = d_mean + 32 * i; p.invstd = d_invstd + 32 * i;
+        p.coef = reinterpret_cast<float*>(p.partial + (size_t)kPfnBwdBlocks * 2 * 32);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("pfn_backward_kernel", s);
+    hipLaunchKernelGGL(pfn_walk_kernel<1>, dim3(kPfnBwdBlocks, n_sweeps), dim3(256), 0, s, m);
+    for (int i = 0; i < n_sweeps; ++i) {
+        float* coef = const_cast<float*>(m.s[i].coef);
+        hipLaunchKernelGGL(pfn_bn_finalize_kernel<1>, dim3(1), dim3(1024), 0, s, m.s[i].partial, kPfnBwdBlocks, m.s[i].b.cell_count,
+                           m.s[i].b.block_sum, grid_w * grid_h, (const float*)nullptr, (const float*)nullptr, 0.f, 0.f, (float*)nullptr,
+                           (float*)nullptr, d_dgamma, d_dbeta, coef, coef + 32, (i > 0 || (flags & 1u)) ? 1 : 0);
+    }
+    hipLaunchKernelGGL(pfn_walk_kernel<2>, dim3(kPfnBwdBlocks, n_sweeps), dim3(256), 0, s, m);
+    for (int i = 0; i < n_sweeps; ++i)
+        hipLaunchKernelGGL(pfn_backward_reduce_kernel, dim3(9), dim3(1024), 0, s, m.s[i].b.partial, kPfnBwdBlocks, d_dweight,
+                           (i > 0 || (flags & 1u)) ? 1 : 0);
+    HIMO_LAUNCH_CHECK("pfn_backward_bn kernels");
+    return HIMO_OK;
+}
+
 extern "C" int himo_pfn_backward_bn(int64_t n, const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
                                     const float* d_pfn_weight, const float* d_scale, const float* d_shift, const float* d_mean,
                                     const float* d_invstd, const float* d_xyz_t, const void* d_pillar_workspace, const float* d_dimage,
                                     int image_pitch, float* d_dweight, float* d_dgamma, float* d_dbeta, unsigned flags, void* d_workspace,
                                     size_t workspace_bytes, void* stream) {
-    if (!d_scale || !d_shift || !d_mean || !d_invstd || !d_dimage || !d_dweight || !d_dgamma || !d_dbeta || image_pitch < 32)
-        return HIMO_ERR_INVALID_ARGUMENT;
-    PfnBnArgs p;
-    const int st = pfn_bn_args(p, n, h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight, d_xyz_t, d_pillar_workspace, d_workspace,
-                               workspace_bytes);
-    if (st != HIMO_OK) return st;
-    p.b.pfn_scale = d_scale; p.b.pfn_shift = d_shift; p.b.d_image = d_dimage; p.b.image_pitch = image_pitch;
-    p.mean = d_mean; p.invstd = d_invstd;
-    float* coef = reinterpret_cast<float*>(p.partial + (size_t)kPfnBwdBlocks * 2 * 32);
-    p.coef = coef;
-    hipStream_t s = (hipStream_t)stream;
-    const int acc = (flags & 1u) ? 1 : 0;
-    ProfScope ps("pfn_backward_kernel", s);
-    hipLaunchKernelGGL(pfn_walk_kernel<1>, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(pfn_bn_finalize_kernel<1>, dim3(1), dim3(1024), 0, s, p.partial, kPfnBwdBlocks, p.b.cell_count, p.b.block_sum,
-                       grid_w * grid_h, (const float*)nullptr, (const float*)nullptr, 0.f, 0.f, (float*)nullptr, (float*)nullptr, d_dgamma,
-                       d_dbeta, coef, coef + 32, acc);
-    hipLaunchKernelGGL(pfn_walk_kernel<2>, dim3(kPfnBwdBlocks), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(pfn_backward_reduce_kernel, dim3(9), dim3(1024), 0, s, p.b.partial, kPfnBwdBlocks, d_dweight, acc);
-    HIMO_LAUNCH_CHECK("pfn_backward_bn kernels");
-    return HIMO_OK;
+    return himo_pfn_backward_bn_multi(1, &n, &d_xyz_t, &d_pillar_workspace, &d_dimage, image_pitch, h_voxel, h_centre_offset, grid_w, grid_h,
+                                      d_pfn_weight, d_scale, d_shift, d_mean, d_invstd, d_dweight, d_dgamma, d_dbeta, flags, d_workspace,
+                                      workspace_bytes, stream);
 }
 
 extern "C" int himo_head_scatter(int64_t n, int grid_w, int grid_h, const void* d_pillar_workspace, const float* d_dhx, int dhx_pitch,

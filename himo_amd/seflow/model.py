@@ -36,6 +36,7 @@ class ConvDesc(ctypes.Structure):
 
 
 ACT_SPLIT_IN, ACT_SPLIT_OUT = 1, 2      # himo_conv_desc.act_layout: x / y in the split activation format (csrc/convsg.hip)
+ACT_ACCUMULATE = 8                      # y += result (two-term bf16 3x3 kernel, float32 maps)
 
 
 _lib.register({
@@ -654,14 +655,15 @@ class SeFlowNet:
 # ---- stand-alone operators (tests / experiments): the same kernels on caller-provided tensors -------------------
 def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, stride: int = 1, epilogue: int = EPI_BIAS,
                 scale: torch.Tensor | None = None, shift: torch.Tensor | None = None, precision: str = "f32",
-                tile_hint: int = 0, act_layout: int = 0) -> torch.Tensor:
+                tile_hint: int = 0, act_layout: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
     """x [N,H,W,Cin] float32 (contiguous, device), weight [k,k,Cin,Cout] -> y [N,Ho,Wo,Cout].  ``act_layout``:
-    ACT_SPLIT_IN / ACT_SPLIT_OUT -- x / y hold the split activation format (same shape, fp16 pairs; f16x2 3x3 layers only)."""
+    ACT_SPLIT_IN / ACT_SPLIT_OUT -- x / y hold the split activation format (same shape, fp16 pairs; f16x2 3x3 layers only);
+    ACT_ACCUMULATE with ``out`` given: out += result (bf16x2 3x3 stride-1 layers)."""
     lib = _lib.load()
     n, h, w, cin = x.shape
     k, _, _, cout = weight.shape
     ho, wo = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
-    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device) if out is None else out
     d = ConvDesc()
     d.x = x.data_ptr(); d.x_batch_stride = h * w * cin; d.x_pitch = cin
     d.w = weight.data_ptr(); d.bias = bias.data_ptr()

@@ -343,6 +343,10 @@ _lib.register({
     "himo_pfn_bn_workspace_bytes": (ctypes.c_size_t, []),
     "himo_pfn_bn_stats": (c_i, [c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                 ctypes.c_size_t, c_p]),
+    "himo_pfn_bn_stats_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                      ctypes.c_size_t, c_p]),
+    "himo_pfn_backward_bn_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                         ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
     "himo_pillar_features_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, ctypes.c_size_t, c_i, c_p]),
     "himo_pfn_backward_bn": (c_i, [c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, ctypes.c_uint,
                                    c_p, ctypes.c_size_t, c_p]),
@@ -516,7 +520,7 @@ class SeFlowTrainer:
                  int(self.lib.himo_wgrad_workspace_bytes_ex(H * W // 16, 384, 256)),
                  int(self.lib.himo_wgrad_workspace_bytes_ex(max_points, 192, 256)),
                  int(self.lib.himo_pfn_backward_workspace_bytes()))
-        ws = max(ws, int(self.lib.himo_pfn_bn_workspace_bytes()),
+        ws = max(ws, F * int(self.lib.himo_pfn_bn_workspace_bytes()),
                  max(int(self.lib.himo_bn_workspace_bytes(F * L[6] * L[7], L[2])) for L in self.layers))
         self.ws = torch.empty(ws + 64, dtype=torch.uint8, device=dev)
         self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
@@ -567,10 +571,10 @@ class SeFlowTrainer:
                    "weight_prepare_batch")
 
     # ---- launch helpers (raw device addresses: most operands are channel groups of wider buffers) --------------
-    def _conv(self, x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride=1, packed=None, fmt=0):
+    def _conv(self, x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride=1, packed=None, fmt=0, accumulate=False):
         if packed is not None and self.precision != "f32" and packed in self._flip_ptrs:
             fmt = self.bwd3_format                    # a data-gradient copy (_flip)
-        key = (x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride, packed, fmt)
+        key = (x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride, packed, fmt, accumulate)
         d = self._descs.get(key)                 # cached per call site: see HeadTrainer._gemm
         if d is None:
             d = ConvDesc()
@@ -579,6 +583,7 @@ class SeFlowTrainer:
             d.w_packed = packed; d.packed_format = fmt
             d.y, d.y_batch_stride, d.y_pitch = y, y_bs, y_pitch
             d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = n, h, wd, cin, cout, ks, stride, EPI_BIAS
+            d.act_layout = 8 if accumulate else 0     # HIMO_ACT_ACCUMULATE: y += result (two-term bf16 3x3 kernel)
             if len(self._descs) > 4096:
                 self._descs.clear()
             self._descs[key] = d
@@ -662,12 +667,11 @@ class SeFlowTrainer:
             self._bn_folded = False
             g, b = net.p["pfn.bn.gamma"].data_ptr(), net.p["pfn.bn.beta"].data_ptr()
             rm, rv = net.p["pfn.bn.mean"].data_ptr(), net.p["pfn.bn.var"].data_ptr()
-            for slot in range(F):
-                _lib.check(lib.himo_pfn_bn_stats(self.n_pts[slot], net._voxel, net._centre, net.W, net.H, self.p["pfn.weight"].data_ptr(),
-                                                 net.xyz_t[slot].data_ptr(), net.ws_slots[slot].data_ptr(), g, b, spec.BN_EPS_PFN, BN_MOMENTUM,
-                                                 rm, rv, self.pfn_scale[slot].data_ptr(), self.pfn_shift[slot].data_ptr(),
-                                                 self.pfn_mean[slot].data_ptr(), self.pfn_invstd[slot].data_ptr(), self.ws.data_ptr(),
-                                                 self.ws.numel(), s()), "pfn_bn_stats")
+            ns, xs, wss = self._pfn_sweep_arrays()
+            _lib.check(lib.himo_pfn_bn_stats_multi(F, ns, xs, wss, net._voxel, net._centre, net.W, net.H, self.p["pfn.weight"].data_ptr(),
+                                                   g, b, spec.BN_EPS_PFN, BN_MOMENTUM, rm, rv, self.pfn_scale.data_ptr(),
+                                                   self.pfn_shift.data_ptr(), self.pfn_mean.data_ptr(), self.pfn_invstd.data_ptr(),
+                                                   self.ws.data_ptr(), self.ws.numel(), s()), "pfn_bn_stats_multi")
             net.pillar_features(sweeps, transforms, self.pfn_scale, self.pfn_shift)
         # encoder with saved activations
         src, src_bs, src_pitch = net.B0.data_ptr(), 32, 32 * F
@@ -814,16 +818,28 @@ class SeFlowTrainer:
             if stride == 2:
                 z = self.Z.data_ptr()
                 _lib.check(lib.himo_zero_stuff2x(F, ho, wo, cout, dp, ho * wo * cout, cout, z, h * w * cout, cout, s()), "zero_stuff")
-                tmp = self.TMP.data_ptr()
-                self._conv(z, h * w * cout, cout, wf, zb, tmp, h * w * cin, cin, F, h, w, cout, cin, 3, packed=wp)
                 dst = dcat[cin]                                  # fan-in: add to the decoder's skip gradient
-                for f in range(F):
-                    self._add2d(h * w, cin, tmp + 4 * f * h * w * cin, cin, dst.data_ptr() + 4 * cin * f, cin * F)
+                if self.bwd3_format == 2:                        # ... in the convolution's own epilogue (frames = channel groups of dst)
+                    self._conv(z, h * w * cout, cout, wf, zb, dst.data_ptr(), cin, cin * F, F, h, w, cout, cin, 3, packed=wp, accumulate=True)
+                else:
+                    tmp = self.TMP.data_ptr()
+                    self._conv(z, h * w * cout, cout, wf, zb, tmp, h * w * cin, cin, F, h, w, cout, cin, 3, packed=wp)
+                    for f in range(F):
+                        self._add2d(h * w, cin, tmp + 4 * f * h * w * cin, cin, dst.data_ptr() + 4 * cin * f, cin * F)
             else:
                 nxt = self.dA.data_ptr() if dy != self.dA.data_ptr() else self.dB.data_ptr()
                 self._conv(dp, ho * wo * cout, cout, wf, zb, nxt, h * w * cin, cin, F, h, w, cout, cin, 3, packed=wp)
                 dy = nxt
         # pillar feature net
+        if self._fwd_batch:                                      # the three sweeps' walks share their launches
+            ns, xs, wss = self._pfn_sweep_arrays()
+            dimg = (ctypes.c_void_p * F)(*[self.dB0.data_ptr() + 4 * 32 * slot for slot in range(F)])
+            _lib.check(lib.himo_pfn_backward_bn_multi(F, ns, xs, wss, dimg, 32 * F, net._voxel, net._centre, W, H, self.p["pfn.weight"].data_ptr(),
+                                                      self.pfn_scale.data_ptr(), self.pfn_shift.data_ptr(), self.pfn_mean.data_ptr(),
+                                                      self.pfn_invstd.data_ptr(), self.g["pfn.weight"].data_ptr(),
+                                                      self.g["pfn.bn.gamma"].data_ptr(), self.g["pfn.bn.beta"].data_ptr(), 0,
+                                                      self.ws.data_ptr(), self.ws.numel(), s()), "pfn_backward_bn_multi")
+            return
         for slot in range(F):
             if self._fwd_batch:
                 _lib.check(lib.himo_pfn_backward_bn(self.n_pts[slot], net._voxel, net._centre, W, H, self.p["pfn.weight"].data_ptr(),
@@ -839,6 +855,12 @@ class SeFlowTrainer:
                                              net.ws_slots[slot].data_ptr(), self.dB0.data_ptr() + 4 * 32 * slot, 32 * F,
                                              self.g["pfn.weight"].data_ptr(), 1 if slot else 0, self.ws.data_ptr(), self.ws.numel(), s()),
                        "pfn_backward")
+
+    def _pfn_sweep_arrays(self):
+        """host arrays of the sample's sweeps for the multi-sweep pillar-net calls: point counts, transformed points, pillar workspaces"""
+        net, F = self.net, self.net.F
+        return ((ctypes.c_int64 * F)(*self.n_pts), (ctypes.c_void_p * F)(*[net.xyz_t[k].data_ptr() for k in range(F)]),
+                (ctypes.c_void_p * F)(*[net.ws_slots[k].data_ptr() for k in range(F)]))
 
     # ---- optimiser / data parallel -----------------------------------------------------------------------------
     def sync_running_stats(self, src: int = 0):

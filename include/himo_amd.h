@@ -289,6 +289,8 @@ typedef struct himo_conv_desc {
 } himo_conv_desc;
 #define HIMO_ACT_SPLIT_IN 1
 #define HIMO_ACT_SPLIT_OUT 2
+#define HIMO_ACT_ACCUMULATE 8   /* alone: y += result instead of y = result -- float32 maps, 3x3 stride 1, packed_format HIMO_PACK_BF16X2,
+                                   bias epilogue (the training step's stride-2 data gradients add into the decoder's skip gradient in place) */
 int himo_conv2d(const himo_conv_desc* h_desc, void* stream);
 /* one-time weight preparation for the split-bf16 path: [k][k][cin][cout] float32 -> three bf16 planes */
 size_t himo_conv_packed_weight_bytes(int ksize, int cin, int cout);
@@ -587,6 +589,20 @@ int himo_bn_fold(int ch, const float* d_gamma, const float* d_beta, const float*
  *   (d_scale / d_shift: [n_sweeps][32]);
  * himo_pfn_backward_bn = himo_pfn_backward through the batch statistics, also yielding d gamma / d beta [32]. */
 size_t himo_pfn_bn_workspace_bytes(void);
+/* the same for the n_sweeps (<= 12) sweeps of a sample in one call: host arrays of per-sweep point counts, d_xyz_t and pillar
+ * workspaces (and, backward, image-gradient bases); d_scale / d_shift / d_mean / d_invstd are [n_sweeps][32]; the running statistics
+ * (forward) and d_dweight / d_dgamma / d_dbeta (backward) are updated sweep after sweep, so the results have the bits of n_sweeps single
+ * calls.  Workspace: n_sweeps * himo_pfn_bn_workspace_bytes(). */
+int himo_pfn_bn_stats_multi(int n_sweeps, const int64_t* h_n, const float* const* h_xyz_t, const void* const* h_pillar_workspace,
+                            const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
+                            const float* d_pfn_weight, const float* d_gamma, const float* d_beta, float eps, float momentum,
+                            float* d_running_mean, float* d_running_var, float* d_scale, float* d_shift, float* d_mean,
+                            float* d_invstd, void* d_workspace, size_t workspace_bytes, void* stream);
+int himo_pfn_backward_bn_multi(int n_sweeps, const int64_t* h_n, const float* const* h_xyz_t, const void* const* h_pillar_workspace,
+                               const float* const* h_dimage, int image_pitch, const float* h_voxel, const float* h_centre_offset,
+                               int grid_w, int grid_h, const float* d_pfn_weight, const float* d_scale, const float* d_shift,
+                               const float* d_mean, const float* d_invstd, float* d_dweight, float* d_dgamma, float* d_dbeta,
+                               unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);
 int himo_pfn_bn_stats(int64_t n, const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
                       const float* d_pfn_weight, const float* d_xyz_t, const void* d_pillar_workspace, const float* d_gamma,
                       const float* d_beta, float eps, float momentum, float* d_running_mean, float* d_running_var,

@@ -148,6 +148,12 @@ def test_two_term_bf16_convolution_for_the_data_gradients(gpu, stride, h, w, cin
     # scale of an output = sum of |x| |w| over its window (what the rounding errors are relative to)
     mag = F.conv2d(tx.abs(), tw.abs(), None, stride=stride, padding=1).permute(0, 2, 3, 1).numpy()
     assert (np.abs(y - ref) / mag).max() <= 2.0 ** -15
+    if stride == 1:                      # HIMO_ACT_ACCUMULATE: the same product added into an existing map, in the epilogue
+        from himo_amd.seflow.model import ACT_ACCUMULATE
+        base = rng.normal(size=y.shape).astype(np.float32)
+        out = torch.from_numpy(base.copy()).to(gpu)
+        conv2d_nhwc(*(torch.from_numpy(a).to(gpu) for a in (x, wt, b)), stride=1, precision="bf16x2", act_layout=ACT_ACCUMULATE, out=out)
+        assert np.array_equal(out.cpu().numpy(), base + y)
 
 
 @pytest.mark.parametrize("n,cin,cout", [(5000, 128, 128), (70_001, 192, 256), (33_333, 384, 64), (4096, 3, 64)])
