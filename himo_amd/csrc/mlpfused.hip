@@ -24,6 +24,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int kMlpRows = 64, kMlpHidden = 128, kMlpSlabs = kMlpHidden / 16, kMlpMaxHidden = 12;
 constexpr int kMlpPlane = kMlpSlabs * kMlpRows * 32;             // bytes per 16-bit plane of the A operand
 
+struct MlpBiasOut { float* db[16]; };                           // per hidden layer: [128]
+
 struct MlpFusedArgs {
     int64_t n;
     int n_hidden;                                               // hidden layers (128 wide): H_0 .. H_{n_hidden-1}
@@ -36,6 +38,7 @@ struct MlpFusedArgs {
     float* dZ[kMlpMaxHidden];                                   // [n][128] masked gradients at the hidden layers' outputs (backward)
     float* out;                                                 // forward: [n][4] network output
     const float* dout;                                          // backward: [n][4] gradient of the output
+    float* db_partial;                                          // backward, or NULL: [n_hidden][blocks][128] column sums of dZ_k over a block's rows
 };
 
 // A operand: [plane][slab][row][16 x 16 bit], the two 16-byte halves of a row swapped for rows 16..31 of each 32-row tile (every
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(256, 3) void mlp_backward_kernel(MlpFusedArgs a) {
         // the first layer -- hand it to the next product as the split-bf16 A operand
         const float* __restrict__ Hb = a.H[k] + r0 * kMlpHidden;
         float* __restrict__ Zb = a.dZ[k] + r0 * kMlpHidden;
+        float csum = 0.f;                                       // this lane's 32 rows of column `col`: the layer's bias gradient rides along
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             float hv[16];
@@ -201,7 +205,12 @@ __global__ __launch_bounds__(256, 3) void mlp_backward_kernel(MlpFusedArgs a) {
                 const float v = hv[r] > 0.f ? g[rt][r] : 0.f;
                 Zb[lane_off + (unsigned)((rt * 32 + (r & 3) + 8 * (r >> 2)) * kMlpHidden)] = v;
                 if (k > 0) mlp_a_store<true>(A, mlp_row(rt, r, lh), col, v);
+                csum += v;
             }
+        }
+        if (a.db_partial) {                                     // (padding rows carry zeros: d_dout's are zero and the mask keeps them so)
+            csum += __shfl_xor(csum, 32, 64);
+            if (lh == 0) a.db_partial[((int64_t)k * gridDim.x + blockIdx.x) * kMlpHidden + col] = csum;
         }
         if (k == 0) break;
         __syncthreads();                                        // A = dZ_k
@@ -211,6 +220,29 @@ __global__ __launch_bounds__(256, 3) void mlp_backward_kernel(MlpFusedArgs a) {
             for (int r = 0; r < 16; ++r) g[rt][r] = 0.f;
         mlp_gemm<true>(A, a.w_hidden[k], wave * 32, g, li, lh);         // packed W_k^T: rows = W_k's outputs, columns = its inputs
         __syncthreads();                                        // every wave has read A
+    }
+}
+
+// the bias gradients of all hidden layers from the backward kernel's block partials: block = layer, 8 groups x 128 columns, four
+// independent chains per thread, fixed-order combine
+__global__ __launch_bounds__(1024) void mlp_bias_reduce_kernel(const float* __restrict__ partial, int n_blocks, MlpBiasOut out) {
+    __shared__ float sh[8][kMlpHidden];
+    const int c = threadIdx.x & 127, grp = threadIdx.x >> 7, k = blockIdx.x;
+    const float* p = partial + (int64_t)k * n_blocks * kMlpHidden + c;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    int b = grp;
+    for (; b + 24 < n_blocks; b += 32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] += p[(int64_t)(b + 8 * q) * kMlpHidden];
+    }
+    for (; b < n_blocks; b += 8) t[0] += p[(int64_t)b * kMlpHidden];
+    sh[grp][c] = (t[0] + t[1]) + (t[2] + t[3]);
+    __syncthreads();
+    if (grp == 0) {
+        float r = sh[0][c];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) r += sh[g][c];
+        out.db[k][c] = r;
     }
 }
 
@@ -262,8 +294,30 @@ extern "C" int himo_mlp_forward_fused(int64_t n, const float* d_x0, int n_hidden
 // d_dout [n][4] = gradient of the output; hidden layer k = 1 .. n_hidden - 1: himo_mlp_repack's BACKWARD copy (W_k^T, two-term bf16);
 // h_H as written by the forward pass; h_dZ: n_hidden device pointers [n][128] (written): dZ_k = gradient at H_k, masked -- the
 // operand of layer k's weight gradient (X = H_{k-1}) and, through W_k^T, of dZ_{k-1}.
+extern "C" size_t himo_mlp_bias_workspace_bytes(int64_t n, int n_hidden) {
+    return (size_t)(n_hidden > 0 ? n_hidden : 1) * (size_t)((n + kMlpRows - 1) / kMlpRows) * kMlpHidden * 4 + 64;
+}
+
+static int mlp_backward_fused(int64_t n, const float* d_dout, int n_hidden, const void* const* h_wT_hidden_packed, const float* d_w_last,
+                              float* const* h_H, float* const* h_dZ, float* const* h_db, void* d_workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int himo_mlp_backward_fused(int64_t n, const float* d_dout, int n_hidden, const void* const* h_wT_hidden_packed,
                                        const float* d_w_last, float* const* h_H, float* const* h_dZ, void* stream) {
+    return mlp_backward_fused(n, d_dout, n_hidden, h_wT_hidden_packed, d_w_last, h_H, h_dZ, nullptr, nullptr, 0, stream);
+}
+
+// ... and the hidden layers' bias gradients h_db[k] [128] = column sums of dZ_k, collected while dZ_k passes through the kernel
+// (workspace: himo_mlp_bias_workspace_bytes(n, n_hidden)); d_dout's padding rows must be ZERO.
+extern "C" int himo_mlp_backward_fused_bias(int64_t n, const float* d_dout, int n_hidden, const void* const* h_wT_hidden_packed,
+                                            const float* d_w_last, float* const* h_H, float* const* h_dZ, float* const* h_db,
+                                            void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!h_db || !d_workspace || n_hidden > 16 || workspace_bytes < himo_mlp_bias_workspace_bytes(n, n_hidden) || !aligned16(d_workspace))
+        return HIMO_ERR_INVALID_ARGUMENT;
+    return mlp_backward_fused(n, d_dout, n_hidden, h_wT_hidden_packed, d_w_last, h_H, h_dZ, h_db, d_workspace, workspace_bytes, stream);
+}
+
+static int mlp_backward_fused(int64_t n, const float* d_dout, int n_hidden, const void* const* h_wT_hidden_packed, const float* d_w_last,
+                              float* const* h_H, float* const* h_dZ, float* const* h_db, void* d_workspace, size_t workspace_bytes, void* stream) {
     MlpFusedArgs a;
     if (!h_dZ) return HIMO_ERR_INVALID_ARGUMENT;
     const int st = mlp_fused_args(a, n, n_hidden, d_w_last /* unused slot */, nullptr, h_wT_hidden_packed, nullptr, d_w_last, nullptr, h_H);
@@ -275,9 +329,19 @@ extern "C" int himo_mlp_backward_fused(int64_t n, const float* d_dout, int n_hid
     }
     if (n == 0) return HIMO_OK;
     a.dout = d_dout;
+    MlpBiasOut bo{};
+    if (h_db) {
+        for (int k = 0; k < n_hidden; ++k) {
+            if (!h_db[k]) return HIMO_ERR_INVALID_ARGUMENT;
+            bo.db[k] = h_db[k];
+        }
+        a.db_partial = reinterpret_cast<float*>(d_workspace);
+    }
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("mlp_backward_kernel", s);
-    hipLaunchKernelGGL(mlp_backward_kernel, dim3((unsigned)((n + kMlpRows - 1) / kMlpRows)), dim3(256), 0, s, a);
+    const unsigned blocks = (unsigned)((n + kMlpRows - 1) / kMlpRows);
+    hipLaunchKernelGGL(mlp_backward_kernel, dim3(blocks), dim3(256), 0, s, a);
+    if (h_db) hipLaunchKernelGGL(mlp_bias_reduce_kernel, dim3(n_hidden), dim3(1024), 0, s, a.db_partial, (int)blocks, bo);
     HIMO_LAUNCH_CHECK("mlp_backward_kernel");
     return HIMO_OK;
 }

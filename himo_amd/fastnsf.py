@@ -59,6 +59,9 @@ _lib.register({
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "himo_mlp_backward_fused": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p]),
+    "himo_mlp_bias_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
+    "himo_mlp_backward_fused_bias": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "himo_dt_volume_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "himo_dt_build": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
@@ -186,7 +189,7 @@ class FastNSF:
         P = ctypes.c_void_p * N_HIDDEN
         hid = lambda bufs: P(*([None] + [bufs[k].data_ptr() for k in range(1, L - 1)]))
         self._fz = dict(wf=hid(self.pk_fwd), wb=hid(self.pk_bwd), bias=hid(self.b), H=P(*[h.data_ptr() for h in self.H]),
-                        dZ=P(*[z.data_ptr() for z in self.dZ]))
+                        dZ=P(*[z.data_ptr() for z in self.dZ]), gb=P(*[self.gb[k].data_ptr() for k in range(N_HIDDEN)]))
 
     def _forward(self, n):
         L = len(self.W)
@@ -240,6 +243,7 @@ class FastNSF:
             nn_ws = torch.empty(int(lib.himo_nn_grid_workspace_bytes(max(n, n1), GRID_W, GRID_H)), dtype=torch.uint8, device=dev)
             ch_ws = torch.empty(int(lib.himo_chamfer_trunc_workspace_bytes(n, n1)), dtype=torch.uint8, device=dev)
         wg_ws = torch.empty(int(lib.himo_wgrad_workspace_bytes_ex(n, HIDDEN, HIDDEN)), dtype=torch.uint8, device=dev)
+        mb_ws = torch.empty(int(lib.himo_mlp_bias_workspace_bytes(n, N_HIDDEN)), dtype=torch.uint8, device=dev)
         loss = torch.zeros(1, dtype=torch.float64, device=dev)
         self._moved, self._gmoved = moved, gmoved             # (tests read the objective's gradient)
         self.loss_history, best, stale = [], float("inf"), 0
@@ -265,14 +269,16 @@ class FastNSF:
             # backward: dZ_k is the gradient at layer k's output (post-mask for hidden layers)
             if self.fused:
                 f = self._fz
-                _lib.check(lib.himo_mlp_backward_fused(n, self.dOUT.data_ptr(), N_HIDDEN, f["wb"], self.W[L - 1].data_ptr(), f["H"], f["dZ"], s()),
-                           "himo_mlp_backward_fused")
+                # ... which also leaves the hidden layers' bias gradients (column sums of dZ_k, taken inside the kernel)
+                _lib.check(lib.himo_mlp_backward_fused_bias(n, self.dOUT.data_ptr(), N_HIDDEN, f["wb"], self.W[L - 1].data_ptr(), f["H"], f["dZ"],
+                                                            f["gb"], mb_ws.data_ptr(), mb_ws.numel(), s()), "himo_mlp_backward_fused_bias")
                 for k in range(L):
                     xk = self.X0 if k == 0 else self.H[k - 1]
                     dz = self.dOUT if k == L - 1 else self.dZ[k]
                     cin, cout = self.W[k].shape
                     _lib.check(lib.himo_linear_wgrad_ex(n, xk.data_ptr(), xk.shape[1], cin, dz.data_ptr(), dz.shape[1], cout,
-                                                        self.gW[k].data_ptr(), self.gb[k].data_ptr(), 2, wg_ws.data_ptr(), wg_ws.numel(), s()), "wgrad")
+                                                        self.gW[k].data_ptr(), self.gb[k].data_ptr() if k == L - 1 else None, 2,
+                                                        wg_ws.data_ptr(), wg_ws.numel(), s()), "wgrad")
             dz = self.dOUT
             for k in (range(L - 1, -1, -1) if not self.fused else ()):
                 xk = self.X0 if k == 0 else self.H[k - 1]

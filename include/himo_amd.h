@@ -545,6 +545,12 @@ int himo_mlp_forward_fused(int64_t n, const float* d_x0, int n_hidden, const flo
                            const float* d_b_last, float* const* h_H, float* d_out, void* stream);
 int himo_mlp_backward_fused(int64_t n, const float* d_dout, int n_hidden, const void* const* h_wT_hidden_packed,
                             const float* d_w_last, float* const* h_H, float* const* h_dZ, void* stream);
+/* the same, also yielding the hidden layers' bias gradients h_db[k] [128] (column sums of dZ_k, taken while dZ_k passes through the kernel:
+ * one reduction launch for all layers instead of a column-sum pass per layer); the padding rows of d_dout must be zero */
+size_t himo_mlp_bias_workspace_bytes(int64_t n, int n_hidden);
+int himo_mlp_backward_fused_bias(int64_t n, const float* d_dout, int n_hidden, const void* const* h_wT_hidden_packed,
+                                 const float* d_w_last, float* const* h_H, float* const* h_dZ, float* const* h_db,
+                                 void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---- FastNSF's distance-transform objective (BASELINE config 4, `model=fastnsf`, README.md:53; implementation absent from the
  * reference tree: PARITY UNPINNED, specification in csrc/dtloss.hip / himo_amd/fastnsf.py).  himo_dt_build: ONCE per sweep pair, the
