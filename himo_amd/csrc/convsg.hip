@@ -31,7 +31,6 @@
 // Specification / oracle as conv.hip (reference network absent: PARITY UNPINNED).
 #include "conv_common.h"
 #include "bf16x3.h"
-#include <algorithm>
 
 namespace himo {
 
@@ -286,117 +285,6 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     }
 }
 
-// ---- enc1.0 (3x3, stride 2, 32 -> 64 channels): activation fragments STRAIGHT FROM GLOBAL MEMORY, weights resident in LDS ------------
-// profiles/r03_exp_stride2_phase_breakdown.txt: in the LDS-DMA kernel above this layer's fetch, matrix and store phases add up (878 us per
-// 16 samples where the fetch alone takes 487): the bytes in flight per CU are bounded by the LDS the resident blocks hold times the share of
-// a block's life spent fetching.  This layer has 54 matrix instructions per wave and tile -- nothing an LDS patch could be reused for -- so
-// here nothing is staged at all: a lane's A operand of a tap (8 channels of one input pixel = 16 bytes of its split record, high plane and
-// low plane) is one global_load_dwordx4 into registers, one (slab, kernel row) group ahead of its matrix instructions, across tile
-// boundaries and under the epilogue; the only LDS is the layer's whole packed weight tensor (73.7 KB, staged once per persistent block,
-// rows swizzled so a 16-lane read phase covers the banks once) and the epilogue's 4 KB per wave.  A wave = one output row segment of 32
-// pixels x all 64 channels; same summation order per accumulator as the kernel above (slab, ky, kx, terms l*h, h*l, h*h): identical bits.
-template <int EPI, bool OSPLIT>
-__global__ __launch_bounds__(512, 1) void conv3s2_c32_direct_kernel(ConvArgs a, const unsigned short* __restrict__ wpk, int n_tiles) {
-    constexpr int kW = 9 * 2 * 2 * 64 * 32;                      // bytes of packed weights: [tap][slab][plane][64 co][16 ci] fp16
-    __shared__ __attribute__((aligned(16))) unsigned char wl[kW];
-    __shared__ __attribute__((aligned(1024))) unsigned char stg_all[8 * 4096];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int li = lane & 31, lh = lane >> 5;
-    // weights -> LDS: piece (row co, half h) of a [64][16] block goes to co * 32 + ((h ^ ((co >> 3) & 1)) << 4)
-    for (int e = threadIdx.x; e < kW / 16; e += 512) {
-        const int h = e & 1, co = (e >> 1) & 63, blk = e >> 7;
-        *reinterpret_cast<uint4*>(&wl[blk * 2048 + co * 32 + ((h ^ ((co >> 3) & 1)) << 4)]) =
-            *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(wpk) + (size_t)e * 16);
-    }
-    __syncthreads();
-    unsigned char* stg = stg_all + wave * 4096;
-    const int tx = a.Wo / 32;
-    const int b_off[2] = {li * 32 + ((lh ^ ((li >> 3) & 1)) << 4), (32 + li) * 32 + ((lh ^ (((32 + li) >> 3) & 1)) << 4)};   // column tiles 0, 1
-    float eA[2], eB[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int c = nt * 32 + li;
-        epi_affine<EPI>(kF16AccScale, a.bias ? a.bias[c] : 0.f, EPI == kEpiBiasBnGelu ? a.scale[c] : 1.f, EPI == kEpiBiasBnGelu ? a.shift[c] : 0.f,
-                        eA[nt], eB[nt]);
-    }
-    const unsigned char* zero = g_zero_page;
-    // a group = (slab, kernel row): three taps x two planes = six 16-byte loads per lane
-    const unsigned char* ap[3][3];                               // this tile's nine tap addresses (slab 0, high plane, this lane's k half)
-    auto tile_addr = [&](int t) {
-        const int ox0 = (t % tx) * 32;
-        const int rem = t / tx;
-        const int oy = rem % a.Ho, img = rem / a.Ho;
-        const unsigned char* xin = reinterpret_cast<const unsigned char*>(a.x + image_offset(img, a.n_inner, a.x_batch_stride, a.x_outer_stride));
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = 2 * oy + ky - 1;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = 2 * (ox0 + li) + kx - 1;
-                const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                ap[ky][kx] = ok ? xin + ((unsigned)(iy * a.W + ix) * (unsigned)a.x_pitch) * 4u + lh * 16 : zero + lh * 16;
-            }
-        }
-    };
-    // the fragments of TWO groups ahead stay in flight (three register sets in rotation; the tile's six groups unroll, so the rotation
-    // is a renaming): with one group ahead a wave had 6 KB outstanding and the layer ran at 2.4 TB/s
-    uint4 fr[3][3][2];
-    auto fetch = [&](int slab, int ky, uint4 (&f)[3][2]) {
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const bool live = ap[ky][kx] != zero + lh * 16;       // (the zero page is one 64-byte record: no slab offset)
-            const unsigned char* p = ap[ky][kx] + (live ? slab * 64 : 0);
-            f[kx][0] = *reinterpret_cast<const uint4*>(p);
-            f[kx][1] = *reinterpret_cast<const uint4*>(p + 32);
-        }
-    };
-    int t = (int)blockIdx.x * 8 + wave;
-    const int t_step = (int)gridDim.x * 8;
-    if (t < n_tiles) { tile_addr(t); fetch(0, 0, fr[0]); fetch(0, 1, fr[1]); }
-    for (; t < n_tiles; t += t_step) {
-        floatx16 acc[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-        const int ox0 = (t % tx) * 32, rem = t / tx, oy = rem % a.Ho, img = rem / a.Ho;
-        const bool more = t + t_step < n_tiles;
-#pragma unroll
-        for (int g = 0; g < 6; ++g) {
-            const int slab = g / 3, ky = g % 3;
-            // group g + 2 (of this tile, or the next tile's group g - 4: its addresses replace this tile's once group 5's loads are out)
-            if (g < 4) fetch((g + 2) / 3, (g + 2) % 3, fr[(g + 2) % 3]);
-            else if (more) { if (g == 4) tile_addr(t + t_step); fetch(0, g - 4, fr[(g + 2) % 3]); }
-            const uint4 (&cur)[3][2] = fr[g % 3];
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const unsigned char* wb = &wl[((ky * 3 + kx) * 2 + slab) * 4096];           // [plane][64][32 bytes]
-                uint4 b[2][2];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) b[nt][pl] = *reinterpret_cast<const uint4*>(wb + pl * 2048 + b_off[nt]);
-#define HIMO_TERM16(SA, SB)                                                                                                   \
-    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                                            \
-        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, cur[kx][SA]), __builtin_bit_cast(f16x8, b[nt][SB]), acc[nt], 0, 0, 0);
-                HIMO_TERM16(1, 0) HIMO_TERM16(0, 1) HIMO_TERM16(0, 0)
-#undef HIMO_TERM16
-            }
-        }
-        float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            unsigned word[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = epi_activate<EPI>(acc[nt][r], eA[nt], eB[nt]);
-                word[r] = OSPLIT ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
-            }
-            store_block_vec<OSPLIT>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, 32, nt * 32);
-        }
-    }
-}
-
 // 1x1 layers (row GEMMs over the pixels of an image) on the same structure: a block owns TH = MI * PH segments of 32
 // consecutive pixels, two 16-channel slabs are staged per barrier step, weight fragments run one slab ahead in two
 // register sets.  Same summation order as convbf.hip's row GEMM (slab by slab, terms l*h, h*l, h*h): identical bits.
@@ -592,26 +480,6 @@ bool launch_conv3_presplit(const ConvArgs& a, int epilogue, const void* w_packed
     if ((int64_t)a.H * a.W * a.x_pitch * 4 >= (int64_t)1 << 31) return false;       // 32-bit DMA source offsets
     const bool wide = a.Cout > 64;
     const int bn = wide ? 128 : 64, ph = wide ? 1 : 2;
-#ifndef HIMO_EXP_NODIRECT
-    if (stride == 2 && a.Cin == 32 && a.Cout == 64 && !(a.Wo & 31) && a.W == 2 * a.Wo && a.H == 2 * a.Ho && vec_store_ok(a) &&
-        (int64_t)a.N * a.Ho * (a.Wo / 32) < ((int64_t)1 << 31)) {
-        // the two-slab layer (enc1.0): fragments straight from global memory, weights resident in LDS, persistent blocks of 8 waves
-        ConvArgs b = a;
-        b.act_flags |= kActVecStore;
-        const int n_tiles = (int)((int64_t)a.N * a.Ho * (a.Wo / 32));
-        const dim3 grid((unsigned)std::min(256, (n_tiles + 7) / 8));
-        ProfScope ps("conv3x3s2_f16x2_kernel", s);
-        const unsigned short* w = (const unsigned short*)w_packed;
-        if (epilogue == kEpiBias) {
-            if (out_split) hipLaunchKernelGGL((conv3s2_c32_direct_kernel<kEpiBias, true>), grid, dim3(512), 0, s, b, w, n_tiles);
-            else hipLaunchKernelGGL((conv3s2_c32_direct_kernel<kEpiBias, false>), grid, dim3(512), 0, s, b, w, n_tiles);
-        } else {
-            if (out_split) hipLaunchKernelGGL((conv3s2_c32_direct_kernel<kEpiBiasBnGelu, true>), grid, dim3(512), 0, s, b, w, n_tiles);
-            else hipLaunchKernelGGL((conv3s2_c32_direct_kernel<kEpiBiasBnGelu, false>), grid, dim3(512), 0, s, b, w, n_tiles);
-        }
-        return true;
-    }
-#endif
     if (stride == 2) {                                  // two output rows per block: a 5-row x 80-slot patch, double-buffered
         const int64_t blocks = (int64_t)a.N * ((a.Ho + 1) / 2) * ((a.Wo + 31) / 32) * ((a.Cout + bn - 1) / bn);
         ProfScope ps("conv3x3s2_f16x2_kernel", s);
