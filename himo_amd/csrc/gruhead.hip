@@ -548,12 +548,13 @@ extern "C" int himo_gru_head_train(int64_t n, const int32_t* d_pid, const float*
         return HIMO_ERR_INVALID_ARGUMENT;
     if (n == 0) return HIMO_OK;
     if (!d_pid || !d_offsets || !d_img0 || !d_img1 || !d_dec) return HIMO_ERR_INVALID_ARGUMENT;
-    if ((n + 63) / 64 * 64 * 768 >= ((int64_t)1 << 32)) return HIMO_ERR_UNSUPPORTED;      // 32-bit byte offsets inside a saved tensor
+    if (h_saved && h_saved->rows * 768 >= ((int64_t)1 << 32)) return HIMO_ERR_UNSUPPORTED;      // 32-bit byte offsets inside a saved tensor
     GruHeadSave sv{};
     sv.hx = h_saved->d_hx; sv.rhx = h_saved->d_rhx; sv.z = h_saved->d_z; sv.r = h_saved->d_r; sv.q = h_saved->d_q;
     sv.pre1 = h_saved->d_pre1; sv.y1 = h_saved->d_y1; sv.res = h_saved->d_res;
-    sv.rows = (n + 63) / 64 * 64;
-    if (!sv.hx || !sv.rhx || !sv.z || !sv.r || !sv.q || !sv.pre1 || !sv.y1 || !sv.res || h_saved->rows != sv.rows) return HIMO_ERR_INVALID_ARGUMENT;
+    sv.rows = h_saved->rows;                                   // the iteration stride: >= ceil(n / 64) * 64 (a caller may keep capacity)
+    if (!sv.hx || !sv.rhx || !sv.z || !sv.r || !sv.q || !sv.pre1 || !sv.y1 || !sv.res || sv.rows < (n + 63) / 64 * 64 || (sv.rows & 63))
+        return HIMO_ERR_INVALID_ARGUMENT;
     GruHeadBatch b{};
     b.n_samples = 1;
     GruHeadSample& g = b.s[0];

@@ -202,8 +202,8 @@ extern "C" int himo_gru_head_backward(int64_t n, int iters, const float* d_dhx_l
                                       float* d_dazr, float* d_dhx0, void* stream) {
     if (n < 0 || iters < 1 || iters > 4 || !h_saved || !(packed_format == 0 || packed_format == 2)) return HIMO_ERR_INVALID_ARGUMENT;
     if (n == 0) return HIMO_OK;
-    const int64_t rows = (n + 63) / 64 * 64;
-    if (!d_dhx_last || !d_wq_t_packed || !d_wzr_t_packed || !d_daq || !d_dazr || !d_dhx0 || h_saved->rows != rows || !h_saved->d_hx ||
+    const int64_t rows = h_saved->rows;                          // the iteration stride: >= ceil(n / 64) * 64
+    if (!d_dhx_last || !d_wq_t_packed || !d_wzr_t_packed || !d_daq || !d_dazr || !d_dhx0 || rows < (n + 63) / 64 * 64 || (rows & 63) || !h_saved->d_hx ||
         !h_saved->d_z || !h_saved->d_r || !h_saved->d_q)
         return HIMO_ERR_INVALID_ARGUMENT;
     if ((reinterpret_cast<uintptr_t>(d_wq_t_packed) | reinterpret_cast<uintptr_t>(d_wzr_t_packed)) & 15) return HIMO_ERR_INVALID_ARGUMENT;
@@ -215,7 +215,7 @@ extern "C" int himo_gru_head_backward(int64_t n, int iters, const float* d_dhx_l
     a.daq = d_daq; a.dazr = d_dazr; a.dhx0 = d_dhx0;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("gru_head_bwd_kernel", s);
-    const dim3 grid((unsigned)(rows / kHbRows));
+    const dim3 grid((unsigned)((n + 63) / 64 * 64 / kHbRows));       // whole 64-row blocks of the n points (rows beyond: the caller's business)
     if (packed_format == 2) hipLaunchKernelGGL(gru_head_bwd_kernel<2>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(gru_head_bwd_kernel<3>, grid, dim3(256), 0, s, a);
     HIMO_LAUNCH_CHECK("gru_head_bwd_kernel");

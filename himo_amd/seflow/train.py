@@ -133,6 +133,7 @@ class HeadTrainer:
         else:
             self.p, self.g = p, g
         self.n = 0
+        self.rows = 0
         self._descs = {}
         self.WT = {k: torch.empty((v.shape[1], v.shape[0]), dtype=torch.float32, device=dev) for k, v in self.p.items() if v.dim() == 2}
         pk = lambda cin, cout: torch.empty(int(self.lib.himo_conv_packed_weight_bytes(1, cin, cout)), dtype=torch.uint8, device=dev)
@@ -156,32 +157,40 @@ class HeadTrainer:
         return jobs
 
     def _reserve(self, n):
+        """Buffers for n points.  Capacity only grows (real sweeps differ in size from sample to sample: reallocating ~2 GB of states per
+        step would cost more than the step's head): the stacked tensors keep ``self.rows`` = the capacity as their iteration stride and
+        the lists are views of the first n rows."""
         if n == self.n:
             return
         dev, T = self.device, spec.GRU_ITERS
-        buf = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        need_rows = (n + 63) // 64 * 64
+        if need_rows > self.rows:
+            rows = self.rows = (int(need_rows * 1.125) + 63) // 64 * 64 if self.rows else need_rows      # headroom once it has had to grow
+            buf = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+            zbuf = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)      # (the unfused forward never writes the padding rows)
+            # saved states: iterations stacked, rows padded to whole 64-row blocks (the fused forward writes whole blocks: himo_gru_head_train)
+            self._HX, self._RHX = zbuf(T + 1, rows, 192), zbuf(T, rows, 192)
+            self._Z, self._R, self._Q = zbuf(T, rows, 128), zbuf(T, rows, 128), zbuf(T, rows, 128)
+            self._PRE1, self._Y1, self._RES = buf(rows, 32), buf(rows, 32), buf(rows, 4)
+            self._AZR, self._AQ, self._A1 = buf(rows, 256), buf(rows, 128), buf(rows, 32)
+            # backward scratch (the fused sweep's buffers are padded like the saved states; zeros in the padding of its input and outputs)
+            self._DHX = zbuf(rows, 192)
+            self._DAQ, self._DAZR, self._DHX0 = zbuf(T, rows, 128), zbuf(T, rows, 256), buf(rows, 192)
+            self._DY1, self._DRHX = buf(rows, 32), buf(rows, 192)
+            self._DH, self._DHP, self._DZ, self._DAQ1, self._DAZR1 = buf(rows, 128), buf(rows, 128), buf(rows, 128), buf(rows, 128), buf(rows, 256)
+            self._DX = buf(rows, 64)
+            self.ws = torch.empty(int(self.lib.himo_wgrad_workspace_bytes_ex(T * rows, 192, 256)), dtype=torch.uint8, device=dev)
+            self._dirty = 0                              # rows of _DAQ / _DAZR / _DHX that may hold a previous sample's values
+            self._descs.clear()
         self.n = n
-        # saved states: iterations stacked, rows padded to whole 64-row blocks (the fused forward writes whole blocks:
-        # himo_gru_head_train); the lists are views of the first n rows
-        rows = self.rows = (n + 63) // 64 * 64
-        zbuf = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)      # (the unfused forward never writes the padding rows)
-        self._HX, self._RHX = zbuf(T + 1, rows, 192), zbuf(T, rows, 192)
-        self._Z, self._R, self._Q = zbuf(T, rows, 128), zbuf(T, rows, 128), zbuf(T, rows, 128)
-        self._PRE1, self._Y1, self._RES = buf(rows, 32), buf(rows, 32), buf(rows, 4)
         self.HX = [self._HX[t, :n] for t in range(T + 1)]
         self.RHX = [self._RHX[t, :n] for t in range(T)]
         self.Z, self.R, self.Q = ([x[t, :n] for t in range(T)] for x in (self._Z, self._R, self._Q))
-        self.AZR, self.AQ = buf(n, 256), buf(n, 128)
+        self.AZR, self.AQ, self.A1 = self._AZR[:n], self._AQ[:n], self._A1[:n]
         self.PRE1, self.Y1, self.RES = self._PRE1[:n], self._Y1[:n], self._RES[:n]
-        self.A1 = buf(n, 32)
-        # backward scratch (the fused sweep's buffers are padded like the saved states; zeros in the padding of its input)
-        self._DHX = torch.zeros((rows, 192), dtype=torch.float32, device=dev)
-        self._DAQ, self._DAZR, self._DHX0 = buf(T, rows, 128), buf(T, rows, 256), buf(rows, 192)
-        self.DY1, self.DHX, self.DRHX = buf(n, 32), self._DHX[:n], buf(n, 192)
-        self.DH, self.DHP, self.DZ, self.DAQ, self.DAZR = buf(n, 128), buf(n, 128), buf(n, 128), buf(n, 128), buf(n, 256)
-        self.DX = buf(n, 64)
-        need = int(self.lib.himo_wgrad_workspace_bytes_ex(T * rows, 192, 256))
-        self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        self.DY1, self.DHX, self.DRHX = self._DY1[:n], self._DHX[:n], self._DRHX[:n]
+        self.DH, self.DHP, self.DZ, self.DAQ, self.DAZR = self._DH[:n], self._DHP[:n], self._DZ[:n], self._DAQ1[:n], self._DAZR1[:n]
+        self.DX = self._DX[:n]
 
     def _pack(self, w, buf, fmt):
         _lib.check(self.lib.himo_conv_pack_weights_ex(w.data_ptr(), 1, w.shape[0], w.shape[1], fmt, buf.data_ptr(), _lib.stream_handle()), "pack")
@@ -249,18 +258,27 @@ class HeadTrainer:
         """The GRU iterations' backward sweep as one launch (csrc/gruheadbwd.hip) + ONE weight-gradient product per matrix over the
         stacked iterations (rows of all T iterations; the sweep leaves zeros in the padding rows of the gate gradients)."""
         T, n = spec.GRU_ITERS, self.n
+        n_pad = (n + 63) // 64 * 64
         sv = self._saved()
         if not self.external_pack:
             for k in ("q", "zr"):
                 self._transposed_packed(k)
+        if n_pad < self._dirty:                          # a larger sample left gate gradients behind the rows this sweep writes
+            self._DAQ[:, n_pad:self._dirty].zero_()
+            self._DAZR[:, n_pad:self._dirty].zero_()
+        self._dirty = n_pad
         _lib.check(self.lib.himo_gru_head_backward(n, T, self._DHX.data_ptr(), ctypes.byref(sv), self.PKT["q"].data_ptr(),
                                                    self.PKT["zr"].data_ptr(), self.fmt_bwd, self._DAQ.data_ptr(), self._DAZR.data_ptr(),
                                                    self._DHX0.data_ptr(), _lib.stream_handle()), "himo_gru_head_backward")
-        rows = T * self.rows
+        if self.rows <= n_pad + n_pad // 4:              # one product per matrix over the stacked iterations (zeros in the padding rows)
+            runs = [(T * self.rows, 0, 0)]
+        else:                                            # a much smaller sample than the capacity: iteration by iteration, n rows each
+            runs = [(n, t, 1 if t else 0) for t in range(T)]
         for name, x, dz, cout in (("q", self._RHX, self._DAQ, 128), ("zr", self._HX, self._DAZR, 256)):
-            _lib.check(self.lib.himo_linear_wgrad_ex(rows, x.data_ptr(), 192, 192, dz.data_ptr(), cout, cout, self.g[f"{name}.weight"].data_ptr(),
-                                                     self.g[f"{name}.bias"].data_ptr(), self.wgrad_flags, self.ws.data_ptr(), self.ws.numel(),
-                                                     _lib.stream_handle()), "wgrad")
+            for rows, t, acc in runs:
+                _lib.check(self.lib.himo_linear_wgrad_ex(rows, x[t].data_ptr(), 192, 192, dz[t].data_ptr(), cout, cout,
+                                                         self.g[f"{name}.weight"].data_ptr(), self.g[f"{name}.bias"].data_ptr(),
+                                                         self.wgrad_flags | acc, self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle()), "wgrad")
         return self._DHX0[:n]
 
     def _saved(self):

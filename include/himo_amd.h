@@ -375,11 +375,12 @@ int himo_gru_head_batch_guarded(int n_samples, const himo_head_sample* h_samples
 /* The head's TRAINING forward in one launch (BASELINE config 5; csrc/gruhead.hip with its saves enabled): gather -> `iters` (<= 4) GRU
  * iterations -> Linear(192,32) + GELU -> Linear(32,3), the explicit-x form of himo_gru_head_batch, writing the network's RESIDUAL flow
  * d_res [rows][4] (zeros for dropped points and in column 3) and every tensor the backward pass reads.  All saved buffers have
- * rows = ceil(n / 64) * 64 rows per iteration.  d_w2 is [32][w2_pitch], w2_pitch 3 or 4.  Replaces, in the trainer, himo_head_gather + 2 * iters row
+ * h_saved->rows rows per iteration, a multiple of 64 >= ceil(n / 64) * 64 (a caller may keep capacity beyond the current sweep).  d_w2 is [32][w2_pitch], w2_pitch 3 or 4.  Replaces, in the trainer, himo_head_gather + 2 * iters row
  * products (himo_conv2d) + 2 * iters gate kernels (himo_gru_gates_fwd) + the decoder.  Spec: himo_amd/seflow/spec.py steps 5-6
  * (reference model source absent: PARITY UNPINNED). */
 typedef struct himo_head_saved {
-    int64_t rows;              /* ceil(n / 64) * 64: the row count of every buffer below; iterations are stacked */
+    int64_t rows;              /* the row count of every buffer below = the stride between the stacked iterations: a multiple of 64,
+                                  >= ceil(n / 64) * 64 */
     float* d_hx;               /* [iters + 1][rows][192]  [h_t | x], t = 0 .. iters */
     float* d_rhx;              /* [iters][rows][192]      [r_t h_t | x] */
     float* d_z; float* d_r; float* d_q;               /* [iters][rows][128] */
@@ -394,7 +395,7 @@ int himo_gru_head_train(int64_t n, const int32_t* d_pid, const float* d_offsets,
 /* Backpropagation through the head's GRU iterations in one launch (csrc/gruheadbwd.hip): d_dhx_last [rows][192] = d loss / d [h_T | x]
  * (from the decoder's backward) and the states himo_gru_head_train saved -> d_daq [iters][rows][128], d_dazr [iters][rows][256] (the gate
  * pre-activation gradients: the dz operands of the q / z|r weight-gradient products, zero in the padding rows) and d_dhx0 [rows][192] =
- * d loss / d [h_0 | x].  rows = h_saved->rows = ceil(n / 64) * 64 for every buffer.  d_wq_t_packed / d_wzr_t_packed =
+ * d loss / d [h_0 | x].  Every buffer has h_saved->rows rows (per iteration); the sweep writes whole 64-row blocks of the n points.  d_wq_t_packed / d_wzr_t_packed =
  * himo_weight_prepare_batch's flipped copies (ksize 1: the transposes) of q [192][128] and zr [192][256], packed_format
  * HIMO_PACK_BF16X3 or HIMO_PACK_BF16X2.  Replaces gru_bwd1/2/3 + two himo_conv2d row products per iteration. */
 int himo_gru_head_backward(int64_t n, int iters, const float* d_dhx_last, const himo_head_saved* h_saved,

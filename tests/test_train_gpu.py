@@ -467,3 +467,38 @@ def test_fused_training_head_matches_the_unfused_path(gpu, precision, n):
     np.testing.assert_allclose(db, da, rtol=0, atol=2e-4 * max(1.0, float(np.abs(da).max())))
     for k in ga:
         np.testing.assert_allclose(gb[k], ga[k], rtol=0, atol=2e-4 * max(1.0, float(np.abs(ga[k]).max())), err_msg=k)
+
+
+def test_head_trainer_reuses_its_buffers_across_sweep_sizes(gpu):
+    """One HeadTrainer fed sweeps of 5000, 3000, 700 and 5200 points (capacity only grows; the stacked weight-gradient products read the
+    padding rows): every call gives what a fresh trainer gives for that sweep -- nothing of a larger earlier sweep leaks in."""
+    from himo_amd import _lib
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.train import HeadTrainer
+    params = spec.init_params(4)
+    rng = np.random.default_rng(2)
+    H = W = 32
+    B0 = torch.from_numpy(rng.standard_normal((H * W, 96)).astype(np.float32)).to(gpu)
+    DEC = torch.from_numpy(rng.standard_normal((H * W, 64)).astype(np.float32)).to(gpu)
+    w_off = torch.from_numpy(params["head.offset.weight"]).to(gpu)
+    b_off = torch.from_numpy(params["head.offset.bias"]).to(gpu)
+
+    def run(ht, n, seed):
+        r = np.random.default_rng(seed)
+        pid = torch.from_numpy(r.integers(0, H * W, n).astype(np.int32)).to(gpu)
+        off = torch.from_numpy((r.standard_normal((n, 3)) * 0.1).astype(np.float32)).to(gpu)
+        res = ht.forward_fused(n, pid.data_ptr(), off.data_ptr(), B0.data_ptr() + 128, B0.data_ptr() + 256, 96, DEC.data_ptr(), 64,
+                               w_off.data_ptr(), b_off.data_ptr()).clone()
+        dres = torch.from_numpy(r.standard_normal((n, 4)).astype(np.float32)).to(gpu)
+        dres[:, 3] = 0
+        d0 = ht.backward(dres).clone()
+        torch.cuda.synchronize()
+        return res.cpu().numpy(), d0.cpu().numpy(), {k: v.cpu().numpy().copy() for k, v in ht.g.items()}
+
+    shared = HeadTrainer(params, device=gpu, precision="mixed")
+    for seed, n in enumerate((5000, 3000, 700, 5200)):
+        got = run(shared, n, seed)
+        want = run(HeadTrainer(params, device=gpu, precision="mixed"), n, seed)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), n
+        for k in want[2]:
+            np.testing.assert_allclose(got[2][k], want[2][k], rtol=0, atol=1e-6 * max(1.0, float(np.abs(want[2][k]).max())), err_msg=f"{k} n={n}")
