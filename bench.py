@@ -631,6 +631,8 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
             extra = extra_precision_legs(args, params, sets, device, ref_flow, exclude=args.precision)
         if world == 1 and not args.no_extra_workloads:
             extra.update(extra_workload_legs(args, device))
+        if world == 1 and not args.no_extra_precisions and args.precision == "f16x2":
+            extra.update(two_stream_leg(args, params, sets, device))
     line = {
         "metric": "lidar_frames_per_sec_120k", "value": total_frames / elapsed, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -836,6 +838,40 @@ def extra_workload_legs(args, device) -> dict:
         step = obj = result = None
         torch.cuda.empty_cache()
     return out
+
+
+def two_stream_leg(args, params, sets, device) -> dict:
+    """N = 1 only, after the timed region: the SAME workload with TWO batches in flight -- two pipelines (own network buffers, 2 x 16 GB)
+    fed alternately on two HIP streams -- so that one batch's latency-bound stages (pillar stage, stride-2 / 1x1 layers, upsampling, the
+    head's gather) overlap the other's matrix-bound convolutions.  Reported beside ``value`` (``value_two_streams``), not as it: with two
+    streams the per-launch HIP-event time of the roofline kernel includes whatever co-runs, and ``roofline`` is a statement about
+    that kernel alone."""
+    import torch
+    from himo_amd.pipeline import HiMoPipeline
+    from himo_amd.seflow.model import SeFlowNet
+    B, P = args.frames_per_step, args.points
+    pipes = [HiMoPipeline(SeFlowNet(params, device=device, max_points=P, precision="f16x2", max_batch=B), device=device) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+
+    def run(steps):
+        for i in range(steps):
+            with torch.cuda.stream(streams[i % 2]):
+                pipes[i % 2].run(sets[i % len(sets)], sensor_dt=0.1, refined=args.refined)
+        for p in pipes:
+            p.sync_check()
+        torch.cuda.synchronize()
+
+    run(6)                                                      # priming: autotune, plans
+    run(4)
+    steps = max(8, args.steps // 2 * 2)
+    t0 = time.perf_counter()
+    run(steps)
+    el = time.perf_counter() - t0
+    leg = {"frames_per_s": B * steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "streams": 2,
+           "note": "two batches in flight on two HIP streams (two pipelines, own buffers); same kernels, same results"}
+    del pipes
+    torch.cuda.empty_cache()
+    return {"value_two_streams": leg["frames_per_s"], "leg_two_streams": leg}
 
 
 def extra_precision_legs(args, params, sets, device, ref_flow, exclude: str) -> dict:
