@@ -861,14 +861,19 @@ def two_stream_leg(args, params, sets, device) -> dict:
             p.sync_check()
         torch.cuda.synchronize()
 
+    from himo_amd import _lib
     run(6)                                                      # priming: autotune, plans
     run(4)
     steps = max(8, args.steps // 2 * 2)
+    _lib.prof_start(only="conv3x3_f16x2_kernel")                # the roofline kernel's launches, each on its own stream
     t0 = time.perf_counter()
     run(steps)
     el = time.perf_counter() - t0
+    k = _lib.prof_stop().get("conv3x3_f16x2_kernel", {})
     leg = {"frames_per_s": B * steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "streams": 2,
-           "note": "two batches in flight on two HIP streams (two pipelines, own buffers); same kernels, same results"}
+           "roofline_kernel_avg_launch_ms": k.get("avg_ms"),
+           "note": "two batches in flight on two HIP streams (two pipelines, own buffers); same kernels, same results; the roofline kernel's "
+                   "launch time here includes whatever the other stream co-runs"}
     del pipes
     torch.cuda.empty_cache()
     return {"value_two_streams": leg["frames_per_s"], "leg_two_streams": leg}
