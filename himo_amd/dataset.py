@@ -11,13 +11,16 @@ taken from the in-tree writers and consumers only:
     (lists of ``[scene_id, timestamp]``, tools/pkl_extract.py:5-19).
 ``pose1`` is the pose of the next timestamp in the same scene (the flow is pc0 -> pc1).
 
-``h5py`` is not installed in the build image; ``HDF5Dataset`` raises ImportError with that message
-rather than guessing (its index / successor / key-renaming logic is exercised through the ``opener`` hook with an
-in-memory scene mapping, and against real files wherever h5py exists: tests/test_dataset.py).  ``NpzDataset`` is this
-package's own container for the same dicts.
+``h5py`` is not installed in the build image, so the scene files are opened with ``h5py`` when it is importable and with
+this package's own dependency-free reader otherwise (``h5lite``: pinned against files written by the real HDF5 library,
+tests/test_h5lite.py, tests/golden/h5).  Results a run could not put INTO a scene file (no HDF5 library to modify it with)
+live in a result file beside it -- ``<dir>/results_h5/<res_name>/<scene_id>.h5``, same ``<timestamp>/<res_name>`` layout,
+written by ``save.H5ResultSink`` -- and the loader looks there when the scene file does not hold ``<res_name>``.
+``NpzDataset`` is this package's own container for the same dicts.
 """
 from __future__ import annotations
 
+import os
 import pickle
 from pathlib import Path
 
@@ -72,17 +75,27 @@ class NpzDataset:
                 pickle.dump([index[i] for i in eval_subset], fh)
 
 
-def require_h5py():
+def h5_reader():
+    """The module that opens scene files read-only: ``h5py`` when importable, else this package's ``h5lite``."""
     try:
         import h5py
-    except ImportError as e:
-        raise ImportError("the .h5 scene files need h5py, which is not installed in this image; "
-                          "use NpzDataset / SyntheticDataset, or install h5py on the target box") from e
-    return h5py
+        return h5py
+    except ImportError:
+        from . import h5lite
+        return h5lite
 
 
 def _open_h5(path):
-    return require_h5py().File(path, "r")
+    return h5_reader().File(path, "r")
+
+
+def result_file(directory, res_name: str, scene_id: str) -> Path:
+    """Where a scene's ``<res_name>`` results live when they could not be written into ``<scene_id>.h5`` itself."""
+    return Path(directory) / "results_h5" / res_name / f"{scene_id}.h5"
+
+
+def allow_dropped_eval_default() -> bool:
+    return os.environ.get("HIMO_ALLOW_DROPPED_EVAL", "0") not in ("", "0", "false", "False")
 
 
 def load_index(directory, eval: bool = False) -> list:  # noqa: A002
@@ -102,13 +115,14 @@ class HDF5Dataset:
     (the last sweep of a scene) has no ``pose1`` to remove ego motion with (save_zip.py:115), so it is dropped from the
     index at construction -- iterating the dataset never yields a frame the consumers cannot process.
     ``opener(path)`` returns the scene file as a read-only mapping ``{timestamp: {name: array-like}}`` usable as a context
-    manager; the default is ``h5py.File(path, "r")`` (ImportError with a clear message when h5py is absent)."""
+    manager; the default is ``h5py.File(path, "r")``, or ``h5lite.File(path)`` where h5py is not installed.
+    ``allow_dropped_eval`` (default: env ``HIMO_ALLOW_DROPPED_EVAL``, else False): see the KeyError below."""
 
     def __init__(self, directory, vis_name="", eval: bool = False, n_frames: int = 2, opener=None,  # noqa: A002
-                 allow_dropped_eval: bool = False):
+                 allow_dropped_eval: bool | None = None):
         self._open = opener if opener is not None else _open_h5
-        if opener is None:
-            require_h5py()                                   # fail at construction, not at the first frame
+        if allow_dropped_eval is None:
+            allow_dropped_eval = allow_dropped_eval_default()
         self.directory = Path(directory)
         self.vis_name = list(vis_name) if isinstance(vis_name, (list, tuple)) else [vis_name]
         total = load_index(self.directory, eval=False)
@@ -128,7 +142,7 @@ class HDF5Dataset:
             msg = (f"{len(self.dropped)} of {len(wanted)} index entries have no successor sweep in their scene and cannot be "
                    f"processed: {self.dropped[:5]}{' ...' if len(self.dropped) > 5 else ''}")
             if from_eval_list and not allow_dropped_eval:
-                raise KeyError("pose1: " + msg + " (index_eval.pkl names them; pass allow_dropped_eval=True to skip them)")
+                raise KeyError("pose1: " + msg + " (index_eval.pkl names them; pass allow_dropped_eval=True / --allow_dropped_eval / HIMO_ALLOW_DROPPED_EVAL=1 to skip them)")
             import warnings
             warnings.warn(msg, stacklevel=2)
 
@@ -150,8 +164,15 @@ class HDF5Dataset:
                 if k in g:
                     d[k] = np.asarray(g[k][:])
             for name in self.vis_name:
-                if name and name != "raw" and name in g:
-                    d[name] = np.asarray(g[name][:])
+                if name and name != "raw":
+                    if name in g:
+                        d[name] = np.asarray(g[name][:])
+                    else:                                      # a run that could not modify the scene file wrote beside it
+                        side = result_file(self.directory, name, scene_id)
+                        if side.exists():
+                            with self._open(side) as r:
+                                if ts in r and name in r[ts]:
+                                    d[name] = np.asarray(r[ts][name][:])
             nxt = f[self._next[(scene_id, ts)]]
             d["pose1"], d["pc1"] = np.asarray(nxt["pose"][:]), np.asarray(nxt["lidar"][:])
             if "flow_instance_id" in nxt:                      # the training loop clusters both sweeps (seflow/fit.py)
@@ -159,10 +180,12 @@ class HDF5Dataset:
         return d
 
 
-def open_dataset(directory, vis_name="", eval: bool = False):  # noqa: A002
+def open_dataset(directory, vis_name="", eval: bool = False, allow_dropped_eval: bool | None = None):  # noqa: A002
     """The frame source behind ``HDF5Dataset(dir, vis_name=<res>, eval=True)`` at save_zip.py:111 / eval.py:279: the h5
-    scene files when the directory holds them, this package's npz container (``NpzDataset.write``) when it holds that."""
+    scene files when the directory holds them, this package's npz container (``NpzDataset.write``) when it holds that.
+    ``allow_dropped_eval`` only concerns h5 scene files: an npz frame carries its own ``pose1`` / ``pc1``, so no entry of
+    an npz index can lack a successor."""
     directory = Path(directory)
     if any(directory.glob("*/*.npz")) and not any(directory.glob("*.h5")):
         return NpzDataset(directory, vis_name=vis_name, eval=eval)
-    return HDF5Dataset(directory, vis_name=vis_name, eval=eval)
+    return HDF5Dataset(directory, vis_name=vis_name, eval=eval, allow_dropped_eval=allow_dropped_eval)

@@ -464,7 +464,7 @@ def stream_batches(metrics: "InstanceMetrics", source, res_name: str = ""):
 
 
 def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo", res_name: str = "", comp_dis_zip: str = "",
-         batch_frames: int = 16, dataset=None, file_name: str | None = None):
+         batch_frames: int = 16, dataset=None, file_name: str | None = None, allow_dropped_eval: bool | None = None):
     """eval.py:270-313.  Under ``torchrun`` sweep i is scored by rank i % world on its own GPU, the per-sweep contribution
     logs are all-gathered once at the end and rank 0 alone prints / writes ``res-<data>.json``."""
     from . import distenv
@@ -478,7 +478,8 @@ def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo", res_name: str = 
         err = None
         try:
             if dataset is None:
-                dataset = open_dataset(data_dir, vis_name=res_name if eval_flag == 2 else "", eval=True)
+                dataset = open_dataset(data_dir, vis_name=res_name if eval_flag == 2 else "", eval=True,
+                                       allow_dropped_eval=allow_dropped_eval)
             mine = list(range(rank, len(dataset), world))
 
             def batches():
@@ -504,7 +505,9 @@ if __name__ == "__main__":
     ap.add_argument("--data_dir", default="/home/kin/data/av2/h5py/sensor/himo")
     ap.add_argument("--res_name", "--flow_mode", dest="res_name", default="")
     ap.add_argument("--comp_dis_zip", default="")
+    ap.add_argument("--allow_dropped_eval", action="store_true", default=None,
+                    help="skip index_eval.pkl sweeps that have no successor sweep in their h5 scene instead of failing")
     a = ap.parse_args()
     start_time = time.time()
-    main(a.data_dir, a.res_name, a.comp_dis_zip)
+    main(a.data_dir, a.res_name, a.comp_dis_zip, allow_dropped_eval=a.allow_dropped_eval)
     print(f"Time used: {time.time() - start_time:.2f} s")

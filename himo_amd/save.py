@@ -8,8 +8,9 @@ name defaults to the checkpoint's stem (``seflowpp_best`` for ``seflowpp_best.ck
 walked in dataset order, and under ``torchrun`` frame i goes to rank i % world (h5 scene files: scene k goes to rank
 k % world, so every file has exactly one writer).  Results are written through a ``sink(frame_index, frame, flow)``
 callable: ``NpzResultSink`` rewrites the frame's npz, ``H5ResultSink`` creates / replaces the ``<res_name>`` dataset in
-group ``<timestamp>`` of ``<scene_id>.h5`` (the dataset ``tools/test/repack_h5_scania.py:50`` deletes by name; needs
-``h5py``), no sink keeps them in memory.
+group ``<timestamp>`` of ``<scene_id>.h5`` (the dataset ``tools/test/repack_h5_scania.py:50`` deletes by name) through
+``h5py`` or, without it, the HDF5 C library by ``ctypes`` (``h5c``); with neither it writes a result file beside the scene
+file and says so (``dataset.result_file``; the loader reads it back), no sink keeps them in memory.
 """
 from __future__ import annotations
 
@@ -64,19 +65,38 @@ class NpzResultSink:
         os.replace(tmp, path)
 
 
+def h5_writer():
+    """(module, how) that can open a scene file for modification: ``h5py``, else libhdf5 through ``ctypes``, else None."""
+    try:
+        import h5py
+        return h5py, "h5py"
+    except ImportError:
+        pass
+    from . import h5c
+    if h5c.available():
+        return h5c, f"libhdf5 {'.'.join(map(str, h5c.load().version))} via ctypes"
+    return None, "no HDF5 library"
+
+
 class H5ResultSink:
     """``(N,3) float32`` under ``<scene_id>.h5 : <timestamp>/<res_name>`` (consumers: save_zip.py:117 via the
     loader's ``vis_name``, eval.py:302).  A scene's results are held back until the walk has moved on to the next scene
     (frames arrive in dataset order and the reader runs ahead of the results, never behind), so the file is never open for
-    reading by the loader and for writing here at the same time; ``close()`` writes what is left."""
+    reading by the loader and for writing here at the same time; ``close()`` writes what is left.
+
+    Modifying an existing HDF5 file needs an HDF5 library (``h5_writer``).  Where none can be loaded the results go to
+    ``dataset.result_file(directory, res_name, scene_id)`` instead -- a new HDF5 file with the same ``<timestamp>/<res_name>``
+    layout, written by ``h5lite`` -- with a warning naming the file; ``HDF5Dataset`` falls back to it when reading."""
 
     def __init__(self, directory, res_name: str, opener=None):
-        from .dataset import require_h5py
         self.directory, self.res_name = Path(directory), res_name
-        self._open = opener if opener is not None else (lambda path: require_h5py().File(path, "a"))
+        self.how = "opener"
         if opener is None:
-            require_h5py()
+            mod, self.how = h5_writer()
+            opener = (lambda path: mod.File(path, "a")) if mod is not None else None
+        self._open = opener
         self._scene, self._pending = None, []
+        self.side_files = []
 
     def __call__(self, index: int, frame: dict, flow: np.ndarray):
         if frame["scene_id"] != self._scene:
@@ -87,14 +107,37 @@ class H5ResultSink:
         self._pending.append((str(frame["timestamp"]), np.ascontiguousarray(flow, dtype=np.float32)))
 
     def flush(self):
-        if self._pending:
+        if not self._pending:
+            return
+        if self._open is not None:
             with self._open(self.directory / f"{self._scene}.h5") as f:
                 for ts, flow in self._pending:
                     g = f[ts]
                     if self.res_name in g:
                         del g[self.res_name]                       # re-running a checkpoint replaces its result
                     g.create_dataset(self.res_name, data=flow)
-            self._pending = []
+        else:
+            self._flush_beside()
+        self._pending = []
+
+    def _flush_beside(self):
+        import warnings
+        from . import h5lite
+        from .dataset import result_file
+        path = result_file(self.directory, self.res_name, self._scene)
+        tree = {}
+        if path.exists():                                          # an earlier run / an earlier part of this scene: keep, then replace
+            with h5lite.File(path) as old:
+                tree = {ts: {k: old[ts][k][:] for k in old[ts].keys()} for ts in old.keys()}
+        for ts, flow in self._pending:
+            tree.setdefault(ts, {})[self.res_name] = flow
+        path.parent.mkdir(parents=True, exist_ok=True)
+        h5lite.write_file(path, tree)
+        if path not in self.side_files:
+            self.side_files.append(path)
+            warnings.warn(f"no HDF5 library (h5py / libhdf5) to modify {self._scene}.h5 with: '{self.res_name}' for "
+                          f"{len(tree)} sweep(s) written to {path} instead (himo_amd's loader reads it from there; "
+                          f"merge with h5copy or h5py to hand the scene file to other tools)", stacklevel=3)
 
     def close(self):
         self.flush()

@@ -160,7 +160,7 @@ def run_dataset(dataset, res_name: str, output_dir: Path, batch_frames: int = 32
 
 
 def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo/demo", res_name: str = "seflowpp_best",
-         batch_frames: int = 32):
+         batch_frames: int = 32, allow_dropped_eval: bool | None = None):
     """save_zip.py:102-125.  Under ``torchrun`` (one rank per GPU) the sweeps are sharded i % world, every rank writes its
     own Feather files, and rank 0 zips once all of them are on disk (distenv.process_group joins / leaves the job's group;
     a rank that fails still reaches the rendezvous, so nobody zips a partial result or waits for a dead process)."""
@@ -173,7 +173,7 @@ def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo/demo", res_name: s
     with distenv.process_group() as (rank, world):
         err = None
         try:
-            dataset = open_dataset(data_dir, vis_name=res_name, eval=True)
+            dataset = open_dataset(data_dir, vis_name=res_name, eval=True, allow_dropped_eval=allow_dropped_eval)
             run_dataset(dataset, res_name, output_dir, batch_frames=batch_frames)
         except Exception as e:                                   # (an interrupt leaves at once; the launcher ends the job)
             err = e
@@ -190,8 +190,10 @@ def _cli(argv=None):
     ap.add_argument("--data_dir", default="/home/kin/data/av2/h5py/sensor/himo/demo")
     ap.add_argument("--res_name", default="seflowpp_best")
     ap.add_argument("--batch_frames", type=int, default=32)
+    ap.add_argument("--allow_dropped_eval", action="store_true", default=None,
+                    help="skip index_eval.pkl sweeps that have no successor sweep in their h5 scene instead of failing")
     a = ap.parse_args(argv)
-    main(a.data_dir, a.res_name, a.batch_frames)
+    main(a.data_dir, a.res_name, a.batch_frames, a.allow_dropped_eval)
 
 
 if __name__ == "__main__":

@@ -1,7 +1,8 @@
 """Frame sources and result sinks at the h5 boundary: index handling on the reference's own frame
-lists, the loader's key renaming and successor logic, the ``<res_name>`` result dataset.  ``h5py`` is absent from the build
-image, so the logic runs through the ``opener`` hook on an in-memory scene mapping; wherever h5py exists the same checks
-run on real files (importorskip)."""
+lists, the loader's key renaming and successor logic, the ``<res_name>`` result dataset.  The index / successor logic runs
+through the ``opener`` hook on an in-memory scene mapping; the file format itself is exercised on REAL HDF5 files: the
+committed fixtures the HDF5 library wrote (tests/golden/h5), files written here through libhdf5 (``h5c``) where it loads,
+and the result files ``H5ResultSink`` writes with ``h5lite`` where nothing can modify a scene file in place."""
 import json
 import pickle
 from contextlib import contextmanager
@@ -172,24 +173,93 @@ def test_open_dataset_picks_the_container(tmp_path):
     assert isinstance(open_dataset(tmp_path, vis_name="x", eval=True), NpzDataset)
 
 
-def test_real_h5_files_round_trip(tmp_path):
-    """Where h5py exists: the extract_sca.py:76-93 schema on disk -> HDF5Dataset -> H5ResultSink -> read back as <res_name>."""
-    h5py = pytest.importorskip("h5py")
-    frames = [make_frame(i, n_points=64 + i, scene_id=f"scene{i // 3}") for i in range(6)]
+def _write_scene_files(directory, frames, writer):
     for scene, groups in _scene_groups(frames).items():
-        with h5py.File(tmp_path / f"{scene}.h5", "w") as f:
-            for ts, arrays in groups.items():
-                g = f.create_group(ts)
-                for name, a in arrays.items():
-                    g.create_dataset(name, data=a)
+        if writer == "h5lite":
+            from himo_amd import h5lite
+            h5lite.write_file(directory / f"{scene}.h5", groups)
+        else:
+            with writer.File(directory / f"{scene}.h5", "w") as f:
+                for ts, arrays in groups.items():
+                    g = f.create_group(ts)
+                    for name, a in arrays.items():
+                        g.create_dataset(name, data=a)
+
+
+def _round_trip(tmp_path, writer, force_beside=False, monkeypatch=None):
+    """the extract_sca.py:76-93 schema on disk -> HDF5Dataset -> H5ResultSink -> read back as <res_name>"""
+    frames = [make_frame(i, n_points=64 + i, scene_id=f"scene{i // 3}") for i in range(6)]
+    _write_scene_files(tmp_path, frames, writer)
     _dataset_dir(tmp_path, frames)
     ds = HDF5Dataset(tmp_path, vis_name="seflowpp_best")
     assert len(ds) == 4 and np.array_equal(ds[0]["pc0"], frames[0]["pc0"]) and np.array_equal(ds[0]["pose1"], frames[1]["pose0"])
+    assert ds[0]["gm0"].dtype == bool and np.array_equal(ds[0]["gm0"], frames[0]["gm0"])
+    assert ds[0]["flow_is_valid"].dtype == bool and ds[0]["flow_instance_id"].dtype == np.uint32 and ds[0]["pose0"].dtype == np.float64
+    assert "seflowpp_best" not in ds[0]
+    if force_beside:
+        monkeypatch.setattr(save, "h5_writer", lambda: (None, "no HDF5 library"))
     sink = save.H5ResultSink(tmp_path, "seflowpp_best")
     for i in range(len(ds)):
         f0 = ds[i]
         sink(i, f0, np.full((len(f0["pc0"]), 3), i, np.float32))
-    sink.close()
+    if force_beside:
+        with pytest.warns(UserWarning, match="results_h5"):
+            sink.close()
+        assert [p.name for p in sink.side_files] == ["scene0.h5", "scene1.h5"]
+    else:
+        sink.close()
+        assert sink.side_files == []
     again = HDF5Dataset(tmp_path, vis_name="seflowpp_best")
     for i in range(len(again)):
         assert (again[i]["seflowpp_best"] == i).all() and again[i]["seflowpp_best"].dtype == np.float32
+        assert again[i]["seflowpp_best"].shape == (len(again[i]["pc0"]), 3)
+    sink = save.H5ResultSink(tmp_path, "seflowpp_best")               # a re-run replaces, never duplicates
+    sink(0, ds[0], np.full((len(ds[0]["pc0"]), 3), 7, np.float32))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sink.close()
+    again = HDF5Dataset(tmp_path, vis_name="seflowpp_best")
+    assert (again[0]["seflowpp_best"] == 7).all() and (again[1]["seflowpp_best"] == 1).all()
+    return frames
+
+
+def test_real_h5_files_round_trip_through_libhdf5(tmp_path):
+    """Scene files written AND modified by the real HDF5 library (ctypes), read by h5lite (or h5py where it exists)."""
+    from himo_amd import h5c
+    if not h5c.available():
+        pytest.skip("no HDF5 C library on this box")
+    _round_trip(tmp_path, h5c)
+    from himo_amd import h5lite
+    with h5lite.File(tmp_path / "scene0.h5") as f:                     # the result really is inside the scene file
+        assert all("seflowpp_best" in f[ts] for ts in sorted(f.keys())[:2])
+
+
+def test_real_h5_files_round_trip_without_any_hdf5_library(tmp_path, monkeypatch):
+    """No h5py, no libhdf5: results go to <dir>/results_h5/<res_name>/<scene>.h5 (real HDF5, written by h5lite), the sink says
+    so, and the loader reads them from there."""
+    _round_trip(tmp_path, "h5lite", force_beside=True, monkeypatch=monkeypatch)
+    from himo_amd.dataset import result_file
+    assert result_file(tmp_path, "seflowpp_best", "scene0").exists()
+    assert not any(p.name.endswith(".writing") for p in (tmp_path / "results_h5" / "seflowpp_best").iterdir())
+
+
+def test_fixture_directory_opens_as_the_reference_call_does(tmp_path):
+    """``HDF5Dataset(data_dir, vis_name=res_name, eval=True)[i]`` (save_zip.py:111-113, eval.py:279-282) over the committed
+    libhdf5-written fixture: every key the two consumers read, with the dtypes extract_sca.py:76-93 put on disk."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_h5_fixture", GOLDEN / "make_h5_fixture.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    frames = mod.frames()
+    ds = open_dataset(GOLDEN / "h5", vis_name="seflowpp_best", eval=True)
+    assert isinstance(ds, HDF5Dataset) and len(ds) == 4
+    for d, i in zip((ds[k] for k in range(4)), (0, 2, 4, 5)):
+        f = frames[i]
+        assert d["scene_id"] == f["scene_id"] and d["timestamp"] == f["timestamp"]
+        for k in ("pc0", "pose0", "pose1", "lidar_dt", "gm0", "flow", "flow_is_valid", "flow_category_indices",
+                  "flow_instance_id", "seflowpp_best", "lidar_id"):
+            assert np.array_equal(d[k], f[k]) and d[k].dtype == f[k].dtype, k
+        assert np.array_equal(d["pc1"], frames[i + 1]["pc0"])
+    total = open_dataset(GOLDEN / "h5", vis_name="raw")
+    assert len(total) == 6 and "seflowpp_best" not in total[0]
