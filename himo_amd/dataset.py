@@ -165,14 +165,15 @@ class HDF5Dataset:
                     d[k] = np.asarray(g[k][:])
             for name in self.vis_name:
                 if name and name != "raw":
-                    if name in g:
+                    # a run that could not modify the scene file wrote beside it; that file, when present, is the NEWER result
+                    # (the in-place writer removes the entries it supersedes: save.H5ResultSink.flush)
+                    side = result_file(self.directory, name, scene_id)
+                    if side.exists():
+                        with self._open(side) as r:
+                            if ts in r and name in r[ts]:
+                                d[name] = np.asarray(r[ts][name][:])
+                    if name not in d and name in g:
                         d[name] = np.asarray(g[name][:])
-                    else:                                      # a run that could not modify the scene file wrote beside it
-                        side = result_file(self.directory, name, scene_id)
-                        if side.exists():
-                            with self._open(side) as r:
-                                if ts in r and name in r[ts]:
-                                    d[name] = np.asarray(r[ts][name][:])
             nxt = f[self._next[(scene_id, ts)]]
             d["pose1"], d["pc1"] = np.asarray(nxt["pose"][:]), np.asarray(nxt["lidar"][:])
             if "flow_instance_id" in nxt:                      # the training loop clusters both sweeps (seflow/fit.py)

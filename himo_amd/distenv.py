@@ -38,21 +38,27 @@ def process_group():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this host driver
     backend = os.environ.get("HIMO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-    # these are batch tools: a peer that was hard-killed must not leave the rest parked for RCCL's default 10 minutes
+    # Two clocks.  DATA collectives (the metric gather, the gradient all-reduce) start when every rank is already there, so
+    # a short timeout only ever catches a dead peer.  The RENDEZVOUS after the sharded loop is different: it completes when
+    # the SLOWEST rank has finished its shard, so its timeout bounds the finish-time skew between ranks (whole-scene shards,
+    # slow h5 reads) -- a rank that is merely early must wait, for hours if need be, not fail the job after all the work is
+    # done.  A peer that was hard-killed is the launcher's business (torchrun takes the whole job down).
     timeout = timedelta(seconds=float(os.environ.get("HIMO_DIST_TIMEOUT_S", "300")))
+    rendezvous_timeout = timedelta(seconds=float(os.environ.get("HIMO_RENDEZVOUS_TIMEOUT_S", str(12 * 3600))))
     global _FLAG_GROUP
     if backend == "nccl":
         if torch.cuda.device_count() <= local:
             raise RuntimeError(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} HIP device(s) visible")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=timeout)
-        # the "did every rank get through" flag travels over a host-side gloo group: a rank whose GPU faulted would fail again
-        # inside an RCCL collective and bury the original error; data (the metric gather, gradients) stays on RCCL
-        _FLAG_GROUP = dist.new_group(backend="gloo", timeout=timeout)
     else:
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
+    # the "did every rank get through" flag travels over a host-side gloo group of its own: a rank whose GPU faulted would
+    # fail again inside an RCCL collective and bury the original error, and this group carries the long rendezvous timeout;
+    # data (the metric gather, gradients) stays on the job's main group
+    _FLAG_GROUP = dist.new_group(backend="gloo", timeout=rendezvous_timeout)
     try:
         yield rank, world
     finally:

@@ -116,9 +116,27 @@ class H5ResultSink:
                     if self.res_name in g:
                         del g[self.res_name]                       # re-running a checkpoint replaces its result
                     g.create_dataset(self.res_name, data=flow)
+            self._supersede_beside()
         else:
             self._flush_beside()
         self._pending = []
+
+    def _supersede_beside(self):
+        """After an in-place write: drop the same sweeps from a result file an earlier library-less run left beside the scene
+        (the loader prefers that file while it names a sweep)."""
+        from . import h5lite
+        from .dataset import result_file
+        path = result_file(self.directory, self.res_name, self._scene)
+        if not path.exists():
+            return
+        with h5lite.File(path) as old:
+            tree = {ts: {k: old[ts][k][:] for k in old[ts].keys()} for ts in old.keys()}
+        for ts, _ in self._pending:
+            tree.pop(ts, None)
+        if tree:
+            h5lite.write_file(path, tree)
+        else:
+            path.unlink()
 
     def _flush_beside(self):
         import warnings

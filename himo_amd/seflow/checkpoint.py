@@ -88,11 +88,16 @@ def to_state_dict(params: dict) -> dict:
 class TopK:
     """``save_top_model=k`` (ssl-train-av2.sh:32): keep the k checkpoints with the LOWEST validation figure in ``directory``."""
 
-    def __init__(self, directory, k: int = 3, prefix: str = "seflowpp"):
+    def __init__(self, directory, k: int = 3, prefix: str = "seflowpp", resume: bool = False):
+        """``resume=True`` (a run continued with ``fit(resume=...)``) adopts the ranking of the checkpoints already in
+        ``directory`` -- else more than k accumulate over the restarts.  A FRESH run never adopts, ranks against or deletes
+        files it did not write: checkpoints of another run in a reused directory are left alone (and a new file whose name
+        collides with one of them replaces only that file)."""
         self.directory, self.k, self.prefix = Path(directory), int(k), prefix
         self.directory.mkdir(parents=True, exist_ok=True)
         self.kept = []                                       # (val, path)
-        # a resumed run continues the ranking of the files already in the directory (else more than k accumulate)
+        if not resume:
+            return
         for path in sorted(self.directory.glob(f"{self.prefix}-epoch*-val*.npz")):
             try:
                 with np.load(path) as z:

@@ -83,7 +83,7 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
     if resume is not None:
         extra = tr.load_checkpoint(resume)
         start_epoch = int(extra.get("epoch", -1)) + 1
-    top = TopK(out_dir, k=save_top) if (out_dir is not None and rank == 0) else None
+    top = TopK(out_dir, k=save_top, resume=resume is not None) if (out_dir is not None and rank == 0) else None
     trips = triplets(dataset)
     if not trips:
         raise ValueError("the dataset has no frame with a successor in its scene")

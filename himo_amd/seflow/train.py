@@ -827,9 +827,12 @@ class SeFlowTrainer:
                 _lib.check(lib.himo_affine_gelu_bwd(F * ho * wo, cout, dy, cout, pre.data_ptr(), cout, sc, dp, cout, s()), "affine_gelu_bwd")
             # a bias in front of a training-mode BatchNorm has exactly zero gradient (the batch mean absorbs it); the column sums
             # of dp would be rounding noise that Adam's normalisation turns into full-size random steps.  Nothing ever writes
-            # these entries of flat_g in batch mode: they keep the zeros they were created with.
+            # these entries of flat_g in batch mode -- but a backward() after a frozen-statistics forward does (the branch
+            # below), and train_batch ADDS flat_g into its accumulator: so batch mode zeroes them, it does not assume them zero.
             if not self._fwd_batch:
                 self._colsum(F * ho * wo, dp, cout, cout, f"{name}.bias")
+            else:
+                self.g[f"{name}.bias"].zero_()
             x, x_bs, x_pitch = self.inputs[li]
             self._wgrad3_batch(F, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride)
             wf, wp = self._flip(name, 3, cin, cout)

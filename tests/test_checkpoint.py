@@ -51,7 +51,10 @@ def test_top_k_resumes_its_ranking_and_rejects_non_finite_figures(tmp_path):
     first = ck.TopK(tmp_path, k=2)
     for e, v in enumerate([0.6, 0.4, 0.5]):
         first.offer(v, e, params)
-    resumed = ck.TopK(tmp_path, k=2)                               # --resume: a fresh object over the same directory
+    fresh = ck.TopK(tmp_path, k=2)                                 # a NEW run pointed at a used directory: ADVICE r03 --
+    assert fresh.kept == [] and fresh.best() is None               # it neither ranks against nor deletes another run's files
+    assert len(list(tmp_path.glob("*.npz"))) == 2
+    resumed = ck.TopK(tmp_path, k=2, resume=True)                  # --resume: a fresh object over the same directory
     assert sorted(v for v, _ in resumed.kept) == [0.4, 0.5]
     assert resumed.offer(float("nan"), 3, params) is None and resumed.offer(float("inf"), 3, params) is None
     assert resumed.offer(0.45, 4, params) is not None

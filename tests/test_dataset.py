@@ -244,6 +244,36 @@ def test_real_h5_files_round_trip_without_any_hdf5_library(tmp_path, monkeypatch
     assert not any(p.name.endswith(".writing") for p in (tmp_path / "results_h5" / "seflowpp_best").iterdir())
 
 
+def test_result_beside_the_scene_file_is_the_newer_one_until_superseded(tmp_path, monkeypatch):
+    """A scene file that already holds ``seflowpp_best`` + a library-less re-run: the loader must hand out the re-run's result,
+    and a later in-place write must retire the file beside the scene."""
+    import shutil
+    import warnings
+    from himo_amd import h5c
+    from himo_amd.dataset import result_file
+    shutil.copytree(GOLDEN / "h5", tmp_path / "d")
+    root = tmp_path / "d"
+    ds = HDF5Dataset(root, vis_name="seflowpp_best")
+    old = ds[0]["seflowpp_best"].copy()
+    real_writer = save.h5_writer
+    monkeypatch.setattr(save, "h5_writer", lambda: (None, "no HDF5 library"))
+    sink = save.H5ResultSink(root, "seflowpp_best")
+    sink(0, ds[0], np.full_like(old, 3.0))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sink.close()
+    assert (HDF5Dataset(root, vis_name="seflowpp_best")[0]["seflowpp_best"] == 3).all()
+    assert np.array_equal(HDF5Dataset(root, vis_name="seflowpp_best")[1]["seflowpp_best"], ds[1]["seflowpp_best"])   # untouched sweep: in-file
+    if not h5c.available():
+        return
+    monkeypatch.setattr(save, "h5_writer", real_writer)
+    sink = save.H5ResultSink(root, "seflowpp_best")
+    sink(0, ds[0], np.full_like(old, 4.0))
+    sink.close()
+    assert (HDF5Dataset(root, vis_name="seflowpp_best")[0]["seflowpp_best"] == 4).all()
+    assert not result_file(root, "seflowpp_best", ds[0]["scene_id"]).exists()
+
+
 def test_fixture_directory_opens_as_the_reference_call_does(tmp_path):
     """``HDF5Dataset(data_dir, vis_name=res_name, eval=True)[i]`` (save_zip.py:111-113, eval.py:279-282) over the committed
     libhdf5-written fixture: every key the two consumers read, with the dtypes extract_sca.py:76-93 put on disk."""

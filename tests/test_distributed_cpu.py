@@ -342,3 +342,24 @@ def test_train_batch_exchange_weighs_every_sample_of_the_global_batch_alike(tmp_
         got = json.loads(Path(tmp_path, f"rank{r}.json").read_text())
         for name in ("2+1", "3+0"):
             assert got[name]["g"] == pytest.approx(want_g) and got[name]["loss"] == pytest.approx(want_loss), (r, name)
+
+
+def _worker_skewed_rendezvous(rank, world, port, out_dir):
+    _cli_env(rank, world, port)
+    os.environ["HIMO_DIST_TIMEOUT_S"] = "2"                      # the data collectives' clock: far shorter than the skew below
+    import time
+    from himo_amd import distenv
+    with distenv.process_group() as (r, w):
+        if r == 1:
+            time.sleep(6)                                        # the slow shard (whole scenes per rank, slow h5 reads)
+        distenv.rendezvous(None)
+        got = [None] * w
+        dist.all_gather_object(got, r)                           # the gather that follows the rendezvous still works
+    Path(out_dir, f"ok{rank}").write_text(str(got))
+
+
+def test_rendezvous_waits_for_the_slow_rank_longer_than_the_collective_timeout(tmp_path):
+    """the rendezvous completes when the SLOWEST rank is done, so it must not share the short timeout that
+    guards the data collectives -- a rank that finishes early waits (HIMO_RENDEZVOUS_TIMEOUT_S, hours by default)."""
+    mp.spawn(_worker_skewed_rendezvous, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").read_text() == (tmp_path / "ok1").read_text() == "[0, 1]"
