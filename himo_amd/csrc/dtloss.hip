@@ -7,25 +7,22 @@
 //   volume    nx x ny x nz cells of edge `cell` from `origin`, x fastest; a cell is occupied when a pc1 point falls into it;
 //             G[c] = squared distance IN CELLS from cell c to the nearest occupied cell (uint16; 0xFFFF = further than the window
 //             W in some axis), D[c] = min(sqrt(G[c]), W) * cell -- exact Euclidean distance transform up to W cells;
-//   lookup    u = (p - origin) / cell - 1/2 (cell-centre coordinates), clamped to [0, n - 1] per axis; D(p) = trilinear interpolation
-//             of the eight surrounding D values; loss = (1 / n) sum_i [D(p_i) <= trunc] D(p_i); gradient = its exact derivative
-//             (zero along an axis where the point is clamped).
+//   lookup    u = (p - origin) / cell - 1/2 (cell-centre coordinates); a point is IN THE VOLUME when 0 < u < n - 1 on every axis;
+//             D(p) = trilinear interpolation of the eight surrounding D values;
+//             loss = (1 / m) sum_{i in volume} [D(p_i) <= trunc] D(p_i) with m = the number of points in the volume (0 -> loss 0);
+//             gradient = its exact derivative.  A point outside the volume (AV2 sweeps reach ~200 m, the volume is the network
+//             range + trunc) has no defined distance: it adds neither loss nor gradient and is not counted (csrc/dtlookup.h).
 // The transform is separable: min over (dx, dy, dz) of dx^2 + dy^2 + dz^2 = min_dz (dz^2 + min_dy (dy^2 + min_dx dx^2)), each
 // pass a windowed min-plus through an LDS tile (the volume is 113 M cells for the 106 x 106 x 10 m box at 0.1 m: three passes of
 // ~0.25 GB read + written each, milliseconds once per pair against ~0.3 ms of NN searches EVERY iteration).
 // HBM-bound streams; integer arithmetic; bit-deterministic.
 #include "himo_common.h"
+#include "dtlookup.h"
 #include <math.h>
 
 namespace himo {
 
-constexpr unsigned short kDtInf = 0xFFFFu;
 constexpr int kDtMaxWindow = 40;
-
-struct DtGrid {
-    float ox, oy, oz, cell;
-    int nx, ny, nz, window;
-};
 
 __device__ inline unsigned dt_add(unsigned short g, int d2) {           // saturating: INF stays INF
     return g == kDtInf ? 0xFFFFFFFFu : (unsigned)g + (unsigned)d2;
@@ -89,12 +86,6 @@ __global__ __launch_bounds__(256) void dt_pass_axis_kernel(DtGrid g, const unsig
     }
 }
 
-__device__ inline float dt_value(const unsigned short* __restrict__ vol, const DtGrid& g, int ix, int iy, int iz) {
-    const unsigned short v = vol[((int64_t)iz * g.ny + iy) * g.nx + ix];
-    const float d = v == kDtInf ? (float)g.window : sqrtf((float)v);
-    return fminf(d, (float)g.window) * g.cell;
-}
-
 // block_sum of doubles in a fixed order (deterministic)
 __device__ inline void dt_block_sum(double t, double* out) {
     __shared__ double sh[256];
@@ -107,55 +98,59 @@ __device__ inline void dt_block_sum(double t, double* out) {
     if (threadIdx.x == 0) *out = sh[0];
 }
 
+// per point: unnormalised gradient d D / d p (zero outside the volume or beyond trunc); per block: sum of the counted distances and
+// the number of points in the volume
 __global__ __launch_bounds__(256) void dt_loss_kernel(int n, const float* __restrict__ moved, DtGrid g, const unsigned short* __restrict__ vol,
-                                                      float trunc, float* __restrict__ grad, double* __restrict__ partial) {
+                                                      float trunc, float* __restrict__ grad, double* __restrict__ partial,
+                                                      int* __restrict__ partial_count) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     double t = 0.0;
+    int inside = 0;
     if (i < n) {
-        const int dims[3] = {g.nx, g.ny, g.nz};
-        const float org[3] = {g.ox, g.oy, g.oz};
-        int i0[3]; float f[3]; bool inside[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float u = (moved[i * 3 + c] - org[c]) / g.cell - 0.5f;
-            const float hi = (float)(dims[c] - 1);
-            inside[c] = u > 0.f && u < hi;                              // NaN -> clamped to 0, no gradient
-            const float uc = u > 0.f ? (u < hi ? u : hi) : 0.f;
-            int b = (int)floorf(uc);
-            if (b > dims[c] - 2) b = dims[c] - 2;
-            if (b < 0) b = 0;                                           // a one-cell axis
-            i0[c] = b; f[c] = uc - (float)b;
-        }
-        const int x1 = i0[0] + 1 < g.nx ? i0[0] + 1 : i0[0], y1 = i0[1] + 1 < g.ny ? i0[1] + 1 : i0[1], z1 = i0[2] + 1 < g.nz ? i0[2] + 1 : i0[2];
-        const float d000 = dt_value(vol, g, i0[0], i0[1], i0[2]), d100 = dt_value(vol, g, x1, i0[1], i0[2]);
-        const float d010 = dt_value(vol, g, i0[0], y1, i0[2]), d110 = dt_value(vol, g, x1, y1, i0[2]);
-        const float d001 = dt_value(vol, g, i0[0], i0[1], z1), d101 = dt_value(vol, g, x1, i0[1], z1);
-        const float d011 = dt_value(vol, g, i0[0], y1, z1), d111 = dt_value(vol, g, x1, y1, z1);
-        const float fx = f[0], fy = f[1], fz = f[2], gx = 1.f - fx, gy = 1.f - fy, gz = 1.f - fz;
-        const float c00 = d000 * gx + d100 * fx, c10 = d010 * gx + d110 * fx, c01 = d001 * gx + d101 * fx, c11 = d011 * gx + d111 * fx;
-        const float c0 = c00 * gy + c10 * fy, c1 = c01 * gy + c11 * fy;
-        const float D = c0 * gz + c1 * fz;
-        float gr[3] = {0.f, 0.f, 0.f};
-        if (D <= trunc) {
-            t = (double)D / (double)n;
-            const float s = 1.0f / ((float)n * g.cell);
-            const float dDx = ((d100 - d000) * gy + (d110 - d010) * fy) * gz + ((d101 - d001) * gy + (d111 - d011) * fy) * fz;
-            const float dDy = (c10 - c00) * gz + (c11 - c01) * fz;
-            const float dDz = c1 - c0;
-            gr[0] = inside[0] ? dDx * s : 0.f; gr[1] = inside[1] ? dDy * s : 0.f; gr[2] = inside[2] ? dDz * s : 0.f;
-        }
+        float D, gr[3];
+        const float p[3] = {moved[i * 3], moved[i * 3 + 1], moved[i * 3 + 2]};
+        inside = dt_lookup(p, g, vol, trunc, D, gr) ? 1 : 0;
+        if (inside && D <= trunc) t = (double)D;
 #pragma unroll
         for (int c = 0; c < 3; ++c) grad[i * 3 + c] = gr[c];
     }
     dt_block_sum(t, partial + blockIdx.x);
+    __shared__ int cnt[256];
+    cnt[threadIdx.x] = inside;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) cnt[threadIdx.x] += cnt[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial_count[blockIdx.x] = cnt[0];
 }
 
-__global__ __launch_bounds__(256) void dt_sum_partials_kernel(const double* __restrict__ partial, int n, double* __restrict__ out) {
-    double t = 0.0;
-    for (int b = threadIdx.x; b < n; b += 256) t += partial[b];
-    __shared__ double res;
-    dt_block_sum(t, &res);
-    if (threadIdx.x == 0) *out = res;
+// every block: m = sum of the count partials (same order everywhere), its 256 points' gradients *= 1 / m; block 0 also writes the loss
+__global__ __launch_bounds__(256) void dt_finish_kernel(int n, int nb, const double* __restrict__ partial, const int* __restrict__ partial_count,
+                                                        float* __restrict__ grad, double* __restrict__ out) {
+    __shared__ int cnt[256];
+    int c = 0;
+    for (int b = threadIdx.x; b < nb; b += 256) c += partial_count[b];
+    cnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) cnt[threadIdx.x] += cnt[threadIdx.x + s];
+        __syncthreads();
+    }
+    const int m = cnt[0];
+    const float inv = m > 0 ? 1.0f / (float)m : 0.f;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) grad[i * 3 + k] *= inv;
+    }
+    if (blockIdx.x == 0) {
+        double t = 0.0;
+        for (int b = threadIdx.x; b < nb; b += 256) t += partial[b];
+        __shared__ double res;
+        dt_block_sum(t, &res);
+        if (threadIdx.x == 0) *out = m > 0 ? res / (double)m : 0.0;
+    }
 }
 
 static bool dt_grid_ok(const float* h_origin, float cell, const int* h_dims, int window, DtGrid& g) {
@@ -199,7 +194,7 @@ extern "C" int himo_dt_build(int n1, const float* d_pc1, const float* h_origin, 
     return HIMO_OK;
 }
 
-extern "C" size_t himo_dt_loss_workspace_bytes(int n) { return ((size_t)(n + 255) / 256 + 2) * 8 + 64; }
+extern "C" size_t himo_dt_loss_workspace_bytes(int n) { return ((size_t)(n + 255) / 256 + 2) * 12 + 64; }
 
 extern "C" int himo_dt_loss(int n, const float* d_moved, const float* h_origin, float cell, const int* h_dims, int window,
                             const void* d_volume, float trunc_dist, double* d_loss, float* d_grad_moved, void* d_workspace,
@@ -209,12 +204,13 @@ extern "C" int himo_dt_loss(int n, const float* d_moved, const float* h_origin, 
     if (n > 0 && (!d_moved || !d_grad_moved)) return HIMO_ERR_INVALID_ARGUMENT;
     if (workspace_bytes < himo_dt_loss_workspace_bytes(n)) return HIMO_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    double* partial = reinterpret_cast<double*>(d_workspace);
     const int nb = (n + 255) / 256;
+    double* partial = reinterpret_cast<double*>(d_workspace);
+    int* partial_count = reinterpret_cast<int*>(partial + nb + 1);
     ProfScope ps("dt_loss_kernel", s);
     if (nb) hipLaunchKernelGGL(dt_loss_kernel, dim3(nb), dim3(256), 0, s, n, d_moved, g, reinterpret_cast<const unsigned short*>(d_volume),
-                               trunc_dist, d_grad_moved, partial);
-    hipLaunchKernelGGL(dt_sum_partials_kernel, dim3(1), dim3(256), 0, s, partial, nb, d_loss);
+                               trunc_dist, d_grad_moved, partial, partial_count);
+    hipLaunchKernelGGL(dt_finish_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, s, n, nb, partial, partial_count, d_grad_moved, d_loss);
     HIMO_LAUNCH_CHECK("dt_loss kernels");
     return HIMO_OK;
 }

@@ -80,16 +80,19 @@ def dt_volume(pc1, origin, dims, cell, window):
 
 
 def dt_lookup(vol, moved, origin, cell):
-    """Trilinear interpolation of ``vol`` (torch float32 (nz, ny, nx)) at ``moved`` (torch (n, 3), may require grad) in cell-centre
-    coordinates, clamped to the volume -- the rule of csrc/dtloss.hip, with autograd supplying the gradient."""
+    """(D, in_volume): trilinear interpolation of ``vol`` (torch float32 (nz, ny, nx)) at ``moved`` (torch (n, 3), may require
+    grad) in cell-centre coordinates, and which points are IN THE VOLUME (0 < u < n - 1 on every axis) -- the rule of
+    csrc/dtlookup.h, with autograd supplying the gradient.  D of a point outside the volume is meaningless (its indices are
+    clamped only to keep the gather legal); callers mask it."""
     nz, ny, nx = vol.shape
     dims = (nx, ny, nz)
     idx, frac = [], []
+    inside = torch.ones(len(moved), dtype=torch.bool)
     for k in range(3):
         u = (moved[:, k] - float(np.float32(origin[k]))) / float(np.float32(cell)) - 0.5
-        uc = u.clamp(0.0, float(dims[k] - 1))
-        b = uc.detach().floor().clamp(max=float(max(dims[k] - 2, 0))).long()
-        idx.append(b); frac.append(uc - b.to(uc.dtype))
+        inside = inside & (u.detach() > 0.0) & (u.detach() < float(dims[k] - 1))
+        b = u.detach().floor().clamp(min=0.0, max=float(max(dims[k] - 2, 0))).nan_to_num(0.0).long()
+        idx.append(b); frac.append(u - b.to(u.dtype))
     def at(dx, dy, dz):
         x = (idx[0] + dx).clamp(max=nx - 1); y = (idx[1] + dy).clamp(max=ny - 1); z = (idx[2] + dz).clamp(max=nz - 1)
         return vol[z, y, x]
@@ -100,7 +103,15 @@ def dt_lookup(vol, moved, origin, cell):
     c11 = at(0, 1, 1) * (1 - fx) + at(1, 1, 1) * fx
     c0 = c00 * (1 - fy) + c10 * fy
     c1 = c01 * (1 - fy) + c11 * fy
-    return c0 * (1 - fz) + c1 * fz
+    return c0 * (1 - fz) + c1 * fz, inside
+
+
+def dt_objective(vol, moved, origin, cell, trunc):
+    """loss = (1 / m) sum_{i in volume} [D_i <= trunc] D_i, m = points in the volume (0 -> 0): himo_amd/fastnsf.py's "dt" objective"""
+    D, inside = dt_lookup(vol, moved, origin, cell)
+    keep = inside & (D.detach() <= trunc)
+    m = int(inside.sum())
+    return torch.where(keep, D, torch.zeros_like(D)).double().sum() / max(m, 1)
 
 
 def dt_loss_and_grads(layers_np, pc0, pc1, origin, dims, cell, window, trunc=2.0):
@@ -111,8 +122,7 @@ def dt_loss_and_grads(layers_np, pc0, pc1, origin, dims, cell, window, trunc=2.0
     f = mlp(layers, p0)
     moved = p0 + f
     moved.retain_grad()
-    D = dt_lookup(vol, moved, origin, cell)
-    loss = (D * (D.detach() <= trunc)).double().sum() / len(p0)
+    loss = dt_objective(vol, moved, origin, cell, trunc)
     loss.backward()
     return float(loss), [(w.grad.numpy(), b.grad.numpy()) for w, b in layers], f.detach().numpy(), moved.grad.numpy()
 
@@ -125,8 +135,7 @@ def dt_fit(layers_np, pc0, pc1, origin, dims, cell, window, iters, lr=1e-3, trun
     hist = []
     for _ in range(iters):
         opt.zero_grad()
-        D = dt_lookup(vol, p0 + mlp(layers, p0), origin, cell)
-        loss = (D * (D.detach() <= trunc)).double().sum() / len(p0)
+        loss = dt_objective(vol, p0 + mlp(layers, p0), origin, cell, trunc)
         loss.backward()
         opt.step()
         hist.append(float(loss))
