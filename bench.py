@@ -672,33 +672,47 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     return line
 
 
-FASTNSF_DOMINANT = "mlp_"          # mlp_forward_kernel + mlp_backward_kernel (csrc/mlpfused.hip): substring filter of himo_prof_filter
+FASTNSF_DOMINANT = "nsf_"          # nsf_forward / nsf_backward / nsf_update_kernel (csrc/nsffused.hip): substring filter of himo_prof_filter
 
 
 def fastnsf_roofline(args, prof: dict, n_fits: int, elapsed: float):
-    """roofline object / workload / dtype of the FastNSF fit.  Dominant kernels: the two fused MLP kernels (whole forward pass;
-    whole chain of input gradients), which are HBM-bound streams: what leaves / enters the chip per iteration is the eight
-    128-wide activation maps written by the forward pass and read (mask) + the eight gradient maps written by the backward pass."""
+    """roofline object / workload / dtype of the FastNSF fit (csrc/nsffused.hip: three launches per iteration).  The dominant kernel
+    is nsf_backward_kernel -- the chain of input gradients AND all weight gradients: 14 of the iteration's 21 products of
+    128 x 128 per point -- which is matrix-bound; the forward kernel's figure (an HBM stream: it spills the activations) and the
+    update kernel's ride along."""
     from himo_amd.fastnsf import HIDDEN, N_HIDDEN
     P = args.points
-    f = prof.get("mlp_forward_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
-    b = prof.get("mlp_backward_kernel", {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")})
-    map_bytes = 4.0 * P * HIDDEN
-    bytes_fwd = N_HIDDEN * map_bytes + 16.0 * P + 16.0 * P                                 # H_k written; x0 read, output written
-    bytes_bwd = 2 * N_HIDDEN * map_bytes + 16.0 * P                                        # H_k read (ReLU mask), dZ_k written; d out read
-    total_ms = f["total_ms"] + b["total_ms"]
-    total_bytes = f["count"] * bytes_fwd + b["count"] * bytes_bwd
-    gbs = total_bytes / (total_ms * 1e-3) / 1e9 if f["count"] and b["count"] else float("nan")
-    flops = 2.0 * P * HIDDEN * HIDDEN * (N_HIDDEN - 1) * (f["count"] + b["count"])           # the 128 x 128 products of both directions
-    roofline = {"bound": "hbm", "kernel": "mlp_forward_kernel + mlp_backward_kernel (csrc/mlpfused.hip: the MLP's whole forward pass / whole chain of "
-                                          "input gradients, activations on chip between layers; v_mfma_f32_32x32x16_f16 / _bf16, 3 per float32 product block)",
-                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": {"forward": bytes_fwd, "backward": bytes_bwd},
-                "avg_launch_ms": {"forward": f["avg_ms"], "backward": b["avg_ms"]}, "launches_timed": f["count"] + b["count"],
-                "matrix_tflops_f32_equivalent": flops / (total_ms * 1e-3) / 1e12 if total_ms == total_ms else float("nan"),
+    nil = {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")}
+    f, b, u = prof.get("nsf_forward_kernel", nil), prof.get("nsf_backward_kernel", nil), prof.get("nsf_update_kernel", nil)
+    map_bytes = 4.0 * P * HIDDEN                                                           # one H_k: two bf16 planes
+    blocks = -(-P // 256)
+    params = 2 * (4 * HIDDEN + HIDDEN) + (N_HIDDEN - 1) * (HIDDEN * HIDDEN + HIDDEN) + 4 - HIDDEN
+    bytes_fwd = N_HIDDEN * map_bytes + 3 * 16.0 * P                                        # H_k spilled; x0 read, out + dout written
+    bytes_bwd = (N_HIDDEN + 0.5 * N_HIDDEN) * map_bytes + 2 * 16.0 * P + 4.0 * blocks * params    # H_{k-1} read (both planes), H_k's high plane read for the mask; partials written
+    bytes_upd = 4.0 * blocks * params + 7 * 4.0 * params
+    flops_bwd = 2.0 * P * HIDDEN * HIDDEN * 2 * (N_HIDDEN - 1)                              # input gradients + weight gradients of the 7 hidden products
+    flops_fwd = 2.0 * P * HIDDEN * HIDDEN * (N_HIDDEN - 1)
+    tf = lambda fl, k: fl / (k["avg_ms"] * 1e-3) / 1e12 if k["count"] else float("nan")
+    gbs = lambda by, k: by / (k["avg_ms"] * 1e-3) / 1e9 if k["count"] else float("nan")
+    peak = MFMA_BF16_PEAK_TF / 3.0
+    total_ms = f["total_ms"] + b["total_ms"] + u["total_ms"]
+    roofline = {"bound": "mfma", "kernel": "nsf_backward_kernel (csrc/nsffused.hip: per block of 256 points the whole chain of input gradients and every "
+                                           "weight gradient; v_mfma_f32_32x32x16_bf16 with two-term bf16 operands, 3 per float32 product block; "
+                                           "weight-gradient operands straight from accumulator-layout registers / spilled fragments)",
+                "achieved": tf(flops_bwd, b), "peak": peak, "peak_note": f"{MFMA_BF16_PEAK_TF:.0f} TFLOP/s dense bf16 MFMA peak / 3 matrix products per float32 product",
+                "unit": "TFLOP/s", "frac": tf(flops_bwd, b) / peak, "traffic": None,
+                "algorithmic_flops_per_launch": flops_bwd, "avg_launch_ms": b["avg_ms"], "launches_timed": b["count"],
+                "hbm_side": {"algorithmic_bytes_per_launch": bytes_bwd, "GB/s": gbs(bytes_bwd, b), "frac_of_hbm_peak": gbs(bytes_bwd, b) / HBM_PEAK_GBS},
+                "forward_kernel": {"kernel": "nsf_forward_kernel (whole forward pass + distance-transform objective; spills H_k as bf16 fragments)",
+                                   "avg_launch_ms": f["avg_ms"], "launches_timed": f["count"], "algorithmic_bytes_per_launch": bytes_fwd,
+                                   "GB/s": gbs(bytes_fwd, f), "frac_of_hbm_peak": gbs(bytes_fwd, f) / HBM_PEAK_GBS,
+                                   "matrix_tflops_f32_equivalent": tf(flops_fwd, f)},
+                "update_kernel": {"kernel": "nsf_update_kernel (fixed-order sum of the block partials, Adam, re-pack)", "avg_launch_ms": u["avg_ms"],
+                                  "launches_timed": u["count"], "algorithmic_bytes_per_launch": bytes_upd, "GB/s": gbs(bytes_upd, u)},
                 "share_of_step_time": total_ms / (elapsed * 1e3),
-                "note": "an iteration = fused forward, distance-transform lookup (loss + gradient), fused backward, 9 split-K weight-gradient "
-                        "products (the largest remaining family), Adam, one re-pack launch; the distance transform of pc1 is built once per pair"}
+                "launches_per_iteration": 3,
+                "note": "an iteration = nsf_forward_kernel, nsf_backward_kernel, nsf_update_kernel; the distance transform of pc1 is built once per pair "
+                        "(round 3: 29 launches per iteration, 49 % of the fit in eight split-K weight-gradient products)"}
     workload = (f"FastNSF (BASELINE config 4): fit the per-scene coordinate MLP (3 -> 8 x 128 -> 3) to one pair of {P}-point sweeps, "
                 f"{args.fastnsf_iters} Adam iterations per frame, distance-transform objective (pc1 -> 0.1 m distance volume once per pair, "
                 "trilinear lookup per iteration)")

@@ -17,9 +17,12 @@ This build's own specification, after the published Neural Scene Flow Prior fami
   * optimiser   Adam(lr 1e-3, betas (0.9, 0.999), eps 1e-8), ``iters`` steps, optional early stop on the loss;
   * output      (N,3) float32 flow INCLUDING ego motion, row-aligned with pc0 -- the h5 ``<res_name>`` payload.
 
-Everything that touches point data runs in HIP: the forward / input-gradient products on the matrix cores
-(csrc/conv.hip row GEMM with BIAS_RELU / RELU_MASK epilogues), the weight gradients as a split-K MFMA product
-(csrc/fastnsf.hip), the objective, Adam.  Python sequences launches and owns no arithmetic.
+Everything that touches point data runs in HIP.  The default configuration (mixed precision, "dt" objective) runs an optimiser
+iteration as THREE launches (csrc/nsffused.hip): forward + objective, backward + every weight gradient, reduce + Adam + re-pack.
+The other configurations ("nn" objective, float32 products, ``fused=False``) keep the layer-by-layer kernels of rounds 1-3: the
+forward / input-gradient products on the matrix cores (csrc/conv.hip row GEMM with BIAS_RELU / RELU_MASK epilogues, or
+csrc/mlpfused.hip), the weight gradients as a split-K MFMA product (csrc/fastnsf.hip), the objective, Adam.
+Python sequences launches and owns no arithmetic.
 """
 from __future__ import annotations
 
@@ -62,6 +65,18 @@ _lib.register({
     "himo_mlp_bias_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
     "himo_mlp_backward_fused_bias": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "himo_nsf_padded_rows": (ctypes.c_int64, [ctypes.c_int64]),
+    "himo_nsf_spill_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int]),
+    "himo_nsf_backward_blocks": (ctypes.c_int, [ctypes.c_int64]),
+    "himo_nsf_forward": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p,
+                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "himo_nsf_backward": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+    "himo_nsf_update": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                       ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p]),
     "himo_dt_volume_bytes": (ctypes.c_size_t, [ctypes.c_void_p]),
     "himo_dt_build": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
@@ -102,9 +117,11 @@ def init_mlp(seed: int = 0) -> list:
 class FastNSF:
     def __init__(self, device=None, lr: float = 1e-3, iters: int = 100, seed: int = 0, trunc: float = TRUNC,
                  early_patience: int = 0, early_min_delta: float = 1e-4, objective: str = "dt", dt_cell: float = DT_CELL, dt_box=None,
-                 precision: str = "mixed", fused: bool = True):
+                 precision: str = "mixed", fused: bool = True, three_launch: bool = True):
         """``fused`` (mixed precision only): the whole forward pass and the whole chain of input gradients as ONE kernel each
-        (csrc/mlpfused.hip) instead of a row GEMM per layer and direction.
+        instead of a row GEMM per layer and direction; with ``three_launch`` (default; "dt" objective) also the objective, every
+        weight gradient and the optimiser step: three launches per iteration (csrc/nsffused.hip) -- ``three_launch=False`` keeps
+        round 3's kernels (csrc/mlpfused.hip + a split-K weight-gradient product per layer), which the tests compare with.
         ``precision``: "mixed" (default) runs the MLP's products on the 16-bit matrix instructions with split operands -- forward
         fp16 split (x = h + l: 22-bit products; activations are O(1) and coordinates < 64 m), input gradients and weight gradients
         two-term bf16 (16 significant bits at float32's range: gradients sit far below fp16's subnormal floor), float32 sums
@@ -115,6 +132,7 @@ class FastNSF:
             raise ValueError(precision)
         self.mixed = precision == "mixed"
         self.fused = bool(fused) and self.mixed
+        self.three_launch = bool(three_launch)
         self.lib = _lib.load()
         self.device = device if device is not None else _lib.require_gpu()
         self.lr, self.iters, self.seed, self.trunc = lr, iters, seed, trunc
@@ -137,10 +155,12 @@ class FastNSF:
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g, self.flat_m, self.flat_v = (torch.zeros_like(self.flat_p) for _ in range(3))
         self.W, self.b, self.gW, self.gb, self.Wt = [], [], [], [], []
+        self.off_w, self.off_b = [], []
         host = np.zeros(total, np.float32)
         o = 0
         for (w, b), (pin, pout) in zip(layers, shapes):
             cin, cout = w.shape
+            self.off_w.append(o); self.off_b.append(o + pin * pout)
             wp = host[o:o + pin * pout].reshape(pin, pout); wp[:cin, :cout] = w
             self.W.append(self.flat_p[o:o + pin * pout].view(pin, pout)); self.gW.append(self.flat_g[o:o + pin * pout].view(pin, pout))
             o += pin * pout
@@ -211,6 +231,8 @@ class FastNSF:
         up = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(dev, torch.float32)
         p0_raw, p1 = up(pc0)[:, :3].contiguous(), up(pc1)[:, :3].contiguous()
         n, n1 = p0_raw.shape[0], p1.shape[0]
+        if self.fused and self.three_launch and self.objective == "dt" and n > 0:
+            return self._fit_three_launches(p0_raw, p1, pose0, pose1, layers)
         # ego transform (host 4x4, float32 like seflow/spec.py step 0), applied by the pillar front end's rule
         T = np.eye(4) if pose0 is None else np.linalg.inv(np.asarray(pose1, np.float64)) @ np.asarray(pose0, np.float64)
         T32 = torch.from_numpy(np.ascontiguousarray(T, dtype=np.float32)).to(dev)
@@ -312,6 +334,81 @@ class FastNSF:
         # flow incl. ego motion = (p' + f(p')) - p
         _lib.check(lib.himo_rows_add(n, 3, self.X0.data_ptr(), 4, self.OUT.data_ptr(), 4, 1.0, moved.data_ptr(), 3, 0, s()), "rows_add")
         _lib.check(lib.himo_rows_add(n, 3, moved.data_ptr(), 3, p0_raw.data_ptr(), 3, -1.0, flow.data_ptr(), 3, 0, s()), "rows_add")
+        return flow
+
+    def _fit_three_launches(self, p0_raw, p1, pose0, pose1, layers) -> torch.Tensor:
+        """The default path: per iteration himo_nsf_forward -> himo_nsf_backward -> himo_nsf_update (csrc/nsffused.hip)."""
+        lib, dev, s = self.lib, self.device, _lib.stream_handle
+        n, n1 = p0_raw.shape[0], p1.shape[0]
+        T = np.eye(4) if pose0 is None else np.linalg.inv(np.asarray(pose1, np.float64)) @ np.asarray(pose0, np.float64)
+        T32 = torch.from_numpy(np.ascontiguousarray(T, dtype=np.float32)).to(dev)
+        n_pad = int(lib.himo_nsf_padded_rows(n))
+        tiles, blocks = n_pad // 64, int(lib.himo_nsf_backward_blocks(n))
+        self.X0 = torch.zeros((n_pad, 4), dtype=torch.float32, device=dev)[:n]                 # [x', y', z', 0]; padding rows zero
+        _lib.check(lib.himo_rigid_transform(n, p0_raw.data_ptr(), 3, T32.data_ptr(), self.X0.data_ptr(), 4, s()), "rigid")
+        self._load(init_mlp(self.seed) if layers is None else layers)
+        L = len(self.W)                                         # 1 + (N_HIDDEN - 1) + 1 layers
+        total = self.flat_p.numel()
+        stride = (total + 63) // 64 * 64
+        self.OUT = torch.zeros((n_pad, 4), dtype=torch.float32, device=dev)[:n]               # (views of the padded buffers)
+        self.dOUT = torch.zeros((n_pad, 4), dtype=torch.float32, device=dev)[:n]
+        spill = torch.empty(int(lib.himo_nsf_spill_bytes(n, N_HIDDEN)), dtype=torch.uint8, device=dev)
+        partial = torch.empty((blocks, stride), dtype=torch.float32, device=dev)
+        loss_partial = torch.zeros(tiles, dtype=torch.float64, device=dev)
+        count_partial = torch.zeros(tiles, dtype=torch.int32, device=dev)
+        loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        # the target sweep as a distance-transform volume, built once for this pair
+        origin, dims, window = dt_grid(self.trunc, self.dt_cell, self.dt_box)
+        o_c, d_c = (ctypes.c_float * 3)(*origin.tolist()), (ctypes.c_int * 3)(*dims.tolist())
+        need = int(lib.himo_dt_volume_bytes(d_c))
+        if self._dt_vol is None or self._dt_vol.numel() < need:
+            self._dt_vol = torch.empty(need, dtype=torch.uint8, device=dev)
+        _lib.check(lib.himo_dt_build(n1, p1.data_ptr(), o_c, self.dt_cell, d_c, window, self._dt_vol.data_ptr(), self._dt_vol.numel(), s()),
+                   "himo_dt_build")
+        P = ctypes.c_void_p * N_HIDDEN
+        hid = lambda bufs: P(*([None] + [bufs[k].data_ptr() for k in range(1, L - 1)]))
+        wf, wb, bias = hid(self.pk_fwd), hid(self.pk_bwd), hid(self.b)
+        I = ctypes.c_int * L
+        off_w, off_b = I(*self.off_w), I(*self.off_b)
+
+        def forward(with_objective: bool):
+            _lib.check(lib.himo_nsf_forward(n, self.X0.data_ptr(), N_HIDDEN, self.W[0].data_ptr(), self.b[0].data_ptr(), wf, bias,
+                                            self.W[L - 1].data_ptr(), self.b[L - 1].data_ptr(), spill.data_ptr(), self.OUT.data_ptr(),
+                                            o_c, self.dt_cell, d_c, window, self._dt_vol.data_ptr(), self.trunc,
+                                            self.dOUT.data_ptr() if with_objective else None, loss_partial.data_ptr(), count_partial.data_ptr(),
+                                            s()), "himo_nsf_forward")
+
+        self.loss_history, best, stale = [], float("inf"), 0
+        for it in range(1, self.iters + 1):
+            forward(True)
+            _lib.check(lib.himo_nsf_backward(n, self.X0.data_ptr(), self.dOUT.data_ptr(), N_HIDDEN, wb, self.W[L - 1].data_ptr(), spill.data_ptr(),
+                                             off_w, off_b, stride, partial.data_ptr(), s()), "himo_nsf_backward")
+            _lib.check(lib.himo_nsf_update(total, blocks, stride, partial.data_ptr(), tiles, spill.data_ptr(), loss_partial.data_ptr(), count_partial.data_ptr(),
+                                           self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
+                                           self.lr, 0.9, 0.999, 1e-8, it, N_HIDDEN, off_w, wf, wb, loss.data_ptr(), count.data_ptr(), s()),
+                       "himo_nsf_update")
+            if self.early_patience > 0 or it == self.iters or it <= 3:
+                lv = float(loss.item())
+                self.loss_history.append((it, lv))
+                if self.early_patience > 0:
+                    if lv < best - self.early_min_delta:
+                        best, stale = lv, 0
+                    else:
+                        stale += 1
+                        if stale >= self.early_patience:
+                            break
+        # (tests read the objective's gradient of the LAST iteration: d loss / d moved = dOUT / points in the volume)
+        m_in = max(int(count.item()), 1)
+        self._gmoved = self.dOUT[:, :3] / float(m_in)
+        self.points_in_volume = m_in
+        forward(False)
+        moved = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        flow = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        # flow incl. ego motion = (p' + f(p')) - p
+        _lib.check(lib.himo_rows_add(n, 3, self.X0.data_ptr(), 4, self.OUT.data_ptr(), 4, 1.0, moved.data_ptr(), 3, 0, s()), "rows_add")
+        _lib.check(lib.himo_rows_add(n, 3, moved.data_ptr(), 3, p0_raw.data_ptr(), 3, -1.0, flow.data_ptr(), 3, 0, s()), "rows_add")
+        self._moved = moved
         return flow
 
     def layers(self) -> list:

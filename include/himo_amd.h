@@ -535,6 +535,35 @@ int himo_weight_prepare_batch(const himo_weight_job* d_jobs, int n_jobs, int tot
 int himo_mlp_repack(int n_layers, const float* const* h_w, const int* h_cin, const int* h_cout, void* const* h_fwd_packed,
                     void* const* h_bwd_packed, void* stream);
 
+/* FastNSF (README.md:53 `model=fastnsf`; specification himo_amd/fastnsf.py, PARITY UNPINNED) -- one optimiser iteration of the
+ * coordinate MLP as THREE launches (csrc/nsffused.hip):
+ *   himo_nsf_forward   the MLP over all points (activations spilled as two-term bf16 matrix fragments + ReLU mask bits for the backward
+ *                      pass) and, when d_dout is given, the distance-transform objective of the moved points: d loss / d out
+ *                      WITHOUT the 1 / (points in the volume) factor, per-tile loss and count sums, and the last layer's own
+ *                      gradients per tile (into d_spill);
+ *   himo_nsf_backward  the whole chain of input gradients AND the gradient of every parameter, summed over each block of 256
+ *                      points: d_partial [himo_nsf_backward_blocks(n)][partial_stride], each row laid out like the flat parameter
+ *                      vector (h_off_w[i] / h_off_b[i]: float offsets of layer i's W [cin][cout] / b; i = 0 first (W [4][128]),
+ *                      1 .. n_hidden - 1 hidden, n_hidden last (W [128][4]));
+ *   himo_nsf_update    fixed-order sum of the block rows / (points in the volume) -> d_grad, one Adam step on d_param / d_m / d_v,
+ *                      the packed copies of every hidden W (himo_mlp_repack's two formats), the loss and the count.
+ * EVERY [n][.] buffer (d_x0, d_out, d_dout) holds himo_nsf_padded_rows(n) rows (whole blocks of 4 x 64 points, no bounds checks);
+ * d_x0's padding rows must be zero.  d_spill: himo_nsf_spill_bytes(n, n_hidden).  2 <= n_hidden <= 12. */
+int64_t himo_nsf_padded_rows(int64_t n);
+size_t himo_nsf_spill_bytes(int64_t n, int n_hidden);
+int himo_nsf_backward_blocks(int64_t n);
+int himo_nsf_forward(int64_t n, const float* d_x0, int n_hidden, const float* d_w_first, const float* d_b_first,
+                     const void* const* h_w_hidden_packed, const float* const* h_b_hidden, const float* d_w_last, const float* d_b_last,
+                     void* d_spill, float* d_out, const float* h_origin, float cell, const int* h_dims, int window, const void* d_volume,
+                     float trunc_dist, float* d_dout, double* d_loss_partial, int* d_count_partial, void* stream);
+int himo_nsf_backward(int64_t n, const float* d_x0, const float* d_dout, int n_hidden, const void* const* h_wT_hidden_packed,
+                      const float* d_w_last, const void* d_spill, const int* h_off_w, const int* h_off_b, int64_t partial_stride,
+                      float* d_partial, void* stream);
+int himo_nsf_update(int total, int n_partials, int64_t partial_stride, const float* d_partial, int n_fwd_blocks, const void* d_spill,
+                    const double* d_loss_partial, const int* d_count_partial, float* d_param, float* d_grad, float* d_m, float* d_v,
+                    float lr, float beta1, float beta2, float eps, int step, int n_hidden, const int* h_off_w, void* const* h_fwd_packed,
+                    void* const* h_bwd_packed, double* d_loss, int* d_count, void* stream);
+
 /* FastNSF's coordinate MLP (3 -> 128 x n_hidden, ReLU -> 3; himo_amd/fastnsf.py) over all n points as ONE kernel per direction
  * (csrc/mlpfused.hip): the forward pass writes the post-ReLU activations h_H[k] [n][128] and d_out [n][4]; the backward pass turns
  * d_dout [n][4] into the masked gradients h_dZ[k] [n][128] at every hidden layer's output.  Hidden layer k = 1 .. n_hidden - 1 is
