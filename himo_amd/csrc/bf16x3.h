@@ -49,9 +49,6 @@ constexpr float kF16WeightScale = 64.0f, kF16AccScale = 1.0f / 64.0f;
 #endif
 
 __device__ inline void split2(float x, unsigned& h, unsigned& l) {
-#ifdef HIMO_EXP_NOSPLIT
-    { const unsigned u = __builtin_bit_cast(unsigned, x); h = u & 0x3fffu; l = (u >> 16) & 0x3fffu; return; }   // experiment: no conversion work
-#endif
     const _Float16 hh = (_Float16)x;                            // round to nearest even
     const _Float16 ll = (_Float16)((x - (float)hh) * kF16LowScale);
     h = __builtin_bit_cast(unsigned short, hh);

@@ -300,11 +300,7 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(UpArgs a) {
 #pragma unroll
     for (int part = 0; part < CPT / 4; ++part) {
         auto ld = [&](int yy, int xx) { return *reinterpret_cast<const float4*>(a.x + ((int64_t)yy * a.W + xx) * a.x_pitch + q * CPT + part * 4); };
-#ifdef HIMO_EXP_UPNOLOAD                     // experiment: stores only
-        const float4 v00 = make_float4(lx0, ly0, lx1, ly1), v01 = v00, v10 = v00, v11 = v00;
-#else
         const float4 v00 = ld(y0, x0), v01 = ld(y0, x1), v10 = ld(y1, x0), v11 = ld(y1, x1);
-#endif
         o[part * 4 + 0] = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
         o[part * 4 + 1] = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
         o[part * 4 + 2] = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
@@ -368,10 +364,7 @@ __global__ __launch_bounds__(256) void upsample2x_split_row_kernel(UpArgs a) {
 // output = 2.4-2.6 TB/s, while the same stores without the loads sustain 5.8).  Here a block owns kUpRows output rows x 256 / CQ output
 // columns: the (kUpRows / 2 + 2) x (PX / 2 + 2) source pixels they can touch are loaded ONCE, coalesced, into LDS (1.1 global loads per
 // 8 output channels instead of 8) and the four corners come from ds_read_b128.  Same arithmetic per value: identical bits.
-#ifndef HIMO_EXP_UPROWS
-#define HIMO_EXP_UPROWS 8
-#endif
-constexpr int kUpRows = HIMO_EXP_UPROWS;
+constexpr int kUpRows = 8;
 template <int CQ>
 __global__ __launch_bounds__(256) void upsample2x_split_lds_kernel(UpArgs a) {
     constexpr int PX = 256 / CQ, NC = PX / 2 + 2, NR = kUpRows / 2 + 2, C = CQ * 8, C4 = C / 4;
@@ -542,7 +535,6 @@ extern "C" int himo_upsample2x_batch_ex(int n, const float* d_x, int64_t x_batch
     a.ry = h > 1 ? (float)(h - 1) / (float)(2 * h - 1) : 0.f;
     a.rx = w > 1 ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
     ProfScope ps("upsample2x_kernel", (hipStream_t)stream);
-#if !defined(HIMO_EXP_UP8) && !defined(HIMO_EXP_UPROW)
     if (out_split && (c == 64 || c == 128 || c == 256) && (2 * h + kUpRows - 1) / kUpRows <= 65535 && n <= 65535) {
         const int cq = c / 8, px = 256 / cq;
         const dim3 grid((2 * w + px - 1) / px, (2 * h + kUpRows - 1) / kUpRows, n);
@@ -552,15 +544,12 @@ extern "C" int himo_upsample2x_batch_ex(int n, const float* d_x, int64_t x_batch
         HIMO_LAUNCH_CHECK("upsample2x_split_lds_kernel");
         return HIMO_OK;
     }
-#endif
-#ifndef HIMO_EXP_UP8                         // (experiment switch: the flat-index kernel of rounds 1-2 for the split output as well)
     if (out_split && 2 * h <= 65535 && n <= 65535 && (int64_t)w * x_pitch < ((int64_t)1 << 31)) {
         const unsigned row_items = (unsigned)(2 * w) * (unsigned)(c / 8);
         hipLaunchKernelGGL(upsample2x_split_row_kernel, dim3((row_items + 255) / 256, 2 * h, n), dim3(256), 0, (hipStream_t)stream, a);
         HIMO_LAUNCH_CHECK("upsample2x_split_row_kernel");
         return HIMO_OK;
     }
-#endif
     const int64_t total = (int64_t)(2 * h) * (2 * w) * (c / (out_split ? 8 : 4));
     const dim3 grid((unsigned)((total + 255) / 256), n);
     if (out_split) hipLaunchKernelGGL(upsample2x_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);

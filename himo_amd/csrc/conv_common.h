@@ -52,13 +52,9 @@ __device__ inline int64_t image_offset(int img, int n_inner, int64_t batch_strid
 // run on the same XCD close in time and meet in its L2.  Bijective for any grid size; a different placement would change
 // speed only.
 __device__ inline int xcd_block_id(int bid, int n_blocks) {
-#ifdef HIMO_EXP_NOXCD
-    return bid;
-#else
     const int per = n_blocks >> 3, rem = n_blocks & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     return xcd * per + (xcd < rem ? xcd : rem) + idx;
-#endif
 }
 
 // GELU through erf(|v| / sqrt 2) = 1 - p(t) t exp(-v^2 / 2), t = 1 / (1 + 0.3275911 |v| / sqrt 2) (Abramowitz & Stegun 7.1.26, 1.5e-7
@@ -195,32 +191,15 @@ __device__ inline void store_block_vec(const ConvArgs& a, float* __restrict__ yo
                 const float4 m = *reinterpret_cast<const float4*>(a.aux_in + (pix0 + px) * (int64_t)a.aux_in_pitch + ch0 + piece * 4);
                 d.x = m.x > 0.f ? d.x : 0u; d.y = m.y > 0.f ? d.y : 0u; d.z = m.z > 0.f ? d.z : 0u; d.w = m.w > 0.f ? d.w : 0u;
             }
-#ifdef HIMO_EXP_STORE_SCRATCH          // experiment: same store instructions, but into a 2 MB window (stays in L2: no HBM write traffic)
-            float* dst = a.y + ((((pix0 + px) * (int64_t)a.y_pitch + ch0 + piece * 4) & 0x7ffff) + (blockIdx.x & 7) * 0) ;
-#else
             // 32-bit offset from the (uniform) image base: vec_store_ok() admits only images below 2 GB, and a 64-bit multiply-add per
             // store was ~8 vector instructions of the block's ~60
             float* dst = yout + (((unsigned)pix0 + (unsigned)px) * (unsigned)a.y_pitch + (unsigned)(ch0 + piece * 4));
-#endif
             if (ACC) {                                     // y += result (float32 words)
                 const float4 o = *reinterpret_cast<const float4*>(dst);
                 d.x = __builtin_bit_cast(unsigned, o.x + __builtin_bit_cast(float, d.x)); d.y = __builtin_bit_cast(unsigned, o.y + __builtin_bit_cast(float, d.y));
                 d.z = __builtin_bit_cast(unsigned, o.z + __builtin_bit_cast(float, d.z)); d.w = __builtin_bit_cast(unsigned, o.w + __builtin_bit_cast(float, d.w));
             }
-#if defined(HIMO_EXP_STORE_NT)
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(u32x4{d.x, d.y, d.z, d.w}, reinterpret_cast<u32x4*>(dst));
-#elif defined(HIMO_EXP_STORE_SC1)
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 dv = {d.x, d.y, d.z, d.w};
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(dv) : "memory");
-#elif defined(HIMO_EXP_STORE_SC01)
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 dv = {d.x, d.y, d.z, d.w};
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(dv) : "memory");
-#else
             *reinterpret_cast<uint4*>(dst) = d;
-#endif
         }
     }
     __builtin_amdgcn_wave_barrier();

@@ -36,27 +36,6 @@ namespace himo {
 
 __device__ __attribute__((aligned(64))) unsigned char g_zero_page[64];
 
-#ifdef HIMO_EXP_STAGGER
-// experiment: put the blocks that share a CU out of phase.  Blocks of one launch have identical lengths and the first round
-// starts together, so the OCC blocks of a CU reach their epilogues (VALU + a burst of stores, matrix pipe idle) together,
-// round after round.  Each first-round block takes a ticket from its CU's arrival counter (HW_ID: XCC / SE / SH / CU) and
-// waits ticket % OCC phases of `phase_cycles` before it starts; later blocks inherit the offsets.
-__device__ unsigned g_cu_arrivals[8 * 256];
-__device__ inline void stagger_start(int first_round_blocks, int occ, long long phase_cycles) {
-    if ((int)blockIdx.x >= first_round_blocks) return;
-    __shared__ int phase;
-    if (threadIdx.x == 0) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const unsigned slot = (xcc & 7) * 256 + ((hw >> 8) & 0xff);          // CU_ID[11:8] SH_ID[12] SE_ID[15:13]
-        phase = (int)(atomicAdd(&g_cu_arrivals[slot], 1u) % (unsigned)occ);
-    }
-    __syncthreads();
-    const long long until = clock64() + (long long)phase * phase_cycles;
-    while (clock64() < until) __builtin_amdgcn_s_sleep(32);
-}
-#endif
 
 __device__ inline void glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -81,13 +60,6 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int BN = (4 / PH) * 32 * NT;                       // NT column tiles of 32 channels per wave
     __shared__ __attribute__((aligned(1024))) unsigned char patch[2 * kBuf];
 
-#ifdef HIMO_EXP_STAGGER
-    {
-        constexpr int OCC = (S == 2 || MI == 4) ? 3 : 4;
-        if ((int)gridDim.x >= 256 * OCC * 6)                       // only launches of many rounds: the start-up wait is paid once
-            stagger_start(256 * OCC, OCC, (long long)(a.Cin >> 4) * 9 * 3 * MI * 32 * HIMO_EXP_STAGGER / 100);
-    }
-#endif
     const int n_tiles_n = (a.Cout + BN - 1) / BN;
     int bid = xcd_block_id(blockIdx.x, gridDim.x);
     const int tn = bid % n_tiles_n; bid /= n_tiles_n;
@@ -171,9 +143,6 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     stage(0, 0);
     load_b(0, 0, bq[0]);
     load_b(1, 0, bq[1]);
-#ifdef HIMO_EXP_NOB
-    load_b(2, 0, bq[2]);                       // experiment: real operand values, loaded once
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -182,9 +151,7 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         const int buf = slab & 1;
         const bool more = slab + 1 < slabs;
         const int nslab = more ? slab + 1 : slab;
-#ifndef HIMO_EXP_NOSTAGE
         if (more) stage(slab + 1, buf ^ 1);                  // that buffer was last read before the previous barrier
-#endif
 #pragma unroll 1
         for (int ky = 0; ky < 3; ++ky) {
             const int rowoff = buf * kBuf + ky * kRow;
@@ -192,9 +159,7 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
             for (int kx = 0; kx < 3; ++kx) {
                 const int tap = ky * 3 + kx;
                 const int t2 = tap + 2;
-#ifndef HIMO_EXP_NOB
                 load_b(t2 < 9 ? t2 : t2 - 9, t2 < 9 ? slab : nslab, bq[(kx + 2) % 3]);
-#endif
                 f16x8 af[MI][2];
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
@@ -205,27 +170,20 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #define HIMO_TERM16(SA, SB)                                                                                        \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)              \
         acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][SA], __builtin_bit_cast(f16x8, bcur[nt][SB]), acc[mi][nt], 0, 0, 0);
-#ifdef HIMO_EXP_NOMFMA                       // experiment: everything but the matrix instructions
-                if (af[0][0][0] == (_Float16)12345.f)
-#endif
                 { HIMO_TERM16(1, 0) HIMO_TERM16(0, 1) HIMO_TERM16(0, 0) }
 #undef HIMO_TERM16
-#ifndef HIMO_EXP_NOSCHED
                 // this tap's weight prefetch and ALL its activation-fragment reads before its matrix instructions (the
                 // compiler otherwise feeds each MFMA pair from a just-issued ds_read and sinks the prefetch next to its use)
                 __builtin_amdgcn_sched_group_barrier(0x020, 2 * NT, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, MI * 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, MI * NT * 3, 0);
-#endif
             }
         }
-#ifndef HIMO_EXP_NOBAR
         if (more) {
             if (NT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // at most the next slab's first two weight fragments stay in flight
             __syncthreads();
         }
-#endif
     }
 
     float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
@@ -236,7 +194,6 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         epi_affine<EPI>(kF16AccScale, a.bias ? a.bias[c] : 0.f, EPI == kEpiBiasBnGelu ? a.scale[c] : 1.f, EPI == kEpiBiasBnGelu ? a.shift[c] : 0.f,
                         eA[nt], eB[nt]);
     }
-#if !defined(HIMO_EXP_NOEPI) && !defined(HIMO_EXP_NOSTORE) && !defined(HIMO_EXP_DWORDSTORE)
     if (NT > 1 || (a.act_flags & kActVecStore)) {   // 16-byte stores through a wave-private LDS transpose (store_block_vec)
         __syncthreads();                         // every wave has read its last patch rows: the patch memory is free
         unsigned char* stg = patch + wave * 4096;
@@ -257,7 +214,6 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         }
         return;
     }
-#endif
     if (!co_ok) return;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -265,22 +221,11 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-#if defined(HIMO_EXP_NOEPI)                    // experiment: no activation / split arithmetic, same stores (results are wrong)
-            const float v = fmaf(acc[mi][0][r], eA[0], eB[0]);
-            if (oy < a.Ho && ox < a.Wo) yout[((int64_t)oy * a.Wo + ox) * a.y_pitch + (OSPLIT ? (co & ~15) + ((co & 1) ? 8 : 0) + ((co & 15) >> 1) : co)] = v;
-#elif defined(HIMO_EXP_NOSTORE)                // experiment: full epilogue arithmetic, (almost) no stores
-            if (oy < a.Ho && ox < a.Wo) {
-                const float v = epi_activate<EPI>(acc[mi][0][r], eA[0], eB[0]);
-                const unsigned w = split2_packed(v);
-                if (w == 0x12345u) yout[((int64_t)oy * a.Wo + ox) * a.y_pitch + co] = v;
-            }
-#else
             if (oy < a.Ho && ox < a.Wo) {                       // (scalar-store fallback: outputs that do not admit 16-byte stores)
                 const float v = epi_activate<EPI>(acc[mi][0][r], eA[0], eB[0]);
                 if (OSPLIT) split_store<kEpiBias, true>(a, yout, (int64_t)oy * a.Wo + ox, co, v, 1.f, 0.f);
                 else yout[((int64_t)oy * a.Wo + ox) * a.y_pitch + co] = v;
             }
-#endif
         }
     }
 }
@@ -392,7 +337,6 @@ void conv1_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
     float eA, eB;
     epi_affine<EPI>(kF16AccScale, a.bias ? a.bias[co_ld] : 0.f, EPI == kEpiBiasBnGelu ? a.scale[co_ld] : 1.f, EPI == kEpiBiasBnGelu ? a.shift[co_ld] : 0.f, eA, eB);
-#if !defined(HIMO_EXP_DWORDSTORE)
     if (a.act_flags & kActVecStore) {            // 16-byte stores through a wave-private LDS transpose (store_block_vec)
         __syncthreads();
         unsigned char* stg = patch + wave * 4096;
@@ -410,7 +354,6 @@ void conv1_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         }
         return;
     }
-#endif
     if (!co_ok) return;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -515,9 +458,7 @@ bool launch_conv3_presplit(const ConvArgs& a, int epilogue, const void* w_packed
     };
     int mi = blocks_for(4) >= 1024 ? 4 : 2;
     if (rows_hint == 4 || rows_hint == 2 || rows_hint == 1) mi = rows_hint;
-#ifndef HIMO_EXP_PH2MI4
     if (!wide && mi == 4) mi = 2;                       // 64-channel blocks: 8-row patches would not leave three blocks per CU
-#endif
     const dim3 grid((unsigned)blocks_for(mi));
     const unsigned short* w = (const unsigned short*)w_packed;
     ProfScope ps("conv3x3_f16x2_kernel", s);
@@ -526,9 +467,6 @@ bool launch_conv3_presplit(const ConvArgs& a, int epilogue, const void* w_packed
         else if (mi == 2) launch_sg<1, 2>(a, epilogue, out_split, w, grid, s);
         else launch_sg<1, 1>(a, epilogue, out_split, w, grid, s);
     } else {
-#ifdef HIMO_EXP_PH2MI4
-        if (mi == 4) launch_sg<2, 4>(a, epilogue, out_split, w, grid, s); else
-#endif
         if (mi == 2) launch_sg<2, 2>(a, epilogue, out_split, w, grid, s);
         else launch_sg<2, 1>(a, epilogue, out_split, w, grid, s);
     }

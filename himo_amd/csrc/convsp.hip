@@ -158,9 +158,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         const int buf = NB == 2 ? (slab & 1) : 0;
         const bool more = slab + 1 < slabs;
         const int nslab = more ? slab + 1 : slab;            // clamped: the last slab re-loads its own (unused) weights
-#ifndef HIMO_EXP_NOSTAGE
         if (more) load_patch(slab + 1, pr);
-#endif
 #pragma unroll 1
         for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -168,9 +166,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
                 const int tap = ky * 3 + kx;
                 {   // prefetch tap + 2 (of this slab, or taps 0 / 1 of the next)
                     const int t2 = tap + 2;
-#ifndef HIMO_EXP_NOB
                     load_b(t2 < 9 ? t2 : t2 - 9, t2 < 9 ? slab : nslab, bq[(kx + 2) % 3]);
-#endif
                 }
                 const int tapoff = S == 1 ? ky * PW + kx : ky * PW + (kx & 1) * 33 + (kx >> 1);
                 bf16x8 af[MI][NP];
@@ -178,11 +174,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
                 for (int s = 0; s < NP; ++s)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
-#ifdef HIMO_EXP_NOA
-                        af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[0][s][PL::slot(li, lh) + (slab & 1) * 64]);
-#else
                         af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[buf][s][PL::slot((wp * MI + mi) * S * PW + li + tapoff, lh)]);
-#endif
                 const uint4 (&bcur)[NP] = bq[kx];
 #define HIMO_TERM(SA, SB)                                                                                          \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                \
@@ -212,15 +204,9 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
                     __builtin_amdgcn_sched_group_barrier(0x008, MI * 6, 0);
                 }
             }
-#ifndef HIMO_EXP_NOSTAGE
             if (NB == 2 && more) store_patch(buf ^ 1, pr, ky);   // the other buffer was last read before the previous barrier
-#endif
         }
-#ifdef HIMO_EXP_NOSTAGE
-        if (false) {
-#else
         if (more) {
-#endif
             if (NB == 1) {
                 __syncthreads();               // single buffer: every wave is done reading this slab's patch
                 store_patch(0, pr, -1);

@@ -73,11 +73,7 @@ struct GruHeadBatch {
 // for the whole kernel, and every GEMM of the head runs 9 slabs instead of 12: a quarter less matrix work, fragment reads,
 // weight stream and operand LDS, with no extra vector work.
 constexpr int kGhRows = 64;
-#ifdef HIMO_EXP_HLAUNDER                     // experiment: the inference kernel also recomputes its gate-stage LDS addresses per stage
-constexpr bool kGhLaunder = true;
-#else
 constexpr bool kGhLaunder = false;
-#endif
 
 template <int SLABS>
 __device__ inline int a_slot(int s, int slab, int row, int half) {
@@ -88,9 +84,6 @@ __device__ inline int a_slot(int s, int slab, int row, int half) {
 template <int FMT, int SLABS>
 __device__ inline void a_store(unsigned char* A, int row, int k, float v) {
     constexpr int kGhPlane = SLABS * kGhRows * 32;       // bytes per 16-bit plane
-#ifdef HIMO_EXP_HNOSTORE
-    if (v != 12345.678f) return;
-#endif
     unsigned h, m = 0, l;
     if (FMT == 3) split3(v, h, m, l); else split2(v, h, l);
     const int slab = k >> 4, kk = k & 15;
@@ -127,9 +120,7 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
     constexpr int kUnroll = SLABS % 2 == 0 ? 2 : 3;      // a divisor of the trip count: no remainder loop, no full unroll
 #pragma unroll kUnroll
     for (int slab = 0; slab < SLABS; ++slab) {
-#ifndef HIMO_EXP_HNOB
         if (slab + 1 < SLABS) load_b(slab + 1, bnxt);
-#endif
         bf16x8 af[RT][FMT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -143,9 +134,6 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) _Pragma("unroll") for (int t = 0; t < NT; ++t)                  \
         ACC[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[rt][SA]),                    \
                                                            __builtin_bit_cast(f16x8, bcur[t][SB]), ACC[rt][t], 0, 0, 0);
-#ifdef HIMO_EXP_HNOMFMA                      // experiment: operand traffic without the matrix instructions
-        if (af[0][0][0] == (__bf16)12345.f)
-#endif
         if constexpr (FMT == 3) {
             HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
         } else {
@@ -170,21 +158,14 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
     }
 }
 
-#ifdef HIMO_EXP_HNOGATE                      // experiment: the gates without their exp / rcp (results are wrong)
-#define sigmoid_f(v) ((v) * 0.25f + 0.5f)
-#define tanh_f(v) ((v) * 0.5f)
-#endif
 // (Round 3, measured and dropped -- profiles/r03_exp_head_gate_pipelining.txt: the z | r product as two products with the r
 // gate issued slab by slab under the z product's matrix instructions and the z gate under the q product's.  The unrolled slab
 // loop it needs costs 20 spilled registers at the 168 budget; 204-208 us per 120k points against 200.7.)
 // a saved value: uniform tensor base (scalar registers) + a 32-bit per-lane byte offset -- written as 64-bit pointers per element the
 // compiler hoists ~160 loop-invariant address registers out of the iteration loop and spills them
-#ifndef HIMO_EXP_SVMASK                  // experiment: bit k = keep the saves of group k (0 x, 1 h0, 2 z r, 3 r h, 4 q, 5 h', 6 decoder)
-#define HIMO_EXP_SVMASK 0xff
-#endif
 template <int GROUP>
 __device__ inline void sv_store(float* base, unsigned byte_off, float v) {
-    if ((HIMO_EXP_SVMASK >> GROUP) & 1) *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
 template <int FMT, int SLABS, bool SAVE = false>
@@ -337,9 +318,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
         gemm192<2, 2, FMT, SLABS>(A, a.wzr, 256, col_zr, acc, 0, li, lh);
-#ifndef HIMO_EXP_HNOWAR                                         // experiment (results are wrong): the two write-after-read barriers gone --
         __syncthreads();                                        // every wave has read [h | x]      the bound on what a second operand buffer could buy
-#endif
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -363,9 +342,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
 #pragma unroll
             for (int r = 0; r < 16; ++r) acq[rt][0][r] = 0.f;
         gemm192<2, 1, FMT, SLABS>(A, a.wq, 128, col_q, acq, 0, li, lh);
-#ifndef HIMO_EXP_HNOWAR
         __syncthreads();
-#endif
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll

@@ -210,9 +210,6 @@ __global__ __launch_bounds__(256) void pillar_feature_kernel(PillarBatch m) {
             *reinterpret_cast<float4*>(a.image + (int64_t)(cell0 + lc) * a.image_pitch + (threadIdx.x & 7) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-#ifdef HIMO_EXP_PILLAR_NOLOOP                 // experiment: prologue + zero fill only
-    if (s_nlist >= 0) return;
-#endif
     const int nlist = s_nlist;
     float w[9];
 #pragma unroll

@@ -171,3 +171,37 @@ def test_overflowing_weights_send_auto_to_the_bf16_split(gpu, so):
     frames = [make_frame(590 + i, n_points=20_000) for i in range(3)]
     row = _compare("gain_1e6_overflow", gpu, so, _with_gain(spec.init_params(3), 1e6), frames, 20_000, expect_auto="bf16x3")
     assert not row["f16x2"]["finite"]
+
+
+def test_trained_looking_weights_per_arithmetic_vs_cpu_restatement(gpu, so):
+    """every other case runs ``spec.init_params`` weights (He-uniform, BatchNorm gamma in [0.8, 1.2]).  The
+    f16x2 headline's range assumptions (|activation| < 65504, weights packed x 2^6) meet here the only trained-looking weights
+    this repo can produce: the parameters after 20 optimiser steps of its own trainer (BatchNorm in training mode: running
+    statistics and gamma / beta have moved; Adam has reshaped every weight tensor), on a full-size 3 x 120k sample, all three
+    arithmetics against the CPU restatement fed the SAME exported parameters."""
+    from himo_amd.dataset import ListDataset
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.fit import make_sample, triplets
+    from himo_amd.seflow.train import SeFlowTrainer
+    from himo_amd.synthetic import make_frame
+    train_frames = [make_frame(900 + i, n_points=30_000, scene_id="t") for i in range(6)]
+    ds = ListDataset(train_frames)
+    trips = triplets(ds)
+    tr = SeFlowTrainer(spec.init_params(3), device=gpu, max_points=32_000, batchnorm="batch")
+    losses = []
+    for step in range(20):
+        losses.append(float(tr.train_batch([make_sample(ds, trips[step % len(trips)], gpu)], lr=3e-4).item()))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    tr.sync_running_stats()
+    params = tr.export_params()
+    init = spec.init_params(3)
+    moved = max(float(np.abs(params[k] - init[k]).max()) for k in init if k.endswith(".weight"))
+    bn_moved = max(float(np.abs(params[k] - init[k]).max()) for k in init if k.endswith((".mean", ".var", ".gamma", ".beta")))
+    assert moved > 1e-3 and bn_moved > 1e-3, (moved, bn_moved)            # these really are not the initial weights any more
+    del tr
+    torch.cuda.empty_cache()
+    frames = [make_frame(950 + i, n_points=120_000) for i in range(3)]
+    row = _compare("trained_20_steps_120k", gpu, so, params, frames, 120_000, expect_auto=None)
+    row["weights_moved_max_abs"], row["batchnorm_moved_max_abs"] = moved, bn_moved
+    row["train_loss_first_last"] = [losses[0], losses[-1]]
+    assert row["f16x2"]["finite"]
