@@ -159,11 +159,18 @@ class HiMoPipeline:
         ``save.run`` writes.  In the fp16 split every call checks its flows for non-finite values BEFORE returning them (one
         host sync per call): ``precision="auto"`` redoes the batch in the bf16 split and stays there, an explicit
         ``"f16x2"`` raises FloatingPointError -- an overflowed activation never reaches a result file."""
+        _, outs = self._flows_launch(samples)
+        return self._flows_check(samples, outs)
+
+    def _flows_launch(self, samples):
         counts = [int(s.pc0.shape[0]) for s in samples]
         flat = torch.empty((sum(counts), 3), dtype=torch.float32, device=self.device)
         outs = list(torch.split(flat, counts)) if counts else []
         self._guard_begin()
         self._forward(samples, outs)
+        return flat, outs
+
+    def _flows_check(self, samples, outs):
         if not self._guard_now():
             if not self.auto:
                 raise FloatingPointError("non-finite flow: activations left the fp16 range of precision='f16x2'; "
@@ -217,3 +224,83 @@ class HiMoPipeline:
         if copy:
             out.update({k: out[k].clone() for k in ("flow", "comp_dis", "refined") if out[k] is not None})
         return out
+
+
+class OverlappedPipeline:
+    """Two batches in flight: two ``HiMoPipeline``s (own network buffers) fed alternately on two HIP streams, so that one batch's
+    latency-bound stages (pillar stage, stride-2 / 1x1 layers, upsampling, the head's gather) run under the other's matrix-bound
+    3x3 convolutions -- measured +4 % frames/s in round 3 (profiles/r03_exp_two_streams.txt) and adopted as the default way to
+    run a stream of batches in round 4.  Same kernels, same launch order within a batch: results are bit-identical to the
+    single-stream pipeline's (tests/test_pipeline_gpu.py).
+
+    ``run`` returns at once; the result dict carries ``"ready"`` (a HIP event recorded on the batch's stream).  Consume results
+    on a SIDE stream after ``ready`` (``feeder.ResultDrain`` does) or call ``wait(result)`` to make the current stream wait --
+    which also orders every later ``run`` behind this batch, i.e. a caller that consumes each result on the launch stream before
+    launching the next gets correct results and no overlap.  Result tensors of a batch stay valid until that inner pipeline's
+    next-but-one batch, i.e. for four ``run`` calls.  Inputs must be ready on the calling stream (``run`` makes the batch's
+    stream wait for the calling stream as of the call)."""
+
+    def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, max_batch: int = 8, precision: str = "auto",
+                 in_flight: int = 2, nets=None):
+        self.device = device if device is not None else _lib.require_gpu()
+        if nets is not None:
+            self.pipes = [HiMoPipeline(net, device=self.device) for net in nets]
+        else:
+            self.pipes = [HiMoPipeline(None, device=self.device, max_points=max_points, max_batch=max_batch, precision=precision, params=params)
+                          for _ in range(in_flight)]
+        for p in self.pipes[1:]:                                # one tuning table: a layer shape is timed once, by whoever meets it first
+            if hasattr(p.net, "tiles") and hasattr(self.pipes[0].net, "tiles"):
+                p.net.tiles = self.pipes[0].net.tiles       # (the tile variants of a layer are bit-identical: tests/test_seflow_gpu.py)
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in self.pipes]
+        self._turn = 0
+
+    @property
+    def net(self):
+        return self.pipes[0].net
+
+    def _next(self):
+        i = self._turn
+        self._turn = (self._turn + 1) % len(self.pipes)
+        st = self.streams[i]
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        return self.pipes[i], st
+
+    def run(self, samples, **kw) -> dict:
+        pipe, st = self._next()
+        with torch.cuda.stream(st):
+            out = pipe.run(samples, **kw)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        out["ready"], out["stream"] = ev, st
+        return out
+
+    def wait(self, result: dict) -> dict:
+        torch.cuda.current_stream(self.device).wait_event(result["ready"])
+        return result
+
+    def flows_stream(self, batches):
+        """``HiMoPipeline.flows`` over an iterable of sample lists with one batch of lookahead: yields (samples, flows) in order.
+        Batch k's finite-flow check (a host read-back: a sync of ITS stream) happens while batch k + 1 is already queued on the
+        other stream, so the device does not idle through it."""
+        pending = None
+        for samples in batches:
+            pipe, st = self._next()
+            with torch.cuda.stream(st):
+                flat, outs = pipe._flows_launch(samples)
+            if pending is not None:
+                yield pending[0], self._flows_finish(*pending)
+            pending = (samples, pipe, st, flat, outs)
+        if pending is not None:
+            yield pending[0], self._flows_finish(*pending)
+
+    def _flows_finish(self, samples, pipe, st, flat, outs):
+        with torch.cuda.stream(st):
+            outs = pipe._flows_check(samples, outs)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_stream(st)
+        flat.record_stream(cur)                                 # allocated on the batch's stream, consumed on the caller's
+        return outs
+
+    def sync_check(self):
+        for p in self.pipes:
+            p.sync_check()

@@ -189,12 +189,14 @@ def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, si
     """Flow for every frame of ``dataset`` that has a ``pc1`` / next sweep.  Returns the frames this rank processed.
     Frames are read, staged in pinned memory and copied to the device by a background thread two batches ahead of the
     network (``feeder.SampleFeeder``); results leave through pinned buffers and a writer thread (``feeder.ResultDrain``),
-    so neither the dataset reads nor the sink's file writes stall the launch thread.  ``HiMoPipeline.flows`` checks every
-    batch for fp16-range overflow before it is handed to the sink (auto: redone in the bf16 split)."""
+    so neither the dataset reads nor the sink's file writes stall the launch thread.  The network runs two batches in flight
+    (``pipeline.OverlappedPipeline``; pass a ``HiMoPipeline`` as ``pipeline`` for the single-stream path); every batch is
+    checked for fp16-range overflow before it is handed to the sink (auto: redone in the bf16 split)."""
     import torch.distributed as dist
     from .feeder import ResultDrain, SampleFeeder
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
-    pipe = pipeline if pipeline is not None else HiMoPipeline(params=params, max_batch=max(1, batch_frames))
+    from .pipeline import OverlappedPipeline
+    pipe = pipeline if pipeline is not None else OverlappedPipeline(params=params, max_batch=max(1, batch_frames))
     results = {} if sink is None else None
 
     def deliver(key, flow):
@@ -207,8 +209,19 @@ def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, si
     drain = ResultDrain(deliver, device=pipe.device)
     done = 0
     try:
-        for batch in SampleFeeder(frame_source(dataset, rank, world, by_scene=by_scene), device=pipe.device, batch=max(1, batch_frames)):
-            for (i, f0, _), flow in zip(batch, pipe.flows([s for _, _, s in batch])):
+        feeder = SampleFeeder(frame_source(dataset, rank, world, by_scene=by_scene), device=pipe.device, batch=max(1, batch_frames))
+        if isinstance(pipe, OverlappedPipeline):               # two batches in flight: batch k's finite-flow check under batch k + 1
+            queued = []
+
+            def sample_lists():
+                for batch in feeder:
+                    queued.append(batch)
+                    yield [s for _, _, s in batch]
+            batches = ((queued.pop(0), flows) for _, flows in pipe.flows_stream(sample_lists()))
+        else:
+            batches = ((batch, pipe.flows([s for _, _, s in batch])) for batch in feeder)
+        for batch, flows in batches:
+            for (i, f0, _), flow in zip(batch, flows):
                 drain.put((i, f0), flow)
                 done += 1
     finally:

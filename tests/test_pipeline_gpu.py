@@ -454,3 +454,44 @@ def test_cli_programs_as_two_ranks_on_this_box(gpu, tmp_path):
     torchrun("himo_amd.seflow.fit", "--dataset_path", str(two), "--out_dir", str(tmp_path / "ckpt"), "--epochs", "1", "--batch_size", "2",
              cwd=tmp_path / "two")
     assert list((tmp_path / "ckpt").glob("*.npz"))
+
+
+def test_two_batches_in_flight_deliver_the_single_stream_bits(gpu):
+    """pipeline.OverlappedPipeline (two networks' buffers, two HIP streams, batches alternate) against HiMoPipeline on the same
+    stream of ragged batches: flow and comp_dis of every batch bit-identical, whatever co-runs; and ``flows_stream`` (the
+    ``save`` program's path, finite-flow check of batch k under batch k + 1) against ``HiMoPipeline.flows``."""
+    from himo_amd.pipeline import HiMoPipeline, OverlappedPipeline, Sample
+    from himo_amd.seflow import spec
+    from himo_amd.synthetic import make_frame
+    params = spec.init_params(2)
+    frames = [make_frame(300 + i, n_points=9_000 + 137 * (i % 5)) for i in range(12)]
+    batches = [[Sample.from_frames(frames[j], frames[j + 1], frames[j + 2], device=gpu) for j in range(lo, lo + n)]
+               for lo, n in ((0, 3), (3, 2), (5, 3), (8, 1), (2, 3), (6, 2))]
+    single = HiMoPipeline(device=gpu, max_points=10_000, max_batch=3, params=params, precision="f16x2")
+    want = []
+    for b in batches:
+        r = single.run(b, copy=True)
+        want.append((r["flow"].clone(), r["comp_dis"].clone()))
+    single.sync_check()
+    two = OverlappedPipeline(params=params, device=gpu, max_points=10_000, max_batch=3, precision="f16x2")
+    side = torch.cuda.Stream(device=gpu)
+    got = []
+    for b in batches:                                             # results consumed on a side stream, as feeder.ResultDrain does
+        r = two.run(b)
+        with torch.cuda.stream(side):
+            side.wait_event(r["ready"])
+            got.append((r["flow"].clone(), r["comp_dis"].clone()))
+    two.sync_check()
+    torch.cuda.synchronize()
+    for (f0, c0), (f1, c1) in zip(want, got):
+        assert torch.equal(f0, f1) and torch.equal(c0, c1)
+    ref_flows = [[o.clone() for o in single.flows(b)] for b in batches]
+    seen = 0
+    for (samples, flows), ref in zip(two.flows_stream(iter(batches)), ref_flows):
+        assert len(flows) == len(ref) == len(samples)
+        for a, b in zip(flows, ref):
+            assert torch.equal(a, b)
+        seen += 1
+    assert seen == len(batches)
+    r = two.wait(two.run(batches[0]))                             # the convenience path: the current stream waits
+    assert torch.equal(r["flow"], want[0][0])
