@@ -1,0 +1,246 @@
+// dbscan.hip -- stage a11's missing input: the self-supervised cluster labels (`+ssl_label=seflow_auto`,
+// assets/slurm/ssl-train-av2.sh:32) generated on the GPU instead of read from files the reference tree does not hold.
+//
+// PARITY UNPINNED: the reference's label generator is in the absent OpenSceneFlow submodule; this is this
+// build's own specification (himo_amd/seflow/ssl_label.py), its oracle is sklearn.cluster.DBSCAN (oracle/dbscan_oracle.py).
+//
+// DBSCAN(eps, min_pts) over 3-D points, Euclidean, min_pts counting the point itself (sklearn's convention):
+//   core      a point with >= min_pts points within eps;
+//   clusters  connected components of the core points under "within eps" -- unique, whatever the processing order;
+//   border    a non-core point with a core point within eps joins a cluster; DBSCAN leaves WHICH one to the processing order, this
+//             build fixes it: the cluster whose lowest-index member is lowest among the clusters of its core neighbours;
+//   noise     everything else: label 0.  Points flagged in `skip` (ground, static) take no part and get label 0.
+// Labels are 1 .. K in the order of each cluster's lowest point index: the result is a pure function of the input.
+//
+// Structure: the points are counting-sorted into BEV cells of edge >= eps (HBM-bound integer work: histogram with integer atomics,
+// one-block exclusive scan, scatter of xyz + original index as one 16-byte row), so a point's neighbours are in its 3 x 3 cells;
+// core test = one pass over those cells with early exit; components = lock-free union-find on the original indices (hook the
+// larger root under the smaller with atomicMin: a component's root ends as its lowest index, deterministically); labels = find.
+#include "himo_common.h"
+#include <math.h>
+
+namespace himo {
+
+struct DbGrid {
+    float x0, y0, inv_cell;
+    int gw, gh;
+};
+
+__device__ inline int db_clamp(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+__global__ __launch_bounds__(256) void db_count_kernel(int n, const float* __restrict__ xyz, int pitch, const unsigned char* __restrict__ skip,
+                                                       DbGrid g, int* __restrict__ count, int* __restrict__ cell_id) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int c = -1;
+    const float x = xyz[(int64_t)i * pitch], y = xyz[(int64_t)i * pitch + 1], z = xyz[(int64_t)i * pitch + 2];
+    if (!(skip && skip[i]) && x == x && y == y && z == z) {                 // (NaN rows take no part)
+        const int cx = db_clamp((int)floorf((x - g.x0) * g.inv_cell), g.gw - 1), cy = db_clamp((int)floorf((y - g.y0) * g.inv_cell), g.gh - 1);
+        c = cy * g.gw + cx;
+        atomicAdd(&count[c], 1);
+    }
+    cell_id[i] = c;
+}
+
+// exclusive scan of v[0..n) in place by ONE block (n up to a few million: each thread owns a contiguous chunk); v[n] = the total
+__global__ __launch_bounds__(1024) void db_scan_kernel(int* __restrict__ v, int n) {
+    __shared__ int part[1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += v[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int y = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += y;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - s;
+    for (int i = lo; i < hi; ++i) { const int x = v[i]; v[i] = run; run += x; }
+    if (threadIdx.x == 1023) v[n] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void db_scatter_kernel(int n, const float* __restrict__ xyz, int pitch, const int* __restrict__ cell_id,
+                                                         const int* __restrict__ offset, int* __restrict__ cursor, float4* __restrict__ rows) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = cell_id[i];
+    if (c < 0) return;
+    const int slot = offset[c] + atomicAdd(&cursor[c], 1);
+    rows[slot] = float4{xyz[(int64_t)i * pitch], xyz[(int64_t)i * pitch + 1], xyz[(int64_t)i * pitch + 2], __int_as_float(i)};
+}
+
+// visit every row of the 3 x 3 cells around (cx, cy): f(row) returns false to stop
+template <typename F>
+__device__ inline void db_neighbours(const DbGrid& g, int cx, int cy, const int* __restrict__ offset, const float4* __restrict__ rows, F f) {
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int y = cy + dy;
+        if (y < 0 || y >= g.gh) continue;
+        const int x_lo = cx > 0 ? cx - 1 : 0, x_hi = cx + 1 < g.gw ? cx + 1 : g.gw - 1;
+        const int lo = offset[y * g.gw + x_lo], hi = offset[y * g.gw + x_hi + 1];          // the three cells of a row are contiguous
+        for (int s = lo; s < hi; ++s)
+            if (!f(rows[s])) return;
+    }
+}
+
+// one thread per SORTED row: core flag of its point (indexed by original index)
+__global__ __launch_bounds__(256) void db_core_kernel(const float4* __restrict__ rows, DbGrid g, const int* __restrict__ offset, float eps2,
+                                                      int min_pts, unsigned char* __restrict__ core) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= offset[g.gw * g.gh]) return;                       // the number of points that take part (db_scan_kernel's total)
+    const float4 p = rows[s];
+    const int cx = db_clamp((int)floorf((p.x - g.x0) * g.inv_cell), g.gw - 1), cy = db_clamp((int)floorf((p.y - g.y0) * g.inv_cell), g.gh - 1);
+    int cnt = 0;
+    db_neighbours(g, cx, cy, offset, rows, [&](const float4& q) {
+        const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+        if (dx * dx + dy * dy + dz * dz <= eps2) ++cnt;
+        return cnt < min_pts;
+    });
+    core[__float_as_int(p.w)] = cnt >= min_pts ? 1 : 0;
+}
+
+__device__ inline int db_find(const int* __restrict__ parent, int x) {
+    int p = parent[x];
+    while (p != x) { x = p; p = parent[x]; }
+    return x;
+}
+__device__ inline void db_union(int* __restrict__ parent, int a, int b) {
+    while (true) {
+        a = db_find(parent, a); b = db_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }            // hook the larger root a under the smaller b
+        const int old = atomicMin(&parent[a], b);
+        if (old == a) return;                                   // a was still a root: hooked
+        a = old;                                                // somebody hooked a meanwhile: carry on from there
+    }
+}
+
+// one thread per sorted row: a core point is joined with every core neighbour of lower original index
+__global__ __launch_bounds__(256) void db_union_kernel(const float4* __restrict__ rows, DbGrid g, const int* __restrict__ offset, float eps2,
+                                                       const unsigned char* __restrict__ core, int* __restrict__ parent) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= offset[g.gw * g.gh]) return;                       // the number of points that take part (db_scan_kernel's total)
+    const float4 p = rows[s];
+    const int i = __float_as_int(p.w);
+    if (!core[i]) return;
+    const int cx = db_clamp((int)floorf((p.x - g.x0) * g.inv_cell), g.gw - 1), cy = db_clamp((int)floorf((p.y - g.y0) * g.inv_cell), g.gh - 1);
+    db_neighbours(g, cx, cy, offset, rows, [&](const float4& q) {
+        const int j = __float_as_int(q.w);
+        if (j < i && core[j]) {
+            const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+            if (dx * dx + dy * dy + dz * dz <= eps2) db_union(parent, i, j);
+        }
+        return true;
+    });
+}
+
+// root[i] = lowest index of i's cluster, or -1 (noise / skipped); is_root[i] = 1 for the cluster's lowest index
+__global__ __launch_bounds__(256) void db_root_kernel(const float4* __restrict__ rows, DbGrid g, const int* __restrict__ offset, float eps2,
+                                                      const unsigned char* __restrict__ core, const int* __restrict__ parent, int* __restrict__ root,
+                                                      int* __restrict__ is_root) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= offset[g.gw * g.gh]) return;                       // the number of points that take part (db_scan_kernel's total)
+    const float4 p = rows[s];
+    const int i = __float_as_int(p.w);
+    int r = -1;
+    if (core[i]) {
+        r = db_find(parent, i);
+    } else {
+        const int cx = db_clamp((int)floorf((p.x - g.x0) * g.inv_cell), g.gw - 1), cy = db_clamp((int)floorf((p.y - g.y0) * g.inv_cell), g.gh - 1);
+        db_neighbours(g, cx, cy, offset, rows, [&](const float4& q) {
+            const int j = __float_as_int(q.w);
+            if (core[j]) {
+                const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+                if (dx * dx + dy * dy + dz * dz <= eps2) {
+                    const int rj = db_find(parent, j);
+                    r = (r < 0 || rj < r) ? rj : r;
+                }
+            }
+            return true;
+        });
+    }
+    root[i] = r;
+    if (r == i) is_root[i] = 1;
+}
+
+__global__ __launch_bounds__(256) void db_init_kernel(int n, int* __restrict__ parent, int* __restrict__ root, int* __restrict__ is_root,
+                                                      unsigned char* __restrict__ core) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    parent[i] = i; root[i] = -1; is_root[i] = 0; core[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void db_label_kernel(int n, const int* __restrict__ root, const int* __restrict__ rank, int* __restrict__ labels,
+                                                       int* __restrict__ n_clusters) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && n_clusters) *n_clusters = rank[n];
+    if (i >= n) return;
+    const int r = root[i];
+    labels[i] = r < 0 ? 0 : rank[r] + 1;
+}
+
+struct DbLayout {
+    size_t count, cursor, cell_id, rows, parent, root, is_root, core, total;
+};
+static DbLayout db_layout(int n, int gw, int gh) {
+    DbLayout L{};
+    const size_t cells = (size_t)gw * gh;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += round_up(bytes, 256); return at; };
+    L.count = take((cells + 1) * 4); L.cursor = take(cells * 4); L.cell_id = take((size_t)n * 4); L.rows = take((size_t)n * 16);
+    L.parent = take((size_t)n * 4); L.root = take((size_t)n * 4); L.is_root = take(((size_t)n + 1) * 4); L.core = take((size_t)n);
+    L.total = o;
+    return L;
+}
+
+}  // namespace himo
+
+using namespace himo;
+
+extern "C" size_t himo_dbscan_workspace_bytes(int n, int grid_w, int grid_h) {
+    if (n < 0 || grid_w < 1 || grid_h < 1) return 0;
+    return db_layout(n, grid_w, grid_h).total + 256;
+}
+
+// d_xyz [n][pitch >= 3] float32; d_skip [n] bytes or NULL (non-zero = the point takes no part, label 0); BEV grid of `cell` >= eps
+// metre cells from (x0, y0), grid_w x grid_h of them (points beyond it are binned into the border cells: still exact, only slower
+// there); d_labels [n] int32: 0 noise / skipped, 1 .. K clusters ordered by their lowest point index; d_n_clusters: K (or NULL).
+extern "C" int himo_dbscan(int n, const float* d_xyz, int pitch, const unsigned char* d_skip, float eps, int min_pts, float x0, float y0,
+                           float cell, int grid_w, int grid_h, int32_t* d_labels, int32_t* d_n_clusters, void* d_workspace,
+                           size_t workspace_bytes, void* stream) {
+    if (n < 0 || pitch < 3 || !(eps > 0.f) || min_pts < 1 || !(cell >= eps) || grid_w < 1 || grid_h < 1 || (int64_t)grid_w * grid_h > (1 << 26))
+        return HIMO_ERR_INVALID_ARGUMENT;
+    if (n > 0 && (!d_xyz || !d_labels)) return HIMO_ERR_INVALID_ARGUMENT;
+    if (!d_workspace || workspace_bytes < himo_dbscan_workspace_bytes(n, grid_w, grid_h) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        if (d_n_clusters) HIMO_HIP(hipMemsetAsync(d_n_clusters, 0, 4, s));
+        return HIMO_OK;
+    }
+    const DbLayout L = db_layout(n, grid_w, grid_h);
+    char* w = reinterpret_cast<char*>(d_workspace);
+    int* count = reinterpret_cast<int*>(w + L.count); int* cursor = reinterpret_cast<int*>(w + L.cursor);
+    int* cell_id = reinterpret_cast<int*>(w + L.cell_id); float4* rows = reinterpret_cast<float4*>(w + L.rows);
+    int* parent = reinterpret_cast<int*>(w + L.parent); int* root = reinterpret_cast<int*>(w + L.root);
+    int* is_root = reinterpret_cast<int*>(w + L.is_root); unsigned char* core = reinterpret_cast<unsigned char*>(w + L.core);
+    const int cells = grid_w * grid_h, nb = (n + 255) / 256;
+    const DbGrid g{x0, y0, 1.0f / cell, grid_w, grid_h};
+    const float eps2 = eps * eps;
+    ProfScope ps("dbscan_kernels", s);
+    HIMO_HIP(hipMemsetAsync(count, 0, ((size_t)cells + 1) * 4, s));
+    HIMO_HIP(hipMemsetAsync(cursor, 0, (size_t)cells * 4, s));
+    hipLaunchKernelGGL(db_init_kernel, dim3(nb), dim3(256), 0, s, n, parent, root, is_root, core);
+    hipLaunchKernelGGL(db_count_kernel, dim3(nb), dim3(256), 0, s, n, d_xyz, pitch, d_skip, g, count, cell_id);
+    hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, s, count, cells);              // count -> offsets; count[cells] = points taking part
+    hipLaunchKernelGGL(db_scatter_kernel, dim3(nb), dim3(256), 0, s, n, d_xyz, pitch, cell_id, count, cursor, rows);
+    // (the sorted-row kernels are launched over n slots and stop at the number of participating points, which only the device knows)
+    hipLaunchKernelGGL(db_core_kernel, dim3(nb), dim3(256), 0, s, rows, g, count, eps2, min_pts, core);
+    hipLaunchKernelGGL(db_union_kernel, dim3(nb), dim3(256), 0, s, rows, g, count, eps2, core, parent);
+    hipLaunchKernelGGL(db_root_kernel, dim3(nb), dim3(256), 0, s, rows, g, count, eps2, core, parent, root, is_root);
+    hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, s, is_root, n);                // is_root -> rank of each cluster's lowest index
+    hipLaunchKernelGGL(db_label_kernel, dim3(nb), dim3(256), 0, s, n, root, is_root, d_labels, d_n_clusters);
+    HIMO_LAUNCH_CHECK("dbscan kernels");
+    return HIMO_OK;
+}

@@ -176,6 +176,8 @@ class HDF5Dataset:
                         d[name] = np.asarray(g[name][:])
             nxt = f[self._next[(scene_id, ts)]]
             d["pose1"], d["pc1"] = np.asarray(nxt["pose"][:]), np.asarray(nxt["lidar"][:])
+            if "ground_mask" in nxt:                           # the label generator needs both sweeps' ground masks (seflow/ssl_label.py)
+                d["gm1"] = np.asarray(nxt["ground_mask"][:]).astype(bool)
             if "flow_instance_id" in nxt:                      # the training loop clusters both sweeps (seflow/fit.py)
                 d["flow_instance_id_next"] = np.asarray(nxt["flow_instance_id"][:])
         return d

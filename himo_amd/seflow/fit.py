@@ -11,8 +11,10 @@ Conventions of this build: BatchNorm runs in TRAINING mode by default (``batchno
 gamma / beta, running statistics with momentum 0.1 -- the launcher passes no checkpoint, so the reference's job trains from
 scratch; statistics are per forward call = per sample on a rank, un-synchronised across ranks like DDP's default, and rank
 0's running statistics go into the checkpoints); ``batchnorm="frozen"`` is the fine-tuning convention (running statistics
-and affine folded into constants); validation always uses the running statistics; labels are the
-frame's dynamic-cluster ids (``flow_instance_id`` here; the reference's ``ssl_label=seflow_auto`` files are absent).
+and affine folded into constants); validation always uses the running statistics; the labels (0 static, > 0 dynamic
+cluster id) are GENERATED from the sweep pair on the GPU by default (``ssl_label="seflow_auto"``, the launcher's
+``+ssl_label=seflow_auto``: seflow/ssl_label.py -- nearest-neighbour dynamic candidates + DBSCAN; the reference's generator
+and its label files are absent: unpinned); ``ssl_label=<frame key>`` (e.g. ``flow_instance_id``) reads them from the frames.
 """
 from __future__ import annotations
 
@@ -45,30 +47,44 @@ def triplets(dataset):
     return out
 
 
+AUTO_LABELS = ("seflow_auto", "seflowpp_auto")                  # the launchers' option values (ssl-train-av2.sh:32, ssl-train-scania.sh:32)
+
+
 def make_sample(dataset, trip, device, label_key: str = "flow_instance_id"):
-    """(pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels) on ``device`` for one triplet."""
+    """(pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels) on ``device`` for one triplet.  ``label_key`` in
+    ``AUTO_LABELS``: the labels are generated from the pair (needs the sweeps' ground masks ``gm0``; a frame that carries its
+    successor also carries ``gm1``); any other value names the frame key that holds them."""
     ih, i0, i1 = trip
     f0 = dataset[i0]
     fh = dataset[ih] if ih != i0 else f0
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
     lab = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).to(device)
+    auto = label_key in AUTO_LABELS
     if i1 is None:                                            # the frame carries its successor (HDF5Dataset)
-        pc1, lab1 = f0["pc1"], f0.get(label_key + "_next")
-        if lab1 is None:
+        pc1, lab1, gm1 = f0["pc1"], f0.get(label_key + "_next"), f0.get("gm1")
+        if lab1 is None and not auto:
             raise KeyError(f"{label_key}_next: the frame carries pc1 but not its labels")
     else:
         f1 = dataset[i1]
-        pc1, lab1 = f1["pc0"], f1[label_key]
-    l0, l1 = lab(f0[label_key]), lab(lab1)
-    n_labels = int(max(int(np.max(f0[label_key], initial=0)), int(np.max(lab1, initial=0)))) + 1
-    return (up(fh["pc0"]), up(f0["pc0"]), up(pc1), np.asarray(fh["pose0"], np.float64), np.asarray(f0["pose0"], np.float64),
-            np.asarray(f0["pose1"], np.float64), l0, l1, n_labels)
+        pc1, lab1, gm1 = f1["pc0"], f1.get(label_key), f1.get("gm0")
+    p0, p1 = up(f0["pc0"]), up(pc1)
+    pose0, pose1 = np.asarray(f0["pose0"], np.float64), np.asarray(f0["pose1"], np.float64)
+    if auto:
+        from .ssl_label import auto_labels
+        if f0.get("gm0") is None or gm1 is None:
+            raise KeyError("gm0 / gm1: ssl_label=seflow_auto needs the ground masks of both sweeps")
+        l0, l1 = auto_labels(p0, p1, f0["gm0"], gm1, pose0, pose1)
+        n_labels = int(torch.maximum(l0.max() if l0.numel() else l0.new_zeros(()), l1.max() if l1.numel() else l1.new_zeros(())).item()) + 1
+    else:
+        l0, l1 = lab(f0[label_key]), lab(lab1)
+        n_labels = int(max(int(np.max(f0[label_key], initial=0)), int(np.max(lab1, initial=0)))) + 1
+    return (up(fh["pc0"]), p0, p1, np.asarray(fh["pose0"], np.float64), pose0, pose1, l0, l1, n_labels)
 
 
 def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, batch_size: int = 8, lr: float = 6e-5,
         step_size: int = 3, gamma: float = 0.5, save_top: int = 3, val_dataset=None, resume=None, precision: str = "mixed",
         max_points: int = 140_000, device=None, seed: int = 0, max_steps: int | None = None, log=print,
-        trainer: SeFlowTrainer | None = None, batchnorm: str = "batch") -> dict:
+        trainer: SeFlowTrainer | None = None, batchnorm: str = "batch", ssl_label: str = "seflow_auto") -> dict:
     """Train for ``epochs`` passes over ``dataset``; returns {"trainer", "history", "best"}.
 
     Ranks (torch.distributed, initialised by the caller / ``distenv.process_group``): step s of an epoch takes the global
@@ -99,14 +115,14 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
                 break
             batch = order[s * batch_size:(s + 1) * batch_size]
             mine = [trips[j] for j in batch[rank::world]]    # may be empty in a partial last batch: the rank still joins the
-            loss = tr.train_batch((make_sample(dataset, t, dev) for t in mine), lr=lr_e)      # all-reduce, with zeros
+            loss = tr.train_batch((make_sample(dataset, t, dev, ssl_label) for t in mine), lr=lr_e)      # all-reduce, with zeros
             losses.append(loss)
             steps_done += 1
         train_loss = float(torch.stack(losses).mean().item()) if losses else float("nan")
         tr.sync_running_stats()                              # validation and the checkpoint use rank 0's running statistics
         val_loss = None
         if val_trips:
-            vals = [tr.loss_only(*make_sample(val_dataset, t, dev)) for t in val_trips[rank::world]]
+            vals = [tr.loss_only(*make_sample(val_dataset, t, dev, ssl_label)) for t in val_trips[rank::world]]
             v = torch.stack(vals).sum() if vals else torch.zeros((), dtype=torch.float64, device=dev)
             cnt = torch.tensor([float(len(vals))], dtype=torch.float64, device=dev)
             tot = torch.stack([v.reshape(()), cnt.reshape(())])
@@ -144,13 +160,15 @@ def main(argv=None):
     ap.add_argument("--save_top_model", type=int, default=3)
     ap.add_argument("--batchnorm", default="batch", choices=["batch", "frozen"],
                     help="batch: BatchNorm in training mode (from-scratch training, the reference job); frozen: fine-tuning convention")
+    ap.add_argument("--ssl_label", default="seflow_auto",
+                    help="seflow_auto (the launcher's +ssl_label=seflow_auto): labels generated on the GPU; or the frame key that holds them")
     a = ap.parse_args(argv)
     with distenv.process_group():
         ds = open_dataset(Path(a.dataset_path))
         val = open_dataset(Path(a.val_path)) if a.val_path else None
         params = load_params(a.checkpoint) if a.checkpoint else None
         return fit(ds, params, out_dir=a.out_dir, epochs=a.epochs, batch_size=a.batch_size, lr=a.lr, save_top=a.save_top_model,
-                   val_dataset=val, resume=a.resume or None, batchnorm=a.batchnorm)
+                   val_dataset=val, resume=a.resume or None, batchnorm=a.batchnorm, ssl_label=a.ssl_label)
 
 
 if __name__ == "__main__":

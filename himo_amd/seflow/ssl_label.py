@@ -1,0 +1,89 @@
+"""Self-supervised cluster labels on the GPU -- this build's counterpart of ``+ssl_label=seflow_auto``
+(assets/slurm/ssl-train-av2.sh:32, ssl-train-scania.sh:32): the per-point ``0 = static / > 0 = dynamic cluster id`` labels the
+training loss consumes (``ssl_loss.SeFlowLoss``), generated from the sweeps themselves instead of read from ground truth.
+
+PARITY UNPINNED.  The reference's generator (DUFOMap dynamic awareness + HDBSCAN clustering, per the SeFlow papers) lives in the
+absent OpenSceneFlow submodule together with its dependencies; only the option's name is in the tree.  This build's own
+specification, chosen so that every step is exact and order-independent:
+
+  1. dynamic candidates of a sweep A against its neighbour sweep B (both in ONE frame: A is moved with ``inv(poseB) @ poseA``):
+     non-ground points of A whose nearest non-ground point of B is further than ``dyn_dist`` (0.35 m: a point on a static
+     surface has a return of the other sweep next to it once ego motion is removed; a point on an object faster than
+     3.5 m/s does not).  Exact nearest neighbours through the BEV cell grid (csrc/nngrid.hip).
+  2. clusters: DBSCAN(``eps``, ``min_pts``) over the candidates (csrc/dbscan.hip: labels are a pure function of the input --
+     clusters numbered by their lowest point index, a border point joins the neighbouring cluster of lowest such index).
+  3. everything else -- ground, static, noise -- is label 0.
+
+The oracle is sklearn.cluster.DBSCAN + scipy's cKDTree (oracle/dbscan_oracle.py); tests/test_ssl_label_gpu.py.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..ssl_loss import nn_grid
+
+_lib.register({
+    "himo_dbscan_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "himo_dbscan": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_float,
+                                   ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_size_t, ctypes.c_void_p]),
+    "himo_rigid_transform": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_int, ctypes.c_void_p]),
+})
+
+EPS, MIN_PTS, DYN_DIST = 0.5, 8, 0.35
+RANGE_XY = 52.0                     # the BEV cell grid covers +- this (points beyond it are binned into its border cells)
+
+
+def dbscan(points: torch.Tensor, eps: float = EPS, min_pts: int = MIN_PTS, skip: torch.Tensor | None = None):
+    """(labels int32 (n,), number of clusters) of DBSCAN over the xyz of ``points`` (device (n, >= 3) float32).  ``skip``: bool /
+    uint8 (n,), True = the point takes no part (label 0)."""
+    lib, dev = _lib.load(), _lib.require_gpu()
+    p = points.to(device=dev, dtype=torch.float32)
+    if p.stride(-1) != 1 or p.stride(0) < 3:
+        p = p.contiguous()
+    n = p.shape[0]
+    gw = gh = int(math.ceil(2 * RANGE_XY / eps))
+    labels = torch.empty(n, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib.himo_dbscan_workspace_bytes(n, gw, gh)), dtype=torch.uint8, device=dev)
+    sk = None if skip is None else skip.to(device=dev, dtype=torch.uint8).contiguous()
+    _lib.check(lib.himo_dbscan(n, _lib.ptr(p), int(p.stride(0)) if n else 3, _lib.ptr(sk), float(eps), int(min_pts), -RANGE_XY, -RANGE_XY, float(eps),
+                               gw, gh, _lib.ptr(labels), _lib.ptr(count), _lib.ptr(ws), ws.numel(), _lib.stream_handle()), "himo_dbscan")
+    return labels, count
+
+
+def _moved(pc: torch.Tensor, T: np.ndarray) -> torch.Tensor:
+    lib, dev = _lib.load(), _lib.require_gpu()
+    src = pc[:, :3].contiguous()
+    out = torch.empty((src.shape[0], 3), dtype=torch.float32, device=dev)
+    T32 = torch.from_numpy(np.ascontiguousarray(T, dtype=np.float32)).to(dev)
+    _lib.check(lib.himo_rigid_transform(src.shape[0], _lib.ptr(src), 3, _lib.ptr(T32), _lib.ptr(out), 3, _lib.stream_handle()), "rigid")
+    return out
+
+
+def auto_labels(pc0, pc1, ground0, ground1, pose0, pose1, eps: float = EPS, min_pts: int = MIN_PTS, dyn_dist: float = DYN_DIST):
+    """(label0 (n0,), label1 (n1,)) int32 device tensors for the sweep pair (module docstring).  ``pc*``: (n, >= 3) float32 in their
+    own sensor frames, ``ground*``: bool masks, ``pose*``: 4x4 world poses."""
+    dev = _lib.require_gpu()
+    up = lambda a, dt: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device=dev, dtype=dt)
+    p0, p1 = up(pc0, torch.float32), up(pc1, torch.float32)
+    g0, g1 = up(ground0, torch.bool), up(ground1, torch.bool)
+    T = np.linalg.inv(np.asarray(pose1, np.float64)) @ np.asarray(pose0, np.float64)
+    a = _moved(p0, T)                                           # pc0 in pc1's frame
+    b = p1[:, :3].contiguous()
+    a_ng, b_ng = a[~g0], b[~g1]                                 # (index selection: data movement, no arithmetic)
+    far2 = float(dyn_dist) ** 2
+    out = []
+    for pts, ground, mine, other in ((a, g0, a_ng, b_ng), (b, g1, b_ng, a_ng)):
+        skip = ground.clone()
+        if mine.shape[0] and other.shape[0]:
+            d2 = nn_grid(mine, other, return_index=False)
+            skip[~ground] = d2 <= far2                          # a close return in the other sweep: static
+        out.append(dbscan(pts, eps, min_pts, skip)[0])
+    return out[0], out[1]

@@ -535,6 +535,16 @@ int himo_weight_prepare_batch(const himo_weight_job* d_jobs, int n_jobs, int tot
 int himo_mlp_repack(int n_layers, const float* const* h_w, const int* h_cin, const int* h_cout, void* const* h_fwd_packed,
                     void* const* h_bwd_packed, void* stream);
 
+/* Self-supervised cluster labels (`+ssl_label=seflow_auto`, assets/slurm/ssl-train-av2.sh:32; the reference's generator is in the
+ * absent OpenSceneFlow submodule: PARITY UNPINNED, specification himo_amd/seflow/ssl_label.py, oracle sklearn.cluster.DBSCAN):
+ * DBSCAN(eps, min_pts) over 3-D points on the GPU (csrc/dbscan.hip).  d_xyz [n][pitch >= 3] float32; d_skip [n] bytes or NULL
+ * (non-zero: the point takes no part); BEV cell grid of `cell` >= eps metres from (x0, y0); d_labels [n] int32: 0 = noise / skipped,
+ * 1 .. K = clusters in the order of their lowest point index (a border point joins the neighbouring cluster of lowest such index):
+ * a pure function of the input.  d_n_clusters: K (or NULL). */
+size_t himo_dbscan_workspace_bytes(int n, int grid_w, int grid_h);
+int himo_dbscan(int n, const float* d_xyz, int pitch, const unsigned char* d_skip, float eps, int min_pts, float x0, float y0, float cell,
+                int grid_w, int grid_h, int32_t* d_labels, int32_t* d_n_clusters, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* FastNSF (README.md:53 `model=fastnsf`; specification himo_amd/fastnsf.py, PARITY UNPINNED) -- one optimiser iteration of the
  * coordinate MLP as THREE launches (csrc/nsffused.hip):
  *   himo_nsf_forward   the MLP over all points (activations spilled as two-term bf16 matrix fragments + ReLU mask bits for the backward

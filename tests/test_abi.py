@@ -26,6 +26,7 @@ def test_library_exports_every_declared_symbol():
     import himo_amd.ssl_loss  # noqa: F401
     import himo_amd.fastnsf  # noqa: F401
     import himo_amd.seflow.train  # noqa: F401
+    import himo_amd.seflow.ssl_label  # noqa: F401
     lib = _lib.load()
     raw = ctypes.CDLL(str(_lib.LIB_PATH))
     for name in declared_symbols():

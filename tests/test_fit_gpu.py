@@ -53,7 +53,7 @@ def test_fit_runs_epochs_batches_schedule_and_keeps_the_top_checkpoints(gpu, tmp
     assert len(trips) == 10 and trips[0] == (0, 0, 1) and trips[1] == (0, 1, 2) and trips[5] == (6, 6, 7)      # no pair across scenes
     logs = []
     out = fit(ds, spec.init_params(9), out_dir=tmp_path, epochs=5, batch_size=4, lr=2e-4, step_size=2, gamma=0.5, save_top=2,
-              max_points=6_000, device=gpu, log=logs.append)
+              max_points=6_000, device=gpu, log=logs.append, ssl_label="flow_instance_id")
     hist = out["history"]
     assert [h["epoch"] for h in hist] == [0, 1, 2, 3, 4] and all(h["steps"] == 3 for h in hist)            # ceil(10 / 4) steps per epoch
     assert [h["lr"] for h in hist] == [2e-4, 2e-4, 1e-4, 1e-4, 5e-5]                                         # StepLR(2, 0.5)
@@ -79,7 +79,7 @@ def test_fit_trains_from_scratch_with_batchnorm_in_training_mode(gpu, tmp_path):
     start = spec.init_params(12, fresh_bn=True)
     assert np.all(start["enc2.3.bn.gamma"] == 1) and np.all(start["pfn.bn.var"] == 1) and np.all(start["enc1.0.bn.mean"] == 0)
     out = fit(ListDataset(frames), start, out_dir=tmp_path, epochs=4, batch_size=4, lr=2e-4, save_top=1, max_points=6_000, device=gpu,
-              val_dataset=ListDataset(frames[:5]), log=None)
+              val_dataset=ListDataset(frames[:5]), log=None, ssl_label="flow_instance_id")
     hist = out["history"]
     assert all(np.isfinite(h["train_loss"]) and np.isfinite(h["val_loss"]) for h in hist), hist
     assert hist[-1]["train_loss"] < 0.9 * hist[0]["train_loss"], hist
