@@ -732,8 +732,8 @@ def fastnsf_roofline(args, prof: dict, n_fits: int, elapsed: float):
     map_bytes = 4.0 * P * HIDDEN                                                           # one H_k: two bf16 planes
     blocks = -(-P // 256)
     params = 2 * (4 * HIDDEN + HIDDEN) + (N_HIDDEN - 1) * (HIDDEN * HIDDEN + HIDDEN) + 4 - HIDDEN
-    bytes_fwd = N_HIDDEN * map_bytes + 3 * 16.0 * P                                        # H_k spilled; x0 read, out + dout written
-    bytes_bwd = (N_HIDDEN + 0.5 * N_HIDDEN) * map_bytes + 2 * 16.0 * P + 4.0 * blocks * params    # H_{k-1} read (both planes), H_k's high plane read for the mask; partials written
+    bytes_fwd = (N_HIDDEN - 1) * map_bytes + N_HIDDEN * 4.0 * P + 3 * 16.0 * P             # H_0..H_6 spilled + mask bits; x0 read, out + dout written
+    bytes_bwd = (N_HIDDEN - 1) * map_bytes + N_HIDDEN * 4.0 * P + 2 * 16.0 * P + 4.0 * blocks * params    # H_0..H_6 read (both planes) + mask bits; partials written
     bytes_upd = 4.0 * blocks * params + 7 * 4.0 * params
     flops_bwd = 2.0 * P * HIDDEN * HIDDEN * 2 * (N_HIDDEN - 1)                              # input gradients + weight gradients of the 7 hidden products
     flops_fwd = 2.0 * P * HIDDEN * HIDDEN * (N_HIDDEN - 1)

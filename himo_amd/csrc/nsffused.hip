@@ -22,7 +22,7 @@
 //                        tile), against W_k^T staged in LDS once per layer and block.
 //   nsf_update_kernel    fixed-order sum of the blocks' partials x 1 / (points in the volume), Adam, and the two packed copies of
 //                        every hidden W the next iteration's kernels read (csrc/convbf.hip mlp_repack_kernel's layouts).
-// Algorithmic HBM bytes per point and iteration: H spill 8 x 512 B written, 7 x 512 B read; 8 x 16 B of mask bits written + read;
+// Algorithmic HBM bytes per point and iteration: H spill 7 x 512 B written, 7 x 512 B read; 8 x 16 B of mask bits written + read;
 // 16 + 16 + 16 B of x / out / dout; per BLOCK of 256 points 459 KB of partial gradients written + read: ~11.6 kB / point against
 // round 3's 28.3 kB.  Matrix work: 22 products of 128 x 128 per point, 3 instructions per float32 product block.
 #include "himo_common.h"
@@ -95,6 +95,46 @@ __device__ inline void nsf_a_store_bits(unsigned char* A, int row, int k, unsign
     const int off = nsf_slot(0, k >> 4, row, (k & 15) >> 3) + (k & 7) * 2;
     *reinterpret_cast<unsigned short*>(A + off) = (unsigned short)h;
     *reinterpret_cast<unsigned short*>(A + off + kNsfPlane) = (unsigned short)l;
+}
+
+// ---- the row-major A operand from accumulator-layout registers WITHOUT 2-byte stores.  A lane holds one COLUMN; the 16 bytes of
+// a row's eight consecutive columns belong to eight consecutive lanes.  64 ds_write_b16 per lane and step were the largest single
+// cost of the backward kernel's vector phase (measured: 100 of 358 us; an LDS store costs its instruction, not its bytes).  Instead
+// the 8 lanes x 8 rows block of 16-bit values (a uint4 per lane: element i = row i of the block) is TRANSPOSED across the lanes
+// -- xor-1 at half-word granularity (DPP quad_perm + v_perm), xor-2 and xor-4 at dword granularity (DPP / ds_swizzle + selects) --
+// so that lane q of the group holds row q's eight columns: one ds_write_b128.
+__device__ __forceinline__ unsigned nsf_sel(bool c, unsigned a, unsigned b) { return c ? a : b; }
+__device__ __forceinline__ uint4 nsf_transpose8(const uint4& v, int lane) {
+    const bool e = lane & 1, f = lane & 2, g = lane & 4;
+    unsigned d[4] = {v.x, v.y, v.z, v.w};
+    const unsigned selA = e ? 0x03020706u : 0x05040100u;        // even: (own.lo, partner.lo); odd: (partner.hi, own.hi)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const unsigned pd = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d[m], 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]: lane ^ 1
+        d[m] = __builtin_amdgcn_perm(pd, d[m], selA);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m += 2) {                            // lane ^ 2: 2 x 2 blocks of the dword matrix
+        const unsigned send = nsf_sel(f, d[m], d[m + 1]);
+        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+        d[m] = nsf_sel(f, recv, d[m]);
+        d[m + 1] = nsf_sel(f, d[m + 1], recv);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {                               // lane ^ 4
+        const unsigned send = nsf_sel(g, d[m], d[m + 2]);
+        const unsigned recv = (unsigned)__builtin_amdgcn_ds_swizzle((int)send, 0x101F);                     // bit mode: and 0x1f, or 0, xor 4
+        d[m] = nsf_sel(g, recv, d[m]);
+        d[m + 2] = nsf_sel(g, d[m + 2], recv);
+    }
+    return uint4{d[0], d[1], d[2], d[3]};
+}
+// block (rt, j) of a tile (rows rt * 32 + nsf_row(8 j + i, lh), i = 0 .. 7), plane p, this lane's column col: vec = the lane's eight values
+__device__ __forceinline__ void nsf_a_store_block(unsigned char* A, int p, const uint4& vec, int rt, int j, int lane, int col) {
+    const uint4 t = nsf_transpose8(vec, lane);
+    const int q = lane & 7, lh = lane >> 5, c0 = col & ~7;
+    const int row = rt * 32 + nsf_row(8 * j + q, lh);
+    *reinterpret_cast<uint4*>(A + nsf_slot(p, c0 >> 4, row, (c0 & 15) >> 3)) = t;
 }
 
 struct NsfFwdArgs {
@@ -185,17 +225,19 @@ __global__ __launch_bounds__(256, 3) void nsf_forward_kernel(NsfFwdArgs a) {
         a.maskbits[((int64_t)k * a.tiles + blockIdx.x) * 256 + threadIdx.x] = bits;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
+            if (!last) {    // (H_{L-1} is not spilled: its only consumers are the mask bits above and the last layer's gradients below)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float v[8];
+                for (int j = 0; j < 2; ++j) {
+                    float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = h[rt][8 * j + i];
-                uint4 hi, mid;
-                nsf_split_pack(v, hi, mid);
-                *reinterpret_cast<uint4*>(sp + nsf_frag(wave, rt, j, 0)) = hi;
-                *reinterpret_cast<uint4*>(sp + nsf_frag(wave, rt, j, 1)) = mid;
+                    for (int i = 0; i < 8; ++i) v[i] = h[rt][8 * j + i];
+                    uint4 hi, mid;
+                    nsf_split_pack(v, hi, mid);
+                    *reinterpret_cast<uint4*>(sp + nsf_frag(wave, rt, j, 0)) = hi;
+                    *reinterpret_cast<uint4*>(sp + nsf_frag(wave, rt, j, 1)) = mid;
+                }
             }
-            if (!last) {
+            if (!last) {    // (2-byte stores here: with three blocks per CU they hide under the other blocks; the lane transpose: 164 -> 176 us)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) nsf_a_store<false>(A, rt * 32 + nsf_row(r, lh), col, h[rt][r]);
             }
@@ -382,9 +424,8 @@ __device__ __forceinline__ void nsf_bwd_layer(const NsfBwdArgs& a, const NsfBwdC
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = dz[8 * j + i];
                 nsf_split_pack(v, bz[rt][j][0], bz[rt][j][1]);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    nsf_a_store_bits(A, rt * 32 + nsf_row(8 * j + i, lh), col, nsf_u16_at(bz[rt][j][0], i), nsf_u16_at(bz[rt][j][1], i));
+                nsf_a_store_block(A, 0, bz[rt][j][0], rt, j, x.lane, col);
+                nsf_a_store_block(A, 1, bz[rt][j][1], rt, j, x.lane, col);
             }
         }
         mbits = mnext[threadIdx.x];                             // (k >= 1: layer k - 1 exists)
@@ -412,7 +453,7 @@ __device__ __forceinline__ void nsf_bwd_layer(const NsfBwdArgs& a, const NsfBwdC
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
-#pragma unroll 2
+#pragma unroll
         for (int slab = 0; slab < kNsfSlabs; ++slab) {
             bf16x8 af[2][2], bf[2];
 #pragma unroll
