@@ -13,6 +13,7 @@ buffer, and a single all-reduce of the flat gradient across ranks.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -517,7 +518,7 @@ class SeFlowTrainer:
         self.dB0, self.dDEC = buf(H * W, 32 * F), buf(H * W, 64)
         self.dF1, self.dF2, self.dF3 = buf(H * W // 4, 64 * F), buf(H * W // 16, 128 * F), buf(H * W // 64, 256 * F)
         big = F * (H // 2) * (W // 2) * 64                       # the largest encoder activation (floats)
-        self.dA, self.dB, self.DP = buf(big), buf(big), buf(big)
+        self.dA, self.dB, self.DP, self.DP2 = buf(big), buf(big), buf(big), buf(big)
         self.Z = buf(F * H * W * 64)                             # zero-stuffed dY of the stride-2 layers (largest: enc1.0)
         self.TMP = buf(max(H * W * 128, F * H * W * 32))        # a decoder-sized scratch / the enc1.0 data gradient
         self.dWORK = [buf(H * W * 64) for _ in range(2)]         # d work[0] and d (block input) ping-pong
@@ -541,6 +542,11 @@ class SeFlowTrainer:
         ws = max(ws, F * int(self.lib.himo_pfn_bn_workspace_bytes()),
                  max(int(self.lib.himo_bn_workspace_bytes(F * L[6] * L[7], L[2])) for L in self.layers))
         self.ws = torch.empty(ws + 64, dtype=torch.uint8, device=dev)
+        # the encoder's weight gradients run on a SIDE stream under the data-gradient chain (backward): own workspace, and the
+        # pre-activation gradient they read alternates between two buffers so the chain never waits for them
+        self.overlap_wgrad = os.environ.get("HIMO_TRAIN_SIDE_STREAM", "0") != "0"
+        self.side = torch.cuda.Stream(device=dev)
+        self.ws_side = torch.empty(ws + 64, dtype=torch.uint8, device=dev)
         self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
         # BatchNorm in training mode: per-layer batch statistics kept for the backward pass; the pillar net has one set per sweep
         self.bn_mean = torch.zeros((len(self.layers), 256), dtype=torch.float32, device=dev)
@@ -607,10 +613,11 @@ class SeFlowTrainer:
             self._descs[key] = d
         _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), "himo_conv2d(train)")
 
-    def _wgrad3_batch(self, n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, gname, stride=1):
+    def _wgrad3_batch(self, n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, gname, stride=1, ws=None):
         """weight gradient over n images in one launch (LDS-tiled kernel)"""
+        ws = self.ws if ws is None else ws
         _lib.check(self.lib.himo_conv3x3_wgrad_batch(n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, stride,
-                                                     self.g[gname].data_ptr(), self.wgrad_flags, self.ws.data_ptr(), self.ws.numel(),
+                                                     self.g[gname].data_ptr(), self.wgrad_flags, ws.data_ptr(), ws.numel(),
                                                      _lib.stream_handle()), "conv3x3_wgrad_batch")
 
     def _wgrad3(self, x, x_pitch, h, w, cin, dy, dy_pitch, cout, stride, gname, acc):
@@ -631,9 +638,10 @@ class SeFlowTrainer:
         self._wgrad3(x, x_pitch, h, w, cin, dy, dy_pitch, cout, 1, wname, False)
         self._colsum(h * w, dy, dy_pitch, cout, bname)
 
-    def _colsum(self, rows, z, pitch, cout, gname, acc=False):
-        _lib.check(self.lib.himo_colsum(rows, z, pitch, cout, self.g[gname].data_ptr(), 1 if acc else 0, self.ws.data_ptr(),
-                                        self.ws.numel(), _lib.stream_handle()), "colsum")
+    def _colsum(self, rows, z, pitch, cout, gname, acc=False, ws=None):
+        ws = self.ws if ws is None else ws
+        _lib.check(self.lib.himo_colsum(rows, z, pitch, cout, self.g[gname].data_ptr(), 1 if acc else 0, ws.data_ptr(),
+                                        ws.numel(), _lib.stream_handle()), "colsum")
 
     def _wgrad1(self, rows, x, x_pitch, cin, dz, z_pitch, cout, name):
         _lib.check(self.lib.himo_linear_wgrad_ex(rows, x, x_pitch, cin, dz, z_pitch, cout, self.g[f"{name}.weight"].data_ptr(),
@@ -806,11 +814,15 @@ class SeFlowTrainer:
         # encoder, last layer to first
         dcat = {256: self.dF3, 128: self.dF2, 64: self.dF1, 32: self.dB0}
         dy = None
+        main = torch.cuda.current_stream(self.device)
+        side_done = {}                                           # layer -> event: its side-stream launches have finished reading dp
         for li in range(len(self.layers) - 1, -1, -1):
             name, cin, cout, stride, h, w, ho, wo, last = self.layers[li]
             pre = self.PRE[li]
             sc = net.p[f"{name}.scale"].data_ptr()
-            dp = self.DP.data_ptr()
+            dp = (self.DP2 if (self.overlap_wgrad and li & 1) else self.DP).data_ptr()
+            if li + 2 in side_done:                              # this buffer's previous reader (two layers up) must be through
+                main.wait_event(side_done.pop(li + 2))
             if self._fwd_batch:                                  # through GELU and the batch statistics; also d gamma / d beta
                 pfx = f"{name}.bn"
                 dy_ptr, dy_bs, dy_pitch = (dcat[cout].data_ptr(), cout, cout * F) if last else (dy, ho * wo * cout, cout)
@@ -829,12 +841,27 @@ class SeFlowTrainer:
             # of dp would be rounding noise that Adam's normalisation turns into full-size random steps.  Nothing ever writes
             # these entries of flat_g in batch mode -- but a backward() after a frozen-statistics forward does (the branch
             # below), and train_batch ADDS flat_g into its accumulator: so batch mode zeroes them, it does not assume them zero.
-            if not self._fwd_batch:
-                self._colsum(F * ho * wo, dp, cout, cout, f"{name}.bias")
-            else:
-                self.g[f"{name}.bias"].zero_()
             x, x_bs, x_pitch = self.inputs[li]
-            self._wgrad3_batch(F, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride)
+            if self.overlap_wgrad:
+                # the weight (and bias) gradient only READS dp and the saved layer input: it runs beside the data-gradient chain,
+                # which is the critical path (same kernels, same arguments: bit-identical gradients)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(ready)
+                    if not self._fwd_batch:
+                        self._colsum(F * ho * wo, dp, cout, cout, f"{name}.bias", ws=self.ws_side)
+                    self._wgrad3_batch(F, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride, ws=self.ws_side)
+                    side_done[li] = torch.cuda.Event()
+                    side_done[li].record(self.side)
+                if self._fwd_batch:
+                    self.g[f"{name}.bias"].zero_()
+            else:
+                if not self._fwd_batch:
+                    self._colsum(F * ho * wo, dp, cout, cout, f"{name}.bias")
+                else:
+                    self.g[f"{name}.bias"].zero_()
+                self._wgrad3_batch(F, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride)
             wf, wp = self._flip(name, 3, cin, cout)
             if stride == 2:
                 z = self.Z.data_ptr()
@@ -860,6 +887,7 @@ class SeFlowTrainer:
                                                       self.pfn_invstd.data_ptr(), self.g["pfn.weight"].data_ptr(),
                                                       self.g["pfn.bn.gamma"].data_ptr(), self.g["pfn.bn.beta"].data_ptr(), 0,
                                                       self.ws.data_ptr(), self.ws.numel(), s()), "pfn_backward_bn_multi")
+            main.wait_stream(self.side)                         # every gradient is in flat_g when this stream goes on
             return
         for slot in range(F):
             if self._fwd_batch:
@@ -876,6 +904,7 @@ class SeFlowTrainer:
                                              net.ws_slots[slot].data_ptr(), self.dB0.data_ptr() + 4 * 32 * slot, 32 * F,
                                              self.g["pfn.weight"].data_ptr(), 1 if slot else 0, self.ws.data_ptr(), self.ws.numel(), s()),
                        "pfn_backward")
+        main.wait_stream(self.side)
 
     def _pfn_sweep_arrays(self):
         """host arrays of the sample's sweeps for the multi-sweep pillar-net calls: point counts, transformed points, pillar workspaces"""

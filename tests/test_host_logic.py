@@ -72,13 +72,17 @@ def test_datasets_roundtrip(tmp_path):
 
 
 def test_hdf5_dataset_says_what_is_missing(tmp_path):
+    """No h5py needed any more (h5lite reads the scene files): what can be missing is the index, or a scene file -- both by name."""
+    import pickle
     from himo_amd.dataset import HDF5Dataset
-    try:
-        import h5py  # noqa: F401
-        pytest.skip("h5py present")
-    except ImportError:
-        with pytest.raises(ImportError, match="h5py"):
-            HDF5Dataset(tmp_path)
+    with pytest.raises(FileNotFoundError, match="index_total.pkl"):
+        HDF5Dataset(tmp_path)
+    with open(tmp_path / "index_total.pkl", "wb") as fh:
+        pickle.dump([["sceneA", "100"], ["sceneA", "200"]], fh)
+    ds = HDF5Dataset(tmp_path)
+    assert len(ds) == 1
+    with pytest.raises((FileNotFoundError, OSError), match="sceneA.h5"):
+        ds[0]
 
 
 def test_bench_cli_contract(monkeypatch):
