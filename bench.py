@@ -672,7 +672,7 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
                                       "FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, separate passes, per launch of the tuned kernels) -- "
                                       "a cross-reference read from profiles/, NOT measured in this run") if roofline.get("traffic") else None
         if world == 1 and not args.no_extra_precisions:
-            extra = extra_precision_legs(args, params, sets, device, ref_flow, exclude=args.precision)
+            extra.update(extra_precision_legs(args, params, sets, device, ref_flow, exclude=args.precision))
         if world == 1 and not args.no_extra_workloads:
             extra.update(extra_workload_legs(args, device))
         if world == 1 and not args.no_hostfed_leg:
