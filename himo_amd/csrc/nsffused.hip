@@ -182,11 +182,7 @@ __device__ inline void nsf_fwd_gemm(const unsigned char* A, const unsigned short
     }
 }
 
-#ifdef NSF_X_OCC4
-__global__ __launch_bounds__(256, 4) void nsf_forward_kernel(NsfFwdArgs a) {
-#else
 __global__ __launch_bounds__(256, 3) void nsf_forward_kernel(NsfFwdArgs a) {
-#endif
     __shared__ __attribute__((aligned(16))) unsigned char A[2 * kNsfPlane + 64 * 4];      // (+ padding so that Y [64][129] fits)
     __shared__ float s_x[kNsfRows][4];
     __shared__ float s_o[kNsfRows][4];
@@ -237,13 +233,8 @@ __global__ __launch_bounds__(256, 3) void nsf_forward_kernel(NsfFwdArgs a) {
                     for (int i = 0; i < 8; ++i) v[i] = h[rt][8 * j + i];
                     uint4 hi, mid;
                     nsf_split_pack(v, hi, mid);
-#ifdef NSF_X_NOSPILL
-                    if (hi.x == 0x12345678u && mid.y == 0x9abcdef0u)
-#endif
-                    {
                     *reinterpret_cast<uint4*>(sp + nsf_frag(wave, rt, j, 0)) = hi;
                     *reinterpret_cast<uint4*>(sp + nsf_frag(wave, rt, j, 1)) = mid;
-                    }
                 }
             }
             if (!last) {    // (2-byte stores here: with three blocks per CU they hide under the other blocks; the lane transpose: 164 -> 176 us)

@@ -544,7 +544,7 @@ class SeFlowTrainer:
         self.ws = torch.empty(ws + 64, dtype=torch.uint8, device=dev)
         # the encoder's weight gradients run on a SIDE stream under the data-gradient chain (backward): own workspace, and the
         # pre-activation gradient they read alternates between two buffers so the chain never waits for them
-        self.overlap_wgrad = os.environ.get("HIMO_TRAIN_SIDE_STREAM", "0") != "0"
+        self.overlap_wgrad = os.environ.get("HIMO_TRAIN_SIDE_STREAM", "1") != "0"
         self.side = torch.cuda.Stream(device=dev)
         self.ws_side = torch.empty(ws + 64, dtype=torch.uint8, device=dev)
         self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
