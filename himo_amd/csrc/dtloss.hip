@@ -48,12 +48,14 @@ __global__ __launch_bounds__(256) void dt_pass_x_kernel(DtGrid g, const unsigned
         const int x = x0 - W + t;
         tile[t] = (x >= 0 && x < g.nx) ? src[x] : kDtInf;
     }
-    __syncthreads();
+    // most 256-cell segments of a sweep's occupancy volume hold no occupied cell within the window: those write INF and are done
+    const int any = __syncthreads_or(tile[threadIdx.x] == 0 || (threadIdx.x < 2 * W && tile[256 + threadIdx.x] == 0));
     const int x = x0 + threadIdx.x;
     if (x >= g.nx) return;
     unsigned best = 0xFFFFFFFFu;
-    for (int d = -W; d <= W; ++d)
-        if (tile[threadIdx.x + W + d] == 0) { const unsigned v = (unsigned)(d * d); best = v < best ? v : best; }
+    if (any)
+        for (int d = -W; d <= W; ++d)
+            if (tile[threadIdx.x + W + d] == 0) { const unsigned v = (unsigned)(d * d); best = v < best ? v : best; }
     out[row * g.nx + x] = best >= kDtInf ? kDtInf : (unsigned short)best;
 }
 
