@@ -380,28 +380,28 @@ class FastNSF:
                                             s()), "himo_nsf_forward")
 
         self.loss_history, best, stale = [], float("inf"), 0
+        loss_hist = torch.zeros(max(self.iters, 1), dtype=torch.float64, device=dev)       # one slot per iteration: read back ONCE, after the fit
+        done = 0
         for it in range(1, self.iters + 1):
             forward(True)
             _lib.check(lib.himo_nsf_backward(n, self.X0.data_ptr(), self.dOUT.data_ptr(), N_HIDDEN, wb, self.W[L - 1].data_ptr(), spill.data_ptr(),
                                              off_w, off_b, stride, partial.data_ptr(), s()), "himo_nsf_backward")
             _lib.check(lib.himo_nsf_update(total, blocks, stride, partial.data_ptr(), tiles, spill.data_ptr(), loss_partial.data_ptr(), count_partial.data_ptr(),
                                            self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
-                                           self.lr, 0.9, 0.999, 1e-8, it, N_HIDDEN, off_w, wf, wb, loss.data_ptr(), count.data_ptr(), s()),
+                                           self.lr, 0.9, 0.999, 1e-8, it, N_HIDDEN, off_w, wf, wb, loss_hist.data_ptr() + 8 * (it - 1), count.data_ptr(), s()),
                        "himo_nsf_update")
-            if self.early_patience > 0 or it == self.iters or it <= 3:
-                lv = float(loss.item())
+            done = it
+            if self.early_patience > 0:                         # early stopping watches the loss: one host sync per iteration
+                lv = float(loss_hist[it - 1].item())
                 self.loss_history.append((it, lv))
-                if self.early_patience > 0:
-                    if lv < best - self.early_min_delta:
-                        best, stale = lv, 0
-                    else:
-                        stale += 1
-                        if stale >= self.early_patience:
-                            break
-        # (tests read the objective's gradient of the LAST iteration: d loss / d moved = dOUT / points in the volume)
-        m_in = max(int(count.item()), 1)
-        self._gmoved = self.dOUT[:, :3] / float(m_in)
-        self.points_in_volume = m_in
+                if lv < best - self.early_min_delta:
+                    best, stale = lv, 0
+                else:
+                    stale += 1
+                    if stale >= self.early_patience:
+                        break
+        # (tests read the objective's gradient of the LAST iteration: d loss / d moved = dOUT / points in the volume -- on demand)
+        self._gm_lazy = (self.dOUT, count)
         forward(False)
         moved = torch.empty((n, 3), dtype=torch.float32, device=dev)
         flow = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -409,7 +409,23 @@ class FastNSF:
         _lib.check(lib.himo_rows_add(n, 3, self.X0.data_ptr(), 4, self.OUT.data_ptr(), 4, 1.0, moved.data_ptr(), 3, 0, s()), "rows_add")
         _lib.check(lib.himo_rows_add(n, 3, moved.data_ptr(), 3, p0_raw.data_ptr(), 3, -1.0, flow.data_ptr(), 3, 0, s()), "rows_add")
         self._moved = moved
+        if self.early_patience <= 0 and done:                   # the loss trajectory, read once the whole fit is queued: no bubble inside it
+            hist = loss_hist[:done].cpu().numpy()
+            self.loss_history = [(it, float(hist[it - 1])) for it in range(1, done + 1) if it <= 3 or it == done]
+        self.points_in_volume = max(int(count.item()), 1)
         return flow
+
+    @property
+    def _gmoved(self):
+        """d loss / d moved of the last iteration (tests)"""
+        if getattr(self, "_gm_lazy", None) is not None:
+            dout, count = self._gm_lazy
+            return dout[:, :3] / float(max(int(count.item()), 1))
+        return self._gm_value
+
+    @_gmoved.setter
+    def _gmoved(self, v):
+        self._gm_lazy, self._gm_value = None, v
 
     def layers(self) -> list:
         """Current parameters as [(W [in,out], b [out])] numpy with the padding removed."""
