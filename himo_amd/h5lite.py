@@ -7,13 +7,15 @@ neither ``h5py`` nor the reference's loader exists in this image.  This module r
 the other encodings the HDF5 library may choose for the same calls -- straight from the file format:
 
   superblock versions 0-3; version-1 and version-2 object headers (with continuation blocks); groups stored as symbol
-  tables (version-1 B-tree + local heap + ``SNOD`` nodes: the default) or as compact link messages (``libver="latest"``);
-  contiguous, compact and chunked (version-1 B-tree index) dataset layouts; the deflate, shuffle and fletcher32 filters;
+  tables (version-1 B-tree + local heap + ``SNOD`` nodes: the default), as compact link messages or densely (fractal heap +
+  version-2 B-tree name index: ``libver="latest"``); contiguous, compact and chunked dataset layouts (version-1 B-tree index;
+  the 1.10 single-chunk, implicit and fixed-array indexes); the deflate, shuffle and fletcher32 filters;
   fixed-point, IEEE floating-point, fixed-length string and enum datatypes, little or big endian (an 8-bit enum
   {FALSE, TRUE} is ``bool``, as h5py stores it).
 
-Anything else -- dense (fractal-heap) groups, the version-4 chunk indexes, compound / variable-length / reference types,
-external or virtual storage, soft links -- raises ``Unsupported`` NAMING the feature, never a wrong array.
+Anything else -- extensible-array / version-2-B-tree chunk indexes (unlimited dimensions under ``libver="latest"``), paged fixed
+arrays, filtered fractal heaps, compound / variable-length / reference types, external or virtual storage, soft links -- raises
+``Unsupported`` NAMING the feature, never a wrong array.
 
 The reader is pinned against files written by the real library (``tests/golden/h5/*.h5``, made by
 ``tests/golden/make_h5_fixture.py`` through ``ctypes`` on libhdf5 1.10.6) in ``tests/test_h5lite.py``.
@@ -209,8 +211,8 @@ class Group:
             elif mtype == 0x02:                                          # link info: dense storage when a fractal heap is named
                 b = f._buf
                 q = p + 2 + (8 if b[p + 1] & 1 else 0)
-                if f._addr(q) != UNDEF:
-                    raise Unsupported("dense link storage (fractal heap + version-2 B-tree groups)")
+                if f._addr(q) != UNDEF:                                  # dense storage: fractal heap of link messages + name index
+                    _dense_links(f, f._addr(q), f._addr(q + f.O), self._link, links)
         self._links = links
         return links
 
@@ -288,6 +290,127 @@ class Group:
             raise KeyError(f"{name!r} is not in {self.name!r} of {self._f.path}")
         obj = _open_object(self._f, links[head], self.name.rstrip("/") + "/" + head)
         return obj[rest] if rest else obj
+
+
+# ---- dense groups (libver="latest" with more than eight links): link messages live in a fractal heap, a version-2 B-tree indexes them by
+# name hash.  The B-tree is the authority (a heap block may hold freed space); every record names one heap object.
+def _enc_size(n: int) -> int:
+    """bytes the library uses to encode values up to n (H5VM_limit_enc_size)"""
+    return (max(int(n), 1).bit_length() - 1) // 8 + 1
+
+
+def _btree2_records(f: File, addr: int, want_type: int):
+    """every record (as a buffer offset) of the version-2 B-tree whose header is at ``addr``"""
+    b = f._buf
+    if b[addr:addr + 4] != b"BTHD" or b[addr + 4] != 0:
+        raise OSError(f"{f.path}: bad version-2 B-tree header at {addr}")
+    if b[addr + 5] != want_type:
+        raise Unsupported(f"version-2 B-tree of type {b[addr + 5]}")
+    node_size, rec_size, depth = f._u(addr + 6, 4), f._u(addr + 10, 2), f._u(addr + 12, 2)
+    root, root_nrec = f._addr(addr + 16), f._u(addr + 16 + f.O, 2)
+    # per-level geometry (H5B2__hdr_init)
+    max_nrec = [(node_size - 10) // rec_size]
+    cum_max, cum_size = [max_nrec[0]], [0]
+    nrec_size = _enc_size(max_nrec[0])
+    for u in range(1, depth + 1):
+        ptr = f.O + nrec_size + cum_size[u - 1]
+        max_nrec.append((node_size - (10 + ptr)) // (rec_size + ptr))
+        cum_max.append((max_nrec[u] + 1) * cum_max[u - 1] + max_nrec[u])
+        cum_size.append(_enc_size(cum_max[u]))
+    out = []
+
+    def walk(node, nrec, level):
+        if node == UNDEF or nrec == 0:
+            return
+        sig = b"BTLF" if level == 0 else b"BTIN"
+        if b[node:node + 4] != sig:
+            raise OSError(f"{f.path}: bad version-2 B-tree node at {node}")
+        p = node + 6
+        recs = [p + i * rec_size for i in range(nrec)]
+        if level == 0:
+            out.extend(recs)
+            return
+        q = p + nrec * rec_size
+        for i in range(nrec + 1):
+            child = f._addr(q)
+            cn = f._u(q + f.O, nrec_size)
+            q += f.O + nrec_size + (cum_size[level - 1] if level > 1 else 0)
+            walk(child, cn, level - 1)
+            if i < nrec:
+                out.append(recs[i])
+    walk(root, root_nrec, depth)
+    return out
+
+
+class _FractalHeap:
+    def __init__(self, f: File, addr: int):
+        b = f._buf
+        if b[addr:addr + 4] != b"FRHP" or b[addr + 4] != 0:
+            raise OSError(f"{f.path}: bad fractal heap header at {addr}")
+        self.f = f
+        p = addr + 5
+        self.id_len, filt_len, self.flags = f._u(p, 2), f._u(p + 2, 2), b[p + 4]
+        if filt_len:
+            raise Unsupported("filtered fractal heap")
+        self.max_man_size = f._u(p + 5, 4)
+        p += 9 + f.L + f.O + f.L + f.O + 4 * f.L + 4 * f.L          # huge-id / B-tree, free space + manager, four managed counters, huge / tiny counters
+        self.width, self.start, self.max_direct = f._u(p, 2), f._u(p + 2, f.L), f._u(p + 2 + f.L, f.L)
+        p += 2 + 2 * f.L
+        self.max_bits, p = f._u(p, 2), p + 2
+        p += 2                                                          # starting rows of the root indirect block
+        self.root, self.root_rows = f._addr(p), f._u(p + f.O, 2)
+        self.off_size = (self.max_bits + 7) // 8
+        self.len_size = min(_enc_size(self.max_direct), _enc_size(self.max_man_size))
+        self.max_direct_rows = (self.max_direct.bit_length() - 1) - (self.start.bit_length() - 1) + 2
+        self.block_hdr = 5 + f.O + self.off_size + (4 if self.flags & 2 else 0)
+
+    def row_size(self, r):
+        return self.start if r < 2 else self.start << (r - 1)
+
+    def object(self, heap_id_off: int):
+        """(buffer offset, length) of the managed object named by the heap ID at ``heap_id_off``"""
+        f, b = self.f, self.f._buf
+        kind = (b[heap_id_off] >> 4) & 3
+        if b[heap_id_off] >> 6 or kind != 0:
+            raise Unsupported({1: "huge", 2: "tiny"}.get(kind, "unknown") + " fractal-heap object")
+        off = f._u(heap_id_off + 1, self.off_size)
+        length = f._u(heap_id_off + 1 + self.off_size, self.len_size)
+        if self.root_rows == 0:
+            return self.root + off, length                               # the root IS a direct block starting at heap offset 0
+        return self._locate(self.root, self.root_rows, 0, off), length
+
+    def _locate(self, iblock, nrows, base, off):
+        f, b = self.f, self.f._buf
+        if b[iblock:iblock + 4] != b"FHIB":
+            raise OSError(f"{f.path}: bad fractal-heap indirect block at {iblock}")
+        p = iblock + 5 + f.O + self.off_size
+        pos = base
+        for r in range(nrows):
+            size = self.row_size(r)
+            for c in range(self.width):
+                if r < self.max_direct_rows:
+                    child = f._addr(p)
+                    p += f.O
+                    if pos <= off < pos + size:
+                        if child == UNDEF or b[child:child + 4] != b"FHDB":
+                            raise OSError(f"{f.path}: fractal-heap offset {off} is in no direct block")
+                        return child + (off - pos)
+                else:
+                    child = f._addr(p)
+                    p += f.O
+                    if pos <= off < pos + size:
+                        rows = (size.bit_length() - 1) - ((self.start.bit_length() - 1) + (self.width.bit_length() - 1)) + 1
+                        return self._locate(child, rows, pos, off)
+                pos += size
+        raise OSError(f"{f.path}: fractal-heap offset {off} beyond the heap")
+
+
+def _dense_links(f: File, heap_addr: int, btree_addr: int, parse_link, links: dict):
+    heap = _FractalHeap(f, heap_addr)
+    for rec in _btree2_records(f, btree_addr, 5):                        # type 5: link name index: hash (4), heap ID
+        at, _ = heap.object(rec + 4)
+        name, target = parse_link(at)
+        links[name] = target
 
 
 def _open_object(f: File, addr: int, name: str):
@@ -446,7 +569,9 @@ class Dataset:
             return ("single", f._addr(q), (dims, None))
         if index == 2:                                                   # implicit: chunks laid out in order, never filtered
             return ("implicit", f._addr(q), dims)
-        names = {3: "fixed-array", 4: "extensible-array", 5: "version-2 B-tree"}
+        if index == 3:                                                   # fixed array: one entry per chunk, in chunk-grid order
+            return ("farray", f._addr(q + 1), (dims, bool(flags & 0x01) or None))
+        names = {4: "extensible-array", 5: "version-2 B-tree"}
         raise Unsupported(f"{names.get(index, f'type-{index}')} chunk index (write the file with libver='earliest', or unchunked)")
 
     @property
@@ -503,6 +628,11 @@ class Dataset:
                 if addr != UNDEF:
                     csize = size if size is not None else int(np.prod(chunk)) * item
                     self._place(a, chunk, (0,) * len(chunk), self._unfilter(bytes(b[addr:addr + csize])) if size is not None else b[addr:addr + csize])
+            elif kind == "farray":
+                dims, _ = extra
+                chunk = tuple(dims[:len(self.shape)])
+                if addr != UNDEF:
+                    self._read_fixed_array(addr, chunk, a)
             else:                                                        # implicit index
                 chunk = tuple(extra[:len(self.shape)])
                 csize = int(np.prod(chunk)) * item
@@ -513,6 +643,38 @@ class Dataset:
         if self._bool:
             return a.astype(bool)
         return a.astype(self.dtype, copy=False) if self._dtype.byteorder == ">" else a
+
+    def _read_fixed_array(self, addr, chunk, out):
+        f, b = self._f, self._f._buf
+        if b[addr:addr + 4] != b"FAHD" or b[addr + 4] != 0:
+            raise OSError(f"{f.path}: bad fixed-array header at {addr}")
+        client, esize, page_bits = b[addr + 5], b[addr + 6], b[addr + 7]
+        n = f._u(addr + 8, f.L)
+        dblk = f._addr(addr + 8 + f.L)
+        if dblk == UNDEF:
+            return
+        if b[dblk:dblk + 4] != b"FADB":
+            raise OSError(f"{f.path}: bad fixed-array data block at {dblk}")
+        if n > (1 << page_bits):
+            raise Unsupported("paged fixed-array chunk index (more than 2^page_bits chunks)")
+        p = dblk + 6 + f.O
+        grid = [-(-s // c) for s, c in zip(self.shape, chunk)]
+        item = self._dtype.itemsize
+        plain = int(np.prod(chunk)) * item
+        for k, idx in enumerate(np.ndindex(*grid)):
+            if k >= n:
+                break
+            e = p + k * esize
+            caddr = f._addr(e)
+            if caddr == UNDEF:
+                continue
+            origin = tuple(i * c for i, c in zip(idx, chunk))
+            if client == 1:                                              # filtered chunks: address, size, filter mask
+                csize = f._u(e + f.O, esize - f.O - 4)
+                mask = f._u(e + esize - 4, 4)
+                self._place(out, chunk, origin, self._unfilter(bytes(b[caddr:caddr + csize]), mask))
+            else:
+                self._place(out, chunk, origin, b[caddr:caddr + plain])
 
     def _place(self, out, chunk, origin, raw):
         block = np.frombuffer(raw, self._dtype, int(np.prod(chunk))).reshape(chunk)
