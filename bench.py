@@ -720,13 +720,18 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
 FASTNSF_DOMINANT = "nsf_"          # nsf_forward / nsf_backward / nsf_update_kernel (csrc/nsffused.hip): substring filter of himo_prof_filter
 
 
-def fastnsf_roofline(args, prof: dict, n_fits: int, elapsed: float):
+def fastnsf_roofline(args, prof: dict, n_fits: int, elapsed: float, traffic: dict | None = None):
     """roofline object / workload / dtype of the FastNSF fit (csrc/nsffused.hip: three launches per iteration).  The dominant kernel
     is nsf_backward_kernel -- the chain of input gradients AND all weight gradients: 14 of the iteration's 21 products of
     128 x 128 per point -- which is matrix-bound; the forward kernel's figure (an HBM stream: it spills the activations) and the
     update kernel's ride along."""
     from himo_amd.fastnsf import HIDDEN, N_HIDDEN
     P = args.points
+    if traffic is None:
+        try:
+            traffic = json.loads(Path(args.traffic_json).read_text())
+        except Exception:
+            traffic = {}
     nil = {"avg_ms": float("nan"), "count": 0, "total_ms": float("nan")}
     f, b, u = prof.get("nsf_forward_kernel", nil), prof.get("nsf_backward_kernel", nil), prof.get("nsf_update_kernel", nil)
     map_bytes = 4.0 * P * HIDDEN                                                           # one H_k: two bf16 planes
@@ -745,10 +750,13 @@ def fastnsf_roofline(args, prof: dict, n_fits: int, elapsed: float):
                                            "weight gradient; v_mfma_f32_32x32x16_bf16 with two-term bf16 operands, 3 per float32 product block; "
                                            "weight-gradient operands straight from accumulator-layout registers / spilled fragments)",
                 "achieved": tf(flops_bwd, b), "peak": peak, "peak_note": f"{MFMA_BF16_PEAK_TF:.0f} TFLOP/s dense bf16 MFMA peak / 3 matrix products per float32 product",
-                "unit": "TFLOP/s", "frac": tf(flops_bwd, b) / peak, "traffic": None,
+                "unit": "TFLOP/s", "frac": tf(flops_bwd, b) / peak, "traffic": traffic.get("nsf_backward_kernel", {}).get("hbm_bytes_per_launch"),
                 "algorithmic_flops_per_launch": flops_bwd, "avg_launch_ms": b["avg_ms"], "launches_timed": b["count"],
                 "hbm_side": {"algorithmic_bytes_per_launch": bytes_bwd, "GB/s": gbs(bytes_bwd, b), "frac_of_hbm_peak": gbs(bytes_bwd, b) / HBM_PEAK_GBS},
+                "traffic_source": ("traffic_latest.json: builder-run rocprofv3 PMC passes (scripts/collect_traffic.sh), a cross-reference read from "
+                                   "profiles/, NOT measured in this run") if traffic.get("nsf_backward_kernel") else None,
                 "forward_kernel": {"kernel": "nsf_forward_kernel (whole forward pass + distance-transform objective; spills H_k as bf16 fragments)",
+                                   "traffic": traffic.get("nsf_forward_kernel", {}).get("hbm_bytes_per_launch"),
                                    "avg_launch_ms": f["avg_ms"], "launches_timed": f["count"], "algorithmic_bytes_per_launch": bytes_fwd,
                                    "GB/s": gbs(bytes_fwd, f), "frac_of_hbm_peak": gbs(bytes_fwd, f) / HBM_PEAK_GBS,
                                    "matrix_tflops_f32_equivalent": tf(flops_fwd, f)},

@@ -17,14 +17,16 @@ FAMILIES = {"compdis_kernel": ("compdis_kernel<",), "frame_prep_kernel": ("frame
             "conv3x3_split_kernel": (r"conv3_split_kernel<.*, 1>", "conv_bf16x3_kernel<3,", r"conv3_presplit_kernel<\d+, \d+, \d+, \w+, 1, \d+>"),
             "conv3x3s2_split_kernel": (r"conv3_split_kernel<.*, 2>", r"conv3_presplit_kernel<\d+, \d+, \d+, \w+, 2, \d+>"),
             "conv1x1_split_kernel": ("conv_bf16x3_kernel<1,", "conv1_presplit_kernel<"), "gru_head_kernel": ("gru_head_kernel",),
-            "upsample2x_kernel": ("upsample2x_kernel",)}
+            "upsample2x_kernel": ("upsample2x_kernel",),
+            "nsf_forward_kernel": ("nsf_forward_kernel",), "nsf_backward_kernel": ("nsf_backward_kernel",), "nsf_update_kernel": ("nsf_update_kernel",)}
 # each kernel family is read from the workload whose bench configuration is the quoted one
-SOURCE = {"compdis_kernel": "compdis", "frame_prep_kernel": "compdis"}
+SOURCE = {"compdis_kernel": "compdis", "frame_prep_kernel": "compdis", "nsf_forward_kernel": "fastnsf", "nsf_backward_kernel": "fastnsf",
+          "nsf_update_kernel": "fastnsf"}
 # Only the launches of the LAST timed step count: the run starts with the network's one-off tile autotune, which launches every
 # variant of every layer (slower tiles, more halo traffic) and would otherwise be averaged into the tuned kernels' figure.
 # bench.py runs: priming pass, warm-up, parity pass, K timed steps, one fully profiled step -- all with identical launch lists
 # once tuned, so "the last 1 / (K + 3)" of a family's launches in dispatch order is one clean step.
-KEEP_LAST_FRACTION = {"pipeline": 0.2, "compdis": 1.0}
+KEEP_LAST_FRACTION = {"pipeline": 0.2, "compdis": 1.0, "fastnsf": 0.5}
 # launches per bench step (16 samples per step) of the pipeline's kernel families: exactly the last TWO steps are averaged, so
 # every layer of a family enters with equal weight
 PER_STEP = {"conv3x3_split_kernel": 20, "conv3x3s2_split_kernel": 3, "conv1x1_split_kernel": 6, "upsample2x_kernel": 3,
