@@ -589,11 +589,46 @@ struct NsfUpdArgs {
     int* count;                                                 // points in the volume
 };
 
+constexpr int kNsfUpdSplit = 4;                                 // threads per parameter: each sums a quarter of the partial list
+
+// One block = 64 parameters x kNsfUpdSplit runs of the partial list.  The sum of ~470 partials is a chain of HBM latencies, not a
+// byte rate: four threads per parameter with eight independent chains each keep 32 loads per parameter in flight (one thread with
+// eight chains: 56 us per launch at 3.4 TB/s).  Fixed order: run q covers partials [q * per, (q + 1) * per), chain c of a run
+// its every eighth, chains and runs are combined pairwise in index order -- the same bits on every launch.
 __global__ __launch_bounds__(256) void nsf_update_kernel(NsfUpdArgs a) {
     __shared__ int s_c[256];
     __shared__ double s_l[256];
+    __shared__ float s_t[kNsfUpdSplit][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    // the count partials first: their loads are in flight under the gradient partials'
     int c = 0;
-    for (int b = threadIdx.x; b < a.n_fwd_blocks; b += 256) c += a.count_partial[b];
+    for (int base = 0; base < a.n_fwd_blocks; base += 2048) {
+        int cv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int b = base + k * 256 + (int)threadIdx.x;
+            cv[k] = b < a.n_fwd_blocks ? a.count_partial[b] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c += cv[k];
+    }
+    float run = 0.f;
+    if (i < a.total) {
+        const int per = (a.n_partials + kNsfUpdSplit - 1) / kNsfUpdSplit;
+        int b = q * per;
+        const int b1 = b + per < a.n_partials ? b + per : a.n_partials;
+        const float* __restrict__ src = a.partial + i;
+        float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (; b + 7 < b1; b += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t8[k] += src[(int64_t)(b + k) * a.partial_stride];
+        }
+        for (; b < b1; ++b) t8[0] += src[(int64_t)b * a.partial_stride];
+        const float t4[4] = {t8[0] + t8[4], t8[1] + t8[5], t8[2] + t8[6], t8[3] + t8[7]};
+        run = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+    }
+    s_t[q][lane] = run;
     s_c[threadIdx.x] = c;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -613,18 +648,8 @@ __global__ __launch_bounds__(256) void nsf_update_kernel(NsfUpdArgs a) {
         }
         if (threadIdx.x == 0) { *a.loss = m_in > 0 ? s_l[0] / (double)m_in : 0.0; *a.count = m_in; }
     }
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.total) return;
-    const float* __restrict__ src = a.partial + i;
-    float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int b = 0;
-    for (; b + 7 < a.n_partials; b += 8) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t8[q] += src[(int64_t)(b + q) * a.partial_stride];
-    }
-    for (; b < a.n_partials; ++b) t8[0] += src[(int64_t)b * a.partial_stride];
-    const float t4[4] = {t8[0] + t8[4], t8[1] + t8[5], t8[2] + t8[6], t8[3] + t8[7]};
-    const float gi = ((t4[0] + t4[1]) + (t4[2] + t4[3])) * inv;
+    if (q != 0 || i >= a.total) return;
+    const float gi = ((s_t[0][lane] + s_t[1][lane]) + (s_t[2][lane] + s_t[3][lane])) * inv;
     a.g[i] = gi;
     const float mi = a.b1 * a.m[i] + (1.f - a.b1) * gi;          // Adam, torch.optim.Adam's update order (csrc/fastnsf.hip adam_kernel)
     const float vi = a.b2 * a.v[i] + (1.f - a.b2) * gi * gi;
@@ -770,7 +795,7 @@ extern "C" int himo_nsf_update(int total, int n_partials, int64_t partial_stride
     a.loss = d_loss; a.count = d_count;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("nsf_update_kernel", s);
-    hipLaunchKernelGGL(nsf_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nsf_update_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a);
     HIMO_LAUNCH_CHECK("nsf_update_kernel");
     return HIMO_OK;
 }

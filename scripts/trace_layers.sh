@@ -20,8 +20,8 @@ rows = rows[int(len(rows) * 0.6):]
 agg = collections.defaultdict(list)
 for r in rows:
     name = r["Kernel_Name"].replace("void himo::", "").split("(")[0]
-    agg[(name, r["Grid_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    agg[(name, r["Grid_Size_X"] + "x" + r.get("Grid_Size_Y", "1"))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = sum(sum(v) for v in agg.values())
 for (name, grid), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-    print(f"{name[:90]:90s} grid {grid:>9s}  n={len(v):4d}  avg {sum(v)/len(v):8.1f} us  share {100*sum(v)/tot:5.1f} %")
+    print(f"{name[:90]:90s} grid {grid:>12s}  n={len(v):4d}  avg {sum(v)/len(v):8.1f} us  share {100*sum(v)/tot:5.1f} %")
 PY
