@@ -28,6 +28,7 @@
 #include "himo_common.h"
 #include "bf16x3.h"
 #include "dtlookup.h"
+#include "lanetranspose.h"
 #include <math.h>
 
 namespace himo {
@@ -103,35 +104,9 @@ __device__ inline void nsf_a_store_bits(unsigned char* A, int row, int k, unsign
 // the 8 lanes x 8 rows block of 16-bit values (a uint4 per lane: element i = row i of the block) is TRANSPOSED across the lanes
 // -- xor-1 at half-word granularity (DPP quad_perm + v_perm), xor-2 and xor-4 at dword granularity (DPP / ds_swizzle + selects) --
 // so that lane q of the group holds row q's eight columns: one ds_write_b128.
-__device__ __forceinline__ unsigned nsf_sel(bool c, unsigned a, unsigned b) { return c ? a : b; }
-__device__ __forceinline__ uint4 nsf_transpose8(const uint4& v, int lane) {
-    const bool e = lane & 1, f = lane & 2, g = lane & 4;
-    unsigned d[4] = {v.x, v.y, v.z, v.w};
-    const unsigned selA = e ? 0x03020706u : 0x05040100u;        // even: (own.lo, partner.lo); odd: (partner.hi, own.hi)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const unsigned pd = (unsigned)__builtin_amdgcn_update_dpp(0, (int)d[m], 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]: lane ^ 1
-        d[m] = __builtin_amdgcn_perm(pd, d[m], selA);
-    }
-#pragma unroll
-    for (int m = 0; m < 4; m += 2) {                            // lane ^ 2: 2 x 2 blocks of the dword matrix
-        const unsigned send = nsf_sel(f, d[m], d[m + 1]);
-        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-        d[m] = nsf_sel(f, recv, d[m]);
-        d[m + 1] = nsf_sel(f, d[m + 1], recv);
-    }
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {                               // lane ^ 4
-        const unsigned send = nsf_sel(g, d[m], d[m + 2]);
-        const unsigned recv = (unsigned)__builtin_amdgcn_ds_swizzle((int)send, 0x101F);                     // bit mode: and 0x1f, or 0, xor 4
-        d[m] = nsf_sel(g, recv, d[m]);
-        d[m + 2] = nsf_sel(g, d[m + 2], recv);
-    }
-    return uint4{d[0], d[1], d[2], d[3]};
-}
 // block (rt, j) of a tile (rows rt * 32 + nsf_row(8 j + i, lh), i = 0 .. 7), plane p, this lane's column col: vec = the lane's eight values
 __device__ __forceinline__ void nsf_a_store_block(unsigned char* A, int p, const uint4& vec, int rt, int j, int lane, int col) {
-    const uint4 t = nsf_transpose8(vec, lane);
+    const uint4 t = lane_transpose8(vec, lane);
     const int q = lane & 7, lh = lane >> 5, c0 = col & ~7;
     const int row = rt * 32 + nsf_row(8 * j + q, lh);
     *reinterpret_cast<uint4*>(A + nsf_slot(p, c0 >> 4, row, (c0 & 15) >> 3)) = t;
@@ -773,13 +748,13 @@ extern "C" int himo_nsf_backward(int64_t n, const float* d_x0, const float* d_do
 // d_v (csrc/fastnsf.hip adam_kernel's arithmetic); the fp16-split copy of every hidden W and the two-term bf16 copy of its transpose
 // (himo_mlp_repack's layouts; h_fwd_packed[i] / h_bwd_packed[i] for layer i = 1 .. n_hidden - 1, others ignored);
 // d_loss = mean distance over the points in the volume, d_count = their number.
-extern "C" int himo_nsf_update(int total, int n_partials, int64_t partial_stride, const float* d_partial, int n_fwd_blocks, const void* d_spill,
+extern "C" int himo_nsf_update(int total, int n_partials, int64_t partial_stride, const float* d_partial, int n_fwd_blocks,
                                const double* d_loss_partial, const int* d_count_partial, float* d_param, float* d_grad, float* d_m, float* d_v,
                                float lr, float beta1, float beta2, float eps, int step, int n_hidden, const int* h_off_w,
                                void* const* h_fwd_packed, void* const* h_bwd_packed, double* d_loss, int* d_count, void* stream) {
     if (total < 1 || n_partials < 0 || n_fwd_blocks < 0 || step < 1 || n_hidden < 1 || n_hidden > kNsfMaxHidden || !d_partial || !d_loss_partial ||
         !d_count_partial || !d_param || !d_grad || !d_m || !d_v || !h_off_w || !h_fwd_packed || !h_bwd_packed || !d_loss || !d_count ||
-        partial_stride < total || !d_spill)
+        partial_stride < total)
         return HIMO_ERR_INVALID_ARGUMENT;
     NsfUpdArgs a{};
     a.total = total; a.n_partials = n_partials; a.n_fwd_blocks = n_fwd_blocks; a.n_layers = n_hidden + 1; a.partial_stride = partial_stride;

@@ -73,7 +73,7 @@ _lib.register({
                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "himo_nsf_backward": (ctypes.c_int, [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
-    "himo_nsf_update": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+    "himo_nsf_update": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p]),
@@ -386,7 +386,7 @@ class FastNSF:
             forward(True)
             _lib.check(lib.himo_nsf_backward(n, self.X0.data_ptr(), self.dOUT.data_ptr(), N_HIDDEN, wb, self.W[L - 1].data_ptr(), spill.data_ptr(),
                                              off_w, off_b, stride, partial.data_ptr(), s()), "himo_nsf_backward")
-            _lib.check(lib.himo_nsf_update(total, blocks, stride, partial.data_ptr(), tiles, spill.data_ptr(), loss_partial.data_ptr(), count_partial.data_ptr(),
+            _lib.check(lib.himo_nsf_update(total, blocks, stride, partial.data_ptr(), tiles, loss_partial.data_ptr(), count_partial.data_ptr(),
                                            self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(),
                                            self.lr, 0.9, 0.999, 1e-8, it, N_HIDDEN, off_w, wf, wb, loss_hist.data_ptr() + 8 * (it - 1), count.data_ptr(), s()),
                        "himo_nsf_update")

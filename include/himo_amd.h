@@ -550,7 +550,7 @@ int himo_dbscan(int n, const float* d_xyz, int pitch, const unsigned char* d_ski
  *   himo_nsf_forward   the MLP over all points (activations spilled as two-term bf16 matrix fragments + ReLU mask bits for the backward
  *                      pass) and, when d_dout is given, the distance-transform objective of the moved points: d loss / d out
  *                      WITHOUT the 1 / (points in the volume) factor, per-tile loss and count sums, and the last layer's own
- *                      gradients per tile (into d_spill);
+ *                      gradients per tile (into d_spill's tail);
  *   himo_nsf_backward  the whole chain of input gradients AND the gradient of every parameter, summed over each block of 256
  *                      points: d_partial [himo_nsf_backward_blocks(n)][partial_stride], each row laid out like the flat parameter
  *                      vector (h_off_w[i] / h_off_b[i]: float offsets of layer i's W [cin][cout] / b; i = 0 first (W [4][128]),
@@ -569,7 +569,7 @@ int himo_nsf_forward(int64_t n, const float* d_x0, int n_hidden, const float* d_
 int himo_nsf_backward(int64_t n, const float* d_x0, const float* d_dout, int n_hidden, const void* const* h_wT_hidden_packed,
                       const float* d_w_last, const void* d_spill, const int* h_off_w, const int* h_off_b, int64_t partial_stride,
                       float* d_partial, void* stream);
-int himo_nsf_update(int total, int n_partials, int64_t partial_stride, const float* d_partial, int n_fwd_blocks, const void* d_spill,
+int himo_nsf_update(int total, int n_partials, int64_t partial_stride, const float* d_partial, int n_fwd_blocks,
                     const double* d_loss_partial, const int* d_count_partial, float* d_param, float* d_grad, float* d_m, float* d_v,
                     float lr, float beta1, float beta2, float eps, int step, int n_hidden, const int* h_off_w, void* const* h_fwd_packed,
                     void* const* h_bwd_packed, double* d_loss, int* d_count, void* stream);
