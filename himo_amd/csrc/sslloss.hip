@@ -17,8 +17,10 @@
 //   total = sum of the four.  Correspondences are treated as constants in the gradient.
 //
 // All nearest-neighbour searches run through nngrid.hip (exact).  Loss sums are fixed two-level trees
-// (deterministic); the pc1 -> moved direction scatters its gradient with float atomics (order-dependent in the
-// last bits, like every scatter-add Chamfer backward).
+// (deterministic); the pc1 -> moved direction scatters its gradient onto the matched pc0 points as 64-bit FIXED-POINT
+// integer atomics (2^-40 units: integer addition is associative, so the sum does not depend on the arrival order --
+// float atomics made two runs of the same step differ in the last bits, and 20 optimiser steps amplified that into
+// different weights), converted once per point: the whole gradient is bit-reproducible.
 #include "himo_common.h"
 #include <math.h>
 
@@ -29,12 +31,15 @@ extern "C" size_t himo_nn_grid_workspace_bytes(int64_t n_ref, int grid_w, int gr
 
 namespace himo {
 
+constexpr double kScatScale = 1099511627776.0;              // 2^40: |sum| < 2^23 fits; one unit = 9e-13
+
 struct LossArgs {
     int n0, n1, n_labels;
     const float* pc0; const float* pc1; const float* flow;
     const int* lab0; const int* lab1;
     float* moved;                    // [n0][3]
     float* grad;                     // [n0][3]
+    unsigned long long* scat;        // [n0][3] scattered pc1 -> moved gradient, two's-complement fixed point (kScatScale)
     // correspondences
     float* d_a; int* i_a;            // moved -> pc1
     float* d_b; int* i_b;            // pc1 -> moved
@@ -203,9 +208,14 @@ __global__ __launch_bounds__(256) void loss_pc0_kernel(LossArgs a) {
             }
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a.grad[i * 3 + c] = g[c];      // this kernel runs before the scattering one
+        for (int c = 0; c < 3; ++c)                                // the scattering kernel ran before this one
+            a.grad[i * 3 + c] = g[c] + (float)((double)(long long)a.scat[i * 3 + c] * (1.0 / kScatScale));
     }
     block_sum4(t, a.partial + (size_t)blockIdx.x * 4);
+}
+
+__device__ inline void scat_add(unsigned long long* p, float v) {
+    atomicAdd(p, (unsigned long long)__double2ll_rn((double)v * kScatScale));
 }
 
 // per pc1 point: the pc1 -> moved halves (scatter their gradient onto the matched pc0 point)
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(256) void loss_pc1_kernel(LossArgs a, int blocks0) 
         t[0] += (double)a.d_b[j] * inv_n1;
         const int i = a.i_b[j];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) atomicAdd(&a.grad[i * 3 + c], 2.0f * inv_n1 * (a.moved[i * 3 + c] - a.pc1[j * 3 + c]));
+        for (int c = 0; c < 3; ++c) scat_add(a.scat + i * 3 + c, 2.0f * inv_n1 * (a.moved[i * 3 + c] - a.pc1[j * 3 + c]));
     }
     const int nd0 = a.counts[0], nd1 = a.counts[1];
     if (j < nd1 && nd0 > 0) {                                   // j indexes the dynamic pc1 subset here
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(256) void loss_pc1_kernel(LossArgs a, int blocks0) 
         const int k = a.i_d[j];
         const int i = a.dyn0[k];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) atomicAdd(&a.grad[i * 3 + c], 2.0f / (float)nd1 * (a.mdyn[k * 3 + c] - a.qdyn[j * 3 + c]));
+        for (int c = 0; c < 3; ++c) scat_add(a.scat + i * 3 + c, 2.0f / (float)nd1 * (a.mdyn[k * 3 + c] - a.qdyn[j * 3 + c]));
     }
     block_sum4(t, a.partial + ((size_t)blocks0 + blockIdx.x) * 4);
 }
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const double* __restric
     }
 }
 
-struct LossLayout { size_t moved, da, ia, db, ib, dr, ir, dyn0, dyn1, pos0, mdyn, qdyn, dc, ic, dd, id, bc0, bc1, counts, anchor, partial, nn, end; };
+struct LossLayout { size_t moved, scat, da, ia, db, ib, dr, ir, dyn0, dyn1, pos0, mdyn, qdyn, dc, ic, dd, id, bc0, bc1, counts, anchor, partial, nn, end; };
 
 static LossLayout loss_layout(int n0, int n1, int n_labels, int gw, int gh) {
     LossLayout L;
@@ -251,6 +261,7 @@ static LossLayout loss_layout(int n0, int n1, int n_labels, int gw, int gh) {
     auto take = [&](size_t bytes) { size_t at = o; o += round_up(bytes > 0 ? bytes : 16, 16); return at; };
     const size_t N0 = (size_t)(n0 > 0 ? n0 : 1), N1 = (size_t)(n1 > 0 ? n1 : 1);
     L.moved = take(N0 * 12);
+    L.scat = take(N0 * 24);
     L.da = take(N0 * 4); L.ia = take(N0 * 4); L.db = take(N1 * 4); L.ib = take(N1 * 4); L.dr = take(N0 * 4); L.ir = take(N0 * 4);
     L.dyn0 = take(N0 * 4); L.dyn1 = take(N1 * 4); L.pos0 = take(N0 * 4); L.mdyn = take(N0 * 12); L.qdyn = take(N1 * 12);
     L.dc = take(N0 * 4); L.ic = take(N0 * 4); L.dd = take(N1 * 4); L.id = take(N1 * 4);
@@ -287,7 +298,7 @@ extern "C" int himo_ssl_loss(int n0, int n1, const float* d_pc0, const float* d_
     LossArgs a{};
     a.n0 = n0; a.n1 = n1; a.n_labels = n_labels;
     a.pc0 = d_pc0; a.pc1 = d_pc1; a.flow = d_flow; a.lab0 = d_label0; a.lab1 = d_label1;
-    a.moved = (float*)(ws + L.moved); a.grad = d_grad_flow;
+    a.moved = (float*)(ws + L.moved); a.grad = d_grad_flow; a.scat = (unsigned long long*)(ws + L.scat);
     a.d_a = (float*)(ws + L.da); a.i_a = (int*)(ws + L.ia); a.d_b = (float*)(ws + L.db); a.i_b = (int*)(ws + L.ib);
     a.d_r = (float*)(ws + L.dr); a.i_r = (int*)(ws + L.ir);
     a.dyn0 = (int*)(ws + L.dyn0); a.dyn1 = (int*)(ws + L.dyn1); a.pos0 = (int*)(ws + L.pos0);
@@ -301,6 +312,7 @@ extern "C" int himo_ssl_loss(int n0, int n1, const float* d_pc0, const float* d_
     const int blocks0 = (n0 + 255) / 256, blocks1 = (n1 + 255) / 256;
 
     HIMO_HIP(hipMemsetAsync(a.counts, 0, 32, s));
+    if (n0 > 0) HIMO_HIP(hipMemsetAsync(a.scat, 0, (size_t)n0 * 24, s));
     HIMO_HIP(hipMemsetAsync(a.anchor, 0, (size_t)n_labels * 8, s));
     HIMO_HIP(hipMemsetAsync(a.partial, 0, ((size_t)blocks0 + blocks1 + 2) * 32, s));
     if (n0 > 0) hipLaunchKernelGGL(loss_prepare_kernel, dim3(blocks0), dim3(256), 0, s, a);
@@ -343,8 +355,8 @@ extern "C" int himo_ssl_loss(int n0, int n1, const float* d_pc0, const float* d_
     HIMO_LAUNCH_CHECK("cluster_kernels");
     {
         ProfScope ps("ssl_loss_point_kernels", s);
-        if (n0 > 0) hipLaunchKernelGGL(loss_pc0_kernel, dim3(blocks0), dim3(256), 0, s, a);
         if (n1 > 0) hipLaunchKernelGGL(loss_pc1_kernel, dim3(blocks1), dim3(256), 0, s, a, blocks0);
+        if (n0 > 0) hipLaunchKernelGGL(loss_pc0_kernel, dim3(blocks0), dim3(256), 0, s, a);
         hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, a.partial, blocks0 + blocks1, d_loss);
     }
     HIMO_LAUNCH_CHECK("ssl_loss_point_kernels");

@@ -16,7 +16,7 @@ def _labelled(dataset_frames):
 def test_one_full_size_train_step_is_finite_and_reproducible(gpu):
     """3 x 120k-point sweeps, labelled clusters: forward with saved activations -> 4-term loss -> full backward -> Adam.
     Two fresh trainers on the same sample give the same loss and the same gradient norm (the backward pass is fixed-order
-    reductions except the loss's scatter-add half: last-bit differences only)."""
+    reductions; the loss's scatter-add half accumulates fixed point: see test_training_steps_are_bit_reproducible)."""
     from himo_amd.seflow import spec
     from himo_amd.seflow.fit import make_sample
     from himo_amd.seflow.train import SeFlowTrainer
@@ -39,6 +39,31 @@ def test_one_full_size_train_step_is_finite_and_reproducible(gpu):
     assert np.isfinite(l0) and l0 > 0 and n0 > 0
     assert l0 == pytest.approx(l1, rel=1e-9) and n0 == pytest.approx(n1, rel=1e-5), runs
     assert all(v >= 0 for v in t0.values()) and sum(t0.values()) == pytest.approx(l0, rel=1e-9)
+
+
+def test_training_steps_are_bit_reproducible(gpu):
+    """Two fresh trainers, the same four samples, BatchNorm in training mode, the encoder's weight gradients on the side stream:
+    the same parameter bits after four optimiser steps.  Every reduction of the step is a fixed-order tree, and the one scatter-add
+    (the pc1 -> moved half of the Chamfer gradient, csrc/sslloss.hip) accumulates 64-bit fixed point -- with float atomics the
+    last bits of a step depended on the arrival order, and the trained-weights parity case saw different weights on every run."""
+    from himo_amd.dataset import ListDataset
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.fit import make_sample, triplets
+    from himo_amd.seflow.train import SeFlowTrainer
+    from himo_amd.synthetic import make_frame
+    ds = ListDataset([make_frame(760 + i, n_points=30_000, scene_id="r") for i in range(6)])
+    trips = triplets(ds)
+    finals, losses = [], []
+    for _ in range(2):
+        tr = SeFlowTrainer(spec.init_params(5), device=gpu, max_points=32_000, batchnorm="batch")
+        ls = [float(tr.train_batch([make_sample(ds, trips[k % len(trips)], gpu)], lr=3e-4).item()) for k in range(4)]
+        torch.cuda.synchronize()
+        finals.append(tr.flat_p.clone())
+        losses.append(ls)
+        del tr
+        torch.cuda.empty_cache()
+    assert losses[0] == losses[1], losses
+    assert torch.equal(finals[0], finals[1]), int((finals[0] != finals[1]).sum())
 
 
 def test_fit_runs_epochs_batches_schedule_and_keeps_the_top_checkpoints(gpu, tmp_path):
@@ -109,7 +134,7 @@ def test_checkpoint_resume_continues_bit_for_bit(gpu, tmp_path):
     extra = other.load_checkpoint(path)
     assert int(extra["epoch"]) == 0 and other.step_count == 2
     other.train_step(*a, lr=1e-4); other.train_step(*b, lr=1e-4)
-    # the loss's scatter-add half may differ in the last bits between runs: compare to float32 round-off, moments included
+    # (written when the loss's scatter-add half used float atomics; the step is bit-reproducible now, the float32 round-off bar stays)
     for x, y in ((tr.flat_p, other.flat_p), (tr.flat_m, other.flat_m), (tr.flat_v, other.flat_v)):
         assert (x - y).abs().max().item() <= 1e-6 * max(x.abs().max().item(), 1e-30)
     assert other.step_count == tr.step_count == 4
