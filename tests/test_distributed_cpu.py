@@ -346,12 +346,12 @@ def test_train_batch_exchange_weighs_every_sample_of_the_global_batch_alike(tmp_
 
 def _worker_skewed_rendezvous(rank, world, port, out_dir):
     _cli_env(rank, world, port)
-    os.environ["HIMO_DIST_TIMEOUT_S"] = "2"                      # the data collectives' clock: far shorter than the skew below
+    os.environ["HIMO_DIST_TIMEOUT_S"] = "5"                      # the data collectives' clock: far shorter than the skew below
     import time
     from himo_amd import distenv
     with distenv.process_group() as (r, w):
         if r == 1:
-            time.sleep(6)                                        # the slow shard (whole scenes per rank, slow h5 reads)
+            time.sleep(12)                                       # the slow shard (whole scenes per rank, slow h5 reads)
         distenv.rendezvous(None)
         got = [None] * w
         dist.all_gather_object(got, r)                           # the gather that follows the rendezvous still works
