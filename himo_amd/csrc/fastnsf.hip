@@ -401,7 +401,9 @@ struct ChamferArgs {
     float trunc2;
     float* grad;                           // [n0][3] d loss / d moved
     double* partial;                       // [blocks0 + blocks1]
+    unsigned long long* scat;              // [n0][3]: the pc1 -> moved half's scattered gradient, 2^-40 fixed point (order-independent sum)
 };
+constexpr double kChamferScatScale = 1099511627776.0;      // 2^40 (csrc/sslloss.hip uses the same scheme)
 
 __device__ inline void block_sum1(double v, double* out) {
     __shared__ double red[256];
@@ -426,7 +428,8 @@ __global__ __launch_bounds__(256) void chamfer_trunc_a_kernel(ChamferArgs a) {
             for (int c = 0; c < 3; ++c) g[c] = 2.0f / (float)a.n0 * (a.moved[i * 3 + c] - a.pc1[j * 3 + c]);
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a.grad[i * 3 + c] = g[c];
+        for (int c = 0; c < 3; ++c)                        // (the scattering kernel ran first)
+            a.grad[i * 3 + c] = g[c] + (float)((double)(long long)a.scat[i * 3 + c] * (1.0 / kChamferScatScale));
     }
     block_sum1(t, a.partial + blockIdx.x);
 }
@@ -438,7 +441,8 @@ __global__ __launch_bounds__(256) void chamfer_trunc_b_kernel(ChamferArgs a, int
         t = (double)a.d_b[j] / (double)a.n1;
         const int i = a.i_b[j];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) atomicAdd(&a.grad[i * 3 + c], 2.0f / (float)a.n1 * (a.moved[i * 3 + c] - a.pc1[j * 3 + c]));
+        for (int c = 0; c < 3; ++c)
+            atomicAdd(a.scat + i * 3 + c, (unsigned long long)__double2ll_rn((double)(2.0f / (float)a.n1 * (a.moved[i * 3 + c] - a.pc1[j * 3 + c])) * kChamferScatScale));
     }
     block_sum1(t, a.partial + blocks0 + blockIdx.x);
 }
@@ -650,7 +654,7 @@ extern "C" int himo_adam_step(int64_t n, float* d_param, const float* d_grad, fl
 }
 
 extern "C" size_t himo_chamfer_trunc_workspace_bytes(int n0, int n1) {
-    return ((size_t)(n0 + 255) / 256 + (size_t)(n1 + 255) / 256 + 2) * 8 + 64;
+    return round_up(((size_t)(n0 + 255) / 256 + (size_t)(n1 + 255) / 256 + 2) * 8, 16) + (size_t)(n0 > 0 ? n0 : 1) * 24 + 64;
 }
 
 extern "C" int himo_chamfer_trunc(int n0, int n1, const float* d_moved, const float* d_pc1, const float* d_dist_a,
@@ -661,11 +665,13 @@ extern "C" int himo_chamfer_trunc(int n0, int n1, const float* d_moved, const fl
     if (n0 > 0 && n1 > 0 && (!d_pc1 || !d_dist_a || !d_idx_a || !d_dist_b || !d_idx_b)) return HIMO_ERR_INVALID_ARGUMENT;
     if (workspace_bytes < himo_chamfer_trunc_workspace_bytes(n0, n1)) return HIMO_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    ChamferArgs a{n0, n1, d_moved, d_pc1, d_dist_a, d_idx_a, d_dist_b, d_idx_b, trunc_dist * trunc_dist, d_grad_moved,
-                  reinterpret_cast<double*>(d_workspace)};
     const int b0 = (n0 + 255) / 256, b1 = (n1 + 255) / 256;
-    if (b0) hipLaunchKernelGGL(chamfer_trunc_a_kernel, dim3(b0), dim3(256), 0, s, a);
+    ChamferArgs a{n0, n1, d_moved, d_pc1, d_dist_a, d_idx_a, d_dist_b, d_idx_b, trunc_dist * trunc_dist, d_grad_moved,
+                  reinterpret_cast<double*>(d_workspace),
+                  reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(d_workspace) + round_up(((size_t)b0 + b1 + 2) * 8, 16))};
+    if (n0 > 0) HIMO_HIP(hipMemsetAsync(a.scat, 0, (size_t)n0 * 24, s));
     if (b1) hipLaunchKernelGGL(chamfer_trunc_b_kernel, dim3(b1), dim3(256), 0, s, a, b0);
+    if (b0) hipLaunchKernelGGL(chamfer_trunc_a_kernel, dim3(b0), dim3(256), 0, s, a);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, a.partial, b0 + b1, d_loss);
     HIMO_LAUNCH_CHECK("chamfer_trunc kernels");
     return HIMO_OK;
