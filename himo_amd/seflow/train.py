@@ -545,6 +545,13 @@ class SeFlowTrainer:
         # the encoder's weight gradients run on a SIDE stream under the data-gradient chain (backward): own workspace, and the
         # pre-activation gradient they read alternates between two buffers so the chain never waits for them
         self.overlap_wgrad = os.environ.get("HIMO_TRAIN_SIDE_STREAM", "1") != "0"
+        # 3x3 convolutions of the forward and data-gradient passes: the fastest of the library's tile variants per layer shape,
+        # timed once at the shape's first launch (the variants return identical bits: tests/test_train_gpu.py)
+        self.tune_tiles = os.environ.get("HIMO_TRAIN_TUNE_TILES", "1") != "0"
+        self._tile_hints = {}
+        if self.tune_tiles and precision != "f32":   # the decoder's forward runs through net._conv: the same restricted candidates
+            net.autotune = True
+            net._tune = lambda d: self._tune_tile(d) if (d.ksize == 3 and d.w_packed) else 0
         self.side = torch.cuda.Stream(device=dev)
         self.ws_side = torch.empty(ws + 64, dtype=torch.uint8, device=dev)
         self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
@@ -608,10 +615,46 @@ class SeFlowTrainer:
             d.y, d.y_batch_stride, d.y_pitch = y, y_bs, y_pitch
             d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = n, h, wd, cin, cout, ks, stride, EPI_BIAS
             d.act_layout = 8 if accumulate else 0     # HIMO_ACT_ACCUMULATE: y += result (two-term bf16 3x3 kernel)
+            if self.tune_tiles and ks == 3 and packed is not None and self.precision != "f32":
+                tkey = (n, h, wd, cin, cout, stride, fmt, bool(accumulate))
+                if tkey not in self._tile_hints:
+                    self._tile_hints[tkey] = self._tune_tile(d)
+                d.tile_hint = self._tile_hints[tkey]
             if len(self._descs) > 4096:
                 self._descs.clear()
             self._descs[key] = d
         _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), "himo_conv2d(train)")
+
+    TILE_HINTS = (0, 0x1004, 0x1002, 0x1001)          # library heuristic, then the weights-from-L2 structure pinned to 4 / 2 / 1 rows per wave
+
+    def _tune_tile(self, d) -> int:
+        """The fastest tile variant of one 3x3 layer shape (csrc/convsp.hip; all return the same bits).  Runs on the layer's own
+        operands at its first launch: the convolution overwrites its output, so repeating it is harmless -- except with
+        HIMO_ACT_ACCUMULATE (y += result), which is timed on a twin writing a dense scratch image instead."""
+        t = ConvDesc.from_buffer_copy(d)
+        if t.act_layout & 8:
+            ho, wo = ((t.h + 1) // 2, (t.w_in + 1) // 2) if t.stride == 2 else (t.h, t.w_in)
+            if t.n * ho * wo * t.cout > self.TMP.numel():
+                return 0
+            t.act_layout &= ~8
+            t.y, t.y_batch_stride, t.y_pitch = self.TMP.data_ptr(), ho * wo * t.cout, t.cout
+        stream = _lib.stream_handle()
+        best, best_ms = 0, float("inf")
+        for _round in range(2):                       # two interleaved rounds (the clock drifts with load), best time of each variant
+            for hint in self.TILE_HINTS:
+                t.tile_hint = hint
+                if self.lib.himo_conv2d(ctypes.byref(t), stream) != 0:
+                    continue                          # a variant this shape does not admit
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    self.lib.himo_conv2d(ctypes.byref(t), stream)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                if ms < best_ms:
+                    best, best_ms = hint, ms
+        return best
 
     def _wgrad3_batch(self, n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, gname, stride=1, ws=None):
         """weight gradient over n images in one launch (LDS-tiled kernel)"""

@@ -502,3 +502,27 @@ def test_head_trainer_reuses_its_buffers_across_sweep_sizes(gpu):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), n
         for k in want[2]:
             np.testing.assert_allclose(got[2][k], want[2][k], rtol=0, atol=1e-6 * max(1.0, float(np.abs(want[2][k]).max())), err_msg=f"{k} n={n}")
+
+
+@pytest.mark.parametrize("prec,stride", [("f16x2", 1), ("f16x2", 2), ("bf16x2", 1)])
+def test_tile_variants_of_the_training_convolutions_return_identical_bits(gpu, prec, stride):
+    """SeFlowTrainer picks the fastest tile variant per 3x3 layer shape at the shape's first launch (train.py _tune_tile): the
+    choice may differ between runs, so the variants must agree bit for bit -- float32 maps in, both split formats, stride 1 and 2."""
+    from himo_amd import _lib
+    from himo_amd.seflow.model import conv2d_nhwc
+    from himo_amd.seflow.train import SeFlowTrainer
+    torch.manual_seed(5)
+    for n, h, w, cin, cout in ((3, 64, 64, 64, 64), (1, 128, 128, 128, 64), (3, 32, 64, 256, 256), (2, 96, 64, 32, 64)):
+        if prec == "bf16x2" and stride == 2:
+            continue
+        x = torch.randn(n, h, w, cin, device=gpu) * (1e-3 if prec == "bf16x2" else 1.0)
+        wt = torch.randn(3, 3, cin, cout, device=gpu) * 0.05
+        b = torch.randn(cout, device=gpu) * 0.1
+        ref = conv2d_nhwc(x, wt, b, stride=stride, precision=prec, tile_hint=0)
+        for hint in SeFlowTrainer.TILE_HINTS[1:]:
+            try:
+                got = conv2d_nhwc(x, wt, b, stride=stride, precision=prec, tile_hint=hint)
+            except (_lib.HimoError, ValueError):
+                continue                                   # a variant the shape does not admit
+            assert torch.equal(got, ref), (prec, stride, (n, h, w, cin, cout), hex(hint))
+
