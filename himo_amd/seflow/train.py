@@ -143,6 +143,7 @@ class HeadTrainer:
         self.PKT = {k: pk(*self.p[f"{k}.weight"].shape[::-1]) for k in ("zr", "q", "dec1")} if self.fmt_bwd is not None else {}
         # True: the owner refreshes PK / PKT itself after every parameter update (SeFlowTrainer: one launch for the whole network)
         self.external_pack = False
+        self.wgrad_stream = None       # a torch stream for the gate weight gradients of the fused backward (None: in place)
         self.fused_backward = True     # split precisions: the GRU iterations' backward sweep as one kernel (False: three element-wise
                                        # kernels around two row products per iteration -- kept as the statement the fused sweep is tested against)
 
@@ -275,11 +276,22 @@ class HeadTrainer:
             runs = [(T * self.rows, 0, 0)]
         else:                                            # a much smaller sample than the capacity: iteration by iteration, n rows each
             runs = [(n, t, 1 if t else 0) for t in range(T)]
-        for name, x, dz, cout in (("q", self._RHX, self._DAQ, 128), ("zr", self._HX, self._DAZR, 256)):
-            for rows, t, acc in runs:
-                _lib.check(self.lib.himo_linear_wgrad_ex(rows, x[t].data_ptr(), 192, 192, dz[t].data_ptr(), cout, cout,
-                                                         self.g[f"{name}.weight"].data_ptr(), self.g[f"{name}.bias"].data_ptr(),
-                                                         self.wgrad_flags | acc, self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle()), "wgrad")
+        def gate_weight_gradients():
+            for name, x, dz, cout in (("q", self._RHX, self._DAQ, 128), ("zr", self._HX, self._DAZR, 256)):
+                for rows, t, acc in runs:
+                    _lib.check(self.lib.himo_linear_wgrad_ex(rows, x[t].data_ptr(), 192, 192, dz[t].data_ptr(), cout, cout,
+                                                             self.g[f"{name}.weight"].data_ptr(), self.g[f"{name}.bias"].data_ptr(),
+                                                             self.wgrad_flags | acc, self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle()), "wgrad")
+        if self.wgrad_stream is None:
+            gate_weight_gradients()
+        else:
+            # 1.5 GB of saved states and gate gradients, read only: beside whatever the caller's stream does next (SeFlowTrainer: the
+            # decoder's backward pass); the caller waits for this stream before it reads the gradients or runs the next backward
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.wgrad_stream):
+                self.wgrad_stream.wait_event(ready)
+                gate_weight_gradients()
         return self._DHX0[:n]
 
     def _saved(self):
@@ -554,6 +566,16 @@ class SeFlowTrainer:
             net._tune = lambda d: self._tune_tile(d) if (d.ksize == 3 and d.w_packed) else 0
         self.side = torch.cuda.Stream(device=dev)
         self.ws_side = torch.empty(ws + 64, dtype=torch.uint8, device=dev)
+        # ... and the DECODER's weight gradients on a second side stream (the encoder's ping-pong waits on the first: a backlog of
+        # decoder work there would stall the chain).  Their gradient operands get a buffer per block instead of the shared scratch
+        self.overlap_decoder = self.overlap_wgrad and os.environ.get("HIMO_TRAIN_SIDE_STREAM_DECODER", "1") != "0"
+        self.side2 = torch.cuda.Stream(device=dev)
+        self.ws_side2 = torch.empty(ws + 64, dtype=torch.uint8, device=dev) if self.overlap_decoder else None
+        self.head.wgrad_stream = self.side2 if self.overlap_decoder else None      # the GRU gates' weight gradients go there too
+        if self.overlap_decoder:
+            self.dIN = {"dec3": buf(H * W * 64), "dec2": buf(H * W // 4 * 128), "dec1": buf(H * W // 16 * 256)}
+            self.dCATb = {"dec3": self.dCAT, "dec2": buf(H * W // 4 * 256), "dec1": buf(H * W // 16 * 512)}
+            self.dTMPb = {"dec3": self.dTMPc, "dec2": buf(H * W // 16 * 128), "dec1": buf(H * W // 64 * 256)}
         self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
         # BatchNorm in training mode: per-layer batch statistics kept for the backward pass; the pillar net has one set per sweep
         self.bn_mean = torch.zeros((len(self.layers), 256), dtype=torch.float32, device=dev)
@@ -663,32 +685,46 @@ class SeFlowTrainer:
                                                      self.g[gname].data_ptr(), self.wgrad_flags, ws.data_ptr(), ws.numel(),
                                                      _lib.stream_handle()), "conv3x3_wgrad_batch")
 
-    def _wgrad3(self, x, x_pitch, h, w, cin, dy, dy_pitch, cout, stride, gname, acc):
+    def _wgrad3(self, x, x_pitch, h, w, cin, dy, dy_pitch, cout, stride, gname, acc, ws=None):
         if stride == 1 and not acc:
-            return self._wgrad3_batch(1, x, 0, x_pitch, h, w, cin, dy, 0, dy_pitch, cout, gname)
+            return self._wgrad3_batch(1, x, 0, x_pitch, h, w, cin, dy, 0, dy_pitch, cout, gname, ws=ws)
+        ws = self.ws if ws is None else ws
         _lib.check(self.lib.himo_conv3x3_wgrad(x, x_pitch, h, w, cin, dy, dy_pitch, cout, stride, self.g[gname].data_ptr(),
-                                               1 if acc else 0, self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle()), "conv3x3_wgrad")
+                                               1 if acc else 0, ws.data_ptr(), ws.numel(), _lib.stream_handle()), "conv3x3_wgrad")
 
-    def _wgrad3_bias(self, x, x_pitch, h, w, cin, dy, dy_pitch, cout, wname, bname):
+    def _wgrad3_bias(self, x, x_pitch, h, w, cin, dy, dy_pitch, cout, wname, bname, ws=None):
         """stride-1 3x3 weight gradient AND the bias gradient (column sums of dY) of one image: one pass over dY in the split-bf16
         kernel (mixed precision); the float32 kernels keep the separate column-sum launch"""
+        w_ = self.ws if ws is None else ws
         if self.wgrad_flags & 2:
             st = self.lib.himo_conv3x3_wgrad_batch_bias(1, x, 0, x_pitch, h, w, cin, dy, 0, dy_pitch, cout, 1, self.g[wname].data_ptr(),
-                                                        self.g[bname].data_ptr(), self.wgrad_flags, self.ws.data_ptr(), self.ws.numel(),
+                                                        self.g[bname].data_ptr(), self.wgrad_flags, w_.data_ptr(), w_.numel(),
                                                         _lib.stream_handle())
             if st == 0:
                 return
-        self._wgrad3(x, x_pitch, h, w, cin, dy, dy_pitch, cout, 1, wname, False)
-        self._colsum(h * w, dy, dy_pitch, cout, bname)
+        self._wgrad3(x, x_pitch, h, w, cin, dy, dy_pitch, cout, 1, wname, False, ws=ws)
+        self._colsum(h * w, dy, dy_pitch, cout, bname, ws=ws)
+
+    def _beside(self, fn):
+        """a decoder weight gradient: it only READS its operands, so it runs on the second side stream from the point the main stream
+        has reached (fn(workspace)); without the overlap it runs in place"""
+        if not self.overlap_decoder:
+            return fn(self.ws)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side2):
+            self.side2.wait_event(ready)
+            fn(self.ws_side2)
 
     def _colsum(self, rows, z, pitch, cout, gname, acc=False, ws=None):
         ws = self.ws if ws is None else ws
         _lib.check(self.lib.himo_colsum(rows, z, pitch, cout, self.g[gname].data_ptr(), 1 if acc else 0, ws.data_ptr(),
                                         ws.numel(), _lib.stream_handle()), "colsum")
 
-    def _wgrad1(self, rows, x, x_pitch, cin, dz, z_pitch, cout, name):
+    def _wgrad1(self, rows, x, x_pitch, cin, dz, z_pitch, cout, name, ws=None):
+        ws = self.ws if ws is None else ws
         _lib.check(self.lib.himo_linear_wgrad_ex(rows, x, x_pitch, cin, dz, z_pitch, cout, self.g[f"{name}.weight"].data_ptr(),
-                                                 self.g[f"{name}.bias"].data_ptr(), self.wgrad_flags, self.ws.data_ptr(), self.ws.numel(),
+                                                 self.g[f"{name}.bias"].data_ptr(), self.wgrad_flags, ws.data_ptr(), ws.numel(),
                                                  _lib.stream_handle()), "linear_wgrad")
 
     def _flip(self, name, ks, cin, cout):
@@ -801,17 +837,20 @@ class SeFlowTrainer:
         h2, w2 = 2 * ch, 2 * cw
         P = h2 * w2
         zb = self.zero_bias.data_ptr()
+        if self.overlap_decoder:                                 # this block's own gradient buffers: its weight gradients read them later
+            d_in = self.dIN[name].data_ptr()
+        dcat = (self.dCATb[name] if self.overlap_decoder else self.dCAT).data_ptr()
+        dtmp = (self.dTMPb[name] if self.overlap_decoder else self.dTMPc).data_ptr()
         # u5
-        self._wgrad3_bias(work0.data_ptr(), out, h2, w2, out, d_out, out, out, f"{name}.u5.weight", f"{name}.u5.bias")
+        self._beside(lambda ws: self._wgrad3_bias(work0.data_ptr(), out, h2, w2, out, d_out, out, out, f"{name}.u5.weight", f"{name}.u5.bias", ws=ws))
         wf, wp = self._flip(f"{name}.u5", 3, out, out)
         self._conv(d_out, 0, out, wf, zb, d_in, 0, out, 1, h2, w2, out, out, 3, packed=wp)
         # u4
-        self._wgrad3_bias(cat.data_ptr(), 2 * lat, h2, w2, 2 * lat, d_in, out, out, f"{name}.u4.weight", f"{name}.u4.bias")
-        dcat = self.dCAT.data_ptr()
+        self._beside(lambda ws: self._wgrad3_bias(cat.data_ptr(), 2 * lat, h2, w2, 2 * lat, d_in, out, out, f"{name}.u4.weight", f"{name}.u4.bias", ws=ws))
         wf, wp = self._flip(f"{name}.u4", 3, 2 * lat, out)
         self._conv(d_in, 0, out, wf, zb, dcat, 0, 2 * lat, 1, h2, w2, out, 2 * lat, 3, packed=wp)
         # u3 (1x1 on the skip): gradient rows are the right half of dCAT
-        self._wgrad1(P, skip.data_ptr(), skip_c, skip_c, dcat + 4 * lat, 2 * lat, lat, f"{name}.u3")
+        self._beside(lambda ws: self._wgrad1(P, skip.data_ptr(), skip_c, skip_c, dcat + 4 * lat, 2 * lat, lat, f"{name}.u3", ws=ws))
         wt, wp = self._flip(f"{name}.u3", 1, skip_c, lat)                   # [lat][skip_c]
         if skip_acc:
             self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, self.TMP.data_ptr(), 0, skip_c, 1, 1, P, lat, skip_c, 1, packed=wp)
@@ -819,9 +858,8 @@ class SeFlowTrainer:
         else:
             self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, d_skip, 0, skip_c, 1, 1, P, lat, skip_c, 1, packed=wp)
         # upsample, u1 (1x1 on the coarse map)
-        dtmp = self.dTMPc.data_ptr()
         _lib.check(lib.himo_upsample2x_bwd(dcat, 2 * lat, ch, cw, lat, dtmp, lat, s()), "upsample2x_bwd")
-        self._wgrad1(ch * cw, coarse.data_ptr(), c_in, c_in, dtmp, lat, lat, f"{name}.u1")
+        self._beside(lambda ws: self._wgrad1(ch * cw, coarse.data_ptr(), c_in, c_in, dtmp, lat, lat, f"{name}.u1", ws=ws))
         wt, wp = self._flip(f"{name}.u1", 1, c_in, lat)
         self._conv(dtmp, 0, lat, wt, zb, d_coarse, 0, c_in, 1, 1, ch * cw, lat, c_in, 1, packed=wp)
 
@@ -842,7 +880,7 @@ class SeFlowTrainer:
         zb = self.zero_bias.data_ptr()
         # dec4
         u = net.U[1]
-        self._wgrad3_bias(u.data_ptr(), 64, H, W, 64, self.dDEC.data_ptr(), 64, 64, "dec4.weight", "dec4.bias")
+        self._beside(lambda ws: self._wgrad3_bias(u.data_ptr(), 64, H, W, 64, self.dDEC.data_ptr(), 64, 64, "dec4.weight", "dec4.bias", ws=ws))
         d_u = self.dWORK[0].data_ptr()
         wf, wp = self._flip("dec4", 3, 64, 64)
         self._conv(self.dDEC.data_ptr(), 0, 64, wf, zb, d_u, 0, 64, 1, H, W, 64, 64, 3, packed=wp)
@@ -931,6 +969,7 @@ class SeFlowTrainer:
                                                       self.g["pfn.bn.gamma"].data_ptr(), self.g["pfn.bn.beta"].data_ptr(), 0,
                                                       self.ws.data_ptr(), self.ws.numel(), s()), "pfn_backward_bn_multi")
             main.wait_stream(self.side)                         # every gradient is in flat_g when this stream goes on
+            main.wait_stream(self.side2)
             return
         for slot in range(F):
             if self._fwd_batch:
@@ -948,6 +987,7 @@ class SeFlowTrainer:
                                              self.g["pfn.weight"].data_ptr(), 1 if slot else 0, self.ws.data_ptr(), self.ws.numel(), s()),
                        "pfn_backward")
         main.wait_stream(self.side)
+        main.wait_stream(self.side2)
 
     def _pfn_sweep_arrays(self):
         """host arrays of the sample's sweeps for the multi-sweep pillar-net calls: point counts, transformed points, pillar workspaces"""
