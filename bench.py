@@ -75,7 +75,7 @@ def parse_args():
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="pipeline, N=1: skip the short training-step (config 5) and FastNSF (config 4) legs that follow the timed region")
     ap.add_argument("--leg-train-steps", type=int, default=6, help="timed optimiser steps of the `leg_train` leg (after 2 warm-ups)")
-    ap.add_argument("--leg-fastnsf-fits", type=int, default=3, help="timed fits of the `leg_fastnsf` leg (after 1 warm-up)")
+    ap.add_argument("--leg-fastnsf-fits", type=int, default=6, help="timed fits of the `leg_fastnsf` leg (after 1 warm-up)")
     ap.add_argument("--cloud", default="uniform", choices=["uniform", "rings"],
                     help="synthetic sweeps: SURVEY 8(d) uniform cloud with instances (default) or the LiDAR-like ring cloud")
     ap.add_argument("--sample-sets", type=int, default=3, help="distinct input batches rotated through the timed steps")
@@ -397,17 +397,25 @@ def main() -> int:
 def make_fastnsf_step(args, rank: int, device, result: dict):
     """BASELINE config 4: a step fits the per-scene coordinate MLP to one 120k-point sweep pair."""
     import torch
-    from himo_amd.fastnsf import FastNSF
+    from himo_amd.fastnsf import FastNSF, OverlappedFastNSF
     from himo_amd.synthetic import make_frame
     P = args.points
     fr = [make_frame(100_000 * rank + 77 + i, n_points=P, cloud=args.cloud) for i in range(2)]
     p0 = torch.from_numpy(np.ascontiguousarray(fr[0]["pc0"][:, :3])).to(device)
     p1 = torch.from_numpy((fr[0]["pc0"][:, :3] + fr[0]["flow"]).astype(np.float32)).to(device)     # the sweep one step later
-    fitter = FastNSF(device=device, iters=args.fastnsf_iters)
+    # the product's way to run a stream of sweep pairs: two fits in flight on two HIP streams (fastnsf.OverlappedFastNSF; fits of
+    # different pairs are independent); --single-stream keeps one engine
+    nsf = None if args.single_stream else OverlappedFastNSF(device=device, engines=2, iters=args.fastnsf_iters)
+    fitter = FastNSF(device=device, iters=args.fastnsf_iters) if nsf is None else nsf.engines[0]
+
+    def step_single():
+        result["flow"] = fitter.fit(p0, p1, fr[0]["pose0"], fr[0]["pose1"])
 
     def step():
-        result["flow"] = fitter.fit(p0, p1, fr[0]["pose0"], fr[0]["pose1"])
-    return step, fitter, fr
+        if nsf is None:
+            return step_single()
+        result["flow"] = nsf.submit(p0, p1, fr[0]["pose0"], fr[0]["pose1"])[1]      # (valid once the engine's fit is collected)
+    return step, fitter, fr, nsf, step_single
 
 
 def make_train_step(args, rank: int, device, result: dict, n_sets: int = 2):
@@ -461,7 +469,7 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
         def step():
             eng.run(batch, sensor_dt=0.1, refined=args.refined, out=out)
     elif args.workload == "fastnsf":
-        step, fitter, fr = make_fastnsf_step(args, rank, device, result)
+        step, fitter, fr, overlapped, step_single = make_fastnsf_step(args, rank, device, result)
     elif args.workload == "train":
         step, trainer = make_train_step(args, rank, device, result)
     else:
@@ -517,6 +525,8 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
             parity = {"comp_dis_mean_epe_vs_ref": float(np.linalg.norm(d, axis=1).mean()),
                       "comp_dis_max_abs_vs_ref": float(np.abs(d).max()), "bit_exact_fraction": float((got == ref).mean())}
         elif args.workload == "fastnsf":
+            if overlapped is not None:
+                overlapped.sync_check()                         # the fits in flight: loss histories read, flows final
             gt = fr[0]["flow"]
             got = result["flow"].cpu().numpy()
             parity = {"loss_first_to_last_iteration": [fitter.loss_history[0][1], fitter.loss_history[-1][1]],
@@ -582,7 +592,8 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step_single()
-        pipe.sync_check()
+        if pipe is not None:
+            pipe.sync_check()
         sync()
         single = time.perf_counter() - t1
     gc.enable()
@@ -627,7 +638,14 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
                     "over a ragged HBM-resident batch; network forward NOT included")
         dtype = "f64"
     elif args.workload == "fastnsf":
-        roofline, workload, dtype = fastnsf_roofline(args, prof, args.steps, elapsed)
+        roofline, workload, dtype = fastnsf_roofline(args, prof, args.steps, single if single is not None else elapsed)
+        if single is not None:
+            roofline["measured_in"] = ("a second region of the same K fits on ONE engine (un-overlapped launches), right after the timed "
+                                       "region; `value` is the two-fits-in-flight rate")
+            extra["value_single_stream"] = args.steps / single
+            extra["leg_single_stream"] = {"frames_per_s": args.steps / single, "ms_per_step": single / args.steps * 1e3, "steps": args.steps,
+                                          "note": "FastNSF.fit, one fit at a time: the configuration of the earlier rounds' figures; the "
+                                                  "roofline kernel's launches are timed here"}
     elif args.workload == "train":
         roofline, workload, dtype = train_roofline(args, prof, B * args.steps, elapsed)
     else:
@@ -701,6 +719,7 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     if args.workload == "fastnsf":
         line["metric"] = "fastnsf_frames_per_sec_120k"
         line["config"]["iterations_per_frame"] = args.fastnsf_iters
+        line["config"]["fits_in_flight"] = 1 if overlapped is None else 2
     if args.workload == "train":
         line["metric"] = "train_frames_per_sec_120k"
         line["config"]["parallelism"] = f"data parallel x{world}, one flat all-reduce per step"
@@ -872,31 +891,51 @@ def extra_workload_legs(args, device) -> dict:
                 step, obj = make_train_step(a, 0, device, result)
                 dominant = TRAIN_DOMINANT
             else:
-                step, obj, fr = make_fastnsf_step(a, 0, device, result)
+                step, obj, fr, nsf, step_single = make_fastnsf_step(a, 0, device, result)
                 dominant = FASTNSF_DOMINANT
             step()                                                  # priming pass (workspace growth, one-off autotune)
+            if nsf is not None:
+                step()                                              # (the second engine)
             for _ in range(warm):
                 step()
+            if nsf is not None:
+                nsf.sync_check()
             torch.cuda.synchronize()
-            _lib.prof_start(only=dominant)
+            if nsf is None:
+                _lib.prof_start(only=dominant)
             t0 = time.perf_counter()
             for _ in range(steps):
                 step()
+            if nsf is not None:
+                nsf.sync_check()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
+            el_single = None
+            if nsf is not None:                                     # the roofline kernel's launches un-overlapped: two fits on one engine
+                _lib.prof_start(only=dominant)
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    step_single()
+                torch.cuda.synchronize()
+                el_single = (time.perf_counter() - t1) / 2
             prof = _lib.prof_stop()
             if name == "train":
                 roof, workload, dtype = train_roofline(a, prof, steps, el)
                 parity = {"loss_after_leg": float(result["loss"].item()),
                           "note": "gradient parity vs CPU autograd through the oracle network (unpinned): tests/test_train_gpu.py"}
             else:
-                roof, workload, dtype = fastnsf_roofline(a, prof, steps, el)
+                roof, workload, dtype = fastnsf_roofline(a, prof, steps if el_single is None else 2, el if el_single is None else 2 * el_single)
+                if el_single is not None:
+                    roof["measured_in"] = "two fits on ONE engine right after the timed fits (un-overlapped launches)"
                 got = result["flow"].cpu().numpy()
                 parity = {"loss_first_to_last_iteration": [obj.loss_history[0][1], obj.loss_history[-1][1]],
                           "flow_mean_epe_vs_generating_flow": float(np.linalg.norm(got - fr[0]["flow"], axis=1).mean()),
                           "note": "gradient / trajectory parity vs the CPU restatement (oracle/fastnsf_oracle.py, unpinned): tests/test_fastnsf_gpu.py"}
             leg = {"frames_per_s": steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warm,
                    "points_per_frame": a.points, "workload": workload, "dtype": dtype, "roofline": roof, "parity": parity}
+            if name == "fastnsf" and el_single is not None:
+                leg["fits_in_flight"] = 2
+                leg["frames_per_s_one_fit_at_a_time"] = 1.0 / el_single
         except Exception as e:                                      # a leg must never cost the main line
             leg = {"error": f"{type(e).__name__}: {e}"}
         out[f"leg_{name}"] = leg

@@ -141,6 +141,7 @@ class FastNSF:
         self.early_patience, self.early_min_delta = early_patience, early_min_delta
         self.loss_history = []
         self._descs = {}
+        self._defer_finish, self._finish = False, None
 
     # ---- parameters: stored padded to multiples of 4 channels (3 -> 4) -----------------------------------------------
     def _load(self, layers):
@@ -409,11 +410,34 @@ class FastNSF:
         _lib.check(lib.himo_rows_add(n, 3, self.X0.data_ptr(), 4, self.OUT.data_ptr(), 4, 1.0, moved.data_ptr(), 3, 0, s()), "rows_add")
         _lib.check(lib.himo_rows_add(n, 3, moved.data_ptr(), 3, p0_raw.data_ptr(), 3, -1.0, flow.data_ptr(), 3, 0, s()), "rows_add")
         self._moved = moved
-        if self.early_patience <= 0 and done:                   # the loss trajectory, read once the whole fit is queued: no bubble inside it
-            hist = loss_hist[:done].cpu().numpy()
-            self.loss_history = [(it, float(hist[it - 1])) for it in range(1, done + 1) if it <= 3 or it == done]
-        self.points_in_volume = max(int(count.item()), 1)
+
+        def finish():
+            # the loss trajectory and the count, read once the whole fit is queued: no bubble inside it (fit_async: not even here)
+            if self.early_patience <= 0 and done:
+                hist = loss_hist[:done].cpu().numpy()
+                self.loss_history = [(it, float(hist[it - 1])) for it in range(1, done + 1) if it <= 3 or it == done]
+            self.points_in_volume = max(int(count.item()), 1)
+        self._finish = finish
+        if not self._defer_finish:
+            self.wait()
         return flow
+
+    def fit_async(self, pc0, pc1, pose0=None, pose1=None, layers=None) -> torch.Tensor:
+        """``fit`` without its closing host reads: every launch of the fit is queued on the current stream and the flow tensor is
+        returned at once (valid in stream order); ``wait()`` reads the loss trajectory and the point count.  Two engines on two
+        streams keep two fits in flight this way (``OverlappedFastNSF``).  Early stopping reads the loss every iteration and
+        therefore runs synchronously."""
+        self._defer_finish = True
+        try:
+            return self.fit(pc0, pc1, pose0, pose1, layers)
+        finally:
+            self._defer_finish = False
+
+    def wait(self):
+        """completes a ``fit_async``: ``loss_history`` and ``points_in_volume`` are valid afterwards (blocks on the fit's stream)"""
+        f, self._finish = self._finish, None
+        if f is not None:
+            f()
 
     @property
     def _gmoved(self):
@@ -431,3 +455,63 @@ class FastNSF:
         """Current parameters as [(W [in,out], b [out])] numpy with the padding removed."""
         dims = [3] + [HIDDEN] * N_HIDDEN + [3]
         return [(w.cpu().numpy()[:ci, :co].copy(), b.cpu().numpy()[:co].copy()) for w, b, ci, co in zip(self.W, self.b, dims[:-1], dims[1:])]
+
+
+class OverlappedFastNSF:
+    """Two FastNSF engines on two HIP streams: the fit of sweep pair k + 1 is queued while the fit of pair k runs, so one fit's
+    kernel boundaries and partial last waves (the forward kernel's 1875 blocks are 2.4 rounds of the chip, the iteration is a
+    strict chain forward -> backward -> update) are filled by the other's kernels.  Fits of different pairs are independent
+    (the model is per scene pair: README.md:53 ``model=fastnsf``); each is the same launch sequence as ``FastNSF.fit`` -- same bits.
+
+        nsf = OverlappedFastNSF(device=dev, iters=100)
+        for flow in nsf.fits(pairs):          # pairs: iterable of (pc0, pc1, pose0, pose1); flows come back in order
+            ...
+    """
+
+    def __init__(self, device=None, engines: int = 2, **kw):
+        self.device = device if device is not None else _lib.require_gpu()
+        self.engines = [FastNSF(device=self.device, **kw) for _ in range(engines)]
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(engines)]
+        self._turn = 0
+        self._busy = [False] * engines
+
+    def submit(self, pc0, pc1, pose0=None, pose1=None):
+        """queue one fit on the next engine (after completing that engine's previous fit); -> (engine index, flow tensor).  The
+        flow is valid once ``collect(index)`` has returned (or in the engine's stream order)."""
+        k = self._turn % len(self.engines)
+        self._turn += 1
+        self.collect(k)
+        st, caller = self.streams[k], torch.cuda.current_stream(self.device)
+        st.wait_stream(caller)                                   # the inputs were produced on the caller's stream
+        with torch.cuda.stream(st):
+            flow = self.engines[k].fit_async(pc0, pc1, pose0, pose1)
+        flow.record_stream(caller)          # ... and the flow is consumed there: its memory must not go back to the engine's stream early
+        self._busy[k] = True
+        return k, flow
+
+    def collect(self, k: int):
+        """wait for engine k's fit in flight (no-op when it has none): its ``loss_history`` / ``points_in_volume`` are valid after"""
+        if self._busy[k]:
+            with torch.cuda.stream(self.streams[k]):
+                self.engines[k].wait()
+            self.streams[k].synchronize()
+            self._busy[k] = False
+
+    def drain(self):
+        for k in range(len(self.engines)):
+            self.collect(k)
+
+    sync_check = drain                       # (the name OverlappedPipeline gives the same thing)
+
+    def fits(self, pairs):
+        pending = []
+        for pair in pairs:
+            pending.append(self.submit(*pair))
+            if len(pending) == len(self.engines):
+                k, flow = pending.pop(0)
+                self.collect(k)
+                yield flow
+        for k, flow in pending:
+            self.collect(k)
+            yield flow
+

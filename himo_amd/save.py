@@ -231,13 +231,55 @@ def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, si
     return results if sink is None else done
 
 
-def main(checkpoint: str = "", dataset_path: str = "", res_name: str = ""):
-    """``python -m himo_amd.save --checkpoint <weights.npz> --dataset_path <dir>``; under ``torchrun`` one rank per GPU."""
+def run_fastnsf(dataset, res_name: str = "fastnsf", sink=None, by_scene: bool = False, iters: int = 100, **fit_options):
+    """``python save.py model=fastnsf dataset_path=...`` (README.md:53): the optimisation-based baseline instead of the network --
+    one coordinate MLP fitted per sweep pair (``himo_amd/fastnsf.py``; PARITY UNPINNED like the network), the flow of every pc0 row
+    including ego motion stored under ``res_name`` exactly like the network's.  Two fits in flight on two HIP streams
+    (``fastnsf.OverlappedFastNSF``); results leave through the same pinned-buffer writer thread as ``run``'s."""
+    import torch.distributed as dist
+    from .fastnsf import OverlappedFastNSF
+    from .feeder import ResultDrain
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    nsf = OverlappedFastNSF(iters=iters, **fit_options)
+    results = {} if sink is None else None
+
+    def deliver(key, flow):
+        i, f0 = key
+        if sink is None:
+            results[i] = flow
+        else:
+            sink(i, f0, flow)
+
+    drain = ResultDrain(deliver, device=nsf.device)
+    keys, done = [], 0
+
+    def pairs():
+        for i, _, f0, f1 in frame_source(dataset, rank, world, by_scene=by_scene):
+            pc1 = f0["pc1"] if "pc1" in f0 else f1["pc0"]
+            keys.append((i, f0))
+            yield np.asarray(f0["pc0"])[:, :3], np.asarray(pc1)[:, :3], f0["pose0"], f0["pose1"]
+    try:
+        for flow in nsf.fits(pairs()):
+            drain.put(keys.pop(0), flow)
+            done += 1
+    finally:
+        drain.close()
+        if hasattr(sink, "close"):
+            sink.close()
+    return results if sink is None else done
+
+
+def main(checkpoint: str = "", dataset_path: str = "", res_name: str = "", model: str = "", iters: int = 100):
+    """``python -m himo_amd.save --checkpoint <weights.npz> --dataset_path <dir>`` (the feed-forward network), or
+    ``--model fastnsf --dataset_path <dir>`` (the optimisation-based baseline, README.md:50-53); under ``torchrun`` one rank per GPU."""
     from . import distenv
     from .dataset import NpzDataset, open_dataset
-    name = res_name or (Path(checkpoint).stem if checkpoint else "seflowpp_best")
+    if model not in ("", "seflowpp", "deflowpp", "fastnsf"):
+        raise ValueError(f"model={model!r}: this build runs the SeFlow++-style network (default) and 'fastnsf'")
+    fastnsf = model == "fastnsf"
+    name = res_name or ("fastnsf" if fastnsf else (Path(checkpoint).stem if checkpoint else "seflowpp_best"))
     params = None
-    if checkpoint:
+    if checkpoint and not fastnsf:
         from .seflow.checkpoint import load_params
         params = load_params(checkpoint)
     root = Path(dataset_path)
@@ -247,7 +289,8 @@ def main(checkpoint: str = "", dataset_path: str = "", res_name: str = ""):
         sink = NpzResultSink(root, name) if npz else H5ResultSink(root, name)
         done, err = 0, None
         try:
-            done = run(ds, name, params, sink=sink, by_scene=not npz)
+            done = (run_fastnsf(ds, name, sink=sink, by_scene=not npz, iters=iters) if fastnsf else
+                    run(ds, name, params, sink=sink, by_scene=not npz))
         except Exception as e:                                  # arrive at the rendezvous anyway, then re-raise
             err = e
         distenv.rendezvous(err, "writing its share of the flow results")
@@ -260,5 +303,7 @@ if __name__ == "__main__":
     ap.add_argument("--checkpoint", default="")
     ap.add_argument("--dataset_path", required=True)
     ap.add_argument("--res_name", default="")
+    ap.add_argument("--model", default="", help="'fastnsf': fit the optimisation-based baseline per sweep pair instead of running the network")
+    ap.add_argument("--iters", type=int, default=100, help="optimiser iterations per sweep pair (--model fastnsf)")
     a = ap.parse_args()
-    main(a.checkpoint, a.dataset_path, a.res_name)
+    main(a.checkpoint, a.dataset_path, a.res_name, a.model, a.iters)

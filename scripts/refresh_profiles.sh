@@ -32,7 +32,7 @@ python $R/scripts/exp_upsample.py > $OUT/${RN}_upsample.txt 2>&1
 for wl in pipeline compdis train fastnsf; do
   ARGS="--workload $wl --no-cpu-baseline --no-extra-precisions"
   [ $wl = train ] && ARGS="$ARGS --steps 5 --warmup 2 --no-extra-workloads"
-  [ $wl = fastnsf ] && ARGS="$ARGS --steps 2 --warmup 1 --no-extra-workloads"
+  [ $wl = fastnsf ] && ARGS="$ARGS --steps 2 --warmup 1 --no-extra-workloads --single-stream"   # one fit at a time: a launch's duration is its own
   [ $wl = pipeline ] && ARGS="$ARGS --no-extra-workloads --single-stream --no-hostfed-leg"   # one batch in flight: a launch's duration is its own
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$wl -o $wl -- python $R/bench.py $ARGS > $OUT/${RN}_bench_${wl}_n1_under_rocprof.json 2> $OUT/prof_$wl.err
   f=$(find $OUT/prof_$wl -name "*kernel_stats.csv" | head -1)

@@ -252,3 +252,62 @@ def test_three_launch_iteration_equals_the_layer_kernels(gpu, n0, n1):
     assert np.abs(fa.cpu().numpy() - fb.cpu().numpy()).max() < 5e-2
     again = FastNSF(device=gpu, iters=10, lr=1e-3, objective="dt", dt_box=DT_BOX, early_patience=10_000).fit(pc0, pc1, layers=layers)
     assert torch.equal(again, fa)
+
+
+def test_two_fits_in_flight_return_the_single_engine_bits(gpu):
+    """fastnsf.OverlappedFastNSF: two engines on two HIP streams, the fit of pair k + 1 queued while pair k's runs (the product's and
+    bench.py's default way through a stream of sweep pairs).  Each fit is the launch sequence of FastNSF.fit: the flows, the loss
+    trajectories and the point counts are the single engine's, in order, for ragged pair sizes and an odd number of pairs."""
+    from himo_amd.fastnsf import FastNSF, OverlappedFastNSF
+    from himo_amd.synthetic import make_frame
+    pairs = []
+    for i in range(5):
+        f = make_frame(830 + i, n_points=30_000 - 1777 * i)
+        p0 = torch.from_numpy(f["pc0"][:, :3].copy()).to(gpu)
+        p1 = torch.from_numpy((f["pc0"][:, :3] + f["flow"]).astype(np.float32)).to(gpu)
+        pairs.append((p0, p1, f["pose0"], f["pose1"]))
+    one = FastNSF(device=gpu, iters=12, seed=3)
+    ref = []
+    for p in pairs:
+        flow = one.fit(*p)
+        ref.append((flow.clone(), list(one.loss_history), one.points_in_volume))
+    two = OverlappedFastNSF(device=gpu, engines=2, iters=12, seed=3)
+    got = []
+    for k, flow in enumerate(two.fits(iter(pairs))):
+        eng = two.engines[k % 2]
+        got.append((flow.clone(), list(eng.loss_history), eng.points_in_volume))
+    assert len(got) == len(ref)
+    for (fa, la, ca), (fb, lb, cb) in zip(ref, got):
+        assert torch.equal(fa, fb) and la == lb and ca == cb
+    # submit / collect by hand, and a drained object can be reused
+    k, flow = two.submit(*pairs[0])
+    two.drain()
+    assert torch.equal(flow, ref[0][0]) and two.engines[k].loss_history == ref[0][1]
+
+
+def test_save_program_runs_the_fastnsf_baseline_over_a_dataset(gpu, tmp_path):
+    """``python save.py model=fastnsf dataset_path=...`` (README.md:50-53) as ``himo_amd.save.main(model="fastnsf")``: every sweep with a
+    successor gets a flow under ``fastnsf`` in the dataset, row-aligned with pc0, and it is the flow FastNSF.fit returns for that pair."""
+    from himo_amd import save
+    from himo_amd.dataset import NpzDataset
+    from himo_amd.fastnsf import FastNSF
+    from himo_amd.synthetic import make_frame
+    frames = [make_frame(860 + i, n_points=9_000 - 500 * i, scene_id="s0" if i < 3 else "s1") for i in range(5)]
+    NpzDataset.write(tmp_path, frames)
+    done = save.main(dataset_path=str(tmp_path), model="fastnsf", iters=8)
+    assert done == 3                                          # two scenes of 3 and 2 sweeps: the last sweep of each has no successor
+    ds = NpzDataset(tmp_path, vis_name="fastnsf")
+    one = FastNSF(device=gpu, iters=8)
+    seen = 0
+    for i in range(len(ds)):
+        f = ds[i]
+        if "fastnsf" not in f:
+            continue
+        seen += 1
+        assert f["fastnsf"].shape == (len(f["pc0"]), 3) and f["fastnsf"].dtype == np.float32
+        nxt = ds[i + 1]
+        want = one.fit(f["pc0"][:, :3], nxt["pc0"][:, :3], f["pose0"], f["pose1"]).cpu().numpy()
+        assert np.array_equal(f["fastnsf"], want)
+    assert seen == 3
+    with pytest.raises(ValueError):
+        save.main(dataset_path=str(tmp_path), model="nsfp")
