@@ -889,7 +889,7 @@ def extra_workload_legs(args, device) -> dict:
         try:
             if name == "train":
                 step, obj = make_train_step(a, 0, device, result)
-                dominant = TRAIN_DOMINANT
+                dominant, nsf, step_single = TRAIN_DOMINANT, None, None
             else:
                 step, obj, fr, nsf, step_single = make_fastnsf_step(a, 0, device, result)
                 dominant = FASTNSF_DOMINANT
