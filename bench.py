@@ -79,6 +79,7 @@ def parse_args():
     ap.add_argument("--cloud", default="uniform", choices=["uniform", "rings"],
                     help="synthetic sweeps: SURVEY 8(d) uniform cloud with instances (default) or the LiDAR-like ring cloud")
     ap.add_argument("--sample-sets", type=int, default=3, help="distinct input batches rotated through the timed steps")
+    ap.add_argument("--batches-in-flight", type=int, default=3, help="pipeline workload: networks / HIP streams fed in turn (default 3, the product's default)")
     ap.add_argument("--single-stream", action="store_true",
                     help="pipeline: one batch in flight in the timed region (default: two, pipeline.OverlappedPipeline; the roofline "
                          "kernel is then timed in a second, single-stream region of the same K steps)")
@@ -484,11 +485,12 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
         sets, host_frames = synthetic_sample_sets(max(1, args.sample_sets), B, P, device, seed=rank, cloud=args.cloud)
         overlapped = None
         if not args.single_stream:
-            # the product's default way to run a stream of batches: two in flight on two HIP streams (two networks' buffers)
+            # the product's default way to run a stream of batches: several in flight, each on its own HIP stream with its own network buffers
             from himo_amd.pipeline import OverlappedPipeline
-            net_b = SeFlowNet(params, device=device, max_points=P, precision=args.precision, max_batch=B)
-            net_b.split_acts = net.split_acts
-            overlapped = OverlappedPipeline(nets=[net, net_b], device=device)
+            more = [SeFlowNet(params, device=device, max_points=P, precision=args.precision, max_batch=B) for _ in range(max(2, args.batches_in_flight) - 1)]
+            for nb in more:
+                nb.split_acts = net.split_acts
+            overlapped = OverlappedPipeline(nets=[net] + more, device=device)
             pipe = overlapped.pipes[0]                          # (the single-stream region below runs this very pipeline)
 
         def step_single():
@@ -505,7 +507,8 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
 
     step()                                      # priming pass on every rank (one-off tile autotune, operator-list recording,
     if overlapped is not None:                  # workspace growth): never inside the timed region, whatever --warmup is
-        step()                                  # (the second network of the two-in-flight pipeline)
+        for _ in range(len(getattr(overlapped, "pipes", getattr(overlapped, "engines", [0, 0]))) - 1):
+            step()                              # (the other network(s) of the batches-in-flight pipeline / the other FastNSF engine)
     sync()
     for _ in range(args.warmup):
         step()
@@ -568,7 +571,8 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
         # launch thread is timed (spinning OpenMP workers otherwise cost ~5 % of the frame rate)
         torch.set_num_threads(1)
         time.sleep(1.0)
-    if _lib is not None and overlapped is None:
+    train_overlap = args.workload == "train" and not dry and trainer.overlap_wgrad
+    if _lib is not None and overlapped is None and not train_overlap:
         _lib.prof_start(only=dominant)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -596,6 +600,19 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
             pipe.sync_check()
         sync()
         single = time.perf_counter() - t1
+    elif train_overlap:
+        # the training step's roofline kernel alone: the SAME K steps with the weight gradients back on the main stream
+        trainer.set_side_streams(False)
+        for _ in range(2):
+            step()
+        sync()
+        _lib.prof_start(only=dominant)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        single = time.perf_counter() - t1
+        trainer.set_side_streams(True)
     gc.enable()
     torch.set_num_threads(n_threads)
     prof = _lib.prof_stop() if _lib is not None else {}
@@ -647,13 +664,17 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
                                           "note": "FastNSF.fit, one fit at a time: the configuration of the earlier rounds' figures; the "
                                                   "roofline kernel's launches are timed here"}
     elif args.workload == "train":
-        roofline, workload, dtype = train_roofline(args, prof, B * args.steps, elapsed)
+        roofline, workload, dtype = train_roofline(args, prof, B * args.steps, single if single is not None else elapsed)
+        if single is not None:
+            roofline["measured_in"] = ("a second region of the same K steps with every weight gradient on the main stream (un-overlapped "
+                                       "launches), right after the timed region; `value` is the rate with the two side streams")
+            extra["value_single_stream"] = B * args.steps / single
     else:
         roofline, dtype = conv_roofline(args.precision, prof, B, args.steps, single if single is not None else elapsed, traffic,
                                         folded=pipe.net.fold_decoder)
         if single is not None:
             roofline["measured_in"] = ("a second region of the same K steps with ONE batch in flight (un-overlapped launches), right after the "
-                                       "timed region; `value` is the two-in-flight rate")
+                                       f"timed region; `value` is the rate with {len(overlapped.pipes)} batches in flight")
             extra["value_single_stream"] = B * args.steps / single
             extra["leg_single_stream"] = {"frames_per_s": B * args.steps / single, "ms_per_step": single / args.steps * 1e3, "steps": args.steps,
                                           "note": "HiMoPipeline, one batch in flight: the round-3 headline configuration; the roofline "
@@ -710,7 +731,7 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     }
     line.update(extra)
     if args.workload == "pipeline":
-        line["config"]["batches_in_flight"] = 1 if overlapped is None else 2
+        line["config"]["batches_in_flight"] = 1 if overlapped is None else len(overlapped.pipes)
         line["config"]["matrix_arithmetic"] = args.precision
         line["config"]["samples_per_backbone_launch"] = B
         line["config"]["input"] = (f"himo_amd.synthetic.make_frame sweeps (SURVEY 8(d) seeded frames, cloud={args.cloud}); "
@@ -901,7 +922,8 @@ def extra_workload_legs(args, device) -> dict:
             if nsf is not None:
                 nsf.sync_check()
             torch.cuda.synchronize()
-            if nsf is None:
+            side = name == "train" and obj.overlap_wgrad
+            if nsf is None and not side:
                 _lib.prof_start(only=dominant)
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -911,6 +933,17 @@ def extra_workload_legs(args, device) -> dict:
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
             el_single = None
+            if side:                                                # the roofline kernel's launches un-overlapped: weight gradients on the main stream
+                obj.set_side_streams(False)
+                step()
+                torch.cuda.synchronize()
+                _lib.prof_start(only=dominant)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                el_train_single = (time.perf_counter() - t1) / 3
+                obj.set_side_streams(True)
             if nsf is not None:                                     # the roofline kernel's launches un-overlapped: two fits on one engine
                 _lib.prof_start(only=dominant)
                 t1 = time.perf_counter()
@@ -920,7 +953,9 @@ def extra_workload_legs(args, device) -> dict:
                 el_single = (time.perf_counter() - t1) / 2
             prof = _lib.prof_stop()
             if name == "train":
-                roof, workload, dtype = train_roofline(a, prof, steps, el)
+                roof, workload, dtype = train_roofline(a, prof, 3 if side else steps, 3 * el_train_single if side else el)
+                if side:
+                    roof["measured_in"] = "three steps with every weight gradient on the main stream, right after the timed steps (un-overlapped launches)"
                 parity = {"loss_after_leg": float(result["loss"].item()),
                           "note": "gradient parity vs CPU autograd through the oracle network (unpinned): tests/test_train_gpu.py"}
             else:
@@ -933,6 +968,8 @@ def extra_workload_legs(args, device) -> dict:
                           "note": "gradient / trajectory parity vs the CPU restatement (oracle/fastnsf_oracle.py, unpinned): tests/test_fastnsf_gpu.py"}
             leg = {"frames_per_s": steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warm,
                    "points_per_frame": a.points, "workload": workload, "dtype": dtype, "roofline": roof, "parity": parity}
+            if name == "train" and side:
+                leg["frames_per_s_without_side_streams"] = 1.0 / el_train_single
             if name == "fastnsf" and el_single is not None:
                 leg["fits_in_flight"] = 2
                 leg["frames_per_s_one_fit_at_a_time"] = 1.0 / el_single

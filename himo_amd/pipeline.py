@@ -227,7 +227,8 @@ class HiMoPipeline:
 
 
 class OverlappedPipeline:
-    """Two batches in flight: two ``HiMoPipeline``s (own network buffers) fed alternately on two HIP streams, so that one batch's
+    """Several batches in flight (default three; two gave +4.5 %, the third +1 %): ``in_flight`` ``HiMoPipeline``s (own network
+    buffers) fed in turn on as many HIP streams, so that one batch's
     latency-bound stages (pillar stage, stride-2 / 1x1 layers, upsampling, the head's gather) run under the other's matrix-bound
     3x3 convolutions -- measured +4 % frames/s in round 3 (profiles/r03_exp_two_streams.txt) and adopted as the default way to
     run a stream of batches in round 4.  Same kernels, same launch order within a batch: results are bit-identical to the
@@ -237,11 +238,11 @@ class OverlappedPipeline:
     on a SIDE stream after ``ready`` (``feeder.ResultDrain`` does) or call ``wait(result)`` to make the current stream wait --
     which also orders every later ``run`` behind this batch, i.e. a caller that consumes each result on the launch stream before
     launching the next gets correct results and no overlap.  Result tensors of a batch stay valid until that inner pipeline's
-    next-but-one batch, i.e. for four ``run`` calls.  Inputs must be ready on the calling stream (``run`` makes the batch's
+    next-but-one batch, i.e. for 2 x ``in_flight`` ``run`` calls.  Inputs must be ready on the calling stream (``run`` makes the batch's
     stream wait for the calling stream as of the call)."""
 
     def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, max_batch: int = 8, precision: str = "auto",
-                 in_flight: int = 2, nets=None):
+                 in_flight: int = 3, nets=None):
         self.device = device if device is not None else _lib.require_gpu()
         if nets is not None:
             self.pipes = [HiMoPipeline(net, device=self.device) for net in nets]
@@ -279,19 +280,20 @@ class OverlappedPipeline:
         return result
 
     def flows_stream(self, batches):
-        """``HiMoPipeline.flows`` over an iterable of sample lists with one batch of lookahead: yields (samples, flows) in order.
-        Batch k's finite-flow check (a host read-back: a sync of ITS stream) happens while batch k + 1 is already queued on the
-        other stream, so the device does not idle through it."""
-        pending = None
+        """``HiMoPipeline.flows`` over an iterable of sample lists with ``in_flight - 1`` batches of lookahead: yields (samples,
+        flows) in order.  Batch k's finite-flow check (a host read-back: a sync of ITS stream) happens while the following batches
+        are already queued on the other streams, so the device does not idle through it."""
+        pending = []                                            # launched, not yet checked: at most one per inner pipeline
         for samples in batches:
-            pipe, st = self._next()
+            pipe, st = self._next()                             # (round robin: the batch that used this pipeline last was finished below)
             with torch.cuda.stream(st):
                 flat, outs = pipe._flows_launch(samples)
-            if pending is not None:
-                yield pending[0], self._flows_finish(*pending)
-            pending = (samples, pipe, st, flat, outs)
-        if pending is not None:
-            yield pending[0], self._flows_finish(*pending)
+            pending.append((samples, pipe, st, flat, outs))
+            if len(pending) == len(self.pipes):
+                done = pending.pop(0)
+                yield done[0], self._flows_finish(*done)
+        for done in pending:
+            yield done[0], self._flows_finish(*done)
 
     def _flows_finish(self, samples, pipe, st, flat, outs):
         with torch.cuda.stream(st):

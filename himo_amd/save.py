@@ -189,7 +189,7 @@ def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, si
     """Flow for every frame of ``dataset`` that has a ``pc1`` / next sweep.  Returns the frames this rank processed.
     Frames are read, staged in pinned memory and copied to the device by a background thread two batches ahead of the
     network (``feeder.SampleFeeder``); results leave through pinned buffers and a writer thread (``feeder.ResultDrain``),
-    so neither the dataset reads nor the sink's file writes stall the launch thread.  The network runs two batches in flight
+    so neither the dataset reads nor the sink's file writes stall the launch thread.  The network runs several batches in flight
     (``pipeline.OverlappedPipeline``; pass a ``HiMoPipeline`` as ``pipeline`` for the single-stream path); every batch is
     checked for fp16-range overflow before it is handed to the sink (auto: redone in the bf16 split)."""
     import torch.distributed as dist
@@ -210,7 +210,7 @@ def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, si
     done = 0
     try:
         feeder = SampleFeeder(frame_source(dataset, rank, world, by_scene=by_scene), device=pipe.device, batch=max(1, batch_frames))
-        if isinstance(pipe, OverlappedPipeline):               # two batches in flight: batch k's finite-flow check under batch k + 1
+        if isinstance(pipe, OverlappedPipeline):               # several batches in flight: batch k's finite-flow check under the following batches
             queued = []
 
             def sample_lists():

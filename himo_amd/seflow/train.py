@@ -556,7 +556,7 @@ class SeFlowTrainer:
         self.ws = torch.empty(ws + 64, dtype=torch.uint8, device=dev)
         # the encoder's weight gradients run on a SIDE stream under the data-gradient chain (backward): own workspace, and the
         # pre-activation gradient they read alternates between two buffers so the chain never waits for them
-        self.overlap_wgrad = os.environ.get("HIMO_TRAIN_SIDE_STREAM", "1") != "0"
+        self.overlap_wgrad = self._side_streams_built = os.environ.get("HIMO_TRAIN_SIDE_STREAM", "1") != "0"
         # 3x3 convolutions of the forward and data-gradient passes: the fastest of the library's tile variants per layer shape,
         # timed once at the shape's first launch (the variants return identical bits: tests/test_train_gpu.py)
         self.tune_tiles = os.environ.get("HIMO_TRAIN_TUNE_TILES", "1") != "0"
@@ -704,6 +704,14 @@ class SeFlowTrainer:
                 return
         self._wgrad3(x, x_pitch, h, w, cin, dy, dy_pitch, cout, 1, wname, False, ws=ws)
         self._colsum(h * w, dy, dy_pitch, cout, bname, ws=ws)
+
+    def set_side_streams(self, on: bool):
+        """switch the weight-gradient overlap (both side streams) off / back on at run time: the same kernels in the same order per
+        stream either way, so the same bits -- bench.py times the step's dominant kernel with it off (a launch's HIP-event time
+        otherwise includes whatever the other streams co-run)"""
+        self.overlap_wgrad = bool(on) and self._side_streams_built
+        self.overlap_decoder = self.overlap_wgrad and self.ws_side2 is not None
+        self.head.wgrad_stream = self.side2 if self.overlap_decoder else None
 
     def _beside(self, fn):
         """a decoder weight gradient: it only READS its operands, so it runs on the second side stream from the point the main stream

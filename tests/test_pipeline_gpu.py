@@ -456,7 +456,8 @@ def test_cli_programs_as_two_ranks_on_this_box(gpu, tmp_path):
     assert list((tmp_path / "ckpt").glob("*.npz"))
 
 
-def test_two_batches_in_flight_deliver_the_single_stream_bits(gpu):
+@pytest.mark.parametrize("in_flight", [2, 3])
+def test_two_batches_in_flight_deliver_the_single_stream_bits(gpu, in_flight):
     """pipeline.OverlappedPipeline (two networks' buffers, two HIP streams, batches alternate) against HiMoPipeline on the same
     stream of ragged batches: flow and comp_dis of every batch bit-identical, whatever co-runs; and ``flows_stream`` (the
     ``save`` program's path, finite-flow check of batch k under batch k + 1) against ``HiMoPipeline.flows``."""
@@ -473,7 +474,7 @@ def test_two_batches_in_flight_deliver_the_single_stream_bits(gpu):
         r = single.run(b, copy=True)
         want.append((r["flow"].clone(), r["comp_dis"].clone()))
     single.sync_check()
-    two = OverlappedPipeline(params=params, device=gpu, max_points=10_000, max_batch=3, precision="f16x2")
+    two = OverlappedPipeline(params=params, device=gpu, max_points=10_000, max_batch=3, precision="f16x2", in_flight=in_flight)
     side = torch.cuda.Stream(device=gpu)
     got = []
     for b in batches:                                             # results consumed on a side stream, as feeder.ResultDrain does
