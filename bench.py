@@ -80,6 +80,7 @@ def parse_args():
                     help="synthetic sweeps: SURVEY 8(d) uniform cloud with instances (default) or the LiDAR-like ring cloud")
     ap.add_argument("--sample-sets", type=int, default=3, help="distinct input batches rotated through the timed steps")
     ap.add_argument("--batches-in-flight", type=int, default=3, help="pipeline workload: networks / HIP streams fed in turn (default 3, the product's default)")
+    ap.add_argument("--fits-in-flight", type=int, default=2, help="fastnsf workload: engines / HIP streams fed in turn (default 2)")
     ap.add_argument("--single-stream", action="store_true",
                     help="pipeline: one batch in flight in the timed region (default: two, pipeline.OverlappedPipeline; the roofline "
                          "kernel is then timed in a second, single-stream region of the same K steps)")
@@ -406,7 +407,7 @@ def make_fastnsf_step(args, rank: int, device, result: dict):
     p1 = torch.from_numpy((fr[0]["pc0"][:, :3] + fr[0]["flow"]).astype(np.float32)).to(device)     # the sweep one step later
     # the product's way to run a stream of sweep pairs: two fits in flight on two HIP streams (fastnsf.OverlappedFastNSF; fits of
     # different pairs are independent); --single-stream keeps one engine
-    nsf = None if args.single_stream else OverlappedFastNSF(device=device, engines=2, iters=args.fastnsf_iters)
+    nsf = None if args.single_stream else OverlappedFastNSF(device=device, engines=max(2, args.fits_in_flight), iters=args.fastnsf_iters)
     fitter = FastNSF(device=device, iters=args.fastnsf_iters) if nsf is None else nsf.engines[0]
 
     def step_single():
@@ -740,7 +741,7 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
     if args.workload == "fastnsf":
         line["metric"] = "fastnsf_frames_per_sec_120k"
         line["config"]["iterations_per_frame"] = args.fastnsf_iters
-        line["config"]["fits_in_flight"] = 1 if overlapped is None else 2
+        line["config"]["fits_in_flight"] = 1 if overlapped is None else len(overlapped.engines)
     if args.workload == "train":
         line["metric"] = "train_frames_per_sec_120k"
         line["config"]["parallelism"] = f"data parallel x{world}, one flat all-reduce per step"
@@ -915,8 +916,8 @@ def extra_workload_legs(args, device) -> dict:
                 step, obj, fr, nsf, step_single = make_fastnsf_step(a, 0, device, result)
                 dominant = FASTNSF_DOMINANT
             step()                                                  # priming pass (workspace growth, one-off autotune)
-            if nsf is not None:
-                step()                                              # (the second engine)
+            for _ in range(len(nsf.engines) - 1 if nsf is not None else 0):
+                step()                                              # (the other engine(s))
             for _ in range(warm):
                 step()
             if nsf is not None:
@@ -971,7 +972,7 @@ def extra_workload_legs(args, device) -> dict:
             if name == "train" and side:
                 leg["frames_per_s_without_side_streams"] = 1.0 / el_train_single
             if name == "fastnsf" and el_single is not None:
-                leg["fits_in_flight"] = 2
+                leg["fits_in_flight"] = len(nsf.engines)
                 leg["frames_per_s_one_fit_at_a_time"] = 1.0 / el_single
         except Exception as e:                                      # a leg must never cost the main line
             leg = {"error": f"{type(e).__name__}: {e}"}
