@@ -305,5 +305,9 @@ if __name__ == "__main__":
     ap.add_argument("--res_name", default="")
     ap.add_argument("--model", default="", help="'fastnsf': fit the optimisation-based baseline per sweep pair instead of running the network")
     ap.add_argument("--iters", type=int, default=100, help="optimiser iterations per sweep pair (--model fastnsf)")
-    a = ap.parse_args()
+    import sys
+    # the reference's program takes hydra-style overrides (`save.py checkpoint=... dataset_path=...`, `model=fastnsf`: README.md:46-53)
+    argv = [("--" + x) if (not x.startswith("-") and "=" in x and x.split("=", 1)[0] in ("checkpoint", "dataset_path", "res_name", "model", "iters"))
+            else x for x in sys.argv[1:]]
+    a = ap.parse_args(argv)
     main(a.checkpoint, a.dataset_path, a.res_name, a.model, a.iters)

@@ -96,3 +96,16 @@ def test_bench_cli_contract(monkeypatch):
         assert (a.steps, a.warmup, a.frames_per_step) == (steps, warmup, frames), argv
         assert a.points == 120_000 and a.precision == "f16x2"
     assert a.gpus == 8
+
+
+def test_save_program_takes_the_reference_style_overrides():
+    """`python save.py model=fastnsf dataset_path=...` / `checkpoint=... dataset_path=...` (README.md:46-53, hydra overrides) and the
+    --flag form reach the same ``save.main``; an optimisation-based model this build does not have is refused by name before any
+    device work."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    for argv in (["model=nsfp", "dataset_path=/nonexistent"], ["--model", "nsfp", "--dataset_path", "/nonexistent"]):
+        r = subprocess.run([sys.executable, "-m", "himo_amd.save", *argv], capture_output=True, text=True, cwd=root)
+        assert r.returncode != 0 and "model='nsfp'" in r.stderr and "fastnsf" in r.stderr, r.stderr[-400:]
