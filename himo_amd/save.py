@@ -209,7 +209,8 @@ def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, si
     drain = ResultDrain(deliver, device=pipe.device)
     done = 0
     try:
-        feeder = SampleFeeder(frame_source(dataset, rank, world, by_scene=by_scene), device=pipe.device, batch=max(1, batch_frames))
+        feeder = SampleFeeder(frame_source(dataset, rank, world, by_scene=by_scene), device=pipe.device, batch=max(1, batch_frames),
+                              depth=max(2, len(getattr(pipe, "pipes", [0, 0]))))       # as many batches ahead as the pipeline keeps in flight
         if isinstance(pipe, OverlappedPipeline):               # several batches in flight: batch k's finite-flow check under the following batches
             queued = []
 
