@@ -282,10 +282,29 @@ extern "C" size_t himo_ssl_loss_workspace_bytes(int n0, int n1, int n_labels, in
     return loss_layout(n0, n1, n_labels, grid_w, grid_h).end + 64;
 }
 
+// himo_ssl_loss with the RAW correspondences pc0 -> pc1 given: d_raw_dist2 [n0] / d_raw_idx [n0] = himo_nn_grid(n0, pc0, n1, pc1) on the
+// same grid.  They depend on the inputs only, not on the flow, so a training step computes them beside its forward pass
+// (himo_amd/seflow/train.py) instead of on the critical path between forward and backward.  Both NULL: computed here.
+extern "C" int himo_ssl_loss_ex(int n0, int n1, const float* d_pc0, const float* d_pc1, const float* d_flow,
+                                const int32_t* d_label0, const int32_t* d_label1, int n_labels,
+                                float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
+                                const float* d_raw_dist2, const int32_t* d_raw_idx,
+                                double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int himo_ssl_loss(int n0, int n1, const float* d_pc0, const float* d_pc1, const float* d_flow,
                              const int32_t* d_label0, const int32_t* d_label1, int n_labels,
                              float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
                              double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream) {
+    return himo_ssl_loss_ex(n0, n1, d_pc0, d_pc1, d_flow, d_label0, d_label1, n_labels, grid_x0, grid_y0, grid_cell, grid_w, grid_h,
+                            nullptr, nullptr, d_loss, d_grad_flow, d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int himo_ssl_loss_ex(int n0, int n1, const float* d_pc0, const float* d_pc1, const float* d_flow,
+                                const int32_t* d_label0, const int32_t* d_label1, int n_labels,
+                                float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
+                                const float* d_raw_dist2, const int32_t* d_raw_idx,
+                                double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if ((d_raw_dist2 == nullptr) != (d_raw_idx == nullptr)) return HIMO_ERR_INVALID_ARGUMENT;
     if (n0 < 0 || n1 < 0 || n_labels < 1 || grid_w < 1 || grid_h < 1) return HIMO_ERR_INVALID_ARGUMENT;
     if (!d_loss || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
     if (n0 > 0 && (!d_pc0 || !d_flow || !d_label0 || !d_grad_flow)) return HIMO_ERR_INVALID_ARGUMENT;
@@ -323,7 +342,8 @@ extern "C" int himo_ssl_loss(int n0, int n1, const float* d_pc0, const float* d_
     if (n0 > 0 && n1 > 0) {
         NNG(n0, a.moved, n1, d_pc1, a.d_a, a.i_a);
         NNG(n1, d_pc1, n0, a.moved, a.d_b, a.i_b);
-        NNG(n0, d_pc0, n1, d_pc1, a.d_r, a.i_r);
+        if (d_raw_idx) { a.d_r = const_cast<float*>(d_raw_dist2); a.i_r = const_cast<int*>(reinterpret_cast<const int*>(d_raw_idx)); }
+        else { NNG(n0, d_pc0, n1, d_pc1, a.d_r, a.i_r); }
     }
     // dynamic subsets
     if (n0 > 0) {

@@ -756,7 +756,7 @@ class SeFlowTrainer:
                                              net.p[f"{out}.scale"].data_ptr(), net.p[f"{out}.shift"].data_ptr(), _lib.stream_handle()), "bn_fold")
         self._bn_folded = True
 
-    def forward(self, pch1, pc0, pc1, pose_h1, pose0, pose1, training: bool = True) -> torch.Tensor:
+    def forward(self, pch1, pc0, pc1, pose_h1, pose0, pose1, training: bool = True, after_pillarize=None) -> torch.Tensor:
         """``training`` (only meaningful with batchnorm="batch"): True normalises with batch statistics, saves them for
         ``backward`` and moves the running statistics; False (validation) uses the running statistics."""
         net, lib, s = self.net, self.lib, _lib.stream_handle
@@ -772,6 +772,8 @@ class SeFlowTrainer:
         sweeps = (pch1, pc0, pc1)
         transforms = (inv1 @ np.asarray(pose_h1, np.float64), inv1 @ np.asarray(pose0, np.float64), np.eye(4))
         net.pillarize_all(sweeps, transforms)
+        if after_pillarize is not None:                          # the sweeps are in the common frame (net.xyz_t): input-only work may start
+            after_pillarize()
         F = net.F
         if batch:
             # the pass above left every sweep's cell lists (its images were written with stale constants): batch statistics of
@@ -1035,9 +1037,25 @@ class SeFlowTrainer:
         from ..ssl_loss import SeFlowLoss
         if not hasattr(self, "loss"):
             self.loss = SeFlowLoss(device=self.device)
-        res = self.forward(pch1, pc0, pc1, pose_h1, pose0, pose1)
+        raw, hook = None, None
+        if self.overlap_decoder:
+            # the cluster term's correspondences pc0 -> pc1 depend on the sweeps only: searched on the second side stream UNDER the
+            # forward pass instead of between forward and backward (a grid build + a 120k-point query: ~0.17 ms of the chain)
+            def hook():
+                m0, m1 = self.n_pts[1], self.n_pts[2]
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self.side2):
+                    self.side2.wait_event(ready)
+                    self._raw = self.loss.raw_neighbours(self.net.xyz_t[1][:m0], self.net.xyz_t[2][:m1])
+                    self._raw_done = torch.cuda.Event()
+                    self._raw_done.record(self.side2)
+        res = self.forward(pch1, pc0, pc1, pose_h1, pose0, pose1, after_pillarize=hook)
         n0, n1 = self.n_pts[1], self.n_pts[2]
-        terms, total, grad = self.loss(self.net.xyz_t[1][:n0], self.net.xyz_t[2][:n1], res[:, :3].contiguous(), label0, label1, n_labels)
+        if hook is not None and n0 > 0 and n1 > 0:
+            torch.cuda.current_stream(self.device).wait_event(self._raw_done)
+            raw = self._raw[:2]
+        terms, total, grad = self.loss(self.net.xyz_t[1][:n0], self.net.xyz_t[2][:n1], res[:, :3].contiguous(), label0, label1, n_labels, raw=raw)
         dres = torch.zeros((n0, 4), dtype=torch.float32, device=self.device)
         dres[:, :3] = grad
         self.backward(dres)

@@ -21,6 +21,10 @@ _lib.register({
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                      ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "himo_ssl_loss_ex": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 })
 
 # search grid: 1 m BEV cells over the network range +- a margin (points beyond it are binned into border cells)
@@ -55,7 +59,24 @@ class SeFlowLoss:
         self.device = device if device is not None else _lib.require_gpu()
         self._ws = None
 
-    def __call__(self, pc0, pc1, flow, label0, label1, n_labels: int | None = None):
+    def raw_neighbours(self, pc0, pc1):
+        """(squared distances, int32 rows) of every pc0 point's nearest pc1 point -- the correspondences of the cluster term, which do
+        not depend on the flow: a caller may compute them early (on another stream) and hand them to ``__call__`` as ``raw``.  The
+        buffers are this object's own and are overwritten by the next call."""
+        dev = self.device
+        p0, p1 = _f32(pc0, dev)[:, :3].contiguous(), _f32(pc1, dev)[:, :3].contiguous()
+        n0, n1 = p0.shape[0], p1.shape[0]
+        if getattr(self, "_raw_d2", None) is None or self._raw_d2.numel() < n0:
+            self._raw_d2 = torch.empty(max(n0, 1), dtype=torch.float32, device=dev)
+            self._raw_idx = torch.empty(max(n0, 1), dtype=torch.int32, device=dev)
+        need = int(self.lib.himo_nn_grid_workspace_bytes(n1, GRID_W, GRID_H))
+        if getattr(self, "_raw_ws", None) is None or self._raw_ws.numel() < need:
+            self._raw_ws = torch.empty(need + 64, dtype=torch.uint8, device=dev)
+        _lib.check(self.lib.himo_nn_grid(n0, _lib.ptr(p0), n1, _lib.ptr(p1), GRID_X0, GRID_Y0, GRID_CELL, GRID_W, GRID_H, _lib.ptr(self._raw_d2),
+                                         _lib.ptr(self._raw_idx), _lib.ptr(self._raw_ws), self._raw_ws.numel(), _lib.stream_handle()), "himo_nn_grid")
+        return self._raw_d2[:n0], self._raw_idx[:n0], (p0, p1)
+
+    def __call__(self, pc0, pc1, flow, label0, label1, n_labels: int | None = None, raw=None):
         dev = self.device
         p0, p1, f = _f32(pc0, dev)[:, :3].contiguous(), _f32(pc1, dev)[:, :3].contiguous(), _f32(flow, dev)
         l0 = label0.to(device=dev, dtype=torch.int32).contiguous()
@@ -70,6 +91,13 @@ class SeFlowLoss:
             self._ws = torch.empty(need + 64, dtype=torch.uint8, device=dev)
         loss = torch.zeros(5, dtype=torch.float64, device=dev)
         grad = torch.zeros((n0, 3), dtype=torch.float32, device=dev)
+        if raw is not None and n0 > 0 and n1 > 0:
+            if raw[0].shape != (n0,) or raw[1].shape != (n0,):
+                raise ValueError("raw correspondences do not match pc0")
+            _lib.check(self.lib.himo_ssl_loss_ex(n0, n1, _lib.ptr(p0), _lib.ptr(p1), _lib.ptr(f), _lib.ptr(l0), _lib.ptr(l1), n_labels,
+                                                 GRID_X0, GRID_Y0, GRID_CELL, GRID_W, GRID_H, _lib.ptr(raw[0]), _lib.ptr(raw[1]), _lib.ptr(loss),
+                                                 _lib.ptr(grad), _lib.ptr(self._ws), self._ws.numel(), _lib.stream_handle()), "himo_ssl_loss_ex")
+            return {name: loss[k] for k, name in enumerate(TERMS)}, loss[4], grad
         _lib.check(self.lib.himo_ssl_loss(n0, n1, _lib.ptr(p0), _lib.ptr(p1), _lib.ptr(f), _lib.ptr(l0), _lib.ptr(l1), n_labels,
                                           GRID_X0, GRID_Y0, GRID_CELL, GRID_W, GRID_H, _lib.ptr(loss), _lib.ptr(grad),
                                           _lib.ptr(self._ws), self._ws.numel(), _lib.stream_handle()), "himo_ssl_loss")

@@ -434,6 +434,13 @@ int himo_ssl_loss(int n0, int n1, const float* d_pc0, const float* d_pc1, const 
                   const int32_t* d_label0, const int32_t* d_label1, int n_labels,
                   float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
                   double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream);
+/* ... with the raw correspondences pc0 -> pc1 supplied: d_raw_dist2 [n0] / d_raw_idx [n0] = himo_nn_grid(n0, d_pc0, n1, d_pc1) on the same
+ * grid (they depend on the inputs only: a training step computes them beside its forward pass); both NULL = himo_ssl_loss. */
+int himo_ssl_loss_ex(int n0, int n1, const float* d_pc0, const float* d_pc1, const float* d_flow,
+                     const int32_t* d_label0, const int32_t* d_label1, int n_labels,
+                     float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
+                     const float* d_raw_dist2, const int32_t* d_raw_idx,
+                     double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a12: optimisation-based scene flow ("fastnsf", README.md:53).  Reference implementation absent (OpenSceneFlow

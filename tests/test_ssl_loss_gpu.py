@@ -88,3 +88,29 @@ def test_autograd_wrapper(gpu):
     (loss * 2).backward()
     _, total, grad = SeFlowLoss()(pc0, pc1, flow, lab0, lab1)
     assert torch.allclose(f.grad, 2 * grad, rtol=1e-5, atol=1e-7)
+
+
+def test_loss_with_the_raw_correspondences_supplied_is_the_same_loss(gpu):
+    """himo_ssl_loss_ex: the pc0 -> pc1 correspondences of the cluster term computed ahead (SeFlowLoss.raw_neighbours; the training
+    step searches them on a side stream under its forward pass) -- every term and the gradient bit-identical to the all-in-one call;
+    a half-given or mis-sized pair is refused."""
+    from himo_amd import _lib
+    from himo_amd.ssl_loss import SeFlowLoss
+    pc0, pc1, flow, lab0, lab1 = _scene(41, 20_000, 18_500)
+    t = lambda a: torch.from_numpy(a).to(gpu)
+    eng = SeFlowLoss(device=gpu)
+    terms, total, grad = eng(t(pc0), t(pc1), t(flow), t(lab0), t(lab1))
+    d2, idx, _keep = eng.raw_neighbours(t(pc0), t(pc1))
+    terms2, total2, grad2 = eng(t(pc0), t(pc1), t(flow), t(lab0), t(lab1), raw=(d2, idx))
+    assert total.item() == total2.item() and torch.equal(grad, grad2)
+    assert all(terms[k].item() == terms2[k].item() for k in terms)
+    with pytest.raises(ValueError):
+        eng(t(pc0), t(pc1), t(flow), t(lab0), t(lab1), raw=(d2[:-1], idx[:-1]))
+    lib = _lib.load()
+    ws = torch.empty(int(lib.himo_ssl_loss_workspace_bytes(10, 10, 2, 104, 104)), dtype=torch.uint8, device=gpu)
+    z = torch.zeros(64, dtype=torch.float32, device=gpu)
+    zi = torch.zeros(64, dtype=torch.int32, device=gpu)
+    loss = torch.zeros(5, dtype=torch.float64, device=gpu)
+    st = lib.himo_ssl_loss_ex(10, 10, z.data_ptr(), z.data_ptr(), z.data_ptr(), zi.data_ptr(), zi.data_ptr(), 2, -52.0, -52.0, 1.0, 104, 104,
+                              z.data_ptr(), None, loss.data_ptr(), z.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_handle())
+    assert st != 0                                            # distances without indices: invalid argument
