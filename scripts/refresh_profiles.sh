@@ -34,7 +34,8 @@ for wl in pipeline compdis train fastnsf; do
   [ $wl = train ] && ARGS="$ARGS --steps 5 --warmup 2 --no-extra-workloads"
   [ $wl = fastnsf ] && ARGS="$ARGS --steps 2 --warmup 1 --no-extra-workloads --single-stream"   # one fit at a time: a launch's duration is its own
   [ $wl = pipeline ] && ARGS="$ARGS --no-extra-workloads --single-stream --no-hostfed-leg"   # one batch in flight: a launch's duration is its own
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$wl -o $wl -- python $R/bench.py $ARGS > $OUT/${RN}_bench_${wl}_n1_under_rocprof.json 2> $OUT/prof_$wl.err
+  # (train: the weight gradients on the main stream, as in the region bench.py times its roofline kernel in -- with the side streams a launch's duration includes what co-runs)
+  HIMO_TRAIN_SIDE_STREAM=$([ $wl = train ] && echo 0 || echo 1) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$wl -o $wl -- python $R/bench.py $ARGS > $OUT/${RN}_bench_${wl}_n1_under_rocprof.json 2> $OUT/prof_$wl.err
   f=$(find $OUT/prof_$wl -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${RN}_${wl}_rocprofv3_kernel_stats.csv
   rm -rf $OUT/prof_$wl
