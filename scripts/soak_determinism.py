@@ -27,4 +27,25 @@ for step in range(STEPS):
 pipe.sync_check()
 torch.cuda.synchronize()
 print(f"{STEPS} steps, {bad} differing, {time.perf_counter() - t0:.1f} s, finite: {bool(torch.isfinite(ref_flow).all())}")
-sys.exit(1 if bad else 0)
+
+# ---- the same soak through pipeline.OverlappedPipeline (three batches in flight on three streams, results consumed on a side stream
+# after their `ready` event, as feeder.ResultDrain does): every step must still return the single-stream bits
+from himo_amd.pipeline import OverlappedPipeline
+over = OverlappedPipeline(params=spec.init_params(0), device=dev, max_points=P, max_batch=B, precision="f16x2", in_flight=3)
+side = torch.cuda.Stream(device=dev)
+bad2, held = 0, []
+t0 = time.perf_counter()
+for step in range(STEPS):
+    r = over.run(samples)
+    with torch.cuda.stream(side):
+        side.wait_event(r["ready"])
+        same = (r["flow"] == ref_flow).all() & (r["comp_dis"] == ref_cd).all()          # a device flag: no host sync inside the stream of batches
+    held.append(same)
+    if len(held) > 8:
+        ok = bool(held.pop(0).item())
+        bad2 += 0 if ok else 1
+over.sync_check()
+torch.cuda.synchronize()
+bad2 += sum(0 if bool(h.item()) else 1 for h in held)
+print(f"three in flight: {STEPS} steps, {bad2} differing, {time.perf_counter() - t0:.1f} s")
+sys.exit(1 if (bad or bad2) else 0)
