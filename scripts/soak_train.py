@@ -1,0 +1,37 @@
+"""GPU soak of the training step's side streams: N optimiser steps on rotating 120k-point samples, (a) twice with the side streams
+on, (b) once with every weight gradient back on the main stream -- the parameter bits after N steps must be the same in all three
+runs (the streams reorder work, not arithmetic).  A race between the data-gradient chain and a weight gradient reading its operands
+would show up as a difference.  usage: python scripts/soak_train.py [steps]"""
+import sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+from himo_amd.dataset import ListDataset
+from himo_amd.seflow import spec
+from himo_amd.seflow.fit import make_sample, triplets
+from himo_amd.seflow.train import SeFlowTrainer
+from himo_amd.synthetic import make_frame
+
+dev = torch.device("cuda", 0)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+ds = ListDataset([make_frame(1200 + i, n_points=120_000 - 2111 * i, scene_id="soak") for i in range(5)])
+trips = triplets(ds)
+samples = [make_sample(ds, t, dev) for t in trips]
+
+
+def run(side: bool):
+    tr = SeFlowTrainer(spec.init_params(9), device=dev, max_points=121_000, batchnorm="batch")
+    tr.set_side_streams(side)
+    losses = [float(tr.train_batch([samples[k % len(samples)]], lr=2e-4).item()) for k in range(N)]
+    torch.cuda.synchronize()
+    return tr.flat_p.clone(), losses
+
+
+t0 = time.perf_counter()
+a, la = run(True)
+b, lb = run(True)
+c, lc = run(False)
+print(f"{N} steps x 3 runs in {time.perf_counter() - t0:.1f} s; loss first / last {la[0]:.6f} / {la[-1]:.6f}")
+print("side streams on vs on :", "same bits" if torch.equal(a, b) and la == lb else f"{int((a != b).sum())} parameters differ")
+print("side streams on vs off:", "same bits" if torch.equal(a, c) and la == lc else f"{int((a != c).sum())} parameters differ")
+sys.exit(0 if (torch.equal(a, b) and torch.equal(a, c)) else 1)
