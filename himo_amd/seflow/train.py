@@ -282,17 +282,21 @@ class HeadTrainer:
                     _lib.check(self.lib.himo_linear_wgrad_ex(rows, x[t].data_ptr(), 192, 192, dz[t].data_ptr(), cout, cout,
                                                              self.g[f"{name}.weight"].data_ptr(), self.g[f"{name}.bias"].data_ptr(),
                                                              self.wgrad_flags | acc, self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle()), "wgrad")
-        if self.wgrad_stream is None:
-            gate_weight_gradients()
-        else:
-            # 1.5 GB of saved states and gate gradients, read only: beside whatever the caller's stream does next (SeFlowTrainer: the
-            # decoder's backward pass); the caller waits for this stream before it reads the gradients or runs the next backward
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(self.wgrad_stream):
-                self.wgrad_stream.wait_event(ready)
-                gate_weight_gradients()
+        # 1.5 GB of saved states and gate gradients, read only: beside whatever the caller's stream does next (SeFlowTrainer: the
+        # decoder's backward pass); the caller waits for this stream before it reads the gradients or runs the next backward
+        self._aside(gate_weight_gradients)
         return self._DHX0[:n]
+
+    def _aside(self, fn):
+        """run a weight gradient (it only reads its operands; they all share ``self.ws``, so they stay in order on ONE stream) on
+        ``wgrad_stream`` from the point the current stream has reached, or in place when there is none"""
+        if self.wgrad_stream is None or self.fmt_bwd is None or not self.fused_backward:
+            return fn()                  # (the iteration-by-iteration backward reuses its gate-gradient buffers: everything in place)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.wgrad_stream):
+            self.wgrad_stream.wait_event(ready)
+            fn()
 
     def _saved(self):
         sv = HeadSaved()
@@ -322,11 +326,12 @@ class HeadTrainer:
         """dres [n,4] (d loss / d res, column 3 ignored) -> d loss / d hx0 [n,192]; parameter gradients land in ``self.g``."""
         n = self.n
         lib, s = self.lib, _lib.stream_handle
-        # dec2 / dec1
-        self._wgrad(self.Y1, 32, dres, 4, "dec2")
+        # dec2 / dec1 (their weight gradients only read: beside the chain when a weight-gradient stream is set; ``dres`` must then stay
+        # alive and unmodified until that stream has been waited for -- SeFlowTrainer.backward owns it and waits at its end)
+        self._aside(lambda: self._wgrad(self.Y1, 32, dres, 4, "dec2"))
         self._gemm(dres, self._transposed("dec2"), None, self.DY1, 4, 32)
         _lib.check(lib.himo_affine_gelu_bwd(n, 32, self.DY1.data_ptr(), 32, self.PRE1.data_ptr(), 32, None, self.DY1.data_ptr(), 32, s()), "gelu_bwd")
-        self._wgrad(self.HX[-1], 192, self.DY1, 32, "dec1")
+        self._aside(lambda: self._wgrad(self.HX[-1], 192, self.DY1, 32, "dec1"))
         w1_t, w1_p = self._transposed_packed("dec1")
         self._gemm(self.DY1, w1_t, None, self.DHX, 32, 192, packed=w1_p, fmt=self.fmt_bwd or 0)
         if self.fmt_bwd is not None and self.fused_backward:
@@ -881,9 +886,9 @@ class SeFlowTrainer:
         _lib.check(lib.himo_mask_rows(n0, 4, net.pid[1].data_ptr(), dres.data_ptr(), 4, s()), "mask_rows")
         dhx0 = self.head.backward(dres)
         # offset embedding x = offsets @ W + b
-        _lib.check(lib.himo_linear_wgrad_ex(n0, net.offsets[1].data_ptr(), 3, 3, dhx0.data_ptr() + 4 * 128, 192, 64,
-                                            self.g["head.offset.weight"].data_ptr(), self.g["head.offset.bias"].data_ptr(), 0,
-                                            self.ws.data_ptr(), self.ws.numel(), s()), "offset wgrad")
+        self._beside(lambda ws: _lib.check(lib.himo_linear_wgrad_ex(n0, net.offsets[1].data_ptr(), 3, 3, dhx0.data_ptr() + 4 * 128, 192, 64,
+                                                                    self.g["head.offset.weight"].data_ptr(), self.g["head.offset.bias"].data_ptr(), 0,
+                                                                    ws.data_ptr(), ws.numel(), s()), "offset wgrad"))
         # gather adjoint: per-point rows -> image gradients (pc0 is slot 1; it gathers from groups 1 and 2 and from DEC)
         _lib.check(lib.himo_head_scatter(n0, W, H, net.ws_slots[1].data_ptr(), dhx0.data_ptr(), 192, self.dB0.data_ptr(), 32 * F,
                                          1, 2, F, self.dDEC.data_ptr(), 64, s()), "head_scatter")
