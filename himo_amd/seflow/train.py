@@ -575,9 +575,12 @@ class SeFlowTrainer:
         # decoder work there would stall the chain).  Their gradient operands get a buffer per block instead of the shared scratch
         self.overlap_decoder = self.overlap_wgrad and os.environ.get("HIMO_TRAIN_SIDE_STREAM_DECODER", "1") != "0"
         self.side2 = torch.cuda.Stream(device=dev)
+        self.side3 = torch.cuda.Stream(device=dev)
+        self._skip_done = []
         self.ws_side2 = torch.empty(ws + 64, dtype=torch.uint8, device=dev) if self.overlap_decoder else None
         self.head.wgrad_stream = self.side2 if self.overlap_decoder else None      # the GRU gates' weight gradients go there too
         if self.overlap_decoder:
+            self.TMP3 = buf(H * W * 32 * F)                      # dec3's skip gradient before it is added to the head's (third side stream)
             self.dIN = {"dec3": buf(H * W * 64), "dec2": buf(H * W // 4 * 128), "dec1": buf(H * W // 16 * 256)}
             self.dCATb = {"dec3": self.dCAT, "dec2": buf(H * W // 4 * 256), "dec1": buf(H * W // 16 * 512)}
             self.dTMPb = {"dec3": self.dTMPc, "dec2": buf(H * W // 16 * 128), "dec1": buf(H * W // 64 * 256)}
@@ -867,11 +870,26 @@ class SeFlowTrainer:
         # u3 (1x1 on the skip): gradient rows are the right half of dCAT
         self._beside(lambda ws: self._wgrad1(P, skip.data_ptr(), skip_c, skip_c, dcat + 4 * lat, 2 * lat, lat, f"{name}.u3", ws=ws))
         wt, wp = self._flip(f"{name}.u3", 1, skip_c, lat)                   # [lat][skip_c]
-        if skip_acc:
-            self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, self.TMP.data_ptr(), 0, skip_c, 1, 1, P, lat, skip_c, 1, packed=wp)
-            self._add2d(P, skip_c, self.TMP.data_ptr(), skip_c, d_skip, skip_c)
+
+        def skip_gradient(tmp):
+            if skip_acc:
+                self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, tmp, 0, skip_c, 1, 1, P, lat, skip_c, 1, packed=wp)
+                self._add2d(P, skip_c, tmp, skip_c, d_skip, skip_c)
+            else:
+                self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, d_skip, 0, skip_c, 1, 1, P, lat, skip_c, 1, packed=wp)
+        if self.overlap_decoder and self.precision != "f32":     # (float32: _flip's ONE scratch for flipped weights is rewritten by the next layer)
+            # the skip connection's gradient is not on the chain (the encoder's backward pass reads it much later): third side
+            # stream, own scratch; backward() waits for the three events before the encoder loop touches a skip gradient
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.side3):
+                self.side3.wait_event(ready)
+                skip_gradient(self.TMP3.data_ptr())
+                ev = torch.cuda.Event()
+                ev.record(self.side3)
+            self._skip_done.append(ev)
         else:
-            self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, d_skip, 0, skip_c, 1, 1, P, lat, skip_c, 1, packed=wp)
+            skip_gradient(self.TMP.data_ptr())
         # upsample, u1 (1x1 on the coarse map)
         _lib.check(lib.himo_upsample2x_bwd(dcat, 2 * lat, ch, cw, lat, dtmp, lat, s()), "upsample2x_bwd")
         self._beside(lambda ws: self._wgrad1(ch * cw, coarse.data_ptr(), c_in, c_in, dtmp, lat, lat, f"{name}.u1", ws=ws))
@@ -911,6 +929,8 @@ class SeFlowTrainer:
         dcat = {256: self.dF3, 128: self.dF2, 64: self.dF1, 32: self.dB0}
         dy = None
         main = torch.cuda.current_stream(self.device)
+        while self._skip_done:                                   # the decoder blocks' skip gradients (third side stream) are complete
+            main.wait_event(self._skip_done.pop())
         side_done = {}                                           # layer -> event: its side-stream launches have finished reading dp
         for li in range(len(self.layers) - 1, -1, -1):
             name, cin, cout, stride, h, w, ho, wo, last = self.layers[li]
@@ -985,6 +1005,7 @@ class SeFlowTrainer:
                                                       self.ws.data_ptr(), self.ws.numel(), s()), "pfn_backward_bn_multi")
             main.wait_stream(self.side)                         # every gradient is in flat_g when this stream goes on
             main.wait_stream(self.side2)
+            main.wait_stream(self.side3)
             return
         for slot in range(F):
             if self._fwd_batch:
@@ -1003,6 +1024,7 @@ class SeFlowTrainer:
                        "pfn_backward")
         main.wait_stream(self.side)
         main.wait_stream(self.side2)
+        main.wait_stream(self.side3)
 
     def _pfn_sweep_arrays(self):
         """host arrays of the sample's sweeps for the multi-sweep pillar-net calls: point counts, transformed points, pillar workspaces"""

@@ -19,10 +19,10 @@ trips = triplets(ds)
 samples = [make_sample(ds, t, dev) for t in trips]
 
 
-def run(side: bool):
-    tr = SeFlowTrainer(spec.init_params(9), device=dev, max_points=121_000, batchnorm="batch")
+def run(side: bool, precision: str = "mixed", batchnorm: str = "batch", steps: int = N):
+    tr = SeFlowTrainer(spec.init_params(9), device=dev, max_points=121_000, batchnorm=batchnorm, precision=precision)
     tr.set_side_streams(side)
-    losses = [float(tr.train_batch([samples[k % len(samples)]], lr=2e-4).item()) for k in range(N)]
+    losses = [float(tr.train_batch([samples[k % len(samples)]], lr=2e-4).item()) for k in range(steps)]
     torch.cuda.synchronize()
     return tr.flat_p.clone(), losses
 
@@ -34,4 +34,13 @@ c, lc = run(False)
 print(f"{N} steps x 3 runs in {time.perf_counter() - t0:.1f} s; loss first / last {la[0]:.6f} / {la[-1]:.6f}")
 print("side streams on vs on :", "same bits" if torch.equal(a, b) and la == lb else f"{int((a != b).sum())} parameters differ")
 print("side streams on vs off:", "same bits" if torch.equal(a, c) and la == lc else f"{int((a != c).sum())} parameters differ")
-sys.exit(0 if (torch.equal(a, b) and torch.equal(a, c)) else 1)
+ok = torch.equal(a, b) and torch.equal(a, c)
+# the other arithmetics and the frozen-BatchNorm mode take other branches of the backward pass (float32: flipped weights through ONE
+# scratch buffer; frozen: bias column sums on the side stream): 8 steps each, on vs off
+for prec, bn in (("bf16x3", "batch"), ("f32", "batch"), ("mixed", "frozen")):
+    x, lx = run(True, prec, bn, 8)
+    y, ly = run(False, prec, bn, 8)
+    same = torch.equal(x, y) and lx == ly
+    ok = ok and same
+    print(f"{prec:6s} / BatchNorm {bn:6s}: side streams on vs off:", "same bits" if same else f"{int((x != y).sum())} parameters differ")
+sys.exit(0 if ok else 1)
