@@ -7,25 +7,39 @@
 //
 // Why a grid here and brute force in nn.hip: per-instance sets (10..5000 points) are best swept
 // exhaustively, but sweep-to-sweep search is 1.4e10 pairs (~2 ms) five times per training sample.
-// A 1 m x 1 m BEV grid holds ~10 points per cell, so a query inspects ~10^2 candidates instead of 10^5.
-//   build:  cell histogram (integer atomics) -> two-level exclusive scan -> counting-sort scatter of the
-//           reference rows (xyz + original index packed as float4, so a candidate is ONE 16-byte load)
-//   query:  one lane per query walks Chebyshev rings of cells around its own cell and stops when the best
-//           distance so far is <= the distance to the nearest unvisited ring; the result is the exact NN.
-//           (Tried: walking the queries in cell order after a second counting sort -- the query kernel gains 9 us of
-//           52, the extra sort costs 26; not kept.)
-// Ties keep the lowest reference index (the rule of nn.hip), so the two kernels are interchangeable.
-#include "himo_common.h"
+//
+//   build:  BOTH point sets of a search are binned: cell histogram (integer atomics) -> exclusive scan -> counting-sort
+//           scatter of the rows (xyz + original row packed as float4: a candidate is ONE 16-byte load).  The searched set is
+//           kept twice, in row-major and in column-major cell order, so that ANY axis-aligned line of cells -- a row OR a
+//           column of the grid -- is one contiguous run of candidates.
+//   query:  WAVE-COOPERATIVE (round 5).  A 256-thread block owns 64 consecutive queries of the cell-sorted query set: one
+//           query per lane, the same 64 in each of its four waves.  Neighbouring sorted queries share cells, so the block walks
+//           Chebyshev rings around the RECTANGLE of cells its active queries occupy (a stretch of one grid row): ring 0 is
+//           one run, every later ring is exactly four runs (top row, bottom row, left column, right column).  Run bounds and
+//           candidates are wave-uniform: they arrive through the scalar data cache into SGPRs (no per-lane address, no
+//           divergence), every lane tests every candidate of its wave against its own query, and the four waves take
+//           alternate 8-candidate chunks of the ring.  After a ring the four waves merge (distance, row) through LDS; a lane
+//           retires when its best distance is within the ring's guaranteed reach; the block leaves the segment when all its
+//           lanes have.  Queries of the block that sit in another row / beyond 16 cells form the next segment.
+//
+// Why not one lane per query walking its own rings (rounds 1-4): a lane's walk is a chain of dependent loads whose length is
+// its candidate count, and a wave waits for its longest lane.  On the uniform bench cloud every lane meets ~100 candidates;
+// on a LiDAR-shaped sweep (himo_amd.synthetic.lidar_rings) cells near the sensor hold 600 points and a quarter of the queries
+// (surfaces the other sweep does not see) must walk 3-19 m: 500 candidates on average, 12 000 for the worst lane, and the
+// per-lane kernel went from 110 us to 1620 us per search (profiles/r05_train_rings_rocprofv3_kernel_stats_before.csv).
+// Here the longest chain is a quarter of a ring's candidates at ~40 cycles each, shared by 64 queries.
+//
+// Ties keep the lowest reference row (the rule of nn.hip), independent of the order the candidates arrive in: the result
+// does not depend on the atomics' order inside the counting sort.
+#include "nngrid.h"
 #include <math.h>
 
 namespace himo {
 
-struct NnGrid {
-    float x0, y0, inv_cell, cell;
-    int gw, gh;
-};
-
-constexpr int kNngUnroll = 8;        // candidate loads in flight per lane
+constexpr int kNngWaves = 8;          // waves of a query block (a power of two): they share a ring's candidates
+constexpr int kNngChunk = 8;          // candidates per scalar-load batch
+constexpr int kNngSegCells = 16;      // widest stretch of a grid row one segment covers
+constexpr int kNngScanChunk = 4096;   // cells per iteration of the one-block scan
 
 __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -36,169 +50,269 @@ __device__ inline void cell_of(const NnGrid& g, float x, float y, int& cx, int& 
     cy = clampi((int)floorf((y - g.y0) * g.inv_cell), 0, g.gh - 1);
 }
 
-__global__ __launch_bounds__(256) void nng_count_kernel(int64_t n, const float* __restrict__ r, NnGrid g, int* __restrict__ count,
-                                                        int* __restrict__ cell_id) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    int cx, cy;
-    cell_of(g, r[i * 3], r[i * 3 + 1], cx, cy);
-    const int c = cy * g.gw + cx;
-    cell_id[i] = c;
-    atomicAdd(&count[c], 1);
-}
+struct NngArgs {
+    NngSet set[kNngMaxSets];
+    NngJob job[kNngMaxJobs];
+    NnGrid g;
+};
 
-constexpr int kNngScanBlock = 1024;
-__global__ __launch_bounds__(256) void nng_scan_local_kernel(int* v, int n, int* block_sum) {
-    __shared__ int wsum[4];
-    const int base = blockIdx.x * kNngScanBlock + threadIdx.x * 4;
-    int x[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) x[k] = base + k < n ? v[base + k] : 0;
-    const int mine = x[0] + x[1] + x[2] + x[3];
-    int incl = mine;
-    const int lane = threadIdx.x & 63;
-    for (int off = 1; off < 64; off <<= 1) {
-        const int y = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += y;
-    }
-    if (lane == 63) wsum[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    int run = incl - mine;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wsum[w];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { if (base + k < n) v[base + k] = run; run += x[k]; }
-    if (threadIdx.x == 255) block_sum[blockIdx.x] = run;
-}
-
-__global__ __launch_bounds__(1024) void nng_scan_top_kernel(int* block_sum, int nblk, int* v, int n) {
-    __shared__ int part[1024];
-    const int x = (int)threadIdx.x < nblk ? block_sum[threadIdx.x] : 0;
-    part[threadIdx.x] = x;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int y = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += y;
-        __syncthreads();
-    }
-    if ((int)threadIdx.x < nblk) block_sum[threadIdx.x] = part[threadIdx.x] - x;
-    if (threadIdx.x == 1023) v[n] = part[1023];     // grand total, so offset(n_cells) is defined
-}
-
-// make the per-cell offsets global (one add per cell) so the query kernel needs a single load per cell
-__global__ __launch_bounds__(256) void nng_scan_add_kernel(int* v, int n, const int* __restrict__ block_sum) {
+__global__ __launch_bounds__(256) void nng_count_kernel(NngArgs a) {
+    const NngSet& S = a.set[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) v[i] += block_sum[i / kNngScanBlock];
+    if (i >= S.n) return;
+    int cx, cy;
+    cell_of(a.g, S.pts[(size_t)i * 3], S.pts[(size_t)i * 3 + 1], cx, cy);
+    const int c = cy * a.g.gw + cx;
+    S.cell_id[i] = c;
+    atomicAdd(&S.offset[c], 1);
+    if (S.searched) atomicAdd(&S.offset_t[cx * a.g.gh + cy], 1);
 }
 
-__global__ __launch_bounds__(256) void nng_fill_kernel(int64_t n, const float* __restrict__ r, const int* __restrict__ cell_id,
-                                                       const int* __restrict__ offset, int* __restrict__ cursor,
-                                                       float4* __restrict__ sorted) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int c = cell_id[i];
-    const int slot = atomicAdd(&cursor[c], 1);
-    sorted[offset[c] + slot] = make_float4(r[i * 3], r[i * 3 + 1], r[i * 3 + 2], __int_as_float((int)i));
+// in-place exclusive scan of one histogram per block (block 2k: set k row-major, 2k + 1: set k column-major); v[cells] = total
+__global__ __launch_bounds__(1024) void nng_scan_kernel(NngArgs a, int cells) {
+    const NngSet& S = a.set[blockIdx.x >> 1];
+    if ((blockIdx.x & 1) && !S.searched) return;
+    int* v = (blockIdx.x & 1) ? S.offset_t : S.offset;
+    __shared__ int wsum[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int carry = 0;
+    for (int base = 0; base < cells; base += kNngScanChunk) {
+        const int at = base + threadIdx.x * 4;
+        int x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = at + k < cells ? v[at + k] : 0;
+        const int mine = x[0] + x[1] + x[2] + x[3];
+        int incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += y;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int run = carry + incl - mine, total = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int t = wsum[k]; total += t; if (k < w) run += t; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (at + k < cells) v[at + k] = run; run += x[k]; }
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) v[cells] = carry;
 }
 
-__global__ __launch_bounds__(256) void nng_query_kernel(int64_t nq, const float* __restrict__ q, NnGrid g,
-                                                        const int* __restrict__ offset, const float4* __restrict__ sorted,
-                                                        float* __restrict__ dist2, int* __restrict__ idx) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nq) return;
-    const float qx = q[i * 3], qy = q[i * 3 + 1], qz = q[i * 3 + 2];
+__global__ __launch_bounds__(256) void nng_fill_kernel(NngArgs a) {
+    const NngSet& S = a.set[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S.n) return;
+    const int c = S.cell_id[i];
+    const float4 p = make_float4(S.pts[(size_t)i * 3], S.pts[(size_t)i * 3 + 1], S.pts[(size_t)i * 3 + 2], __int_as_float(i));
+    S.sorted[S.offset[c] + atomicAdd(&S.cursor[c], 1)] = p;
+    if (S.searched) {
+        const int cy = c / a.g.gw, cx = c - cy * a.g.gw, ct = cx * a.g.gh + cy;
+        S.sorted_t[S.offset_t[ct] + atomicAdd(&S.cursor_t[ct], 1)] = p;
+    }
+}
+
+// (squared distance, row) as ONE unsigned 64-bit key: distances are >= +0, so their float bits order like the values, and the
+// row in the low word breaks ties towards the lowest row; "no neighbour yet" = (+inf, 0xffffffff).  One compare + two selects
+// per candidate instead of three compares.
+__device__ inline unsigned long long nng_key(float d, int row) {
+    return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)row;
+}
+constexpr unsigned long long kNngNone = 0x7f800000ffffffffull;
+
+__global__ __launch_bounds__(64 * kNngWaves) void nng_query_kernel(NngArgs a) {
+    __shared__ unsigned long long s_best[2][kNngWaves][64];
+    const NngJob& job = a.job[blockIdx.y];
+    const NngSet& Q = a.set[job.q];
+    const NngSet& R = a.set[job.r];
+    const NnGrid& g = a.g;
+    const int base = blockIdx.x * 64;
+    if (base >= Q.n) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool valid = base + lane < Q.n;
+    const float4 me = Q.sorted[min(base + lane, Q.n - 1)];
+    const float qx = me.x, qy = me.y, qz = me.z;
     int cx, cy;
     cell_of(g, qx, qy, cx, cy);
-    // distance from the query to the border of its (clamped) cell: everything outside ring r is at least
-    // r * cell + margin away in the BEV plane (margin may be negative for queries outside the grid -> clamp to 0)
-    const float lx = g.x0 + (float)cx * g.cell, ly = g.y0 + (float)cy * g.cell;
-    const float margin = fmaxf(0.f, fminf(fminf(qx - lx, lx + g.cell - qx), fminf(qy - ly, ly + g.cell - qy)));
-    float best = INFINITY;
-    int bi = -1;
-    const int rmax = max(max(cx, g.gw - 1 - cx), max(cy, g.gh - 1 - cy));
-    // candidates [b, e) of the sorted reference array, kNngUnroll 16-byte loads in flight per step: the walk is a chain of dependent
-    // loads (one lane, ~100 candidates, each compare waiting for its load), so its time is the chain length times the memory
-    // latency (measured 120k x 120k: 240 -> 52 us).  Loads past the end are clamped to the last candidate (re-evaluating it
-    // changes nothing: d == best, same index).
-    auto scan = [&](int b, int e) {
-        for (int k = b; k < e; k += kNngUnroll) {
-            float4 p[kNngUnroll];
+    unsigned long long best = kNngNone;
+    if (R.n > 0) {
+        const int* __restrict__ off = R.offset;
+        const int* __restrict__ off_t = R.offset_t;
+        const float4* __restrict__ rows = R.sorted;
+        const float4* __restrict__ cols = R.sorted_t;
+        // a bound computed in float32 from cell indices may exceed the true clearance by a rounding error of the coordinates
+        const float slack = 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(g.x0) + fabsf(g.y0) + g.cell);
+        int par = 0;
+        unsigned long long pending = __ballot(valid);
+        while (pending) {
+            // the next segment: the first unserved query's grid row, from its cell to at most kNngSegCells further (the sorted
+            // order makes these lanes a contiguous stretch with non-decreasing cx)
+            const int lead = __ffsll((long long)pending) - 1;
+            const int y0 = __builtin_amdgcn_readlane(cy, lead), xa = __builtin_amdgcn_readlane(cx, lead);
+            const bool act = ((pending >> lane) & 1ull) && cy == y0 && cx < xa + kNngSegCells;
+            const unsigned long long actm = __ballot(act);
+            const int xb = __builtin_amdgcn_readlane(cx, 63 - __clzll((long long)actm));
+            // BEV clearance of the query inside the rectangle of cells [xa, xb] x {y0}: everything outside the rectangle grown
+            // by `ring` cells is at least ring * cell + m away (m = 0 for queries outside the grid, binned into border cells)
+            const float lxa = g.x0 + (float)xa * g.cell, lxb = g.x0 + (float)(xb + 1) * g.cell, ly = g.y0 + (float)y0 * g.cell;
+            const float m = fmaxf(0.f, fminf(fminf(qx - lxa, lxb - qx), fminf(qy - ly, ly + g.cell - qy)) - slack);
+            const int rmax = max(max(xa, g.gw - 1 - xb), max(y0, g.gh - 1 - y0));
+            bool alive = act;
+            for (int ring = 0; ring <= rmax; ++ring) {
+                const int xl = xa - ring, xr = xb + ring, yl = y0 - ring, yh = y0 + ring;
+                const int cxl = max(xl, 0), cxr = min(xr, g.gw - 1);
+                // the ring's runs: [0] top row, [1] bottom row (cells cxl..cxr of the row-major copy), [2] left column, [3] right
+                // column (rows yl+1..yh-1 of the column-major copy); absent ones (outside the grid, ring 0) are empty
+                int b0, e0, b1 = 0, e1 = 0, b2 = 0, e2 = 0, b3 = 0, e3 = 0;
+                if (ring == 0) {
+                    b0 = off[y0 * g.gw + xa]; e0 = off[y0 * g.gw + xb + 1];
+                } else {
+                    const int ry0 = max(yl, 0), ry1 = min(yh, g.gh - 1);
+                    const int cyl = max(yl + 1, 0), cyh = min(yh - 1, g.gh - 1);
+                    b0 = off[ry0 * g.gw + cxl]; e0 = off[ry0 * g.gw + cxr + 1];
+                    b1 = off[ry1 * g.gw + cxl]; e1 = off[ry1 * g.gw + cxr + 1];
+                    b2 = off_t[cxl * g.gh + cyl]; e2 = off_t[cxl * g.gh + cyh + 1];
+                    b3 = off_t[cxr * g.gh + cyl]; e3 = off_t[cxr * g.gh + cyh + 1];
+                    if (yl < 0) e0 = b0;
+                    if (yh >= g.gh) e1 = b1;
+                    if (xl < 0) e2 = b2;
+                    if (xr >= g.gw) e3 = b3;
+                }
+                int turn = 0;           // chunks of this ring so far: chunk t goes to wave t % kNngWaves
+                auto scan = [&](const float4* __restrict__ arr, int b, int e) {
+                    const int n_chunks = (e - b + kNngChunk - 1) / kNngChunk;
+                    for (int t = (wave - turn) & (kNngWaves - 1); t < n_chunks; t += kNngWaves) {
+                        const int k = b + t * kNngChunk;
+                        float4 p[kNngChunk];
 #pragma unroll
-            for (int j = 0; j < kNngUnroll; ++j) p[j] = sorted[min(k + j, e - 1)];
+                        for (int j = 0; j < kNngChunk; ++j) p[j] = arr[min(k + j, e - 1)];      // past the end: the last one again
 #pragma unroll
-            for (int j = 0; j < kNngUnroll; ++j) {
-                const float dx = qx - p[j].x, dy = qy - p[j].y, dz = qz - p[j].z;
-                const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                const int pi = __float_as_int(p[j].w);
-                if (d < best || (d == best && pi < bi)) { best = d; bi = pi; }
+                        for (int j = 0; j < kNngChunk; ++j) {
+                            const float dx = qx - p[j].x, dy = qy - p[j].y, dz = qz - p[j].z;
+                            const unsigned long long key = nng_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(p[j].w));
+                            best = key < best ? key : best;
+                        }
+                    }
+                    turn += n_chunks;
+                };
+                scan(rows, b0, e0);
+                scan(rows, b1, e1);
+                scan(cols, b2, e2);
+                scan(cols, b3, e3);
+                if (turn > 0) {         // the ring held candidates: merge the four waves' (distance, row)
+                    s_best[par][wave][lane] = best;
+                    __syncthreads();
+#pragma unroll
+                    for (int w = 0; w < kNngWaves; ++w) { const unsigned long long o = s_best[par][w][lane]; best = o < best ? o : best; }
+                    par ^= 1;           // the next merge writes the other buffer: one barrier per ring
+                }
+                const float reach = (float)ring * g.cell + m;
+                if (best != kNngNone && __uint_as_float((unsigned)(best >> 32)) <= reach * reach) alive = false;
+                if (__ballot(alive) == 0ull) break;
             }
+            pending &= ~actm;
         }
-    };
-    for (int ring = 0; ring <= rmax; ++ring) {
-        const int ylo = cy - ring, yhi = cy + ring;
-        const int xlo = max(cx - ring, 0), xhi = min(cx + ring, g.gw - 1);
-        for (int yy = max(ylo, 0); yy <= min(yhi, g.gh - 1); ++yy) {
-            if (yy == ylo || yy == yhi) {
-                // an edge row of the ring: its cells are consecutive in the sorted array -> ONE run of candidates
-                scan(offset[yy * g.gw + xlo], offset[yy * g.gw + xhi + 1]);
-            } else {                                            // inner rows (ring >= 1): the two end cells of the ring
-                if (cx - ring >= 0) { const int c = yy * g.gw + cx - ring; scan(offset[c], offset[c + 1]); }
-                if (cx + ring < g.gw) { const int c = yy * g.gw + cx + ring; scan(offset[c], offset[c + 1]); }
-            }
-        }
-        const float reach = (float)ring * g.cell + margin;     // nearest possible unvisited point (BEV distance)
-        if (bi >= 0 && best <= reach * reach) break;
     }
-    dist2[i] = best;
-    if (idx) idx[i] = bi;
+    if (wave == 0 && valid) {
+        const int o = __float_as_int(me.w);
+        job.dist2[o] = __uint_as_float((unsigned)(best >> 32));
+        if (job.idx) job.idx[o] = (int)(unsigned)best;
+    }
 }
 
-static size_t nng_cells_bytes(int cells) { return round_up(((size_t)cells + 1) * 4, 16); }
-static size_t nng_blocks_bytes(int cells) { return round_up(((size_t)(cells + kNngScanBlock - 1) / kNngScanBlock + 1) * 4, 16); }
+static size_t nng_ints_bytes(int cells) { return round_up(((size_t)cells + 1) * 4, 16); }
+
+size_t nng_workspace_bytes(int n_sets, int64_t n_max, int cells) {
+    const size_t n = (size_t)(n_max > 0 ? n_max : 1);
+    return (size_t)n_sets * (4 * nng_ints_bytes(cells) + round_up(n * 4, 16) + 2 * round_up(n * 16, 16)) + 64;
+}
+
+void nng_carve(void* workspace, NngSet* sets, int n_sets, const float* const* pts, const int* n, const int* searched, int cells) {
+    char* w = reinterpret_cast<char*>(workspace);
+    const size_t ib = nng_ints_bytes(cells);
+    for (int k = 0; k < n_sets; ++k) {
+        sets[k].pts = pts[k]; sets[k].n = n[k]; sets[k].searched = searched[k];
+        sets[k].offset = reinterpret_cast<int*>(w); sets[k].offset_t = reinterpret_cast<int*>(w + ib);
+        sets[k].cursor = reinterpret_cast<int*>(w + 2 * ib); sets[k].cursor_t = reinterpret_cast<int*>(w + 3 * ib);
+        w += 4 * ib;
+    }
+    for (int k = 0; k < n_sets; ++k) {
+        const size_t nn = (size_t)(n[k] > 0 ? n[k] : 1);
+        sets[k].cell_id = reinterpret_cast<int*>(w); w += round_up(nn * 4, 16);
+        sets[k].sorted = reinterpret_cast<float4*>(w); w += round_up(nn * 16, 16);
+        sets[k].sorted_t = reinterpret_cast<float4*>(w); w += round_up(nn * 16, 16);
+    }
+}
+
+static void nng_pack(NngArgs& a, const NngSet* sets, int n_sets, const NngJob* jobs, int n_jobs, const NnGrid& g) {
+    a = NngArgs{};
+    for (int k = 0; k < n_sets; ++k) a.set[k] = sets[k];
+    for (int k = 0; k < n_jobs; ++k) a.job[k] = jobs[k];
+    a.g = g;
+}
+
+int nng_build(const NngSet* sets, int n_sets, const NnGrid& g, hipStream_t s) {
+    if (n_sets < 1 || n_sets > kNngMaxSets) return HIMO_ERR_INVALID_ARGUMENT;
+    const int cells = g.gw * g.gh;
+    NngArgs a;
+    nng_pack(a, sets, n_sets, nullptr, 0, g);
+    int n_max = 0;
+    for (int k = 0; k < n_sets; ++k) n_max = sets[k].n > n_max ? sets[k].n : n_max;
+    ProfScope ps("nn_grid_build", s);
+    // nng_carve keeps the sets' integer arrays contiguous from set 0's offsets
+    HIMO_HIP(hipMemsetAsync(sets[0].offset, 0, (size_t)n_sets * 4 * nng_ints_bytes(cells), s));
+    if (n_max > 0) hipLaunchKernelGGL(nng_count_kernel, dim3((unsigned)((n_max + 255) / 256), n_sets), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nng_scan_kernel, dim3(2 * n_sets), dim3(1024), 0, s, a, cells);
+    if (n_max > 0) hipLaunchKernelGGL(nng_fill_kernel, dim3((unsigned)((n_max + 255) / 256), n_sets), dim3(256), 0, s, a);
+    HIMO_LAUNCH_CHECK("nn_grid_build");
+    return HIMO_OK;
+}
+
+int nng_query(const NngSet* sets, int n_sets, const NngJob* jobs, int n_jobs, const NnGrid& g, hipStream_t s) {
+    if (n_sets < 1 || n_sets > kNngMaxSets || n_jobs < 1 || n_jobs > kNngMaxJobs) return HIMO_ERR_INVALID_ARGUMENT;
+    NngArgs a;
+    nng_pack(a, sets, n_sets, jobs, n_jobs, g);
+    int nq_max = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        if (jobs[k].q < 0 || jobs[k].q >= n_sets || jobs[k].r < 0 || jobs[k].r >= n_sets || !sets[jobs[k].r].searched)
+            return HIMO_ERR_INVALID_ARGUMENT;
+        nq_max = sets[jobs[k].q].n > nq_max ? sets[jobs[k].q].n : nq_max;
+    }
+    if (nq_max == 0) return HIMO_OK;
+    {
+        ProfScope ps("nn_grid_query_kernel", s);
+        hipLaunchKernelGGL(nng_query_kernel, dim3((unsigned)((nq_max + 63) / 64), n_jobs), dim3(64 * kNngWaves), 0, s, a);
+    }
+    HIMO_LAUNCH_CHECK("nn_grid_query_kernel");
+    return HIMO_OK;
+}
 
 }  // namespace himo
 
 using namespace himo;
 
-extern "C" size_t himo_nn_grid_workspace_bytes(int64_t n_ref, int grid_w, int grid_h) {
-    const int cells = grid_w * grid_h;
-    const size_t n = (size_t)(n_ref > 0 ? n_ref : 1);
-    return 2 * nng_cells_bytes(cells) + nng_blocks_bytes(cells) + round_up(n * 4, 16) + round_up(n * 16, 16) + 64;
+extern "C" size_t himo_nn_grid_workspace_bytes(int64_t n_max, int grid_w, int grid_h) {
+    return nng_workspace_bytes(2, n_max, grid_w * grid_h);
 }
 
 extern "C" int himo_nn_grid(int64_t nq, const float* d_q, int64_t nr, const float* d_r, float x0, float y0, float cell,
                             int grid_w, int grid_h, float* d_dist2, int32_t* d_idx, void* d_workspace,
                             size_t workspace_bytes, void* stream) {
     if (nq < 0 || nr < 0 || grid_w < 1 || grid_h < 1 || !(cell > 0.f)) return HIMO_ERR_INVALID_ARGUMENT;
-    if (nr > 0x7fffffff || (int64_t)grid_w * grid_h > 1024 * kNngScanBlock) return HIMO_ERR_UNSUPPORTED;
+    if (nr > 0x7fffffff || nq > 0x7fffffff || (int64_t)grid_w * grid_h > (1 << 20)) return HIMO_ERR_UNSUPPORTED;
     if (nq == 0) return HIMO_OK;
     if (!d_q || !d_dist2 || !d_workspace || (nr > 0 && !d_r)) return HIMO_ERR_INVALID_ARGUMENT;
-    if (workspace_bytes < himo_nn_grid_workspace_bytes(nr, grid_w, grid_h) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
+    if (workspace_bytes < himo_nn_grid_workspace_bytes(nq > nr ? nq : nr, grid_w, grid_h) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    const int cells = grid_w * grid_h;
-    char* ws = reinterpret_cast<char*>(d_workspace);
-    int* offset = reinterpret_cast<int*>(ws);
-    int* cursor = reinterpret_cast<int*>(ws + nng_cells_bytes(cells));
-    int* block_sum = reinterpret_cast<int*>(ws + 2 * nng_cells_bytes(cells));
-    int* cell_id = reinterpret_cast<int*>(ws + 2 * nng_cells_bytes(cells) + nng_blocks_bytes(cells));
-    float4* sorted = reinterpret_cast<float4*>(ws + 2 * nng_cells_bytes(cells) + nng_blocks_bytes(cells) +
-                                               round_up((size_t)(nr > 0 ? nr : 1) * 4, 16));
     NnGrid g{x0, y0, 1.0f / cell, cell, grid_w, grid_h};
-    HIMO_HIP(hipMemsetAsync(offset, 0, 2 * nng_cells_bytes(cells), s));
-    const int nblk = (cells + kNngScanBlock - 1) / kNngScanBlock;
-    {
-        ProfScope ps("nn_grid_build", s);
-        if (nr > 0) hipLaunchKernelGGL(nng_count_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, s, nr, d_r, g, offset, cell_id);
-        hipLaunchKernelGGL(nng_scan_local_kernel, dim3(nblk), dim3(256), 0, s, offset, cells, block_sum);
-        hipLaunchKernelGGL(nng_scan_top_kernel, dim3(1), dim3(1024), 0, s, block_sum, nblk, offset, cells);
-        hipLaunchKernelGGL(nng_scan_add_kernel, dim3((cells + 255) / 256), dim3(256), 0, s, offset, cells, block_sum);
-        if (nr > 0) hipLaunchKernelGGL(nng_fill_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, s, nr, d_r, cell_id, offset, cursor, sorted);
-    }
-    HIMO_LAUNCH_CHECK("nn_grid_build");
-    {
-        ProfScope ps("nn_grid_query_kernel", s);
-        hipLaunchKernelGGL(nng_query_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, nq, d_q, g, offset, sorted, d_dist2, d_idx);
-    }
-    HIMO_LAUNCH_CHECK("nn_grid_query_kernel");
-    return HIMO_OK;
+    NngSet sets[2];
+    const float* pts[2] = {d_q, d_r};
+    const int n[2] = {(int)nq, (int)nr}, searched[2] = {0, 1};
+    nng_carve(d_workspace, sets, 2, pts, n, searched, grid_w * grid_h);
+    int st = nng_build(sets, 2, g, s);
+    if (st != HIMO_OK) return st;
+    NngJob job{0, 1, d_dist2, d_idx};
+    return nng_query(sets, 2, &job, 1, g, s);
 }

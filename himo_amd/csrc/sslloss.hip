@@ -16,18 +16,14 @@
 //                          index) and t_c = pc1[NN_raw(a_c)] - pc0[a_c]; clusters without such a member are skipped
 //   total = sum of the four.  Correspondences are treated as constants in the gradient.
 //
-// All nearest-neighbour searches run through nngrid.hip (exact).  Loss sums are fixed two-level trees
+// All nearest-neighbour searches run through nngrid.hip (exact): the full sweeps are binned once and searched in ONE launch
+// (moved -> pc1, pc1 -> moved, and pc0 -> pc1 unless the caller supplies it), the dynamic subsets in a second one.  Loss sums are fixed two-level trees
 // (deterministic); the pc1 -> moved direction scatters its gradient onto the matched pc0 points as 64-bit FIXED-POINT
 // integer atomics (2^-40 units: integer addition is associative, so the sum does not depend on the arrival order --
 // float atomics made two runs of the same step differ in the last bits, and 20 optimiser steps amplified that into
 // different weights), converted once per point: the whole gradient is bit-reproducible.
-#include "himo_common.h"
+#include "nngrid.h"
 #include <math.h>
-
-extern "C" int himo_nn_grid(int64_t nq, const float* d_q, int64_t nr, const float* d_r, float x0, float y0, float cell,
-                            int grid_w, int grid_h, float* d_dist2, int32_t* d_idx, void* d_workspace,
-                            size_t workspace_bytes, void* stream);
-extern "C" size_t himo_nn_grid_workspace_bytes(int64_t n_ref, int grid_w, int grid_h);
 
 namespace himo {
 
@@ -269,7 +265,7 @@ static LossLayout loss_layout(int n0, int n1, int n_labels, int gw, int gh) {
     L.counts = take(8 * 4);
     L.anchor = take((size_t)(n_labels > 0 ? n_labels : 1) * 8);
     L.partial = take(((N0 + 255) / 256 + (N1 + 255) / 256 + 2) * 4 * 8);
-    L.nn = take(himo_nn_grid_workspace_bytes((int64_t)(N0 > N1 ? N0 : N1), gw, gh));
+    L.nn = take(nng_workspace_bytes(3, (int64_t)(N0 > N1 ? N0 : N1), gw * gh));
     L.end = o;
     return L;
 }
@@ -327,8 +323,9 @@ extern "C" int himo_ssl_loss_ex(int n0, int n1, const float* d_pc0, const float*
     a.partial = (double*)(ws + L.partial); a.loss = d_loss;
     int* bc0 = (int*)(ws + L.bc0); int* bc1 = (int*)(ws + L.bc1);
     void* nnws = ws + L.nn;
-    const size_t nnbytes = himo_nn_grid_workspace_bytes((int64_t)(n0 > n1 ? n0 : n1), grid_w, grid_h);
     const int blocks0 = (n0 + 255) / 256, blocks1 = (n1 + 255) / 256;
+    const NnGrid g{grid_x0, grid_y0, 1.0f / grid_cell, grid_cell, grid_w, grid_h};
+    if (!(grid_cell > 0.f) || (int64_t)grid_w * grid_h > (1 << 20)) return HIMO_ERR_INVALID_ARGUMENT;
 
     HIMO_HIP(hipMemsetAsync(a.counts, 0, 32, s));
     if (n0 > 0) HIMO_HIP(hipMemsetAsync(a.scat, 0, (size_t)n0 * 24, s));
@@ -337,13 +334,17 @@ extern "C" int himo_ssl_loss_ex(int n0, int n1, const float* d_pc0, const float*
     if (n0 > 0) hipLaunchKernelGGL(loss_prepare_kernel, dim3(blocks0), dim3(256), 0, s, a);
     HIMO_LAUNCH_CHECK("loss_prepare_kernel");
     int st;
-#define NNG(nq, q, nr, r, d, i) \
-    st = himo_nn_grid(nq, q, nr, r, grid_x0, grid_y0, grid_cell, grid_w, grid_h, d, i, nnws, nnbytes, s); if (st != HIMO_OK) return st;
     if (n0 > 0 && n1 > 0) {
-        NNG(n0, a.moved, n1, d_pc1, a.d_a, a.i_a);
-        NNG(n1, d_pc1, n0, a.moved, a.d_b, a.i_b);
+        // sets: 0 = moved, 1 = pc1, (2 = pc0, searched FROM only); jobs: moved -> pc1, pc1 -> moved, (pc0 -> pc1)
+        NngSet sets[3];
+        const float* pts[3] = {a.moved, d_pc1, d_pc0};
+        const int n[3] = {n0, n1, n0}, searched[3] = {1, 1, 0};
+        const int n_sets = d_raw_idx ? 2 : 3;
+        nng_carve(nnws, sets, n_sets, pts, n, searched, grid_w * grid_h);
+        st = nng_build(sets, n_sets, g, s); if (st != HIMO_OK) return st;
+        NngJob jobs[3] = {{0, 1, a.d_a, a.i_a}, {1, 0, a.d_b, a.i_b}, {2, 1, a.d_r, a.i_r}};
+        st = nng_query(sets, n_sets, jobs, n_sets, g, s); if (st != HIMO_OK) return st;
         if (d_raw_idx) { a.d_r = const_cast<float*>(d_raw_dist2); a.i_r = const_cast<int*>(reinterpret_cast<const int*>(d_raw_idx)); }
-        else { NNG(n0, d_pc0, n1, d_pc1, a.d_r, a.i_r); }
     }
     // dynamic subsets
     if (n0 > 0) {
@@ -361,11 +362,15 @@ extern "C" int himo_ssl_loss_ex(int n0, int n1, const float* d_pc0, const float*
     HIMO_HIP(hipMemcpyAsync(h_counts, a.counts, 8, hipMemcpyDeviceToHost, s));
     HIMO_HIP(hipStreamSynchronize(s));
     const int nd0 = h_counts[0], nd1 = h_counts[1];
-    if (nd0 > 0 && nd1 > 0) {
-        NNG(nd0, a.mdyn, nd1, a.qdyn, a.d_c, a.i_c);
-        NNG(nd1, a.qdyn, nd0, a.mdyn, a.d_d, a.i_d);
+    if (nd0 > 0 && nd1 > 0) {           // the dynamic subsets, both directions in one launch (the workspace of the full search is free again)
+        NngSet sets[2];
+        const float* pts[2] = {a.mdyn, a.qdyn};
+        const int n[2] = {nd0, nd1}, searched[2] = {1, 1};
+        nng_carve(nnws, sets, 2, pts, n, searched, grid_w * grid_h);
+        st = nng_build(sets, 2, g, s); if (st != HIMO_OK) return st;
+        NngJob jobs[2] = {{0, 1, a.d_c, a.i_c}, {1, 0, a.d_d, a.i_d}};
+        st = nng_query(sets, 2, jobs, 2, g, s); if (st != HIMO_OK) return st;
     }
-#undef NNG
     if (n0 > 0 && n1 > 0) {
         hipLaunchKernelGGL(cluster_anchor_kernel, dim3(blocks0), dim3(256), 0, s, a);
         hipLaunchKernelGGL(cluster_count_kernel, dim3(blocks0), dim3(256), 0, s, a);

@@ -44,7 +44,7 @@ def nn_grid(query: torch.Tensor, ref: torch.Tensor, return_index: bool = True):
     nq, nr = q.shape[0], r.shape[0]
     d2 = torch.empty(nq, dtype=torch.float32, device=dev)
     idx = torch.empty(nq, dtype=torch.int32, device=dev) if return_index else None
-    ws = torch.empty(int(lib.himo_nn_grid_workspace_bytes(nr, GRID_W, GRID_H)), dtype=torch.uint8, device=dev)
+    ws = torch.empty(int(lib.himo_nn_grid_workspace_bytes(max(nq, nr), GRID_W, GRID_H)), dtype=torch.uint8, device=dev)
     _lib.check(lib.himo_nn_grid(nq, _lib.ptr(q), nr, _lib.ptr(r), GRID_X0, GRID_Y0, GRID_CELL, GRID_W, GRID_H, _lib.ptr(d2),
                                 _lib.ptr(idx), _lib.ptr(ws), ws.numel(), _lib.stream_handle()), "himo_nn_grid")
     return (d2, idx) if return_index else d2
@@ -69,7 +69,7 @@ class SeFlowLoss:
         if getattr(self, "_raw_d2", None) is None or self._raw_d2.numel() < n0:
             self._raw_d2 = torch.empty(max(n0, 1), dtype=torch.float32, device=dev)
             self._raw_idx = torch.empty(max(n0, 1), dtype=torch.int32, device=dev)
-        need = int(self.lib.himo_nn_grid_workspace_bytes(n1, GRID_W, GRID_H))
+        need = int(self.lib.himo_nn_grid_workspace_bytes(max(n0, n1), GRID_W, GRID_H))
         if getattr(self, "_raw_ws", None) is None or self._raw_ws.numel() < need:
             self._raw_ws = torch.empty(need + 64, dtype=torch.uint8, device=dev)
         _lib.check(self.lib.himo_nn_grid(n0, _lib.ptr(p0), n1, _lib.ptr(p1), GRID_X0, GRID_Y0, GRID_CELL, GRID_W, GRID_H, _lib.ptr(self._raw_d2),

@@ -420,9 +420,11 @@ int himo_head_final(int64_t n, const float* d_y1, int y1_pitch, const float* d_w
  * assets/slurm/ssl-train-av2.sh:33.  Definitions: himo_amd/csrc/sslloss.hip header (this build's own spec).
  */
 /* exact k=1 NN between two sweeps through a uniform BEV grid (cell metres, grid_w x grid_h cells from
- * (x0, y0); points outside are binned into border cells).  float32 [n][3] in, squared distances + int32
- * reference rows out (idx may be NULL; -1 / +inf when nr == 0).  Ties keep the lowest reference row. */
-size_t himo_nn_grid_workspace_bytes(int64_t n_ref, int grid_w, int grid_h);
+ * (x0, y0), at most 2^20 cells; points outside are binned into border cells).  float32 [n][3] in, squared distances + int32
+ * reference rows out (idx may be NULL; -1 / +inf when nr == 0).  Ties keep the lowest reference row.  BOTH sets are
+ * binned (the query side is searched in cell order, 64 neighbouring queries per block): the workspace is sized for
+ * n_max = max(nq, nr). */
+size_t himo_nn_grid_workspace_bytes(int64_t n_max, int grid_w, int grid_h);
 int himo_nn_grid(int64_t nq, const float* d_q, int64_t nr, const float* d_r, float x0, float y0, float cell,
                  int grid_w, int grid_h, float* d_dist2, int32_t* d_idx, void* d_workspace,
                  size_t workspace_bytes, void* stream);

@@ -51,6 +51,68 @@ def test_nn_grid_matches_brute_force_kernel_including_ties(gpu):
     assert torch.equal(idx, bi) and (idx < 3000).all()       # lowest index wins in both kernels
 
 
+def _density_case(name):
+    """query / reference clouds that break a one-lane-per-query grid walk: crowded cells, far walks, empty grids"""
+    from himo_amd.synthetic import make_frame
+    rng = np.random.default_rng(11)
+    if name == "rings":                     # LiDAR-shaped sweeps: ~600 points per cell near the sensor; walls the other sweep lacks
+        q, r = (make_frame(s, cloud="rings")["pc0"][:, :3].copy() for s in (0, 1))
+    elif name == "crowded":                 # 100k points in 2 m^2 (four cells), every fourth reference point duplicated: ties
+        r = rng.uniform([10.0, 10.0, -1.0], [11.4142, 11.4142, 1.0], (100_000, 3)).astype(np.float32)
+        r[25_000:50_000] = r[:25_000]
+        q = rng.uniform([9.5, 9.5, -1.0], [12.0, 12.0, 1.0], (100_000, 3)).astype(np.float32)
+    elif name == "far_apart":               # the two sets in opposite corners, partly outside the grid: every ring but the last is empty
+        q = rng.uniform([-60.0, -60.0, -3.0], [-40.0, -40.0, 3.0], (20_000, 3)).astype(np.float32)
+        r = rng.uniform([40.0, 40.0, -3.0], [60.0, 60.0, 3.0], (20_000, 3)).astype(np.float32)
+    elif name == "one_row":                 # everything on a line along x: one grid row holds all points
+        q = np.stack([rng.uniform(-50, 50, 30_000), np.full(30_000, 0.5), rng.uniform(-1, 1, 30_000)], 1).astype(np.float32)
+        r = np.stack([rng.uniform(-50, 50, 30_000), np.full(30_000, 0.5), rng.uniform(-1, 1, 30_000)], 1).astype(np.float32)
+    elif name == "sparse_queries":          # a handful of queries scattered over the grid against a full sweep
+        q = rng.uniform([-60, -60, -3], [60, 60, 3], (37, 3)).astype(np.float32)
+        r = make_frame(2, cloud="rings")["pc0"][:, :3].copy()
+    else:
+        raise ValueError(name)
+    return q, r
+
+
+@pytest.mark.parametrize("case", ["rings", "crowded", "far_apart", "one_row", "sparse_queries"])
+def test_nn_grid_is_exact_whatever_the_density(gpu, case):
+    """the same ROWS as the exhaustive kernel (csrc/nn.hip, pinned bit-for-bit against cKDTree in test_eval_gpu.py), ties
+    included, and cKDTree's distances"""
+    from himo_amd.eval import nearest_neighbor
+    from himo_amd.ssl_loss import nn_grid
+    import sslloss_oracle as so
+    q, r = _density_case(case)
+    tq, tr = torch.from_numpy(q).to(gpu), torch.from_numpy(r).to(gpu)
+    d2, idx = nn_grid(tq, tr)
+    bd, bi = nearest_neighbor(tq, tr)
+    assert torch.equal(idx, bi.to(idx.dtype))
+    diff = q.astype(np.float64) - r[idx.cpu().numpy().astype(np.int64)].astype(np.float64)
+    ref_d2, _ = so.nearest(q, r)
+    assert np.allclose((diff * diff).sum(1), ref_d2.astype(np.float64), rtol=1e-5, atol=1e-9)   # that row IS a nearest neighbour
+    assert np.allclose(d2.cpu().numpy(), ref_d2, rtol=1e-5, atol=1e-9)
+
+
+def test_nn_grid_does_not_depend_on_the_cell_size(gpu):
+    """finer / coarser / non-power-of-two cells return the same rows (the ring bound is conservative for any geometry)"""
+    import ctypes
+    from himo_amd import _lib
+    q, r = _density_case("rings")
+    q, r = q[:40_000], r[:40_000]
+    tq, tr = torch.from_numpy(q).to(gpu), torch.from_numpy(r).to(gpu)
+    lib = _lib.load()
+    rows = []
+    for cell, w in [(1.0, 104), (0.5, 208), (0.3, 347), (4.0, 26), (104.0, 1)]:
+        d2 = torch.empty(len(q), dtype=torch.float32, device=gpu)
+        idx = torch.empty(len(q), dtype=torch.int32, device=gpu)
+        ws = torch.empty(int(lib.himo_nn_grid_workspace_bytes(max(len(q), len(r)), w, w)), dtype=torch.uint8, device=gpu)
+        _lib.check(lib.himo_nn_grid(len(q), _lib.ptr(tq), len(r), _lib.ptr(tr), -52.0, -52.0, cell, w, w, _lib.ptr(d2), _lib.ptr(idx),
+                                    _lib.ptr(ws), ws.numel(), _lib.stream_handle()), "himo_nn_grid")
+        rows.append((idx.clone(), d2.clone()))
+    for idx, d2 in rows[1:]:
+        assert torch.equal(idx, rows[0][0]) and torch.equal(d2, rows[0][1])
+
+
 @pytest.mark.parametrize("n0,n1", [(4000, 3500), (30_000, 32_000), (120_000, 118_000)])      # incl. BASELINE size
 def test_loss_terms_and_gradient(gpu, n0, n1):
     import sslloss_oracle as so
