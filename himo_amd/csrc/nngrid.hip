@@ -37,7 +37,6 @@
 namespace himo {
 
 constexpr int kNngWaves = 8;          // waves of a query block (a power of two): they share a ring's candidates
-constexpr int kNngChunk = 8;          // candidates per scalar-load batch
 constexpr int kNngSegCells = 16;      // widest stretch of a grid row one segment covers
 constexpr int kNngScanChunk = 4096;   // cells per iteration of the one-block scan
 
@@ -120,9 +119,11 @@ __device__ inline unsigned long long nng_key(float d, int row) {
     return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)row;
 }
 constexpr unsigned long long kNngNone = 0x7f800000ffffffffull;
+typedef float float2v __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(64 * kNngWaves) void nng_query_kernel(NngArgs a) {
     __shared__ unsigned long long s_best[2][kNngWaves][64];
+    __shared__ __attribute__((aligned(16))) float s_cand[kNngWaves][64 * 4];    // per wave: 32 candidate PAIRS [x0 x1 y0 y1 z0 z1 row0 row1]
     const NngJob& job = a.job[blockIdx.y];
     const NngSet& Q = a.set[job.q];
     const NngSet& R = a.set[job.r];
@@ -137,14 +138,18 @@ __global__ __launch_bounds__(64 * kNngWaves) void nng_query_kernel(NngArgs a) {
     int cx, cy;
     cell_of(g, qx, qy, cx, cy);
     unsigned long long best = kNngNone;
+    float best_d = INFINITY;                 // the distance half of `best`
+    const float2v q2x{qx, qx}, q2y{qy, qy}, q2z{qz, qz};
     if (R.n > 0) {
         const int* __restrict__ off = R.offset;
         const int* __restrict__ off_t = R.offset_t;
         const float4* __restrict__ rows = R.sorted;
         const float4* __restrict__ cols = R.sorted_t;
+        float* const mine = s_cand[wave];
+        float* const my_slot = mine + (lane >> 1) * 8 + (lane & 1);
         // a bound computed in float32 from cell indices may exceed the true clearance by a rounding error of the coordinates
         const float slack = 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(g.x0) + fabsf(g.y0) + g.cell);
-        int par = 0;
+        int par = 0, turn = 0;          // turn: pieces handed out so far -- piece t goes to wave t % kNngWaves, across rings
         unsigned long long pending = __ballot(valid);
         while (pending) {
             // the next segment: the first unserved query's grid row, from its cell to at most kNngSegCells further (the sorted
@@ -160,56 +165,100 @@ __global__ __launch_bounds__(64 * kNngWaves) void nng_query_kernel(NngArgs a) {
             const float m = fmaxf(0.f, fminf(fminf(qx - lxa, lxb - qx), fminf(qy - ly, ly + g.cell - qy)) - slack);
             const int rmax = max(max(xa, g.gw - 1 - xb), max(y0, g.gh - 1 - y0));
             bool alive = act;
+            bool fresh = false;         // candidates seen since the last merge
+            int check = 0;              // the next ring after which the waves merge and the lanes test their bound
+            int rbase = -8, ofs = 0;    // lane l of `ofs`: run bound (l & 7) of ring rbase + (l >> 3)
             for (int ring = 0; ring <= rmax; ++ring) {
-                const int xl = xa - ring, xr = xb + ring, yl = y0 - ring, yh = y0 + ring;
-                const int cxl = max(xl, 0), cxr = min(xr, g.gw - 1);
-                // the ring's runs: [0] top row, [1] bottom row (cells cxl..cxr of the row-major copy), [2] left column, [3] right
-                // column (rows yl+1..yh-1 of the column-major copy); absent ones (outside the grid, ring 0) are empty
-                int b0, e0, b1 = 0, e1 = 0, b2 = 0, e2 = 0, b3 = 0, e3 = 0;
-                if (ring == 0) {
-                    b0 = off[y0 * g.gw + xa]; e0 = off[y0 * g.gw + xb + 1];
-                } else {
-                    const int ry0 = max(yl, 0), ry1 = min(yh, g.gh - 1);
-                    const int cyl = max(yl + 1, 0), cyh = min(yh - 1, g.gh - 1);
-                    b0 = off[ry0 * g.gw + cxl]; e0 = off[ry0 * g.gw + cxr + 1];
-                    b1 = off[ry1 * g.gw + cxl]; e1 = off[ry1 * g.gw + cxr + 1];
-                    b2 = off_t[cxl * g.gh + cyl]; e2 = off_t[cxl * g.gh + cyh + 1];
-                    b3 = off_t[cxr * g.gh + cyl]; e3 = off_t[cxr * g.gh + cyh + 1];
-                    if (yl < 0) e0 = b0;
-                    if (yh >= g.gh) e1 = b1;
-                    if (xl < 0) e2 = b2;
-                    if (xr >= g.gw) e3 = b3;
+                if (ring >= rbase + 8) {
+                    // the run bounds of the next eight rings in ONE vector load.  A ring's runs: [0] top row, [1] bottom row
+                    // (cells xl..xr of the row-major copy), [2] left column, [3] right column (rows yl+1..yh-1 of the column-major copy)
+                    rbase = ring;
+                    const int r = rbase + (lane >> 3), k = lane & 7;
+                    const int cxl = clampi(xa - r, 0, g.gw - 1), cxr = clampi(xb + r, 0, g.gw - 1);
+                    const int ry = clampi((k & 2) ? y0 + r : y0 - r, 0, g.gh - 1);
+                    const int cyl = clampi(y0 - r + 1, 0, g.gh - 1), cyh = clampi(y0 + r - 1, 0, g.gh - 1);
+                    const int row_major = ry * g.gw + ((k & 1) ? cxr + 1 : cxl);
+                    const int col_major = ((k & 2) ? cxr : cxl) * g.gh + ((k & 1) ? cyh + 1 : cyl);
+                    ofs = (k & 4) ? off_t[col_major] : off[row_major];
                 }
-                int turn = 0;           // chunks of this ring so far: chunk t goes to wave t % kNngWaves
-                auto scan = [&](const float4* __restrict__ arr, int b, int e) {
-                    const int n_chunks = (e - b + kNngChunk - 1) / kNngChunk;
-                    for (int t = (wave - turn) & (kNngWaves - 1); t < n_chunks; t += kNngWaves) {
-                        const int k = b + t * kNngChunk;
-                        float4 p[kNngChunk];
-#pragma unroll
-                        for (int j = 0; j < kNngChunk; ++j) p[j] = arr[min(k + j, e - 1)];      // past the end: the last one again
-#pragma unroll
-                        for (int j = 0; j < kNngChunk; ++j) {
-                            const float dx = qx - p[j].x, dy = qy - p[j].y, dz = qz - p[j].z;
-                            const unsigned long long key = nng_key(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), __float_as_int(p[j].w));
-                            best = key < best ? key : best;
+                const int sl = (ring - rbase) * 8;
+                const int b0 = __builtin_amdgcn_readlane(ofs, sl), b1 = __builtin_amdgcn_readlane(ofs, sl + 2);
+                const int b2 = __builtin_amdgcn_readlane(ofs, sl + 4), b3 = __builtin_amdgcn_readlane(ofs, sl + 6);
+                int n0 = __builtin_amdgcn_readlane(ofs, sl + 1) - b0, n1 = __builtin_amdgcn_readlane(ofs, sl + 3) - b1;
+                int n2 = __builtin_amdgcn_readlane(ofs, sl + 5) - b2, n3 = __builtin_amdgcn_readlane(ofs, sl + 7) - b3;
+                if (ring == 0) { n1 = 0; n2 = 0; n3 = 0; }         // ring 0 is the rectangle itself: one run
+                else {
+                    if (y0 - ring < 0) n0 = 0;                      // a side of the ring outside the grid
+                    if (y0 + ring >= g.gh) n1 = 0;
+                    if (xa - ring < 0) n2 = 0;
+                    if (xb + ring >= g.gw) n3 = 0;
+                }
+                // the ring's candidates as ONE list (the four runs end to end), cut into pieces of 16 / 32 / 64; a piece is one
+                // coalesced vector load of its wave (a lane per candidate), parked in the wave's LDS slice and read back as
+                // broadcasts: every lane tests every candidate of the piece against its own query
+                const int p1 = n0, p2 = p1 + n1, p3 = p2 + n2, total = p3 + n3;
+                if (total > 0) {
+                    fresh = true;
+                    // (short walks split a ring finely so that all waves share it; from ring 4 on the merges are rings apart and
+                    // whole 64-candidate pieces -- often a whole ring -- go to the waves in turn: a wave then pays the memory latency of
+                    // every eighth ring instead of every ring's)
+                    const int lg = (ring >= 4 || total >= 32 * kNngWaves) ? 6 : (total >= 16 * kNngWaves ? 5 : 4);
+                    const int pieces = (total + (1 << lg) - 1) >> lg;
+                    for (int t = (wave - turn) & (kNngWaves - 1); t < pieces; t += kNngWaves) {
+                        const int x = min((t << lg) + lane, total - 1);                 // past the end: the last candidate again
+                        const int in_run = x >= p3 ? b3 + (x - p3) : (x >= p2 ? b2 + (x - p2) : (x >= p1 ? b1 + (x - p1) : b0 + x));
+                        if (lane < (1 << lg)) {
+                            const float4 c = (x >= p2 ? cols : rows)[in_run];
+                            my_slot[0] = c.x; my_slot[2] = c.y; my_slot[4] = c.z; my_slot[6] = c.w;
                         }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        // eight candidates (four pairs) per step, the LDS reads in flight before the first use; the slots past the
+                        // piece's last candidate hold that candidate again (pieces are multiples of 16 slots).  FAST REJECT: after the
+                        // first ring or two a lane's best rarely improves, so a step computes its eight distances on packed float32
+                        // pairs, reduces them to their minimum, and only when that reaches SOME lane's best (ties included) does the
+                        // wave take the exact (distance, row) update of the step -- 4.5 vector instructions per candidate instead of 9
+                        const int steps = (min(1 << lg, total - (t << lg)) + 7) >> 3;
+                        for (int j = 0; j < steps; ++j) {
+                            float2v d[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float4 u = *reinterpret_cast<const float4*>(mine + (j * 4 + i) * 8);          // x0 x1 y0 y1
+                                const float2v z = *reinterpret_cast<const float2v*>(mine + (j * 4 + i) * 8 + 4);    // z0 z1
+                                const float2v dx = q2x - float2v{u.x, u.y}, dy = q2y - float2v{u.z, u.w}, dz = q2z - z;
+                                d[i] = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                            }
+                            const float lo = fminf(fminf(fminf(d[0].x, d[0].y), fminf(d[1].x, d[1].y)), fminf(fminf(d[2].x, d[2].y), fminf(d[3].x, d[3].y)));
+                            if (__ballot(lo <= best_d) != 0ull) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const float2v row = *reinterpret_cast<const float2v*>(mine + (j * 4 + i) * 8 + 6);  // row0 row1
+                                    const unsigned long long k0 = nng_key(d[i].x, __float_as_int(row.x)), k1 = nng_key(d[i].y, __float_as_int(row.y));
+                                    best = k0 < best ? k0 : best;
+                                    best = k1 < best ? k1 : best;
+                                }
+                                best_d = __uint_as_float((unsigned)(best >> 32));
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
                     }
-                    turn += n_chunks;
-                };
-                scan(rows, b0, e0);
-                scan(rows, b1, e1);
-                scan(cols, b2, e2);
-                scan(cols, b3, e3);
-                if (turn > 0) {         // the ring held candidates: merge the four waves' (distance, row)
+                    turn += pieces;
+                }
+                if (ring < check && ring < rmax) continue;         // rings 0 1 2 3 5 8 13 20 31 ... : far walkers merge less often
+                check = ring + 1 + (ring >= 3 ? ring / 2 : 0);
+                if (fresh) {            // merge the waves' (distance, row)
                     s_best[par][wave][lane] = best;
                     __syncthreads();
 #pragma unroll
                     for (int w = 0; w < kNngWaves; ++w) { const unsigned long long o = s_best[par][w][lane]; best = o < best ? o : best; }
-                    par ^= 1;           // the next merge writes the other buffer: one barrier per ring
+                    best_d = __uint_as_float((unsigned)(best >> 32));
+                    par ^= 1;           // the next merge writes the other buffer: one barrier per merge
+                    fresh = false;
                 }
                 const float reach = (float)ring * g.cell + m;
-                if (best != kNngNone && __uint_as_float((unsigned)(best >> 32)) <= reach * reach) alive = false;
+                if (best != kNngNone && best_d <= reach * reach) alive = false;
                 if (__ballot(alive) == 0ull) break;
             }
             pending &= ~actm;

@@ -12,10 +12,8 @@ from pathlib import Path
 R = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(R))
 VARIANTS = {                                  # name -> {constant: value}
-    "w8": {"kNngWaves": 8}, "w2": {"kNngWaves": 2}, "w16": {"kNngWaves": 16},
-    "seg8": {"kNngSegCells": 8}, "seg32": {"kNngSegCells": 32}, "seg4": {"kNngSegCells": 4},
-    "chunk4": {"kNngChunk": 4}, "chunk16": {"kNngChunk": 16},
-    "w8seg8": {"kNngWaves": 8, "kNngSegCells": 8},
+    "w4": {"kNngWaves": 4}, "w16": {"kNngWaves": 16},
+    "seg8": {"kNngSegCells": 8}, "seg32": {"kNngSegCells": 32},
 }
 
 
