@@ -902,11 +902,17 @@ def extra_workload_legs(args, device) -> dict:
     import torch
     from himo_amd import _lib
     out = {}
-    for name, steps, warm in (("train", args.leg_train_steps, 2), ("fastnsf", args.leg_fastnsf_fits, 1)):
+    legs = [("train", args.leg_train_steps, 2), ("fastnsf", args.leg_fastnsf_fits, 1)]
+    if args.cloud == "uniform":         # the training step again on LiDAR-shaped sweeps (himo_amd.synthetic.lidar_rings: crowded cells near the
+        legs.insert(1, ("train_rings", args.leg_train_steps, 2))       # sensor, surfaces the other sweep lacks): `leg_train_rings` must stay near `leg_train`
+    for leg_name, steps, warm in legs:
         if steps <= 0:
             continue
+        name = "train" if leg_name.startswith("train") else leg_name
         a = copy.copy(args)
         a.workload, a.frames_per_step = name, 1
+        if leg_name == "train_rings":
+            a.cloud = "rings"
         result = {}
         try:
             if name == "train":
@@ -968,7 +974,7 @@ def extra_workload_legs(args, device) -> dict:
                           "flow_mean_epe_vs_generating_flow": float(np.linalg.norm(got - fr[0]["flow"], axis=1).mean()),
                           "note": "gradient / trajectory parity vs the CPU restatement (oracle/fastnsf_oracle.py, unpinned): tests/test_fastnsf_gpu.py"}
             leg = {"frames_per_s": steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warm,
-                   "points_per_frame": a.points, "workload": workload, "dtype": dtype, "roofline": roof, "parity": parity}
+                   "points_per_frame": a.points, "cloud": a.cloud, "workload": workload, "dtype": dtype, "roofline": roof, "parity": parity}
             if name == "train" and side:
                 leg["frames_per_s_without_side_streams"] = 1.0 / el_train_single
             if name == "fastnsf" and el_single is not None:
@@ -976,9 +982,9 @@ def extra_workload_legs(args, device) -> dict:
                 leg["frames_per_s_one_fit_at_a_time"] = 1.0 / el_single
         except Exception as e:                                      # a leg must never cost the main line
             leg = {"error": f"{type(e).__name__}: {e}"}
-        out[f"leg_{name}"] = leg
+        out[f"leg_{leg_name}"] = leg
         if "frames_per_s" in leg:
-            out[f"value_{name}"] = leg["frames_per_s"]
+            out[f"value_{leg_name}"] = leg["frames_per_s"]
         step = obj = result = None
         torch.cuda.empty_cache()
     return out
