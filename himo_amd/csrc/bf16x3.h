@@ -32,25 +32,19 @@ __device__ inline void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
 // low parts would sit deep in the subnormal range) that absolute floor would cost precision, so they are packed
 // multiplied by 2^6 -- exact, |w| < 1023 -- and the accumulator is multiplied by 2^-6 in the epilogue (measured flow error
 // without the weight scale 5.3e-5, with it 3.1e-5 = the float32-MFMA kernels' own 3.05e-5).
-// One accumulator instead of two halves the accumulator registers: the 4-row convolution tiles and the fused head run
+// One accumulator instead of two (the form of rounds 1-2: l' = 2^11 (x - h), always a normal number, cross terms in a second
+// accumulator; removed in round 5) halves the accumulator registers: the 4-row convolution tiles and the fused head run
 // three waves per SIMD instead of two (+13 % on the 128/256-channel layers).
-// -DHIMO_F16_SCALED builds the earlier form: l' = 2^11 (x - h) (always a normal number), cross terms in a second
-// accumulator, result = acc0 + 2^-11 acc1.
-// Range: |x| must stay below 65504 (fp16 max) -- true for normalised activations; the bf16 split has float32's range.
+// Range: |x| must stay below 65504 (fp16 max) -- true for normalised activations; the bf16 split has float32's range -- and
+// a layer whose values ALL sit below ~2^-6 has lost the relative precision (the absolute floor above): both ends are watched
+// at run time (the head's finite-flow word, the split-output epilogues' range word: conv_common.h note_range) and
+// pipeline.HiMoPipeline(precision="auto") leaves for the bf16 split when either fires.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-#ifdef HIMO_F16_SCALED
-constexpr bool kF16Scaled = true;
-constexpr float kF16LowScale = 2048.0f, kF16LowInv = 1.0f / 2048.0f;
-constexpr float kF16WeightScale = 1.0f, kF16AccScale = 1.0f;
-#else
-constexpr bool kF16Scaled = false;
-constexpr float kF16LowScale = 1.0f, kF16LowInv = 1.0f;
 constexpr float kF16WeightScale = 64.0f, kF16AccScale = 1.0f / 64.0f;
-#endif
 
 __device__ inline void split2(float x, unsigned& h, unsigned& l) {
     const _Float16 hh = (_Float16)x;                            // round to nearest even
-    const _Float16 ll = (_Float16)((x - (float)hh) * kF16LowScale);
+    const _Float16 ll = (_Float16)(x - (float)hh);
     h = __builtin_bit_cast(unsigned short, hh);
     l = __builtin_bit_cast(unsigned short, ll);
 }
@@ -69,7 +63,7 @@ typedef _Float16 himo_half2 __attribute__((ext_vector_type(2)));
 __device__ inline unsigned split2_packed(float x) {
     asm("" : "+v"(x));
     const _Float16 hh = (_Float16)x;
-    const _Float16 ll = (_Float16)((x - (float)hh) * kF16LowScale);
+    const _Float16 ll = (_Float16)(x - (float)hh);
     return __builtin_bit_cast(unsigned, himo_half2{hh, ll});
 }
 

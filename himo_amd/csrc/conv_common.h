@@ -31,6 +31,7 @@ struct ConvArgs {
     const float* aux_in; int aux_in_pitch;                    // z (kEpiGruQ) / h (kEpiGruZR), [rows][pitch]
     float* aux_out; int aux_out_pitch;                        // r*h (kEpiGruZR) / h in place (kEpiGruQ)
     int act_flags;                                            // kActSplitIn | kActSplitOut: split activation format (convsg.hip)
+    unsigned* range_seen;                                     // himo_conv_desc.d_range_seen (split outputs; may be null)
 };
 enum ActFlags { kActSplitIn = 1, kActSplitOut = 2, kActVecStore = 4, kActAccumulate = 8 };
 // kActVecStore: set by the launchers (vec_store_ok).  kActAccumulate (HIMO_ACT_ACCUMULATE): y += result -- float32 output of the
@@ -147,6 +148,18 @@ __device__ inline void split_store(const ConvArgs& a, float* __restrict__ yout, 
         rec[co & 15] = (unsigned short)h;
         rec[16 + (co & 15)] = (unsigned short)l;
     }
+}
+
+// Low-side guard of the two-term fp16 split (bf16x3.h: below |x| = 1/4 the low part is an fp16 subnormal, a value keeps 2^-25
+// ABSOLUTE): a split-output epilogue hands ONE of its values per lane here; the layer's word is set as soon as one of them
+// reaches 2^-6 (where the split still carries 19 bits).  A layer whose word stays 0 lives wholly on the absolute floor -- e.g.
+// a BatchNorm gamma of 1e-3 compensated by large weights one layer on multiplies that floor straight into the flow (measured:
+// 1.3e-4 at gain 1e-3, tests/test_parity_hardening_gpu.py).  Cost: a compare, a branch and -- until the word is set -- a store.
+constexpr float kSplitRangeGuard = 0.015625f;
+__device__ inline void note_range(const ConvArgs& a, float v) {
+    if (a.range_seen && __ballot(fabsf(v) >= kSplitRangeGuard) != 0ull && (threadIdx.x & 63) == 0 &&
+        __hip_atomic_load(a.range_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        __hip_atomic_store(a.range_seen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // the output admits 16-byte stores: base, pitches and strides multiples of four floats, whole 4-channel groups

@@ -111,17 +111,12 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
     for (int mi = 0; mi < MI; ++mi) ppA[mi] = KS == 1 ? (wm * MI + mi) * 32 + li : (wm * MI + mi) * PW + li;
 
     floatx16 acc[MI][NI];
-    constexpr bool XACC = FMT == 2 && kF16Scaled;               // scaled fp16 split: the cross terms (scaled by 2^11)
-    floatx16 acx[XACC ? MI : 1][XACC ? NI : 1];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc[mi][ni][r] = 0.f;
-                if (XACC) acx[mi][ni][r] = 0.f;
-            }
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int iy0 = oy0 - (KS / 2), ix0 = ox0 - (KS / 2);
     const int64_t in_rows = (int64_t)a.H * a.W;
@@ -246,8 +241,7 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
                 } else if constexpr (FMT == 4) {
                     HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
                 } else {
-                    if constexpr (XACC) { HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1) }
-                    else { HIMO_TERM16(acc, 1, 0) HIMO_TERM16(acc, 0, 1) HIMO_TERM16(acc, 0, 0) }
+                    HIMO_TERM16(acc, 1, 0) HIMO_TERM16(acc, 0, 1) HIMO_TERM16(acc, 0, 0)
                 }
 #undef HIMO_TERM16
 #undef HIMO_TERM
@@ -294,7 +288,6 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
                     pix = (int64_t)oy * a.Wo + ox;
                 }
                 float v = acc[mi][ni][r];
-                if (XACC) v += acx[mi][ni][r] * kF16LowInv;
                 if (kEpiAffine<EPI>) {
                     if (ok) yout[pix * a.y_pitch + co] = epi_activate<EPI>(v, eA, eB);
                 } else {

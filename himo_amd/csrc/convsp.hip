@@ -45,7 +45,7 @@ template <> struct PatchLayout<true> {
 // FMT = 4: the two-term bf16 split x = h + m (16 significant bits, float32 range; three products h*h + h*m + m*h) -- the data-gradient
 // convolutions of the mixed-precision training step (himo_conv_pack_weights_ex format 2); NP = planes of the format.
 template <int EPI, int PH, int FMT, int MI, int S>
-__global__ __launch_bounds__(256, (FMT != 3 && !kF16Scaled && S == 1) ? 3 : 2)
+__global__ __launch_bounds__(256, (FMT != 3 && S == 1) ? 3 : 2)
 void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int NP = FMT == 3 ? 3 : 2;
     constexpr int TW = 32, TH = MI * PH;
@@ -79,15 +79,10 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
 
     floatx16 acc[MI];
-    constexpr bool XACC = FMT == 2 && kF16Scaled;              // scaled fp16 split: separate cross-term accumulator
-    floatx16 acx[XACC ? MI : 1];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            acc[mi][r] = 0.f;
-            if (XACC) acx[mi][r] = 0.f;
-        }
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
 
     auto load_patch = [&](int slab, float4 (&r)[kPatchPerThread]) {
 #pragma unroll
@@ -188,8 +183,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
                 } else if constexpr (FMT == 4) {
                     HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
                 } else {
-                    if constexpr (XACC) { HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1) }
-                    else { HIMO_TERM16(acc, 1, 0) HIMO_TERM16(acc, 0, 1) HIMO_TERM16(acc, 0, 0) }
+                    HIMO_TERM16(acc, 1, 0) HIMO_TERM16(acc, 0, 1) HIMO_TERM16(acc, 0, 0)
                 }
 #undef HIMO_TERM16
 #undef HIMO_TERM
@@ -234,7 +228,6 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[mi][r];
-                if (XACC) v += acx[mi][r] * kF16LowInv;
                 if (kEpiAffine<EPI>) {
                     v = epi_activate<EPI>(v, eA, eB);
                 } else {
@@ -242,6 +235,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
                     v = epilogue_value<EPI>(v + bv, scv, shv);
                 }
                 word[r] = (FMT == 2 && osplit) ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
+                if (FMT == 2 && mi == 0 && r == 0 && osplit) note_range(a, v);
             }
             if (FMT == 2 && osplit) store_block_vec<true>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, oy < a.Ho ? n_px : 0, tn * BN + wc * 32);
             else if (FMT == 4 && (a.act_flags & kActAccumulate))
@@ -263,7 +257,6 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         for (int r = 0; r < 16; ++r) {
             const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             float v = acc[mi][r];
-            if (XACC) v += acx[mi][r] * kF16LowInv;
             if (oy < a.Ho && ox < a.Wo) {
                 const int64_t pix = (int64_t)oy * a.Wo + ox;
                 if (kEpiAffine<EPI>) {

@@ -94,20 +94,10 @@ __device__ inline void a_store(unsigned char* A, int row, int k, float v) {
 }
 
 // acc[rt][t] += A[rows of tile rt][0..192) * W[:, col[t] + li] for the wave's NT column tiles; RT row tiles starting at rt0
-// FMT = 2: one accumulator (bf16x3.h); with -DHIMO_F16_SCALED acx collects the 2^11-scaled cross terms
+// FMT = 2: one accumulator for the three terms of the fp16 split (bf16x3.h)
 template <int RT, int NT, int FMT, int SLABS>
 __device__ inline void gemm192(const unsigned char* A, const unsigned short* __restrict__ wpk, int cout, const int (&col)[NT],
                                floatx16 (&acc)[RT][NT], int rt0, int li, int lh) {
-    constexpr bool XACC = FMT == 2 && kF16Scaled;
-    floatx16 acx[XACC ? RT : 1][XACC ? NT : 1];
-    if (XACC) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acx[rt][t][r] = 0.f;
-    }
     uint4 bcur[NT][FMT], bnxt[NT][FMT];
     auto load_b = [&](int slab, uint4 (&b)[NT][FMT]) {
 #pragma unroll
@@ -137,8 +127,7 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
         if constexpr (FMT == 3) {
             HIMO_TERM(2, 0) HIMO_TERM(0, 2) HIMO_TERM(1, 1) HIMO_TERM(1, 0) HIMO_TERM(0, 1) HIMO_TERM(0, 0)
         } else {
-            if constexpr (XACC) { HIMO_TERM16(acx, 1, 0) HIMO_TERM16(acc, 0, 0) HIMO_TERM16(acx, 0, 1) }
-            else { HIMO_TERM16(acc, 1, 0) HIMO_TERM16(acc, 0, 1) HIMO_TERM16(acc, 0, 0) }
+            HIMO_TERM16(acc, 1, 0) HIMO_TERM16(acc, 0, 1) HIMO_TERM16(acc, 0, 0)
         }
 #undef HIMO_TERM16
 #undef HIMO_TERM
@@ -154,7 +143,7 @@ __device__ inline void gemm192(const unsigned char* A, const unsigned short* __r
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    acc[rt][t][r] = (XACC ? acc[rt][t][r] + acx[rt][t][r] * kF16LowInv : acc[rt][t][r]) * kF16AccScale;
+                    acc[rt][t][r] = acc[rt][t][r] * kF16AccScale;
     }
 }
 
@@ -169,7 +158,7 @@ __device__ inline void sv_store(float* base, unsigned byte_off, float v) {
 }
 
 template <int FMT, int SLABS, bool SAVE = false>
-__global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_head_kernel(GruHeadArgs a, GruHeadBatch batch, GruHeadSave sv) {
+__global__ __launch_bounds__(256, FMT == 2 ? 3 : 2) void gru_head_kernel(GruHeadArgs a, GruHeadBatch batch, GruHeadSave sv) {
     constexpr bool FOLD = SLABS == 9;
     static_assert(!(SAVE && FOLD), "the training forward keeps x explicit");
     constexpr int kGhPlane = SLABS * kGhRows * 32;
@@ -263,7 +252,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    h[rt][r] = cell[rt][r] >= 0 ? (float)__builtin_bit_cast(_Float16, hh[rt][r]) + (float)__builtin_bit_cast(_Float16, ll[rt][r]) * kF16LowInv : 0.f;
+                    h[rt][r] = cell[rt][r] >= 0 ? (float)__builtin_bit_cast(_Float16, hh[rt][r]) + (float)__builtin_bit_cast(_Float16, ll[rt][r]) : 0.f;
         } else {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -281,7 +270,7 @@ __global__ __launch_bounds__(256, (FMT == 2 && !kF16Scaled) ? 3 : 2) void gru_he
                     for (int r = 0; r < 16; ++r) {
                         unsigned hh, ll;
                         split2(h[rt][r], hh, ll);
-                        h[rt][r] = (float)__builtin_bit_cast(_Float16, (unsigned short)hh) + (float)__builtin_bit_cast(_Float16, (unsigned short)ll) * kF16LowInv;
+                        h[rt][r] = (float)__builtin_bit_cast(_Float16, (unsigned short)hh) + (float)__builtin_bit_cast(_Float16, (unsigned short)ll);
                     }
             }
         }

@@ -49,8 +49,9 @@ class HiMoPipeline:
                  precision: str = "auto", params: dict | None = None):
         """``net``: a ready network, or None to build one from ``params`` (random-init when None; ``max_batch`` samples per
         backbone launch).  ``precision``: "bf16x3" | "f16x2" | "f32" (see SeFlowNet) or "auto": start in the fast fp16
-        split, check every batch's flow for non-finite values and, the first time an activation leaves fp16's range,
-        rebuild the network in the bf16 split (float32 range), redo that batch and stay there."""
+        split, check every batch's guard words (a non-finite flow value = an activation left fp16's range; a split-output
+        layer without a single value above 2^-6 = activations on the split's absolute floor) and, the first time one fires,
+        rebuild the network in the bf16 split (float32 range and relative precision), redo that batch and stay there."""
         self.device = device if device is not None else _lib.require_gpu()
         self.auto = net is None and precision == "auto"
         self._net_args = dict(params=params, device=self.device, max_points=max_points, max_batch=max_batch)
@@ -138,21 +139,33 @@ class HiMoPipeline:
             self.net.clear_nonfinite()
 
     def _guard_now(self) -> bool:
-        """True when the launches since ``_guard_begin`` wrote only finite flow values (one 4-byte read back: a host sync)"""
-        return self.net.precision != "f16x2" or int(self.net.nonfinite.item()) == 0
+        """True when the launches since ``_guard_begin`` wrote only finite flow values AND every split-output layer produced
+        values above the fp16 split's absolute floor (one small read back: a host sync); the reason otherwise in ``_guard_why``"""
+        if self.net.precision != "f16x2":
+            return True
+        self._guard_why = self.net.guard_verdict(self.net.guard.cpu().tolist())
+        return self._guard_why is None
 
     def _guard_later(self):
-        """queue the read-back of the guard word (4 bytes into pinned memory + an event) for ``sync_check`` one batch later"""
+        """queue the read-back of the guard words (into pinned memory + an event) for ``sync_check`` one batch later"""
         if self.net.precision != "f16x2":
             return
         if not hasattr(self, "_flag_ring"):
-            self._flag_ring, self._flag_next = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)], 0
+            self._flag_ring, self._flag_next = [torch.zeros(self.net.guard.numel(), dtype=torch.int32).pin_memory() for _ in range(2)], 0
         host = self._flag_ring[self._flag_next]
         self._flag_next ^= 1
-        host.copy_(self.net.nonfinite, non_blocking=True)
+        host.copy_(self.net.guard, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        self._finite = (host, ev)
+        self._finite = (host, ev, self.net)
+
+    @staticmethod
+    def _guard_error(why: str) -> FloatingPointError:
+        if why == "overflow":
+            return FloatingPointError("non-finite flow: activations left the fp16 range of precision='f16x2'; "
+                                      "use precision='bf16x3' (or 'auto') for these weights")
+        return FloatingPointError("a layer's activations stayed below 2^-6, on the absolute floor (2^-25) of precision='f16x2''s "
+                                  "two-term fp16 split: the flow may miss 1e-4; use precision='bf16x3' (or 'auto') for these weights")
 
     def flows(self, samples) -> list:
         """Network only, for a list of samples: [(N0_k,3) flow incl. ego motion] -- the h5 ``<res_name>`` payload that
@@ -173,22 +186,22 @@ class HiMoPipeline:
     def _flows_check(self, samples, outs):
         if not self._guard_now():
             if not self.auto:
-                raise FloatingPointError("non-finite flow: activations left the fp16 range of precision='f16x2'; "
-                                         "use precision='bf16x3' (or 'auto') for these weights")
+                raise self._guard_error(self._guard_why)
             self._fall_back()
             self._forward(samples, outs)
         return outs
 
     def sync_check(self):
         """fp16-split precision only: an activation beyond fp16's range (65504) turns into NaN at the next layer's
-        split and reaches the flow; this raises instead of handing such a batch on.  Checked one batch late by
+        split and reaches the flow, and a layer whose activations all sit below 2^-6 has lost the split's relative
+        precision; this raises instead of handing such a batch on.  Checked one batch late by
         ``run`` (so it never stalls the stream) and by the caller after the last batch."""
         if self._finite is not None:
-            (host, ev), self._finite = self._finite, None
+            (host, ev, net), self._finite = self._finite, None
             ev.synchronize()
-            if int(host.item()) != 0:
-                raise FloatingPointError("non-finite flow: activations left the fp16 range of precision='f16x2'; "
-                                         "use SeFlowNet(precision='bf16x3') for these weights")
+            why = net.guard_verdict(host.tolist())
+            if why is not None:
+                raise self._guard_error(why)
 
     def flow(self, s: Sample, out: torch.Tensor | None = None) -> torch.Tensor:
         """Network only: (N0,3) flow including ego motion (the h5 ``<res_name>`` payload)."""

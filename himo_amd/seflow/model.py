@@ -32,7 +32,7 @@ class ConvDesc(ctypes.Structure):
                 ("aux_out", ctypes.c_void_p), ("aux_out_pitch", ctypes.c_int), ("w_packed", ctypes.c_void_p),
                 ("tile_hint", ctypes.c_int), ("packed_format", ctypes.c_int),
                 ("n_outer", ctypes.c_int), ("x_outer_stride", ctypes.c_int64), ("y_outer_stride", ctypes.c_int64),
-                ("act_layout", ctypes.c_int)]
+                ("act_layout", ctypes.c_int), ("range_seen", ctypes.c_void_p)]
 
 
 ACT_SPLIT_IN, ACT_SPLIT_OUT = 1, 2      # himo_conv_desc.act_layout: x / y in the split activation format (csrc/convsg.hip)
@@ -233,8 +233,13 @@ class SeFlowNet:
         self.DEC = buf(H * W, 64)
         self.max_points = 0
         self._reserve_points(max_points)
-        # finite-flow guard: the fused head ORs 1 into this word when it writes a NaN / inf flow value (csrc/gruhead.hip)
-        self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
+        # guard words of the fp16 split (one buffer, one clear, one read-back).  [0] finite-flow guard: the fused head ORs 1 into it
+        # when it writes a NaN / inf flow value (csrc/gruhead.hip).  [1 + k] low-side guard of split-output layer k
+        # (himo_conv_desc.d_range_seen): set by the layer when it sees an output of magnitude >= 2^-6; a word still 0 after a
+        # forward pass = that layer's activations sit on the split's absolute floor (``range_ok``)
+        self.guard = torch.zeros(1 + self.MAX_RANGE_SLOTS, dtype=torch.int32, device=dev)
+        self.nonfinite = self.guard[:1]
+        self._range_slots = {}
         self._range = _f32x(spec.POINT_CLOUD_RANGE[:3])
         self._voxel = _f32x(spec.VOXEL_SIZE)
         r, v = spec.POINT_CLOUD_RANGE, spec.VOXEL_SIZE
@@ -300,9 +305,29 @@ class SeFlowNet:
         self.drop_plan()
         self.reset_images()
 
+    MAX_RANGE_SLOTS = 63
+
     def clear_nonfinite(self):
-        """zero the finite-flow guard word (stream-ordered; no host sync)"""
-        _lib.check(self.lib.himo_clear_u32(self.nonfinite.data_ptr(), 1, _lib.stream_handle()), "himo_clear_u32")
+        """zero the guard words -- finite flow and the layers' low-side words -- stream-ordered; no host sync"""
+        _lib.check(self.lib.himo_clear_u32(self.guard.data_ptr(), self.guard.numel(), _lib.stream_handle()), "himo_clear_u32")
+
+    def _range_word(self, wname: str) -> int:
+        """device address of layer ``wname``'s low-side guard word (fp16 split, split-output layers)"""
+        k = self._range_slots.setdefault(wname, len(self._range_slots))
+        if k >= self.MAX_RANGE_SLOTS:
+            raise RuntimeError("more split-output layers than guard words")
+        return self.guard.data_ptr() + 4 * (1 + k)
+
+    def guard_verdict(self, words) -> str | None:
+        """``words``: host copy of ``self.guard`` taken after a forward pass that followed ``clear_nonfinite``.  None = fine;
+        "overflow" = a non-finite flow value (an activation left fp16's range); "underflow" = some split-output layer never
+        produced a value of magnitude >= 2^-6 (its activations sit on the split's absolute floor)."""
+        w = [int(v) for v in words]
+        if w[0] != 0:
+            return "overflow"
+        if any(w[1 + k] == 0 for k in self._range_slots.values()):
+            return "underflow"
+        return None
 
     def reset_images(self):
         """Mark every pillar-image cell dirty (the next forward rewrites the whole image).  Needed only after something other
@@ -341,6 +366,8 @@ class SeFlowNet:
         d.w_packed = None if pk is None else pk.data_ptr()
         d.packed_format = self.packed_format
         d.act_layout = act if self.split_acts else 0
+        if (d.act_layout & ACT_SPLIT_OUT) and self.packed_format == 1 and epi in (EPI_BIAS, EPI_BIAS_BN_GELU):
+            d.range_seen = self._range_word(wname)
         key = (n * max(d.n_outer, 1), h, w, cin, cout, ks, stride, epi, pk is not None, d.act_layout)
         if self.autotune and key not in self.tiles:
             self.tiles[key] = self._tune(d)

@@ -286,6 +286,12 @@ typedef struct himo_conv_desc {
                                                               16-channel group of a pixel = [16 fp16 high | 16 fp16 low]):
                                                               3x3 layers with packed_format 1, bias or bias+BN+GELU epilogue,
                                                               channel counts and pitches multiples of 16; SPLIT_IN: stride 1 */
+    uint32_t* d_range_seen;                                /* HIMO_ACT_SPLIT_OUT only, may be NULL: the launch stores 1 into this
+                                                              device word when one of the outputs it samples (one per lane and
+                                                              block) has |y| >= 2^-6.  A two-term fp16 split keeps a value to
+                                                              max(2^-25 absolute, 2^-23 relative): a layer whose word stays 0
+                                                              after a forward pass sits on the absolute floor and the caller
+                                                              should redo the pass in the bf16 split (pipeline.HiMoPipeline does) */
 } himo_conv_desc;
 #define HIMO_ACT_SPLIT_IN 1
 #define HIMO_ACT_SPLIT_OUT 2

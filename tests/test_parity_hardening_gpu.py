@@ -139,12 +139,34 @@ def _with_gain(params, g):
     return p
 
 
-@pytest.mark.parametrize("gain", [0.3, 1.0, 3.0, 10.0, 100.0])
+@pytest.mark.parametrize("gain", [1e-4, 1e-3, 1e-2, 0.3, 1.0, 3.0, 10.0, 100.0])
 def test_intermediate_gain_sweep_vs_cpu_restatement(gpu, so, gain):
+    """gains < 1 push the intermediate activations DOWN, towards the two-term fp16 split's absolute
+    floor: below |x| = 1/4 the low part is an fp16 subnormal and a value keeps 2^-25 absolute instead of 2^-23 relative."""
     from himo_amd.seflow import spec
     from himo_amd.synthetic import make_frame
     frames = [make_frame(560 + i, n_points=30_000) for i in range(3)]
     _compare(f"gain_{gain:g}", gpu, so, _with_gain(spec.init_params(3), gain), frames, 30_000, expect_auto=None)
+
+
+@pytest.mark.parametrize("stage", ["enc1", "enc2", "enc3"])
+def test_one_stage_with_tiny_batchnorm_gamma_vs_cpu_restatement(gpu, so, stage):
+    """EVERY block of one encoder stage with BatchNorm gamma and beta x 1e-3: the stage's activations are ~1e-3 (GELU is then
+    nearly x / 2: the function changes, which is fine -- the CPU restatement runs the same parameters), the next consumers'
+    weights x 1e3 bring the signal back to O(1) -- an absolute error floor of the small activations would arrive amplified."""
+    from himo_amd.seflow import spec
+    from himo_amd.synthetic import make_frame
+    p = {k: v.copy() for k, v in spec.init_params(6).items()}
+    blocks = [name for name, _, _, _ in spec.ENCODER if name.startswith(stage + ".")]
+    last = blocks[-1]
+    p[f"{last}.bn.gamma"] *= 1e-3
+    p[f"{last}.bn.beta"] *= 1e-3
+    nxt = {"enc1": "enc2.0", "enc2": "enc3.0"}.get(stage)
+    if nxt is not None:
+        p[f"{nxt}.weight"] *= 1e3
+    p[{"enc1": "dec2.u3.weight", "enc2": "dec1.u3.weight", "enc3": "dec1.u1.weight"}[stage]] *= 1e3     # the decoder's 1x1 on this stage's frames
+    frames = [make_frame(570 + i, n_points=30_000) for i in range(3)]
+    _compare(f"tiny_gamma_{stage}", gpu, so, p, frames, 30_000, expect_auto=None)
 
 
 def test_batchnorm_statistics_far_from_unit_vs_cpu_restatement(gpu, so):
