@@ -717,6 +717,7 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
             extra.update(extra_workload_legs(args, device))
         if world == 1 and not args.no_hostfed_leg:
             extra.update(hostfed_leg(args, overlapped if overlapped is not None else pipe, host_frames, device))
+            extra.update(h5fed_leg(args, overlapped if overlapped is not None else pipe, host_frames, device))
     line = {
         "metric": "lidar_frames_per_sec_120k", "value": total_frames / elapsed, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1026,6 +1027,72 @@ def hostfed_leg(args, pipe, host_frames, device) -> dict:
            "note": "inputs start in pageable host memory every step: staged into a pinned ring and copied over PCIe by a feeder thread three "
                    "batches ahead of the launches (himo_amd/feeder.py); same kernels, same results"}
     return {"value_hostfed": leg["frames_per_s"], "leg_hostfed": leg}
+
+
+def h5fed_leg(args, pipe, host_frames, device) -> dict:
+    """N = 1 only, after the timed region: the reference's loop as a user runs it -- ``dataset[i]`` -> network -> write
+    (save_zip.py:111-123; ``python save.py checkpoint=... dataset_path=...``, README.md:50) -- END TO END over 120k-point ``.h5``
+    scene files: ``himo_amd.save.run`` reads the scenes (``dataset.HDF5Dataset``: files kept open, only the sweeps / poses / time
+    stamps, views of the file mappings), stages them through the pinned feeder, runs the flow network with the batches in flight
+    and writes every sweep's (N,3) flow back under ``<timestamp>/<res_name>`` (``save.H5ResultSink``: libhdf5 in place when one
+    can be loaded, else a result file beside the scene).  The scene files are written once with ``h5lite.write_file`` into a
+    temporary directory (every dataset the reference's extractors write, dataprocess/extract_sca.py:76-93, so that the loader
+    has labels and masks to skip); the first pass is the warm-up (page cache, tile choices), the second is timed."""
+    import pickle
+    import shutil
+    import tempfile
+    import warnings
+    import torch
+    from himo_amd import h5lite, save
+    from himo_amd.dataset import SAVE_FIELDS, HDF5Dataset
+    B = args.frames_per_step
+    n_scenes, per_scene = 6, 2 * B + 9                       # 6 x 40 items of 16 = 15 batches
+    root = Path(tempfile.mkdtemp(prefix="himo_h5fed_"))
+    try:
+        index = []
+        for sc in range(n_scenes):
+            scene, tree = f"bench{sc:02d}", {}
+            for k in range(per_scene):
+                f = host_frames[(7 * sc + k) % len(host_frames)]
+                ts = str(315_965_785_000_000_000 + (1000 * sc + k) * 100_000_000)
+                tree[ts] = {"lidar": f["pc0"], "lidar_dt": f["lidar_dt"], "lidar_id": f["lidar_id"], "pose": f["pose0"], "ground_mask": f["gm0"],
+                            "flow": f["flow"], "flow_is_valid": f["flow_is_valid"], "flow_category_indices": f["flow_category_indices"],
+                            "flow_instance_id": f["flow_instance_id"]}
+                index.append([scene, ts])
+            h5lite.write_file(root / f"{scene}.h5", tree)
+        with open(root / "index_total.pkl", "wb") as fh:
+            pickle.dump(index, fh)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                  # (the last sweep of a scene has no successor; no HDF5 library -> side files)
+            ds = HDF5Dataset(root, fields=SAVE_FIELDS, zero_copy=True)
+            t0 = time.perf_counter()
+            for i in range(len(ds)):
+                ds[i]
+            cold = len(ds) / (time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            for i in range(len(ds)):
+                ds[i]
+            loader = len(ds) / (time.perf_counter() - t0)
+            how = None
+            for rep in range(2):
+                sink = save.H5ResultSink(root, "seflowpp_bench", before_write=ds.forget)
+                how = sink.how
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                done = save.run(ds, "seflowpp_bench", sink=sink, pipeline=pipe, batch_frames=B, by_scene=True)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+            ds.close()
+        leg = {"frames_per_s": done / el, "frames": done, "seconds": el, "scenes": n_scenes, "sweeps_per_scene": per_scene,
+               "points_per_sweep": int(host_frames[0]["pc0"].shape[0]), "loader_items_per_s": loader, "loader_items_per_s_first_pass": cold,
+               "result_writer": how, "scene_file_MB": round((root / "bench00.h5").stat().st_size / 1e6, 1),
+               "note": "himo_amd.save.run end to end: read .h5 scenes -> pinned feeder -> network (batches in flight) -> flow written back per sweep; "
+                       "second pass over the files (page cache warm)"}
+        return {"value_h5fed": leg["frames_per_s"], "leg_h5fed": leg}
+    except Exception as e:                                       # a leg must never cost the main line
+        return {"leg_h5fed": {"error": f"{type(e).__name__}: {e}"}}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def extra_precision_legs(args, params, sets, device, ref_flow, exclude: str) -> dict:

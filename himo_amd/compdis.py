@@ -21,7 +21,12 @@ from . import _lib
 # import this name.  The day the value is readable: change this line (or export HIMO_CLOSE_DISTANCE_THRESHOLD), the oracle's copy
 # (oracle/himo_oracle.py:31) and the stub in tests/golden/make_golden.py:76, and regenerate the a6 / a7 fixtures.
 import os as _os
-CLOSE_DISTANCE_THRESHOLD = float(_os.environ.get("HIMO_CLOSE_DISTANCE_THRESHOLD", "35.0"))
+CLOSE_DISTANCE_DEFAULT = 35.0
+CLOSE_DISTANCE_THRESHOLD = float(_os.environ.get("HIMO_CLOSE_DISTANCE_THRESHOLD", str(CLOSE_DISTANCE_DEFAULT)))
+if CLOSE_DISTANCE_THRESHOLD != CLOSE_DISTANCE_DEFAULT:       # an exported variable changes every eval.py / save_zip.py figure: say so, once
+    import warnings as _warnings
+    _warnings.warn(f"HIMO_CLOSE_DISTANCE_THRESHOLD={CLOSE_DISTANCE_THRESHOLD:g} m replaces the default {CLOSE_DISTANCE_DEFAULT:g} m: evaluation masks, "
+                   f"metrics and submissions of this process are not comparable with default runs (recorded in res-*.json)", stacklevel=2)
 # ego boxes: utils/__init__.py:26 (Scania default) and eval.py:296 (everything else)
 EGO_BOX = {
     "scania": ([-9.5, -3 / 2, 0], [5, 2.760004 / 2, 5]),

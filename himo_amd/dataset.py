@@ -108,19 +108,92 @@ def load_index(directory, eval: bool = False) -> list:  # noqa: A002
         return [[str(s), str(t)] for s, t in pickle.load(f)]
 
 
+# the frame keys ``save`` (network inference over a dataset) consumes: the sweep, its pose / time stamps, and the next sweep
+SAVE_FIELDS = ("pc0", "pose0", "lidar_dt", "pose1", "pc1")
+
+
+class _OpenFiles:
+    """The most recently used scene files, kept OPEN (a walk reads every sweep of a scene in turn, and each sweep three times:
+    as next, current and history): re-opening per item meant an mmap, a superblock parse and a group walk each time -- three
+    quarters of an item's 3.8 ms.  Thread-safe; a file evicted while arrays still view its mapping
+    (``h5lite.Dataset.view``) is left to the garbage collector."""
+
+    def __init__(self, opener, keep: int = 8):
+        import collections
+        import threading
+        self._open, self._keep = opener, keep
+        self._files, self._lock = collections.OrderedDict(), threading.Lock()
+
+    def get(self, path):
+        key = str(path)
+        with self._lock:
+            got = self._files.get(key)
+            if got is not None:
+                self._files.move_to_end(key)
+                return got[0]
+        handle = self._open(path)                              # (outside the lock: another thread may open it too -- one of them stays)
+        # an opener may hand back the mapping itself (h5py.File, h5lite.File) or a context manager that yields it
+        f = handle if hasattr(handle, "__getitem__") else handle.__enter__()
+        with self._lock:
+            have = self._files.get(key)
+            if have is not None:
+                other, f = (f, handle), have[0]
+            else:
+                other = None
+                self._files[key] = (f, handle)
+                while len(self._files) > self._keep:
+                    _, old = self._files.popitem(last=False)
+                    self._close(old)
+        if other is not None:
+            self._close(other)
+        return f
+
+    @staticmethod
+    def _close(entry):
+        f, handle = entry
+        try:
+            if handle is f:
+                f.close()
+            else:
+                handle.__exit__(None, None, None)
+        except Exception:
+            pass
+
+    def forget(self, path):
+        """close ``path`` if open (before something else rewrites the file)"""
+        with self._lock:
+            entry = self._files.pop(str(path), None)
+        if entry is not None:
+            self._close(entry)
+
+    def close(self):
+        with self._lock:
+            files, self._files = list(self._files.values()), type(self._files)()
+        for entry in files:
+            self._close(entry)
+
+
 class HDF5Dataset:
     """h5 scene files -> frame dicts (see module docstring for the provenance of the layout).
 
     ``pose1`` / ``pc1`` come from the next timestamp of the same scene in ``index_total.pkl``; a frame with no successor
     (the last sweep of a scene) has no ``pose1`` to remove ego motion with (save_zip.py:115), so it is dropped from the
     index at construction -- iterating the dataset never yields a frame the consumers cannot process.
-    ``opener(path)`` returns the scene file as a read-only mapping ``{timestamp: {name: array-like}}`` usable as a context
-    manager; the default is ``h5py.File(path, "r")``, or ``h5lite.File(path)`` where h5py is not installed.
+    ``opener(path)`` returns the scene file as a read-only mapping ``{timestamp: {name: array-like}}`` (or a context manager
+    yielding one); the default is ``h5py.File(path, "r")``, or ``h5lite.File(path)`` where h5py is not installed.  Scene files stay open between items
+    (the ``keep_open`` most recent; ``close()`` / ``forget(scene_id)`` release them).
+    ``fields``: the frame keys to read (None = everything the group holds; ``SAVE_FIELDS`` for inference -- labels, masks and
+    ground-truth flow are then not touched).  ``zero_copy``: arrays the file stores as one plain run come back as READ-ONLY
+    views of the file mapping (``h5lite`` only; consumers that stage frames into their own buffers, like
+    ``feeder.SampleFeeder``, then copy each sweep once instead of twice).
     ``allow_dropped_eval`` (default: env ``HIMO_ALLOW_DROPPED_EVAL``, else False): see the KeyError below."""
 
     def __init__(self, directory, vis_name="", eval: bool = False, n_frames: int = 2, opener=None,  # noqa: A002
-                 allow_dropped_eval: bool | None = None):
-        self._open = opener if opener is not None else _open_h5
+                 allow_dropped_eval: bool | None = None, fields=None, zero_copy: bool = False, keep_open: int = 8):
+        self._files = _OpenFiles(opener if opener is not None else _open_h5, keep=keep_open)
+        self.fields = None if fields is None else frozenset(fields)
+        self.zero_copy = zero_copy
+        self._result_choice = {}
         if allow_dropped_eval is None:
             allow_dropped_eval = allow_dropped_eval_default()
         self.directory = Path(directory)
@@ -152,38 +225,85 @@ class HDF5Dataset:
     def scene_path(self, scene_id: str) -> Path:
         return self.directory / f"{scene_id}.h5"
 
+    def close(self):
+        self._files.close()
+
+    def forget(self, scene_id: str):
+        """release the open handle of a scene file (a writer is about to modify it)"""
+        self._files.forget(self.scene_path(scene_id))
+
+    def _array(self, ds):
+        if self.zero_copy:
+            view = getattr(ds, "view", None)
+            if view is not None:
+                a = view()
+                if a is not None:
+                    return a
+        return np.asarray(ds[:])
+
+    def _result_source(self, name: str, scene_id: str):
+        """Which file answers for ``<res_name>`` of a scene when BOTH the scene file and a result file beside it
+        (``result_file``) exist: the one modified LAST.  This package's in-place writer removes the side entries it supersedes
+        (``save.H5ResultSink._supersede_beside``), but another tool -- the reference's ``save.py``, h5py, h5copy -- that writes
+        ``<res_name>`` into the scene file later knows nothing of the side file: preferring it blindly would score stale flows."""
+        key = (name, scene_id)
+        got = self._result_choice.get(key)
+        if got is None:
+            side = result_file(self.directory, name, scene_id)
+            got = "scene"
+            if side.exists():
+                got = "side"
+                scene = self.scene_path(scene_id)
+                if scene.exists() and scene.stat().st_mtime_ns > side.stat().st_mtime_ns:
+                    got = "scene-newer"
+            self._result_choice[key] = got
+        return got
+
     def __getitem__(self, i):
         scene_id, ts = self.index[i]
-        with self._open(self.scene_path(scene_id)) as f:
-            g = f[ts]
-            d = {"scene_id": scene_id, "timestamp": int(ts), "pc0": np.asarray(g["lidar"][:]), "pose0": np.asarray(g["pose"][:]),
-                 "lidar_dt": np.asarray(g["lidar_dt"][:]) if "lidar_dt" in g else np.zeros(g["lidar"].shape[0], np.float32)}
-            if "ground_mask" in g:
-                d["gm0"] = np.asarray(g["ground_mask"][:]).astype(bool)        # the loader's rename
-            for k in ("flow", "flow_is_valid", "flow_category_indices", "flow_instance_id", "lidar_id", "ego_motion"):
-                if k in g:
-                    d[k] = np.asarray(g[k][:])
-            for name in self.vis_name:
-                if name and name != "raw":
-                    # a run that could not modify the scene file wrote beside it; that file, when present, is the NEWER result
-                    # (the in-place writer removes the entries it supersedes: save.H5ResultSink.flush)
-                    side = result_file(self.directory, name, scene_id)
-                    if side.exists():
-                        with self._open(side) as r:
-                            if ts in r and name in r[ts]:
-                                d[name] = np.asarray(r[ts][name][:])
-                    if name not in d and name in g:
-                        d[name] = np.asarray(g[name][:])
-            nxt = f[self._next[(scene_id, ts)]]
-            d["pose1"], d["pc1"] = np.asarray(nxt["pose"][:]), np.asarray(nxt["lidar"][:])
-            if "ground_mask" in nxt:                           # the label generator needs both sweeps' ground masks (seflow/ssl_label.py)
-                d["gm1"] = np.asarray(nxt["ground_mask"][:]).astype(bool)
-            if "flow_instance_id" in nxt:                      # the training loop clusters both sweeps (seflow/fit.py)
-                d["flow_instance_id_next"] = np.asarray(nxt["flow_instance_id"][:])
+        want = self.fields
+        need = (lambda k: True) if want is None else want.__contains__
+        f = self._files.get(self.scene_path(scene_id))
+        g = f[ts]
+        d = {"scene_id": scene_id, "timestamp": int(ts)}
+        if need("pc0"):
+            d["pc0"] = self._array(g["lidar"])
+        if need("pose0"):
+            d["pose0"] = np.asarray(g["pose"][:])
+        if need("lidar_dt"):
+            d["lidar_dt"] = self._array(g["lidar_dt"]) if "lidar_dt" in g else np.zeros(g["lidar"].shape[0], np.float32)
+        if need("gm0") and "ground_mask" in g:
+            d["gm0"] = np.asarray(g["ground_mask"][:]).astype(bool)        # the loader's rename (SURVEY 8b)
+        for k in ("flow", "flow_is_valid", "flow_category_indices", "flow_instance_id", "lidar_id", "ego_motion"):
+            if need(k) and k in g:
+                d[k] = self._array(g[k])
+        for name in self.vis_name:
+            if name and name != "raw" and need(name):
+                src = self._result_source(name, scene_id)
+                if src != "scene":
+                    r = self._files.get(result_file(self.directory, name, scene_id))
+                    in_side = ts in r and name in r[ts]
+                    if in_side and src == "scene-newer" and name in g:
+                        import warnings
+                        warnings.warn(f"{scene_id}.h5 was modified after the result file beside it ({result_file(self.directory, name, scene_id)}) "
+                                      f"and holds '{name}' for sweep {ts} too: using the scene file's; delete or merge the side file", stacklevel=2)
+                    elif in_side:
+                        d[name] = self._array(r[ts][name])
+                if name not in d and name in g:
+                    d[name] = self._array(g[name])
+        nxt = f[self._next[(scene_id, ts)]]
+        if need("pose1"):
+            d["pose1"] = np.asarray(nxt["pose"][:])
+        if need("pc1"):
+            d["pc1"] = self._array(nxt["lidar"])
+        if need("gm1") and "ground_mask" in nxt:               # the label generator needs both sweeps' ground masks (seflow/ssl_label.py)
+            d["gm1"] = np.asarray(nxt["ground_mask"][:]).astype(bool)
+        if need("flow_instance_id_next") and "flow_instance_id" in nxt:        # the training loop clusters both sweeps (seflow/fit.py)
+            d["flow_instance_id_next"] = self._array(nxt["flow_instance_id"])
         return d
 
 
-def open_dataset(directory, vis_name="", eval: bool = False, allow_dropped_eval: bool | None = None):  # noqa: A002
+def open_dataset(directory, vis_name="", eval: bool = False, allow_dropped_eval: bool | None = None, **h5_options):  # noqa: A002
     """The frame source behind ``HDF5Dataset(dir, vis_name=<res>, eval=True)`` at save_zip.py:111 / eval.py:279: the h5
     scene files when the directory holds them, this package's npz container (``NpzDataset.write``) when it holds that.
     ``allow_dropped_eval`` only concerns h5 scene files: an npz frame carries its own ``pose1`` / ``pc1``, so no entry of
@@ -191,4 +311,4 @@ def open_dataset(directory, vis_name="", eval: bool = False, allow_dropped_eval:
     directory = Path(directory)
     if any(directory.glob("*/*.npz")) and not any(directory.glob("*.h5")):
         return NpzDataset(directory, vis_name=vis_name, eval=eval)
-    return HDF5Dataset(directory, vis_name=vis_name, eval=eval, allow_dropped_eval=allow_dropped_eval)
+    return HDF5Dataset(directory, vis_name=vis_name, eval=eval, allow_dropped_eval=allow_dropped_eval, **h5_options)

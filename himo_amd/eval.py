@@ -395,6 +395,10 @@ class InstanceMetrics:
         slot = data.setdefault(self.data_name, {}).setdefault(res_name, {})
         rows = []
         print(f"\nHiMo refinement metrics for {res_name} in {self.data_name}:")
+        from .compdis import CLOSE_DISTANCE_DEFAULT
+        if CLOSE_DISTANCE_THRESHOLD != CLOSE_DISTANCE_DEFAULT:       # a non-default evaluation range is part of the result (the
+            slot["close_distance_threshold"] = CLOSE_DISTANCE_THRESHOLD     # reference's file layout is untouched otherwise)
+            print(f"(evaluation range CLOSE_DISTANCE_THRESHOLD = {CLOSE_DISTANCE_THRESHOLD:g} m, not the default {CLOSE_DISTANCE_DEFAULT:g} m)")
         for cat, shown in (("CAR", "CAR"), ("OTHER_VEHICLES", "OTHERS")):
             if cat not in summ:
                 continue

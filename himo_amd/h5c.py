@@ -70,7 +70,11 @@ def load():
             continue
         lib.version = (maj.value, mnr.value, rel.value)
         lib.path = p
-        _declare(lib)
+        try:
+            _declare(lib)
+        except (AttributeError, ValueError) as e:               # a build of the library without one of the symbols used here:
+            tried.append(f"{p}: {e}")                           # not usable -- callers fall back (save.H5ResultSink: a file beside the scene)
+            continue
         _lib = lib
         return lib
     _why = "no HDF5 C library could be loaded (set HIMO_LIBHDF5=/path/to/libhdf5.so); tried: " + ("; ".join(tried) or "nothing found")
@@ -100,7 +104,6 @@ def _declare(lib):
         "H5Oopen": (hid, [hid, c.c_char_p, hid]), "H5Oclose": (c.c_int, [hid]), "H5Iget_type": (c.c_int, [hid]),
         "H5Lexists": (c.c_int, [hid, c.c_char_p, hid]), "H5Ldelete": (c.c_int, [hid, c.c_char_p, hid]),
         "H5Lget_name_by_idx": (c.c_ssize_t, [hid, c.c_char_p, c.c_int, c.c_int, c.c_uint64, c.c_char_p, c.c_size_t, hid]),
-        "H5Gget_num_objs": (c.c_int, [hid, P(c.c_uint64)]),
         "H5Screate_simple": (hid, [c.c_int, P(c.c_uint64), P(c.c_uint64)]), "H5Screate": (hid, [c.c_int]), "H5Sclose": (c.c_int, [hid]),
         "H5Sget_simple_extent_ndims": (c.c_int, [hid]), "H5Sget_simple_extent_dims": (c.c_int, [hid, P(c.c_uint64), P(c.c_uint64)]),
         "H5Dcreate2": (hid, [hid, c.c_char_p, hid, hid, hid, hid, hid]), "H5Dopen2": (hid, [hid, c.c_char_p, hid]),
@@ -200,13 +203,17 @@ class Group:
         return self._lib.H5Lexists(self._id, name.encode(), H5P_DEFAULT) > 0
 
     def keys(self):
-        n = ctypes.c_uint64()
-        _ok(self._lib.H5Gget_num_objs(self._id, ctypes.byref(n)), "H5Gget_num_objs")
+        # links by index until the library says there is none (H5Gget_num_objs is a deprecated symbol that builds without the
+        # 1.6 API lack; H5Gget_info's struct differs between versions)
         out = []
-        for i in range(n.value):
+        i = 0
+        while True:
             ln = self._lib.H5Lget_name_by_idx(self._id, b".", H5_INDEX_NAME, H5_ITER_INC, i, None, 0, H5P_DEFAULT)
+            if ln < 0:
+                break
+            i += 1
             buf = ctypes.create_string_buffer(ln + 1)
-            self._lib.H5Lget_name_by_idx(self._id, b".", H5_INDEX_NAME, H5_ITER_INC, i, buf, ln + 1, H5P_DEFAULT)
+            self._lib.H5Lget_name_by_idx(self._id, b".", H5_INDEX_NAME, H5_ITER_INC, i - 1, buf, ln + 1, H5P_DEFAULT)
             out.append(buf.value.decode())
         return out
 

@@ -62,6 +62,7 @@ class File:
         except Exception:
             self.close()
             raise
+        self._objects = {}                    # header address -> parsed Group / Dataset (the file is read-only: parsed once)
         self._root = Group(self, self._root_addr, "/")
 
     # -- low-level helpers
@@ -118,8 +119,12 @@ class File:
 
     def close(self):
         buf, self._buf = getattr(self, "_buf", None), None
+        self._objects = {}
         if buf is not None:
-            buf.close()
+            try:
+                buf.close()
+            except BufferError:               # arrays handed out by Dataset.view() still reference the mapping: it goes when they do
+                pass
         if not self._fh.closed:
             self._fh.close()
 
@@ -288,7 +293,9 @@ class Group:
         links = self._load()
         if head not in links:
             raise KeyError(f"{name!r} is not in {self.name!r} of {self._f.path}")
-        obj = _open_object(self._f, links[head], self.name.rstrip("/") + "/" + head)
+        obj = self._f._objects.get(links[head])
+        if obj is None:                       # (two threads may both parse a header: the objects are equivalent, the last one stays)
+            obj = self._f._objects[links[head]] = _open_object(self._f, links[head], self.name.rstrip("/") + "/" + head)
         return obj[rest] if rest else obj
 
 
@@ -604,6 +611,20 @@ class Dataset:
                 names = {4: "szip", 5: "nbit", 6: "scaleoffset", 32000: "lzf", 32001: "blosc", 32004: "lz4", 32015: "zstd"}
                 raise Unsupported(f"{names.get(fid, f'id-{fid}')} filter")
         return raw
+
+    def view(self):
+        """The dataset WITHOUT a copy where the file holds it as one plain run of native-order values (contiguous / compact layout,
+        no filter, not a boolean enum): a read-only array over the file mapping, valid while the ``File`` is open (numpy holds
+        the mapping's buffer: ``File.close`` leaves a still-referenced mapping to the garbage collector).  None otherwise --
+        callers fall back to ``read()``."""
+        f, b = self._f, self._f._buf
+        kind, addr, _ = self._layout
+        n = self._count()
+        if kind not in ("contiguous", "compact") or self._bool or self._filters or self._dtype.byteorder == ">" or n == 0 or addr == UNDEF:
+            return None
+        if addr + n * self._dtype.itemsize > len(b):
+            raise OSError(f"{f.path}: {self.name} extends past the end of the file (truncated?)")
+        return np.frombuffer(b, self._dtype, n, addr).reshape(self.shape)
 
     def read(self) -> np.ndarray:
         f, b = self._f, self._f._buf

@@ -24,21 +24,54 @@ from .pipeline import HiMoPipeline, Sample
 
 class _FrameCache:
     """``dataset[i]`` with the last few frames kept: the walk below touches frame i as "next" of i-1, as itself, and as
-    "history" of i+1 -- one file read instead of three (h5 / npz reads are the slow part of ``save``)."""
+    "history" of i+1 -- one file read instead of three (h5 / npz reads are the slow part of ``save``).  With ``workers`` > 0
+    and a planned walk (``plan``) the frames of the next ``ahead`` steps are read by a small thread pool before they are asked
+    for: page faults, decompression and array copies of several frames overlap (they release the GIL); the frames still come
+    back in order."""
 
-    def __init__(self, dataset, keep: int = 4):
+    def __init__(self, dataset, keep: int = 4, workers: int = 0, ahead: int = 8):
         self.dataset, self.keep, self._frames = dataset, keep, {}
+        self._pool, self._order, self._pos, self._ahead = None, None, 0, ahead
+        if workers > 0:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="himo-reader")
 
     def __len__(self):
         return len(self.dataset)
 
+    def plan(self, order):
+        """the ascending indices the walk will ask for (each also as history of the next and next of the previous)"""
+        self._order, self._pos = list(order), 0
+
+    def _prefetch(self, i):
+        order, n = self._order, len(self.dataset)
+        while self._pos < len(order) and order[self._pos] <= i + self._ahead:
+            o = order[self._pos]
+            self._pos += 1
+            for j in (o - 1, o, o + 1):
+                if 0 <= j < n and j >= i - 1 and j not in self._frames:
+                    self._frames[j] = self._pool.submit(self.dataset.__getitem__, j)
+
     def __getitem__(self, i):
+        if self._pool is not None and self._order is not None:
+            self._prefetch(i)
         f = self._frames.get(i)
         if f is None:
             f = self._frames[i] = self.dataset[i]
+        elif hasattr(f, "result"):
+            f = self._frames[i] = f.result()
+        if self._pool is not None and self._order is not None:
+            for j in [j for j in self._frames if j < i - 2]:      # the walk is ascending: what lies two behind is stale
+                del self._frames[j]
+        else:
             while len(self._frames) > self.keep:
                 self._frames.pop(min(self._frames))               # the walk is ascending: the lowest index is the stale one
         return f
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=False, cancel_futures=True)
+            self._pool = None
 
 
 def history_of(dataset, i: int):
@@ -88,8 +121,11 @@ class H5ResultSink:
     ``dataset.result_file(directory, res_name, scene_id)`` instead -- a new HDF5 file with the same ``<timestamp>/<res_name>``
     layout, written by ``h5lite`` -- with a warning naming the file; ``HDF5Dataset`` falls back to it when reading."""
 
-    def __init__(self, directory, res_name: str, opener=None):
+    def __init__(self, directory, res_name: str, opener=None, before_write=None):
+        """``before_write(scene_id)``: called before a scene file is opened for modification (``HDF5Dataset.forget``: a reader
+        that keeps scene files open must let go of its handle and of what it parsed from the file)"""
         self.directory, self.res_name = Path(directory), res_name
+        self._before_write = before_write
         self.how = "opener"
         if opener is None:
             mod, self.how = h5_writer()
@@ -109,6 +145,8 @@ class H5ResultSink:
     def flush(self):
         if not self._pending:
             return
+        if self._before_write is not None:
+            self._before_write(self._scene)
         if self._open is not None:
             with self._open(self.directory / f"{self._scene}.h5") as f:
                 for ts, flow in self._pending:
@@ -161,11 +199,12 @@ class H5ResultSink:
         self.flush()
 
 
-def frame_source(dataset, rank: int = 0, world: int = 1, by_scene: bool = False):
+def frame_source(dataset, rank: int = 0, world: int = 1, by_scene: bool = False, readers: int = 2):
     """(index, history frame, frame, next frame | None) for every frame of this rank that has a next sweep to flow into.
-    ``by_scene``: shard whole scenes (scene k of the walk -> rank k % world) instead of frames."""
+    ``by_scene``: shard whole scenes (scene k of the walk -> rank k % world) instead of frames.  ``readers``: threads that read
+    the coming frames ahead of the walk (0 = read on the calling thread)."""
     index = getattr(dataset, "index", None)
-    dataset = _FrameCache(dataset)
+    dataset = _FrameCache(dataset, workers=readers)
     if by_scene and index is not None:
         scenes = {}
         for s, _ in index:
@@ -173,15 +212,19 @@ def frame_source(dataset, rank: int = 0, world: int = 1, by_scene: bool = False)
         mine = [i for i, (s, _) in enumerate(index) if scenes[s] % world == rank]
     else:
         mine = range(rank, len(dataset), world)
-    for i in mine:
-        f0 = dataset[i]
-        if "pc1" not in f0:
-            if i + 1 >= len(dataset) or dataset[i + 1].get("scene_id") != f0.get("scene_id"):
-                continue                                       # last sweep of a scene: no pc1 to flow into
-            f1 = dataset[i + 1]
-        else:
-            f1 = None
-        yield i, history_of(dataset, i), f0, f1
+    dataset.plan(mine)
+    try:
+        for i in mine:
+            f0 = dataset[i]
+            if "pc1" not in f0:
+                if i + 1 >= len(dataset) or dataset[i + 1].get("scene_id") != f0.get("scene_id"):
+                    continue                                       # last sweep of a scene: no pc1 to flow into
+                f1 = dataset[i + 1]
+            else:
+                f1 = None
+            yield i, history_of(dataset, i), f0, f1
+    finally:
+        dataset.close()
 
 
 def run(dataset, res_name: str = "seflowpp_best", params: dict | None = None, sink=None, pipeline: HiMoPipeline | None = None,
@@ -274,7 +317,7 @@ def main(checkpoint: str = "", dataset_path: str = "", res_name: str = "", model
     """``python -m himo_amd.save --checkpoint <weights.npz> --dataset_path <dir>`` (the feed-forward network), or
     ``--model fastnsf --dataset_path <dir>`` (the optimisation-based baseline, README.md:50-53); under ``torchrun`` one rank per GPU."""
     from . import distenv
-    from .dataset import NpzDataset, open_dataset
+    from .dataset import SAVE_FIELDS, NpzDataset, open_dataset
     if model not in ("", "seflowpp", "deflowpp", "fastnsf"):
         raise ValueError(f"model={model!r}: this build runs the SeFlow++-style network (default) and 'fastnsf'")
     fastnsf = model == "fastnsf"
@@ -285,9 +328,11 @@ def main(checkpoint: str = "", dataset_path: str = "", res_name: str = "", model
         params = load_params(checkpoint)
     root = Path(dataset_path)
     with distenv.process_group():
-        ds = open_dataset(root, vis_name=name, eval=False)
+        # inference reads the sweeps, poses and time stamps only (no labels, masks, ground-truth flow, earlier results), as views
+        # of the file mappings where the files allow: the feeder stages them straight into its pinned buffers
+        ds = open_dataset(root, vis_name=name, eval=False, fields=SAVE_FIELDS, zero_copy=True)
         npz = isinstance(ds, NpzDataset)
-        sink = NpzResultSink(root, name) if npz else H5ResultSink(root, name)
+        sink = NpzResultSink(root, name) if npz else H5ResultSink(root, name, before_write=ds.forget)
         done, err = 0, None
         try:
             done = (run_fastnsf(ds, name, sink=sink, by_scene=not npz, iters=iters) if fastnsf else

@@ -67,6 +67,12 @@ def make_sample(dataset, trip, device, label_key: str = "flow_instance_id"):
     else:
         f1 = dataset[i1]
         pc1, lab1, gm1 = f1["pc0"], f1.get(label_key), f1.get("gm0")
+        if lab1 is None and not auto:
+            raise KeyError(f"{label_key}: the next frame does not hold the labels ssl_label={label_key!r} names "
+                           f"(ssl_label='seflow_auto' generates them from the sweeps and their ground masks gm0 / gm1)")
+    if not auto and f0.get(label_key) is None:
+        raise KeyError(f"{label_key}: the frame does not hold the labels ssl_label={label_key!r} names "
+                       f"(ssl_label='seflow_auto' generates them from the sweeps and their ground masks gm0 / gm1)")
     p0, p1 = up(f0["pc0"]), up(pc1)
     pose0, pose1 = np.asarray(f0["pose0"], np.float64), np.asarray(f0["pose1"], np.float64)
     if auto:

@@ -6,10 +6,15 @@ PARITY UNPINNED.  The reference's generator (DUFOMap dynamic awareness + HDBSCAN
 absent OpenSceneFlow submodule together with its dependencies; only the option's name is in the tree.  This build's own
 specification, chosen so that every step is exact and order-independent:
 
+  0. only points inside the network's BEV range (+-51.2 m in the common frame, ``RANGE_NET``) take part: the network gives the
+     others no flow and the loss no gradient (``mask_rows``), so labelling them would only dilute the loss's per-cluster and
+     per-point normalisations -- and a 200 m sweep would pile its far half into the border cells of the search grids.
   1. dynamic candidates of a sweep A against its neighbour sweep B (both in ONE frame: A is moved with ``inv(poseB) @ poseA``):
-     non-ground points of A whose nearest non-ground point of B is further than ``dyn_dist`` (0.35 m: a point on a static
-     surface has a return of the other sweep next to it once ego motion is removed; a point on an object faster than
-     3.5 m/s does not).  Exact nearest neighbours through the BEV cell grid (csrc/nngrid.hip).
+     non-ground points of A whose nearest non-ground point of B is further than ``dyn_dist`` x max(1, r / 30 m), r = the
+     point's BEV range (0.35 m near the sensor: a point on a static surface has a return of the other sweep next to it once
+     ego motion is removed, a point on an object faster than 3.5 m/s does not; beyond ~30 m the SAMPLING spacing of a spinning
+     LiDAR exceeds 0.35 m, so the bar grows with range instead of declaring most far static returns candidates).
+     Exact nearest neighbours through the BEV cell grid (csrc/nngrid.hip).
   2. clusters: DBSCAN(``eps``, ``min_pts``) over the candidates (csrc/dbscan.hip: labels are a pure function of the input --
      clusters numbered by their lowest point index, a border point joins the neighbouring cluster of lowest such index).
   3. everything else -- ground, static, noise -- is label 0.
@@ -38,6 +43,8 @@ _lib.register({
 
 EPS, MIN_PTS, DYN_DIST = 0.5, 8, 0.35
 RANGE_XY = 52.0                     # the BEV cell grid covers +- this (points beyond it are binned into its border cells)
+RANGE_NET = 51.2                    # the network's BEV range (assets/slurm/ssl-train-av2.sh:32 point_cloud_range): step 0
+DYN_REF_RANGE = 30.0                # BEV range from which the dynamic-candidate bar grows linearly (step 1)
 
 
 def dbscan(points: torch.Tensor, eps: float = EPS, min_pts: int = MIN_PTS, skip: torch.Tensor | None = None):
@@ -77,13 +84,19 @@ def auto_labels(pc0, pc1, ground0, ground1, pose0, pose1, eps: float = EPS, min_
     T = np.linalg.inv(np.asarray(pose1, np.float64)) @ np.asarray(pose0, np.float64)
     a = _moved(p0, T)                                           # pc0 in pc1's frame
     b = p1[:, :3].contiguous()
-    a_ng, b_ng = a[~g0], b[~g1]                                 # (index selection: data movement, no arithmetic)
-    far2 = float(dyn_dist) ** 2
+    far2 = torch.tensor(float(dyn_dist) ** 2, dtype=torch.float32, device=dev)
+    inv_ref2 = torch.tensor(1.0 / (DYN_REF_RANGE * DYN_REF_RANGE), dtype=torch.float32, device=dev)
+    out_a = (a[:, :2].abs().amax(dim=1) > RANGE_NET) if a.shape[0] else torch.zeros(0, dtype=torch.bool, device=dev)     # step 0
+    out_b = (b[:, :2].abs().amax(dim=1) > RANGE_NET) if b.shape[0] else torch.zeros(0, dtype=torch.bool, device=dev)
+    use_a, use_b = ~(g0 | out_a), ~(g1 | out_b)
+    a_in, b_in = a[use_a], b[use_b]                             # (index selection: data movement)
     out = []
-    for pts, ground, mine, other in ((a, g0, a_ng, b_ng), (b, g1, b_ng, a_ng)):
-        skip = ground.clone()
+    for pts, use, mine, other in ((a, use_a, a_in, b_in), (b, use_b, b_in, a_in)):
+        skip = ~use
         if mine.shape[0] and other.shape[0]:
             d2 = nn_grid(mine, other, return_index=False)
-            skip[~ground] = d2 <= far2                          # a close return in the other sweep: static
+            x, y = mine[:, 0], mine[:, 1]
+            bar2 = far2 * torch.clamp((x * x + y * y) * inv_ref2, min=1.0)       # (dyn_dist * max(1, r / 30 m))^2, float32 as the oracle
+            skip[use] = d2 <= bar2                              # a close return in the other sweep: static
         out.append(dbscan(pts, eps, min_pts, skip)[0])
     return out[0], out[1]

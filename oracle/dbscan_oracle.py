@@ -58,18 +58,25 @@ def dbscan(points: np.ndarray, eps: float, min_pts: int, skip: np.ndarray | None
     return labels
 
 
-def auto_labels(pc0, pc1, ground0, ground1, pose0, pose1, eps, min_pts, dyn_dist):
+def auto_labels(pc0, pc1, ground0, ground1, pose0, pose1, eps, min_pts, dyn_dist, range_net=51.2, ref_range=30.0):
+    """himo_amd/seflow/ssl_label.py steps 0-3: points outside the network's BEV range take no part; a non-ground point is a
+    dynamic candidate when its nearest usable point of the other sweep is further than dyn_dist * max(1, r / ref_range)"""
     T = (np.linalg.inv(np.asarray(pose1, np.float64)) @ np.asarray(pose0, np.float64)).astype(np.float32)
     a = (pc0[:, :3].astype(np.float32) @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
     b = pc1[:, :3].astype(np.float32)
+    use_a = ~(np.asarray(ground0, bool) | (np.abs(a[:, :2]).max(axis=1, initial=0.0) > np.float32(range_net)))
+    use_b = ~(np.asarray(ground1, bool) | (np.abs(b[:, :2]).max(axis=1, initial=0.0) > np.float32(range_net)))
+    far2, inv_ref2 = np.float32(float(dyn_dist) ** 2), np.float32(1.0 / (ref_range * ref_range))
     out = []
-    for pts, ground, other, og in ((a, ground0, b, ground1), (b, ground1, a, ground0)):
-        skip = np.asarray(ground, bool).copy()
-        mine, oth = pts[~skip], other[~np.asarray(og, bool)]
+    for pts, use, other, ouse in ((a, use_a, b, use_b), (b, use_b, a, use_a)):
+        skip = ~use
+        mine, oth = pts[use], other[ouse]
         if len(mine) and len(oth):
             _, j = cKDTree(oth.astype(np.float64)).query(mine.astype(np.float64))
             d = mine - oth[j]
             d2 = (d * d).sum(1)
-            skip[np.flatnonzero(~skip)] = d2 <= np.float32(dyn_dist) ** 2
+            r2 = mine[:, 0] * mine[:, 0] + mine[:, 1] * mine[:, 1]
+            bar2 = far2 * np.maximum(r2 * inv_ref2, np.float32(1.0))
+            skip[np.flatnonzero(use)] = d2 <= bar2
         out.append((dbscan(pts, eps, min_pts, skip), skip))
     return out

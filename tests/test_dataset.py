@@ -293,3 +293,82 @@ def test_fixture_directory_opens_as_the_reference_call_does(tmp_path):
         assert np.array_equal(d["pc1"], frames[i + 1]["pc0"])
     total = open_dataset(GOLDEN / "h5", vis_name="raw")
     assert len(total) == 6 and "seflowpp_best" not in total[0]
+
+
+def test_fields_and_views_read_only_what_inference_needs_and_equal_the_full_read():
+    """``fields=SAVE_FIELDS, zero_copy=True`` (what ``save.main`` opens): the five keys, as views of the file mapping where the
+    libhdf5-written fixture stores plain runs, equal to the copying read; nothing else is touched"""
+    from himo_amd.dataset import SAVE_FIELDS
+    full = HDF5Dataset(GOLDEN / "h5", vis_name="seflowpp_best")
+    lean = HDF5Dataset(GOLDEN / "h5", vis_name="seflowpp_best", fields=SAVE_FIELDS, zero_copy=True)
+    for i in range(len(full)):
+        a, b = full[i], lean[i]
+        assert set(b) == set(SAVE_FIELDS) | {"scene_id", "timestamp"}
+        for k in SAVE_FIELDS:
+            assert np.array_equal(a[k], b[k]) and a[k].dtype == b[k].dtype, k
+    assert not lean[0]["pc0"].flags.writeable and lean[0]["pc0"].base is not None      # a view of the mapping, not a copy
+    view = lean[0]["pc0"]
+    lean.close()                                                        # the view outlives the dataset's handle (the mapping goes with it)
+    assert np.array_equal(view, full[0]["pc0"])
+    with_result = HDF5Dataset(GOLDEN / "h5", vis_name="seflowpp_best", fields=SAVE_FIELDS + ("seflowpp_best",))
+    assert np.array_equal(with_result[0]["seflowpp_best"], full[0]["seflowpp_best"])
+
+
+def test_scene_files_stay_open_between_items(tmp_path):
+    frames = [make_frame(i, n_points=40, scene_id=f"scene{i // 4}") for i in range(12)]     # three scenes of four sweeps
+    _dataset_dir(tmp_path, frames)
+    log = []
+    ds = HDF5Dataset(tmp_path, opener=_memory_opener(_scene_groups(frames), log), keep_open=2)
+    for i in range(len(ds)):
+        ds[i]
+    assert log == ["scene0.h5", "scene1.h5", "scene2.h5"]               # one open per scene, not one per item
+    ds[0]                                                               # scene0 was evicted (two stay open): opened again
+    assert log[-1] == "scene0.h5" and len(log) == 4
+    ds.forget("scene0")
+    ds[0]
+    assert len(log) == 5
+
+
+def test_newer_scene_file_wins_over_a_stale_result_file_beside_it(tmp_path, monkeypatch):
+    """a result file left beside a scene by a library-less run must not shadow a ``<res_name>`` that
+    another tool wrote INTO the scene file later."""
+    import os
+    import shutil
+    import warnings
+    from himo_amd.dataset import result_file
+    shutil.copytree(GOLDEN / "h5", tmp_path / "d")
+    root = tmp_path / "d"
+    ds = HDF5Dataset(root, vis_name="seflowpp_best")
+    in_file = ds[0]["seflowpp_best"].copy()
+    monkeypatch.setattr(save, "h5_writer", lambda: (None, "no HDF5 library"))
+    sink = save.H5ResultSink(root, "seflowpp_best")
+    sink(0, ds[0], np.full_like(in_file, 3.0))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sink.close()
+    side = result_file(root, "seflowpp_best", ds[0]["scene_id"])
+    assert (HDF5Dataset(root, vis_name="seflowpp_best")[0]["seflowpp_best"] == 3).all()         # the side file is the newer one
+    later = side.stat().st_mtime_ns + 5_000_000_000
+    os.utime(root / f"{ds[0]['scene_id']}.h5", ns=(later, later))       # "another tool rewrote the scene file afterwards"
+    with pytest.warns(UserWarning, match="modified after the result file"):
+        got = HDF5Dataset(root, vis_name="seflowpp_best")[0]["seflowpp_best"]
+    assert np.array_equal(got, in_file)
+
+
+def test_prefetching_frame_cache_returns_the_same_frames_in_order(tmp_path):
+    frames = [make_frame(i, n_points=30 + i, scene_id=f"scene{i // 5}") for i in range(15)]
+    _dataset_dir(tmp_path, frames)
+    reads = []
+
+    class Counting(HDF5Dataset):
+        def __getitem__(self, i):
+            reads.append(i)
+            return super().__getitem__(i)
+    ds = Counting(tmp_path, opener=_memory_opener(_scene_groups(frames)))
+    plain = [(i, fh["timestamp"], f0["timestamp"]) for i, fh, f0, f1 in save.frame_source(ds, readers=0)]
+    n_plain, reads[:] = len(reads), []
+    ahead = [(i, fh["timestamp"], f0["timestamp"]) for i, fh, f0, f1 in save.frame_source(ds, readers=3)]
+    assert ahead == plain and len(plain) == len(ds)
+    assert sorted(set(reads)) == list(range(len(ds))) and len(reads) == len(ds) == n_plain     # every frame read exactly once either way
+    mine = [i for i, *_ in save.frame_source(ds, rank=1, world=3, by_scene=True, readers=2)]
+    assert mine == [i for i, (s, _) in enumerate(ds.index) if s == "scene1"]

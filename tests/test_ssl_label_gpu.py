@@ -87,6 +87,32 @@ def test_auto_labels_of_a_sweep_pair(gpu, do):
     assert (g0[~inst] > 0).mean() < 0.02 and (g0[f0["gm0"]] == 0).all()
 
 
+def test_auto_labels_of_a_200_m_sweep_pair(gpu, do):
+    """an AV2-like sweep reaches 200 m.  Points beyond the network's +-51.2 m take no part (label 0, not even as
+    neighbours); inside, the dynamic-candidate bar grows with range, so the sparse far field is not declared dynamic wholesale."""
+    from himo_amd.seflow.ssl_label import DYN_DIST, EPS, MIN_PTS, RANGE_NET, _moved, auto_labels
+    from himo_amd.synthetic import make_frame
+    f0 = make_frame(71, n_points=120_000, cloud="rings")
+    f0["pc0"][:, :3] *= 2.9                                   # walls out to ~200 m, ring spacing x 2.9
+    f0["flow"] *= 2.9
+    rng = np.random.default_rng(6)
+    ego = np.linalg.inv(f0["pose1"]) @ f0["pose0"]
+    moved = f0["pc0"][:, :3].astype(np.float64) + f0["flow"].astype(np.float64)
+    keep = rng.uniform(size=len(moved)) < 0.97
+    pc1 = (moved[keep] + rng.normal(0, 0.03, (int(keep.sum()), 3))).astype(np.float32)
+    gm0 = f0["pc0"][:, 2] < -1.8 * 2.9 + 0.3
+    gm1 = gm0[keep]
+    l0, l1 = auto_labels(f0["pc0"], pc1, gm0, gm1, f0["pose0"], f0["pose1"])
+    a = _moved(torch.from_numpy(f0["pc0"]).to(gpu), ego).cpu().numpy()
+    (w0, s0), (w1, s1) = do.auto_labels(np.concatenate([a, f0["pc0"][:, 3:]], 1), pc1, gm0, gm1, np.eye(4), np.eye(4), EPS, MIN_PTS, DYN_DIST)
+    g0, g1 = l0.cpu().numpy(), l1.cpu().numpy()
+    assert np.array_equal(g0, w0) and np.array_equal(g1, w1)
+    outside = np.abs(a[:, :2]).max(axis=1) > RANGE_NET
+    assert outside.mean() > 0.3 and (g0[outside] == 0).all()
+    inst = f0["flow_instance_id"] > 0
+    assert (g0[~inst & ~outside] > 0).mean() < 0.05                 # the static world stays static although its sampling is 3x sparser
+
+
 def test_training_loop_with_generated_labels(gpu, tmp_path):
     """``fit(..., ssl_label="seflow_auto")`` (the default, the launcher's option): one short run end to end -- labels generated per
     sample on the device, finite losses, a checkpoint."""
