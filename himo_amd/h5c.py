@@ -148,9 +148,13 @@ def _bool_type(lib):
 
 class Dataset:
     _id = 0
+    _file = None
 
-    def __init__(self, lib, did):
-        self._lib, self._id = lib, did
+    def __init__(self, lib, did, file=None):
+        # ``file``: the File this handle lives in.  The file is opened H5F_CLOSE_STRONG (closing it closes every handle open in
+        # it, as h5py does), and the library RE-USES identifier values: a child object collected after its file was closed must
+        # not close "its" identifier again -- by then it may name another thread's dataset or group
+        self._lib, self._id, self._file = lib, did, file
         sp = _ok(lib.H5Dget_space(did), "H5Dget_space")
         nd = lib.H5Sget_simple_extent_ndims(sp)
         dims = (ctypes.c_uint64 * max(nd, 1))()
@@ -185,9 +189,9 @@ class Dataset:
         return a[key] if a.ndim or key != () else a[()]
 
     def close(self):
-        if self._id:
+        if self._id and (self._file is None or self._file._fid):
             self._lib.H5Dclose(self._id)
-            self._id = 0
+        self._id = 0
 
     __del__ = close
 
@@ -195,9 +199,10 @@ class Dataset:
 class Group:
     _id = 0
     _owned = True
+    _file = None
 
-    def __init__(self, lib, gid, owned=True):
-        self._lib, self._id, self._owned = lib, gid, owned
+    def __init__(self, lib, gid, owned=True, file=None):
+        self._lib, self._id, self._owned, self._file = lib, gid, owned, file
 
     def __contains__(self, name):
         return self._lib.H5Lexists(self._id, name.encode(), H5P_DEFAULT) > 0
@@ -229,15 +234,17 @@ class Group:
         oid = _ok(self._lib.H5Oopen(self._id, name.encode(), H5P_DEFAULT), f"H5Oopen({name})")
         kind = self._lib.H5Iget_type(oid)
         self._lib.H5Oclose(oid)
+        home = self._file if self._file is not None else self            # (a File is its own home)
         if kind == 2:                                                    # H5I_GROUP
-            return Group(self._lib, _ok(self._lib.H5Gopen2(self._id, name.encode(), H5P_DEFAULT), "H5Gopen2"))
-        return Dataset(self._lib, _ok(self._lib.H5Dopen2(self._id, name.encode(), H5P_DEFAULT), "H5Dopen2"))
+            return Group(self._lib, _ok(self._lib.H5Gopen2(self._id, name.encode(), H5P_DEFAULT), "H5Gopen2"), file=home)
+        return Dataset(self._lib, _ok(self._lib.H5Dopen2(self._id, name.encode(), H5P_DEFAULT), "H5Dopen2"), file=home)
 
     def __delitem__(self, name):
         _ok(self._lib.H5Ldelete(self._id, name.encode(), H5P_DEFAULT), f"H5Ldelete({name})")
 
     def create_group(self, name):
-        return Group(self._lib, _ok(self._lib.H5Gcreate2(self._id, name.encode(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT), f"H5Gcreate2({name})"))
+        return Group(self._lib, _ok(self._lib.H5Gcreate2(self._id, name.encode(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT), f"H5Gcreate2({name})"),
+                     file=self._file if self._file is not None else self)
 
     def create_dataset(self, name, data, chunks=None, compression=None, shuffle=False, fletcher32=False, compact=False):
         """``h5py``'s ``create_dataset(name, data=...)``: contiguous layout unless ``chunks`` / ``compression="gzip"``."""
@@ -282,7 +289,7 @@ class Group:
                 lib.H5Tclose(ftype)
 
     def close(self):
-        if self._id and self._owned:
+        if self._id and self._owned and (self._file is None or self._file._fid):
             self._lib.H5Gclose(self._id)
         self._id = 0
 
@@ -290,11 +297,14 @@ class Group:
 
 
 class File(Group):
+    _fid = 0
+
     """``File(path, "r" | "a" | "r+" | "w")``; ``libver="latest"`` writes the 1.10 file format (version-2 object headers,
     link messages) instead of the library's -- and h5py's -- default earliest-compatible one."""
 
     def __init__(self, path, mode="r", libver="earliest"):
         lib = load()
+        lib.H5Eset_auto2(0, None, None)                                  # (the library's error printing is per THREAD: writer threads too)
         fapl = _ok(lib.H5Pcreate(lib.P_FILE_ACCESS), "H5Pcreate")
         lib.H5Pset_fclose_degree(fapl, 3)                                # H5F_CLOSE_STRONG, as h5py: closing the file closes what is open in it
         if libver == "latest":
