@@ -291,6 +291,52 @@ def _message(header_type: int, build_header, body_len: int) -> bytes:
     return struct.pack("<II", _CONT, len(fb) + pad) + fb + b"\x00" * pad
 
 
+_FRAMING_CACHE: dict = {}
+
+
+def _framing(names: tuple, dtypes: tuple, length: int):
+    """(bytes before the record batch body, bytes after it, body length, [(offset, nbytes) of each column's data in the body]) of
+    a table of fixed-width columns: everything in a Feather file but the column values depends on the schema and the row
+    count alone, so a stream of equally shaped sweeps builds it once per row count (cached: the last 64 shapes)."""
+    key = (names, tuple(np.dtype(d).str for d in dtypes), int(length))
+    got = _FRAMING_CACHE.get(key)
+    if got is not None:
+        return got
+    buffers, nodes, spans, at = [], [], [], 0
+    for dt in dtypes:
+        dt = np.dtype(dt)
+        nodes.append((length, 0))
+        buffers.append((at, 0))                               # validity bitmap: absent (no nulls)
+        nbytes = (length + 7) // 8 if dt == np.dtype(bool) else length * dt.itemsize
+        buffers.append((at, nbytes))
+        spans.append((at, nbytes))
+        at += nbytes + (-nbytes) % 8
+    body_len = at
+    head = bytearray(MAGIC + b"\x00\x00")
+    head += _message(1, lambda b: _schema(b, names, dtypes), 0)
+
+    def rb_header(b: _Builder):
+        bv = b.struct_vector("qq", buffers)
+        nv = b.struct_vector("qq", nodes)
+        return b.table([("q", length), ("o", nv), ("o", bv), ("n", None)])
+
+    rb_msg = _message(3, rb_header, body_len)
+    rb_off = len(head)
+    head += rb_msg
+    fb = _Builder()
+    sch = _schema(fb, names, dtypes)
+    blocks = fb.struct_vector("qiiq", [(rb_off, len(rb_msg), 0, body_len)])
+    dicts = fb.struct_vector("qiiq", [])
+    root = fb.table([("h", _V5), ("o", sch), ("o", dicts), ("o", blocks), ("n", None)])
+    footer = fb.finish(root)
+    tail = footer + struct.pack("<i", len(footer)) + MAGIC
+    got = (bytes(head), bytes(tail), body_len, spans)
+    if len(_FRAMING_CACHE) >= 64:
+        _FRAMING_CACHE.pop(next(iter(_FRAMING_CACHE)))
+    _FRAMING_CACHE[key] = got
+    return got
+
+
 def write_table(columns: dict) -> bytes:
     """{name: 1-D array} -> Feather V2 bytes (single record batch, uncompressed, 8-byte aligned buffers)."""
     names = list(columns)
@@ -303,37 +349,36 @@ def write_table(columns: dict) -> bytes:
     length = len(arrays[0]) if arrays else 0
     if any(len(a) != length for a in arrays):
         raise ValueError("all columns must have the same length")
-    dtypes = [a.dtype for a in arrays]
-    body = bytearray()
-    buffers, nodes = [], []
-    for a in arrays:
-        nodes.append((length, 0))
-        buffers.append((len(body), 0))                        # validity bitmap: absent (no nulls)
+    head, tail, body_len, spans = _framing(tuple(names), tuple(a.dtype for a in arrays), length)
+    out = np.zeros(len(head) + body_len + len(tail), np.uint8)
+    out[:len(head)] = np.frombuffer(head, np.uint8)
+    for a, (off, nbytes) in zip(arrays, spans):
+        dst = out[len(head) + off:len(head) + off + nbytes]
         if a.dtype == np.dtype(bool):
-            payload = np.packbits(a.astype(np.uint8), bitorder="little").tobytes()
+            dst[:] = np.packbits(a.astype(np.uint8), bitorder="little")
         else:
-            payload = np.ascontiguousarray(a.astype(a.dtype.newbyteorder("<"), copy=False)).tobytes()
-        buffers.append((len(body), len(payload)))
-        body += payload + b"\x00" * ((-len(payload)) % 8)
+            dst.view(a.dtype.newbyteorder("<"))[:] = a          # ONE pass over the column, strided or not, straight into place
+    out[len(head) + body_len:] = np.frombuffer(tail, np.uint8)
+    return out.tobytes()
 
-    out = bytearray(MAGIC + b"\x00\x00")
-    schema_msg = _message(1, lambda b: _schema(b, names, dtypes), 0)
-    out += schema_msg
 
-    def rb_header(b: _Builder):
-        bv = b.struct_vector("qq", buffers)
-        nv = b.struct_vector("qq", nodes)
-        return b.table([("q", length), ("o", nv), ("o", bv), ("n", None)])
-
-    rb_msg = _message(3, rb_header, len(body))
-    rb_off = len(out)
-    out += rb_msg + body
-
-    fb = _Builder()
-    sch = _schema(fb, names, dtypes)
-    blocks = fb.struct_vector("qiiq", [(rb_off, len(rb_msg), 0, len(body))])
-    dicts = fb.struct_vector("qiiq", [])
-    root = fb.table([("h", _V5), ("o", sch), ("o", dicts), ("o", blocks), ("n", None)])
-    footer = fb.finish(root)
-    out += footer + struct.pack("<i", len(footer)) + MAGIC
-    return bytes(out)
+def write_matrix(values: np.ndarray, names) -> np.ndarray:
+    """The same file as ``write_table({names[j]: values[:, j]})`` for an (n, k) array of one fixed-width dtype, as a uint8 array
+    (a buffer for ``file.write`` / ``ZipFile.writestr`` without a further copy): the framing comes from the cache, each column
+    is gathered from the row-major rows straight into its place.  The per-sweep encoder of ``save_zip``."""
+    v = np.asarray(values)
+    if v.ndim != 2 or v.shape[1] != len(names) or v.dtype == np.dtype(bool):
+        raise ValueError("write_matrix takes an (n, len(names)) array of a numeric dtype")
+    n, k = v.shape
+    head, tail, body_len, spans = _framing(tuple(names), (v.dtype,) * k, n)
+    out = np.empty(len(head) + body_len + len(tail), np.uint8)
+    out[:len(head)] = np.frombuffer(head, np.uint8)
+    le = v.dtype.newbyteorder("<")
+    for j, (off, nbytes) in enumerate(spans):
+        lo = len(head) + off
+        out[lo:lo + nbytes].view(le)[:] = v[:, j]
+        pad = (-nbytes) % 8
+        if pad:
+            out[lo + nbytes:lo + nbytes + pad] = 0
+    out[len(head) + body_len:] = np.frombuffer(tail, np.uint8)
+    return out

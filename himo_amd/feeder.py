@@ -186,14 +186,19 @@ class ResultDrain:
 
     _END = object()
 
-    def __init__(self, sink, device=None, depth: int = 32):
+    def __init__(self, sink, device=None, depth: int = 32, threads: int = 1, copy: bool = True):
+        """``threads``: writer threads.  One (default) calls the sink in ``put`` order -- what a sink that groups results needs
+        (``save.H5ResultSink`` flushes a scene when the next one starts); several call it concurrently, in any order -- for sinks
+        whose calls are independent (one Feather file per sweep: the encoding and the file write release the GIL).
+        ``copy=False`` hands the sink a view of the PINNED buffer, valid only until the sink returns (it is reused)."""
         self.device = device if device is not None else _lib.require_gpu()
-        self._sink = sink
+        self._sink, self._copy = sink, copy
         self._q = queue.Queue(maxsize=depth)
         self._free = queue.Queue()
         self._error = None
-        self._thread = threading.Thread(target=self._work, name="himo-drain", daemon=True)
-        self._thread.start()
+        self._threads = [threading.Thread(target=self._work, name=f"himo-drain-{k}", daemon=True) for k in range(max(1, threads))]
+        for t in self._threads:
+            t.start()
 
     def _pinned(self, like: torch.Tensor) -> torch.Tensor:
         """a free pinned buffer that fits (ragged sweeps: capacities are rounded up to a power of two so they are reused)"""
@@ -232,14 +237,16 @@ class ResultDrain:
             try:
                 ev.synchronize()
                 if self._error is None:
-                    self._sink(key, view.numpy().copy())
+                    self._sink(key, view.numpy().copy() if self._copy else view.numpy())
             except BaseException as e:
                 self._error = e
             self._free.put(buf)
 
     def close(self) -> None:
-        self._q.put(self._END)
-        self._thread.join()
+        for _ in self._threads:
+            self._q.put(self._END)
+        for t in self._threads:
+            t.join()
         if self._error is not None:
             raise self._error
 
@@ -288,14 +295,23 @@ class BatchFeeder:
                     tdt = torch.from_numpy(np.empty(0, dtype)).dtype
                     pin = arena.take_growing(shape, tdt)
                     dst = torch.empty(shape, dtype=tdt, device=self.device)
-                    jobs.append((self._pool.submit(np.concatenate, parts, 0, pin.numpy(), casting="unsafe"), pin, dst))
+                    # one copy job per PART (a frame's array), not per tensor: a batch's largest tensor (16 sweeps of points:
+                    # 30 MB) as one job kept one thread busy for 6 ms while the others idled
+                    host, at = pin.numpy(), 0
+                    for p in parts:
+                        n = p.shape[0]
+                        jobs.append((self._pool.submit(np.copyto, host[at:at + n], p, casting="unsafe"), None, None))
+                        at += n
+                    jobs.append((None, pin, dst))
                     return dst
 
                 with torch.cuda.stream(self._stream):
                     obj, tensors = self._build(item, upload)
-                    for job, pin, dst in jobs:
-                        job.result()
-                        dst.copy_(pin, non_blocking=True)
+                    for job, pin, dst in jobs:                 # (a tensor's entry follows its parts' jobs)
+                        if job is not None:
+                            job.result()
+                        else:
+                            dst.copy_(pin, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(self._stream)
                 self._slot_done[slot] = ev
