@@ -25,17 +25,21 @@ python bench.py --workload fastnsf > $OUT/${RN}_bench_fastnsf_n1.json 2>> $OUT/p
 bash scripts/exp_clock_pmc.sh default > $OUT/${RN}_conv3x3_clock_and_mfma_busy.txt 2>&1
 bash scripts/pmc_step_summary.sh > $OUT/${RN}_pmc_step_summary.txt 2>&1
 python scripts/exp_savezip.py > $OUT/${RN}_exp_savezip.log 2>&1
+python scripts/exp_h5_loader.py 4 12 > $OUT/${RN}_h5_loader.txt 2>&1
+python scripts/exp_nn_grid.py > $OUT/${RN}_exp_nn_grid.txt 2>&1
+python bench.py --workload train --cloud rings --no-extra-workloads --no-cpu-baseline > $OUT/${RN}_bench_train_n1_lidar_rings.json 2>> $OUT/train.err
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_peak scripts/micro/mfma_peak.hip && /tmp/mfma_peak > $OUT/${RN}_mfma_sustained_peak.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 python $R/scripts/exp_hbm_layers.py > $OUT/${RN}_hbm_side_layers.txt 2>&1
 python $R/scripts/exp_upsample.py > $OUT/${RN}_upsample.txt 2>&1
-for wl in pipeline compdis train fastnsf; do
-  ARGS="--workload $wl --no-cpu-baseline --no-extra-precisions"
+for wl in pipeline compdis train train_rings fastnsf; do
+  ARGS="--workload ${wl%_rings} --no-cpu-baseline --no-extra-precisions"
   [ $wl = train ] && ARGS="$ARGS --steps 5 --warmup 2 --no-extra-workloads"
+  [ $wl = train_rings ] && ARGS="$ARGS --steps 5 --warmup 2 --no-extra-workloads --cloud rings"
   [ $wl = fastnsf ] && ARGS="$ARGS --steps 2 --warmup 1 --no-extra-workloads --single-stream"   # one fit at a time: a launch's duration is its own
   [ $wl = pipeline ] && ARGS="$ARGS --no-extra-workloads --single-stream --no-hostfed-leg"   # one batch in flight: a launch's duration is its own
   # (train: the weight gradients on the main stream, as in the region bench.py times its roofline kernel in -- with the side streams a launch's duration includes what co-runs)
-  HIMO_TRAIN_SIDE_STREAM=$([ $wl = train ] && echo 0 || echo 1) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$wl -o $wl -- python $R/bench.py $ARGS > $OUT/${RN}_bench_${wl}_n1_under_rocprof.json 2> $OUT/prof_$wl.err
+  HIMO_TRAIN_SIDE_STREAM=$([ ${wl%_rings} = train ] && echo 0 || echo 1) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$wl -o $wl -- python $R/bench.py $ARGS > $OUT/${RN}_bench_${wl}_n1_under_rocprof.json 2> $OUT/prof_$wl.err
   f=$(find $OUT/prof_$wl -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${RN}_${wl}_rocprofv3_kernel_stats.csv
   rm -rf $OUT/prof_$wl
