@@ -116,3 +116,27 @@ def test_lz4_decoder_rejects_garbage():
     assert lib.himo_lz4_frame_decompress(b"\\x00" * 32, 32, dst, 64) == -1
     bad = b"\\x04\\x22\\x4d\\x18\\x60\\x40\\x82" + b"\\xff\\xff\\xff\\x7f" + b"\\x00" * 8     # block larger than the input
     assert lib.himo_lz4_frame_decompress(bad, len(bad), dst, 64) == -1
+
+
+def test_write_matrix_is_the_same_file_as_write_table_and_pyarrow_reads_it():
+    """the per-sweep encoder of save_zip (cached framing, columns gathered straight into the file image) against the general
+    writer and against pyarrow's reader, for row counts around the 8-byte buffer alignment and for a cache hit"""
+    import io
+    from himo_amd import feather
+    from himo_amd.save_zip import COLUMNS
+    rng = np.random.default_rng(4)
+    for n in (0, 1, 2, 3, 7, 1000, 120_000, 120_000, 119_999):
+        cd = rng.normal(size=(n, 3)).astype(np.float32)
+        want = feather.write_table({c: np.ascontiguousarray(cd[:, i]) for i, c in enumerate(COLUMNS)})
+        got = feather.write_matrix(cd, COLUMNS)
+        assert got.dtype == np.uint8 and got.tobytes() == want
+        back = feather.read_table(got.tobytes())
+        assert all(np.array_equal(back[c], cd[:, i]) for i, c in enumerate(COLUMNS))
+    try:
+        import pyarrow.feather as paf
+    except ImportError:
+        return
+    t = paf.read_table(io.BytesIO(feather.write_matrix(cd, COLUMNS).tobytes()))
+    assert t.column_names == list(COLUMNS) and np.array_equal(t.column(2).to_numpy(), cd[:, 2])
+    with pytest.raises(ValueError):
+        feather.write_matrix(cd[:, :2], COLUMNS)
