@@ -229,8 +229,12 @@ class HDF5Dataset:
         self._files.close()
 
     def forget(self, scene_id: str):
-        """release the open handle of a scene file (a writer is about to modify it)"""
+        """release the open handles of a scene (a writer is about to modify its file, or the result file beside it) and what
+        was decided about where its results live"""
         self._files.forget(self.scene_path(scene_id))
+        for key in [k for k in self._result_choice if k[1] == scene_id]:
+            self._files.forget(result_file(self.directory, key[0], scene_id))
+            del self._result_choice[key]
 
     def _array(self, ds):
         if self.zero_copy:
