@@ -413,7 +413,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(ConvWgradTiled
     const int n_tiles = a.n_img * tiles_per_img;
     const int t0 = (int)blockIdx.x * a.tiles_per_chunk;
     const int t1 = min(t0 + a.tiles_per_chunk, n_tiles);
-    const int sc = threadIdx.x & 63, sg = threadIdx.x >> 6;      // staging: this thread's channel, its group of items
+    // staging: this thread's channel; its wave stages halo row sg of X (five 8-pixel chunks) and chunk sg of both dY rows.  The wave
+    // index goes through readfirstlane so that every coordinate, bound test and row address below is SCALAR: a load is one
+    // global_load_dword (scalar row base + the lane's channel offset) and a tile's bound tests are a handful of scalar branches
+    // (per-lane 64-bit address arithmetic and an exec-mask branch around each of the 56 loads cost more than the tile's matrix loop)
+    const int sc = threadIdx.x & 63;
+    const int sg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 
     floatx16 acc[9];
 #pragma unroll
@@ -428,31 +433,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(ConvWgradTiled
 
     // a tile's operands travel global -> registers one tile AHEAD (issued before the previous tile's matrix loop, which hides
     // their latency), then registers -> split -> transposed LDS between two barriers
-    constexpr int kXItems = HR * 5 / 4, kYItems = TR * 4 / 4;
+    constexpr int kXItems = 5, kYItems = TR;
     float vx[kXItems][8], vy[kYItems][8];
     auto fetch = [&](int t) {
         const int img = t / tiles_per_img;
         const int rem = t - img * tiles_per_img;
         const int y0 = (rem / col_blocks) * TR, x0 = (rem % col_blocks) * 32;
-        const float* xi = a.x + img * a.x_bs + ci0 + sc;
-        const float* di = a.dy + img * a.dy_bs + co0 + sc;
-        // X halo: item = (halo row, 8-pixel chunk) of this thread's channel: 8 coalesced loads (64 lanes = 64 consecutive
-        // channels of one pixel)
+        const int iy = y0 - 1 + sg;
+        const bool row_ok = iy >= 0 && iy < a.H, left_ok = x0 > 0, right_ok = x0 + 32 < a.W;
+        // halo column hx of this row sits at xrow[hx * pitch]; 64 lanes = 64 consecutive channels of one pixel
+        const float* xrow = a.x + img * a.x_bs + ci0 + ((int64_t)iy * a.W + (x0 - 1)) * a.x_pitch;
 #pragma unroll
-        for (int it = 0; it < kXItems; ++it) {
-            const int item = sg + 4 * it, hr = item / 5, ch = item % 5;
-            const int iy = y0 - 1 + hr;
+        for (int ch = 0; ch < kXItems; ++ch)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int hx = ch * 8 + j, ix = x0 - 1 + hx;
-                vx[it][j] = (hx < HC && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? xi[((int64_t)iy * a.W + ix) * a.x_pitch] : 0.f;
-            }
+            for (int j = 0; j < 8; ++j) vx[ch][j] = 0.f;
+        if (row_ok) {
+#pragma unroll
+            for (int hx = 1; hx < HC - 1; ++hx) vx[hx >> 3][hx & 7] = xrow[(int64_t)hx * a.x_pitch + sc];
+            if (left_ok) vx[0][0] = xrow[sc];
+            if (right_ok) vx[(HC - 1) >> 3][(HC - 1) & 7] = xrow[(int64_t)(HC - 1) * a.x_pitch + sc];
         }
 #pragma unroll
-        for (int it = 0; it < kYItems; ++it) {
-            const int item = sg + 4 * it, r = item >> 2, ch = item & 3;
+        for (int r = 0; r < kYItems; ++r) {
+            const float* drow = a.dy + img * a.dy_bs + co0 + ((int64_t)(y0 + r) * a.Wo + x0 + sg * 8) * a.dy_pitch;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vy[it][j] = di[((int64_t)(y0 + r) * a.Wo + x0 + ch * 8 + j) * a.dy_pitch];
+            for (int j = 0; j < 8; ++j) vy[r][j] = drow[(int64_t)j * a.dy_pitch + sc];
         }
     };
     if (t0 < t1) fetch(t0);
@@ -466,22 +471,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(ConvWgradTiled
             bacc[threadIdx.x] += bs;
         }
 #pragma unroll
-        for (int it = 0; it < kXItems; ++it) {
-            const int item = sg + 4 * it, hr = item / 5, ch = item % 5;
+        for (int ch = 0; ch < kXItems; ++ch) {
             uint4 h, m;
-            split2_bf16_pair(vx[it][0], vx[it][1], h.x, m.x); split2_bf16_pair(vx[it][2], vx[it][3], h.y, m.y);
-            split2_bf16_pair(vx[it][4], vx[it][5], h.z, m.z); split2_bf16_pair(vx[it][6], vx[it][7], h.w, m.w);
-            *reinterpret_cast<uint4*>(&Xt[0][hr][sc][ch * 8]) = h;
-            *reinterpret_cast<uint4*>(&Xt[1][hr][sc][ch * 8]) = m;
+            split2_bf16_pair(vx[ch][0], vx[ch][1], h.x, m.x); split2_bf16_pair(vx[ch][2], vx[ch][3], h.y, m.y);
+            split2_bf16_pair(vx[ch][4], vx[ch][5], h.z, m.z); split2_bf16_pair(vx[ch][6], vx[ch][7], h.w, m.w);
+            *reinterpret_cast<uint4*>(&Xt[0][sg][sc][ch * 8]) = h;
+            *reinterpret_cast<uint4*>(&Xt[1][sg][sc][ch * 8]) = m;
         }
 #pragma unroll
-        for (int it = 0; it < kYItems; ++it) {
-            const int item = sg + 4 * it, r = item >> 2, ch = item & 3;
+        for (int r = 0; r < kYItems; ++r) {
             uint4 h, m;
-            split2_bf16_pair(vy[it][0], vy[it][1], h.x, m.x); split2_bf16_pair(vy[it][2], vy[it][3], h.y, m.y);
-            split2_bf16_pair(vy[it][4], vy[it][5], h.z, m.z); split2_bf16_pair(vy[it][6], vy[it][7], h.w, m.w);
-            *reinterpret_cast<uint4*>(&Yt[0][r][sc][ch * 8]) = h;
-            *reinterpret_cast<uint4*>(&Yt[1][r][sc][ch * 8]) = m;
+            split2_bf16_pair(vy[r][0], vy[r][1], h.x, m.x); split2_bf16_pair(vy[r][2], vy[r][3], h.y, m.y);
+            split2_bf16_pair(vy[r][4], vy[r][5], h.z, m.z); split2_bf16_pair(vy[r][6], vy[r][7], h.w, m.w);
+            *reinterpret_cast<uint4*>(&Yt[0][r][sc][sg * 8]) = h;
+            *reinterpret_cast<uint4*>(&Yt[1][r][sc][sg * 8]) = m;
         }
         if (t + 1 < t1) fetch(t + 1);
         __syncthreads();
@@ -552,7 +555,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split2_kernel(ConvWgradTile
     const int n_tiles = a.n_img * tiles_per_img;
     const int t0 = (int)blockIdx.x * a.tiles_per_chunk;
     const int t1 = min(t0 + a.tiles_per_chunk, n_tiles);
-    const int sc = threadIdx.x & 63, sg = threadIdx.x >> 6;      // staging: this thread's channel, its group of items
+    const int sc = threadIdx.x & 63;                             // staging: this thread's channel; its wave's share of the items
+    const int sg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar, as in the stride-1 kernel
     const bool ci_ok = ci0 + sc < a.cin;                         // a 32-channel input (enc1.0) fills half the tile
 
     floatx16 acc[9];
@@ -561,38 +565,47 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split2_kernel(ConvWgradTile
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // item = (halo row, 16 input pixels) of this thread's channel: 12 items over the 4 thread groups; the 65th column (odd plane,
-    // index 32) of halo row sg is one more load for groups 0 .. 2
+    // item = (halo row, 16 input pixels) of this thread's channel: wave sg stages pixels 16 sg .. 16 sg + 15 of the three halo rows;
+    // the 65th column (odd plane, index 32) of halo row sg is one more load for waves 0 .. 2.  Lanes beyond a 32-channel input load
+    // channel 0 and are zeroed when the values are split.
     float vx[3][16], vlast, vy[8];
     auto fetch = [&](int t) {
         const int img = t / tiles_per_img;
         const int rem = t - img * tiles_per_img;
         const int y0 = rem / col_blocks, x0 = (rem % col_blocks) * 32;
-        const float* xi = a.x + img * a.x_bs + ci0 + (ci_ok ? sc : 0);
-        const float* di = a.dy + img * a.dy_bs + co0 + sc;
+        const int lane_off = ci_ok ? sc : 0;
+        const float* xi = a.x + img * a.x_bs + ci0;
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int item = sg + 4 * it, hr = item >> 2, ch = item & 3;
+        for (int hr = 0; hr < 3; ++hr) {
             const int iy = 2 * y0 - 1 + hr;
+            const int ix0 = 2 * x0 - 1 + 16 * sg;
+            const float* xrow = xi + ((int64_t)iy * a.W + ix0) * a.x_pitch;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int ix = 2 * x0 - 1 + 16 * ch + j;
-                vx[it][j] = (ci_ok && iy >= 0 && ix >= 0) ? xi[((int64_t)iy * a.W + ix) * a.x_pitch] : 0.f;
+            for (int j = 0; j < 16; ++j) vx[hr][j] = 0.f;
+            if (iy >= 0) {
+#pragma unroll
+                for (int j = 1; j < 16; ++j) vx[hr][j] = xrow[(int64_t)j * a.x_pitch + lane_off];
+                if (ix0 >= 0) vx[hr][0] = xrow[lane_off];
             }
         }
         {
             const int iy = 2 * y0 - 1 + sg;
-            vlast = (ci_ok && sg < 3 && iy >= 0) ? xi[((int64_t)iy * a.W + 2 * x0 + 63) * a.x_pitch] : 0.f;
+            vlast = 0.f;
+            if (sg < 3 && iy >= 0) vlast = xi[((int64_t)iy * a.W + 2 * x0 + 63) * a.x_pitch + lane_off];
         }
+        const float* drow = a.dy + img * a.dy_bs + co0 + ((int64_t)y0 * a.Wo + x0 + sg * 8) * a.dy_pitch;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vy[j] = di[((int64_t)y0 * a.Wo + x0 + sg * 8 + j) * a.dy_pitch];
+        for (int j = 0; j < 8; ++j) vy[j] = drow[(int64_t)j * a.dy_pitch + sc];
     };
     if (t0 < t1) fetch(t0);
     for (int t = t0; t < t1; ++t) {
         __syncthreads();                                   // the previous tile's fragment reads are done
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
-            const int item = sg + 4 * it, hr = item >> 2, ch = item & 3;
+            const int hr = it, ch = sg;
+            if (!ci_ok)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) vx[it][j] = 0.f;
             uint4 h, m;                                    // j even -> odd input columns, j odd -> even input columns
             split2_bf16_pair(vx[it][0], vx[it][2], h.x, m.x); split2_bf16_pair(vx[it][4], vx[it][6], h.y, m.y);
             split2_bf16_pair(vx[it][8], vx[it][10], h.z, m.z); split2_bf16_pair(vx[it][12], vx[it][14], h.w, m.w);
@@ -605,7 +618,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split2_kernel(ConvWgradTile
         }
         if (sg < 3) {
             unsigned hw, mw;
-            split2_bf16_pair(vlast, 0.f, hw, mw);
+            split2_bf16_pair(ci_ok ? vlast : 0.f, 0.f, hw, mw);
             Xo[0][sg][sc][32] = (unsigned short)hw; Xo[1][sg][sc][32] = (unsigned short)mw;
         }
         {
