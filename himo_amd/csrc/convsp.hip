@@ -84,20 +84,32 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
 
+    // The halo patch comes through a BUFFER resource over this image: an item's byte offset (pixel, channel quad) is computed
+    // ONCE, out-of-image items get an offset beyond the resource (the load returns zeros without a branch), and a slab is the
+    // scalar offset of the instruction -- a slab's loads cost no vector arithmetic at all.  (Per-slab 64-bit per-lane address
+    // arithmetic with an exec-mask branch around every load was ~25 vector instructions per item and slab.)
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(xin), 0, (int)min((int64_t)a.H * a.W * a.x_pitch * 4, (int64_t)0x7fffffff), 0x00020000);
+    constexpr unsigned kOutside = 0x80000000u;
+    unsigned poff[kPatchPerThread];
+#pragma unroll
+    for (int it = 0; it < kPatchPerThread; ++it) {
+        const int item = it * 256 + threadIdx.x;
+        const int pp = item >> 2, q = item & 3;
+        const int pc = pp % PW;
+        const int iy = iy0 + pp / PW, ix = ix0 + (S == 1 ? pc : pc < 33 ? 2 * pc : 2 * (pc - 33) + 1);
+        const bool ok = item < kPatchItems && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        poff[it] = ok ? (unsigned)(((iy * a.W + ix) * a.x_pitch + q * 4) * 4) : kOutside;
+    }
+    const bool ragged_cin = (a.Cin & 15) != 0;          // the last slab of a Cin that is no multiple of 16: per-quad test
     auto load_patch = [&](int slab, float4 (&r)[kPatchPerThread]) {
 #pragma unroll
         for (int it = 0; it < kPatchPerThread; ++it) {
-            const int item = it * 256 + threadIdx.x;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (item < kPatchItems) {
-                const int pp = item >> 2, q = item & 3;
-                const int pc = pp % PW;
-                const int iy = iy0 + pp / PW, ix = ix0 + (S == 1 ? pc : pc < 33 ? 2 * pc : 2 * (pc - 33) + 1);
-                const int ci = slab * 16 + q * 4;
-                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && ci < a.Cin)
-                    v = *reinterpret_cast<const float4*>(xin + ((int64_t)iy * a.W + ix) * a.x_pitch + ci);
-            }
-            r[it] = v;
+            unsigned off = poff[it];
+            if (ragged_cin && slab * 16 + (int)((it * 256 + threadIdx.x) & 3) * 4 >= a.Cin) off = kOutside;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, slab * 64, 0);
+            r[it] = __builtin_bit_cast(float4, v);      // (whole-vector cast: element extraction from this builtin's result miscompiles to one dword)
         }
     };
     // part 0..2: a third of the items each (the staging of the NEXT slab is spread over the three kernel rows of the
