@@ -121,25 +121,34 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
     const int iy0 = oy0 - (KS / 2), ix0 = ox0 - (KS / 2);
     const int64_t in_rows = (int64_t)a.H * a.W;
 
+    // the patch comes through a buffer resource over this image (as convsp.hip): an item's byte offset is computed once, items
+    // outside the image lie beyond the resource (zeros, no branch), the slab is the instruction's scalar offset
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(xin), 0, (int)std::min<int64_t>(in_rows * a.x_pitch * 4, (int64_t)0x7fffffff), 0x00020000);
+    constexpr unsigned kOutside = 0x80000000u;
+    unsigned poff[kPatchPerThread];
+#pragma unroll
+    for (int it = 0; it < kPatchPerThread; ++it) {
+        const int item = it * 256 + threadIdx.x;
+        const int pp = item >> 2, q = item & 3;
+        int64_t pix;
+        bool ok;
+        if (KS == 1) { pix = row0 + pp; ok = pix < in_rows; }
+        else {
+            const int iy = iy0 + pp / PW, ix = ix0 + pp % PW;
+            ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            pix = (int64_t)iy * a.W + ix;
+        }
+        poff[it] = (ok && item < kPatchItems) ? (unsigned)(((int)pix * a.x_pitch + q * 4) * 4) : kOutside;
+    }
+    const bool ragged_cin = (a.Cin & 15) != 0;          // the last slab of a Cin that is no multiple of 16: per-quad test
     auto load_patch = [&](int slab, float4 (&r)[kPatchPerThread]) {
 #pragma unroll
         for (int it = 0; it < kPatchPerThread; ++it) {
-            const int item = it * 256 + threadIdx.x;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (item < kPatchItems) {
-                const int pp = item >> 2, q = item & 3;
-                int64_t pix;
-                bool ok;
-                if (KS == 1) { pix = row0 + pp; ok = pix < in_rows; }
-                else {
-                    const int iy = iy0 + pp / PW, ix = ix0 + pp % PW;
-                    ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                    pix = (int64_t)iy * a.W + ix;
-                }
-                const int ci = slab * 16 + q * 4;
-                if (ok && ci < a.Cin) v = *reinterpret_cast<const float4*>(xin + pix * a.x_pitch + ci);
-            }
-            r[it] = v;
+            unsigned off = poff[it];
+            if (ragged_cin && slab * 16 + (int)((it * 256 + threadIdx.x) & 3) * 4 >= a.Cin) off = kOutside;
+            // (whole-vector cast: element extraction from this builtin's result miscompiles to one dword)
+            r[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, slab * 64, 0));
         }
     };
     auto store_patch = [&](const float4 (&r)[kPatchPerThread]) {       // split into the three bf16 planes
@@ -265,6 +274,54 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
 
     float* __restrict__ yout = a.y + image_offset(img, a.n_inner, a.y_batch_stride, a.y_outer_stride);
     const int64_t out_rows = (int64_t)a.Ho * a.Wo;
+    // Row GEMMs with an element-wise epilogue: 32-bit element offsets from the (uniform) image base -- a tile's first row times the
+    // pitch once per 32-row block, the 16 rows of a lane as scalar multiples of the pitch -- and no per-store bound test in whole
+    // tiles.  (A 64-bit multiply-add and an exec-mask branch per store made the epilogue of a 64-channel 1x1 layer, 64 stores per
+    // lane, longer than its 48 matrix instructions.)
+    constexpr bool kFastEpi = KS == 1 && (kEpiAffine<EPI> || EPI == kEpiBiasRelu || EPI == kEpiReluMask);
+    if (kFastEpi && out_rows * a.y_pitch < (1ll << 30) && (EPI != kEpiReluMask || out_rows * a.aux_in_pitch < (1ll << 30))) {
+        const int wmu = __builtin_amdgcn_readfirstlane(wm);
+        const float* __restrict__ aux = a.aux_in;                  // (the mask is addressed by the row, as in epilogue_store)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int co = n0 + wn * WN + ni * 32 + li;
+            if (co >= a.Cout) continue;
+            const float b = a.bias ? a.bias[co] : 0.f;
+            float sc = 1.f, sh = 0.f;
+            if (EPI == kEpiBiasBnGelu) { sc = a.scale[co]; sh = a.shift[co]; }
+            float eA = 1.f, eB = 0.f;
+            if (kEpiAffine<EPI>) epi_affine<EPI>(FMT == 2 ? kF16AccScale : 1.f, b, sc, sh, eA, eB);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int64_t p0 = row0 + (wmu * MI + mi) * 32;                       // scalar: this 32-row block's first row
+                const int n_valid = (int)(out_rows - p0 < 32 ? out_rows - p0 : 32);  // scalar
+                const unsigned off = ((unsigned)p0 + 4u * lh) * (unsigned)a.y_pitch + (unsigned)co;
+                const unsigned aoff = EPI == kEpiReluMask ? ((unsigned)p0 + 4u * lh) * (unsigned)a.aux_in_pitch + (unsigned)co : 0u;
+                auto value = [&](int r, unsigned col) -> float {
+                    float v = acc[mi][ni][r];
+                    if (kEpiAffine<EPI>) return epi_activate<EPI>(v, eA, eB);
+                    if (FMT == 2) v *= kF16AccScale;
+                    v += b;
+                    if (EPI == kEpiBiasRelu) return fmaxf(v, 0.f);
+                    return aux[aoff + col * (unsigned)a.aux_in_pitch] > 0.f ? v : 0.f;      // kEpiReluMask
+                };
+                if (n_valid == 32) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned col = (r & 3) + 8 * (r >> 2);
+                        yout[off + col * (unsigned)a.y_pitch] = value(r, col);
+                    }
+                } else if (n_valid > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned col = (r & 3) + 8 * (r >> 2);
+                        if ((int)(col + 4 * lh) < n_valid) yout[off + col * (unsigned)a.y_pitch] = value(r, col);
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int co = n0 + wn * WN + ni * 32 + li;

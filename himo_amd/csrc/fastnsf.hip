@@ -203,25 +203,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_partial_split_kernel(int64_t n, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // staging: this thread's column of the tile, its two 8-row chunks of the 32-row stage (chunk = sg + 2 it)
-    const int sc = threadIdx.x & 127, sg = threadIdx.x >> 7;
+    // staging: this thread's column of the tile, its two 8-row chunks of the 32-row stage (chunk = sg + 2 it).  The chunk index is
+    // wave-uniform and goes through readfirstlane: row numbers, the end-of-range test and the row base addresses are SCALAR, a load is
+    // one global_load_dword (scalar row base + the lane's column); columns beyond the matrix load column 0 and are zeroed when staged
+    // (per-lane 64-bit row arithmetic and an exec-mask branch around each of a stage's 32 loads outweighed its 24 matrix instructions)
+    const int sc = threadIdx.x & 127;
+    const int sg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));
     const bool x_ok = ci0 + sc < cin, z_ok = co0 + sc < cout;
+    const int x_col = x_ok ? sc : 0, z_col = z_ok ? sc : 0;
     float vx[2][8], vz[2][8];
     auto fetch = [&](int64_t base) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
+        for (int it = 0; it < 2; ++it) {
+            const int64_t row0 = base + (sg + 2 * it) * 8;
+            const float* xr = X + row0 * x_pitch + ci0;
+            const float* zr = dZ + row0 * z_pitch + co0;
+            if (row0 + 8 <= r1) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int64_t row = base + (sg + 2 * it) * 8 + j;
-                const bool ok = row < r1;
-                vx[it][j] = (ok && x_ok) ? X[row * x_pitch + ci0 + sc] : 0.f;
-                vz[it][j] = (ok && z_ok) ? dZ[row * z_pitch + co0 + sc] : 0.f;
+                for (int j = 0; j < 8; ++j) { vx[it][j] = xr[(int64_t)j * x_pitch + x_col]; vz[it][j] = zr[(int64_t)j * z_pitch + z_col]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    vx[it][j] = 0.f; vz[it][j] = 0.f;
+                    if (row0 + j < r1) { vx[it][j] = xr[(int64_t)j * x_pitch + x_col]; vz[it][j] = zr[(int64_t)j * z_pitch + z_col]; }
+                }
             }
+        }
     };
     auto stage = [&]() {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int ch = sg + 2 * it;
+            if (!x_ok)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vx[it][j] = 0.f;
+            if (!z_ok)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vz[it][j] = 0.f;
             uint4 h, m;
             wg_split_pair(vx[it][0], vx[it][1], h.x, m.x); wg_split_pair(vx[it][2], vx[it][3], h.y, m.y);
             wg_split_pair(vx[it][4], vx[it][5], h.z, m.z); wg_split_pair(vx[it][6], vx[it][7], h.w, m.w);
