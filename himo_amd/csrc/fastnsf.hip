@@ -185,7 +185,7 @@ __device__ inline void wg_split_pair(float a, float b, unsigned& hw, unsigned& m
 
 __global__ __launch_bounds__(256, 2) void wgrad_partial_split_kernel(int64_t n, const float* __restrict__ X, int x_pitch, int cin,
                                                                      const float* __restrict__ dZ, int z_pitch, int cout,
-                                                                     float* __restrict__ partial, int rows_pb) {
+                                                                     float* __restrict__ partial, int rows_pb, float* __restrict__ colpart) {
     __shared__ __attribute__((aligned(16))) unsigned short Xt[2][128][kWsRowsPad];
     __shared__ __attribute__((aligned(16))) unsigned short Zt[2][128][kWsRowsPad];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -212,6 +212,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_partial_split_kernel(int64_t n, 
     const bool x_ok = ci0 + sc < cin, z_ok = co0 + sc < cout;
     const int x_col = x_ok ? sc : 0, z_col = z_ok ? sc : 0;
     float vx[2][8], vz[2][8];
+    // the bias gradient (column sums of dZ) rides along in the blocks of input tile 0: dZ passes through these registers anyway, a
+    // separate column-sum pass read it from HBM a second time (colpart [co tile][block][128], reduced by colsum_reduce_kernel)
+    const bool want_db = colpart != nullptr && ci0 == 0;
+    float bsum = 0.f;
     auto fetch = [&](int64_t base) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -240,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_partial_split_kernel(int64_t n, 
             if (!z_ok)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) vz[it][j] = 0.f;
+            if (want_db) bsum += ((vz[it][0] + vz[it][1]) + (vz[it][2] + vz[it][3])) + ((vz[it][4] + vz[it][5]) + (vz[it][6] + vz[it][7]));
             uint4 h, m;
             wg_split_pair(vx[it][0], vx[it][1], h.x, m.x); wg_split_pair(vx[it][2], vx[it][3], h.y, m.y);
             wg_split_pair(vx[it][4], vx[it][5], h.z, m.z); wg_split_pair(vx[it][6], vx[it][7], h.w, m.w);
@@ -276,6 +281,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_partial_split_kernel(int64_t n, 
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], acc[a][b], 0, 0, 0);
                 }
         }
+    }
+    if (want_db) {                                         // the two chunk groups' shares of a column, fixed order
+        __syncthreads();
+        float* bsh = reinterpret_cast<float*>(&Xt[0][0][0]);
+        bsh[threadIdx.x] = bsum;
+        __syncthreads();
+        if (threadIdx.x < 128) colpart[((int64_t)(co0 / 128) * gridDim.x + blockIdx.x) * 128 + sc] = bsh[sc] + bsh[128 + sc];
     }
     float* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 * 128;
 #pragma unroll
@@ -622,7 +634,7 @@ extern "C" int himo_linear_wgrad_ex(int64_t n, const float* d_x, int x_pitch, in
                          !((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_dz)) & 15);
         if (flags & 2u)
             hipLaunchKernelGGL(wgrad_partial_split_kernel, dim3(nb, ci_tiles * co_tiles), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch,
-                               cout, partial, rows_pb);
+                               cout, partial, rows_pb, d_db ? colpart : nullptr);
         else if (vec)
             hipLaunchKernelGGL(wgrad_partial_lds_kernel, dim3(nb, ci_tiles * co_tiles), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch,
                                cout, partial, rows_pb);
@@ -632,6 +644,11 @@ extern "C" int himo_linear_wgrad_ex(int64_t n, const float* d_x, int x_pitch, in
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cin * cout + 63) / 64), dim3(256), 0, s, partial, nb, cin, cout, d_dw, acc);
     HIMO_LAUNCH_CHECK("wgrad kernels");
+    if (d_db && (flags & 2u)) {                            // the split kernel left the bias partials behind the weight partials
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3(co_tiles), dim3(1024), 0, s, colpart, nb, cout, d_db, acc);
+        HIMO_LAUNCH_CHECK("colsum_reduce_kernel");
+        return HIMO_OK;
+    }
     if (d_db) return colsum_launch(n, d_dz, z_pitch, cout, d_db, acc, colpart, s);
     return HIMO_OK;
 }

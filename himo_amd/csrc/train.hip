@@ -892,7 +892,7 @@ extern "C" int himo_add2d(int64_t rows, int cols, const float* d_b, int b_pitch,
 
 static int wgrad_tiled_chunks(int n_tiles, int tiles_xy) {
     // ~2 blocks per CU over the whole launch, at least 4 pixel tiles per block (each block writes 144 KB of partials)
-    int chunks = (2 * 256 + tiles_xy - 1) / tiles_xy;
+    int chunks = (2 * 256 + tiles_xy - 1) / tiles_xy;     // (256 / 384 / 768 blocks: within 1-2 % either way, scripts/ab_train.sh)
     if (chunks > n_tiles / 4) chunks = n_tiles / 4;
     if (chunks < 1) chunks = 1;
     return chunks;

@@ -1,0 +1,24 @@
+"""One training step as rocprofv3 sees it: from the kernel trace of `bench.py --workload train`, the launches between the last two
+adam_kernel launches (= one whole step in steady state, after every autotune probe), summed per kernel name.
+usage (GPU box): python scripts/prof_train_step.py <kernel_trace.csv> [top]"""
+import csv, re, sys, collections
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+top = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+if len(adam) < 3:
+    sys.exit("fewer than three adam_kernel launches in the trace")
+a, b = adam[-2], adam[-1]
+step = rows[a + 1:b + 1]
+t0, t1 = int(rows[a]["End_Timestamp"]), int(rows[b]["End_Timestamp"])
+fam = collections.OrderedDict()
+busy = 0
+for r in step:
+    n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", "").replace("himo::", ""))
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    e = fam.setdefault(n, [0, 0]); e[0] += 1; e[1] += d
+    busy += d
+print(f"step wall {1e-6 * (t1 - t0):.3f} ms, {len(step)} launches, kernel time summed {1e-6 * busy:.3f} ms (streams overlap)")
+for n, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:top]:
+    print(f"{n[:70]:70s} x{c:3d} {1e-3 * t:9.1f} us  avg {1e-3 * t / c:7.1f}")
