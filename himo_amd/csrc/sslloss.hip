@@ -236,7 +236,10 @@ __global__ __launch_bounds__(256) void loss_pc1_kernel(LossArgs a, int blocks0) 
     block_sum4(t, a.partial + ((size_t)blocks0 + blockIdx.x) * 4);
 }
 
-__global__ __launch_bounds__(256) void loss_final_kernel(const double* __restrict__ partial, int n_blocks, double* __restrict__ loss) {
+// expect0 / expect1 >= 0: the dynamic subset sizes the host was GIVEN (himo_ssl_loss_presized) -- a mismatch with the counted ones would
+// have sized the dynamic searches wrongly, so the loss comes back NaN instead of plausible
+__global__ __launch_bounds__(256) void loss_final_kernel(const double* __restrict__ partial, int n_blocks, double* __restrict__ loss,
+                                                         const int* __restrict__ counts, int expect0, int expect1) {
     double t[4] = {0, 0, 0, 0};
     for (int b = threadIdx.x; b < n_blocks; b += 256)
 #pragma unroll
@@ -246,6 +249,19 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const double* __restric
     if (threadIdx.x == 0) {
         loss[0] = out[0]; loss[1] = out[1]; loss[2] = out[2]; loss[3] = out[3];
         loss[4] = ((out[0] + out[1]) + out[2]) + out[3];
+        if ((expect0 >= 0 && counts[0] != expect0) || (expect1 >= 0 && counts[1] != expect1))
+            for (int k = 0; k < 5; ++k) loss[k] = __builtin_nan("");
+    }
+}
+
+// the two subset sizes alone (label > 0), ahead of time: integer atomics, one per wave
+__global__ __launch_bounds__(256) void dyn_sizes_kernel(int n0, const int* __restrict__ lab0, int n1, const int* __restrict__ lab1,
+                                                        int* __restrict__ counts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long b0 = __ballot(i < n0 && lab0[i] > 0), b1 = __ballot(i < n1 && lab1[i] > 0);
+    if ((threadIdx.x & 63) == 0) {
+        if (b0) atomicAdd(counts + 0, __popcll(b0));
+        if (b1) atomicAdd(counts + 1, __popcll(b1));
     }
 }
 
@@ -295,11 +311,52 @@ extern "C" int himo_ssl_loss(int n0, int n1, const float* d_pc0, const float* d_
                             nullptr, nullptr, d_loss, d_grad_flow, d_workspace, workspace_bytes, stream);
 }
 
+static int ssl_loss_run(int n0, int n1, const float* d_pc0, const float* d_pc1, const float* d_flow,
+                        const int32_t* d_label0, const int32_t* d_label1, int n_labels,
+                        float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
+                        const float* d_raw_dist2, const int32_t* d_raw_idx, int n_dyn0, int n_dyn1,
+                        double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int himo_ssl_loss_ex(int n0, int n1, const float* d_pc0, const float* d_pc1, const float* d_flow,
                                 const int32_t* d_label0, const int32_t* d_label1, int n_labels,
                                 float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
                                 const float* d_raw_dist2, const int32_t* d_raw_idx,
                                 double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream) {
+    return ssl_loss_run(n0, n1, d_pc0, d_pc1, d_flow, d_label0, d_label1, n_labels, grid_x0, grid_y0, grid_cell, grid_w, grid_h, d_raw_dist2,
+                        d_raw_idx, -1, -1, d_loss, d_grad_flow, d_workspace, workspace_bytes, stream);
+}
+
+// ... and with the sizes of the two dynamic subsets (points with label > 0 of pc0 / pc1) GIVEN: they size the dynamic searches, and
+// himo_ssl_loss_ex fetches them with a blocking copy in the middle of the call -- in a training step that drains the whole forward
+// pass out of the queue before the host may enqueue the backward pass.  They depend on the labels only: himo_ssl_dyn_sizes counts
+// them ahead of time (beside the forward pass), the host reads them from pinned memory, and this call never blocks.  Sizes that
+// do not match the labels turn the loss into NaN (loss_final_kernel).
+extern "C" int himo_ssl_loss_presized(int n0, int n1, const float* d_pc0, const float* d_pc1, const float* d_flow,
+                                      const int32_t* d_label0, const int32_t* d_label1, int n_labels,
+                                      float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
+                                      const float* d_raw_dist2, const int32_t* d_raw_idx, int n_dyn0, int n_dyn1,
+                                      double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (n_dyn0 < 0 || n_dyn1 < 0 || n_dyn0 > n0 || n_dyn1 > n1) return HIMO_ERR_INVALID_ARGUMENT;
+    return ssl_loss_run(n0, n1, d_pc0, d_pc1, d_flow, d_label0, d_label1, n_labels, grid_x0, grid_y0, grid_cell, grid_w, grid_h, d_raw_dist2,
+                        d_raw_idx, n_dyn0, n_dyn1, d_loss, d_grad_flow, d_workspace, workspace_bytes, stream);
+}
+
+// d_counts [2] (int32) = number of points with label > 0 in label0 / label1
+extern "C" int himo_ssl_dyn_sizes(int n0, const int32_t* d_label0, int n1, const int32_t* d_label1, int32_t* d_counts, void* stream) {
+    if (n0 < 0 || n1 < 0 || !d_counts || (n0 > 0 && !d_label0) || (n1 > 0 && !d_label1)) return HIMO_ERR_INVALID_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    HIMO_HIP(hipMemsetAsync(d_counts, 0, 8, s));
+    const int n = n0 > n1 ? n0 : n1;
+    if (n > 0) hipLaunchKernelGGL(dyn_sizes_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n0, d_label0, n1, d_label1, d_counts);
+    HIMO_LAUNCH_CHECK("dyn_sizes_kernel");
+    return HIMO_OK;
+}
+
+static int ssl_loss_run(int n0, int n1, const float* d_pc0, const float* d_pc1, const float* d_flow,
+                        const int32_t* d_label0, const int32_t* d_label1, int n_labels,
+                        float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
+                        const float* d_raw_dist2, const int32_t* d_raw_idx, int n_dyn0, int n_dyn1,
+                        double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream) {
     if ((d_raw_dist2 == nullptr) != (d_raw_idx == nullptr)) return HIMO_ERR_INVALID_ARGUMENT;
     if (n0 < 0 || n1 < 0 || n_labels < 1 || grid_w < 1 || grid_h < 1) return HIMO_ERR_INVALID_ARGUMENT;
     if (!d_loss || !d_workspace) return HIMO_ERR_INVALID_ARGUMENT;
@@ -358,9 +415,11 @@ extern "C" int himo_ssl_loss_ex(int n0, int n1, const float* d_pc0, const float*
         hipLaunchKernelGGL(dyn_write_kernel, dim3(blocks1), dim3(256), 0, s, n1, d_label1, bc1, d_pc1, a.dyn1, (int*)nullptr, a.qdyn);
     }
     HIMO_LAUNCH_CHECK("dyn_compaction");
-    int h_counts[2] = {0, 0};                    // subset sizes size the two dynamic searches (one small blocking copy)
-    HIMO_HIP(hipMemcpyAsync(h_counts, a.counts, 8, hipMemcpyDeviceToHost, s));
-    HIMO_HIP(hipStreamSynchronize(s));
+    int h_counts[2] = {n_dyn0, n_dyn1};          // subset sizes size the two dynamic searches: given, or one small blocking copy
+    if (n_dyn0 < 0) {
+        HIMO_HIP(hipMemcpyAsync(h_counts, a.counts, 8, hipMemcpyDeviceToHost, s));
+        HIMO_HIP(hipStreamSynchronize(s));
+    }
     const int nd0 = h_counts[0], nd1 = h_counts[1];
     if (nd0 > 0 && nd1 > 0) {           // the dynamic subsets, both directions in one launch (the workspace of the full search is free again)
         NngSet sets[2];
@@ -382,7 +441,7 @@ extern "C" int himo_ssl_loss_ex(int n0, int n1, const float* d_pc0, const float*
         ProfScope ps("ssl_loss_point_kernels", s);
         if (n1 > 0) hipLaunchKernelGGL(loss_pc1_kernel, dim3(blocks1), dim3(256), 0, s, a, blocks0);
         if (n0 > 0) hipLaunchKernelGGL(loss_pc0_kernel, dim3(blocks0), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, a.partial, blocks0 + blocks1, d_loss);
+        hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, a.partial, blocks0 + blocks1, d_loss, a.counts, n_dyn0, n_dyn1);
     }
     HIMO_LAUNCH_CHECK("ssl_loss_point_kernels");
     return HIMO_OK;

@@ -1064,7 +1064,8 @@ class SeFlowTrainer:
         from ..ssl_loss import SeFlowLoss
         if not hasattr(self, "loss"):
             self.loss = SeFlowLoss(device=self.device)
-        raw, hook = None, None
+        raw, hook, sizes = None, None, None
+        self._sizes = None
         if self.overlap_decoder:
             # the cluster term's correspondences pc0 -> pc1 depend on the sweeps only: searched on the second side stream UNDER the
             # forward pass instead of between forward and backward (a grid build + a 120k-point query: ~0.17 ms of the chain)
@@ -1075,6 +1076,9 @@ class SeFlowTrainer:
                 with torch.cuda.stream(self.side2):
                     self.side2.wait_event(ready)
                     self._raw = self.loss.raw_neighbours(self.net.xyz_t[1][:m0], self.net.xyz_t[2][:m1])
+                    # ... and the sizes of the two dynamic subsets (labels only): counted here, read from pinned memory at the loss,
+                    # which then never blocks -- the host enqueues the backward pass while the forward pass is still running
+                    self._sizes = self.loss.dyn_sizes(label0, label1)
                     self._raw_done = torch.cuda.Event()
                     self._raw_done.record(self.side2)
         res = self.forward(pch1, pc0, pc1, pose_h1, pose0, pose1, after_pillarize=hook)
@@ -1082,7 +1086,10 @@ class SeFlowTrainer:
         if hook is not None and n0 > 0 and n1 > 0:
             torch.cuda.current_stream(self.device).wait_event(self._raw_done)
             raw = self._raw[:2]
-        terms, total, grad = self.loss(self.net.xyz_t[1][:n0], self.net.xyz_t[2][:n1], res[:, :3].contiguous(), label0, label1, n_labels, raw=raw)
+        if self._sizes is not None and n_labels is not None:
+            sizes, (label0, label1) = self._sizes[:2], self._sizes[2]
+        terms, total, grad = self.loss(self.net.xyz_t[1][:n0], self.net.xyz_t[2][:n1], res[:, :3].contiguous(), label0, label1, n_labels, raw=raw,
+                                       sizes=sizes)
         dres = torch.zeros((n0, 4), dtype=torch.float32, device=self.device)
         dres[:, :3] = grad
         self.backward(dres)

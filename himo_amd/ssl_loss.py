@@ -25,6 +25,12 @@ _lib.register({
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "himo_ssl_dyn_sizes": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "himo_ssl_loss_presized": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                              ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                              ctypes.c_void_p]),
 })
 
 # search grid: 1 m BEV cells over the network range +- a margin (points beyond it are binned into border cells)
@@ -76,7 +82,26 @@ class SeFlowLoss:
                                          _lib.ptr(self._raw_idx), _lib.ptr(self._raw_ws), self._raw_ws.numel(), _lib.stream_handle()), "himo_nn_grid")
         return self._raw_d2[:n0], self._raw_idx[:n0], (p0, p1)
 
-    def __call__(self, pc0, pc1, flow, label0, label1, n_labels: int | None = None, raw=None):
+    def dyn_sizes(self, label0, label1):
+        """The sizes of the two dynamic subsets (label > 0), counted NOW on the current stream and copied to pinned host memory: hand
+        the result to ``__call__`` as ``sizes`` and the loss call never blocks the host (it otherwise copies the two numbers back in
+        the middle of the call, after everything enqueued before it -- a training step's whole forward pass -- has drained).  They
+        depend on the labels only, so a training step counts them beside its forward pass (himo_amd/seflow/train.py).  The buffers
+        are this object's own: one outstanding count at a time."""
+        dev = self.device
+        l0 = label0.to(device=dev, dtype=torch.int32).contiguous()
+        l1 = label1.to(device=dev, dtype=torch.int32).contiguous()
+        if getattr(self, "_sizes_dev", None) is None:
+            self._sizes_dev = torch.zeros(2, dtype=torch.int32, device=dev)
+            self._sizes_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        _lib.check(self.lib.himo_ssl_dyn_sizes(l0.shape[0], _lib.ptr(l0), l1.shape[0], _lib.ptr(l1), _lib.ptr(self._sizes_dev),
+                                               _lib.stream_handle()), "himo_ssl_dyn_sizes")
+        self._sizes_host.copy_(self._sizes_dev, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        return done, self._sizes_host, (l0, l1)
+
+    def __call__(self, pc0, pc1, flow, label0, label1, n_labels: int | None = None, raw=None, sizes=None):
         dev = self.device
         p0, p1, f = _f32(pc0, dev)[:, :3].contiguous(), _f32(pc1, dev)[:, :3].contiguous(), _f32(flow, dev)
         l0 = label0.to(device=dev, dtype=torch.int32).contiguous()
@@ -91,9 +116,18 @@ class SeFlowLoss:
             self._ws = torch.empty(need + 64, dtype=torch.uint8, device=dev)
         loss = torch.zeros(5, dtype=torch.float64, device=dev)
         grad = torch.zeros((n0, 3), dtype=torch.float32, device=dev)
+        if raw is not None and n0 > 0 and n1 > 0 and (raw[0].shape != (n0,) or raw[1].shape != (n0,)):
+            raise ValueError("raw correspondences do not match pc0")
+        if sizes is not None:
+            sizes[0].synchronize()                               # the count's own event (long past by now), not the stream
+            nd0, nd1 = int(sizes[1][0]), int(sizes[1][1])
+            r0, r1 = (raw[0], raw[1]) if (raw is not None and n0 > 0 and n1 > 0) else (None, None)
+            _lib.check(self.lib.himo_ssl_loss_presized(n0, n1, _lib.ptr(p0), _lib.ptr(p1), _lib.ptr(f), _lib.ptr(l0), _lib.ptr(l1), n_labels,
+                                                       GRID_X0, GRID_Y0, GRID_CELL, GRID_W, GRID_H, _lib.ptr(r0), _lib.ptr(r1), nd0, nd1,
+                                                       _lib.ptr(loss), _lib.ptr(grad), _lib.ptr(self._ws), self._ws.numel(),
+                                                       _lib.stream_handle()), "himo_ssl_loss_presized")
+            return {name: loss[k] for k, name in enumerate(TERMS)}, loss[4], grad
         if raw is not None and n0 > 0 and n1 > 0:
-            if raw[0].shape != (n0,) or raw[1].shape != (n0,):
-                raise ValueError("raw correspondences do not match pc0")
             _lib.check(self.lib.himo_ssl_loss_ex(n0, n1, _lib.ptr(p0), _lib.ptr(p1), _lib.ptr(f), _lib.ptr(l0), _lib.ptr(l1), n_labels,
                                                  GRID_X0, GRID_Y0, GRID_CELL, GRID_W, GRID_H, _lib.ptr(raw[0]), _lib.ptr(raw[1]), _lib.ptr(loss),
                                                  _lib.ptr(grad), _lib.ptr(self._ws), self._ws.numel(), _lib.stream_handle()), "himo_ssl_loss_ex")

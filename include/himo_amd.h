@@ -449,6 +449,17 @@ int himo_ssl_loss_ex(int n0, int n1, const float* d_pc0, const float* d_pc1, con
                      float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
                      const float* d_raw_dist2, const int32_t* d_raw_idx,
                      double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream);
+/* ... and without the internal synchronisation: n_dyn0 / n_dyn1 = the number of points with label > 0 in d_label0 / d_label1, which
+ * size the dynamic-subset searches (himo_ssl_loss_ex copies them back in the middle of the call -- in a training step that drains the
+ * forward pass out of the queue before the backward pass can be enqueued).  himo_ssl_dyn_sizes counts them into d_counts [2] ahead of
+ * time (they depend on the labels only; the caller copies them to pinned host memory beside the forward pass).  Sizes that do not
+ * match the labels return every loss term as NaN.  (Reference: the loss of assets/slurm/ssl-train-av2.sh:33, source absent.) */
+int himo_ssl_dyn_sizes(int n0, const int32_t* d_label0, int n1, const int32_t* d_label1, int32_t* d_counts, void* stream);
+int himo_ssl_loss_presized(int n0, int n1, const float* d_pc0, const float* d_pc1, const float* d_flow,
+                           const int32_t* d_label0, const int32_t* d_label1, int n_labels,
+                           float grid_x0, float grid_y0, float grid_cell, int grid_w, int grid_h,
+                           const float* d_raw_dist2, const int32_t* d_raw_idx, int n_dyn0, int n_dyn1,
+                           double* d_loss, float* d_grad_flow, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a12: optimisation-based scene flow ("fastnsf", README.md:53).  Reference implementation absent (OpenSceneFlow

@@ -19,6 +19,21 @@ for r in step:
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     e = fam.setdefault(n, [0, 0]); e[0] += 1; e[1] += d
     busy += d
-print(f"step wall {1e-6 * (t1 - t0):.3f} ms, {len(step)} launches, kernel time summed {1e-6 * busy:.3f} ms (streams overlap)")
+# union of the busy intervals, and the idle gaps between them (who ended before, who started after)
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in step)
+union, gaps, cur_end, cur_name = 0, [], t0, "adam_kernel"
+for a_, b_, n_ in iv:
+    if a_ > cur_end:
+        gaps.append((a_ - cur_end, cur_name, n_))
+        union += b_ - a_
+        cur_end, cur_name = b_, n_
+    elif b_ > cur_end:
+        union += b_ - cur_end
+        cur_end, cur_name = b_, n_
+short = lambda n: re.sub(r"\(.*", "", n.replace("void ", "").replace("himo::", ""))[:40]
+print(f"step wall {1e-6 * (t1 - t0):.3f} ms, {len(step)} launches, kernel time summed {1e-6 * busy:.3f} ms (streams overlap), "
+      f"device busy (union) {1e-6 * union:.3f} ms, idle {1e-6 * sum(g[0] for g in gaps):.3f} ms in {len(gaps)} gaps")
+for g, before, after in sorted(gaps, reverse=True)[:12]:
+    print(f"   gap {1e-3 * g:7.1f} us  after {short(before)}  before {short(after)}")
 for n, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"{n[:70]:70s} x{c:3d} {1e-3 * t:9.1f} us  avg {1e-3 * t / c:7.1f}")

@@ -176,3 +176,42 @@ def test_loss_with_the_raw_correspondences_supplied_is_the_same_loss(gpu):
     st = lib.himo_ssl_loss_ex(10, 10, z.data_ptr(), z.data_ptr(), z.data_ptr(), zi.data_ptr(), zi.data_ptr(), 2, -52.0, -52.0, 1.0, 104, 104,
                               z.data_ptr(), None, loss.data_ptr(), z.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_handle())
     assert st != 0                                            # distances without indices: invalid argument
+
+
+@pytest.mark.gpu
+def test_loss_with_the_dynamic_subset_sizes_supplied_is_the_same_loss_and_never_blocks(gpu):
+    """himo_ssl_loss_presized: the sizes of the two dynamic subsets counted ahead (SeFlowLoss.dyn_sizes; the training step counts them on a
+    side stream under its forward pass) -- every term and the gradient bit-identical to the call that copies them back itself, with and
+    without the raw correspondences; sizes that do not match the labels give NaN, sizes out of range are refused; edge cases: no
+    dynamic point on one side, an empty pc1."""
+    from himo_amd import _lib
+    from himo_amd.ssl_loss import SeFlowLoss
+    pc0, pc1, flow, lab0, lab1 = _scene(43, 20_000, 18_500)
+    t = lambda a: torch.from_numpy(a).to(gpu)
+    eng = SeFlowLoss(device=gpu)
+    terms, total, grad = eng(t(pc0), t(pc1), t(flow), t(lab0), t(lab1), n_labels=int(lab0.max()) + 1)
+    sizes = eng.dyn_sizes(t(lab0), t(lab1))
+    sizes[0].synchronize()
+    assert sizes[1].tolist() == [int((lab0 > 0).sum()), int((lab1 > 0).sum())]
+    terms2, total2, grad2 = eng(t(pc0), t(pc1), t(flow), t(lab0), t(lab1), n_labels=int(lab0.max()) + 1, sizes=sizes[:2])
+    assert total.item() == total2.item() and torch.equal(grad, grad2)
+    assert all(terms[k].item() == terms2[k].item() for k in terms)
+    d2, idx, _keep = eng.raw_neighbours(t(pc0), t(pc1))
+    sizes = eng.dyn_sizes(t(lab0), t(lab1))
+    terms3, total3, grad3 = eng(t(pc0), t(pc1), t(flow), t(lab0), t(lab1), n_labels=int(lab0.max()) + 1, raw=(d2, idx), sizes=sizes[:2])
+    assert total.item() == total3.item() and torch.equal(grad, grad3)
+    # wrong sizes: loud
+    done, host, _ = eng.dyn_sizes(t(lab0), t(lab1))
+    done.synchronize()
+    wrong = host.clone(); wrong[0] -= 1
+    _, total4, _ = eng(t(pc0), t(pc1), t(flow), t(lab0), t(lab1), n_labels=int(lab0.max()) + 1, sizes=(done, wrong))
+    assert np.isnan(total4.item())
+    wrong[0] = pc0.shape[0] + 1
+    with pytest.raises(Exception):
+        eng(t(pc0), t(pc1), t(flow), t(lab0), t(lab1), n_labels=int(lab0.max()) + 1, sizes=(done, wrong))
+    # no dynamic point in pc1; an empty pc1
+    for l1, p1 in ((np.zeros_like(lab1), pc1), (lab1[:0], pc1[:0])):
+        a = eng(t(pc0), t(p1), t(flow), t(lab0), t(l1), n_labels=int(lab0.max()) + 1)
+        sizes = eng.dyn_sizes(t(lab0), t(l1))
+        b = eng(t(pc0), t(p1), t(flow), t(lab0), t(l1), n_labels=int(lab0.max()) + 1, sizes=sizes[:2])
+        assert a[1].item() == b[1].item() and torch.equal(a[2], b[2])
