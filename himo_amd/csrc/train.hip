@@ -403,6 +403,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(ConvWgradTiled
     constexpr int TR = 2, HR = 4, HC = 34;
     __shared__ __attribute__((aligned(16))) unsigned short Xt[2][HR][64][kWsPxp];
     __shared__ __attribute__((aligned(16))) unsigned short Yt[2][TR][64][kWsPxp];
+    // the 32-bit word that FOLLOWS an 8-pixel fragment (pixels 8 c + 8, + 9 of a channel: the first word of chunk c + 1), a second time
+    // as [plane][row][c][channel]: read from Xt it is a ds_read_b32 at a 20-dword channel pitch -- 32 banks, lanes 8 apart on the same
+    // one, 4-way conflicts that made these six small reads of a step cost more LDS cycles than its eight 16-byte reads (PMC: 62 % of
+    // the kernel's LDS cycles were bank conflicts); here consecutive lanes read consecutive words
+    __shared__ unsigned Xn[2][HR][4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = wave & 1, wn = wave >> 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -477,6 +482,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(ConvWgradTiled
             split2_bf16_pair(vx[ch][4], vx[ch][5], h.z, m.z); split2_bf16_pair(vx[ch][6], vx[ch][7], h.w, m.w);
             *reinterpret_cast<uint4*>(&Xt[0][sg][sc][ch * 8]) = h;
             *reinterpret_cast<uint4*>(&Xt[1][sg][sc][ch * 8]) = m;
+            if (ch > 0) { Xn[0][sg][ch - 1][sc] = h.x; Xn[1][sg][ch - 1][sc] = m.x; }
         }
 #pragma unroll
         for (int r = 0; r < kYItems; ++r) {
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_kernel(ConvWgradTiled
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
                         q[p] = *reinterpret_cast<const uint4*>(&Xt[p][r + ky][wm * 32 + li][px]);
-                        q4[p] = *reinterpret_cast<const unsigned*>(&Xt[p][r + ky][wm * 32 + li][px + 8]);
+                        q4[p] = Xn[p][r + ky][2 * s + lh][wm * 32 + li];
                     }
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {

@@ -585,6 +585,7 @@ class SeFlowTrainer:
             self.dCATb = {"dec3": self.dCAT, "dec2": buf(H * W // 4 * 256), "dec1": buf(H * W // 16 * 512)}
             self.dTMPb = {"dec3": self.dTMPc, "dec2": buf(H * W // 16 * 128), "dec1": buf(H * W // 64 * 256)}
         self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self._bn_bias_zeroed = set()                              # see _zero_bn_bias
         # BatchNorm in training mode: per-layer batch statistics kept for the backward pass; the pillar net has one set per sweep
         self.bn_mean = torch.zeros((len(self.layers), 256), dtype=torch.float32, device=dev)
         self.bn_invstd = torch.zeros((len(self.layers), 256), dtype=torch.float32, device=dev)
@@ -732,7 +733,17 @@ class SeFlowTrainer:
             self.side2.wait_event(ready)
             fn(self.ws_side2)
 
+    def _zero_bn_bias(self, name):
+        """batch mode: the bias gradient of a convolution in front of a training-mode BatchNorm is exactly zero.  Its entries of flat_g
+        are zeroed once and stay zero until something writes them -- ``_colsum`` does (a backward after a frozen-statistics forward)
+        and forgets the layer here -- instead of one fill launch per layer and step (16 of a step's ~340 launches, each with its
+        launch gap on the data-gradient chain)."""
+        if name not in self._bn_bias_zeroed:
+            self.g[f"{name}.bias"].zero_()
+            self._bn_bias_zeroed.add(name)
+
     def _colsum(self, rows, z, pitch, cout, gname, acc=False, ws=None):
+        self._bn_bias_zeroed.discard(gname.rsplit(".", 1)[0])
         ws = self.ws if ws is None else ws
         _lib.check(self.lib.himo_colsum(rows, z, pitch, cout, self.g[gname].data_ptr(), 1 if acc else 0, ws.data_ptr(),
                                         ws.numel(), _lib.stream_handle()), "colsum")
@@ -971,12 +982,12 @@ class SeFlowTrainer:
                     side_done[li] = torch.cuda.Event()
                     side_done[li].record(self.side)
                 if self._fwd_batch:
-                    self.g[f"{name}.bias"].zero_()
+                    self._zero_bn_bias(name)
             else:
                 if not self._fwd_batch:
                     self._colsum(F * ho * wo, dp, cout, cout, f"{name}.bias")
                 else:
-                    self.g[f"{name}.bias"].zero_()
+                    self._zero_bn_bias(name)
                 self._wgrad3_batch(F, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride)
             wf, wp = self._flip(name, 3, cin, cout)
             if stride == 2:

@@ -1,6 +1,7 @@
 """One training step as rocprofv3 sees it: from the kernel trace of `bench.py --workload train`, the launches between the last two
 adam_kernel launches (= one whole step in steady state, after every autotune probe), summed per kernel name.
-usage (GPU box): python scripts/prof_train_step.py <kernel_trace.csv> [top]"""
+usage (GPU box): python scripts/prof_train_step.py <kernel_trace.csv> [top] [step index]   (bench.py: 1 priming step, the warm-up steps, the K timed
+steps, K more for the single-stream figure, K more for the roofline region, one step with every kernel timed)"""
 import csv, re, sys, collections
 
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -9,7 +10,10 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
 if len(adam) < 3:
     sys.exit("fewer than three adam_kernel launches in the trace")
-a, b = adam[-2], adam[-1]
+walls = [1e-6 * (int(rows[adam[i + 1]]["End_Timestamp"]) - int(rows[adam[i]]["End_Timestamp"])) for i in range(len(adam) - 1)]
+print("step walls (ms) between consecutive adam_kernel launches:", " ".join(f"{w:.2f}" for w in walls))
+which = int(sys.argv[3]) if len(sys.argv) > 3 else len(adam) - 2       # the step that ENDS with adam launch `which + 1`
+a, b = adam[which], adam[which + 1]
 step = rows[a + 1:b + 1]
 t0, t1 = int(rows[a]["End_Timestamp"]), int(rows[b]["End_Timestamp"])
 fam = collections.OrderedDict()
