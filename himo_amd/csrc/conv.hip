@@ -470,8 +470,11 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
     a.aux_in = d->aux_in; a.aux_in_pitch = d->aux_in_pitch; a.aux_out = d->aux_out; a.aux_out_pitch = d->aux_out_pitch;
     a.act_flags = d->act_layout;
     a.range_seen = (d->act_layout & 2) ? d->d_range_seen : nullptr;
-    if (d->act_layout & 8) {      // HIMO_ACT_ACCUMULATE: y += result; the two-term bf16 3x3 stride-1 kernel with the bias epilogue only
-        if (d->act_layout != 8 || !d->w_packed || d->packed_format != 2 || d->ksize != 3 || d->stride != 1 || d->epilogue != kEpiBias)
+    if (d->act_layout & (8 | 16)) {      // HIMO_ACT_ACCUMULATE (y += result) / HIMO_ACT_STUFFED_2X (compact input read zero-stuffed):
+        // the two-term bf16 3x3 stride-1 kernel with the bias epilogue only
+        if ((d->act_layout & ~(8 | 16)) || !d->w_packed || d->packed_format != 2 || d->ksize != 3 || d->stride != 1 || d->epilogue != kEpiBias)
+            return HIMO_ERR_UNSUPPORTED;
+        if ((d->act_layout & 16) && ((d->h & 1) || (d->w_in & 1) || (int64_t)(d->h / 2) * (d->w_in / 2) * d->x_pitch * 4 >= ((int64_t)1 << 31)))
             return HIMO_ERR_UNSUPPORTED;
     } else if (d->act_layout) {   // split activation format: fp16-split 3x3 layers only, whole 16-channel groups
         if ((d->act_layout & ~3) || !d->w_packed || d->packed_format != 1) return HIMO_ERR_UNSUPPORTED;

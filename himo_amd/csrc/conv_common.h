@@ -33,7 +33,8 @@ struct ConvArgs {
     int act_flags;                                            // kActSplitIn | kActSplitOut: split activation format (convsg.hip)
     unsigned* range_seen;                                     // himo_conv_desc.d_range_seen (split outputs; may be null)
 };
-enum ActFlags { kActSplitIn = 1, kActSplitOut = 2, kActVecStore = 4, kActAccumulate = 8 };
+enum ActFlags { kActSplitIn = 1, kActSplitOut = 2, kActVecStore = 4, kActAccumulate = 8, kActStuffedIn = 16 };
+// kActStuffedIn (HIMO_ACT_STUFFED_2X): x is a compact [H / 2][W / 2] map read as its zero-stuffed x2 image (two-term bf16 3x3 kernel)
 // kActVecStore: set by the launchers (vec_store_ok).  kActAccumulate (HIMO_ACT_ACCUMULATE): y += result -- float32 output of the
 // two-term bf16 3x3 kernels only (the training step's stride-2 data gradients add into the decoder's skip gradient in place)
 

@@ -44,7 +44,9 @@ template <> struct PatchLayout<true> {
 // 2 li + kx -- are again 32 CONSECUTIVE patch pixels for every tap.
 // FMT = 4: the two-term bf16 split x = h + m (16 significant bits, float32 range; three products h*h + h*m + m*h) -- the data-gradient
 // convolutions of the mixed-precision training step (himo_conv_pack_weights_ex format 2); NP = planes of the format.
-template <int EPI, int PH, int FMT, int MI, int S>
+// STUF (FMT = 4, S = 1 only): the zero-stuffed input of kActStuffedIn, as its own instantiation (the plain kernels sit at their
+// register limit: the second path spilled in them).
+template <int EPI, int PH, int FMT, int MI, int S, bool STUF = false>
 __global__ __launch_bounds__(256, (FMT != 3 && S == 1) ? 3 : 2)
 void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int NP = FMT == 3 ? 3 : 2;
@@ -73,6 +75,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wp = wave % PH, wc = wave / PH;
+    const int wpu = __builtin_amdgcn_readfirstlane(wp);          // (scalar copy: the zero-row test of the stuffed input)
     const int li = lane & 31, lh = lane >> 5;
     const int co = tn * BN + wc * 32 + li;
     const bool co_ok = co < a.Cout;
@@ -88,8 +91,13 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     // ONCE, out-of-image items get an offset beyond the resource (the load returns zeros without a branch), and a slab is the
     // scalar offset of the instruction -- a slab's loads cost no vector arithmetic at all.  (Per-slab 64-bit per-lane address
     // arithmetic with an exec-mask branch around every load was ~25 vector instructions per item and slab.)
+    // kActStuffedIn (FMT = 4, S = 1: the data gradient of a stride-2 layer): x is the COMPACT [H / 2][W / 2] gradient map and the
+    // image convolved is its zero-stuffed x2 version -- pixel (iy, ix) exists where both are even, at compact (iy / 2, ix / 2); every
+    // other item lies "outside" and loads zeros.  Rows with odd iy are zero as a whole: their matrix instructions are skipped below.
+    constexpr bool stuffed = STUF;
+    const int xh = stuffed ? a.H >> 1 : a.H, xw = stuffed ? a.W >> 1 : a.W;
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(xin), 0, (int)min((int64_t)a.H * a.W * a.x_pitch * 4, (int64_t)0x7fffffff), 0x00020000);
+        const_cast<float*>(xin), 0, (int)min((int64_t)xh * xw * a.x_pitch * 4, (int64_t)0x7fffffff), 0x00020000);
     constexpr unsigned kOutside = 0x80000000u;
     unsigned poff[kPatchPerThread];
 #pragma unroll
@@ -98,8 +106,13 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
         const int pp = item >> 2, q = item & 3;
         const int pc = pp % PW;
         const int iy = iy0 + pp / PW, ix = ix0 + (S == 1 ? pc : pc < 33 ? 2 * pc : 2 * (pc - 33) + 1);
-        const bool ok = item < kPatchItems && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        poff[it] = ok ? (unsigned)(((iy * a.W + ix) * a.x_pitch + q * 4) * 4) : kOutside;
+        bool ok = item < kPatchItems && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        if (stuffed) {
+            ok = ok && !((iy | ix) & 1);
+            poff[it] = ok ? (unsigned)((((iy >> 1) * xw + (ix >> 1)) * a.x_pitch + q * 4) * 4) : kOutside;
+        } else {
+            poff[it] = ok ? (unsigned)(((iy * a.W + ix) * a.x_pitch + q * 4) * 4) : kOutside;
+        }
     }
     const bool ragged_cin = (a.Cin & 15) != 0;          // the last slab of a Cin that is no multiple of 16: per-quad test
     auto load_patch = [&](int slab, float4 (&r)[kPatchPerThread]) {
@@ -176,13 +189,27 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
                     load_b(t2 < 9 ? t2 : t2 - 9, t2 < 9 ? slab : nslab, bq[(kx + 2) % 3]);
                 }
                 const int tapoff = S == 1 ? ky * PW + kx : ky * PW + (kx & 1) * 33 + (kx >> 1);
+                const uint4 (&bcur)[NP] = bq[kx];
+                if constexpr (STUF) {
+                    {                            // output row oy reads input row oy + ky - 1: zero as a whole when that is odd (scalar test)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            if ((oy0 + wpu * MI + mi + ky - 1) & 1) continue;
+                            bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&patch[buf][0][PL::slot((wp * MI + mi) * PW + li + tapoff, lh)]);
+                            bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&patch[buf][1][PL::slot((wp * MI + mi) * PW + li + tapoff, lh)]);
+                            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, __builtin_bit_cast(bf16x8, bcur[0]), acc[mi], 0, 0, 0);
+                            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, bcur[1]), acc[mi], 0, 0, 0);
+                            acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, __builtin_bit_cast(bf16x8, bcur[0]), acc[mi], 0, 0, 0);
+                        }
+                        continue;
+                    }
+                }
                 bf16x8 af[MI][NP];
 #pragma unroll
                 for (int s = 0; s < NP; ++s)
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi)
                         af[mi][s] = *reinterpret_cast<const bf16x8*>(&patch[buf][s][PL::slot((wp * MI + mi) * S * PW + li + tapoff, lh)]);
-                const uint4 (&bcur)[NP] = bq[kx];
 #define HIMO_TERM(SA, SB)                                                                                          \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                                \
         acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][SA], __builtin_bit_cast(bf16x8, bcur[SB]), acc[mi], 0, 0, 0);
@@ -290,6 +317,9 @@ static void launch_sp_epi(const ConvArgs& a_in, int epi, const unsigned short* w
     ConvArgs a = a_in;
     if (vec_store_ok(a) && (!(a.act_flags & kActSplitOut) || !(a.Cout & 15))) a.act_flags |= kActVecStore;
     if constexpr (FMT == 4) {          // the data-gradient format: bias epilogue only (launch_conv3_split has checked)
+        if constexpr (S == 1) {
+            if (a.act_flags & kActStuffedIn) { hipLaunchKernelGGL((conv3_split_kernel<kEpiBias, PH, FMT, MI, S, true>), grid, dim3(256), 0, s, a, w); return; }
+        }
         hipLaunchKernelGGL((conv3_split_kernel<kEpiBias, PH, FMT, MI, S>), grid, dim3(256), 0, s, a, w);
         return;
     }
@@ -317,8 +347,9 @@ static void launch_sp_mi(const ConvArgs& a, int epi, int mi, int stride, const u
 // rows_hint: 0 = heuristic, else image rows per wave (4 | 2 | 1; stride 2 always uses 2).
 bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, int format, int rows_hint, int stride, hipStream_t s) {
     if (epilogue == kEpiGruZR || epilogue == kEpiGruQ) return false;
-    if (format == 2 && (epilogue != kEpiBias || (a.act_flags & ~kActAccumulate))) return false;        // two-term bf16: float32 maps, bias epilogue
+    if (format == 2 && (epilogue != kEpiBias || (a.act_flags & ~(kActAccumulate | kActStuffedIn)))) return false;   // two-term bf16: float32 maps, bias epilogue
     if ((a.act_flags & kActAccumulate) && (format != 2 || !vec_store_ok(a))) return false;              // y += result: that kernel's 16-byte store path only
+    if ((a.act_flags & kActStuffedIn) && (format != 2 || stride != 1)) return false;                    // zero-stuffed input: that kernel, stride 1
     const bool wide = a.Cout > 64;                     // PH = 1: 128-channel tiles; PH = 2: 64-channel tiles
     const int bn = wide ? 128 : 64, ph = wide ? 1 : 2;
     auto blocks_for = [&](int mi) -> int64_t {

@@ -37,6 +37,7 @@ class ConvDesc(ctypes.Structure):
 
 ACT_SPLIT_IN, ACT_SPLIT_OUT = 1, 2      # himo_conv_desc.act_layout: x / y in the split activation format (csrc/convsg.hip)
 ACT_ACCUMULATE = 8                      # y += result (two-term bf16 3x3 kernel, float32 maps)
+ACT_STUFFED_2X = 16                     # x is a compact [H/2][W/2] map read as its zero-stuffed x2 image (same kernel)
 
 
 _lib.register({
@@ -685,14 +686,18 @@ def conv2d_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, strid
                 tile_hint: int = 0, act_layout: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
     """x [N,H,W,Cin] float32 (contiguous, device), weight [k,k,Cin,Cout] -> y [N,Ho,Wo,Cout].  ``act_layout``:
     ACT_SPLIT_IN / ACT_SPLIT_OUT -- x / y hold the split activation format (same shape, fp16 pairs; f16x2 3x3 layers only);
-    ACT_ACCUMULATE with ``out`` given: out += result (bf16x2 3x3 stride-1 layers)."""
+    ACT_ACCUMULATE with ``out`` given: out += result (bf16x2 3x3 stride-1 layers); ACT_STUFFED_2X: x [N,H/2,W/2,Cin] is read as its
+    zero-stuffed [N,H,W,Cin] image (x[2i][2j] = map[i][j]; the data gradient of a stride-2 layer) -> y [N,H,W,Cout]."""
     lib = _lib.load()
     n, h, w, cin = x.shape
     k, _, _, cout = weight.shape
+    stuffed = bool(act_layout & ACT_STUFFED_2X)
+    if stuffed:
+        h, w = 2 * h, 2 * w
     ho, wo = ((h + 1) // 2, (w + 1) // 2) if stride == 2 else (h, w)
     y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device) if out is None else out
     d = ConvDesc()
-    d.x = x.data_ptr(); d.x_batch_stride = h * w * cin; d.x_pitch = cin
+    d.x = x.data_ptr(); d.x_batch_stride = (h * w * cin) // (4 if stuffed else 1); d.x_pitch = cin
     d.w = weight.data_ptr(); d.bias = bias.data_ptr()
     d.scale = None if scale is None else scale.data_ptr(); d.shift = None if shift is None else shift.data_ptr()
     d.y = y.data_ptr(); d.y_batch_stride = ho * wo * cout; d.y_pitch = cout

@@ -586,6 +586,7 @@ class SeFlowTrainer:
             self.dTMPb = {"dec3": self.dTMPc, "dec2": buf(H * W // 16 * 128), "dec1": buf(H * W // 64 * 256)}
         self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
         self._bn_bias_zeroed = set()                              # see _zero_bn_bias
+        self.stuffed_dgrad = True            # stride-2 data gradients read dY as its zero-stuffed image (HIMO_ACT_STUFFED_2X); False: a stuffed copy first
         # BatchNorm in training mode: per-layer batch statistics kept for the backward pass; the pillar net has one set per sweep
         self.bn_mean = torch.zeros((len(self.layers), 256), dtype=torch.float32, device=dev)
         self.bn_invstd = torch.zeros((len(self.layers), 256), dtype=torch.float32, device=dev)
@@ -633,10 +634,12 @@ class SeFlowTrainer:
                    "weight_prepare_batch")
 
     # ---- launch helpers (raw device addresses: most operands are channel groups of wider buffers) --------------
-    def _conv(self, x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride=1, packed=None, fmt=0, accumulate=False):
+    def _conv(self, x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride=1, packed=None, fmt=0, accumulate=False,
+              stuffed=False):
+        """``stuffed``: x is the compact [h / 2][wd / 2] map read as its zero-stuffed x2 image (HIMO_ACT_STUFFED_2X)"""
         if packed is not None and self.precision != "f32" and packed in self._flip_ptrs:
             fmt = self.bwd3_format                    # a data-gradient copy (_flip)
-        key = (x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride, packed, fmt, accumulate)
+        key = (x, x_bs, x_pitch, w, bias, y, y_bs, y_pitch, n, h, wd, cin, cout, ks, stride, packed, fmt, accumulate, stuffed)
         d = self._descs.get(key)                 # cached per call site: see HeadTrainer._gemm
         if d is None:
             d = ConvDesc()
@@ -645,9 +648,9 @@ class SeFlowTrainer:
             d.w_packed = packed; d.packed_format = fmt
             d.y, d.y_batch_stride, d.y_pitch = y, y_bs, y_pitch
             d.n, d.h, d.w_in, d.cin, d.cout, d.ksize, d.stride, d.epilogue = n, h, wd, cin, cout, ks, stride, EPI_BIAS
-            d.act_layout = 8 if accumulate else 0     # HIMO_ACT_ACCUMULATE: y += result (two-term bf16 3x3 kernel)
+            d.act_layout = (8 if accumulate else 0) | (16 if stuffed else 0)     # HIMO_ACT_ACCUMULATE | HIMO_ACT_STUFFED_2X (two-term bf16 3x3 kernel)
             if self.tune_tiles and ks == 3 and packed is not None and self.precision != "f32":
-                tkey = (n, h, wd, cin, cout, stride, fmt, bool(accumulate))
+                tkey = (n, h, wd, cin, cout, stride, fmt, bool(accumulate), bool(stuffed))
                 if tkey not in self._tile_hints:
                     self._tile_hints[tkey] = self._tune_tile(d)
                 d.tile_hint = self._tile_hints[tkey]
@@ -991,10 +994,16 @@ class SeFlowTrainer:
                 self._wgrad3_batch(F, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride)
             wf, wp = self._flip(name, 3, cin, cout)
             if stride == 2:
+                dst = dcat[cin]                                  # fan-in: add to the decoder's skip gradient
+                if self.bwd3_format == 2 and self.stuffed_dgrad:
+                    # ... in the convolution's own epilogue (frames = channel groups of dst), and the convolution reads dp as its own
+                    # zero-stuffed image: no stuffed copy is written or read, and the all-zero rows cost no matrix instructions
+                    self._conv(dp, ho * wo * cout, cout, wf, zb, dst.data_ptr(), cin, cin * F, F, h, w, cout, cin, 3, packed=wp, accumulate=True,
+                               stuffed=True)
+                    continue
                 z = self.Z.data_ptr()
                 _lib.check(lib.himo_zero_stuff2x(F, ho, wo, cout, dp, ho * wo * cout, cout, z, h * w * cout, cout, s()), "zero_stuff")
-                dst = dcat[cin]                                  # fan-in: add to the decoder's skip gradient
-                if self.bwd3_format == 2:                        # ... in the convolution's own epilogue (frames = channel groups of dst)
+                if self.bwd3_format == 2:
                     self._conv(z, h * w * cout, cout, wf, zb, dst.data_ptr(), cin, cin * F, F, h, w, cout, cin, 3, packed=wp, accumulate=True)
                 else:
                     tmp = self.TMP.data_ptr()

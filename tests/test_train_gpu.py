@@ -156,6 +156,42 @@ def test_two_term_bf16_convolution_for_the_data_gradients(gpu, stride, h, w, cin
         assert np.array_equal(out.cpu().numpy(), base + y)
 
 
+@pytest.mark.parametrize("h,w,cin,cout,n", [(16, 32, 64, 32, 2), (24, 64, 128, 64, 3), (8, 96, 256, 128, 1), (64, 64, 64, 32, 1)])
+def test_stride2_data_gradient_reads_the_compact_map_as_its_zero_stuffed_image(gpu, h, w, cin, cout, n):
+    """HIMO_ACT_STUFFED_2X: the two-term bf16 3x3 kernel convolving a compact [h][w] gradient map as its zero-stuffed [2h][2w] image (the
+    data gradient of a stride-2 layer, himo_amd/seflow/train.py) returns the bits of the same kernel on the materialised image
+    (himo_zero_stuff2x) -- every tile variant, alone and with HIMO_ACT_ACCUMULATE -- and equals the float64 transposed convolution."""
+    from himo_amd import _lib
+    from himo_amd.seflow.model import ACT_ACCUMULATE, ACT_STUFFED_2X, conv2d_nhwc
+    import himo_amd.seflow.train  # noqa: F401  (registers himo_zero_stuff2x)
+    lib = _lib.load()
+    rng = np.random.default_rng(h + 3 * cin)
+    g = (rng.normal(size=(n, h, w, cin)) * 10.0 ** rng.uniform(-6, 0, size=(n, h, w, 1))).astype(np.float32)
+    wt = (rng.normal(size=(3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = np.zeros(cout, np.float32)
+    tg, tw, tb = (torch.from_numpy(a).to(gpu) for a in (g, wt, b))
+    z = torch.empty((n, 2 * h, 2 * w, cin), dtype=torch.float32, device=gpu)
+    _lib.check(lib.himo_zero_stuff2x(n, h, w, cin, tg.data_ptr(), h * w * cin, cin, z.data_ptr(), 4 * h * w * cin, cin, _lib.stream_handle()), "stuff")
+    for hint in (0, 0x1001, 0x1002, 0x1004):
+        try:
+            want = conv2d_nhwc(z, tw, tb, precision="bf16x2", tile_hint=hint)
+        except Exception:
+            continue                                          # a variant this shape does not admit
+        got = conv2d_nhwc(tg, tw, tb, precision="bf16x2", tile_hint=hint, act_layout=ACT_STUFFED_2X)
+        assert got.shape == want.shape and torch.equal(got, want), hint
+    base = torch.from_numpy(rng.normal(size=tuple(want.shape)).astype(np.float32)).to(gpu)
+    out = base.clone()
+    conv2d_nhwc(tg, tw, tb, precision="bf16x2", act_layout=ACT_STUFFED_2X | ACT_ACCUMULATE, out=out)
+    assert torch.equal(out, base + want)
+    # = the adjoint of the stride-2 convolution with the flipped kernel: conv_transpose2d(g, flip(w)) cropped to [2h][2w]
+    ref = F.conv2d(z.permute(0, 3, 1, 2).double().cpu(), torch.from_numpy(wt).permute(3, 2, 0, 1).double(), None, padding=1).permute(0, 2, 3, 1).numpy()
+    mag = F.conv2d(z.permute(0, 3, 1, 2).double().cpu().abs(), torch.from_numpy(wt).permute(3, 2, 0, 1).double().abs(), None, padding=1).permute(0, 2, 3, 1).numpy()
+    assert (np.abs(want.cpu().numpy() - ref) / np.maximum(mag, 1e-30)).max() <= 2.0 ** -15
+    # odd stuffed sizes / other formats are refused
+    with pytest.raises(Exception):
+        conv2d_nhwc(tg, tw, tb, precision="f16x2", act_layout=ACT_STUFFED_2X)
+
+
 @pytest.mark.parametrize("n,cin,cout", [(5000, 128, 128), (70_001, 192, 256), (33_333, 384, 64), (4096, 3, 64)])
 def test_split_bf16_linear_weight_gradient(gpu, n, cin, cout):
     """himo_linear_wgrad_ex with flag 2 (split-bf16 operands, the mixed training default for the 1x1 layers and the head):
