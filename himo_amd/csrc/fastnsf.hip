@@ -185,15 +185,23 @@ __device__ inline void wg_split_pair(float a, float b, unsigned& hw, unsigned& m
 
 __global__ __launch_bounds__(256, 2) void wgrad_partial_split_kernel(int64_t n, const float* __restrict__ X, int x_pitch, int cin,
                                                                      const float* __restrict__ dZ, int z_pitch, int cout,
-                                                                     float* __restrict__ partial, int rows_pb, float* __restrict__ colpart) {
+                                                                     float* __restrict__ partial, int rows_pb, float* __restrict__ colpart,
+                                                                     int n_chunks) {
     __shared__ __attribute__((aligned(16))) unsigned short Xt[2][128][kWsRowsPad];
     __shared__ __attribute__((aligned(16))) unsigned short Zt[2][128][kWsRowsPad];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = wave & 1, wn = wave >> 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int co_tiles = (cout + 127) / 128;
-    const int ci0 = ((int)blockIdx.y / co_tiles) * 128, co0 = ((int)blockIdx.y % co_tiles) * 128;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_pb;
+    const int co_tiles = (cout + 127) / 128, tiles = ((cin + 127) / 128) * co_tiles;
+    // 1-D grid: the (input tile, output tile) blocks of ONE row chunk get the linear ids m * 8 + x for consecutive m -- the dispatcher
+    // places block b on XCD b % 8, so they run on the same XCD at the same time and the X / dZ rows that two of them read (each operand
+    // tile is read once per tile of the other operand: 1.7 GB for the head's 480k x 192 x 256 gate gradient, which ran at HBM speed)
+    // meet in that XCD's L2 instead of coming from HBM once per reader
+    const int lin = (int)blockIdx.x, xcd = lin & 7, m = lin >> 3;
+    const int tile = m % tiles, chunk = (m / tiles) * 8 + xcd;
+    if (chunk >= n_chunks) return;
+    const int ci0 = (tile / co_tiles) * 128, co0 = (tile % co_tiles) * 128;
+    const int64_t r0 = (int64_t)chunk * rows_pb;
     const int64_t r1 = r0 + rows_pb < n ? r0 + rows_pb : n;
     floatx16 acc[2][2];
 #pragma unroll
@@ -287,9 +295,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_partial_split_kernel(int64_t n, 
         float* bsh = reinterpret_cast<float*>(&Xt[0][0][0]);
         bsh[threadIdx.x] = bsum;
         __syncthreads();
-        if (threadIdx.x < 128) colpart[((int64_t)(co0 / 128) * gridDim.x + blockIdx.x) * 128 + sc] = bsh[sc] + bsh[128 + sc];
+        if (threadIdx.x < 128) colpart[((int64_t)(co0 / 128) * n_chunks + chunk) * 128 + sc] = bsh[sc] + bsh[128 + sc];
     }
-    float* out = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 128 * 128;
+    float* out = partial + ((int64_t)tile * n_chunks + chunk) * 128 * 128;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -633,8 +641,8 @@ extern "C" int himo_linear_wgrad_ex(int64_t n, const float* d_x, int x_pitch, in
         const bool vec = !(x_pitch & 3) && !(z_pitch & 3) && !(cin & 3) && !(cout & 3) &&
                          !((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_dz)) & 15);
         if (flags & 2u)
-            hipLaunchKernelGGL(wgrad_partial_split_kernel, dim3(nb, ci_tiles * co_tiles), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch,
-                               cout, partial, rows_pb, d_db ? colpart : nullptr);
+            hipLaunchKernelGGL(wgrad_partial_split_kernel, dim3((unsigned)((nb + 7) / 8 * 8 * ci_tiles * co_tiles)), dim3(256), 0, s, n, d_x, x_pitch,
+                               cin, d_dz, z_pitch, cout, partial, rows_pb, d_db ? colpart : nullptr, nb);
         else if (vec)
             hipLaunchKernelGGL(wgrad_partial_lds_kernel, dim3(nb, ci_tiles * co_tiles), dim3(256), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch,
                                cout, partial, rows_pb);

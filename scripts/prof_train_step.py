@@ -41,3 +41,11 @@ for g, before, after in sorted(gaps, reverse=True)[:12]:
     print(f"   gap {1e-3 * g:7.1f} us  after {short(before)}  before {short(after)}")
 for n, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"{n[:70]:70s} x{c:3d} {1e-3 * t:9.1f} us  avg {1e-3 * t / c:7.1f}")
+
+import os
+pat = os.environ.get("LIST")                        # LIST=<substring>: every launch of the matching kernels, in start order
+if pat:
+    for r in sorted(step, key=lambda r: int(r["Start_Timestamp"])):
+        if pat in r["Kernel_Name"]:
+            print(f"   {short(r['Kernel_Name'])}  grid {r.get('Grid_Size', '?'):>9s}  wg {r.get('Workgroup_Size', '?'):>5s}  "
+                  f"{1e-3 * (int(r['End_Timestamp']) - int(r['Start_Timestamp'])):8.1f} us  stream {r.get('Stream_Id', r.get('Queue_Id', '?'))}")
