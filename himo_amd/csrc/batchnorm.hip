@@ -13,7 +13,7 @@
 //             dx = gamma invstd (g - mean(g) - xhat mean(g xhat))            (in place on dx)
 // Every reduction is a fixed two-level tree (block partials -> one block per 128 channels): bit-deterministic, no atomics.
 // Algorithmic bytes per element: forward 4 + 4 + 8 = 16 B, backward 8 + 4 + 8 + 4 = 24 B.
-#include "himo_common.h"
+#include "conv_common.h"
 #include <math.h>
 
 namespace himo {
@@ -23,16 +23,25 @@ struct BnMap {                 // [n_img][rows][ch] view: element (i, r, c) at p
 };
 struct BnMapW { float* p; int64_t img_stride; int pitch; };
 
-__device__ inline float bn_gelu(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
-__device__ inline float bn_gelu_grad(float v) {
-    return 0.5f * (1.0f + erff(v * 0.70710678118654752440f)) + v * 0.39894228040143267794f * expf(-0.5f * v * v);
-}
+// GELU and its derivative as the convolution epilogues evaluate them (conv_common.h: erf to 1.5e-7 absolute, hardware exp2 / rcp): the
+// library's erff / expf made both element-wise passes instruction-bound (~80 instructions per activation against 12-24 B of traffic)
+__device__ inline float bn_gelu(float v) { return gelu_exact(v); }
+__device__ inline float bn_gelu_grad(float v) { return gelu_grad_exact(v); }
 
 // block = 8 row groups x 32 float4 columns (a 128-channel tile, blockIdx.y) over `rows_pb` consecutive global rows
 __device__ inline int64_t bn_addr(int64_t r, int64_t rows, int64_t img_stride, int pitch) {
     const int64_t img = r / rows;
     return img * img_stride + (r - img * rows) * pitch;
 }
+// The row walks below split their FIRST global row into (image, row in image) with 32-bit divisions (the entry points admit only
+// total rows x quads < 2^31) and then step: a 64-bit division per row and quad -- ~150 instructions, emulated -- used to be most of
+// these kernels' instruction count.
+struct BnRow {
+    int img, rr;
+    __device__ inline BnRow(unsigned r, unsigned rows) : img((int)(r / rows)), rr((int)(r - (r / rows) * rows)) {}
+    __device__ inline void step(int by, int rows) { rr += by; while (rr >= rows) { rr -= rows; ++img; } }
+    __device__ inline int64_t at(int64_t img_stride, int pitch) const { return (int64_t)img * img_stride + (int64_t)rr * pitch; }
+};
 
 // narrow layers keep every lane busy: a block covers 2^qs float4 columns (32 for > 64 channels, 16 for > 32, else 8) x 256 >> qs row groups
 __device__ __host__ inline int bn_quad_shift(int ch) { return ch > 64 ? 5 : (ch > 32 ? 4 : 3); }
@@ -62,9 +71,10 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(int64_t total, in
     const int64_t r1 = r0 + rows_pb < total ? r0 + rows_pb : total;
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     if (col < ch) {
+        BnRow row((unsigned)(r0 + grp), (unsigned)rows);
 #pragma unroll 4
-        for (int64_t r = r0 + grp; r < r1; r += G) {
-            const float4 v = *reinterpret_cast<const float4*>(x.p + bn_addr(r, rows, x.img_stride, x.pitch) + col);
+        for (int64_t r = r0 + grp; r < r1; r += G, row.step(G, (int)rows)) {
+            const float4 v = *reinterpret_cast<const float4*>(x.p + row.at(x.img_stride, x.pitch) + col);
             s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
             ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
         }
@@ -126,12 +136,13 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const double* _
 __global__ __launch_bounds__(256) void bn_normalize_gelu_kernel(int64_t total, int64_t rows, int ch, BnMap x, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, BnMapW xhat, BnMapW y) {
-    const int c4 = ch >> 2;
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total * c4) return;
-    const int64_t r = e / c4;
+    const unsigned c4 = (unsigned)ch >> 2;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= (unsigned)total * c4) return;
+    const unsigned r = e / c4;
     const int col = (int)(e - r * c4) * 4;
-    const int64_t img = r / rows, rr = r - img * rows;
+    const BnRow row(r, (unsigned)rows);
+    const int64_t img = row.img, rr = row.rr;
     const float4 v = *reinterpret_cast<const float4*>(x.p + img * x.img_stride + rr * x.pitch + col);
     const float4 m = *reinterpret_cast<const float4*>(mean + col), is = *reinterpret_cast<const float4*>(invstd + col);
     const float4 ga = *reinterpret_cast<const float4*>(gamma + col), be = *reinterpret_cast<const float4*>(beta + col);
@@ -151,22 +162,25 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(int64_t total, int6
     const int col = (int)blockIdx.y * 128 + q * 4;
     const int64_t r0 = (int64_t)blockIdx.x * rows_pb;
     const int64_t r1 = r0 + rows_pb < total ? r0 + rows_pb : total;
-    double s[4] = {0, 0, 0, 0}, sx[4] = {0, 0, 0, 0};
+    // a thread's own rows (a few dozen at most: rows_pb / G) are summed in float32, everything across threads and blocks in float64
+    float fs[4] = {0, 0, 0, 0}, fx[4] = {0, 0, 0, 0};
     if (col < ch) {
         const float4 ga = *reinterpret_cast<const float4*>(gamma + col), be = *reinterpret_cast<const float4*>(beta + col);
-#pragma unroll 2
-        for (int64_t r = r0 + grp; r < r1; r += G) {
-            const int64_t img = r / rows, rr = r - img * rows;
+        BnRow row((unsigned)(r0 + grp), (unsigned)rows);
+#pragma unroll 4
+        for (int64_t r = r0 + grp; r < r1; r += G, row.step(G, (int)rows)) {
+            const int64_t img = row.img, rr = row.rr;
             const float4 d = *reinterpret_cast<const float4*>(dy.p + img * dy.img_stride + rr * dy.pitch + col);
             const float4 h = *reinterpret_cast<const float4*>(xhat.p + img * xhat.img_stride + rr * xhat.pitch + col);
             float4 g;
             g.x = d.x * bn_gelu_grad(ga.x * h.x + be.x); g.y = d.y * bn_gelu_grad(ga.y * h.y + be.y);
             g.z = d.z * bn_gelu_grad(ga.z * h.z + be.z); g.w = d.w * bn_gelu_grad(ga.w * h.w + be.w);
             *reinterpret_cast<float4*>(dx.p + img * dx.img_stride + rr * dx.pitch + col) = g;
-            s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
-            sx[0] += (double)g.x * h.x; sx[1] += (double)g.y * h.y; sx[2] += (double)g.z * h.z; sx[3] += (double)g.w * h.w;
+            fs[0] += g.x; fs[1] += g.y; fs[2] += g.z; fs[3] += g.w;
+            fx[0] = fmaf(g.x, h.x, fx[0]); fx[1] = fmaf(g.y, h.y, fx[1]); fx[2] = fmaf(g.z, h.z, fx[2]); fx[3] = fmaf(g.w, h.w, fx[3]);
         }
     }
+    const double s[4] = {fs[0], fs[1], fs[2], fs[3]}, sx[4] = {fx[0], fx[1], fx[2], fx[3]};
     bn_block_partials(s, sx, qs, q, grp, G, partial);
 }
 
@@ -189,12 +203,13 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double* __r
 // dx = k1 * (g - k2 - xhat * k3), in place on dx (which holds g)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int64_t total, int64_t rows, int ch, BnMap xhat, const float* __restrict__ coef,
                                                            BnMapW dx) {
-    const int c4 = ch >> 2;
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total * c4) return;
-    const int64_t r = e / c4;
+    const unsigned c4 = (unsigned)ch >> 2;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= (unsigned)total * c4) return;
+    const unsigned r = e / c4;
     const int col = (int)(e - r * c4) * 4;
-    const int64_t img = r / rows, rr = r - img * rows;
+    const BnRow row(r, (unsigned)rows);
+    const int64_t img = row.img, rr = row.rr;
     float* p = dx.p + img * dx.img_stride + rr * dx.pitch + col;
     const float4 g = *reinterpret_cast<const float4*>(p);
     const float4 h = *reinterpret_cast<const float4*>(xhat.p + img * xhat.img_stride + rr * xhat.pitch + col);
@@ -247,6 +262,7 @@ extern "C" int himo_bn_train_fwd(int n_img, int64_t rows, int ch, const float* d
         return HIMO_ERR_UNSUPPORTED;                        // 16-byte accesses: aligned bases, strides multiples of 4 floats
     if ((d_running_mean == nullptr) != (d_running_var == nullptr)) return HIMO_ERR_INVALID_ARGUMENT;
     const int64_t total = (int64_t)n_img * rows;
+    if (total * (ch >> 2) >= ((int64_t)1 << 31)) return HIMO_ERR_UNSUPPORTED;      // 32-bit element indices in the kernels
     if (workspace_bytes < bn_ws(total, ch) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int rows_pb = bn_rows_per_block(total);
@@ -279,6 +295,7 @@ extern "C" int himo_bn_train_bwd(int n_img, int64_t rows, int ch, const float* d
     if (!bn_map_ok(d_dy, dy_img_stride, dy_pitch, ch) || !bn_map_ok(d_xhat, xhat_img_stride, xhat_pitch, ch) || !bn_map_ok(d_dx, dx_img_stride, dx_pitch, ch))
         return HIMO_ERR_UNSUPPORTED;
     const int64_t total = (int64_t)n_img * rows;
+    if (total * (ch >> 2) >= ((int64_t)1 << 31)) return HIMO_ERR_UNSUPPORTED;      // 32-bit element indices in the kernels
     if (workspace_bytes < bn_ws(total, ch) || !aligned16(d_workspace)) return HIMO_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int rows_pb = bn_rows_per_block(total);

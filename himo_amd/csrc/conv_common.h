@@ -75,6 +75,19 @@ __device__ inline float gelu_exact(float v) {
     const float e = fmaf(-(p * t), ex, 1.0f);                 // erf(|v| / sqrt 2)
     return fmaf(fabsf(hv), e, hv);
 }
+// d gelu / dv = Phi(v) + v phi(v) in the same arrangement: the erf polynomial and ONE exponential (exp(-v^2 / 2) is both the tail of
+// the erf form and the density) -- 16 vector + 2 transcendental instructions where erff + expf from the library take ~80; the
+// BatchNorm backward pass evaluates it once per activation and was bound by exactly that, not by its three HBM streams
+__device__ inline float gelu_grad_exact(float v) {
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, fabsf(v), 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float ex = __builtin_amdgcn_exp2f((v * v) * (-0.5f * 1.44269504088896340736f));      // exp(-v^2 / 2)
+    const float e = fmaf(-(p * t), ex, 1.0f);                 // erf(|v| / sqrt 2)
+    return fmaf(v * 0.39894228040143267794f, ex, 0.5f + copysignf(0.5f * e, v));
+}
 // GRU gates: hardware exp2 / rcp (~1 ulp each); the gate outputs are O(1) and feed a 1e-4 abs budget
 __device__ inline float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ inline float tanh_f(float v) {

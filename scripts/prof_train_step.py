@@ -49,3 +49,12 @@ if pat:
         if pat in r["Kernel_Name"]:
             print(f"   {short(r['Kernel_Name'])}  grid {r.get('Grid_Size', '?'):>9s}  wg {r.get('Workgroup_Size', '?'):>5s}  "
                   f"{1e-3 * (int(r['End_Timestamp']) - int(r['Start_Timestamp'])):8.1f} us  stream {r.get('Stream_Id', r.get('Queue_Id', '?'))}")
+
+# per-stream totals: which stream the step's time sits on (the main stream's chain is the critical path when the others hide under it)
+per = collections.OrderedDict()
+for r in step:
+    k = r.get("Stream_Id", r.get("Queue_Id", "?"))
+    e = per.setdefault(k, [0, 0, collections.Counter()]); e[0] += 1
+    d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); e[1] += d; e[2][short(r["Kernel_Name"])] += d
+for k, (c, t, names) in per.items():
+    print(f"stream {k}: {c} launches, {1e-6 * t:.3f} ms of kernel time; top: " + ", ".join(f"{n} {1e-3 * v:.0f} us" for n, v in names.most_common(6)))
