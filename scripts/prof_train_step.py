@@ -57,4 +57,4 @@ for r in step:
     e = per.setdefault(k, [0, 0, collections.Counter()]); e[0] += 1
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); e[1] += d; e[2][short(r["Kernel_Name"])] += d
 for k, (c, t, names) in per.items():
-    print(f"stream {k}: {c} launches, {1e-6 * t:.3f} ms of kernel time; top: " + ", ".join(f"{n} {1e-3 * v:.0f} us" for n, v in names.most_common(6)))
+    print(f"stream {k}: {c} launches, {1e-6 * t:.3f} ms of kernel time; top: " + ", ".join(f"{n} {1e-3 * v:.0f} us" for n, v in names.most_common(int(os.environ.get("STREAM_TOP", "6")))))
