@@ -404,6 +404,7 @@ int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w
         HIMO_LAUNCH_CHECK("conv3_split_kernel");
         return HIMO_OK;
     }
+    if (ksize == 3 && (tile_hint & 0x1000) && (tile_hint & 15) > 4) return HIMO_ERR_UNSUPPORTED;     // a pinned variant this layer does not admit
     if (stride != 1) return HIMO_ERR_UNSUPPORTED;
     if (format == 2 && (ksize != 1 || (epilogue != kEpiBias && epilogue != kEpiReluMask) || a.act_flags)) return HIMO_ERR_UNSUPPORTED;     // two-term bf16: 3x3 in convsp.hip, row GEMMs here
     auto blocks_for = [&](int bn, int mi) -> int64_t {

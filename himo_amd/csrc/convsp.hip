@@ -11,6 +11,10 @@
 // double-buffered -- ONE barrier per slab (9 taps = 108 / 216 matrix instructions per wave).
 //   PH = 1: block = 128 pixels x 128 channels (waves = 4 channel tiles);
 //   PH = 2: block = 256 pixels x  64 channels (waves = 2 pixel groups x 2 channel tiles), for the 64-channel layers.
+//   PH = 4: block = 4 pixel groups x ONE 32-channel tile (stride 1, the two-term formats; rows_hint 9 | 10): every wave of the block reads
+//           the SAME weight fragments, so they come from L2 once per block and from the CU's vector cache for the other three waves.
+//           For the low-resolution wide layers of a one-sample training step: a 64 x 64 x 256 -> 256 layer's 768 blocks of PH = 1,
+//           one image row each, pull 1.2 MB of weight fragments apiece through L2 -- 0.9 GB per layer, which is what its 58 us were.
 // With float32 activations in HBM this is the kernel of every 3x3 layer (bf16 split: always; fp16 split: training, and
 // `SeFlowNet.split_acts = False`); the fp16-split inference network stores its maps already split and runs convsg.hip,
 // which replaces the register staging below by LDS-DMA.  This kernel's epilogue can WRITE that format (kActSplitOut).
@@ -56,7 +60,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
     constexpr int kPatchItems = NPIX * 4;
     constexpr int kPatchPerThread = (kPatchItems + 255) / 256;
     // double-buffered while two blocks still fit a CU's LDS; else single-buffered with a second barrier per slab
-    using PL = PatchLayout<(PH == 2 || S == 2)>;
+    using PL = PatchLayout<(PH >= 2 || S == 2)>;
     constexpr int NB = 2 * NP * NPIX * PL::kPitch <= 66 * 1024 ? 2 : 1;
     // raw bytes, at least the 4 x 4 KB the vectorised epilogue stages through (store_block_vec, conv_common.h)
     constexpr int kPatchBytes = NB * NP * NPIX * PL::kPitch;
@@ -350,20 +354,30 @@ bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, i
     if (format == 2 && (epilogue != kEpiBias || (a.act_flags & ~(kActAccumulate | kActStuffedIn)))) return false;   // two-term bf16: float32 maps, bias epilogue
     if ((a.act_flags & kActAccumulate) && (format != 2 || !vec_store_ok(a))) return false;              // y += result: that kernel's 16-byte store path only
     if ((a.act_flags & kActStuffedIn) && (format != 2 || stride != 1)) return false;                    // zero-stuffed input: that kernel, stride 1
-    const bool wide = a.Cout > 64;                     // PH = 1: 128-channel tiles; PH = 2: 64-channel tiles
-    const int bn = wide ? 128 : 64, ph = wide ? 1 : 2;
+    // rows_hint 5 | 6: PH = 2 forced (wide layers too), 1 | 2 rows per wave; 9 | 10: PH = 4, 1 | 2 rows per wave -- stride 1, two-term formats
+    const int ph_hint = (stride == 1 && format != 0 && (rows_hint == 5 || rows_hint == 6)) ? 2
+                      : (stride == 1 && format != 0 && (rows_hint == 9 || rows_hint == 10)) ? 4 : 0;
+    if (!ph_hint && rows_hint > 4) return false;
+    const bool wide = a.Cout > 64 && ph_hint == 0;     // PH = 1: 128-channel tiles; PH = 2: 64-channel tiles
+    const int ph = ph_hint ? ph_hint : (wide ? 1 : 2), bn = (4 / ph) * 32;
     auto blocks_for = [&](int mi) -> int64_t {
         const int th = mi * ph;
         return (int64_t)a.N * ((a.Ho + th - 1) / th) * ((a.Wo + 31) / 32) * ((a.Cout + bn - 1) / bn);
     };
     int mi = blocks_for(4) >= 1024 ? 4 : 2;            // two blocks per CU, at least two rounds of them
     if (rows_hint == 4 || rows_hint == 2 || rows_hint == 1) mi = rows_hint;
+    if (ph_hint) mi = rows_hint & 3;
     if (stride == 2) mi = (rows_hint == 1 || rows_hint == 2) ? rows_hint : (wide ? 2 : 1);
     const dim3 grid((unsigned)blocks_for(mi));
     const unsigned short* w = (const unsigned short*)w_packed;
     const char* name = stride == 2 ? (format == 1 ? "conv3x3s2_f16x2_kernel" : format == 2 ? "conv3x3s2_bf16x2_kernel" : "conv3x3s2_bf16x3_kernel")
                                    : (format == 1 ? "conv3x3_f16x2_kernel" : format == 2 ? "conv3x3_bf16x2_kernel" : "conv3x3_bf16x3_kernel");
     ProfScope ps(name, s);
+    if (ph == 4) {                                      // stride 1, rows per wave 1 | 2 only (fewer instantiations)
+        if (format == 2) { if (mi == 1) launch_sp_epi<4, 4, 1, 1>(a, epilogue, w, grid, s); else launch_sp_epi<4, 4, 2, 1>(a, epilogue, w, grid, s); }
+        else { if (mi == 1) launch_sp_epi<4, 2, 1, 1>(a, epilogue, w, grid, s); else launch_sp_epi<4, 2, 2, 1>(a, epilogue, w, grid, s); }
+        return true;
+    }
     if (format == 2) { if (wide) launch_sp_mi<1, 4>(a, epilogue, mi, stride, w, grid, s); else launch_sp_mi<2, 4>(a, epilogue, mi, stride, w, grid, s); }
     else if (format == 1) { if (wide) launch_sp_mi<1, 2>(a, epilogue, mi, stride, w, grid, s); else launch_sp_mi<2, 2>(a, epilogue, mi, stride, w, grid, s); }
     else { if (wide) launch_sp_mi<1, 3>(a, epilogue, mi, stride, w, grid, s); else launch_sp_mi<2, 3>(a, epilogue, mi, stride, w, grid, s); }

@@ -659,7 +659,9 @@ class SeFlowTrainer:
             self._descs[key] = d
         _lib.check(self.lib.himo_conv2d(ctypes.byref(d), _lib.stream_handle()), "himo_conv2d(train)")
 
-    TILE_HINTS = (0, 0x1004, 0x1002, 0x1001)          # library heuristic, then the weights-from-L2 structure pinned to 4 / 2 / 1 rows per wave
+    # library heuristic, then the weights-from-L2 structure pinned to 4 / 2 / 1 rows per wave, to two pixel groups x two channel tiles
+    # (5 / 6: 1 / 2 rows per wave) and to four pixel groups x one 32-channel tile (9 / 10): the waves of a block share their weight fragments
+    TILE_HINTS = (0, 0x1004, 0x1002, 0x1001, 0x1005, 0x1006, 0x1009, 0x100A)
 
     def _tune_tile(self, d) -> int:
         """The fastest tile variant of one 3x3 layer shape (csrc/convsp.hip; all return the same bits).  Runs on the layer's own

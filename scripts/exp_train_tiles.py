@@ -15,7 +15,7 @@ shapes = [("enc1.0", 3, 512, 512, 32, 64, 2, 1), ("enc1.x", 3, 256, 256, 64, 64,
           ("enc2.x", 3, 128, 128, 128, 128, 1, 5), ("enc3.0", 3, 128, 128, 128, 256, 2, 1), ("enc3.x", 3, 64, 64, 256, 256, 1, 5),
           ("dec1.u4", 1, 128, 128, 512, 256, 1, 1), ("dec1.u5", 1, 128, 128, 256, 256, 1, 1), ("dec2.u4", 1, 256, 256, 256, 128, 1, 1),
           ("dec2.u5", 1, 256, 256, 128, 128, 1, 1), ("dec3.u4", 1, 512, 512, 128, 64, 1, 1), ("dec3.u5|dec4", 1, 512, 512, 64, 64, 1, 2)]
-HINTS = [0, 0x1004, 0x1002, 0x1001]
+HINTS = [0, 0x1004, 0x1002, 0x1001, 0x1006, 0x100A, 0x41, 0x42, 0x81, 0x82]
 
 
 def timed(call, reps=8):

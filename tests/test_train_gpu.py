@@ -172,7 +172,8 @@ def test_stride2_data_gradient_reads_the_compact_map_as_its_zero_stuffed_image(g
     tg, tw, tb = (torch.from_numpy(a).to(gpu) for a in (g, wt, b))
     z = torch.empty((n, 2 * h, 2 * w, cin), dtype=torch.float32, device=gpu)
     _lib.check(lib.himo_zero_stuff2x(n, h, w, cin, tg.data_ptr(), h * w * cin, cin, z.data_ptr(), 4 * h * w * cin, cin, _lib.stream_handle()), "stuff")
-    for hint in (0, 0x1001, 0x1002, 0x1004):
+    from himo_amd.seflow.train import SeFlowTrainer
+    for hint in SeFlowTrainer.TILE_HINTS:
         try:
             want = conv2d_nhwc(z, tw, tb, precision="bf16x2", tile_hint=hint)
         except Exception:
