@@ -9,10 +9,10 @@
 //
 // All three stages are HBM-bound streams over an [n_img][rows][ch] NHWC map with a per-channel reduction:
 //   forward   stats (read x once, float64 sums)  ->  finalize  ->  normalise + GELU (read x, write xhat and y)
-//   backward  g = dy * gelu'(gamma xhat + beta) written to dx, float64 sums of g and g xhat  ->  finalize  ->
-//             dx = gamma invstd (g - mean(g) - xhat mean(g xhat))            (in place on dx)
+//   backward  float64 sums of g = dy * gelu'(gamma xhat + beta) and of g xhat (read dy, xhat)  ->  finalize  ->
+//             dx = gamma invstd (g - mean(g) - xhat mean(g xhat)), g evaluated again    (read dy, xhat; write dx)
 // Every reduction is a fixed two-level tree (block partials -> one block per 128 channels): bit-deterministic, no atomics.
-// Algorithmic bytes per element: forward 4 + 4 + 8 = 16 B, backward 8 + 4 + 8 + 4 = 24 B.
+// Algorithmic bytes per element: forward 4 + 4 + 8 = 16 B, backward 8 + 8 + 4 = 20 B.
 #include "conv_common.h"
 #include <math.h>
 
@@ -175,7 +175,6 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(int64_t total, int6
             float4 g;
             g.x = d.x * bn_gelu_grad(ga.x * h.x + be.x); g.y = d.y * bn_gelu_grad(ga.y * h.y + be.y);
             g.z = d.z * bn_gelu_grad(ga.z * h.z + be.z); g.w = d.w * bn_gelu_grad(ga.w * h.w + be.w);
-            *reinterpret_cast<float4*>(dx.p + img * dx.img_stride + rr * dx.pitch + col) = g;
             fs[0] += g.x; fs[1] += g.y; fs[2] += g.z; fs[3] += g.w;
             fx[0] = fmaf(g.x, h.x, fx[0]); fx[1] = fmaf(g.y, h.y, fx[1]); fx[2] = fmaf(g.z, h.z, fx[2]); fx[3] = fmaf(g.w, h.w, fx[3]);
         }
@@ -200,9 +199,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double* __r
     }
 }
 
-// dx = k1 * (g - k2 - xhat * k3), in place on dx (which holds g)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int64_t total, int64_t rows, int ch, BnMap xhat, const float* __restrict__ coef,
-                                                           BnMapW dx) {
+// dx = k1 * (g - k2 - xhat * k3) with g = dy * gelu'(gamma xhat + beta) evaluated AGAIN (the same expression on the same operands
+// as in the sums: the same bits) -- the partial pass used to park g in dx (4 B per activation written, 4 B read back here; GELU' is
+// ~20 instructions since round 5, cheaper than the round trip).  dx may alias dy (each element is read before it is written).
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int64_t total, int64_t rows, int ch, BnMap dy, BnMap xhat,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ coef, BnMapW dx) {
     const unsigned c4 = (unsigned)ch >> 2;
     const unsigned e = blockIdx.x * 256u + threadIdx.x;
     if (e >= (unsigned)total * c4) return;
@@ -211,8 +213,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int64_t total, int64_
     const BnRow row(r, (unsigned)rows);
     const int64_t img = row.img, rr = row.rr;
     float* p = dx.p + img * dx.img_stride + rr * dx.pitch + col;
-    const float4 g = *reinterpret_cast<const float4*>(p);
+    const float4 d = *reinterpret_cast<const float4*>(dy.p + img * dy.img_stride + rr * dy.pitch + col);
     const float4 h = *reinterpret_cast<const float4*>(xhat.p + img * xhat.img_stride + rr * xhat.pitch + col);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + col), be = *reinterpret_cast<const float4*>(beta + col);
+    float4 g;
+    g.x = d.x * bn_gelu_grad(ga.x * h.x + be.x); g.y = d.y * bn_gelu_grad(ga.y * h.y + be.y);
+    g.z = d.z * bn_gelu_grad(ga.z * h.z + be.z); g.w = d.w * bn_gelu_grad(ga.w * h.w + be.w);
     const float4 k1 = *reinterpret_cast<const float4*>(coef + col), k2 = *reinterpret_cast<const float4*>(coef + ch + col),
                  k3 = *reinterpret_cast<const float4*>(coef + 2 * ch + col);
     float4 o;
@@ -311,7 +317,8 @@ extern "C" int himo_bn_train_bwd(int n_img, int64_t rows, int ch, const float* d
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tiles * 8), dim3(1024), 0, s, partial, nb, ch, (double)total, d_gamma, d_invstd, d_dgamma,
                            d_dbeta, (flags & 1u) ? 1 : 0, coef);
         const int64_t n4 = total * (ch >> 2);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, total, rows, ch, xh, coef, dx);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, total, rows, ch,
+                           BnMap{d_dy, dy_img_stride, dy_pitch}, xh, d_gamma, d_beta, coef, dx);
     }
     HIMO_LAUNCH_CHECK("bn_bwd kernels");
     return HIMO_OK;
