@@ -149,14 +149,18 @@ __global__ __launch_bounds__(256) void bn_normalize_gelu_kernel(int64_t total, i
     float4 h, o;
     h.x = (v.x - m.x) * is.x; h.y = (v.y - m.y) * is.y; h.z = (v.z - m.z) * is.z; h.w = (v.w - m.w) * is.w;
     o.x = bn_gelu(ga.x * h.x + be.x); o.y = bn_gelu(ga.y * h.y + be.y); o.z = bn_gelu(ga.z * h.z + be.z); o.w = bn_gelu(ga.w * h.w + be.w);
-    *reinterpret_cast<float4*>(xhat.p + img * xhat.img_stride + rr * xhat.pitch + col) = h;
+    if (xhat.p) *reinterpret_cast<float4*>(xhat.p + img * xhat.img_stride + rr * xhat.pitch + col) = h;      // (optional: see himo_bn_train_bwd_x)
     *reinterpret_cast<float4*>(y.p + img * y.img_stride + rr * y.pitch + col) = o;
 }
 
 // ---- backward ---------------------------------------------------------------------------------------------------------------
 // g = dy * gelu'(gamma * xhat + beta) -> dx; partial float64 sums of g and g * xhat per channel
+// FROM_X: `xhat` holds the layer's INPUT x and xhat = (x - mean) * invstd is formed here, as the forward pass formed it (the forward
+// pass then need not write xhat at all: 4 of its 16 B per activation)
+template <bool FROM_X>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(int64_t total, int64_t rows, int ch, BnMap dy, BnMap xhat,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta, BnMapW dx,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              double* __restrict__ partial, int rows_pb) {
     const int qs = bn_quad_shift(ch), q = threadIdx.x & ((1 << qs) - 1), grp = threadIdx.x >> qs, G = 256 >> qs;
     const int col = (int)blockIdx.y * 128 + q * 4;
@@ -166,12 +170,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(int64_t total, int6
     float fs[4] = {0, 0, 0, 0}, fx[4] = {0, 0, 0, 0};
     if (col < ch) {
         const float4 ga = *reinterpret_cast<const float4*>(gamma + col), be = *reinterpret_cast<const float4*>(beta + col);
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f), is = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (FROM_X) { m = *reinterpret_cast<const float4*>(mean + col); is = *reinterpret_cast<const float4*>(invstd + col); }
         BnRow row((unsigned)(r0 + grp), (unsigned)rows);
 #pragma unroll 4
         for (int64_t r = r0 + grp; r < r1; r += G, row.step(G, (int)rows)) {
             const int64_t img = row.img, rr = row.rr;
             const float4 d = *reinterpret_cast<const float4*>(dy.p + img * dy.img_stride + rr * dy.pitch + col);
-            const float4 h = *reinterpret_cast<const float4*>(xhat.p + img * xhat.img_stride + rr * xhat.pitch + col);
+            float4 h = *reinterpret_cast<const float4*>(xhat.p + img * xhat.img_stride + rr * xhat.pitch + col);
+            if (FROM_X) { h.x = (h.x - m.x) * is.x; h.y = (h.y - m.y) * is.y; h.z = (h.z - m.z) * is.z; h.w = (h.w - m.w) * is.w; }
             float4 g;
             g.x = d.x * bn_gelu_grad(ga.x * h.x + be.x); g.y = d.y * bn_gelu_grad(ga.y * h.y + be.y);
             g.z = d.z * bn_gelu_grad(ga.z * h.z + be.z); g.w = d.w * bn_gelu_grad(ga.w * h.w + be.w);
@@ -202,8 +209,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const double* __r
 // dx = k1 * (g - k2 - xhat * k3) with g = dy * gelu'(gamma xhat + beta) evaluated AGAIN (the same expression on the same operands
 // as in the sums: the same bits) -- the partial pass used to park g in dx (4 B per activation written, 4 B read back here; GELU' is
 // ~20 instructions since round 5, cheaper than the round trip).  dx may alias dy (each element is read before it is written).
+template <bool FROM_X>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int64_t total, int64_t rows, int ch, BnMap dy, BnMap xhat,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, BnMapW dx) {
     const unsigned c4 = (unsigned)ch >> 2;
     const unsigned e = blockIdx.x * 256u + threadIdx.x;
@@ -214,7 +223,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(int64_t total, int64_
     const int64_t img = row.img, rr = row.rr;
     float* p = dx.p + img * dx.img_stride + rr * dx.pitch + col;
     const float4 d = *reinterpret_cast<const float4*>(dy.p + img * dy.img_stride + rr * dy.pitch + col);
-    const float4 h = *reinterpret_cast<const float4*>(xhat.p + img * xhat.img_stride + rr * xhat.pitch + col);
+    float4 h = *reinterpret_cast<const float4*>(xhat.p + img * xhat.img_stride + rr * xhat.pitch + col);
+    if (FROM_X) {
+        const float4 m = *reinterpret_cast<const float4*>(mean + col), is = *reinterpret_cast<const float4*>(invstd + col);
+        h.x = (h.x - m.x) * is.x; h.y = (h.y - m.y) * is.y; h.z = (h.z - m.z) * is.z; h.w = (h.w - m.w) * is.w;
+    }
     const float4 ga = *reinterpret_cast<const float4*>(gamma + col), be = *reinterpret_cast<const float4*>(beta + col);
     float4 g;
     g.x = d.x * bn_gelu_grad(ga.x * h.x + be.x); g.y = d.y * bn_gelu_grad(ga.y * h.y + be.y);
@@ -264,7 +277,8 @@ extern "C" int himo_bn_train_fwd(int n_img, int64_t rows, int ch, const float* d
                                  float* d_y, int64_t y_img_stride, int y_pitch, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (n_img < 1 || rows < 1 || ch < 4 || (ch & 3) || !d_gamma || !d_beta || !d_mean || !d_invstd || !d_workspace)
         return HIMO_ERR_INVALID_ARGUMENT;
-    if (!bn_map_ok(d_x, x_img_stride, x_pitch, ch) || !bn_map_ok(d_xhat, xhat_img_stride, xhat_pitch, ch) || !bn_map_ok(d_y, y_img_stride, y_pitch, ch))
+    if (!bn_map_ok(d_x, x_img_stride, x_pitch, ch) || (d_xhat && !bn_map_ok(d_xhat, xhat_img_stride, xhat_pitch, ch)) ||
+        !bn_map_ok(d_y, y_img_stride, y_pitch, ch))
         return HIMO_ERR_UNSUPPORTED;                        // 16-byte accesses: aligned bases, strides multiples of 4 floats
     if ((d_running_mean == nullptr) != (d_running_var == nullptr)) return HIMO_ERR_INVALID_ARGUMENT;
     const int64_t total = (int64_t)n_img * rows;
@@ -292,10 +306,34 @@ extern "C" int himo_bn_train_fwd(int n_img, int64_t rows, int ch, const float* d
     return HIMO_OK;
 }
 
+static int bn_train_bwd(int n_img, int64_t rows, int ch, const float* d_dy, int64_t dy_img_stride, int dy_pitch,
+                        const float* d_xhat, int64_t xhat_img_stride, int xhat_pitch, const float* d_gamma, const float* d_beta,
+                        const float* d_mean, const float* d_invstd, float* d_dx, int64_t dx_img_stride, int dx_pitch, float* d_dgamma, float* d_dbeta,
+                        unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int himo_bn_train_bwd(int n_img, int64_t rows, int ch, const float* d_dy, int64_t dy_img_stride, int dy_pitch,
                                  const float* d_xhat, int64_t xhat_img_stride, int xhat_pitch, const float* d_gamma, const float* d_beta,
                                  const float* d_invstd, float* d_dx, int64_t dx_img_stride, int dx_pitch, float* d_dgamma, float* d_dbeta,
                                  unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
+    return bn_train_bwd(n_img, rows, ch, d_dy, dy_img_stride, dy_pitch, d_xhat, xhat_img_stride, xhat_pitch, d_gamma, d_beta, nullptr, d_invstd,
+                        d_dx, dx_img_stride, dx_pitch, d_dgamma, d_dbeta, flags, d_workspace, workspace_bytes, stream);
+}
+
+// ... from the layer's INPUT x instead of xhat (himo_bn_train_fwd called with d_xhat = NULL): xhat = (x - mean) * invstd is formed in the
+// kernels exactly as the forward pass formed it -- same results bit for bit, 4 B per activation less written by the forward pass
+extern "C" int himo_bn_train_bwd_x(int n_img, int64_t rows, int ch, const float* d_dy, int64_t dy_img_stride, int dy_pitch,
+                                   const float* d_x, int64_t x_img_stride, int x_pitch, const float* d_gamma, const float* d_beta,
+                                   const float* d_mean, const float* d_invstd, float* d_dx, int64_t dx_img_stride, int dx_pitch,
+                                   float* d_dgamma, float* d_dbeta, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!d_mean) return HIMO_ERR_INVALID_ARGUMENT;
+    return bn_train_bwd(n_img, rows, ch, d_dy, dy_img_stride, dy_pitch, d_x, x_img_stride, x_pitch, d_gamma, d_beta, d_mean, d_invstd,
+                        d_dx, dx_img_stride, dx_pitch, d_dgamma, d_dbeta, flags, d_workspace, workspace_bytes, stream);
+}
+
+static int bn_train_bwd(int n_img, int64_t rows, int ch, const float* d_dy, int64_t dy_img_stride, int dy_pitch,
+                        const float* d_xhat, int64_t xhat_img_stride, int xhat_pitch, const float* d_gamma, const float* d_beta,
+                        const float* d_mean, const float* d_invstd, float* d_dx, int64_t dx_img_stride, int dx_pitch, float* d_dgamma, float* d_dbeta,
+                        unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (n_img < 1 || rows < 1 || ch < 4 || (ch & 3) || !d_gamma || !d_beta || !d_invstd || !d_dgamma || !d_dbeta || !d_workspace)
         return HIMO_ERR_INVALID_ARGUMENT;
     if (!bn_map_ok(d_dy, dy_img_stride, dy_pitch, ch) || !bn_map_ok(d_xhat, xhat_img_stride, xhat_pitch, ch) || !bn_map_ok(d_dx, dx_img_stride, dx_pitch, ch))
@@ -312,13 +350,14 @@ extern "C" int himo_bn_train_bwd(int n_img, int64_t rows, int ch, const float* d
     const BnMapW dx{d_dx, dx_img_stride, dx_pitch};
     {
         ProfScope ps("bn_bwd_kernel", s);
-        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb, tiles), dim3(256), 0, s, total, rows, ch, BnMap{d_dy, dy_img_stride, dy_pitch}, xh,
-                           d_gamma, d_beta, dx, partial, rows_pb);
+        const BnMap dym{d_dy, dy_img_stride, dy_pitch};
+        if (d_mean) hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(nb, tiles), dim3(256), 0, s, total, rows, ch, dym, xh, d_gamma, d_beta, d_mean, d_invstd, partial, rows_pb);
+        else hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(nb, tiles), dim3(256), 0, s, total, rows, ch, dym, xh, d_gamma, d_beta, d_mean, d_invstd, partial, rows_pb);
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(tiles * 8), dim3(1024), 0, s, partial, nb, ch, (double)total, d_gamma, d_invstd, d_dgamma,
                            d_dbeta, (flags & 1u) ? 1 : 0, coef);
         const int64_t n4 = total * (ch >> 2);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, total, rows, ch,
-                           BnMap{d_dy, dy_img_stride, dy_pitch}, xh, d_gamma, d_beta, coef, dx);
+        if (d_mean) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, total, rows, ch, dym, xh, d_gamma, d_beta, d_mean, d_invstd, coef, dx);
+        else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, total, rows, ch, dym, xh, d_gamma, d_beta, d_mean, d_invstd, coef, dx);
     }
     HIMO_LAUNCH_CHECK("bn_bwd kernels");
     return HIMO_OK;

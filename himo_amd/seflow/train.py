@@ -375,6 +375,8 @@ _lib.register({
                                 c_p, ctypes.c_size_t, c_p]),
     "himo_bn_train_bwd": (c_i, [c_i, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_p, ctypes.c_uint,
                                 c_p, ctypes.c_size_t, c_p]),
+    "himo_bn_train_bwd_x": (c_i, [c_i, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_p, ctypes.c_uint,
+                                  c_p, ctypes.c_size_t, c_p]),
     "himo_bn_fold": (c_i, [c_i, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_p]),
     "himo_pfn_bn_workspace_bytes": (ctypes.c_size_t, []),
     "himo_pfn_bn_stats": (c_i, [c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
@@ -586,6 +588,8 @@ class SeFlowTrainer:
             self.dTMPb = {"dec3": self.dTMPc, "dec2": buf(H * W // 16 * 128), "dec1": buf(H * W // 64 * 256)}
         self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
         self._bn_bias_zeroed = set()                              # see _zero_bn_bias
+        self.bn_from_x = True                # batch mode: the forward pass writes no xhat, the backward pass re-forms it (himo_bn_train_bwd_x)
+        self._bn_fwd_from_x = True
         self.stuffed_dgrad = True            # stride-2 data gradients read dY as its zero-stuffed image (HIMO_ACT_STUFFED_2X); False: a stuffed copy first
         # BatchNorm in training mode: per-layer batch statistics kept for the backward pass; the pillar net has one set per sweep
         self.bn_mean = torch.zeros((len(self.layers), 256), dtype=torch.float32, device=dev)
@@ -787,6 +791,7 @@ class SeFlowTrainer:
         dev = self.device
         batch = self.bn_batch and training
         self._fwd_batch = batch
+        self._bn_fwd_from_x = self.bn_from_x                    # what THIS forward pass leaves in PRE (read by backward)
         if self.bn_batch and not training and not self._bn_folded:
             self.fold_batchnorm()
         to_dev = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(dev, torch.float32).contiguous()
@@ -828,13 +833,13 @@ class SeFlowTrainer:
                 y_ptr, y_bs, y_pitch = dst.data_ptr(), cout, cout * F          # frames as channel groups of the concat buffer
             else:
                 y_ptr, y_bs, y_pitch = self.Y[li].data_ptr(), ho * wo * cout, cout
-            if batch:                                            # PRE keeps xhat (normalised, before gamma / beta)
-                pfx = f"{name}.bn"
+            if batch:                                            # PRE keeps the convolution's output x: the backward pass re-forms
+                pfx = f"{name}.bn"                               # xhat from it and the saved mean / invstd (himo_bn_train_bwd_x)
                 _lib.check(lib.himo_bn_train_fwd(F, ho * wo, cout, pre.data_ptr(), ho * wo * cout, cout, net.p[f"{pfx}.gamma"].data_ptr(),
                                                  net.p[f"{pfx}.beta"].data_ptr(), spec.BN_EPS, BN_MOMENTUM, net.p[f"{pfx}.mean"].data_ptr(),
                                                  net.p[f"{pfx}.var"].data_ptr(), self.bn_mean[li].data_ptr(), self.bn_invstd[li].data_ptr(),
-                                                 pre.data_ptr(), ho * wo * cout, cout, y_ptr, y_bs, y_pitch, self.ws.data_ptr(),
-                                                 self.ws.numel(), s()), "bn_train_fwd")
+                                                 None if self.bn_from_x else pre.data_ptr(), ho * wo * cout, cout, y_ptr, y_bs, y_pitch,
+                                                 self.ws.data_ptr(), self.ws.numel(), s()), "bn_train_fwd")
             else:                                                # PRE keeps the affine pre-activation
                 sc, sh = net.p[f"{name}.scale"].data_ptr(), net.p[f"{name}.shift"].data_ptr()
                 if last:
@@ -958,10 +963,16 @@ class SeFlowTrainer:
             if self._fwd_batch:                                  # through GELU and the batch statistics; also d gamma / d beta
                 pfx = f"{name}.bn"
                 dy_ptr, dy_bs, dy_pitch = (dcat[cout].data_ptr(), cout, cout * F) if last else (dy, ho * wo * cout, cout)
-                _lib.check(lib.himo_bn_train_bwd(F, ho * wo, cout, dy_ptr, dy_bs, dy_pitch, pre.data_ptr(), ho * wo * cout, cout,
-                                                 net.p[f"{pfx}.gamma"].data_ptr(), net.p[f"{pfx}.beta"].data_ptr(), self.bn_invstd[li].data_ptr(),
-                                                 dp, ho * wo * cout, cout, self.g[f"{pfx}.gamma"].data_ptr(), self.g[f"{pfx}.beta"].data_ptr(),
-                                                 0, self.ws.data_ptr(), self.ws.numel(), s()), "bn_train_bwd")
+                if not self._bn_fwd_from_x:                      # PRE holds xhat (a forward pass with bn_from_x off)
+                    _lib.check(lib.himo_bn_train_bwd(F, ho * wo, cout, dy_ptr, dy_bs, dy_pitch, pre.data_ptr(), ho * wo * cout, cout,
+                                                     net.p[f"{pfx}.gamma"].data_ptr(), net.p[f"{pfx}.beta"].data_ptr(), self.bn_invstd[li].data_ptr(),
+                                                     dp, ho * wo * cout, cout, self.g[f"{pfx}.gamma"].data_ptr(), self.g[f"{pfx}.beta"].data_ptr(),
+                                                     0, self.ws.data_ptr(), self.ws.numel(), s()), "bn_train_bwd")
+                else:
+                    _lib.check(lib.himo_bn_train_bwd_x(F, ho * wo, cout, dy_ptr, dy_bs, dy_pitch, pre.data_ptr(), ho * wo * cout, cout,
+                                                       net.p[f"{pfx}.gamma"].data_ptr(), net.p[f"{pfx}.beta"].data_ptr(), self.bn_mean[li].data_ptr(),
+                                                       self.bn_invstd[li].data_ptr(), dp, ho * wo * cout, cout, self.g[f"{pfx}.gamma"].data_ptr(),
+                                                       self.g[f"{pfx}.beta"].data_ptr(), 0, self.ws.data_ptr(), self.ws.numel(), s()), "bn_train_bwd_x")
             elif last:                                           # gradient arrives in the concat layout
                 src = dcat[cout]
                 for f in range(F):

@@ -642,7 +642,7 @@ int himo_dt_loss(int n, const float* d_moved, const float* h_origin, float cell,
  * feeds the running estimate, momentum 0.1).  Maps are NHWC float32 views [n_img][rows][ch]: element (i, r, c) at
  * p + i * img_stride + r * pitch + c (16-byte aligned bases, strides multiples of 4 floats, ch % 4 == 0).
  * himo_bn_train_fwd: batch mean / invstd over all n_img * rows rows -> d_mean, d_invstd [ch] (kept for the backward pass);
- *   d_xhat = (x - mean) * invstd (may alias d_x); d_y = gelu(gamma * xhat + beta); running statistics updated in place when
+ *   d_xhat = (x - mean) * invstd (may alias d_x; NULL: not written, see himo_bn_train_bwd_x); d_y = gelu(gamma * xhat + beta); running statistics updated in place when
  *   given.  himo_bn_train_bwd: d_dy = d loss / d y -> d_dx = d loss / d x (the three-term BatchNorm gradient through the
  *   exact-erf GELU; may alias d_dy), d_dgamma / d_dbeta [ch] (flags bit 0: accumulate).  Every reduction is a fixed tree.
  * himo_bn_fold: eval-mode constants scale = gamma / sqrt(var + eps), shift = beta - mean * scale from the running statistics. */
@@ -655,6 +655,12 @@ int himo_bn_train_bwd(int n_img, int64_t rows, int ch, const float* d_dy, int64_
                       const float* d_xhat, int64_t xhat_img_stride, int xhat_pitch, const float* d_gamma, const float* d_beta,
                       const float* d_invstd, float* d_dx, int64_t dx_img_stride, int dx_pitch, float* d_dgamma, float* d_dbeta,
                       unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);
+/* himo_bn_train_bwd from the layer's INPUT x (+ d_mean) instead of xhat: himo_bn_train_fwd may then be called with d_xhat = NULL and
+ * writes 4 B per activation less; xhat is re-formed as the forward pass formed it (same results bit for bit). */
+int himo_bn_train_bwd_x(int n_img, int64_t rows, int ch, const float* d_dy, int64_t dy_img_stride, int dy_pitch,
+                        const float* d_x, int64_t x_img_stride, int x_pitch, const float* d_gamma, const float* d_beta,
+                        const float* d_mean, const float* d_invstd, float* d_dx, int64_t dx_img_stride, int dx_pitch,
+                        float* d_dgamma, float* d_dbeta, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);
 int himo_bn_fold(int ch, const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_var, float eps,
                  float* d_scale, float* d_shift, void* stream);
 /* The same for the pillar feature net's BatchNorm1d (statistics over the in-range points of ONE sweep; y = feats W):

@@ -437,6 +437,17 @@ def test_batchnorm_training_kernels_match_autograd(gpu, n_img, rows, ch, pad):
     np.testing.assert_allclose(DB.cpu().double(), br.grad, rtol=2e-5, atol=2e-5 * float(br.grad.abs().max()))
     if pad:                                              # the padding columns of the pitched maps stay untouched
         assert float(Y.cpu()[:, :, ch:].abs().max()) == 0.0 and float(DX.cpu()[:, :, ch:].abs().max()) == 0.0
+    # the trainer's form: the forward pass writes no xhat, the backward pass re-forms it from x and the saved mean / invstd -- same bits
+    Y2, DX2 = torch.zeros_like(X), torch.zeros_like(X)
+    M2, IS2, DG2, DB2 = (torch.zeros(ch, device=dev) for _ in range(4))
+    _lib.check(lib.himo_bn_train_fwd(n_img, rows, ch, X.data_ptr(), rows * pitch, pitch, G.data_ptr(), B.data_ptr(), eps, mom, None,
+                                     None, M2.data_ptr(), IS2.data_ptr(), None, 0, 0, Y2.data_ptr(), rows * pitch,
+                                     pitch, ws.data_ptr(), ws.numel(), s), "bn_train_fwd (no xhat)")
+    _lib.check(lib.himo_bn_train_bwd_x(n_img, rows, ch, DY.data_ptr(), rows * pitch, pitch, X.data_ptr(), rows * pitch, pitch, G.data_ptr(),
+                                       B.data_ptr(), M2.data_ptr(), IS2.data_ptr(), DX2.data_ptr(), rows * pitch, pitch, DG2.data_ptr(),
+                                       DB2.data_ptr(), 0, ws.data_ptr(), ws.numel(), s), "bn_train_bwd_x")
+    assert torch.equal(Y2, Y) and torch.equal(M2, M) and torch.equal(IS2, IS)
+    assert torch.equal(DX2, DX) and torch.equal(DG2, DG) and torch.equal(DB2, DB)
 
 
 @pytest.mark.parametrize("precision,n", [("mixed", 5000), ("bf16x3", 777), ("mixed", 64)])
