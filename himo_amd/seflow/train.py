@@ -1116,9 +1116,10 @@ class SeFlowTrainer:
                     self._raw_done.record(self.side2)
         res = self.forward(pch1, pc0, pc1, pose_h1, pose0, pose1, after_pillarize=hook)
         n0, n1 = self.n_pts[1], self.n_pts[2]
-        if hook is not None and n0 > 0 and n1 > 0:
+        if hook is not None:                                     # (the side stream's work, the converted labels of dyn_sizes included)
             torch.cuda.current_stream(self.device).wait_event(self._raw_done)
-            raw = self._raw[:2]
+            if n0 > 0 and n1 > 0:
+                raw = self._raw[:2]
         if self._sizes is not None and n_labels is not None:
             sizes, (label0, label1) = self._sizes[:2], self._sizes[2]
         terms, total, grad = self.loss(self.net.xyz_t[1][:n0], self.net.xyz_t[2][:n1], res[:, :3].contiguous(), label0, label1, n_labels, raw=raw,
