@@ -158,7 +158,8 @@ __device__ inline void sv_store(float* base, unsigned byte_off, float v) {
 }
 
 template <int FMT, int SLABS, bool SAVE = false>
-__global__ __launch_bounds__(256, FMT == 2 ? 3 : 2) void gru_head_kernel(GruHeadArgs a, GruHeadBatch batch, GruHeadSave sv) {
+// (SAVE: 74 KB of LDS admit two blocks per CU anyway -- the three-block register cap only bought 13 spilled registers)
+__global__ __launch_bounds__(256, (FMT == 2 && !SAVE) ? 3 : 2) void gru_head_kernel(GruHeadArgs a, GruHeadBatch batch, GruHeadSave sv) {
     constexpr bool FOLD = SLABS == 9;
     static_assert(!(SAVE && FOLD), "the training forward keeps x explicit");
     constexpr int kGhPlane = SLABS * kGhRows * 32;
