@@ -8,7 +8,8 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from himo_amd import _lib
-from himo_amd.seflow.model import conv2d_nhwc
+from himo_amd.seflow.model import conv2d_nhwc, ACT_STUFFED_2X
+from himo_amd.seflow.train import SeFlowTrainer
 import himo_amd.seflow.train  # noqa: F401  (registers the training entry points)
 
 dev = torch.device("cuda", 0)
@@ -45,15 +46,26 @@ for name, n1, h, w, ci, co, st, reps in shapes:
         wt = torch.randn(3, 3, ci, co, device=dev) * 0.05
         bias = torch.zeros(co, device=dev)
         y = torch.empty(n, ho, wo, co, device=dev)
-        fwd = timed(lambda: conv2d_nhwc(x, wt, bias, stride=st, precision="f16x2", out=y)) / b
-        # data gradient: stride 1 = the same convolution with mirrored taps (Cout -> Cin); stride 2 = the zero-stuffed dY at the
-        # input's resolution through a stride-1 convolution (train.py backward)
+        def best(call):                                   # the trainer picks the fastest tile variant per shape (train.py _tune_tile)
+            ts = []
+            for hint in SeFlowTrainer.TILE_HINTS:
+                try:
+                    ts.append(timed(lambda: call(hint)))
+                except Exception:
+                    pass                                     # a variant the shape does not admit
+            return min(ts)
+        fwd = best(lambda hint: conv2d_nhwc(x, wt, bias, stride=st, precision="f16x2", out=y, tile_hint=hint)) / b
+        # data gradient: stride 1 = the same convolution with mirrored taps (Cout -> Cin); stride 2 = the same kernel reading the compact
+        # dY as its zero-stuffed image at the input's resolution (train.py backward)
         dy = torch.randn(n, h, w, co, device=dev) * 1e-3
         wf = torch.randn(3, 3, co, ci, device=dev) * 0.05
         bz = torch.zeros(ci, device=dev)
         dx = torch.empty(n, h, w, ci, device=dev)
-        dgr = timed(lambda: conv2d_nhwc(dy, wf, bz, precision="bf16x2", out=dx)) / b
         dys = torch.randn(n, ho, wo, co, device=dev) * 1e-3
+        if st == 2:                                       # the compact gradient map read as its zero-stuffed image (HIMO_ACT_STUFFED_2X)
+            dgr = best(lambda hint: conv2d_nhwc(dys, wf, bz, precision="bf16x2", out=dx, tile_hint=hint, act_layout=ACT_STUFFED_2X)) / b
+        else:
+            dgr = best(lambda hint: conv2d_nhwc(dy, wf, bz, precision="bf16x2", out=dx, tile_hint=hint)) / b
         dw = torch.empty(3, 3, ci, co, device=dev)
         ws = torch.empty(int(lib.himo_conv_wgrad_batch_workspace_bytes(n, h, w, ci, co, st)) + 64, dtype=torch.uint8, device=dev)
         wg = timed(lambda: _lib.check(lib.himo_conv3x3_wgrad_batch(n, x.data_ptr(), h * w * ci, ci, h, w, ci, dys.data_ptr(), ho * wo * co, co, co, st,
@@ -67,4 +79,4 @@ for name, n1, h, w, ci, co, st, reps in shapes:
 for k in ("fwd", "dgrad", "wgrad"):
     print(f"sum over a step's 3x3 layers, {k:5s}: {tot[(k, 1)]:.3f} ms per sample at 1 per launch, {tot[(k, B)]:.3f} at {B} per launch")
 s1, sb = (sum(tot[(k, b)] for k in ("fwd", "dgrad", "wgrad")) for b in (1, B))
-print(f"all three: {s1:.3f} -> {sb:.3f} ms per sample (the training step is ~10.7 ms per sample)")
+print(f"all three: {s1:.3f} -> {sb:.3f} ms per sample (the training step is ~8.6 ms per sample)")
