@@ -896,9 +896,12 @@ extern "C" int himo_add2d(int64_t rows, int cols, const float* d_b, int b_pitch,
     return HIMO_OK;
 }
 
-static int wgrad_tiled_chunks(int n_tiles, int tiles_xy) {
-    // ~2 blocks per CU over the whole launch, at least 4 pixel tiles per block (each block writes 144 KB of partials)
-    int chunks = (2 * 256 + tiles_xy - 1) / tiles_xy;     // (256 / 384 / 768 blocks: within 1-2 % either way, scripts/ab_train.sh)
+static int wgrad_tiled_chunks(int n_tiles, int tiles_xy, bool beside = false) {
+    // ~2 blocks per CU over the whole launch, at least 4 pixel tiles per block (each block writes 144 KB of partials).
+    // `beside` (flags bit 2): the launch shares the device with another stream's kernels (the training step's data-gradient chain) --
+    // ONE block per CU: two of these blocks hold 496 of a SIMD lane's 512 registers and 141 of 160 KB of LDS, nothing else could be
+    // resident beside them; with one, a block of the other stream's convolutions fits on every CU (same-box: +3.1 % step)
+    int chunks = ((beside ? 1 : 2) * 256 + tiles_xy - 1) / tiles_xy;     // (256 / 384 / 768 blocks: within 1-2 % either way, scripts/ab_train.sh)
     if (chunks > n_tiles / 4) chunks = n_tiles / 4;
     if (chunks < 1) chunks = 1;
     return chunks;
@@ -952,7 +955,7 @@ static int conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_batch_stri
         return HIMO_ERR_WORKSPACE;
     const int ho = h / stride, wo = w / stride;
     const int n_tiles = n_img * (ho / (stride == 1 ? 2 : 1)) * (wo / 32), tiles_xy = ((cin + 63) / 64) * (cout / 64);
-    const int chunks = wgrad_tiled_chunks(n_tiles, tiles_xy);
+    const int chunks = wgrad_tiled_chunks(n_tiles, tiles_xy, (flags & 4u) != 0);      // (the workspace is sized for the larger count)
     ConvWgradTiledArgs a{d_x, x_batch_stride, x_pitch, d_dy, dy_batch_stride, dy_pitch, n_img, h, w, ho, wo, cin, cout,
                          (n_tiles + chunks - 1) / chunks, reinterpret_cast<float*>(d_workspace), nullptr};
     const int grid_x = (n_tiles + a.tiles_per_chunk - 1) / a.tiles_per_chunk;

@@ -588,6 +588,7 @@ class SeFlowTrainer:
             self.dTMPb = {"dec3": self.dTMPc, "dec2": buf(H * W // 16 * 128), "dec1": buf(H * W // 64 * 256)}
         self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
         self._bn_bias_zeroed = set()                              # see _zero_bn_bias
+        self.wgrad_leave_room = True         # 3x3 weight gradients on a side stream: one block per CU (himo_conv3x3_wgrad_batch flags bit 2)
         self.bn_from_x = True                # batch mode: the forward pass writes no xhat, the backward pass re-forms it (himo_bn_train_bwd_x)
         self._bn_fwd_from_x = True
         self.stuffed_dgrad = True            # stride-2 data gradients read dY as its zero-stuffed image (HIMO_ACT_STUFFED_2X); False: a stuffed copy first
@@ -698,10 +699,16 @@ class SeFlowTrainer:
 
     def _wgrad3_batch(self, n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, gname, stride=1, ws=None):
         """weight gradient over n images in one launch (LDS-tiled kernel)"""
+        flags = self.wgrad_flags | self._beside_flag(ws)
         ws = self.ws if ws is None else ws
         _lib.check(self.lib.himo_conv3x3_wgrad_batch(n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, stride,
-                                                     self.g[gname].data_ptr(), self.wgrad_flags, ws.data_ptr(), ws.numel(),
+                                                     self.g[gname].data_ptr(), flags, ws.data_ptr(), ws.numel(),
                                                      _lib.stream_handle()), "conv3x3_wgrad_batch")
+
+    def _beside_flag(self, ws) -> int:
+        """flags bit 2 of the 3x3 weight gradients: a launch on a side stream (it was handed a side workspace) takes ONE block per CU
+        and leaves the other half of every CU's registers and LDS to the data-gradient chain on the main stream"""
+        return 4 if (self.wgrad_leave_room and ws is not None and ws is not self.ws) else 0
 
     def _wgrad3(self, x, x_pitch, h, w, cin, dy, dy_pitch, cout, stride, gname, acc, ws=None):
         if stride == 1 and not acc:
@@ -716,7 +723,7 @@ class SeFlowTrainer:
         w_ = self.ws if ws is None else ws
         if self.wgrad_flags & 2:
             st = self.lib.himo_conv3x3_wgrad_batch_bias(1, x, 0, x_pitch, h, w, cin, dy, 0, dy_pitch, cout, 1, self.g[wname].data_ptr(),
-                                                        self.g[bname].data_ptr(), self.wgrad_flags, w_.data_ptr(), w_.numel(),
+                                                        self.g[bname].data_ptr(), self.wgrad_flags | self._beside_flag(ws), w_.data_ptr(), w_.numel(),
                                                         _lib.stream_handle())
             if st == 0:
                 return
@@ -725,7 +732,8 @@ class SeFlowTrainer:
 
     def set_side_streams(self, on: bool):
         """switch the weight-gradient overlap (both side streams) off / back on at run time: the same kernels in the same order per
-        stream either way, so the same bits -- bench.py times the step's dominant kernel with it off (a launch's HIP-event time
+        stream either way, so the same bits (with ``wgrad_leave_room`` off: on, the side-stream launches split their pixel chunks over
+        half as many blocks, another summation order) -- bench.py times the step's dominant kernel with it off (a launch's HIP-event time
         otherwise includes whatever the other streams co-run)"""
         self.overlap_wgrad = bool(on) and self._side_streams_built
         self.overlap_decoder = self.overlap_wgrad and self.ws_side2 is not None
@@ -987,7 +995,7 @@ class SeFlowTrainer:
             x, x_bs, x_pitch = self.inputs[li]
             if self.overlap_wgrad:
                 # the weight (and bias) gradient only READS dp and the saved layer input: it runs beside the data-gradient chain,
-                # which is the critical path (same kernels, same arguments: bit-identical gradients)
+                # which is the critical path (same kernels; with `wgrad_leave_room` one block per CU, so that the chain's blocks fit beside)
                 ready = torch.cuda.Event()
                 ready.record(main)
                 with torch.cuda.stream(self.side):

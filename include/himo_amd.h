@@ -703,7 +703,9 @@ int himo_pfn_backward_bn(int64_t n, const float* h_voxel, const float* h_centre_
  * h, w = INPUT image size.  stride 1: h even, w % 32 == 0, cin % 64 == 0; stride 2: h even, w % 64 == 0, cin == 32 or
  * cin % 64 == 0; cout % 64 == 0 -- HIMO_ERR_UNSUPPORTED otherwise (workspace_bytes returns 0).
  * flags bit 0: accumulate into d_dw; bit 1 (2): stride-1 layers multiply split-bf16 operands (x = h + m, 16 significant bits,
- * float32 accumulation) on the 16-bit matrix instructions instead of float32 ones */
+ * float32 accumulation) on the 16-bit matrix instructions instead of float32 ones; bit 2 (4): the launch runs BESIDE another stream's
+ * kernels -- one block per CU instead of two, so that the other stream's blocks find registers and LDS on every CU (results differ
+ * from the two-block launch only in the summation order of the pixel chunks) */
 size_t himo_conv_wgrad_batch_workspace_bytes(int n_img, int h, int w, int cin, int cout, int stride);
 int himo_conv3x3_wgrad_batch(int n_img, const float* d_x, int64_t x_batch_stride, int x_pitch, int h, int w, int cin,
                              const float* d_dy, int64_t dy_batch_stride, int dy_pitch, int cout, int stride, float* d_dw,

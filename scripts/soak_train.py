@@ -19,9 +19,12 @@ trips = triplets(ds)
 samples = [make_sample(ds, t, dev) for t in trips]
 
 
-def run(side: bool, precision: str = "mixed", batchnorm: str = "batch", steps: int = N):
+def run(side: bool, precision: str = "mixed", batchnorm: str = "batch", steps: int = N, leave_room: bool = False):
     tr = SeFlowTrainer(spec.init_params(9), device=dev, max_points=121_000, batchnorm=batchnorm, precision=precision)
     tr.set_side_streams(side)
+    # the product default gives the side-stream weight gradients ONE block per CU (flags bit 2: another split of the pixel chunks, so
+    # other bits than the main-stream launch); the race check compares like with like, the default is checked run against run below
+    tr.wgrad_leave_room = leave_room
     losses = [float(tr.train_batch([samples[k % len(samples)]], lr=2e-4).item()) for k in range(steps)]
     torch.cuda.synchronize()
     return tr.flat_p.clone(), losses
@@ -35,6 +38,11 @@ print(f"{N} steps x 3 runs in {time.perf_counter() - t0:.1f} s; loss first / las
 print("side streams on vs on :", "same bits" if torch.equal(a, b) and la == lb else f"{int((a != b).sum())} parameters differ")
 print("side streams on vs off:", "same bits" if torch.equal(a, c) and la == lc else f"{int((a != c).sum())} parameters differ")
 ok = torch.equal(a, b) and torch.equal(a, c)
+d, ld = run(True, leave_room=True)
+e, le = run(True, leave_room=True)
+print("side streams on, one weight-gradient block per CU (the default), run vs run:", "same bits" if torch.equal(d, e) and ld == le else f"{int((d != e).sum())} parameters differ",
+      f"; loss last {ld[-1]:.6f} (two blocks per CU: {la[-1]:.6f})")
+ok = ok and torch.equal(d, e)
 # the other arithmetics and the frozen-BatchNorm mode take other branches of the backward pass (float32: flipped weights through ONE
 # scratch buffer; frozen: bias column sums on the side stream): 8 steps each, on vs off
 for prec, bn in (("bf16x3", "batch"), ("f32", "batch"), ("mixed", "frozen")):
