@@ -118,6 +118,10 @@ def test_split_bf16_weight_gradient_matches_autograd(gpu, h, w, cin, cout, n, st
     err_split = (np.abs(dw_split.cpu().numpy() - ref) / scale).max()
     err_f32 = (np.abs(dw_f32.cpu().numpy() - ref) / scale).max()
     assert err_f32 <= 1e-4 and err_split <= 1e-4, (err_f32, err_split)
+    # flags bit 2: one block per CU (the launch runs beside another stream's kernels): the same products over another split of the pixel chunks
+    _, dw_beside, _ = conv3x3_backward_nhwc(*args, stride, wgrad_flags=2 | 4)
+    assert (np.abs(dw_beside.cpu().numpy() - ref) / scale).max() <= 1e-4
+    assert (np.abs(dw_beside.cpu().numpy() - dw_split.cpu().numpy()) / scale).max() <= 2e-6
     if stride == 1:                      # the bias gradient from the same pass over dY (himo_conv3x3_wgrad_batch_bias)
         from himo_amd import _lib
         lib = _lib.load()
