@@ -406,6 +406,7 @@ int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w
     }
     if (ksize == 3 && (tile_hint & 0x1000) && (tile_hint & 15) > 4) return HIMO_ERR_UNSUPPORTED;     // a pinned variant this layer does not admit
     if (stride != 1) return HIMO_ERR_UNSUPPORTED;
+    if ((int64_t)a.H * a.W * a.x_pitch * 4 >= ((int64_t)1 << 31)) return HIMO_ERR_UNSUPPORTED;          // 32-bit byte offsets into an image (buffer resource)
     if (format == 2 && (ksize != 1 || (epilogue != kEpiBias && epilogue != kEpiReluMask) || a.act_flags)) return HIMO_ERR_UNSUPPORTED;     // two-term bf16: 3x3 in convsp.hip, row GEMMs here
     auto blocks_for = [&](int bn, int mi) -> int64_t {
         const int bm = 64 * mi, th = 2 * mi;

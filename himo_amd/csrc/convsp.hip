@@ -354,6 +354,7 @@ bool launch_conv3_split(const ConvArgs& a, int epilogue, const void* w_packed, i
     if (format == 2 && (epilogue != kEpiBias || (a.act_flags & ~(kActAccumulate | kActStuffedIn)))) return false;   // two-term bf16: float32 maps, bias epilogue
     if ((a.act_flags & kActAccumulate) && (format != 2 || !vec_store_ok(a))) return false;              // y += result: that kernel's 16-byte store path only
     if ((a.act_flags & kActStuffedIn) && (format != 2 || stride != 1)) return false;                    // zero-stuffed input: that kernel, stride 1
+    if ((int64_t)a.H * a.W * a.x_pitch * 4 >= ((int64_t)1 << 31)) return false;                         // 32-bit byte offsets into an image (buffer resource)
     // rows_hint 5 | 6: PH = 2 forced (wide layers too), 1 | 2 rows per wave; 9 | 10: PH = 4, 1 | 2 rows per wave -- stride 1, two-term formats
     const int ph_hint = (stride == 1 && format != 0 && (rows_hint == 5 || rows_hint == 6)) ? 2
                       : (stride == 1 && format != 0 && (rows_hint == 9 || rows_hint == 10)) ? 4 : 0;

@@ -301,6 +301,8 @@ typedef struct himo_conv_desc {
                                    reads as its zero-stuffed x2 image (x[2 i][2 j] = map[i][j], zeros elsewhere; h, w_in even = the stuffed
                                    size; x_batch_stride / x_pitch describe the compact map) -- the data gradient of a stride-2 convolution
                                    without materialising the stuffed image; matrix work on the all-zero rows is skipped */
+/* (split-precision paths: one image -- h * w_in * x_pitch floats -- must stay below 2 GB: 32-bit byte offsets through a buffer resource;
+ *  HIMO_ERR_UNSUPPORTED otherwise) */
 int himo_conv2d(const himo_conv_desc* h_desc, void* stream);
 /* one-time weight preparation for the split-bf16 path: [k][k][cin][cout] float32 -> three bf16 planes */
 size_t himo_conv_packed_weight_bytes(int ksize, int cin, int cout);
