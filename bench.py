@@ -36,6 +36,7 @@ import numpy as np
 
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # as himo_amd/__init__.py (streams that share a hardware queue serialise); before any device call
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 MFMA_F32_PEAK_TF = 157.3         # dense float32-input MFMA peak (MI355X_MICROARCH.md)
