@@ -75,8 +75,11 @@ def parse_args():
                     help="pipeline, N=1: skip the bf16x3 / f32 legs that follow the timed f16x2 region")
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="pipeline, N=1: skip the short training-step (config 5) and FastNSF (config 4) legs that follow the timed region")
-    ap.add_argument("--leg-train-steps", type=int, default=6, help="timed optimiser steps of the `leg_train` leg (after 2 warm-ups)")
+    ap.add_argument("--leg-train-steps", type=int, default=50, help="timed optimiser steps of the `leg_train` leg (after 2 warm-ups)")
+    ap.add_argument("--leg-fit-steps", type=int, default=200,
+                    help="optimiser steps of the `leg_fit_h5` leg (seflow.fit.fit over .h5 scene files, batch_size 8); 0 skips the leg")
     ap.add_argument("--leg-fastnsf-fits", type=int, default=6, help="timed fits of the `leg_fastnsf` leg (after 1 warm-up)")
+    ap.add_argument("--fit-workers", type=int, default=4, help="`leg_fit_h5`: reader threads of the training feeder (0: samples built inside the step loop)")
     ap.add_argument("--cloud", default="uniform", choices=["uniform", "rings"],
                     help="synthetic sweeps: SURVEY 8(d) uniform cloud with instances (default) or the LiDAR-like ring cloud")
     ap.add_argument("--sample-sets", type=int, default=3, help="distinct input batches rotated through the timed steps")
@@ -719,6 +722,8 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
         if world == 1 and not args.no_hostfed_leg:
             extra.update(hostfed_leg(args, overlapped if overlapped is not None else pipe, host_frames, device))
             extra.update(h5fed_leg(args, overlapped if overlapped is not None else pipe, host_frames, device))
+        if world == 1 and not args.no_extra_workloads and args.leg_fit_steps > 0:
+            extra.update(fit_h5_leg(args, device))
     line = {
         "metric": "lidar_frames_per_sec_120k", "value": total_frames / elapsed, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1092,6 +1097,70 @@ def h5fed_leg(args, pipe, host_frames, device) -> dict:
         return {"value_h5fed": leg["frames_per_s"], "leg_h5fed": leg}
     except Exception as e:                                       # a leg must never cost the main line
         return {"leg_h5fed": {"error": f"{type(e).__name__}: {e}"}}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def fit_h5_leg(args, device) -> dict:
+    """N = 1 only, after the timed region: BASELINE config 5 as the PROGRAM a user starts -- ``python -m himo_amd.seflow.fit`` =
+    ``seflow.fit.fit`` over ``.h5`` scene files with the reference launcher's numbers (assets/slurm/ssl-train-av2.sh:31-34:
+    ``batch_size=8``, ``+ssl_label=seflow_auto``, dataloader workers ahead of the step): 8 scenes x 41 consecutive 120k-point sweeps
+    (``synthetic.make_scene``: one coherent drive per scene, written once by ``h5lite.write_file`` with every dataset the
+    reference's extractors write), samples read with ``fields=`` on reader threads, staged in pinned memory, copied and LABELLED
+    on the device (two exact nearest-neighbour passes + two DBSCANs per pair) ahead of the optimiser step
+    (``feeder.TrainFeeder``), ``--leg-fit-steps`` optimiser steps of 8 samples each, BatchNorm in training mode, Adam, StepLR
+    bookkeeping, the epoch's loss read back.  ``leg_train`` beside it is the bare step on resident samples with pre-made labels."""
+    import shutil
+    import tempfile
+    import warnings
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    from himo_amd.dataset import HDF5Dataset
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.fit import fit, train_fields, triplets
+    from himo_amd.seflow.train import SeFlowTrainer
+    from himo_amd.synthetic import make_scene, write_h5_scenes
+    n_scenes, per_scene, bs = 8, 41, 8
+    root = Path(tempfile.mkdtemp(prefix="himo_fit_h5_"))
+    try:
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=n_scenes) as pool:       # (numpy's generators release the GIL)
+            scenes = list(pool.map(lambda sc: make_scene(500 + sc, per_scene, n_points=args.points, scene_id=f"drive{sc:02d}", cloud=args.cloud),
+                                   range(n_scenes)))
+        write_h5_scenes(root, scenes)
+        scenes = None
+        made = time.perf_counter() - t0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                          # (the last sweep of a scene has no successor)
+            ds = HDF5Dataset(root, fields=train_fields("seflow_auto"), zero_copy=True)
+        n_trip = len(triplets(ds))
+        steps_per_epoch = -(-n_trip // bs)
+        epochs = max(1, -(-args.leg_fit_steps // steps_per_epoch))
+        tr = SeFlowTrainer(spec.init_params(0), device=device, max_points=int(args.points * 1.02), precision=args.train_precision,
+                           batchnorm=args.train_batchnorm)
+        fit(ds, trainer=tr, epochs=1, batch_size=bs, max_steps=3, log=None, num_workers=args.fit_workers)      # warm-up: tile choices, buffers, page cache
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fit(ds, trainer=tr, epochs=epochs, batch_size=bs, max_steps=args.leg_fit_steps, log=None, num_workers=args.fit_workers)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ds.close()
+        hist = out["history"]
+        steps = sum(h["steps"] for h in hist)
+        samples = sum(h["samples"] for h in hist)
+        feeder = {k: sum(h["feeder"][k] for h in hist if h.get("feeder")) for k in ("read", "upload", "labels", "samples")}
+        leg = {"frames_per_s": samples / el, "optimiser_steps": steps, "samples": samples, "batch_size": bs, "epochs": len(hist),
+               "seconds": el, "ms_per_sample": el / max(samples, 1) * 1e3, "scenes": n_scenes, "sweeps_per_scene": per_scene,
+               "points_per_sweep": args.points, "ssl_label": "seflow_auto", "reader_threads": args.fit_workers,
+               "train_loss_first_last_epoch": [hist[0]["train_loss"], hist[-1]["train_loss"]],
+               "feeder_thread_host_ms_per_sample": {k: round(feeder[k] / max(feeder["samples"], 1) * 1e3, 3) for k in ("read", "upload", "labels")},
+               "scene_files_written_in_s": round(made, 1), "dtype": args.train_precision,
+               "note": "seflow.fit.fit end to end over .h5 scenes: read (fields=, views of the file mapping) -> pinned -> HBM -> labels generated "
+                       "on a side stream -> train_batch of 8 samples (one Adam step) -> per-epoch loss read-back; feeder host times are per "
+                       "sample on their own threads (reads summed over the reader threads), beside the step, not in series with it"}
+        return {"value_fit_h5": leg["frames_per_s"], "leg_fit_h5": leg}
+    except Exception as e:                                           # a leg must never cost the main line
+        return {"leg_fit_h5": {"error": f"{type(e).__name__}: {e}"}}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 

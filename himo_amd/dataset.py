@@ -188,6 +188,8 @@ class HDF5Dataset:
     ``feeder.SampleFeeder``, then copy each sweep once instead of twice).
     ``allow_dropped_eval`` (default: env ``HIMO_ALLOW_DROPPED_EVAL``, else False): see the KeyError below."""
 
+    carries_next = True        # every item holds its successor's ``pc1`` / ``pose1``: a walk never reads item i + 1 for them
+
     def __init__(self, directory, vis_name="", eval: bool = False, n_frames: int = 2, opener=None,  # noqa: A002
                  allow_dropped_eval: bool | None = None, fields=None, zero_copy: bool = False, keep_open: int = 8):
         self._files = _OpenFiles(opener if opener is not None else _open_h5, keep=keep_open)
@@ -264,8 +266,13 @@ class HDF5Dataset:
         return got
 
     def __getitem__(self, i):
+        return self.read(i)
+
+    def read(self, i, fields=None):
+        """item ``i`` restricted to ``fields`` (None: the dataset's own ``fields``) -- a caller that needs only part of a frame it
+        has no other use for (the training loop's history sweep: ``pc0`` and ``pose0``) does not touch the rest"""
         scene_id, ts = self.index[i]
-        want = self.fields
+        want = self.fields if fields is None else frozenset(fields)
         need = (lambda k: True) if want is None else want.__contains__
         f = self._files.get(self.scene_path(scene_id))
         g = f[ts]
@@ -295,6 +302,8 @@ class HDF5Dataset:
                         d[name] = self._array(r[ts][name])
                 if name not in d and name in g:
                     d[name] = self._array(g[name])
+        if not any(need(k) for k in ("pose1", "pc1", "gm1", "flow_instance_id_next")):
+            return d
         nxt = f[self._next[(scene_id, ts)]]
         if need("pose1"):
             d["pose1"] = np.asarray(nxt["pose"][:])

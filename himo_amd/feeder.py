@@ -7,6 +7,8 @@ device would idle during every read and every copy.  Here
   synthetic generator), stages the three sweeps and ``lidar_dt`` in PINNED host buffers and issues the host -> device
   copies on its own HIP stream, ``depth`` batches ahead; the consumer gets ``Sample`` objects whose tensors are already
   ordered after the copy on the consumer's stream (event wait, no host synchronisation);
+* ``TrainFeeder``: the training loop's samples -- sweep triplets read on reader threads, staged, copied and LABELLED
+  (``ssl_label=seflow_auto``) one to two samples ahead of the optimiser step;
 * ``ResultDrain``: device -> pinned-host copies of the per-frame results on the compute stream, handed to a writer
   thread that waits on the copy's event and calls the sink (Feather / npz writer) off the launch thread.
 
@@ -362,6 +364,169 @@ class BatchFeeder:
                 if t is not None:
                     t.record_stream(cur)
             yield obj
+
+
+class TrainFeeder:
+    """Iterate training samples ``(pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels)`` -- the tuples
+    ``seflow.fit.make_sample`` builds on the spot -- prepared AHEAD of the optimiser step, the way the reference's job keeps
+    its steps fed (``num_workers=16`` dataloader workers prefetching beside ``train.py``'s step, assets/slurm/ssl-train-av2.sh:31-34;
+    the loop shape of save_zip.py:111-113: ``dataset[i]`` -> compute):
+
+    * ``workers`` reader threads call ``seflow.fit.host_sample`` (the frames' sweeps / poses / ground masks or labels, read with
+      ``fields=`` from the open scene files) up to ``depth + workers`` triplets ahead and copy the arrays ONCE, from the file
+      mapping straight into a pinned arena of their own;
+    * the feeder thread takes the reads in order, issues the host -> device copies on a COPY stream, and on a LABEL stream
+      (ordered after the copies by an event) generates the cluster labels of ``ssl_label=seflow_auto``
+      (``seflow.ssl_label.auto_labels``: two exact nearest-neighbour passes and two DBSCANs per pair -- their index selections
+      block the thread that enqueues them, which is why that thread is not the one launching the training step); the label
+      count comes back through pinned memory behind the label stream's own event;
+    * the consumer's stream is ordered after a sample's last kernel by an event: the training thread never waits on the host
+      for a read, a copy or a label, and gets ``n_labels`` as a plain int.
+
+    Labels and samples are pure functions of the frames, so a fed run ends in the parameter bits of the run that builds every
+    sample inside the step (tests/test_fit_gpu.py).  ``close()`` stops early."""
+
+    _END = object()
+
+    def __init__(self, dataset, trips, device=None, label_key: str = "seflow_auto", depth: int = 2, workers: int = 4):
+        from concurrent.futures import ThreadPoolExecutor
+        if depth < 1 or workers < 1:
+            raise ValueError("depth and workers must be >= 1")
+        self.device = device if device is not None else _lib.require_gpu()
+        self.dataset, self.trips, self.label_key = dataset, list(trips), label_key
+        self.depth, self.workers = depth, workers
+        self._window = depth + workers                         # reads in flight ahead of the copy being issued
+        self._free = queue.Queue()                             # (pinned arena, event of the copies that last read it | None)
+        self._arenas = _borrow_arenas(self._window + 2)
+        for a in self._arenas:
+            self._free.put((a, None))
+        self._events = []                                      # copy events of arenas handed back (for _return_arenas)
+        self._q = queue.Queue(maxsize=depth)
+        self._copy = torch.cuda.Stream(device=self.device)
+        self._label = torch.cuda.Stream(device=self.device)
+        self._nl_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="himo-train-read")
+        self._error, self._stop = None, False
+        self.stage_seconds = {"read": 0.0, "upload": 0.0, "labels": 0.0, "samples": 0}      # host time per stage (profiles/r06_fit_stages.txt)
+        self._thread = threading.Thread(target=self._work, name="himo-train-feeder", daemon=True)
+        self._thread.start()
+
+    # ---- reader threads ------------------------------------------------------------------------------------------
+    _F32 = ("pch1", "pc0", "pc1")
+
+    def _read(self, trip):
+        import time
+        from .seflow.fit import host_sample
+        t0 = time.perf_counter()
+        h = host_sample(self.dataset, trip, self.label_key)
+        arena, ev = self._free.get()
+        if ev is not None:
+            ev.synchronize()                                   # the copies that last read this arena's pinned memory
+        arrs = {k: np.asarray(h[k]) for k in self._F32}
+        if "gm0" in h:
+            small = {"gm0": (np.asarray(h["gm0"]), torch.uint8), "gm1": (np.asarray(h["gm1"]), torch.uint8)}
+        else:
+            small = {"lab0": (np.asarray(h["lab0"]), torch.int32), "lab1": (np.asarray(h["lab1"]), torch.int32)}
+        arena.reset(sum(a.size * 4 + 64 for a in arrs.values()) + sum(a.size * 4 + 64 for a, _ in small.values()))
+        pins = {}
+        for k, a in arrs.items():
+            pins[k] = arena.take(a.shape, torch.float32)
+            np.copyto(pins[k].numpy(), a, casting="unsafe")   # file mapping (or array) -> pinned: the one host copy of a sweep
+        n_host = None
+        for k, (a, tdt) in small.items():
+            pins[k] = arena.take(a.shape, tdt)
+            np.copyto(pins[k].numpy(), a, casting="unsafe")
+        if "lab0" in h:                                        # stored labels: their count needs no device pass
+            n_host = int(max(int(np.max(h["lab0"], initial=0)), int(np.max(h["lab1"], initial=0)))) + 1
+        self.stage_seconds["read"] += time.perf_counter() - t0
+        return arena, pins, (h["pose_h1"], h["pose0"], h["pose1"]), n_host
+
+    # ---- feeder thread -------------------------------------------------------------------------------------------
+    def _work(self):
+        import collections
+        import time
+        try:
+            torch.cuda.set_device(self.device)
+            pending, nxt = collections.deque(), 0
+            while True:
+                while nxt < len(self.trips) and len(pending) < self._window and not self._stop:
+                    pending.append(self._pool.submit(self._read, self.trips[nxt]))
+                    nxt += 1
+                if not pending or self._stop:
+                    break
+                arena, pins, poses, n_labels = pending.popleft().result()
+                t0 = time.perf_counter()
+                with torch.cuda.stream(self._copy):
+                    dev = {k: v.to(self.device, non_blocking=True) for k, v in pins.items()}      # pinned -> HBM
+                    copied = torch.cuda.Event()
+                    copied.record(self._copy)
+                self._free.put((arena, copied))
+                self._events.append(copied)
+                del self._events[:-(self._window + 2)]
+                t1 = time.perf_counter()
+                with torch.cuda.stream(self._label):
+                    self._label.wait_event(copied)
+                    for t in dev.values():
+                        t.record_stream(self._label)
+                    if "gm0" in dev:
+                        from .seflow.ssl_label import auto_labels
+                        l0, l1 = auto_labels(dev["pc0"], dev["pc1"], dev["gm0"], dev["gm1"], poses[1], poses[2])
+                        top = torch.maximum(l0.max() if l0.numel() else l0.new_zeros(()), l1.max() if l1.numel() else l1.new_zeros(()))
+                        self._nl_host.copy_(top.reshape(1), non_blocking=True)
+                        counted = torch.cuda.Event()
+                        counted.record(self._label)
+                        counted.synchronize()                  # this thread's wait, not the training thread's
+                        n_labels = int(self._nl_host[0]) + 1
+                    else:
+                        l0, l1 = dev["lab0"], dev["lab1"]
+                    done = torch.cuda.Event()
+                    done.record(self._label)
+                t2 = time.perf_counter()
+                st = self.stage_seconds
+                st["upload"] += t1 - t0; st["labels"] += t2 - t1; st["samples"] += 1
+                sample = (dev["pch1"], dev["pc0"], dev["pc1"], poses[0], poses[1], poses[2], l0, l1, n_labels)
+                if not self._offer((sample, done)):
+                    break
+        except BaseException as e:                             # surfaced on the consumer's thread
+            self._error = e
+        finally:
+            self._pool.shutdown(wait=True, cancel_futures=True)
+            _return_arenas(self._arenas, self._events)
+            self._offer(self._END)
+
+    def _offer(self, item) -> bool:
+        while not self._stop:
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def close(self) -> None:
+        """Stop early (the consumer gave up, or ``max_steps`` ended the run): the workers return their pinned arenas and exit."""
+        self._stop = True
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=30)
+
+    def __iter__(self):
+        while True:
+            got = self._q.get()
+            if got is self._END:
+                if self._error is not None:
+                    raise self._error
+                return
+            sample, done = got
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(done)                                # after the sample's copies and label kernels: no host wait
+            for t in sample:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(cur)                        # allocated on the feeder's streams, used on this one
+            yield sample
 
 
 class EvalFeeder(BatchFeeder):

@@ -39,6 +39,12 @@ class _FrameCache:
     def __len__(self):
         return len(self.dataset)
 
+    def scene(self, j):
+        """scene id of item j WITHOUT reading it (the dataset's ``index``: ``[scene_id, timestamp]`` pairs), or None when the
+        dataset has no index to ask"""
+        index = getattr(self.dataset, "index", None)
+        return index[j][0] if index is not None and 0 <= j < len(index) else None
+
     def plan(self, order):
         """the ascending indices the walk will ask for (each also as history of the next and next of the previous)"""
         self._order, self._pos = list(order), 0
@@ -48,8 +54,12 @@ class _FrameCache:
         while self._pos < len(order) and order[self._pos] <= i + self._ahead:
             o = order[self._pos]
             self._pos += 1
-            for j in (o - 1, o, o + 1):
-                if 0 <= j < n and j >= i - 1 and j not in self._frames:
+            # the neighbours only where the walk will ask for them: the history sweep o - 1 and (for frames that do not carry their
+            # successor) the next sweep o + 1, and only inside o's OWN scene -- with whole scenes per rank (h5 sinks) a neighbour
+            # across the boundary belongs to another rank, which may be rewriting that very file
+            here = self.scene(o)
+            for j in ((o - 1, o) if getattr(self.dataset, "carries_next", False) else (o - 1, o, o + 1)):
+                if 0 <= j < n and j >= i - 1 and j not in self._frames and (j == o or here is None or self.scene(j) == here):
                     self._frames[j] = self._pool.submit(self.dataset.__getitem__, j)
 
     def __getitem__(self, i):
@@ -74,10 +84,23 @@ class _FrameCache:
             self._pool = None
 
 
+def _scene_of(dataset, j):
+    """scene id of item j from the dataset's index (no read), else None"""
+    scene = getattr(dataset, "scene", None)
+    if scene is not None:
+        return scene(j)
+    index = getattr(dataset, "index", None)
+    return index[j][0] if index is not None and 0 <= j < len(index) else None
+
+
 def history_of(dataset, i: int):
-    """The history sweep of frame i: the previous frame of the same scene, else the frame itself."""
+    """The history sweep of frame i: the previous frame of the same scene, else the frame itself.  Where the dataset has an index
+    the scene of i - 1 is looked up there: a frame of another scene is never read (it may be another rank's file)."""
     f = dataset[i]
     if i > 0:
+        here, there = _scene_of(dataset, i), _scene_of(dataset, i - 1)
+        if here is not None and there is not None:
+            return dataset[i - 1] if there == here else f
         p = dataset[i - 1]
         if p.get("scene_id") == f.get("scene_id"):
             return p
@@ -217,7 +240,10 @@ def frame_source(dataset, rank: int = 0, world: int = 1, by_scene: bool = False,
         for i in mine:
             f0 = dataset[i]
             if "pc1" not in f0:
-                if i + 1 >= len(dataset) or dataset[i + 1].get("scene_id") != f0.get("scene_id"):
+                if i + 1 >= len(dataset):
+                    continue
+                here, there = _scene_of(dataset, i), _scene_of(dataset, i + 1)
+                if (there != here) if (here is not None and there is not None) else (dataset[i + 1].get("scene_id") != f0.get("scene_id")):
                     continue                                       # last sweep of a scene: no pc1 to flow into
                 f1 = dataset[i + 1]
             else:

@@ -50,15 +50,29 @@ def triplets(dataset):
 AUTO_LABELS = ("seflow_auto", "seflowpp_auto")                  # the launchers' option values (ssl-train-av2.sh:32, ssl-train-scania.sh:32)
 
 
-def make_sample(dataset, trip, device, label_key: str = "flow_instance_id"):
-    """(pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels) on ``device`` for one triplet.  ``label_key`` in
-    ``AUTO_LABELS``: the labels are generated from the pair (needs the sweeps' ground masks ``gm0``; a frame that carries its
-    successor also carries ``gm1``); any other value names the frame key that holds them."""
+# the frame keys the training loop reads (``HDF5Dataset(fields=...)``): the sweep pair, their poses and -- for generated labels --
+# their ground masks; a run on stored labels adds its label key (and ``<key>_next``) with ``train_fields``
+TRAIN_FIELDS = ("pc0", "pose0", "pose1", "pc1", "gm0", "gm1")
+
+
+def train_fields(label_key: str = "seflow_auto") -> tuple:
+    return TRAIN_FIELDS if label_key in AUTO_LABELS else TRAIN_FIELDS + (label_key, label_key + "_next")
+
+
+def _frame(dataset, i, fields=None):
+    """``dataset[i]``, restricted to ``fields`` where the dataset can restrict a read (``HDF5Dataset.read``)"""
+    read = getattr(dataset, "read", None)
+    return read(i, fields) if (read is not None and fields is not None) else dataset[i]
+
+
+def host_sample(dataset, trip, label_key: str = "flow_instance_id") -> dict:
+    """The HOST half of a training sample: {"pch1", "pc0", "pc1" (float32 arrays, possibly views of a file mapping), "pose_h1",
+    "pose0", "pose1" (float64 4x4), and either "gm0" / "gm1" (``label_key`` in ``AUTO_LABELS``: the labels are generated from the
+    pair and its ground masks) or "lab0" / "lab1" (the frame key that holds them)}.  Same errors as the reference's loader would
+    raise at the same point: a missing key is a KeyError naming it."""
     ih, i0, i1 = trip
     f0 = dataset[i0]
-    fh = dataset[ih] if ih != i0 else f0
-    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
-    lab = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).to(device)
+    fh = _frame(dataset, ih, ("pc0", "pose0")) if ih != i0 else f0
     auto = label_key in AUTO_LABELS
     if i1 is None:                                            # the frame carries its successor (HDF5Dataset)
         pc1, lab1, gm1 = f0["pc1"], f0.get(label_key + "_next"), f0.get("gm1")
@@ -73,25 +87,47 @@ def make_sample(dataset, trip, device, label_key: str = "flow_instance_id"):
     if not auto and f0.get(label_key) is None:
         raise KeyError(f"{label_key}: the frame does not hold the labels ssl_label={label_key!r} names "
                        f"(ssl_label='seflow_auto' generates them from the sweeps and their ground masks gm0 / gm1)")
-    p0, p1 = up(f0["pc0"]), up(pc1)
-    pose0, pose1 = np.asarray(f0["pose0"], np.float64), np.asarray(f0["pose1"], np.float64)
+    out = {"pch1": fh["pc0"], "pc0": f0["pc0"], "pc1": pc1, "pose_h1": np.asarray(fh["pose0"], np.float64),
+           "pose0": np.asarray(f0["pose0"], np.float64), "pose1": np.asarray(f0["pose1"], np.float64)}
     if auto:
-        from .ssl_label import auto_labels
         if f0.get("gm0") is None or gm1 is None:
             raise KeyError("gm0 / gm1: ssl_label=seflow_auto needs the ground masks of both sweeps")
-        l0, l1 = auto_labels(p0, p1, f0["gm0"], gm1, pose0, pose1)
+        out["gm0"], out["gm1"] = f0["gm0"], gm1
+    else:
+        out["lab0"], out["lab1"] = f0[label_key], lab1
+    return out
+
+
+def make_sample(dataset, trip, device, label_key: str = "flow_instance_id"):
+    """(pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels) on ``device`` for one triplet, built HERE and NOW on the
+    calling thread and the current stream (tests, one-off calls; the training loop takes the same tuples from
+    ``feeder.TrainFeeder``, which prepares them ahead of the step).  ``label_key`` in ``AUTO_LABELS``: the labels are generated
+    from the pair (needs the sweeps' ground masks ``gm0``; a frame that carries its successor also carries ``gm1``); any other
+    value names the frame key that holds them."""
+    h = host_sample(dataset, trip, label_key)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+    lab = lambda a: torch.from_numpy(np.ascontiguousarray(a).astype(np.int32)).to(device)
+    p0, p1 = up(h["pc0"]), up(h["pc1"])
+    if "gm0" in h:
+        from .ssl_label import auto_labels
+        l0, l1 = auto_labels(p0, p1, h["gm0"], h["gm1"], h["pose0"], h["pose1"])
         n_labels = int(torch.maximum(l0.max() if l0.numel() else l0.new_zeros(()), l1.max() if l1.numel() else l1.new_zeros(())).item()) + 1
     else:
-        l0, l1 = lab(f0[label_key]), lab(lab1)
-        n_labels = int(max(int(np.max(f0[label_key], initial=0)), int(np.max(lab1, initial=0)))) + 1
-    return (up(fh["pc0"]), p0, p1, np.asarray(fh["pose0"], np.float64), pose0, pose1, l0, l1, n_labels)
+        l0, l1 = lab(h["lab0"]), lab(h["lab1"])
+        n_labels = int(max(int(np.max(h["lab0"], initial=0)), int(np.max(h["lab1"], initial=0)))) + 1
+    return (up(h["pch1"]), p0, p1, h["pose_h1"], h["pose0"], h["pose1"], l0, l1, n_labels)
 
 
 def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, batch_size: int = 8, lr: float = 6e-5,
         step_size: int = 3, gamma: float = 0.5, save_top: int = 3, val_dataset=None, resume=None, precision: str = "mixed",
         max_points: int = 140_000, device=None, seed: int = 0, max_steps: int | None = None, log=print,
-        trainer: SeFlowTrainer | None = None, batchnorm: str = "batch", ssl_label: str = "seflow_auto") -> dict:
+        trainer: SeFlowTrainer | None = None, batchnorm: str = "batch", ssl_label: str = "seflow_auto",
+        num_workers: int = 4, prefetch: int = 2) -> dict:
     """Train for ``epochs`` passes over ``dataset``; returns {"trainer", "history", "best"}.
+
+    ``num_workers`` > 0 (default; the launcher's ``num_workers=16``, ssl-train-av2.sh:32): the samples of an epoch come from
+    ``feeder.TrainFeeder`` -- read on that many threads, staged, copied and labelled ``prefetch`` samples ahead of the optimiser
+    step.  0: every sample is built inside the step loop on the launch thread (``make_sample``) -- same parameter bits, slower.
 
     Ranks (torch.distributed, initialised by the caller / ``distenv.process_group``): step s of an epoch takes the global
     samples [s * batch_size, (s + 1) * batch_size) of that epoch's seeded shuffle; rank r takes every world-th of them.
@@ -112,30 +148,52 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
     val_trips = triplets(val_dataset) if val_dataset is not None else []
     steps_per_epoch = math.ceil(len(trips) / batch_size)
     history, steps_done = [], 0
+    feed_stats = []
+
+    def samples_of(ds, groups):
+        """one iterator of device samples per group of triplets, in order; the groups' samples are prepared ahead across group
+        boundaries (``TrainFeeder``), or built on the spot (``num_workers=0``)"""
+        if num_workers <= 0:
+            for grp in groups:
+                yield (make_sample(ds, t, dev, ssl_label) for t in grp)
+            return
+        import itertools
+        from ..feeder import TrainFeeder
+        feed = TrainFeeder(ds, [t for grp in groups for t in grp], device=dev, label_key=ssl_label, depth=prefetch, workers=num_workers)
+        try:
+            it = iter(feed)
+            for grp in groups:
+                yield itertools.islice(it, len(grp))
+        finally:
+            feed.close()
+            feed_stats.append(dict(feed.stage_seconds))
+
     for epoch in range(start_epoch, epochs):
         lr_e = SeFlowTrainer.step_lr(epoch, lr, step_size, gamma)
         order = np.random.default_rng(seed * 1_000_003 + epoch).permutation(len(trips))      # same shuffle on every rank
+        n_steps = steps_per_epoch if max_steps is None else max(0, min(steps_per_epoch, max_steps - steps_done))
+        # rank r's samples of every step of the epoch (a partial last batch may leave a rank none: it still joins the all-reduce,
+        # with zeros)
+        mine = [[trips[j] for j in order[s * batch_size:(s + 1) * batch_size][rank::world]] for s in range(n_steps)]
         losses = []
-        for s in range(steps_per_epoch):
-            if max_steps is not None and steps_done >= max_steps:
-                break
-            batch = order[s * batch_size:(s + 1) * batch_size]
-            mine = [trips[j] for j in batch[rank::world]]    # may be empty in a partial last batch: the rank still joins the
-            loss = tr.train_batch((make_sample(dataset, t, dev, ssl_label) for t in mine), lr=lr_e)      # all-reduce, with zeros
-            losses.append(loss)
+        del feed_stats[:]
+        for smp in samples_of(dataset, mine):
+            losses.append(tr.train_batch(smp, lr=lr_e))
             steps_done += 1
+        train_feed = dict(feed_stats[0]) if feed_stats else None
         train_loss = float(torch.stack(losses).mean().item()) if losses else float("nan")
         tr.sync_running_stats()                              # validation and the checkpoint use rank 0's running statistics
         val_loss = None
         if val_trips:
-            vals = [tr.loss_only(*make_sample(val_dataset, t, dev, ssl_label)) for t in val_trips[rank::world]]
+            vals = [tr.loss_only(*smp) for grp in samples_of(val_dataset, [val_trips[rank::world]]) for smp in grp]
             v = torch.stack(vals).sum() if vals else torch.zeros((), dtype=torch.float64, device=dev)
             cnt = torch.tensor([float(len(vals))], dtype=torch.float64, device=dev)
             tot = torch.stack([v.reshape(()), cnt.reshape(())])
             if world > 1:
                 dist.all_reduce(tot)
             val_loss = float((tot[0] / tot[1].clamp(min=1.0)).item())
-        entry = {"epoch": epoch, "lr": lr_e, "train_loss": train_loss, "val_loss": val_loss, "steps": len(losses)}
+        entry = {"epoch": epoch, "lr": lr_e, "train_loss": train_loss, "val_loss": val_loss, "steps": len(losses),
+                 "samples": sum(len(g) for g in mine), "feeder": train_feed}      # (feeder: host seconds per stage on its own threads)
         history.append(entry)
         if log is not None and rank == 0:
             log(f"epoch {epoch}: lr {lr_e:.3g}  train loss {train_loss:.6f}" + (f"  val loss {val_loss:.6f}" if val_loss is not None else ""))
@@ -168,13 +226,18 @@ def main(argv=None):
                     help="batch: BatchNorm in training mode (from-scratch training, the reference job); frozen: fine-tuning convention")
     ap.add_argument("--ssl_label", default="seflow_auto",
                     help="seflow_auto (the launcher's +ssl_label=seflow_auto): labels generated on the GPU; or the frame key that holds them")
+    ap.add_argument("--num_workers", type=int, default=4,
+                    help="reader threads that prepare samples ahead of the step (the launcher's num_workers=16); 0: inside the step loop")
+    ap.add_argument("--precision", default="mixed", choices=["mixed", "bf16x3", "f32"])
     a = ap.parse_args(argv)
     with distenv.process_group():
-        ds = open_dataset(Path(a.dataset_path))
-        val = open_dataset(Path(a.val_path)) if a.val_path else None
+        opts = {"fields": train_fields(a.ssl_label), "zero_copy": True}      # (h5 scene files; the npz container ignores them)
+        ds = open_dataset(Path(a.dataset_path), **opts)
+        val = open_dataset(Path(a.val_path), **opts) if a.val_path else None
         params = load_params(a.checkpoint) if a.checkpoint else None
         return fit(ds, params, out_dir=a.out_dir, epochs=a.epochs, batch_size=a.batch_size, lr=a.lr, save_top=a.save_top_model,
-                   val_dataset=val, resume=a.resume or None, batchnorm=a.batchnorm, ssl_label=a.ssl_label)
+                   val_dataset=val, resume=a.resume or None, batchnorm=a.batchnorm, ssl_label=a.ssl_label, num_workers=a.num_workers,
+                   precision=a.precision)
 
 
 if __name__ == "__main__":

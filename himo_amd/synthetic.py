@@ -169,3 +169,86 @@ class SyntheticDataset:
         if self.ragged:  # sweeps differ in point count, as real sweeps do
             n = max(1, int(n * (0.6 + 0.4 * ((i * 2654435761) % 1000) / 999.0)))
         return make_frame(i, n_points=n, **self.kw)
+
+
+def make_scene(seed: int, n_sweeps: int, n_points: int = 120_000, n_instances: int = 30, scene_id: str | None = None,
+               noise: float = 0.02, cloud: str = "uniform") -> list[dict]:
+    """``n_sweeps`` CONSECUTIVE sweeps of one drive as reference-style frame dicts: a static world fixed in world coordinates
+    (re-sampled with ``noise`` m of range noise per sweep), ``n_instances`` box-shaped objects at constant world velocities
+    (0-35 m/s, the speed buckets of eval.py:101-108) and an ego vehicle driving ~10 m/s with a slow yaw -- so that the sweep
+    AFTER a sweep is the same world 0.1 s later, which is what the training loop's label generator and self-supervised loss
+    assume (``make_frame``'s sweeps are unrelated draws: fine for inference timing, meaningless as a (pc0, pc1) pair).
+    ``pose1`` of sweep k is ``pose0`` of sweep k + 1; ``flow`` is the ground-truth motion of every pc0 point into sweep k + 1's
+    sensor frame (ego motion included, as save_zip.py:117 expects)."""
+    rng = np.random.default_rng(1_000_003 * seed + 17)
+    n, dt = int(n_points), 0.1
+    lo, hi = np.array(POINT_CLOUD_RANGE[:3]), np.array(POINT_CLOUD_RANGE[3:])
+    speed_ego, yaw_rate = rng.uniform(6.0, 12.0), np.deg2rad(rng.uniform(-4.0, 4.0))
+    poses, x, y, yaw = [], 0.0, 0.0, 0.0
+    for _ in range(n_sweeps + 1):
+        poses.append(_yaw_pose(yaw, x, y))
+        x, y, yaw = x + speed_ego * dt * np.cos(yaw), y + speed_ego * dt * np.sin(yaw), yaw + yaw_rate * dt
+    # the world: static points around the whole path (so that every sweep's range is populated), objects on top
+    travel = speed_ego * dt * n_sweeps
+    if cloud == "rings":
+        world = lidar_rings(rng, n)
+    else:
+        world = rng.uniform(lo, hi, size=(n, 3))
+    world[:, 0] += rng.uniform(0.0, 1.0, n) * travel * (cloud == "uniform")
+    category, instance = np.zeros(n, np.uint8), np.zeros(n, np.uint32)
+    vel = np.zeros((n, 3))
+    n_instances = int(min(n_instances, max(n // 40, 0)))
+    start = 0
+    if n_instances > 0:
+        per_inst = rng.integers(12, max(13, min(5000, n // (2 * n_instances))), size=n_instances)
+        for k in range(n_instances):
+            cnt = int(per_inst[k])
+            if start + cnt > n:
+                break
+            cls = _VEHICLE_CLASSES[k % len(_VEHICLE_CLASSES)]
+            dims = np.array([4.5, 1.9, 1.6]) if cls == REGULAR_VEHICLE else np.array([10.0, 2.5, 3.2])
+            rad, ang, heading = rng.uniform(4.0, 48.0), rng.uniform(-np.pi, np.pi), rng.uniform(-np.pi, np.pi)
+            c, s = np.cos(heading), np.sin(heading)
+            rot = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+            centre = np.array([rad * np.cos(ang) + travel / 2, rad * np.sin(ang), rng.uniform(-1.6, -0.4)])
+            world[start:start + cnt] = (rng.uniform(-0.5, 0.5, size=(cnt, 3)) * dims) @ rot.T + centre
+            vel[start:start + cnt] = rng.uniform(0.0, 35.0) * np.array([c, s, 0.0])
+            category[start:start + cnt], instance[start:start + cnt] = cls, k + 1
+            start += cnt
+    ground = (world[:, 2] < (-2.6 if cloud == "uniform" else GROUND_Z + 0.12)) & (instance == 0)
+    scene = scene_id if scene_id is not None else f"synthetic-drive-{seed:04d}"
+    frames = []
+    for k in range(n_sweeps):
+        at0, at1 = world + vel * (dt * k), world + vel * (dt * (k + 1))
+        inv0, inv1 = np.linalg.inv(poses[k]), np.linalg.inv(poses[k + 1])
+        p0 = at0 @ inv0[:3, :3].T + inv0[:3, 3] + rng.normal(0.0, noise, (n, 3))
+        p1 = at1 @ inv1[:3, :3].T + inv1[:3, 3]
+        pc0 = np.empty((n, 4), np.float32)
+        pc0[:, :3], pc0[:, 3] = p0, rng.uniform(0.0, 1.0, n)
+        order = rng.permutation(n)                              # rows of successive sweeps do not correspond
+        frames.append({"scene_id": scene, "timestamp": 315_965_785_000_000_000 + (1000 * seed + k) * 100_000_000,
+                       "pc0": pc0[order], "pose0": poses[k], "pose1": poses[k + 1],
+                       "lidar_dt": rng.uniform(0.0, 0.1, n).astype(np.float32), "lidar_id": rng.integers(1, 7, n).astype(np.uint8),
+                       "gm0": ground[order], "flow": (p1 - p0).astype(np.float32)[order], "flow_is_valid": rng.uniform(size=n) > 0.01,
+                       "flow_category_indices": category[order], "flow_instance_id": instance[order]})
+    return frames
+
+
+def write_h5_scenes(root, scenes: list[list[dict]]) -> list:
+    """``<root>/<scene_id>.h5`` + ``index_total.pkl`` for lists of frame dicts, with every dataset the reference's extractors
+    write (dataprocess/extract_sca.py:76-93; ``h5lite.write_file``).  Returns the index."""
+    import pickle
+    from pathlib import Path
+    from . import h5lite
+    root, index = Path(root), []
+    for frames in scenes:
+        tree = {}
+        for f in frames:
+            tree[str(f["timestamp"])] = {"lidar": f["pc0"], "lidar_dt": f["lidar_dt"], "lidar_id": f["lidar_id"], "pose": f["pose0"],
+                                         "ground_mask": f["gm0"], "flow": f["flow"], "flow_is_valid": f["flow_is_valid"],
+                                         "flow_category_indices": f["flow_category_indices"], "flow_instance_id": f["flow_instance_id"]}
+            index.append([f["scene_id"], str(f["timestamp"])])
+        h5lite.write_file(root / f"{frames[0]['scene_id']}.h5", tree)
+    with open(root / "index_total.pkl", "wb") as fh:
+        pickle.dump(index, fh)
+    return index

@@ -370,5 +370,36 @@ def test_prefetching_frame_cache_returns_the_same_frames_in_order(tmp_path):
     ahead = [(i, fh["timestamp"], f0["timestamp"]) for i, fh, f0, f1 in save.frame_source(ds, readers=3)]
     assert ahead == plain and len(plain) == len(ds)
     assert sorted(set(reads)) == list(range(len(ds))) and len(reads) == len(ds) == n_plain     # every frame read exactly once either way
-    mine = [i for i, *_ in save.frame_source(ds, rank=1, world=3, by_scene=True, readers=2)]
-    assert mine == [i for i, (s, _) in enumerate(ds.index) if s == "scene1"]
+    for readers in (0, 2):
+        reads[:] = []
+        mine = [i for i, *_ in save.frame_source(ds, rank=1, world=3, by_scene=True, readers=readers)]
+        assert mine == [i for i, (s, _) in enumerate(ds.index) if s == "scene1"]
+        # a rank never reads a frame of a scene it does not own -- not as the history of its scene's first sweep, not as
+        # the successor of its last, not ahead of the walk (the owner may be rewriting that file in place)
+        assert sorted(set(reads)) == mine and len(reads) == len(mine), (readers, reads)
+
+
+def test_training_host_sample_reads_only_its_fields_and_names_what_is_missing(tmp_path):
+    """the host half of a training sample (``seflow.fit.host_sample``, shared by ``make_sample`` and ``feeder.TrainFeeder``): the
+    history sweep is read with ``fields=("pc0", "pose0")`` only, generated labels need both ground masks, stored labels both label
+    arrays -- a missing one is a KeyError that names it"""
+    from himo_amd.seflow.fit import host_sample, train_fields, triplets
+    frames = [make_frame(i, n_points=40 + i, scene_id="scene0") for i in range(4)]
+    _dataset_dir(tmp_path, frames)
+    groups = _scene_groups(frames)
+    ds = HDF5Dataset(tmp_path, opener=_memory_opener(groups), fields=train_fields("seflow_auto"))
+    assert set(ds[1]) == {"pc0", "pose0", "pose1", "pc1", "gm0", "gm1", "scene_id", "timestamp"}
+    assert set(ds.read(0, ("pc0", "pose0"))) == {"pc0", "pose0", "scene_id", "timestamp"}
+    h = host_sample(ds, triplets(ds)[1], "seflow_auto")
+    assert np.array_equal(h["pch1"], frames[0]["pc0"]) and np.array_equal(h["pc0"], frames[1]["pc0"]) and np.array_equal(h["pc1"], frames[2]["pc0"])
+    assert np.array_equal(h["gm0"], frames[1]["gm0"]) and np.array_equal(h["gm1"], frames[2]["gm0"]) and "lab0" not in h
+    assert np.array_equal(h["pose_h1"], frames[0]["pose0"]) and np.array_equal(h["pose1"], frames[2]["pose0"])
+    with pytest.raises(KeyError, match="flow_instance_id"):
+        host_sample(ds, triplets(ds)[1], "flow_instance_id")                    # the dataset was opened without the label fields
+    lab = HDF5Dataset(tmp_path, opener=_memory_opener(groups), fields=train_fields("flow_instance_id"))
+    h = host_sample(lab, triplets(lab)[0], "flow_instance_id")
+    assert np.array_equal(h["lab0"], frames[0]["flow_instance_id"]) and np.array_equal(h["lab1"], frames[1]["flow_instance_id"])
+    assert h["pch1"] is h["pc0"]                                                # a scene's first sweep is its own history
+    nogm = HDF5Dataset(tmp_path, opener=_memory_opener(groups), fields=("pc0", "pose0", "pose1", "pc1"))
+    with pytest.raises(KeyError, match="gm0 / gm1"):
+        host_sample(nogm, triplets(nogm)[0], "seflow_auto")

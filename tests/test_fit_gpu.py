@@ -147,3 +147,53 @@ def test_checkpoint_resume_continues_bit_for_bit(gpu, tmp_path):
     net = SeFlowNet(load_params(path), device=gpu, max_points=7_000, precision="bf16x3", autotune=False)
     flow = net.forward(frames[0]["pc0"], frames[1]["pc0"], frames[2]["pc0"], frames[0]["pose0"], frames[1]["pose0"], frames[1]["pose1"])
     assert torch.isfinite(flow).all()
+
+
+@pytest.mark.parametrize("ssl_label", ["seflow_auto", "flow_instance_id"])
+def test_fed_loop_ends_in_the_serial_loops_parameter_bits(gpu, tmp_path, ssl_label):
+    """``fit`` over ``.h5`` scene files with the samples prepared AHEAD of the step (``feeder.TrainFeeder``: reader threads, pinned
+    staging, a copy stream, labels generated on a label stream) against the same run with every sample built inside the step loop
+    on the launch thread (``num_workers=0``): the same losses and the same parameter bits -- across an epoch boundary, a partial
+    last batch, validation, and with both kinds of labels."""
+    import warnings
+    from himo_amd.dataset import HDF5Dataset
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.fit import fit, train_fields, triplets
+    from himo_amd.synthetic import make_scene, write_h5_scenes
+    write_h5_scenes(tmp_path, [make_scene(90 + sc, 5, n_points=6_000, scene_id=f"fit{sc:02d}") for sc in range(2)])
+    finals, hists = [], []
+    for workers in (0, 3):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                   # (the last sweep of a scene has no successor)
+            ds = HDF5Dataset(tmp_path, fields=train_fields(ssl_label), zero_copy=True)
+        assert len(triplets(ds)) == 8 and triplets(ds)[0] == (0, 0, None) and triplets(ds)[4] == (4, 4, None)
+        out = fit(ds, spec.init_params(3), epochs=2, batch_size=3, lr=2e-4, max_points=6_000, device=gpu, log=None, ssl_label=ssl_label,
+                  num_workers=workers, prefetch=2, val_dataset=ds)
+        torch.cuda.synchronize()
+        finals.append(out["trainer"].flat_p.clone())
+        hists.append([(h["train_loss"], h["val_loss"], h["steps"]) for h in out["history"]])
+        ds.close()
+        del out
+        torch.cuda.empty_cache()
+    assert hists[0] == hists[1] and all(s == 3 for _, _, s in hists[0]), hists
+    assert torch.equal(finals[0], finals[1]), int((finals[0] != finals[1]).sum())
+
+
+def test_train_feeder_surfaces_reader_errors_and_stops_early(gpu):
+    """a frame without ground masks under ``ssl_label=seflow_auto`` is the KeyError the serial loop raises, raised on the consumer's
+    thread; ``close()`` before the end leaves no thread behind"""
+    import threading
+    from himo_amd.dataset import ListDataset
+    from himo_amd.feeder import TrainFeeder
+    from himo_amd.seflow.fit import triplets
+    from himo_amd.synthetic import make_frame
+    frames = [make_frame(30 + i, n_points=3_000, scene_id="s") for i in range(6)]
+    ds = ListDataset(frames)
+    feed = TrainFeeder(ds, triplets(ds), device=gpu, depth=1, workers=2)
+    first = next(iter(feed))
+    assert first[1].shape == (3_000, 4) and first[6].dtype == torch.int32 and isinstance(first[8], int)
+    feed.close()
+    assert not any(t.name.startswith("himo-train") for t in threading.enumerate() if t.is_alive())
+    bad = ListDataset([{k: v for k, v in f.items() if k != "gm0"} for f in frames])
+    with pytest.raises(KeyError, match="gm0"):
+        list(TrainFeeder(bad, triplets(bad), device=gpu))
