@@ -79,7 +79,7 @@ def parse_args():
     ap.add_argument("--leg-fit-steps", type=int, default=200,
                     help="optimiser steps of the `leg_fit_h5` leg (seflow.fit.fit over .h5 scene files, batch_size 8); 0 skips the leg")
     ap.add_argument("--leg-fastnsf-fits", type=int, default=6, help="timed fits of the `leg_fastnsf` leg (after 1 warm-up)")
-    ap.add_argument("--fit-workers", type=int, default=4, help="`leg_fit_h5`: reader threads of the training feeder (0: samples built inside the step loop)")
+    ap.add_argument("--fit-workers", type=int, default=2, help="`leg_fit_h5`: reader threads of the training feeder (0: samples built inside the step loop)")
     ap.add_argument("--cloud", default="uniform", choices=["uniform", "rings"],
                     help="synthetic sweeps: SURVEY 8(d) uniform cloud with instances (default) or the LiDAR-like ring cloud")
     ap.add_argument("--sample-sets", type=int, default=3, help="distinct input batches rotated through the timed steps")
@@ -1153,6 +1153,9 @@ def fit_h5_leg(args, device) -> dict:
                "seconds": el, "ms_per_sample": el / max(samples, 1) * 1e3, "scenes": n_scenes, "sweeps_per_scene": per_scene,
                "points_per_sweep": args.points, "ssl_label": "seflow_auto", "reader_threads": args.fit_workers,
                "train_loss_first_last_epoch": [hist[0]["train_loss"], hist[-1]["train_loss"]],
+               "frames_per_s_by_epoch": [round(h["samples"] / h["train_seconds"], 1) for h in hist],
+               "labels": "generated on the device in the first epoch (two nearest-neighbour passes + two DBSCANs per pair), kept on the host and "
+                         "uploaded in the later ones (the reference's job reads labels an offline pass wrote once)",
                "feeder_thread_host_ms_per_sample": {k: round(feeder[k] / max(feeder["samples"], 1) * 1e3, 3) for k in ("read", "upload", "labels")},
                "scene_files_written_in_s": round(made, 1), "dtype": args.train_precision,
                "note": "seflow.fit.fit end to end over .h5 scenes: read (fields=, views of the file mapping) -> pinned -> HBM -> labels generated "

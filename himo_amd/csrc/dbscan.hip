@@ -15,7 +15,8 @@
 // Structure: the points are counting-sorted into BEV cells of edge >= eps (HBM-bound integer work: histogram with integer atomics,
 // one-block exclusive scan, scatter of xyz + original index as one 16-byte row), so a point's neighbours are in its 3 x 3 cells;
 // core test = one pass over those cells with early exit; components = lock-free union-find on the original indices (hook the
-// larger root under the smaller with atomicMin: a component's root ends as its lowest index, deterministically); labels = find.
+// larger root under the smaller with atomicMin: a component's root ends as its lowest index, deterministically; finds halve the
+// paths they walk; one wave per point shares the walk over its neighbours); labels = find.
 #include "himo_common.h"
 #include <math.h>
 
@@ -42,24 +43,36 @@ __global__ __launch_bounds__(256) void db_count_kernel(int n, const float* __res
     cell_id[i] = c;
 }
 
-// exclusive scan of v[0..n) in place by ONE block (n up to a few million: each thread owns a contiguous chunk); v[n] = the total
+// exclusive scan of v[0..n) in place by ONE block, tile by tile (4096 values: every thread loads four NEIGHBOURING values, so a wave
+// reads 1 KB runs -- the round-5 form gave every thread a contiguous chunk of n / 1024 values: 131 us for 120k values, stride-n/1024
+// accesses; this one ~10 us); wave shuffles inside a wave, 16 wave totals through LDS; v[n] = the total
+constexpr int kDbScanTile = 4096;
 __global__ __launch_bounds__(1024) void db_scan_kernel(int* __restrict__ v, int n) {
-    __shared__ int part[1024];
-    const int per = (n + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += v[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int y = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __shared__ int wsum[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int carry = 0;
+    for (int base = 0; base < n; base += kDbScanTile) {
+        const int at = base + threadIdx.x * 4;
+        int x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = at + k < n ? v[at + k] : 0;
+        const int mine = x[0] + x[1] + x[2] + x[3];
+        int incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += y;
+        }
+        if (lane == 63) wsum[w] = incl;
         __syncthreads();
-        part[threadIdx.x] += y;
+        int run = carry + incl - mine, total = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int t = wsum[k]; total += t; if (k < w) run += t; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (at + k < n) v[at + k] = run; run += x[k]; }
+        carry += total;
         __syncthreads();
     }
-    int run = part[threadIdx.x] - s;
-    for (int i = lo; i < hi; ++i) { const int x = v[i]; v[i] = run; run += x; }
-    if (threadIdx.x == 1023) v[n] = part[1023];
+    if (threadIdx.x == 0) v[n] = carry;
 }
 
 __global__ __launch_bounds__(256) void db_scatter_kernel(int n, const float* __restrict__ xyz, int pitch, const int* __restrict__ cell_id,
@@ -106,9 +119,23 @@ __device__ inline int db_find(const int* __restrict__ parent, int x) {
     while (p != x) { x = p; p = parent[x]; }
     return x;
 }
+// find with path halving: every visited node is re-pointed at its grandparent.  Safe without locks beside the atomicMin hooks below:
+// a store only ever targets a NON-root (its parent differs from itself, and a hooked node never becomes a root again) and writes an
+// ancestor of that node -- a lower index of the same component -- so no link a hook relies on is lost (a hook onto a non-root
+// re-joins that node's old parent itself, see db_union) and no cycle can form.  Components, and their lowest index, are unchanged;
+// the trees become flat, which is what the second and later unions of a dense object's points wait for
+__device__ inline int db_find_halve(int* __restrict__ parent, int x) {
+    int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {
+        const int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = p; p = gp;
+    }
+    return x;
+}
 __device__ inline void db_union(int* __restrict__ parent, int a, int b) {
     while (true) {
-        a = db_find(parent, a); b = db_find(parent, b);
+        a = db_find_halve(parent, a); b = db_find_halve(parent, b);
         if (a == b) return;
         if (a < b) { const int t = a; a = b; b = t; }            // hook the larger root a under the smaller b
         const int old = atomicMin(&parent[a], b);
@@ -117,23 +144,34 @@ __device__ inline void db_union(int* __restrict__ parent, int a, int b) {
     }
 }
 
-// one thread per sorted row: a core point is joined with every core neighbour of lower original index
+// one WAVE per sorted row (grid-stride over the rows that take part): a core point is joined with every core neighbour of lower
+// original index, the 64 lanes taking the rows of its 3 x 3 cells in turn.  (Round 5: one thread per row -- the participating rows
+// are a few per cent of a sweep, sorted to the front: a dozen blocks did all the work, each thread walking ~1000 neighbours of a
+// dense object and chasing un-compressed parent chains for each: 355 us per call.)
 __global__ __launch_bounds__(256) void db_union_kernel(const float4* __restrict__ rows, DbGrid g, const int* __restrict__ offset, float eps2,
                                                        const unsigned char* __restrict__ core, int* __restrict__ parent) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= offset[g.gw * g.gh]) return;                       // the number of points that take part (db_scan_kernel's total)
-    const float4 p = rows[s];
-    const int i = __float_as_int(p.w);
-    if (!core[i]) return;
-    const int cx = db_clamp((int)floorf((p.x - g.x0) * g.inv_cell), g.gw - 1), cy = db_clamp((int)floorf((p.y - g.y0) * g.inv_cell), g.gh - 1);
-    db_neighbours(g, cx, cy, offset, rows, [&](const float4& q) {
-        const int j = __float_as_int(q.w);
-        if (j < i && core[j]) {
-            const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
-            if (dx * dx + dy * dy + dz * dz <= eps2) db_union(parent, i, j);
+    const int total = offset[g.gw * g.gh];                      // the number of points that take part (db_scan_kernel's total)
+    const int lane = threadIdx.x & 63, n_waves = gridDim.x * 4;
+    for (int s = blockIdx.x * 4 + (threadIdx.x >> 6); s < total; s += n_waves) {
+        const float4 p = rows[s];
+        const int i = __float_as_int(p.w);
+        if (!core[i]) continue;
+        const int cx = db_clamp((int)floorf((p.x - g.x0) * g.inv_cell), g.gw - 1), cy = db_clamp((int)floorf((p.y - g.y0) * g.inv_cell), g.gh - 1);
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int y = cy + dy;
+            if (y < 0 || y >= g.gh) continue;
+            const int x_lo = cx > 0 ? cx - 1 : 0, x_hi = cx + 1 < g.gw ? cx + 1 : g.gw - 1;
+            const int lo = offset[y * g.gw + x_lo], hi = offset[y * g.gw + x_hi + 1];      // the three cells of a row are contiguous
+            for (int t = lo + lane; t < hi; t += 64) {
+                const float4 q = rows[t];
+                const int j = __float_as_int(q.w);
+                if (j < i && core[j]) {
+                    const float dx = q.x - p.x, dy2 = q.y - p.y, dz = q.z - p.z;
+                    if (dx * dx + dy2 * dy2 + dz * dz <= eps2) db_union(parent, i, j);
+                }
+            }
         }
-        return true;
-    });
+    }
 }
 
 // root[i] = lowest index of i's cluster, or -1 (noise / skipped); is_root[i] = 1 for the cluster's lowest index
@@ -237,7 +275,7 @@ extern "C" int himo_dbscan(int n, const float* d_xyz, int pitch, const unsigned 
     hipLaunchKernelGGL(db_scatter_kernel, dim3(nb), dim3(256), 0, s, n, d_xyz, pitch, cell_id, count, cursor, rows);
     // (the sorted-row kernels are launched over n slots and stop at the number of participating points, which only the device knows)
     hipLaunchKernelGGL(db_core_kernel, dim3(nb), dim3(256), 0, s, rows, g, count, eps2, min_pts, core);
-    hipLaunchKernelGGL(db_union_kernel, dim3(nb), dim3(256), 0, s, rows, g, count, eps2, core, parent);
+    hipLaunchKernelGGL(db_union_kernel, dim3(nb < 4096 ? nb : 4096), dim3(256), 0, s, rows, g, count, eps2, core, parent);
     hipLaunchKernelGGL(db_root_kernel, dim3(nb), dim3(256), 0, s, rows, g, count, eps2, core, parent, root, is_root);
     hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, s, is_root, n);                // is_root -> rank of each cluster's lowest index
     hipLaunchKernelGGL(db_label_kernel, dim3(nb), dim3(256), 0, s, n, root, is_root, d_labels, d_n_clusters);

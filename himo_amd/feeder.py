@@ -370,32 +370,40 @@ class TrainFeeder:
     """Iterate training samples ``(pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels)`` -- the tuples
     ``seflow.fit.make_sample`` builds on the spot -- prepared AHEAD of the optimiser step, the way the reference's job keeps
     its steps fed (``num_workers=16`` dataloader workers prefetching beside ``train.py``'s step, assets/slurm/ssl-train-av2.sh:31-34;
-    the loop shape of save_zip.py:111-113: ``dataset[i]`` -> compute):
+    the loop shape of save_zip.py:111-113: ``dataset[i]`` -> compute).  Three stages, each on its own thread(s), samples in order:
 
-    * ``workers`` reader threads call ``seflow.fit.host_sample`` (the frames' sweeps / poses / ground masks or labels, read with
+    * READ: ``workers`` threads call ``seflow.fit.host_sample`` (the frames' sweeps / poses / ground masks or labels, read with
       ``fields=`` from the open scene files) up to ``depth + workers`` triplets ahead and copy the arrays ONCE, from the file
       mapping straight into a pinned arena of their own;
-    * the feeder thread takes the reads in order, issues the host -> device copies on a COPY stream, and on a LABEL stream
-      (ordered after the copies by an event) generates the cluster labels of ``ssl_label=seflow_auto``
-      (``seflow.ssl_label.auto_labels``: two exact nearest-neighbour passes and two DBSCANs per pair -- their index selections
-      block the thread that enqueues them, which is why that thread is not the one launching the training step); the label
-      count comes back through pinned memory behind the label stream's own event;
-    * the consumer's stream is ordered after a sample's last kernel by an event: the training thread never waits on the host
-      for a read, a copy or a label, and gets ``n_labels`` as a plain int.
+    * UPLOAD: the feeder thread takes the reads in order and issues the host -> device copies on a COPY stream;
+    * LABEL: ``label_lanes`` threads, each with its own stream ordered after the sample's copies by an event, generate the cluster
+      labels of ``ssl_label=seflow_auto`` (``seflow.ssl_label.auto_labels``: two exact nearest-neighbour passes and two DBSCANs
+      per pair, one host wait for the sizes of the compacted sweeps, one for the label count -- through pinned memory, on THAT
+      thread).  A pair's chain -- copy, kernels, wait, kernels, wait -- is ~2 ms on an idle device but 5-8 ms beside a training
+      step that owns most of the device and of the interpreter lock; with one lane the feeder delivered a sample per chain and
+      the step waited for it, with two the chains of successive samples overlap (profiles/r06_fit_stages.txt).
 
-    Labels and samples are pure functions of the frames, so a fed run ends in the parameter bits of the run that builds every
-    sample inside the step (tests/test_fit_gpu.py).  ``close()`` stops early."""
+    The consumer's stream is ordered after a sample's last kernel by an event: the training thread never waits on the host for a
+    read, a copy or a label, and gets ``n_labels`` as a plain int.  Labels and samples are pure functions of the frames, so a fed
+    run ends in the parameter bits of the run that builds every sample inside the step (tests/test_fit_gpu.py).  ``close()``
+    stops early."""
 
     _END = object()
 
-    def __init__(self, dataset, trips, device=None, label_key: str = "seflow_auto", depth: int = 2, workers: int = 4):
+    def __init__(self, dataset, trips, device=None, label_key: str = "seflow_auto", depth: int = 2, workers: int = 2,
+                 label_lanes: int = 2, label_priority: int = 0, label_cache: dict | None = None, label_cache_bytes: int = 4 << 30):
+        """``label_cache``: a dict the caller keeps between feeders over the SAME dataset (``fit``: one per dataset, for the whole
+        run).  Generated labels are a pure function of the sweep pair, and the reference's job reads them from files an offline pass
+        wrote once; here the first epoch generates them on the device and leaves a host copy in the dict (up to ``label_cache_bytes``),
+        later epochs upload that copy instead of clustering the pair again -- the same labels, bit for bit."""
         from concurrent.futures import ThreadPoolExecutor
-        if depth < 1 or workers < 1:
-            raise ValueError("depth and workers must be >= 1")
+        if depth < 1 or workers < 1 or label_lanes < 1:
+            raise ValueError("depth, workers and label_lanes must be >= 1")
+        self._cache, self._cache_budget = label_cache, int(label_cache_bytes)
         self.device = device if device is not None else _lib.require_gpu()
         self.dataset, self.trips, self.label_key = dataset, list(trips), label_key
-        self.depth, self.workers = depth, workers
-        self._window = depth + workers                         # reads in flight ahead of the copy being issued
+        self.depth, self.workers, self.lanes = depth, workers, label_lanes
+        self._window = depth + workers + label_lanes           # reads in flight ahead of the copy being issued
         self._free = queue.Queue()                             # (pinned arena, event of the copies that last read it | None)
         self._arenas = _borrow_arenas(self._window + 2)
         for a in self._arenas:
@@ -403,10 +411,12 @@ class TrainFeeder:
         self._events = []                                      # copy events of arenas handed back (for _return_arenas)
         self._q = queue.Queue(maxsize=depth)
         self._copy = torch.cuda.Stream(device=self.device)
-        self._label = torch.cuda.Stream(device=self.device)
-        self._nl_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._label_priority = label_priority
+        self._tls = threading.local()                          # per label thread: its stream and its pinned word
         self._pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="himo-train-read")
+        self._labellers = ThreadPoolExecutor(max_workers=label_lanes, thread_name_prefix="himo-train-label")
         self._error, self._stop = None, False
+        self._stat_lock = threading.Lock()
         self.stage_seconds = {"read": 0.0, "upload": 0.0, "labels": 0.0, "samples": 0}      # host time per stage (profiles/r06_fit_stages.txt)
         self._thread = threading.Thread(target=self._work, name="himo-train-feeder", daemon=True)
         self._thread.start()
@@ -419,6 +429,10 @@ class TrainFeeder:
         from .seflow.fit import host_sample
         t0 = time.perf_counter()
         h = host_sample(self.dataset, trip, self.label_key)
+        cached = self._cache.get(trip[1:]) if self._cache is not None else None
+        if cached is not None:                                 # labels generated in an earlier epoch: upload them like stored labels
+            h = {k: v for k, v in h.items() if k not in ("gm0", "gm1")}
+            h["lab0"], h["lab1"] = cached[0], cached[1]
         arena, ev = self._free.get()
         if ev is not None:
             ev.synchronize()                                   # the copies that last read this arena's pinned memory
@@ -436,10 +450,55 @@ class TrainFeeder:
         for k, (a, tdt) in small.items():
             pins[k] = arena.take(a.shape, tdt)
             np.copyto(pins[k].numpy(), a, casting="unsafe")
-        if "lab0" in h:                                        # stored labels: their count needs no device pass
+        if cached is not None:
+            n_host = cached[2]
+        elif "lab0" in h:                                      # stored labels: their count needs no device pass
             n_host = int(max(int(np.max(h["lab0"], initial=0)), int(np.max(h["lab1"], initial=0)))) + 1
-        self.stage_seconds["read"] += time.perf_counter() - t0
-        return arena, pins, (h["pose_h1"], h["pose0"], h["pose1"]), n_host
+        with self._stat_lock:
+            self.stage_seconds["read"] += time.perf_counter() - t0
+        return arena, pins, (h["pose_h1"], h["pose0"], h["pose1"]), n_host, trip[1:]
+
+    # ---- label threads -------------------------------------------------------------------------------------------
+    def _labels(self, dev, copied, poses, n_labels, key=None):
+        import time
+        t0 = time.perf_counter()
+        tls = self._tls
+        if getattr(tls, "stream", None) is None:
+            torch.cuda.set_device(self.device)
+            tls.stream = torch.cuda.Stream(device=self.device, priority=self._label_priority)
+            tls.word = torch.zeros(1, dtype=torch.int32).pin_memory()
+        with torch.cuda.stream(tls.stream):
+            tls.stream.wait_event(copied)
+            for t in dev.values():
+                t.record_stream(tls.stream)
+            if "gm0" in dev:
+                from .seflow.ssl_label import auto_labels
+                l0, l1 = auto_labels(dev["pc0"], dev["pc1"], dev["gm0"], dev["gm1"], poses[1], poses[2])
+                top = torch.maximum(l0.max() if l0.numel() else l0.new_zeros(()), l1.max() if l1.numel() else l1.new_zeros(()))
+                tls.word.copy_(top.reshape(1), non_blocking=True)
+                keep = self._cache is not None and self._cache_budget > 0
+                if keep:                                       # a host copy for the later epochs, behind the same wait as the count
+                    if getattr(tls, "host", None) is None or tls.host.numel() < l0.numel() + l1.numel():
+                        tls.host = torch.empty(int((l0.numel() + l1.numel()) * 1.25) + 16, dtype=torch.int32).pin_memory()
+                    tls.host[:l0.numel()].copy_(l0, non_blocking=True)
+                    tls.host[l0.numel():l0.numel() + l1.numel()].copy_(l1, non_blocking=True)
+                counted = torch.cuda.Event()
+                counted.record(tls.stream)
+                counted.synchronize()                          # this thread's wait, not the training thread's
+                n_labels = int(tls.word[0]) + 1
+                if keep:
+                    both = tls.host[:l0.numel() + l1.numel()].numpy().copy()
+                    with self._stat_lock:
+                        self._cache_budget -= both.nbytes
+                        self._cache[key] = (both[:l0.numel()], both[l0.numel():], n_labels)
+            else:
+                l0, l1 = dev["lab0"], dev["lab1"]
+            done = torch.cuda.Event()
+            done.record(tls.stream)
+        with self._stat_lock:
+            self.stage_seconds["labels"] += time.perf_counter() - t0
+            self.stage_seconds["samples"] += 1
+        return (dev["pch1"], dev["pc0"], dev["pc1"], poses[0], poses[1], poses[2], l0, l1, n_labels), done
 
     # ---- feeder thread -------------------------------------------------------------------------------------------
     def _work(self):
@@ -447,50 +506,35 @@ class TrainFeeder:
         import time
         try:
             torch.cuda.set_device(self.device)
-            pending, nxt = collections.deque(), 0
-            while True:
-                while nxt < len(self.trips) and len(pending) < self._window and not self._stop:
-                    pending.append(self._pool.submit(self._read, self.trips[nxt]))
+            reads, labelled, nxt = collections.deque(), collections.deque(), 0
+            while not self._stop:
+                while nxt < len(self.trips) and len(reads) < self._window:
+                    reads.append(self._pool.submit(self._read, self.trips[nxt]))
                     nxt += 1
-                if not pending or self._stop:
+                # keep ``lanes`` + 1 samples uploaded and in (or waiting for) the label stage, then hand the oldest on
+                while reads and len(labelled) < self.lanes + 1:
+                    arena, pins, poses, n_labels, key = reads.popleft().result()
+                    t0 = time.perf_counter()
+                    with torch.cuda.stream(self._copy):
+                        dev = {k: v.to(self.device, non_blocking=True) for k, v in pins.items()}      # pinned -> HBM
+                        copied = torch.cuda.Event()
+                        copied.record(self._copy)
+                    self._free.put((arena, copied))
+                    self._events.append(copied)
+                    del self._events[:-(self._window + 2)]
+                    with self._stat_lock:
+                        self.stage_seconds["upload"] += time.perf_counter() - t0
+                    labelled.append(self._labellers.submit(self._labels, dev, copied, poses, n_labels, key))
+                    dev = None
+                if not labelled:
                     break
-                arena, pins, poses, n_labels = pending.popleft().result()
-                t0 = time.perf_counter()
-                with torch.cuda.stream(self._copy):
-                    dev = {k: v.to(self.device, non_blocking=True) for k, v in pins.items()}      # pinned -> HBM
-                    copied = torch.cuda.Event()
-                    copied.record(self._copy)
-                self._free.put((arena, copied))
-                self._events.append(copied)
-                del self._events[:-(self._window + 2)]
-                t1 = time.perf_counter()
-                with torch.cuda.stream(self._label):
-                    self._label.wait_event(copied)
-                    for t in dev.values():
-                        t.record_stream(self._label)
-                    if "gm0" in dev:
-                        from .seflow.ssl_label import auto_labels
-                        l0, l1 = auto_labels(dev["pc0"], dev["pc1"], dev["gm0"], dev["gm1"], poses[1], poses[2])
-                        top = torch.maximum(l0.max() if l0.numel() else l0.new_zeros(()), l1.max() if l1.numel() else l1.new_zeros(()))
-                        self._nl_host.copy_(top.reshape(1), non_blocking=True)
-                        counted = torch.cuda.Event()
-                        counted.record(self._label)
-                        counted.synchronize()                  # this thread's wait, not the training thread's
-                        n_labels = int(self._nl_host[0]) + 1
-                    else:
-                        l0, l1 = dev["lab0"], dev["lab1"]
-                    done = torch.cuda.Event()
-                    done.record(self._label)
-                t2 = time.perf_counter()
-                st = self.stage_seconds
-                st["upload"] += t1 - t0; st["labels"] += t2 - t1; st["samples"] += 1
-                sample = (dev["pch1"], dev["pc0"], dev["pc1"], poses[0], poses[1], poses[2], l0, l1, n_labels)
-                if not self._offer((sample, done)):
+                if not self._offer(labelled.popleft().result()):
                     break
         except BaseException as e:                             # surfaced on the consumer's thread
             self._error = e
         finally:
             self._pool.shutdown(wait=True, cancel_futures=True)
+            self._labellers.shutdown(wait=True, cancel_futures=True)
             _return_arenas(self._arenas, self._events)
             self._offer(self._END)
 

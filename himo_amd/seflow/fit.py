@@ -19,6 +19,7 @@ and its label files are absent: unpinned); ``ssl_label=<frame key>`` (e.g. ``flo
 from __future__ import annotations
 
 import math
+import time
 from pathlib import Path
 
 import numpy as np
@@ -122,12 +123,15 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
         step_size: int = 3, gamma: float = 0.5, save_top: int = 3, val_dataset=None, resume=None, precision: str = "mixed",
         max_points: int = 140_000, device=None, seed: int = 0, max_steps: int | None = None, log=print,
         trainer: SeFlowTrainer | None = None, batchnorm: str = "batch", ssl_label: str = "seflow_auto",
-        num_workers: int = 4, prefetch: int = 2) -> dict:
+        num_workers: int = 2, prefetch: int = 2, label_lanes: int = 2,
+        cache_labels: bool = True) -> dict:
     """Train for ``epochs`` passes over ``dataset``; returns {"trainer", "history", "best"}.
 
     ``num_workers`` > 0 (default; the launcher's ``num_workers=16``, ssl-train-av2.sh:32): the samples of an epoch come from
     ``feeder.TrainFeeder`` -- read on that many threads, staged, copied and labelled ``prefetch`` samples ahead of the optimiser
     step.  0: every sample is built inside the step loop on the launch thread (``make_sample``) -- same parameter bits, slower.
+    ``cache_labels``: labels generated for a pair (``ssl_label=seflow_auto``) are kept on the host and uploaded again in the later
+    epochs instead of being generated again (the reference's job reads labels an offline pass wrote once); same bits.
 
     Ranks (torch.distributed, initialised by the caller / ``distenv.process_group``): step s of an epoch takes the global
     samples [s * batch_size, (s + 1) * batch_size) of that epoch's seeded shuffle; rank r takes every world-th of them.
@@ -149,6 +153,7 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
     steps_per_epoch = math.ceil(len(trips) / batch_size)
     history, steps_done = [], 0
     feed_stats = []
+    label_caches = {}                                        # per dataset: (i0, i1) -> (label0, label1, n_labels), filled by the first epoch
 
     def samples_of(ds, groups):
         """one iterator of device samples per group of triplets, in order; the groups' samples are prepared ahead across group
@@ -159,7 +164,9 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
             return
         import itertools
         from ..feeder import TrainFeeder
-        feed = TrainFeeder(ds, [t for grp in groups for t in grp], device=dev, label_key=ssl_label, depth=prefetch, workers=num_workers)
+        feed = TrainFeeder(ds, [t for grp in groups for t in grp], device=dev, label_key=ssl_label, depth=prefetch, workers=num_workers,
+                           label_lanes=label_lanes,
+                           label_cache=label_caches.setdefault(id(ds), {}) if (cache_labels and ssl_label in AUTO_LABELS) else None)
         try:
             it = iter(feed)
             for grp in groups:
@@ -177,11 +184,13 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
         mine = [[trips[j] for j in order[s * batch_size:(s + 1) * batch_size][rank::world]] for s in range(n_steps)]
         losses = []
         del feed_stats[:]
+        t_epoch = time.perf_counter()
         for smp in samples_of(dataset, mine):
             losses.append(tr.train_batch(smp, lr=lr_e))
             steps_done += 1
         train_feed = dict(feed_stats[0]) if feed_stats else None
-        train_loss = float(torch.stack(losses).mean().item()) if losses else float("nan")
+        train_loss = float(torch.stack(losses).mean().item()) if losses else float("nan")      # (waits for the epoch's last step)
+        t_epoch = time.perf_counter() - t_epoch
         tr.sync_running_stats()                              # validation and the checkpoint use rank 0's running statistics
         val_loss = None
         if val_trips:
@@ -193,7 +202,7 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
                 dist.all_reduce(tot)
             val_loss = float((tot[0] / tot[1].clamp(min=1.0)).item())
         entry = {"epoch": epoch, "lr": lr_e, "train_loss": train_loss, "val_loss": val_loss, "steps": len(losses),
-                 "samples": sum(len(g) for g in mine), "feeder": train_feed}      # (feeder: host seconds per stage on its own threads)
+                 "samples": sum(len(g) for g in mine), "feeder": train_feed, "train_seconds": t_epoch}      # (feeder: host seconds per stage on its own threads)
         history.append(entry)
         if log is not None and rank == 0:
             log(f"epoch {epoch}: lr {lr_e:.3g}  train loss {train_loss:.6f}" + (f"  val loss {val_loss:.6f}" if val_loss is not None else ""))
@@ -226,7 +235,7 @@ def main(argv=None):
                     help="batch: BatchNorm in training mode (from-scratch training, the reference job); frozen: fine-tuning convention")
     ap.add_argument("--ssl_label", default="seflow_auto",
                     help="seflow_auto (the launcher's +ssl_label=seflow_auto): labels generated on the GPU; or the frame key that holds them")
-    ap.add_argument("--num_workers", type=int, default=4,
+    ap.add_argument("--num_workers", type=int, default=2,
                     help="reader threads that prepare samples ahead of the step (the launcher's num_workers=16); 0: inside the step loop")
     ap.add_argument("--precision", default="mixed", choices=["mixed", "bf16x3", "f32"])
     a = ap.parse_args(argv)

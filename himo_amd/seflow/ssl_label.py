@@ -74,9 +74,37 @@ def _moved(pc: torch.Tensor, T: np.ndarray) -> torch.Tensor:
     return out
 
 
+_tls = __import__("threading").local()
+
+
+def _pinned_counts():
+    """this thread's pinned word pair for the sizes of the two compacted sweeps (one outstanding read-back per thread)"""
+    buf = getattr(_tls, "counts", None)
+    if buf is None:
+        buf = _tls.counts = torch.zeros(2, dtype=torch.int32).pin_memory()
+    return buf
+
+
+def _compact(pts: torch.Tensor, use: torch.Tensor):
+    """rows of ``pts`` with ``use`` set, in order, WITHOUT asking the host for their number: every row is copied to its rank among
+    the kept rows, the others to a dump row at the end.  -> (buffer (n + 1, 3), destination row of every input row (n,) int64, the
+    number of kept rows as a 1-element int32 device tensor)"""
+    n = pts.shape[0]
+    pos = torch.cumsum(use.to(torch.int32), 0, dtype=torch.int32)
+    dest = torch.where(use, pos - 1, n).to(torch.int64)
+    buf = torch.empty((n + 1, 3), dtype=torch.float32, device=pts.device)
+    buf.index_copy_(0, dest, pts)                               # (the dump row takes whichever excluded row lands last: never read)
+    return buf, dest, pos[-1:]
+
+
 def auto_labels(pc0, pc1, ground0, ground1, pose0, pose1, eps: float = EPS, min_pts: int = MIN_PTS, dyn_dist: float = DYN_DIST):
     """(label0 (n0,), label1 (n1,)) int32 device tensors for the sweep pair (module docstring).  ``pc*``: (n, >= 3) float32 in their
-    own sensor frames, ``ground*``: bool masks, ``pose*``: 4x4 world poses."""
+    own sensor frames, ``ground*``: bool masks, ``pose*``: 4x4 world poses.
+
+    ONE host wait per pair -- the sizes of the two in-range non-ground subsets, which the nearest-neighbour search takes as host
+    integers; they come back through pinned memory behind an event on the current stream.  Everything else is enqueued without
+    asking the device anything (no boolean-mask indexing: that copies a count back per use -- five waits per pair before round 6,
+    each as long as the queue in front of it when a training step shares the device)."""
     dev = _lib.require_gpu()
     up = lambda a, dt: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(device=dev, dtype=dt)
     p0, p1 = up(pc0, torch.float32), up(pc1, torch.float32)
@@ -84,19 +112,33 @@ def auto_labels(pc0, pc1, ground0, ground1, pose0, pose1, eps: float = EPS, min_
     T = np.linalg.inv(np.asarray(pose1, np.float64)) @ np.asarray(pose0, np.float64)
     a = _moved(p0, T)                                           # pc0 in pc1's frame
     b = p1[:, :3].contiguous()
-    far2 = torch.tensor(float(dyn_dist) ** 2, dtype=torch.float32, device=dev)
-    inv_ref2 = torch.tensor(1.0 / (DYN_REF_RANGE * DYN_REF_RANGE), dtype=torch.float32, device=dev)
-    out_a = (a[:, :2].abs().amax(dim=1) > RANGE_NET) if a.shape[0] else torch.zeros(0, dtype=torch.bool, device=dev)     # step 0
-    out_b = (b[:, :2].abs().amax(dim=1) > RANGE_NET) if b.shape[0] else torch.zeros(0, dtype=torch.bool, device=dev)
-    use_a, use_b = ~(g0 | out_a), ~(g1 | out_b)
-    a_in, b_in = a[use_a], b[use_b]                             # (index selection: data movement)
+    if a.shape[0] == 0 or b.shape[0] == 0:                      # nothing to compare with: every non-ground in-range point is a candidate
+        out = []
+        for pts, g in ((a, g0), (b, g1)):
+            skip = (g | (pts[:, :2].abs().amax(dim=1) > RANGE_NET)) if pts.shape[0] else torch.zeros(0, dtype=torch.bool, device=dev)
+            out.append(dbscan(pts, eps, min_pts, skip)[0])
+        return out[0], out[1]
+    far2 = float(dyn_dist) ** 2
+    inv_ref2 = 1.0 / (DYN_REF_RANGE * DYN_REF_RANGE)
+    use_a = ~(g0 | (a[:, :2].abs().amax(dim=1) > RANGE_NET))   # step 0
+    use_b = ~(g1 | (b[:, :2].abs().amax(dim=1) > RANGE_NET))
+    (buf_a, dest_a, cnt_a), (buf_b, dest_b, cnt_b) = _compact(a, use_a), _compact(b, use_b)
+    host = _pinned_counts()
+    host.copy_(torch.cat([cnt_a, cnt_b]), non_blocking=True)
+    landed = torch.cuda.Event()
+    landed.record(torch.cuda.current_stream(dev))
+    landed.synchronize()                                        # the pair's one host wait
+    na, nb = int(host[0]), int(host[1])
+    a_in, b_in = buf_a[:na], buf_b[:nb]
     out = []
-    for pts, use, mine, other in ((a, use_a, a_in, b_in), (b, use_b, b_in, a_in)):
+    for pts, use, dest, mine, other in ((a, use_a, dest_a, a_in, b_in), (b, use_b, dest_b, b_in, a_in)):
         skip = ~use
         if mine.shape[0] and other.shape[0]:
-            d2 = nn_grid(mine, other, return_index=False)
-            x, y = mine[:, 0], mine[:, 1]
+            n = pts.shape[0]
+            d2 = torch.full((n + 1,), float("inf"), dtype=torch.float32, device=dev)
+            d2[:mine.shape[0]] = nn_grid(mine, other, return_index=False)
+            x, y = pts[:, 0], pts[:, 1]
             bar2 = far2 * torch.clamp((x * x + y * y) * inv_ref2, min=1.0)       # (dyn_dist * max(1, r / 30 m))^2, float32 as the oracle
-            skip[use] = d2 <= bar2                              # a close return in the other sweep: static
+            skip = skip | (d2[dest] <= bar2)                    # a close return in the other sweep: static (the dump row holds inf)
         out.append(dbscan(pts, eps, min_pts, skip)[0])
     return out[0], out[1]

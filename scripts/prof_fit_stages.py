@@ -100,18 +100,21 @@ try:
     del smp
 
     # ---- the loop ---------------------------------------------------------------------------------------------------
-    for workers, prefetch in ((0, 0), (1, 2), (4, 2), (8, 3)):
-        fit(ds, trainer=tr, epochs=1, batch_size=8, max_steps=2, log=None, num_workers=workers, prefetch=max(prefetch, 1))
+    for workers, prefetch, lanes, cache in ((0, 0, 1, False), (1, 2, 1, False), (2, 2, 2, False), (2, 2, 2, True), (1, 2, 1, True)):
+        fit(ds, trainer=tr, epochs=1, batch_size=8, max_steps=2, log=None, num_workers=workers, prefetch=max(prefetch, 1), label_lanes=lanes, cache_labels=cache)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = fit(ds, trainer=tr, epochs=2, batch_size=8, log=None, num_workers=workers, prefetch=max(prefetch, 1))
+        out = fit(ds, trainer=tr, epochs=2, batch_size=8, log=None, num_workers=workers, prefetch=max(prefetch, 1), label_lanes=lanes, cache_labels=cache)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         n = sum(h["samples"] for h in out["history"])
-        what = "samples built inside the step loop (num_workers=0)" if workers == 0 else f"TrainFeeder, {workers} reader threads, {prefetch} samples ahead"
+        what = "samples built inside the step loop (num_workers=0)" if workers == 0 else f"TrainFeeder, {workers} reader threads, {lanes} label lanes, {prefetch} samples ahead"
         fd = out["history"][-1].get("feeder")
         extra = "" if not fd else (f"   feeder host ms per sample: read {1e3 * fd['read'] / fd['samples']:.2f} (summed over threads), "
                                    f"upload {1e3 * fd['upload'] / fd['samples']:.2f}, labels {1e3 * fd['labels'] / fd['samples']:.2f}")
+        what += f", labels {'generated once, uploaded afterwards' if cache else 'generated every epoch'}"
+        per_epoch = ", ".join(f"{1e3 * h['train_seconds'] / h['samples']:.3f}" for h in out["history"])
+        extra += f"   ms per sample by epoch: {per_epoch}"
         print(f"fit, 2 epochs ({n} samples, batch_size 8): {1e3 * el / n:7.3f} ms per sample = {n / el:6.1f} samples/s = {step_alone / (el / n):.3f} of the step alone; {what}{extra}")
     ds.close()
 finally:
