@@ -910,6 +910,10 @@ def extra_workload_legs(args, device) -> dict:
     from himo_amd import _lib
     out = {}
     legs = [("train", args.leg_train_steps, 2), ("fastnsf", args.leg_fastnsf_fits, 1)]
+    if args.train_precision == "mixed" and args.leg_train_steps > 0:
+        # the same step in the float32-class arithmetic (three-term bf16 split forward and data gradients, float32 MFMA weight gradients):
+        # the figure that stands beside `leg_train`'s the way `value_bf16x3` stands beside `value`
+        legs.insert(1, ("train_bf16x3", max(10, args.leg_train_steps // 2), 2))
     if args.cloud == "uniform":         # the training step again on LiDAR-shaped sweeps (himo_amd.synthetic.lidar_rings: crowded cells near the
         legs.insert(1, ("train_rings", args.leg_train_steps, 2))       # sensor, surfaces the other sweep lacks): `leg_train_rings` must stay near `leg_train`
     for leg_name, steps, warm in legs:
@@ -920,6 +924,8 @@ def extra_workload_legs(args, device) -> dict:
         a.workload, a.frames_per_step = name, 1
         if leg_name == "train_rings":
             a.cloud = "rings"
+        if leg_name == "train_bf16x3":
+            a.train_precision = "bf16x3"
         result = {}
         try:
             if name == "train":
