@@ -515,9 +515,12 @@ __global__ __launch_bounds__(256) void pfn_walk_kernel(PfnBnBatch m) {
 // one block of 256 threads: 4 groups x 2 sums x 32 channels over the block partials in fixed order, then the constants.
 // MODE 0 (forward): batch mean / invstd, the feature kernel's scale / shift, running-statistics update (unbiased variance).
 // MODE 1 (backward): dgamma / dbeta (accumulated when asked) and the two means the weight-gradient pass needs.
+// the sweeps whose points share one set of statistics (a per-process batch: the b-th sample's sweep of one frame slot, b = 0 .. n - 1)
+constexpr int kMaxGroup = 16;
+struct PfnGroup { const double* partial[kMaxGroup]; const int* block_sum[kMaxGroup]; int n; };
+
 template <int MODE>
-__global__ __launch_bounds__(1024) void pfn_bn_finalize_kernel(const double* __restrict__ partial, int n_blocks, const int* __restrict__ cell_count,
-                                                              const int* __restrict__ block_sum, int n_cells, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void pfn_bn_finalize_kernel(PfnGroup grp_src, int n_blocks, int n_cells, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps, float momentum,
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
                                                               float* __restrict__ out0, float* __restrict__ out1, float* __restrict__ out2,
@@ -527,22 +530,27 @@ __global__ __launch_bounds__(1024) void pfn_bn_finalize_kernel(const double* __r
     __shared__ double sh[2][16][32];
     const int c = threadIdx.x & 31, which = (threadIdx.x >> 5) & 1, grp = threadIdx.x >> 6;
     {
-        double t[4] = {0, 0, 0, 0};
-        int b = grp;
-        for (; b + 48 < n_blocks; b += 64) {
+        double all = 0.0;                                    // the group's members in order; one member: 0.0 + x = x, the single-sweep bits
+        for (int m = 0; m < grp_src.n; ++m) {
+            const double* __restrict__ partial = grp_src.partial[m];
+            double t[4] = {0, 0, 0, 0};
+            int b = grp;
+            for (; b + 48 < n_blocks; b += 64) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) t[k] += partial[((int64_t)(b + 16 * k) * 2 + which) * 32 + c];
+                for (int k = 0; k < 4; ++k) t[k] += partial[((int64_t)(b + 16 * k) * 2 + which) * 32 + c];
+            }
+            for (; b < n_blocks; b += 16) t[0] += partial[((int64_t)b * 2 + which) * 32 + c];
+            all += (t[0] + t[1]) + (t[2] + t[3]);
         }
-        for (; b < n_blocks; b += 16) t[0] += partial[((int64_t)b * 2 + which) * 32 + c];
-        sh[which][grp][c] = (t[0] + t[1]) + (t[2] + t[3]);
+        sh[which][grp][c] = all;
     }
     __syncthreads();
     if (threadIdx.x >= 32) return;
-    const double count = (double)block_sum[(n_cells + kScanBlock - 1) / kScanBlock];        // in-range points of the sweep
+    double count = 0.0;                                      // in-range points of the group's sweeps
+    for (int m = 0; m < grp_src.n; ++m) count += (double)grp_src.block_sum[m][(n_cells + kScanBlock - 1) / kScanBlock];
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
     for (int g = 0; g < 16; ++g) { a0 += sh[0][g][c]; a1 += sh[1][g][c]; }
-    (void)cell_count;
     if (MODE == 0) {
         if (count < 1.0) {                                   // an empty sweep: nothing to normalise, statistics untouched
             const float sc = gamma[c] / sqrtf((running_var ? running_var[c] : 1.f) + eps);
@@ -802,36 +810,59 @@ static int pfn_bn_args(PfnBnArgs& p, int64_t n, const float* h_voxel, const floa
     return HIMO_OK;
 }
 
-// Batch statistics of y = feats W over the in-range points of each sweep whose cell lists himo_pillarize* left in its
-// d_pillar_workspace -> d_scale / d_shift (what the feature kernel and the backward pass consume: gamma invstd,
-// beta - mean gamma invstd), d_mean / d_invstd (saved for the backward pass), rows of [n_sweeps][32] arrays; running statistics
-// updated in place sweep after sweep (momentum, unbiased variance; NULL: not tracked).  ONE walk launch for all sweeps; the
-// per-sweep finalize kernels follow in order.  Workspace: n_sweeps x himo_pfn_bn_workspace_bytes().
+// Batch statistics of y = feats W over the in-range points of each GROUP of sweeps (sweep i belongs to group i % n_groups: with the sweeps
+// of a per-process batch in the order sample-major, frame-minor, group f = frame slot f of every sample -- what ONE call of the pillar
+// net on a batch of sweeps normalises over) whose cell lists himo_pillarize* left in their d_pillar_workspace -> d_scale / d_shift (what
+// the feature kernel and the backward pass consume: gamma invstd, beta - mean gamma invstd), d_mean / d_invstd (saved for the backward
+// pass), rows of [n_groups][32] arrays; running statistics updated in place group after group (momentum, unbiased variance; NULL: not
+// tracked).  Walk launches of up to 12 sweeps each; the per-group finalize kernels follow in order.  Workspace: n_sweeps x
+// himo_pfn_bn_workspace_bytes().
+extern "C" int himo_pfn_bn_stats_groups(int n_sweeps, int n_groups, const int64_t* h_n, const float* const* h_xyz_t,
+                                        const void* const* h_pillar_workspace, const float* h_voxel, const float* h_centre_offset, int grid_w,
+                                        int grid_h, const float* d_pfn_weight, const float* d_gamma, const float* d_beta, float eps,
+                                        float momentum, float* d_running_mean, float* d_running_var, float* d_scale, float* d_shift,
+                                        float* d_mean, float* d_invstd, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (n_sweeps < 1 || n_groups < 1 || n_sweeps % n_groups || n_sweeps / n_groups > kMaxGroup || !h_n || !h_xyz_t || !h_pillar_workspace)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    if (!d_gamma || !d_beta || !d_scale || !d_shift || !d_mean || !d_invstd || (d_running_mean == nullptr) != (d_running_var == nullptr))
+        return HIMO_ERR_INVALID_ARGUMENT;
+    const size_t one = himo_pfn_bn_workspace_bytes();
+    if (workspace_bytes < one * n_sweeps) return HIMO_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("pfn_bn_stats_kernel", s);
+    PfnGroup groups[kMaxSweeps * kMaxGroup];
+    if (n_groups > kMaxSweeps * kMaxGroup) return HIMO_ERR_UNSUPPORTED;
+    for (int g = 0; g < n_groups; ++g) groups[g].n = 0;
+    for (int lo = 0; lo < n_sweeps; lo += kMaxSweeps) {
+        const int cnt = n_sweeps - lo < kMaxSweeps ? n_sweeps - lo : kMaxSweeps;
+        PfnBnBatch m{};
+        for (int j = 0; j < cnt; ++j) {
+            const int i = lo + j;
+            const int st = pfn_bn_args(m.s[j], h_n[i], h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight, h_xyz_t[i], h_pillar_workspace[i],
+                                       reinterpret_cast<char*>(d_workspace) + one * i, one);
+            if (st != HIMO_OK) return st;
+            PfnGroup& G = groups[i % n_groups];
+            G.partial[G.n] = m.s[j].partial; G.block_sum[G.n] = m.s[j].b.block_sum; ++G.n;
+        }
+        hipLaunchKernelGGL(pfn_walk_kernel<0>, dim3(kPfnBwdBlocks, cnt), dim3(256), 0, s, m);
+    }
+    for (int g = 0; g < n_groups; ++g)
+        hipLaunchKernelGGL(pfn_bn_finalize_kernel<0>, dim3(1), dim3(1024), 0, s, groups[g], kPfnBwdBlocks, grid_w * grid_h, d_gamma, d_beta, eps,
+                           momentum, d_running_mean, d_running_var, d_scale + 32 * g, d_shift + 32 * g, d_mean + 32 * g, d_invstd + 32 * g, 0);
+    HIMO_LAUNCH_CHECK("pfn_bn_stats kernels");
+    return HIMO_OK;
+}
+
+// every sweep its own group: statistics per sweep (one call of the pillar net per sweep)
 extern "C" int himo_pfn_bn_stats_multi(int n_sweeps, const int64_t* h_n, const float* const* h_xyz_t, const void* const* h_pillar_workspace,
                                        const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
                                        const float* d_pfn_weight, const float* d_gamma, const float* d_beta, float eps, float momentum,
                                        float* d_running_mean, float* d_running_var, float* d_scale, float* d_shift, float* d_mean,
                                        float* d_invstd, void* d_workspace, size_t workspace_bytes, void* stream) {
-    if (n_sweeps < 1 || n_sweeps > kMaxSweeps || !h_n || !h_xyz_t || !h_pillar_workspace) return HIMO_ERR_INVALID_ARGUMENT;
-    if (!d_gamma || !d_beta || !d_scale || !d_shift || !d_mean || !d_invstd || (d_running_mean == nullptr) != (d_running_var == nullptr))
-        return HIMO_ERR_INVALID_ARGUMENT;
-    const size_t one = himo_pfn_bn_workspace_bytes();
-    if (workspace_bytes < one * n_sweeps) return HIMO_ERR_WORKSPACE;
-    PfnBnBatch m{};
-    for (int i = 0; i < n_sweeps; ++i) {
-        const int st = pfn_bn_args(m.s[i], h_n[i], h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight, h_xyz_t[i], h_pillar_workspace[i],
-                                   reinterpret_cast<char*>(d_workspace) + one * i, one);
-        if (st != HIMO_OK) return st;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope ps("pfn_bn_stats_kernel", s);
-    hipLaunchKernelGGL(pfn_walk_kernel<0>, dim3(kPfnBwdBlocks, n_sweeps), dim3(256), 0, s, m);
-    for (int i = 0; i < n_sweeps; ++i)
-        hipLaunchKernelGGL(pfn_bn_finalize_kernel<0>, dim3(1), dim3(1024), 0, s, m.s[i].partial, kPfnBwdBlocks, m.s[i].b.cell_count,
-                           m.s[i].b.block_sum, grid_w * grid_h, d_gamma, d_beta, eps, momentum, d_running_mean, d_running_var,
-                           d_scale + 32 * i, d_shift + 32 * i, d_mean + 32 * i, d_invstd + 32 * i, 0);
-    HIMO_LAUNCH_CHECK("pfn_bn_stats kernels");
-    return HIMO_OK;
+    if (n_sweeps > kMaxSweeps) return HIMO_ERR_INVALID_ARGUMENT;
+    return himo_pfn_bn_stats_groups(n_sweeps, n_sweeps, h_n, h_xyz_t, h_pillar_workspace, h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight,
+                                    d_gamma, d_beta, eps, momentum, d_running_mean, d_running_var, d_scale, d_shift, d_mean, d_invstd,
+                                    d_workspace, workspace_bytes, stream);
 }
 
 extern "C" int himo_pfn_bn_stats(int64_t n, const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
@@ -881,45 +912,74 @@ extern "C" int himo_pillar_features_multi(int n_sweeps, const himo_sweep* h_swee
     return HIMO_OK;
 }
 
-// himo_pfn_backward with batch statistics, for the sweeps of a sample at once: d loss / d pfn.weight, d gamma, d beta [32] SUMMED over the
-// sweeps in order (flags bit 0: added to what the three hold).  d_scale / d_shift / d_mean / d_invstd: rows of [n_sweeps][32] arrays as
-// himo_pfn_bn_stats_multi left them.  Two walk launches for all sweeps; the per-sweep finalize / reduce kernels follow in order, so the
-// result has the bits of n_sweeps single calls.
+// himo_pfn_backward with batch statistics, for all sweeps at once: d loss / d pfn.weight, d gamma, d beta [32] SUMMED over the sweeps in
+// order (flags bit 0: added to what the three hold).  Sweep i belongs to group i % n_groups (himo_pfn_bn_stats_groups); d_scale / d_shift
+// / d_mean / d_invstd: rows of [n_groups][32] arrays as it left them.  The two means of the BatchNorm backward (mean g, mean g xhat) are
+// taken over a group's points.  Walk launches of up to 12 sweeps; the per-group finalize and per-sweep reduce kernels follow in order,
+// so with every sweep its own group the result has the bits of n_sweeps single calls.
+extern "C" int himo_pfn_backward_bn_groups(int n_sweeps, int n_groups, const int64_t* h_n, const float* const* h_xyz_t,
+                                           const void* const* h_pillar_workspace, const float* const* h_dimage, int image_pitch,
+                                           const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight,
+                                           const float* d_scale, const float* d_shift, const float* d_mean, const float* d_invstd,
+                                           float* d_dweight, float* d_dgamma, float* d_dbeta, unsigned flags, void* d_workspace,
+                                           size_t workspace_bytes, void* stream) {
+    if (n_sweeps < 1 || n_groups < 1 || n_sweeps % n_groups || n_sweeps / n_groups > kMaxGroup || n_groups > kMaxSweeps * kMaxGroup ||
+        n_sweeps > kMaxSweeps * kMaxGroup || !h_n || !h_xyz_t || !h_pillar_workspace || !h_dimage)
+        return HIMO_ERR_INVALID_ARGUMENT;
+    if (!d_scale || !d_shift || !d_mean || !d_invstd || !d_dweight || !d_dgamma || !d_dbeta || image_pitch < 32) return HIMO_ERR_INVALID_ARGUMENT;
+    const size_t one = himo_pfn_bn_workspace_bytes();
+    if (workspace_bytes < one * n_sweeps) return HIMO_ERR_WORKSPACE;
+    static thread_local PfnBnArgs args[kMaxSweeps * kMaxGroup];
+    PfnGroup groups[kMaxSweeps * kMaxGroup];
+    for (int g = 0; g < n_groups; ++g) groups[g].n = 0;
+    for (int i = 0; i < n_sweeps; ++i) {
+        if (!h_dimage[i]) return HIMO_ERR_INVALID_ARGUMENT;
+        PfnBnArgs& p = args[i];
+        const int st = pfn_bn_args(p, h_n[i], h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight, h_xyz_t[i], h_pillar_workspace[i],
+                                   reinterpret_cast<char*>(d_workspace) + one * i, one);
+        if (st != HIMO_OK) return st;
+        const int g = i % n_groups;
+        p.b.pfn_scale = d_scale + 32 * g; p.b.pfn_shift = d_shift + 32 * g; p.b.d_image = h_dimage[i]; p.b.image_pitch = image_pitch;
+        p.mean = d_mean + 32 * g; p.invstd = d_invstd + 32 * g;
+        // the group's coefficients live behind the partials of its FIRST sweep's workspace block
+        p.coef = i < n_groups ? reinterpret_cast<float*>(p.partial + (size_t)kPfnBwdBlocks * 2 * 32) : args[g].coef;
+        PfnGroup& G = groups[g];
+        G.partial[G.n] = p.partial; G.block_sum[G.n] = p.b.block_sum; ++G.n;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("pfn_backward_kernel", s);
+    auto walk = [&](auto kernel) {
+        for (int lo = 0; lo < n_sweeps; lo += kMaxSweeps) {
+            const int cnt = n_sweeps - lo < kMaxSweeps ? n_sweeps - lo : kMaxSweeps;
+            PfnBnBatch m{};
+            for (int j = 0; j < cnt; ++j) m.s[j] = args[lo + j];
+            hipLaunchKernelGGL(kernel, dim3(kPfnBwdBlocks, cnt), dim3(256), 0, s, m);
+        }
+    };
+    walk(pfn_walk_kernel<1>);
+    for (int g = 0; g < n_groups; ++g) {
+        float* coef = const_cast<float*>(args[g].coef);
+        hipLaunchKernelGGL(pfn_bn_finalize_kernel<1>, dim3(1), dim3(1024), 0, s, groups[g], kPfnBwdBlocks, grid_w * grid_h, (const float*)nullptr,
+                           (const float*)nullptr, 0.f, 0.f, (float*)nullptr, (float*)nullptr, d_dgamma, d_dbeta, coef, coef + 32,
+                           (g > 0 || (flags & 1u)) ? 1 : 0);
+    }
+    walk(pfn_walk_kernel<2>);
+    for (int i = 0; i < n_sweeps; ++i)
+        hipLaunchKernelGGL(pfn_backward_reduce_kernel, dim3(9), dim3(1024), 0, s, args[i].b.partial, kPfnBwdBlocks, d_dweight,
+                           (i > 0 || (flags & 1u)) ? 1 : 0);
+    HIMO_LAUNCH_CHECK("pfn_backward_bn kernels");
+    return HIMO_OK;
+}
+
 extern "C" int himo_pfn_backward_bn_multi(int n_sweeps, const int64_t* h_n, const float* const* h_xyz_t, const void* const* h_pillar_workspace,
                                           const float* const* h_dimage, int image_pitch, const float* h_voxel, const float* h_centre_offset,
                                           int grid_w, int grid_h, const float* d_pfn_weight, const float* d_scale, const float* d_shift,
                                           const float* d_mean, const float* d_invstd, float* d_dweight, float* d_dgamma, float* d_dbeta,
                                           unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream) {
-    if (n_sweeps < 1 || n_sweeps > kMaxSweeps || !h_n || !h_xyz_t || !h_pillar_workspace || !h_dimage) return HIMO_ERR_INVALID_ARGUMENT;
-    if (!d_scale || !d_shift || !d_mean || !d_invstd || !d_dweight || !d_dgamma || !d_dbeta || image_pitch < 32) return HIMO_ERR_INVALID_ARGUMENT;
-    const size_t one = himo_pfn_bn_workspace_bytes();
-    if (workspace_bytes < one * n_sweeps) return HIMO_ERR_WORKSPACE;
-    PfnBnBatch m{};
-    for (int i = 0; i < n_sweeps; ++i) {
-        if (!h_dimage[i]) return HIMO_ERR_INVALID_ARGUMENT;
-        PfnBnArgs& p = m.s[i];
-        const int st = pfn_bn_args(p, h_n[i], h_voxel, h_centre_offset, grid_w, grid_h, d_pfn_weight, h_xyz_t[i], h_pillar_workspace[i],
-                                   reinterpret_cast<char*>(d_workspace) + one * i, one);
-        if (st != HIMO_OK) return st;
-        p.b.pfn_scale = d_scale + 32 * i; p.b.pfn_shift = d_shift + 32 * i; p.b.d_image = h_dimage[i]; p.b.image_pitch = image_pitch;
-        p.mean = d_mean + 32 * i; p.invstd = d_invstd + 32 * i;
-        p.coef = reinterpret_cast<float*>(p.partial + (size_t)kPfnBwdBlocks * 2 * 32);
-    }
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope ps("pfn_backward_kernel", s);
-    hipLaunchKernelGGL(pfn_walk_kernel<1>, dim3(kPfnBwdBlocks, n_sweeps), dim3(256), 0, s, m);
-    for (int i = 0; i < n_sweeps; ++i) {
-        float* coef = const_cast<float*>(m.s[i].coef);
-        hipLaunchKernelGGL(pfn_bn_finalize_kernel<1>, dim3(1), dim3(1024), 0, s, m.s[i].partial, kPfnBwdBlocks, m.s[i].b.cell_count,
-                           m.s[i].b.block_sum, grid_w * grid_h, (const float*)nullptr, (const float*)nullptr, 0.f, 0.f, (float*)nullptr,
-                           (float*)nullptr, d_dgamma, d_dbeta, coef, coef + 32, (i > 0 || (flags & 1u)) ? 1 : 0);
-    }
-    hipLaunchKernelGGL(pfn_walk_kernel<2>, dim3(kPfnBwdBlocks, n_sweeps), dim3(256), 0, s, m);
-    for (int i = 0; i < n_sweeps; ++i)
-        hipLaunchKernelGGL(pfn_backward_reduce_kernel, dim3(9), dim3(1024), 0, s, m.s[i].b.partial, kPfnBwdBlocks, d_dweight,
-                           (i > 0 || (flags & 1u)) ? 1 : 0);
-    HIMO_LAUNCH_CHECK("pfn_backward_bn kernels");
-    return HIMO_OK;
+    if (n_sweeps > kMaxSweeps) return HIMO_ERR_INVALID_ARGUMENT;
+    return himo_pfn_backward_bn_groups(n_sweeps, n_sweeps, h_n, h_xyz_t, h_pillar_workspace, h_dimage, image_pitch, h_voxel, h_centre_offset,
+                                       grid_w, grid_h, d_pfn_weight, d_scale, d_shift, d_mean, d_invstd, d_dweight, d_dgamma, d_dbeta, flags,
+                                       d_workspace, workspace_bytes, stream);
 }
 
 extern "C" int himo_pfn_backward_bn(int64_t n, const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,

@@ -138,8 +138,11 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
     ``max_steps`` bounds the optimiser steps of the whole run (tests)."""
     import torch.distributed as dist
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    # a rank's share of a step's samples goes through the network in ONE pass (BatchNorm statistics over them: torch's semantics
+    # for a per-process batch), up to 8 at a time
+    per_rank = min(8, max(1, math.ceil(batch_size / world)))
     tr = trainer if trainer is not None else SeFlowTrainer(params, device=device, max_points=max_points, seed=seed, precision=precision,
-                                                           batchnorm=batchnorm)
+                                                           batchnorm=batchnorm, batch=per_rank)
     dev = tr.device
     start_epoch = 0
     if resume is not None:

@@ -13,6 +13,7 @@ buffer, and a single all-reduce of the flat gradient across ranks.
 from __future__ import annotations
 
 import ctypes
+import itertools
 import os
 
 import numpy as np
@@ -143,6 +144,7 @@ class HeadTrainer:
         self.PKT = {k: pk(*self.p[f"{k}.weight"].shape[::-1]) for k in ("zr", "q", "dec1")} if self.fmt_bwd is not None else {}
         # True: the owner refreshes PK / PKT itself after every parameter update (SeFlowTrainer: one launch for the whole network)
         self.external_pack = False
+        self.accumulate = False        # True: every weight / bias gradient of a backward pass is ADDED to what ``g`` holds (sample b > 0 of a batch)
         self.wgrad_stream = None       # a torch stream for the gate weight gradients of the fused backward (None: in place)
         self.fused_backward = True     # split precisions: the GRU iterations' backward sweep as one kernel (False: three element-wise
                                        # kernels around two row products per iteration -- kept as the statement the fused sweep is tested against)
@@ -281,7 +283,8 @@ class HeadTrainer:
                 for rows, t, acc in runs:
                     _lib.check(self.lib.himo_linear_wgrad_ex(rows, x[t].data_ptr(), 192, 192, dz[t].data_ptr(), cout, cout,
                                                              self.g[f"{name}.weight"].data_ptr(), self.g[f"{name}.bias"].data_ptr(),
-                                                             self.wgrad_flags | acc, self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle()), "wgrad")
+                                                             self.wgrad_flags | acc | (1 if self.accumulate else 0), self.ws.data_ptr(), self.ws.numel(),
+                                                             _lib.stream_handle()), "wgrad")
         # 1.5 GB of saved states and gate gradients, read only: beside whatever the caller's stream does next (SeFlowTrainer: the
         # decoder's backward pass); the caller waits for this stream before it reads the gradients or runs the next backward
         self._aside(gate_weight_gradients)
@@ -308,7 +311,8 @@ class HeadTrainer:
     def _wgrad(self, x, cin, dz, cout, name, accumulate=False):
         _lib.check(self.lib.himo_linear_wgrad_ex(x.shape[0], x.data_ptr(), x.shape[1], cin, dz.data_ptr(), dz.shape[1], cout,
                                                  self.g[f"{name}.weight"].data_ptr(), self.g[f"{name}.bias"].data_ptr(),
-                                                 (1 if accumulate else 0) | self.wgrad_flags, self.ws.data_ptr(), self.ws.numel(), _lib.stream_handle()), "wgrad")
+                                                 (1 if (accumulate or self.accumulate) else 0) | self.wgrad_flags, self.ws.data_ptr(), self.ws.numel(),
+                                                 _lib.stream_handle()), "wgrad")
 
     def _transposed(self, name):
         w = self.p[f"{name}.weight"]
@@ -385,6 +389,10 @@ _lib.register({
                                       ctypes.c_size_t, c_p]),
     "himo_pfn_backward_bn_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                          ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
+    "himo_pfn_bn_stats_groups": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                       ctypes.c_size_t, c_p]),
+    "himo_pfn_backward_bn_groups": (c_i, [c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                          ctypes.c_uint, c_p, ctypes.c_size_t, c_p]),
     "himo_pillar_features_multi": (c_i, [c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, ctypes.c_size_t, c_i, c_p]),
     "himo_pfn_backward_bn": (c_i, [c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, ctypes.c_uint,
                                    c_p, ctypes.c_size_t, c_p]),
@@ -453,8 +461,18 @@ class SeFlowTrainer:
     """
 
     def __init__(self, params: dict | None = None, device=None, max_points: int = 140_000, seed: int = 0,
-                 precision: str = "bf16x3", batchnorm: str = "batch"):
-        """``precision``: "bf16x3" runs every stride-1 convolution of the forward and data-gradient passes as split-bf16
+                 precision: str = "bf16x3", batchnorm: str = "batch", batch: int = 1):
+        """``batch``: samples one forward / backward pass takes (the launcher's ``batch_size=8`` on one process,
+        assets/slurm/ssl-train-av2.sh:32-34): every encoder layer runs over ``batch`` x F images in ONE launch, every decoder
+        layer over ``batch`` images, and training-mode BatchNorm takes its statistics over the whole batch, as torch does
+        (``forward_batch`` / ``backward_batch`` / ``train_batch``); saved activations and gradient buffers are ``batch`` times
+        the single-sample ones (~5 GB per sample at 120k points).  Layout: the maps whose frames are channel groups (pillar
+        images, the stage outputs the decoder concatenates) hold ALL the batch's images as channel groups of one pixel-major buffer
+        -- image b * F + f at channel offset C * (b * F + f), pitch C * F * batch -- so that every kernel that walks "n images with a
+        stride" (convolutions, BatchNorm, weight gradients) sees the batch as n = batch * F images, and the decoder reads sample
+        b's concatenation as channels [C * F * b, C * F * (b + 1)); every other map is [image][pixel][channel].
+
+        ``precision``: "bf16x3" runs every stride-1 convolution of the forward and data-gradient passes as split-bf16
         on the matrix cores (float32-class accuracy, csrc/convbf.hip; weights are re-packed after every optimiser step);
         "mixed" runs the FORWARD convolutions as the two-term fp16 split (activations are O(1): inside fp16's range) and
         keeps the data gradient split-bf16 (gradients are far below fp16's subnormal floor); "f32" keeps float32 MFMA.
@@ -464,6 +482,10 @@ class SeFlowTrainer:
             raise ValueError(precision)
         if batchnorm not in ("batch", "frozen"):
             raise ValueError(batchnorm)
+        if not 1 <= batch <= 16:
+            raise ValueError("batch must be in 1..16")
+        self.B = B = batch
+        self.nb = 1
         self.precision = precision
         self.bn_batch = batchnorm == "batch"
         self.fwd_format = 1 if precision == "mixed" else 0          # HIMO_PACK_F16X2 / HIMO_PACK_BF16X3
@@ -476,7 +498,7 @@ class SeFlowTrainer:
         self.lib = _lib.load()
         self.device = dev = device if device is not None else _lib.require_gpu()
         params = spec.init_params(seed, fresh_bn=self.bn_batch) if params is None else params      # from scratch: BatchNorm reset
-        net = self.net = SeFlowNet(params, device=dev, max_points=1, precision="f32", autotune=False)
+        net = self.net = SeFlowNet(params, device=dev, max_points=1, precision="f32", autotune=False, max_batch=B)
         net.fold_decoder = False                          # the backward pass reads every decoder layer's own output
         net.keep_cell_lists = True
         net.use_plan = False
@@ -519,7 +541,12 @@ class SeFlowTrainer:
                 net.p[k] = self.p[k]                              # incl. the BatchNorm gamma / beta views in batch mode
         hp = {k[5:]: v for k, v in self.p.items() if k.startswith("head.") and not k.startswith("head.offset")}
         hg = {k[5:]: v for k, v in self.g.items() if k.startswith("head.") and not k.startswith("head.offset")}
-        self.head = HeadTrainer(device=dev, p=hp, g=hg, precision=precision)
+        # one head state per sample of the batch (saved GRU states for the backward pass: ~1.5 GB per 120k points), same parameters,
+        # gradients and packed weights; sample b > 0 ADDS its weight gradients to what sample 0 wrote
+        self.heads = [HeadTrainer(device=dev, p=hp, g=hg, precision=precision) for _ in range(B)]
+        self.head = self.heads[0]
+        for h_ in self.heads[1:]:
+            h_.PK, h_.PKT, h_.WT, h_.accumulate = self.head.PK, self.head.PKT, self.head.WT, True
         self.step_count = 0
         self._descs = {}
         # ---- saved encoder activations: PRE (after BN, before GELU) and Y per layer, frames as the batch
@@ -531,35 +558,39 @@ class SeFlowTrainer:
             last = i + 1 == len(spec.ENCODER) or spec.ENCODER[i + 1][3] == 2
             self.layers.append((name, cin, cout, stride, h, w, ho, wo, last))
             h, w = ho, wo
-        self.PRE = [buf(F, L[6] * L[7], L[2]) for L in self.layers]
-        self.Y = [None if L[8] else buf(F, L[6] * L[7], L[2]) for L in self.layers]
+        BF = B * F
+        self.PRE = [buf(BF, L[6] * L[7], L[2]) for L in self.layers]
+        self.Y = [None if L[8] else buf(BF, L[6] * L[7], L[2]) for L in self.layers]
+        # the maps whose frames are channel groups: pixel-major, ALL the batch's images as channel groups (class docstring); the
+        # network object's [sample][pixel][C * F] buffers have exactly this many elements and are used as raw storage
+        self.B0p, self.F1p, self.F2p, self.F3p = (t.data_ptr() for t in (net._B0, net.F1, net.F2, net.F3))
         # ---- gradient buffers
-        self.dB0, self.dDEC = buf(H * W, 32 * F), buf(H * W, 64)
-        self.dF1, self.dF2, self.dF3 = buf(H * W // 4, 64 * F), buf(H * W // 16, 128 * F), buf(H * W // 64, 256 * F)
-        big = F * (H // 2) * (W // 2) * 64                       # the largest encoder activation (floats)
+        self.dB0, self.dDEC = buf(H * W, 32 * BF), buf(B * H * W, 64)
+        self.dF1, self.dF2, self.dF3 = buf(H * W // 4, 64 * BF), buf(H * W // 16, 128 * BF), buf(H * W // 64, 256 * BF)
+        big = BF * (H // 2) * (W // 2) * 64                      # the largest encoder activation (floats)
         self.dA, self.dB, self.DP, self.DP2 = buf(big), buf(big), buf(big), buf(big)
-        self.Z = buf(F * H * W * 64)                             # zero-stuffed dY of the stride-2 layers (largest: enc1.0)
-        self.TMP = buf(max(H * W * 128, F * H * W * 32))        # a decoder-sized scratch / the enc1.0 data gradient
-        self.dWORK = [buf(H * W * 64) for _ in range(2)]         # d work[0] and d (block input) ping-pong
-        self.dCAT = buf(H * W * 128)
-        self.dTMPc = buf((H // 2) * (W // 2) * 64)               # gradient of the 1x1-projected coarse map
-        self.dCO = [buf((H // 2) * (W // 2) * 128) for _ in range(2)]   # d coarse of dec3 / dec2
+        self._Z = None                                           # zero-stuffed dY of the stride-2 layers (largest: enc1.0): only the fallback path
+        self.TMP = buf(max(B * H * W * 128, BF * H * W * 32))   # a decoder-sized scratch / the enc1.0 data gradient
+        self.dWORK = [buf(B * H * W * 64) for _ in range(2)]     # d work[0] and d (block input) ping-pong
+        self.dCAT = buf(B * H * W * 128)
+        self.dTMPc = buf(B * (H // 2) * (W // 2) * 64)           # gradient of the 1x1-projected coarse map
+        self.dCO = [buf(B * (H // 2) * (W // 2) * 128) for _ in range(2)]   # d coarse of dec3 / dec2
         self.WF = buf(3 * 3 * 512 * 256) if precision == "f32" else None      # flipped weights of the layer being differentiated
         ws = max(int(self.lib.himo_conv_wgrad_workspace_bytes(H // 4, W // 4, 512, 256)),
                  max(int(self.lib.himo_conv_wgrad_batch_workspace_bytes(n, h_, w_, ci, co, st)) for n, h_, w_, ci, co, st in
-                     [(F, H // 2, W // 2, 64, 64, 1), (F, H // 4, W // 4, 128, 128, 1), (F, H // 8, W // 8, 256, 256, 1),
-                      (1, H // 4, W // 4, 512, 256, 1), (1, H // 4, W // 4, 256, 256, 1), (1, H // 2, W // 2, 256, 128, 1),
-                      (1, H // 2, W // 2, 128, 128, 1), (1, H, W, 128, 64, 1), (1, H, W, 64, 64, 1),
-                      (F, H, W, 32, 64, 2), (F, H // 2, W // 2, 64, 128, 2), (F, H // 4, W // 4, 128, 256, 2)]),
+                     [(BF, H // 2, W // 2, 64, 64, 1), (BF, H // 4, W // 4, 128, 128, 1), (BF, H // 8, W // 8, 256, 256, 1),
+                      (B, H // 4, W // 4, 512, 256, 1), (B, H // 4, W // 4, 256, 256, 1), (B, H // 2, W // 2, 256, 128, 1),
+                      (B, H // 2, W // 2, 128, 128, 1), (B, H, W, 128, 64, 1), (B, H, W, 64, 64, 1),
+                      (BF, H, W, 32, 64, 2), (BF, H // 2, W // 2, 64, 128, 2), (BF, H // 4, W // 4, 128, 256, 2)]),
                  int(self.lib.himo_conv_wgrad_workspace_bytes(H, W, 128, 64)),
                  int(self.lib.himo_conv_wgrad_workspace_bytes(H // 2, W // 2, 256, 128)),
-                 int(self.lib.himo_wgrad_workspace_bytes_ex(H * W, 96, 64)),
-                 int(self.lib.himo_wgrad_workspace_bytes_ex(H * W // 4, 192, 128)),
-                 int(self.lib.himo_wgrad_workspace_bytes_ex(H * W // 16, 384, 256)),
+                 int(self.lib.himo_wgrad_workspace_bytes_ex(B * H * W, 96, 64)),
+                 int(self.lib.himo_wgrad_workspace_bytes_ex(B * H * W // 4, 192, 128)),
+                 int(self.lib.himo_wgrad_workspace_bytes_ex(B * H * W // 16, 384, 256)),
                  int(self.lib.himo_wgrad_workspace_bytes_ex(max_points, 192, 256)),
                  int(self.lib.himo_pfn_backward_workspace_bytes()))
-        ws = max(ws, F * int(self.lib.himo_pfn_bn_workspace_bytes()),
-                 max(int(self.lib.himo_bn_workspace_bytes(F * L[6] * L[7], L[2])) for L in self.layers))
+        ws = max(ws, BF * int(self.lib.himo_pfn_bn_workspace_bytes()),
+                 max(int(self.lib.himo_bn_workspace_bytes(BF * L[6] * L[7], L[2])) for L in self.layers))
         self.ws = torch.empty(ws + 64, dtype=torch.uint8, device=dev)
         # the encoder's weight gradients run on a SIDE stream under the data-gradient chain (backward): own workspace, and the
         # pre-activation gradient they read alternates between two buffers so the chain never waits for them
@@ -580,12 +611,13 @@ class SeFlowTrainer:
         self.side3 = torch.cuda.Stream(device=dev)
         self._skip_done = []
         self.ws_side2 = torch.empty(ws + 64, dtype=torch.uint8, device=dev) if self.overlap_decoder else None
-        self.head.wgrad_stream = self.side2 if self.overlap_decoder else None      # the GRU gates' weight gradients go there too
+        for h_ in self.heads:
+            h_.wgrad_stream = self.side2 if self.overlap_decoder else None      # the GRU gates' weight gradients go there too
         if self.overlap_decoder:
-            self.TMP3 = buf(H * W * 32 * F)                      # dec3's skip gradient before it is added to the head's (third side stream)
-            self.dIN = {"dec3": buf(H * W * 64), "dec2": buf(H * W // 4 * 128), "dec1": buf(H * W // 16 * 256)}
-            self.dCATb = {"dec3": self.dCAT, "dec2": buf(H * W // 4 * 256), "dec1": buf(H * W // 16 * 512)}
-            self.dTMPb = {"dec3": self.dTMPc, "dec2": buf(H * W // 16 * 128), "dec1": buf(H * W // 64 * 256)}
+            self.TMP3 = buf(H * W * 32 * BF)                     # dec3's skip gradient before it is added to the head's (third side stream)
+            self.dIN = {"dec3": buf(B * H * W * 64), "dec2": buf(B * H * W // 4 * 128), "dec1": buf(B * H * W // 16 * 256)}
+            self.dCATb = {"dec3": self.dCAT, "dec2": buf(B * H * W // 4 * 256), "dec1": buf(B * H * W // 16 * 512)}
+            self.dTMPb = {"dec3": self.dTMPc, "dec2": buf(B * H * W // 16 * 128), "dec1": buf(B * H * W // 64 * 256)}
         self.zero_bias = torch.zeros(1024, dtype=torch.float32, device=dev)
         self._bn_bias_zeroed = set()                              # see _zero_bn_bias
         self.wgrad_leave_room = True         # 3x3 weight gradients on a side stream: one block per CU (himo_conv3x3_wgrad_batch flags bit 2)
@@ -596,6 +628,7 @@ class SeFlowTrainer:
         self.bn_mean = torch.zeros((len(self.layers), 256), dtype=torch.float32, device=dev)
         self.bn_invstd = torch.zeros((len(self.layers), 256), dtype=torch.float32, device=dev)
         self.pfn_scale, self.pfn_shift, self.pfn_mean, self.pfn_invstd = (torch.zeros((F, 32), dtype=torch.float32, device=dev) for _ in range(4))
+        self._dres = [None] * B                                  # the loss gradients a backward pass reads (kept alive until it has finished)
         self._bn_folded = True                                   # net.p[*.scale / *.shift] match the running statistics
         # split-bf16 copies of the convolution weights (forward) and a scratch for the flipped ones (data gradient)
         self.packed = {}
@@ -616,7 +649,8 @@ class SeFlowTrainer:
                 jobs.append((self.p[k], ks, cin, cout, self.fwd_format, 0, buf))
                 jobs.append((self.p[k], ks, cin, cout, self.bwd3_format, 1, self.packed_flip[k]))
             jobs += self.head.weight_jobs()
-            self.head.external_pack = True
+            for h_ in self.heads:
+                h_.external_pack = True
             table = np.zeros(len(jobs), dtype=np.dtype([("w", "<u8"), ("packed", "<u8"), ("ksize", "<i4"), ("cin", "<i4"), ("cout", "<i4"),
                                                         ("format", "<i4"), ("flip", "<i4"), ("first_block", "<i4")]))   # himo_weight_job
             blocks = 0
@@ -717,18 +751,23 @@ class SeFlowTrainer:
         _lib.check(self.lib.himo_conv3x3_wgrad(x, x_pitch, h, w, cin, dy, dy_pitch, cout, stride, self.g[gname].data_ptr(),
                                                1 if acc else 0, ws.data_ptr(), ws.numel(), _lib.stream_handle()), "conv3x3_wgrad")
 
-    def _wgrad3_bias(self, x, x_pitch, h, w, cin, dy, dy_pitch, cout, wname, bname, ws=None):
-        """stride-1 3x3 weight gradient AND the bias gradient (column sums of dY) of one image: one pass over dY in the split-bf16
-        kernel (mixed precision); the float32 kernels keep the separate column-sum launch"""
+    def _wgrad3_bias(self, n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, wname, bname, ws=None):
+        """stride-1 3x3 weight gradient AND the bias gradient (column sums of dY) over n images ([image][pixel][channel] maps): one
+        pass over dY in the split-bf16 kernel (mixed precision); the float32 kernels keep the separate column-sum launch"""
         w_ = self.ws if ws is None else ws
         if self.wgrad_flags & 2:
-            st = self.lib.himo_conv3x3_wgrad_batch_bias(1, x, 0, x_pitch, h, w, cin, dy, 0, dy_pitch, cout, 1, self.g[wname].data_ptr(),
+            st = self.lib.himo_conv3x3_wgrad_batch_bias(n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, 1, self.g[wname].data_ptr(),
                                                         self.g[bname].data_ptr(), self.wgrad_flags | self._beside_flag(ws), w_.data_ptr(), w_.numel(),
                                                         _lib.stream_handle())
             if st == 0:
                 return
-        self._wgrad3(x, x_pitch, h, w, cin, dy, dy_pitch, cout, 1, wname, False, ws=ws)
-        self._colsum(h * w, dy, dy_pitch, cout, bname, ws=ws)
+        if n == 1:
+            self._wgrad3(x, x_pitch, h, w, cin, dy, dy_pitch, cout, 1, wname, False, ws=ws)
+        else:
+            self._wgrad3_batch(n, x, x_bs, x_pitch, h, w, cin, dy, dy_bs, dy_pitch, cout, wname, ws=ws)
+        if n > 1 and (dy_bs != h * w * dy_pitch):
+            raise ValueError("bias gradient over a batch needs consecutive images")
+        self._colsum(n * h * w, dy, dy_pitch, cout, bname, ws=ws)
 
     def set_side_streams(self, on: bool):
         """switch the weight-gradient overlap (both side streams) off / back on at run time: the same kernels in the same order per
@@ -737,7 +776,8 @@ class SeFlowTrainer:
         otherwise includes whatever the other streams co-run)"""
         self.overlap_wgrad = bool(on) and self._side_streams_built
         self.overlap_decoder = self.overlap_wgrad and self.ws_side2 is not None
-        self.head.wgrad_stream = self.side2 if self.overlap_decoder else None
+        for h_ in self.heads:
+            h_.wgrad_stream = self.side2 if self.overlap_decoder else None
 
     def _beside(self, fn):
         """a decoder weight gradient: it only READS its operands, so it runs on the second side stream from the point the main stream
@@ -765,10 +805,10 @@ class SeFlowTrainer:
         _lib.check(self.lib.himo_colsum(rows, z, pitch, cout, self.g[gname].data_ptr(), 1 if acc else 0, ws.data_ptr(),
                                         ws.numel(), _lib.stream_handle()), "colsum")
 
-    def _wgrad1(self, rows, x, x_pitch, cin, dz, z_pitch, cout, name, ws=None):
+    def _wgrad1(self, rows, x, x_pitch, cin, dz, z_pitch, cout, name, ws=None, acc=False):
         ws = self.ws if ws is None else ws
         _lib.check(self.lib.himo_linear_wgrad_ex(rows, x, x_pitch, cin, dz, z_pitch, cout, self.g[f"{name}.weight"].data_ptr(),
-                                                 self.g[f"{name}.bias"].data_ptr(), self.wgrad_flags, ws.data_ptr(), ws.numel(),
+                                                 self.g[f"{name}.bias"].data_ptr(), self.wgrad_flags | (1 if acc else 0), ws.data_ptr(), ws.numel(),
                                                  _lib.stream_handle()), "linear_wgrad")
 
     def _flip(self, name, ks, cin, cout):
@@ -793,57 +833,106 @@ class SeFlowTrainer:
         self._bn_folded = True
 
     def forward(self, pch1, pc0, pc1, pose_h1, pose0, pose1, training: bool = True, after_pillarize=None) -> torch.Tensor:
-        """``training`` (only meaningful with batchnorm="batch"): True normalises with batch statistics, saves them for
-        ``backward`` and moves the running statistics; False (validation) uses the running statistics."""
+        """One sample (``forward_batch`` with a batch of one): res [n0, 4]."""
+        return self.forward_batch([(pch1, pc0, pc1, pose_h1, pose0, pose1)], training=training, after_pillarize=after_pillarize)[0]
+
+    def _pillar_stage(self, jobs, constants=None):
+        """The pillar stage for the sweeps of ``jobs`` = [(sample b, F sweeps, F transforms)]: image b * F + slot of the pixel-major
+        pillar-image buffer, up to 12 sweeps per launch group.  ``constants`` = (scale, shift) [n sweeps][32]: the feature kernel
+        ALONE with per-sweep BatchNorm constants (the cell lists are those of the pass that ran before)."""
+        net, lib, F = self.net, self.lib, self.net.F
+        from .model import HimoSweep, _f32x
+        pitch = 32 * F * self.B
+        flat = [(b, slot, pts, T) for b, sweeps, transforms in jobs for slot, (pts, T) in enumerate(zip(sweeps, transforms))]
+        flags = (1 if net.split_acts else 0) | (2 if net.incremental_images else 0)
+        for lo in range(0, len(flat), net.MAX_SWEEPS):
+            grp = flat[lo:lo + net.MAX_SWEEPS]
+            arr = (HimoSweep * len(grp))()
+            for j, (b, slot, pts, T) in enumerate(grp):
+                st, w = net._pt[b], arr[j]
+                w.n, w.d_pts, w.pc_stride = pts.shape[0], pts.data_ptr(), pts.shape[1]
+                w.transform = _f32x(np.asarray(T, dtype=np.float32).reshape(-1))
+                w.d_xyz_t, w.d_pid, w.d_offsets = st["xyz_t"][slot].data_ptr(), st["pid"][slot].data_ptr(), st["offsets"][slot].data_ptr()
+                w.d_image = self.B0p + 4 * 32 * (b * F + slot)
+                w.d_workspace = st["ws_slots"][slot].data_ptr()
+            ws_bytes = net._pt[0]["ws_slots"][0].numel()
+            if constants is None:
+                _lib.check(lib.himo_pillarize_multi_ex(len(arr), ctypes.addressof(arr), net._range, net._voxel, net._centre, net.W, net.H,
+                                                       self.p["pfn.weight"].data_ptr(), net.p["pfn.scale"].data_ptr(), net.p["pfn.shift"].data_ptr(),
+                                                       pitch, ws_bytes, flags, _lib.stream_handle()), "himo_pillarize_multi_ex")
+            else:
+                _lib.check(lib.himo_pillar_features_multi(len(arr), ctypes.addressof(arr), net._range, net._voxel, net._centre, net.W, net.H,
+                                                          self.p["pfn.weight"].data_ptr(), constants[0].data_ptr() + 4 * 32 * lo,
+                                                          constants[1].data_ptr() + 4 * 32 * lo, pitch, ws_bytes, flags, _lib.stream_handle()),
+                           "himo_pillar_features_multi")
+
+    def _per_sweep(self, t: torch.Tensor) -> torch.Tensor:
+        """[F][32] constants of the frame slots -> one row per sweep of the batch (sweep b * F + f takes row f)"""
+        return t if self.nb == 1 else t.repeat(self.nb, 1)
+
+    def forward_batch(self, samples, training: bool = True, after_pillarize=None) -> list:
+        """``samples``: 1 .. ``batch`` tuples (pch1, pc0, pc1, pose_h1, pose0, pose1) -> [res [n0_b, 4]] per sample (columns 0..2 =
+        network flow of the pc0 rows, column 3 = 0).  ``training`` (only meaningful with batchnorm="batch"): True normalises with
+        the statistics of THIS batch (all its sweeps per frame slot in the pillar net, all its images in the encoder), saves them
+        for the backward pass and moves the running statistics; False (validation) uses the running statistics."""
         net, lib, s = self.net, self.lib, _lib.stream_handle
         dev = self.device
+        nb = len(samples)
+        if not 1 <= nb <= self.B:
+            raise ValueError(f"forward_batch takes 1..{self.B} samples (SeFlowTrainer(batch=...))")
+        self.nb = nb
         batch = self.bn_batch and training
         self._fwd_batch = batch
         self._bn_fwd_from_x = self.bn_from_x                    # what THIS forward pass leaves in PRE (read by backward)
         if self.bn_batch and not training and not self._bn_folded:
             self.fold_batchnorm()
         to_dev = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))).to(dev, torch.float32).contiguous()
-        pch1, pc0, pc1 = to_dev(pch1), to_dev(pc0), to_dev(pc1)
-        inv1 = np.linalg.inv(np.asarray(pose1, np.float64))
-        self.n_pts = [pch1.shape[0], pc0.shape[0], pc1.shape[0]]
-        sweeps = (pch1, pc0, pc1)
-        transforms = (inv1 @ np.asarray(pose_h1, np.float64), inv1 @ np.asarray(pose0, np.float64), np.eye(4))
-        net.pillarize_all(sweeps, transforms)
-        if after_pillarize is not None:                          # the sweeps are in the common frame (net.xyz_t): input-only work may start
+        jobs, self.n_pts_b = [], []
+        for b_, (pch1, pc0, pc1, pose_h1, pose0, pose1) in enumerate(samples):
+            pch1, pc0, pc1 = to_dev(pch1), to_dev(pc0), to_dev(pc1)
+            inv1 = np.linalg.inv(np.asarray(pose1, np.float64))
+            jobs.append((b_, (pch1, pc0, pc1), (inv1 @ np.asarray(pose_h1, np.float64), inv1 @ np.asarray(pose0, np.float64), np.eye(4))))
+            self.n_pts_b.append([pch1.shape[0], pc0.shape[0], pc1.shape[0]])
+            for t in (pch1, pc0, pc1):
+                net._reserve_points(t.shape[0])
+        self.n_pts = self.n_pts_b[0]
+        self._fwd_jobs = jobs                                    # (keeps the converted sweeps alive until the next pass)
+        self._pillar_stage(jobs)
+        if after_pillarize is not None:                          # the sweeps are in the common frame (net._pt[b]["xyz_t"]): input-only work may start
             after_pillarize()
-        F = net.F
+        F, B = net.F, self.B
+        NI = nb * F                                              # images the encoder's launches run over
         if batch:
-            # the pass above left every sweep's cell lists (its images were written with stale constants): batch statistics of
-            # each sweep -- one call of the embedder each, in call order for the running estimate -- then the feature kernel
-            # again with per-sweep constants
+            # the pass above left every sweep's cell lists (its images were written with stale constants): batch statistics of each
+            # frame slot over the batch's sweeps -- one call of the embedder per slot, in slot order for the running estimate --
+            # then the feature kernel again with the slot's constants
             self._bn_folded = False
             g, b = net.p["pfn.bn.gamma"].data_ptr(), net.p["pfn.bn.beta"].data_ptr()
             rm, rv = net.p["pfn.bn.mean"].data_ptr(), net.p["pfn.bn.var"].data_ptr()
             ns, xs, wss = self._pfn_sweep_arrays()
-            _lib.check(lib.himo_pfn_bn_stats_multi(F, ns, xs, wss, net._voxel, net._centre, net.W, net.H, self.p["pfn.weight"].data_ptr(),
-                                                   g, b, spec.BN_EPS_PFN, BN_MOMENTUM, rm, rv, self.pfn_scale.data_ptr(),
-                                                   self.pfn_shift.data_ptr(), self.pfn_mean.data_ptr(), self.pfn_invstd.data_ptr(),
-                                                   self.ws.data_ptr(), self.ws.numel(), s()), "pfn_bn_stats_multi")
-            net.pillar_features(sweeps, transforms, self.pfn_scale, self.pfn_shift)
+            _lib.check(lib.himo_pfn_bn_stats_groups(NI, F, ns, xs, wss, net._voxel, net._centre, net.W, net.H, self.p["pfn.weight"].data_ptr(),
+                                                    g, b, spec.BN_EPS_PFN, BN_MOMENTUM, rm, rv, self.pfn_scale.data_ptr(),
+                                                    self.pfn_shift.data_ptr(), self.pfn_mean.data_ptr(), self.pfn_invstd.data_ptr(),
+                                                    self.ws.data_ptr(), self.ws.numel(), s()), "pfn_bn_stats_groups")
+            self._pillar_stage(jobs, constants=(self._per_sweep(self.pfn_scale), self._per_sweep(self.pfn_shift)))
         # encoder with saved activations
-        src, src_bs, src_pitch = net.B0.data_ptr(), 32, 32 * F
-        cat = {64: net.F1, 128: net.F2, 256: net.F3}
+        src, src_bs, src_pitch = self.B0p, 32, 32 * F * B
+        cat = {64: self.F1p, 128: self.F2p, 256: self.F3p}
         self.inputs = []
         for li, (name, cin, cout, stride, h, w, ho, wo, last) in enumerate(self.layers):
             self.inputs.append((src, src_bs, src_pitch))
             pre = self.PRE[li]
             pk = self.packed.get(f"{name}.weight")
             self._conv(src, src_bs, src_pitch, self.p[f"{name}.weight"].data_ptr(), self.p[f"{name}.bias"].data_ptr(),
-                       pre.data_ptr(), ho * wo * cout, cout, F, h, w, cin, cout, 3, stride, packed=None if pk is None else pk.data_ptr(),
+                       pre.data_ptr(), ho * wo * cout, cout, NI, h, w, cin, cout, 3, stride, packed=None if pk is None else pk.data_ptr(),
                        fmt=self.fwd_format)
             if last:
-                dst = cat[cout]
-                y_ptr, y_bs, y_pitch = dst.data_ptr(), cout, cout * F          # frames as channel groups of the concat buffer
+                y_ptr, y_bs, y_pitch = cat[cout], cout, cout * F * B          # images as channel groups of the concat buffer
             else:
                 y_ptr, y_bs, y_pitch = self.Y[li].data_ptr(), ho * wo * cout, cout
             if batch:                                            # PRE keeps the convolution's output x: the backward pass re-forms
                 pfx = f"{name}.bn"                               # xhat from it and the saved mean / invstd (himo_bn_train_bwd_x)
-                _lib.check(lib.himo_bn_train_fwd(F, ho * wo, cout, pre.data_ptr(), ho * wo * cout, cout, net.p[f"{pfx}.gamma"].data_ptr(),
+                _lib.check(lib.himo_bn_train_fwd(NI, ho * wo, cout, pre.data_ptr(), ho * wo * cout, cout, net.p[f"{pfx}.gamma"].data_ptr(),
                                                  net.p[f"{pfx}.beta"].data_ptr(), spec.BN_EPS, BN_MOMENTUM, net.p[f"{pfx}.mean"].data_ptr(),
                                                  net.p[f"{pfx}.var"].data_ptr(), self.bn_mean[li].data_ptr(), self.bn_invstd[li].data_ptr(),
                                                  None if self.bn_from_x else pre.data_ptr(), ho * wo * cout, cout, y_ptr, y_bs, y_pitch,
@@ -851,61 +940,107 @@ class SeFlowTrainer:
             else:                                                # PRE keeps the affine pre-activation
                 sc, sh = net.p[f"{name}.scale"].data_ptr(), net.p[f"{name}.shift"].data_ptr()
                 if last:
-                    for f in range(F):
-                        _lib.check(lib.himo_affine_gelu_fwd(ho * wo, cout, pre[f].data_ptr(), cout, sc, sh, pre[f].data_ptr(), cout,
-                                                            y_ptr + 4 * cout * f, y_pitch, s()), "affine_gelu_fwd")
+                    for i in range(NI):
+                        _lib.check(lib.himo_affine_gelu_fwd(ho * wo, cout, pre[i].data_ptr(), cout, sc, sh, pre[i].data_ptr(), cout,
+                                                            y_ptr + 4 * cout * i, y_pitch, s()), "affine_gelu_fwd")
                 else:
-                    _lib.check(lib.himo_affine_gelu_fwd(F * ho * wo, cout, pre.data_ptr(), cout, sc, sh, pre.data_ptr(), cout,
+                    _lib.check(lib.himo_affine_gelu_fwd(NI * ho * wo, cout, pre.data_ptr(), cout, sc, sh, pre.data_ptr(), cout,
                                                         y_ptr, cout, s()), "affine_gelu_fwd")
             src, src_bs, src_pitch = y_ptr, y_bs, y_pitch
-        net.decoder()
-        # head: gather -> GRU with saved states
-        n0 = pc0.shape[0]
-        self.n0 = n0
-        if self.precision != "f32" and n0 > 0:        # gather + GRU + decoder + row mask as one launch, states saved for backward
-            return self.head.forward_fused(n0, net.pid[1].data_ptr(), net.offsets[1].data_ptr(), net.B0.data_ptr() + 4 * 32,
-                                           net.B0.data_ptr() + 4 * 64, 32 * F, net.DEC.data_ptr(), 64,
-                                           self.p["head.offset.weight"].data_ptr(), self.p["head.offset.bias"].data_ptr())
-        hx0 = torch.empty((n0, 192), dtype=torch.float32, device=dev)
-        rhx = torch.empty((n0, 192), dtype=torch.float32, device=dev)
-        _lib.check(lib.himo_head_gather(n0, net.pid[1].data_ptr(), net.offsets[1].data_ptr(), net.B0.data_ptr() + 4 * 32,
-                                        net.B0.data_ptr() + 4 * 64, 32 * F, net.DEC.data_ptr(), 64,
-                                        self.p["head.offset.weight"].data_ptr(), self.p["head.offset.bias"].data_ptr(),
-                                        hx0.data_ptr(), rhx.data_ptr(), 192, s()), "himo_head_gather")
-        res = self.head.forward(hx0)
-        _lib.check(lib.himo_mask_rows(n0, 4, net.pid[1].data_ptr(), res.data_ptr(), 4, s()), "mask_rows")
-        return res
+        self._decoder_fwd()
+        # head: gather -> GRU with saved states, sample by sample (120k rows fill the device: nothing to gain from one launch)
+        H, W = net.H, net.W
+        out = []
+        self.n0_b = []
+        for b_, (_, (pch1, pc0, pc1), _) in enumerate(jobs):
+            st, head = net._pt[b_], self.heads[b_]
+            n0 = pc0.shape[0]
+            self.n0_b.append(n0)
+            img0, img1 = self.B0p + 4 * 32 * (b_ * F + 1), self.B0p + 4 * 32 * (b_ * F + 2)
+            dec = net.DEC.data_ptr() + 4 * b_ * H * W * 64
+            if self.precision != "f32" and n0 > 0:    # gather + GRU + decoder + row mask as one launch, states saved for backward
+                out.append(head.forward_fused(n0, st["pid"][1].data_ptr(), st["offsets"][1].data_ptr(), img0, img1, 32 * F * B, dec, 64,
+                                              self.p["head.offset.weight"].data_ptr(), self.p["head.offset.bias"].data_ptr()))
+                continue
+            hx0 = torch.empty((n0, 192), dtype=torch.float32, device=dev)
+            rhx = torch.empty((n0, 192), dtype=torch.float32, device=dev)
+            _lib.check(lib.himo_head_gather(n0, st["pid"][1].data_ptr(), st["offsets"][1].data_ptr(), img0, img1, 32 * F * B, dec, 64,
+                                            self.p["head.offset.weight"].data_ptr(), self.p["head.offset.bias"].data_ptr(),
+                                            hx0.data_ptr(), rhx.data_ptr(), 192, s()), "himo_head_gather")
+            res = head.forward(hx0)
+            _lib.check(lib.himo_mask_rows(n0, 4, st["pid"][1].data_ptr(), res.data_ptr(), 4, s()), "mask_rows")
+            out.append(res)
+        self.n0 = self.n0_b[0]
+        return out
+
+    def _fwd_conv(self, x, x_bs, x_pitch, name, y, y_bs, y_pitch, h, w, cin, cout, ks):
+        """a decoder layer of the forward pass over the batch's ``nb`` images"""
+        pk = self.packed.get(f"{name}.weight")
+        self._conv(x, x_bs, x_pitch, self.p[f"{name}.weight"].data_ptr(), self.p[f"{name}.bias"].data_ptr(), y, y_bs, y_pitch, self.nb, h, w,
+                   cin, cout, ks, 1, packed=None if pk is None else pk.data_ptr(), fmt=self.fwd_format)
+
+    def _decoder_fwd(self):
+        """pillar images + the three stage outputs (pixel-major, the batch's images as channel groups) -> DEC [sample][pixel][64];
+        every intermediate keeps its own [sample][pixel][channel] buffer of the network object (the backward pass reads them)."""
+        net, nb = self.net, self.nb
+        H, W, F, B = net.H, net.W, net.F, self.B
+        conv = self._fwd_conv
+
+        def block(name, coarse, coarse_bs, coarse_pitch, c_in, ch, cw, tmp, cat, skip, skip_c, lat, out, work):
+            Pc, P = ch * cw, 4 * ch * cw
+            conv(coarse, coarse_bs, coarse_pitch, f"{name}.u1", tmp.data_ptr(), Pc * lat, lat, 1, Pc, c_in, lat, 1)
+            _lib.check(self.lib.himo_upsample2x_batch_ex(nb, tmp.data_ptr(), Pc * lat if nb > 1 else 0, lat, ch, cw, lat, cat.data_ptr(),
+                                                         P * 2 * lat if nb > 1 else 0, 2 * lat, 0, _lib.stream_handle()), "himo_upsample2x_batch_ex")
+            conv(skip, skip_c, skip_c * B, f"{name}.u3", cat.data_ptr() + 4 * lat, P * 2 * lat, 2 * lat, 1, P, skip_c, lat, 1)
+            conv(cat.data_ptr(), P * 2 * lat, 2 * lat, f"{name}.u4", work[0].data_ptr(), P * out, out, 2 * ch, 2 * cw, 2 * lat, out, 3)
+            conv(work[0].data_ptr(), P * out, out, f"{name}.u5", work[1].data_ptr(), P * out, out, 2 * ch, 2 * cw, out, out, 3)
+            return work[1]
+        s_ = block("dec1", self.F3p, 256 * F, 256 * F * B, 256 * F, H // 8, W // 8, net.T1, net.CAT1, self.F2p, 128 * F, 256, 256, net.S)
+        t_ = block("dec2", s_.data_ptr(), (H // 4) * (W // 4) * 256, 256, 256, H // 4, W // 4, net.T2, net.CAT2, self.F1p, 64 * F, 128, 128, net.T)
+        u_ = block("dec3", t_.data_ptr(), (H // 2) * (W // 2) * 128, 128, 128, H // 2, W // 2, net.T3, net.CAT3, self.B0p, 32 * F, 64, 64, net.U)
+        conv(u_.data_ptr(), H * W * 64, 64, "dec4", net.DEC.data_ptr(), H * W * 64, 64, H, W, 64, 64, 3)
 
     # ---- backward ----------------------------------------------------------------------------------------------
-    def _block_bwd(self, name, coarse, c_in, ch, cw, skip, skip_c, lat, out, cat, work0, d_out, d_in, d_coarse, d_skip, skip_acc):
-        """UpsampleSkip block: d_out (gradient of its output, [P][out]) -> parameter gradients, d_coarse ([ch*cw][c_in]),
-        d_skip ([P][skip_c], added when ``skip_acc``).  ``d_in`` is scratch for the gradient of work[0]."""
+    def _block_bwd(self, name, coarse, coarse_bs, coarse_pitch, c_in, ch, cw, skip, skip_c, lat, out, cat, work0, d_out, d_in,
+                   d_coarse, dc_bs, dc_pitch, d_skip, skip_acc):
+        """UpsampleSkip block over the batch's ``nb`` images: d_out (gradient of its output, [image][P][out]) -> parameter gradients,
+        d_coarse ([ch*cw][c_in] per image: batch stride ``dc_bs``, pitch ``dc_pitch``), d_skip (pixel-major, the batch's images as
+        channel groups of ``skip_c`` channels; added when ``skip_acc``).  ``coarse`` / ``skip``: device addresses of the forward
+        pass's inputs (``skip`` in the pixel-major layout).  ``d_in`` is scratch for the gradient of work[0]."""
         lib, s = self.lib, _lib.stream_handle
+        nb, B = self.nb, self.B
         h2, w2 = 2 * ch, 2 * cw
-        P = h2 * w2
+        P, Pc = h2 * w2, ch * cw
         zb = self.zero_bias.data_ptr()
         if self.overlap_decoder:                                 # this block's own gradient buffers: its weight gradients read them later
             d_in = self.dIN[name].data_ptr()
         dcat = (self.dCATb[name] if self.overlap_decoder else self.dCAT).data_ptr()
         dtmp = (self.dTMPb[name] if self.overlap_decoder else self.dTMPc).data_ptr()
         # u5
-        self._beside(lambda ws: self._wgrad3_bias(work0.data_ptr(), out, h2, w2, out, d_out, out, out, f"{name}.u5.weight", f"{name}.u5.bias", ws=ws))
+        self._beside(lambda ws: self._wgrad3_bias(nb, work0.data_ptr(), P * out, out, h2, w2, out, d_out, P * out, out, out,
+                                                  f"{name}.u5.weight", f"{name}.u5.bias", ws=ws))
         wf, wp = self._flip(f"{name}.u5", 3, out, out)
-        self._conv(d_out, 0, out, wf, zb, d_in, 0, out, 1, h2, w2, out, out, 3, packed=wp)
+        self._conv(d_out, P * out, out, wf, zb, d_in, P * out, out, nb, h2, w2, out, out, 3, packed=wp)
         # u4
-        self._beside(lambda ws: self._wgrad3_bias(cat.data_ptr(), 2 * lat, h2, w2, 2 * lat, d_in, out, out, f"{name}.u4.weight", f"{name}.u4.bias", ws=ws))
+        self._beside(lambda ws: self._wgrad3_bias(nb, cat.data_ptr(), P * 2 * lat, 2 * lat, h2, w2, 2 * lat, d_in, P * out, out, out,
+                                                  f"{name}.u4.weight", f"{name}.u4.bias", ws=ws))
         wf, wp = self._flip(f"{name}.u4", 3, 2 * lat, out)
-        self._conv(d_in, 0, out, wf, zb, dcat, 0, 2 * lat, 1, h2, w2, out, 2 * lat, 3, packed=wp)
-        # u3 (1x1 on the skip): gradient rows are the right half of dCAT
-        self._beside(lambda ws: self._wgrad1(P, skip.data_ptr(), skip_c, skip_c, dcat + 4 * lat, 2 * lat, lat, f"{name}.u3", ws=ws))
+        self._conv(d_in, P * out, out, wf, zb, dcat, P * 2 * lat, 2 * lat, nb, h2, w2, out, 2 * lat, 3, packed=wp)
+        # u3 (1x1 on the skip): gradient rows are the right half of dCAT; the skip rows of sample b are its channel groups of the
+        # pixel-major map -- one product per sample, the later ones added to the first
+        def u3_weight_gradient(ws):
+            for b_ in range(nb):
+                self._wgrad1(P, skip + 4 * skip_c * b_, skip_c * B, skip_c, dcat + 4 * (b_ * P * 2 * lat + lat), 2 * lat, lat, f"{name}.u3", ws=ws,
+                             acc=b_ > 0)
+        self._beside(u3_weight_gradient)
         wt, wp = self._flip(f"{name}.u3", 1, skip_c, lat)                   # [lat][skip_c]
 
         def skip_gradient(tmp):
-            if skip_acc:
-                self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, tmp, 0, skip_c, 1, 1, P, lat, skip_c, 1, packed=wp)
-                self._add2d(P, skip_c, tmp, skip_c, d_skip, skip_c)
+            if skip_acc:                                         # (tmp: pixel-major like d_skip)
+                self._conv(dcat + 4 * lat, P * 2 * lat, 2 * lat, wt, zb, tmp, skip_c, skip_c * B, nb, 1, P, lat, skip_c, 1, packed=wp)
+                self._add2d(P, skip_c * nb, tmp, skip_c * B, d_skip, skip_c * B)
             else:
-                self._conv(dcat + 4 * lat, 0, 2 * lat, wt, zb, d_skip, 0, skip_c, 1, 1, P, lat, skip_c, 1, packed=wp)
+                self._conv(dcat + 4 * lat, P * 2 * lat, 2 * lat, wt, zb, d_skip, skip_c, skip_c * B, nb, 1, P, lat, skip_c, 1, packed=wp)
         if self.overlap_decoder and self.precision != "f32":     # (float32: _flip's ONE scratch for flipped weights is rewritten by the next layer)
             # the skip connection's gradient is not on the chain (the encoder's backward pass reads it much later): third side
             # stream, own scratch; backward() waits for the three events before the encoder loop touches a skip gradient
@@ -920,40 +1055,59 @@ class SeFlowTrainer:
         else:
             skip_gradient(self.TMP.data_ptr())
         # upsample, u1 (1x1 on the coarse map)
-        _lib.check(lib.himo_upsample2x_bwd(dcat, 2 * lat, ch, cw, lat, dtmp, lat, s()), "upsample2x_bwd")
-        self._beside(lambda ws: self._wgrad1(ch * cw, coarse.data_ptr(), c_in, c_in, dtmp, lat, lat, f"{name}.u1", ws=ws))
+        for b_ in range(nb):
+            _lib.check(lib.himo_upsample2x_bwd(dcat + 4 * b_ * P * 2 * lat, 2 * lat, ch, cw, lat, dtmp + 4 * b_ * Pc * lat, lat, s()), "upsample2x_bwd")
+        if coarse_bs == Pc * c_in and coarse_pitch == c_in:      # the coarse maps of the batch are consecutive rows: one product
+            self._beside(lambda ws: self._wgrad1(nb * Pc, coarse, c_in, c_in, dtmp, lat, lat, f"{name}.u1", ws=ws))
+        else:                                                    # (dec1: the coarse map is the pixel-major stage output)
+            def u1_weight_gradient(ws):
+                for b_ in range(nb):
+                    self._wgrad1(Pc, coarse + 4 * coarse_bs * b_, coarse_pitch, c_in, dtmp + 4 * b_ * Pc * lat, lat, lat, f"{name}.u1", ws=ws, acc=b_ > 0)
+            self._beside(u1_weight_gradient)
         wt, wp = self._flip(f"{name}.u1", 1, c_in, lat)
-        self._conv(dtmp, 0, lat, wt, zb, d_coarse, 0, c_in, 1, 1, ch * cw, lat, c_in, 1, packed=wp)
+        self._conv(dtmp, Pc * lat, lat, wt, zb, d_coarse, dc_bs, dc_pitch, nb, 1, Pc, lat, c_in, 1, packed=wp)
 
     def backward(self, dres: torch.Tensor):
-        """dres [n0,4] = d loss / d res.  Gradients of every trainable tensor land in ``self.flat_g``."""
+        """One sample (``backward_batch`` after a ``forward`` of one sample)."""
+        return self.backward_batch([dres])
+
+    def backward_batch(self, dres_list):
+        """``dres_list[b]`` [n0_b, 4] = d loss / d res of sample b of the last ``forward_batch``.  The gradients of every trainable
+        tensor -- of the SUM of the samples' losses -- land in ``self.flat_g``."""
         net, lib, s = self.net, self.lib, _lib.stream_handle
-        H, W, F, n0 = net.H, net.W, net.F, self.n0
-        dres = dres.contiguous().clone()
-        _lib.check(lib.himo_mask_rows(n0, 4, net.pid[1].data_ptr(), dres.data_ptr(), 4, s()), "mask_rows")
-        dhx0 = self.head.backward(dres)
-        # offset embedding x = offsets @ W + b
-        self._beside(lambda ws: _lib.check(lib.himo_linear_wgrad_ex(n0, net.offsets[1].data_ptr(), 3, 3, dhx0.data_ptr() + 4 * 128, 192, 64,
-                                                                    self.g["head.offset.weight"].data_ptr(), self.g["head.offset.bias"].data_ptr(), 0,
-                                                                    ws.data_ptr(), ws.numel(), s()), "offset wgrad"))
-        # gather adjoint: per-point rows -> image gradients (pc0 is slot 1; it gathers from groups 1 and 2 and from DEC)
-        _lib.check(lib.himo_head_scatter(n0, W, H, net.ws_slots[1].data_ptr(), dhx0.data_ptr(), 192, self.dB0.data_ptr(), 32 * F,
-                                         1, 2, F, self.dDEC.data_ptr(), 64, s()), "head_scatter")
+        H, W, F, B, nb = net.H, net.W, net.F, self.B, self.nb
+        if len(dres_list) != nb:
+            raise ValueError(f"backward_batch: {len(dres_list)} gradients for the {nb} samples of the last forward pass")
+        NI = nb * F
+        for b_ in range(nb):
+            st, head, n0 = net._pt[b_], self.heads[b_], self.n0_b[b_]
+            dres = self._dres[b_] = dres_list[b_].contiguous().clone()
+            _lib.check(lib.himo_mask_rows(n0, 4, st["pid"][1].data_ptr(), dres.data_ptr(), 4, s()), "mask_rows")
+            head.accumulate = b_ > 0
+            dhx0 = head.backward(dres)
+            # offset embedding x = offsets @ W + b
+            self._beside(lambda ws, n0=n0, st=st, dhx0=dhx0, acc=1 if b_ > 0 else 0: _lib.check(lib.himo_linear_wgrad_ex(
+                n0, st["offsets"][1].data_ptr(), 3, 3, dhx0.data_ptr() + 4 * 128, 192, 64, self.g["head.offset.weight"].data_ptr(),
+                self.g["head.offset.bias"].data_ptr(), acc, ws.data_ptr(), ws.numel(), s()), "offset wgrad"))
+            # gather adjoint: per-point rows -> image gradients (pc0 is slot 1; it gathers from groups 1 and 2 of its sample and from DEC)
+            _lib.check(lib.himo_head_scatter(n0, W, H, st["ws_slots"][1].data_ptr(), dhx0.data_ptr(), 192, self.dB0.data_ptr() + 4 * 32 * F * b_,
+                                             32 * F * B, 1, 2, F, self.dDEC.data_ptr() + 4 * b_ * H * W * 64, 64, s()), "head_scatter")
         zb = self.zero_bias.data_ptr()
+        P, P2, P4, P8 = H * W, (H // 2) * (W // 2), (H // 4) * (W // 4), (H // 8) * (W // 8)
         # dec4
         u = net.U[1]
-        self._beside(lambda ws: self._wgrad3_bias(u.data_ptr(), 64, H, W, 64, self.dDEC.data_ptr(), 64, 64, "dec4.weight", "dec4.bias", ws=ws))
+        self._beside(lambda ws: self._wgrad3_bias(nb, u.data_ptr(), P * 64, 64, H, W, 64, self.dDEC.data_ptr(), P * 64, 64, 64, "dec4.weight", "dec4.bias", ws=ws))
         d_u = self.dWORK[0].data_ptr()
         wf, wp = self._flip("dec4", 3, 64, 64)
-        self._conv(self.dDEC.data_ptr(), 0, 64, wf, zb, d_u, 0, 64, 1, H, W, 64, 64, 3, packed=wp)
+        self._conv(self.dDEC.data_ptr(), P * 64, 64, wf, zb, d_u, P * 64, 64, nb, H, W, 64, 64, 3, packed=wp)
         # decoder blocks, last to first
         d_t, d_s = self.dCO[0].data_ptr(), self.dCO[1].data_ptr()
-        self._block_bwd("dec3", net.T[1], 128, H // 2, W // 2, net.B0, 32 * F, 64, 64, net.CAT3, net.U[0], d_u, self.dWORK[1].data_ptr(),
-                        d_t, self.dB0.data_ptr(), True)
-        self._block_bwd("dec2", net.S[1], 256, H // 4, W // 4, net.F1, 64 * F, 128, 128, net.CAT2, net.T[0], d_t, self.dWORK[1].data_ptr(),
-                        d_s, self.dF1.data_ptr(), False)
-        self._block_bwd("dec1", net.F3, 256 * F, H // 8, W // 8, net.F2, 128 * F, 256, 256, net.CAT1, net.S[0], d_s, self.dWORK[1].data_ptr(),
-                        self.dF3.data_ptr(), self.dF2.data_ptr(), False)
+        self._block_bwd("dec3", net.T[1].data_ptr(), P2 * 128, 128, 128, H // 2, W // 2, self.B0p, 32 * F, 64, 64, net.CAT3, net.U[0], d_u,
+                        self.dWORK[1].data_ptr(), d_t, P2 * 128, 128, self.dB0.data_ptr(), True)
+        self._block_bwd("dec2", net.S[1].data_ptr(), P4 * 256, 256, 256, H // 4, W // 4, self.F1p, 64 * F, 128, 128, net.CAT2, net.T[0], d_t,
+                        self.dWORK[1].data_ptr(), d_s, P4 * 256, 256, self.dF1.data_ptr(), False)
+        self._block_bwd("dec1", self.F3p, 256 * F, 256 * F * B, 256 * F, H // 8, W // 8, self.F2p, 128 * F, 256, 256, net.CAT1, net.S[0], d_s,
+                        self.dWORK[1].data_ptr(), self.dF3.data_ptr(), 256 * F, 256 * F * B, self.dF2.data_ptr(), False)
         # encoder, last layer to first
         dcat = {256: self.dF3, 128: self.dF2, 64: self.dF1, 32: self.dB0}
         dy = None
@@ -970,24 +1124,24 @@ class SeFlowTrainer:
                 main.wait_event(side_done.pop(li + 2))
             if self._fwd_batch:                                  # through GELU and the batch statistics; also d gamma / d beta
                 pfx = f"{name}.bn"
-                dy_ptr, dy_bs, dy_pitch = (dcat[cout].data_ptr(), cout, cout * F) if last else (dy, ho * wo * cout, cout)
+                dy_ptr, dy_bs, dy_pitch = (dcat[cout].data_ptr(), cout, cout * F * B) if last else (dy, ho * wo * cout, cout)
                 if not self._bn_fwd_from_x:                      # PRE holds xhat (a forward pass with bn_from_x off)
-                    _lib.check(lib.himo_bn_train_bwd(F, ho * wo, cout, dy_ptr, dy_bs, dy_pitch, pre.data_ptr(), ho * wo * cout, cout,
+                    _lib.check(lib.himo_bn_train_bwd(NI, ho * wo, cout, dy_ptr, dy_bs, dy_pitch, pre.data_ptr(), ho * wo * cout, cout,
                                                      net.p[f"{pfx}.gamma"].data_ptr(), net.p[f"{pfx}.beta"].data_ptr(), self.bn_invstd[li].data_ptr(),
                                                      dp, ho * wo * cout, cout, self.g[f"{pfx}.gamma"].data_ptr(), self.g[f"{pfx}.beta"].data_ptr(),
                                                      0, self.ws.data_ptr(), self.ws.numel(), s()), "bn_train_bwd")
                 else:
-                    _lib.check(lib.himo_bn_train_bwd_x(F, ho * wo, cout, dy_ptr, dy_bs, dy_pitch, pre.data_ptr(), ho * wo * cout, cout,
+                    _lib.check(lib.himo_bn_train_bwd_x(NI, ho * wo, cout, dy_ptr, dy_bs, dy_pitch, pre.data_ptr(), ho * wo * cout, cout,
                                                        net.p[f"{pfx}.gamma"].data_ptr(), net.p[f"{pfx}.beta"].data_ptr(), self.bn_mean[li].data_ptr(),
                                                        self.bn_invstd[li].data_ptr(), dp, ho * wo * cout, cout, self.g[f"{pfx}.gamma"].data_ptr(),
                                                        self.g[f"{pfx}.beta"].data_ptr(), 0, self.ws.data_ptr(), self.ws.numel(), s()), "bn_train_bwd_x")
             elif last:                                           # gradient arrives in the concat layout
                 src = dcat[cout]
-                for f in range(F):
-                    _lib.check(lib.himo_affine_gelu_bwd(ho * wo, cout, src.data_ptr() + 4 * cout * f, cout * F, pre[f].data_ptr(), cout, sc,
-                                                        dp + 4 * f * ho * wo * cout, cout, s()), "affine_gelu_bwd")
+                for i in range(NI):
+                    _lib.check(lib.himo_affine_gelu_bwd(ho * wo, cout, src.data_ptr() + 4 * cout * i, cout * F * B, pre[i].data_ptr(), cout, sc,
+                                                        dp + 4 * i * ho * wo * cout, cout, s()), "affine_gelu_bwd")
             else:
-                _lib.check(lib.himo_affine_gelu_bwd(F * ho * wo, cout, dy, cout, pre.data_ptr(), cout, sc, dp, cout, s()), "affine_gelu_bwd")
+                _lib.check(lib.himo_affine_gelu_bwd(NI * ho * wo, cout, dy, cout, pre.data_ptr(), cout, sc, dp, cout, s()), "affine_gelu_bwd")
             # a bias in front of a training-mode BatchNorm has exactly zero gradient (the batch mean absorbs it); the column sums
             # of dp would be rounding noise that Adam's normalisation turns into full-size random steps.  Nothing ever writes
             # these entries of flat_g in batch mode -- but a backward() after a frozen-statistics forward does (the branch
@@ -1001,77 +1155,71 @@ class SeFlowTrainer:
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(ready)
                     if not self._fwd_batch:
-                        self._colsum(F * ho * wo, dp, cout, cout, f"{name}.bias", ws=self.ws_side)
-                    self._wgrad3_batch(F, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride, ws=self.ws_side)
+                        self._colsum(NI * ho * wo, dp, cout, cout, f"{name}.bias", ws=self.ws_side)
+                    self._wgrad3_batch(NI, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride, ws=self.ws_side)
                     side_done[li] = torch.cuda.Event()
                     side_done[li].record(self.side)
                 if self._fwd_batch:
                     self._zero_bn_bias(name)
             else:
                 if not self._fwd_batch:
-                    self._colsum(F * ho * wo, dp, cout, cout, f"{name}.bias")
+                    self._colsum(NI * ho * wo, dp, cout, cout, f"{name}.bias")
                 else:
                     self._zero_bn_bias(name)
-                self._wgrad3_batch(F, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride)
+                self._wgrad3_batch(NI, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride)
             wf, wp = self._flip(name, 3, cin, cout)
             if stride == 2:
                 dst = dcat[cin]                                  # fan-in: add to the decoder's skip gradient
-                if self.bwd3_format == 2 and self.stuffed_dgrad:
-                    # ... in the convolution's own epilogue (frames = channel groups of dst), and the convolution reads dp as its own
+                if self.bwd3_format == 2 and self.stuffed_dgrad and h % 2 == 0 and w % 2 == 0:
+                    # ... in the convolution's own epilogue (images = channel groups of dst), and the convolution reads dp as its own
                     # zero-stuffed image: no stuffed copy is written or read, and the all-zero rows cost no matrix instructions
-                    self._conv(dp, ho * wo * cout, cout, wf, zb, dst.data_ptr(), cin, cin * F, F, h, w, cout, cin, 3, packed=wp, accumulate=True,
+                    self._conv(dp, ho * wo * cout, cout, wf, zb, dst.data_ptr(), cin, cin * F * B, NI, h, w, cout, cin, 3, packed=wp, accumulate=True,
                                stuffed=True)
                     continue
-                z = self.Z.data_ptr()
-                _lib.check(lib.himo_zero_stuff2x(F, ho, wo, cout, dp, ho * wo * cout, cout, z, h * w * cout, cout, s()), "zero_stuff")
+                if self._Z is None:                              # (the fallback: a zero-stuffed copy of dY first)
+                    self._Z = torch.empty(B * F * H * W * 64, dtype=torch.float32, device=self.device)
+                z = self._Z.data_ptr()
+                _lib.check(lib.himo_zero_stuff2x(NI, ho, wo, cout, dp, ho * wo * cout, cout, z, h * w * cout, cout, s()), "zero_stuff")
                 if self.bwd3_format == 2:
-                    self._conv(z, h * w * cout, cout, wf, zb, dst.data_ptr(), cin, cin * F, F, h, w, cout, cin, 3, packed=wp, accumulate=True)
+                    self._conv(z, h * w * cout, cout, wf, zb, dst.data_ptr(), cin, cin * F * B, NI, h, w, cout, cin, 3, packed=wp, accumulate=True)
                 else:
                     tmp = self.TMP.data_ptr()
-                    self._conv(z, h * w * cout, cout, wf, zb, tmp, h * w * cin, cin, F, h, w, cout, cin, 3, packed=wp)
-                    for f in range(F):
-                        self._add2d(h * w, cin, tmp + 4 * f * h * w * cin, cin, dst.data_ptr() + 4 * cin * f, cin * F)
+                    self._conv(z, h * w * cout, cout, wf, zb, tmp, h * w * cin, cin, NI, h, w, cout, cin, 3, packed=wp)
+                    for i in range(NI):
+                        self._add2d(h * w, cin, tmp + 4 * i * h * w * cin, cin, dst.data_ptr() + 4 * cin * i, cin * F * B)
             else:
                 nxt = self.dA.data_ptr() if dy != self.dA.data_ptr() else self.dB.data_ptr()
-                self._conv(dp, ho * wo * cout, cout, wf, zb, nxt, h * w * cin, cin, F, h, w, cout, cin, 3, packed=wp)
+                self._conv(dp, ho * wo * cout, cout, wf, zb, nxt, h * w * cin, cin, NI, h, w, cout, cin, 3, packed=wp)
                 dy = nxt
         # pillar feature net
-        if self._fwd_batch:                                      # the three sweeps' walks share their launches
+        if self._fwd_batch:                                      # the sweeps' walks share their launches; statistics per frame slot
             ns, xs, wss = self._pfn_sweep_arrays()
-            dimg = (ctypes.c_void_p * F)(*[self.dB0.data_ptr() + 4 * 32 * slot for slot in range(F)])
-            _lib.check(lib.himo_pfn_backward_bn_multi(F, ns, xs, wss, dimg, 32 * F, net._voxel, net._centre, W, H, self.p["pfn.weight"].data_ptr(),
-                                                      self.pfn_scale.data_ptr(), self.pfn_shift.data_ptr(), self.pfn_mean.data_ptr(),
-                                                      self.pfn_invstd.data_ptr(), self.g["pfn.weight"].data_ptr(),
-                                                      self.g["pfn.bn.gamma"].data_ptr(), self.g["pfn.bn.beta"].data_ptr(), 0,
-                                                      self.ws.data_ptr(), self.ws.numel(), s()), "pfn_backward_bn_multi")
-            main.wait_stream(self.side)                         # every gradient is in flat_g when this stream goes on
-            main.wait_stream(self.side2)
-            main.wait_stream(self.side3)
-            return
-        for slot in range(F):
-            if self._fwd_batch:
-                _lib.check(lib.himo_pfn_backward_bn(self.n_pts[slot], net._voxel, net._centre, W, H, self.p["pfn.weight"].data_ptr(),
-                                                    self.pfn_scale[slot].data_ptr(), self.pfn_shift[slot].data_ptr(),
-                                                    self.pfn_mean[slot].data_ptr(), self.pfn_invstd[slot].data_ptr(),
-                                                    net.xyz_t[slot].data_ptr(), net.ws_slots[slot].data_ptr(),
-                                                    self.dB0.data_ptr() + 4 * 32 * slot, 32 * F, self.g["pfn.weight"].data_ptr(),
-                                                    self.g["pfn.bn.gamma"].data_ptr(), self.g["pfn.bn.beta"].data_ptr(), 1 if slot else 0,
-                                                    self.ws.data_ptr(), self.ws.numel(), s()), "pfn_backward_bn")
-                continue
-            _lib.check(lib.himo_pfn_backward(self.n_pts[slot], net._voxel, net._centre, W, H, self.p["pfn.weight"].data_ptr(),
-                                             net.p["pfn.scale"].data_ptr(), net.p["pfn.shift"].data_ptr(), net.xyz_t[slot].data_ptr(),
-                                             net.ws_slots[slot].data_ptr(), self.dB0.data_ptr() + 4 * 32 * slot, 32 * F,
-                                             self.g["pfn.weight"].data_ptr(), 1 if slot else 0, self.ws.data_ptr(), self.ws.numel(), s()),
-                       "pfn_backward")
-        main.wait_stream(self.side)
+            dimg = (ctypes.c_void_p * NI)(*[self.dB0.data_ptr() + 4 * 32 * i for i in range(NI)])
+            _lib.check(lib.himo_pfn_backward_bn_groups(NI, F, ns, xs, wss, dimg, 32 * F * B, net._voxel, net._centre, W, H, self.p["pfn.weight"].data_ptr(),
+                                                       self.pfn_scale.data_ptr(), self.pfn_shift.data_ptr(), self.pfn_mean.data_ptr(),
+                                                       self.pfn_invstd.data_ptr(), self.g["pfn.weight"].data_ptr(),
+                                                       self.g["pfn.bn.gamma"].data_ptr(), self.g["pfn.bn.beta"].data_ptr(), 0,
+                                                       self.ws.data_ptr(), self.ws.numel(), s()), "pfn_backward_bn_groups")
+        else:
+            for i in range(NI):
+                b_, slot = divmod(i, F)
+                st = net._pt[b_]
+                _lib.check(lib.himo_pfn_backward(self.n_pts_b[b_][slot], net._voxel, net._centre, W, H, self.p["pfn.weight"].data_ptr(),
+                                                 net.p["pfn.scale"].data_ptr(), net.p["pfn.shift"].data_ptr(), st["xyz_t"][slot].data_ptr(),
+                                                 st["ws_slots"][slot].data_ptr(), self.dB0.data_ptr() + 4 * 32 * i, 32 * F * B,
+                                                 self.g["pfn.weight"].data_ptr(), 1 if i else 0, self.ws.data_ptr(), self.ws.numel(), s()),
+                           "pfn_backward")
+        main.wait_stream(self.side)                             # every gradient is in flat_g when this stream goes on
         main.wait_stream(self.side2)
         main.wait_stream(self.side3)
 
     def _pfn_sweep_arrays(self):
-        """host arrays of the sample's sweeps for the multi-sweep pillar-net calls: point counts, transformed points, pillar workspaces"""
-        net, F = self.net, self.net.F
-        return ((ctypes.c_int64 * F)(*self.n_pts), (ctypes.c_void_p * F)(*[net.xyz_t[k].data_ptr() for k in range(F)]),
-                (ctypes.c_void_p * F)(*[net.ws_slots[k].data_ptr() for k in range(F)]))
+        """host arrays of the batch's sweeps (sweep b * F + f) for the pillar-net calls: point counts, transformed points, pillar workspaces"""
+        net, F, nb = self.net, self.net.F, self.nb
+        n = nb * F
+        return ((ctypes.c_int64 * n)(*[self.n_pts_b[b][k] for b in range(nb) for k in range(F)]),
+                (ctypes.c_void_p * n)(*[net._pt[b]["xyz_t"][k].data_ptr() for b in range(nb) for k in range(F)]),
+                (ctypes.c_void_p * n)(*[net._pt[b]["ws_slots"][k].data_ptr() for b in range(nb) for k in range(F)]))
 
     # ---- optimiser / data parallel -----------------------------------------------------------------------------
     def sync_running_stats(self, src: int = 0):
@@ -1099,52 +1247,71 @@ class SeFlowTrainer:
         """Mean of the flat gradient over ranks: ONE collective per step (RCCL over xGMI)."""
         allreduce_mean_(self.flat_g)
 
-    def loss_and_grad(self, pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels: int | None = None):
-        """forward + self-supervised loss (himo_amd/ssl_loss.py; the flow it scores is the network's residual flow of
-        pc0 in pc1's frame) + backward: this sample's gradient lands in ``flat_g``.  Returns (terms, total)."""
+    def _loss_engine(self, b: int):
+        """sample slot b's loss engine (each keeps its own neighbour / count buffers: a batch's searches run ahead of its losses)"""
         from ..ssl_loss import SeFlowLoss
-        if not hasattr(self, "loss"):
-            self.loss = SeFlowLoss(device=self.device)
-        raw, hook, sizes = None, None, None
-        self._sizes = None
+        if not hasattr(self, "losses"):
+            self.losses = [SeFlowLoss(device=self.device) for _ in range(self.B)]
+            self.loss = self.losses[0]
+        return self.losses[b]
+
+    def loss_and_grad(self, pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels: int | None = None):
+        """One sample (``loss_and_grad_batch`` with a batch of one).  Returns (terms, total)."""
+        terms, totals = self.loss_and_grad_batch([(pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels)])
+        return terms[0], totals[0]
+
+    def loss_and_grad_batch(self, samples):
+        """forward over the batch + self-supervised loss per sample (himo_amd/ssl_loss.py; the flow it scores is the network's residual
+        flow of pc0 in pc1's frame) + backward: the gradient of the SUM of the samples' losses lands in ``flat_g``.  ``samples``: 1 ..
+        ``batch`` tuples (pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels).  Returns ([terms per sample], [total per
+        sample]) as 0-d float64 device tensors."""
+        samples = list(samples)
+        nb = len(samples)
+        engines = [self._loss_engine(b) for b in range(nb)]
+        hook = None
+        raws, sizes_all = [None] * nb, [None] * nb
         if self.overlap_decoder:
             # the cluster term's correspondences pc0 -> pc1 depend on the sweeps only: searched on the second side stream UNDER the
             # forward pass instead of between forward and backward (a grid build + a 120k-point query: ~0.17 ms of the chain)
             def hook():
-                m0, m1 = self.n_pts[1], self.n_pts[2]
                 ready = torch.cuda.Event()
                 ready.record(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self.side2):
                     self.side2.wait_event(ready)
-                    self._raw = self.loss.raw_neighbours(self.net.xyz_t[1][:m0], self.net.xyz_t[2][:m1])
-                    # ... and the sizes of the two dynamic subsets (labels only): counted here, read from pinned memory at the loss,
-                    # which then never blocks -- the host enqueues the backward pass while the forward pass is still running
-                    self._sizes = self.loss.dyn_sizes(label0, label1)
+                    for b in range(nb):
+                        m0, m1 = self.n_pts_b[b][1], self.n_pts_b[b][2]
+                        st = self.net._pt[b]
+                        raws[b] = engines[b].raw_neighbours(st["xyz_t"][1][:m0], st["xyz_t"][2][:m1])
+                        # ... and the sizes of the two dynamic subsets (labels only): counted here, read from pinned memory at the loss,
+                        # which then never blocks -- the host enqueues the backward pass while the forward pass is still running
+                        sizes_all[b] = engines[b].dyn_sizes(samples[b][6], samples[b][7])
                     self._raw_done = torch.cuda.Event()
                     self._raw_done.record(self.side2)
-        res = self.forward(pch1, pc0, pc1, pose_h1, pose0, pose1, after_pillarize=hook)
-        n0, n1 = self.n_pts[1], self.n_pts[2]
+        res = self.forward_batch([smp[:6] for smp in samples], after_pillarize=hook)
         if hook is not None:                                     # (the side stream's work, the converted labels of dyn_sizes included)
             torch.cuda.current_stream(self.device).wait_event(self._raw_done)
-            if n0 > 0 and n1 > 0:
-                raw = self._raw[:2]
-        if self._sizes is not None and n_labels is not None:
-            sizes, (label0, label1) = self._sizes[:2], self._sizes[2]
-        terms, total, grad = self.loss(self.net.xyz_t[1][:n0], self.net.xyz_t[2][:n1], res[:, :3].contiguous(), label0, label1, n_labels, raw=raw,
-                                       sizes=sizes)
-        dres = torch.zeros((n0, 4), dtype=torch.float32, device=self.device)
-        dres[:, :3] = grad
-        self.backward(dres)
-        return terms, total
+        terms_all, totals, dres_list = [], [], []
+        for b, smp in enumerate(samples):
+            label0, label1, n_labels = smp[6], smp[7], smp[8] if len(smp) > 8 else None
+            n0, n1 = self.n_pts_b[b][1], self.n_pts_b[b][2]
+            st = self.net._pt[b]
+            raw = raws[b][:2] if (raws[b] is not None and n0 > 0 and n1 > 0) else None
+            sizes = None
+            if sizes_all[b] is not None and n_labels is not None:
+                sizes, (label0, label1) = sizes_all[b][:2], sizes_all[b][2]
+            terms, total, grad = engines[b](st["xyz_t"][1][:n0], st["xyz_t"][2][:n1], res[b][:, :3].contiguous(), label0, label1, n_labels,
+                                            raw=raw, sizes=sizes)
+            dres = torch.zeros((n0, 4), dtype=torch.float32, device=self.device)
+            dres[:, :3] = grad
+            terms_all.append(terms); totals.append(total); dres_list.append(dres)
+        self.backward_batch(dres_list)
+        return terms_all, totals
 
     def loss_only(self, pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels: int | None = None):
         """forward + loss without a backward pass (validation): the total as a 0-d float64 device tensor"""
-        from ..ssl_loss import SeFlowLoss
-        if not hasattr(self, "loss"):
-            self.loss = SeFlowLoss(device=self.device)
         res = self.forward(pch1, pc0, pc1, pose_h1, pose0, pose1, training=False)
         n0, n1 = self.n_pts[1], self.n_pts[2]
-        _, total, _ = self.loss(self.net.xyz_t[1][:n0], self.net.xyz_t[2][:n1], res[:, :3].contiguous(), label0, label1, n_labels)
+        _, total, _ = self._loss_engine(0)(self.net.xyz_t[1][:n0], self.net.xyz_t[2][:n1], res[:, :3].contiguous(), label0, label1, n_labels)
         return total
 
     def train_step(self, pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels: int | None = None, lr: float = 6e-5):
@@ -1157,22 +1324,34 @@ class SeFlowTrainer:
         return terms, total
 
     def train_batch(self, samples, lr: float = 6e-5):
-        """One optimisation step on SEVERAL samples per rank (the launcher's ``batch_size=8`` on fewer than 8 GPUs):
-        ``samples`` = iterable of (pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels).  Every sample of the
-        GLOBAL batch weighs the same whatever the split over the ranks: each rank sums its per-sample gradients (and its
-        sample count and loss) in one flat buffer, ONE all-reduce adds the ranks, and the sum is divided by the global
-        count once.  A rank may hold no sample of a partial last batch -- it still enters the collective with zeros.
-        Returns the mean loss over the global batch (the same number on every rank)."""
+        """One optimisation step on SEVERAL samples per rank (the launcher's ``batch_size=8``): ``samples`` = iterable of (pch1, pc0,
+        pc1, pose_h1, pose0, pose1, label0, label1, n_labels).  They go through the network ``batch`` at a time (the constructor's
+        capacity: ONE forward / backward pass over up to that many samples, BatchNorm statistics over the pass's samples -- torch's
+        semantics for a per-process batch; with ``batch=1`` sample by sample, statistics per sample).  Every sample of the GLOBAL batch
+        weighs the same whatever the split over the ranks and passes: each rank sums its passes' gradients (and its sample count and
+        loss) in one flat buffer, ONE all-reduce adds the ranks, and the sum is divided by the global count once.  A rank may hold no
+        sample of a partial last batch -- it still enters the collective with zeros.  Returns the mean loss over the global batch
+        (the same number on every rank)."""
         n = self.flat_g.numel()
         if not hasattr(self, "flat_acc") or self.flat_acc.numel() != n + 2:
             self.flat_acc = torch.zeros(n + 2, dtype=self.flat_g.dtype, device=self.flat_g.device)   # [gradient sum | count | loss sum]
-        self.flat_acc.zero_()
         acc = self.flat_acc[:n]
-        for smp in samples:
-            _, total = self.loss_and_grad(*smp)
-            acc.add_(self.flat_g)
-            self.flat_acc[n] += 1.0
-            self.flat_acc[n + 1] += total.to(self.flat_acc.dtype)
+        it, passes = iter(samples), 0
+        while True:
+            chunk = list(itertools.islice(it, self.B))
+            if not chunk:
+                break
+            _, totals = self.loss_and_grad_batch(chunk)
+            if passes == 0:
+                self.flat_acc[n:].zero_()
+                acc.copy_(self.flat_g)
+            else:
+                acc.add_(self.flat_g)
+            passes += 1
+            self.flat_acc[n] += float(len(chunk))
+            self.flat_acc[n + 1] += torch.stack(totals).sum().to(self.flat_acc.dtype)
+        if passes == 0:
+            self.flat_acc.zero_()
         loss = combine_batch_(self.flat_acc, self.flat_g)
         self.adam_step(lr)
         return loss

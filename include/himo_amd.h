@@ -677,6 +677,21 @@ size_t himo_pfn_bn_workspace_bytes(void);
  * workspaces (and, backward, image-gradient bases); d_scale / d_shift / d_mean / d_invstd are [n_sweeps][32]; the running statistics
  * (forward) and d_dweight / d_dgamma / d_dbeta (backward) are updated sweep after sweep, so the results have the bits of n_sweeps single
  * calls.  Workspace: n_sweeps * himo_pfn_bn_workspace_bytes(). */
+/* ... and for the sweeps of a per-process BATCH (the reference launcher's batch_size=8 on one process, assets/slurm/ssl-train-av2.sh:32-34):
+ * sweep i belongs to GROUP i % n_groups, and a group shares ONE set of statistics -- with the sweeps ordered sample-major, frame-minor
+ * and n_groups = the frames per sample, group f is frame slot f of every sample: what one call of the pillar net on a batch of sweeps
+ * normalises over (torch.nn.BatchNorm1d on the concatenated points).  d_scale / d_shift / d_mean / d_invstd are [n_groups][32]; up to 16
+ * sweeps per group; the _multi forms are these with every sweep its own group.  Workspace: n_sweeps * himo_pfn_bn_workspace_bytes(). */
+int himo_pfn_bn_stats_groups(int n_sweeps, int n_groups, const int64_t* h_n, const float* const* h_xyz_t,
+                             const void* const* h_pillar_workspace, const float* h_voxel, const float* h_centre_offset, int grid_w,
+                             int grid_h, const float* d_pfn_weight, const float* d_gamma, const float* d_beta, float eps, float momentum,
+                             float* d_running_mean, float* d_running_var, float* d_scale, float* d_shift, float* d_mean, float* d_invstd,
+                             void* d_workspace, size_t workspace_bytes, void* stream);
+int himo_pfn_backward_bn_groups(int n_sweeps, int n_groups, const int64_t* h_n, const float* const* h_xyz_t,
+                                const void* const* h_pillar_workspace, const float* const* h_dimage, int image_pitch, const float* h_voxel,
+                                const float* h_centre_offset, int grid_w, int grid_h, const float* d_pfn_weight, const float* d_scale,
+                                const float* d_shift, const float* d_mean, const float* d_invstd, float* d_dweight, float* d_dgamma,
+                                float* d_dbeta, unsigned flags, void* d_workspace, size_t workspace_bytes, void* stream);
 int himo_pfn_bn_stats_multi(int n_sweeps, const int64_t* h_n, const float* const* h_xyz_t, const void* const* h_pillar_workspace,
                             const float* h_voxel, const float* h_centre_offset, int grid_w, int grid_h,
                             const float* d_pfn_weight, const float* d_gamma, const float* d_beta, float eps, float momentum,

@@ -195,3 +195,66 @@ def forward_train(params, pch1, pc0, pc1, pose_h1, pose0, pose1, training: bool 
     dec = backbone(params, imgs, training)
     res = head(params, img0, img1, dec, pid0[valid0], off0[valid0])
     return res, valid0, p0t
+
+
+def pillar_images_batch(params, sweeps, training: bool = False):
+    """The pillar net over a BATCH of sweeps in one call of the embedder (torch semantics of a per-process batch: the pillar net's
+    BatchNorm1d sees the in-range points of ALL the sweeps it is handed): per sweep (image (32,H,W), valid, pid, offsets).  With one
+    sweep this is ``pillar_image``."""
+    n_cells = GRID_H * GRID_W
+    vs = torch.tensor(VOXEL_SIZE, dtype=torch.float32)
+    off = torch.tensor([VOXEL_SIZE[0] / 2 + PC_RANGE[0], VOXEL_SIZE[1] / 2 + PC_RANGE[1], VOXEL_SIZE[2] / 2 + PC_RANGE[2]], dtype=torch.float32)
+    pre, ys = [], []
+    for xyz in sweeps:
+        valid, iy, ix = voxelize(xyz)
+        pid = iy * GRID_W + ix
+        pts, pv = xyz[valid], pid[valid]
+        cnt = torch.zeros(n_cells, dtype=torch.float32).index_add_(0, pv, torch.ones(len(pv)))
+        sums = torch.zeros(n_cells, 3, dtype=torch.float32).index_add_(0, pv, pts)
+        mean = sums[pv] / cnt[pv, None]
+        centre = torch.stack([ix[valid].float(), iy[valid].float(), torch.zeros(len(pv))], dim=1) * vs + off
+        feats = torch.cat([pts, pts - mean, pts - centre], dim=1)
+        ys.append(feats @ _t(params["pfn.weight"]))
+        pre.append((valid, pid, pv, cnt, pts - centre, xyz))
+    total = sum(len(y) for y in ys)
+    y_all = torch.relu(_batch_norm(params, "pfn.bn", torch.cat(ys, dim=0), BN_EPS_PFN, training and total > 0))
+    out, at = [], 0
+    for (valid, pid, pv, cnt, rel, xyz), y0 in zip(pre, ys):
+        y = y_all[at:at + len(y0)]
+        at += len(y0)
+        acc = torch.zeros(n_cells, y.shape[1], dtype=torch.float32).index_add_(0, pv, y)
+        img = (acc / cnt.clamp(min=1.0)[:, None]).T.reshape(-1, GRID_H, GRID_W).contiguous()
+        offsets = torch.zeros_like(xyz)
+        offsets[valid] = rel
+        out.append((img, valid, pid, offsets))
+    return out
+
+
+def forward_train_batch(params, samples, training: bool = False):
+    """``forward_train`` for a per-process BATCH (the reference launcher's ``batch_size=8`` on one GPU, assets/slurm/ssl-train-av2.sh:32-34):
+    ``samples`` = [(pch1, pc0, pc1, pose_h1, pose0, pose1), ...].  Training-mode BatchNorm takes its statistics over the WHOLE batch,
+    as torch does: the pillar net per embedder call -- the history sweeps of all samples, then their pc0s, then their pc1s (three
+    running-statistics updates, in that order) -- and every encoder layer over the B x F images (image b * F + f).  The decoder and
+    the head have no BatchNorm.  Returns [(res (n_valid,3), valid0, pc0 in pc1's frame)] per sample.  With one sample: ``forward_train``."""
+    slots = [[], [], []]
+    p0ts = []
+    for pch1, pc0, pc1, pose_h1, pose0, pose1 in samples:
+        p0 = _t(pc0)[:, :3].float()
+        T0, Th = ego_transform(pose0, pose1), ego_transform(pose_h1, pose1)
+        p0t = transform_points(p0, T0)
+        slots[0].append(transform_points(pch1, Th)); slots[1].append(p0t); slots[2].append(_t(pc1)[:, :3].float())
+        p0ts.append(p0t)
+    per_slot = [pillar_images_batch(params, sw, training) for sw in slots]            # call order: history, pc0, pc1
+    B, Fr = len(samples), len(slots)
+    imgs = torch.stack([per_slot[f][b][0] for b in range(B) for f in range(Fr)])      # (B * F, 32, H, W), image b * F + f
+    f1, f2, f3 = encoder(params, imgs, training)
+    cat = lambda t: t.reshape(B, -1, t.shape[2], t.shape[3])                          # a sample's frames stacked on channels
+    s = upsample_skip(params, "dec1", cat(f3), cat(f2))
+    t = upsample_skip(params, "dec2", s, cat(f1))
+    u = upsample_skip(params, "dec3", t, cat(imgs))
+    dec = _conv(params, "dec4", u)
+    out = []
+    for b in range(B):
+        img0, valid0, pid0, off0 = per_slot[1][b]
+        out.append((head(params, img0, per_slot[2][b][0], dec[b], pid0[valid0], off0[valid0]), valid0, p0ts[b]))
+    return out

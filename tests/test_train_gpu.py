@@ -315,6 +315,12 @@ def test_full_network_gradients_match_autograd(gpu, precision, n_points, batchno
     assert np.abs(res_gpu[v][:, :3] - ref_res.detach().numpy()).max() <= 1e-4
     assert np.all(res_gpu[~v] == 0)
     (ref_res * torch.from_numpy(G[v][:, :3])).sum().backward()
+    _compare_with_autograd(tr, params, P, got, batch, precision, f"{precision}/{n_points}/{batchnorm}")
+
+
+def _compare_with_autograd(tr, params, P, got, batch, precision, case):
+    """every trainable tensor's gradient in ``got`` against the autograd leaves of ``P`` (+ the running statistics in batch mode)"""
+    from himo_amd.seflow import spec
     ref = {k: P[k].grad.numpy() for k in P if P[k].grad is not None}
     pairs = {k: ref[k] for k in got if k in ref}
     pairs["head.zr.weight"] = np.concatenate([ref["head.gru.z.weight"], ref["head.gru.r.weight"]], 1)
@@ -334,17 +340,92 @@ def test_full_network_gradients_match_autograd(gpu, precision, n_points, batchno
             continue
         scale = max(np.abs(r).max(), 1e-12)
         worst[k] = np.abs(g - r).max() / scale
-    _record_margins(f"{precision}/{n_points}/{batchnorm}", worst)
+    _record_margins(case, worst)
     bad = {k: e for k, e in worst.items() if not e <= GRAD_BAR[precision]}
     assert not bad, bad
     if batch:
         # running statistics after ONE training-mode forward (momentum 0.1, unbiased variance; the pillar net's moved three
-        # times, once per sweep in call order) against torch's in-place updates of the oracle's tensors
+        # times, once per frame slot in call order) against torch's in-place updates of the oracle's tensors
         for prefix in ["pfn.bn"] + [f"{n}.bn" for n, *_ in spec.ENCODER]:
             for stat in ("mean", "var"):
                 mine, theirs = tr.net.p[f"{prefix}.{stat}"].cpu().numpy(), P[f"{prefix}.{stat}"].numpy()
                 assert not np.array_equal(theirs, params[f"{prefix}.{stat}"]), prefix          # it did move
                 assert np.abs(mine - theirs).max() <= 2e-5 * max(np.abs(theirs).max(), 1.0), (prefix, stat, np.abs(mine - theirs).max())
+
+
+@pytest.mark.parametrize("precision,n_points,batchnorm,B", [
+    ("mixed", 6000, "batch", 2), ("bf16x3", 6000, "batch", 2), ("f32", 6000, "batch", 2), ("mixed", 6000, "frozen", 3),
+    ("mixed", 120_000, "batch", 8)])
+def test_batched_pass_gradients_match_autograd(gpu, precision, n_points, batchnorm, B):
+    """a per-process BATCH as ONE pass (the launcher's ``batch_size=8``, assets/slurm/ssl-train-av2.sh:32-34) --
+    the encoder's launches over B x F images, the decoder's over B, BatchNorm statistics over the whole batch (pillar net: all the
+    batch's sweeps of a frame slot; encoder: all B x F images), as torch.nn.BatchNorm does -- against CPU autograd through the oracle's
+    batched network (``forward_train_batch``), for L = sum over the samples of sum(res_b * G_b): every trainable tensor's gradient, the
+    per-sample outputs and the running statistics.  B = 2 in the three arithmetics, B = 3 with frozen statistics, and B = 8 at BASELINE
+    size (8 x 3 x 120k points) in the training default; the samples differ in size."""
+    import oracle.seflow_oracle as so
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.train import SeFlowTrainer
+    params = spec.init_params(4)
+    samples = [_sample(n_points - 431 * b, seed=3 + b) for b in range(B)]
+    tr = SeFlowTrainer(params, device=gpu, max_points=n_points + 2000, precision=precision, batchnorm=batchnorm, batch=B)
+    res = tr.forward_batch(samples)
+    rng = np.random.default_rng(9)
+    Gs = []
+    for smp in samples:
+        G = np.zeros((len(smp[1]), 4), np.float32)
+        G[:, :3] = rng.normal(0, 1.0, (len(smp[1]), 3)).astype(np.float32)
+        Gs.append(G)
+    tr.backward_batch([torch.from_numpy(G).to(gpu) for G in Gs])
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in tr.g.items()}
+    res_gpu = [r.cpu().numpy() for r in res]
+    batch = batchnorm == "batch"
+    P = {k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    for k in P:
+        if k.endswith(".weight") or k.endswith(".bias") or (batch and (k.endswith(".gamma") or k.endswith(".beta"))):
+            P[k].requires_grad_(True)
+    outs = so.forward_train_batch(P, samples, training=batch)
+    total = 0.0
+    for (ref_res, valid, _), G, rg in zip(outs, Gs, res_gpu):
+        v = valid.numpy()
+        assert np.abs(rg[v][:, :3] - ref_res.detach().numpy()).max() <= 1e-4
+        assert np.all(rg[~v] == 0)
+        total = total + (ref_res * torch.from_numpy(G[v][:, :3])).sum()
+    total.backward()
+    _compare_with_autograd(tr, params, P, got, batch, precision, f"{precision}/{n_points}/{batchnorm}/batch{B}")
+
+
+@pytest.mark.parametrize("batchnorm", ["batch", "frozen"])
+def test_a_batch_of_one_in_a_larger_trainer_is_the_single_sample_pass(gpu, batchnorm):
+    """the batch layout (all images as channel groups of pixel-major maps, pitch C * F * batch) changes addresses, not arithmetic: one
+    sample through a trainer built for four gives the loss BITS of the trainer built for one and its gradients to float32 round-off
+    (the weight-gradient kernels split their reductions by the size of the workspace they are handed, which grows with the batch
+    capacity: another summation order, not another sum); and a different batch through the same buffers first (2 samples, then 1)
+    leaves nothing behind"""
+    from himo_amd.seflow import spec
+    from himo_amd.seflow.train import SeFlowTrainer
+    params = spec.init_params(6)
+    (args, lab0, lab1), (args2, lab0b, lab1b) = _labelled_sample(5000, 21), _labelled_sample(4600, 22)
+    mk = lambda a, l0, l1: (*a, torch.from_numpy(l0).to(gpu), torch.from_numpy(l1).to(gpu), int(l0.max()) + 1)
+    smp, smp2 = mk(args, lab0, lab1), mk(args2, lab0b, lab1b)
+    outs = []
+    for B in (1, 4):
+        tr = SeFlowTrainer(params, device=gpu, max_points=6000, batchnorm=batchnorm, batch=B)
+        if B == 4:
+            tr.loss_and_grad_batch([smp2, smp])                  # something else first: the buffers are not fresh
+        terms, total = tr.loss_and_grad(*smp)
+        torch.cuda.synchronize()
+        outs.append((float(total.item()), {k: v.clone() for k, v in tr.g.items()}, tr.net.p["enc2.1.bn.mean"].clone()))
+        del tr
+        torch.cuda.empty_cache()
+    assert outs[0][0] == outs[1][0]
+    for k, a in outs[0][1].items():
+        if batchnorm == "batch" and k.startswith("enc") and k.endswith(".bias") and ".bn." not in k:
+            continue                                              # (exactly zero by construction on both sides)
+        assert (a - outs[1][1][k]).abs().max().item() <= 3e-6 * max(a.abs().max().item(), 1e-12), k
+    if batchnorm == "frozen":
+        assert torch.equal(outs[0][2], outs[1][2])
 
 
 def _labelled_sample(n, seed):
