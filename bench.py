@@ -76,6 +76,9 @@ def parse_args():
     ap.add_argument("--no-extra-workloads", action="store_true",
                     help="pipeline, N=1: skip the short training-step (config 5) and FastNSF (config 4) legs that follow the timed region")
     ap.add_argument("--leg-train-steps", type=int, default=50, help="timed optimiser steps of the `leg_train` leg (after 2 warm-ups)")
+    ap.add_argument("--train-batch", type=int, default=1,
+                    help="train workload: samples per forward / backward pass and optimiser step (the launcher's batch_size=8 on one process: 8); "
+                         "the default line's `leg_train` is 1, `leg_train_b8` is 8")
     ap.add_argument("--leg-fit-steps", type=int, default=200,
                     help="optimiser steps of the `leg_fit_h5` leg (seflow.fit.fit over .h5 scene files, batch_size 8); 0 skips the leg")
     ap.add_argument("--leg-fastnsf-fits", type=int, default=6, help="timed fits of the `leg_fastnsf` leg (after 1 warm-up)")
@@ -108,6 +111,8 @@ def parse_args():
         a.steps = 10 if a.steps is None else a.steps
         a.warmup = 2 if a.warmup is None else a.warmup
         a.frames_per_step = 1 if a.frames_per_step is None else a.frames_per_step
+        if a.train_batch > 1:
+            a.frames_per_step = a.train_batch                   # a step = one pass over train_batch samples
     elif a.workload == "pipeline":
         a.steps = 100 if a.steps is None else a.steps           # 1600 frames: ~2.4 s timed -- long enough for an outside observer's
                                                                 # utilisation samples to see the region; 20 steps give the same rate
@@ -425,16 +430,19 @@ def make_fastnsf_step(args, rank: int, device, result: dict):
 
 
 def make_train_step(args, rank: int, device, result: dict, n_sets: int = 2):
-    """BASELINE config 5: self-supervised training, ``frames_per_step`` samples per rank per step (one optimiser step each), ONE
-    flat-gradient all-reduce over RCCL per optimiser step, Adam.  Labels: ~10 % of the points in 30 dynamic clusters.
-    ``n_sets`` distinct sample sets rotate through the steps, so the incremental pillar images meet cells that emptied
-    and cells that filled (a single repeated sample would skip every empty cell: a best case)."""
+    """BASELINE config 5: self-supervised training.  ``--train-batch 1`` (default): ``frames_per_step`` samples per rank per step, one
+    optimiser step each; ``--train-batch B``: a step is ONE forward / backward pass over B samples (every encoder layer one launch over
+    B x 3 images, BatchNorm statistics over the batch) and one optimiser step -- the reference launcher's ``batch_size=8`` on one
+    process (assets/slurm/ssl-train-av2.sh:32-34).  ONE flat-gradient all-reduce over RCCL per optimiser step, Adam.  Labels: ~10 % of
+    the points in 30 dynamic clusters.  ``n_sets`` distinct sample sets rotate through the steps, so the incremental pillar images meet
+    cells that emptied and cells that filled (a single repeated sample would skip every empty cell: a best case)."""
     import torch
     from himo_amd.seflow import spec
     from himo_amd.seflow.train import SeFlowTrainer
-    B, P = args.frames_per_step, args.points
+    TB = max(1, getattr(args, "train_batch", 1))
+    B, P = (TB if TB > 1 else args.frames_per_step), args.points
     params = spec.init_params(0)
-    trainer = SeFlowTrainer(params, device=device, max_points=P, precision=args.train_precision, batchnorm=args.train_batchnorm)
+    trainer = SeFlowTrainer(params, device=device, max_points=P, precision=args.train_precision, batchnorm=args.train_batchnorm, batch=TB)
     sets, _ = synthetic_sample_sets(n_sets, B, P, device, seed=rank, cloud=args.cloud)
     g = torch.Generator(device=device); g.manual_seed(99 + rank)
     labels = []
@@ -447,6 +455,10 @@ def make_train_step(args, rank: int, device, result: dict, n_sets: int = 2):
     def step():
         samples = sets[turn[0] % len(sets)]
         turn[0] += 1
+        if TB > 1:
+            result["loss"] = trainer.train_batch([(smp.pch1, smp.pc0, smp.pc1, smp.pose_h1, smp.pose0, smp.pose1, l0, l1, 31)
+                                                  for smp, (l0, l1) in zip(samples, labels)])
+            return
         for smp, (l0, l1) in zip(samples, labels):
             _, total = trainer.train_step(smp.pch1, smp.pc0, smp.pc1, smp.pose_h1, smp.pose0, smp.pose1, l0, l1, n_labels=31)
             result["loss"] = total
@@ -670,6 +682,10 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
                                                   "roofline kernel's launches are timed here"}
     elif args.workload == "train":
         roofline, workload, dtype = train_roofline(args, prof, B * args.steps, single if single is not None else elapsed)
+        # the parameter BITS this rank ends with (every rank holds the same): two runs that must agree bit for bit compare this
+        extra["param_bits_sum_at_end"] = int(trainer.flat_p.view(torch.int32).to(torch.int64).sum().item())
+        extra["gradient_exchange"] = ("bucket by bucket under the backward pass (BucketedAllReduce)" if (args.train_batch > 1 and trainer.overlap_allreduce)
+                                      else "one flat all-reduce after the backward pass")
         if single is not None:
             roofline["measured_in"] = ("a second region of the same K steps with every weight gradient on the main stream (un-overlapped "
                                        "launches), right after the timed region; `value` is the rate with the two side streams")
@@ -754,6 +770,7 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
         line["config"]["parallelism"] = f"data parallel x{world}, one flat all-reduce per step"
         line["config"]["matrix_arithmetic"] = args.train_precision
         line["config"]["batchnorm"] = args.train_batchnorm
+        line["config"]["samples_per_pass_and_optimiser_step"] = args.train_batch
     if not dry and not args.no_cpu_baseline and args.workload in ("pipeline", "compdis") and world == 1:     # CPU leg: rank 0 at N = 1 only
         if args.workload == "compdis":
             frames = [frame_to_host(batch, i) for i in range(min(8, B))]
@@ -914,6 +931,9 @@ def extra_workload_legs(args, device) -> dict:
         # the same step in the float32-class arithmetic (three-term bf16 split forward and data gradients, float32 MFMA weight gradients):
         # the figure that stands beside `leg_train`'s the way `value_bf16x3` stands beside `value`
         legs.insert(1, ("train_bf16x3", max(10, args.leg_train_steps // 2), 2))
+    if args.leg_train_steps > 0:
+        # ... and as the launcher batches it: 8 samples per pass and optimiser step (`leg_train_b8`; frames/s = samples/s)
+        legs.insert(1, ("train_b8", max(6, args.leg_train_steps // 5), 2))
     if args.cloud == "uniform":         # the training step again on LiDAR-shaped sweeps (himo_amd.synthetic.lidar_rings: crowded cells near the
         legs.insert(1, ("train_rings", args.leg_train_steps, 2))       # sensor, surfaces the other sweep lacks): `leg_train_rings` must stay near `leg_train`
     for leg_name, steps, warm in legs:
@@ -926,6 +946,8 @@ def extra_workload_legs(args, device) -> dict:
             a.cloud = "rings"
         if leg_name == "train_bf16x3":
             a.train_precision = "bf16x3"
+        a.train_batch = 8 if leg_name == "train_b8" else 1
+        per_step = a.train_batch                                   # samples per step of this leg
         result = {}
         try:
             if name == "train":
@@ -973,7 +995,7 @@ def extra_workload_legs(args, device) -> dict:
                 el_single = (time.perf_counter() - t1) / 2
             prof = _lib.prof_stop()
             if name == "train":
-                roof, workload, dtype = train_roofline(a, prof, 3 if side else steps, 3 * el_train_single if side else el)
+                roof, workload, dtype = train_roofline(a, prof, (3 if side else steps) * per_step, 3 * el_train_single if side else el)
                 if side:
                     roof["measured_in"] = "three steps with every weight gradient on the main stream, right after the timed steps (un-overlapped launches)"
                 parity = {"loss_after_leg": float(result["loss"].item()),
@@ -986,10 +1008,10 @@ def extra_workload_legs(args, device) -> dict:
                 parity = {"loss_first_to_last_iteration": [obj.loss_history[0][1], obj.loss_history[-1][1]],
                           "flow_mean_epe_vs_generating_flow": float(np.linalg.norm(got - fr[0]["flow"], axis=1).mean()),
                           "note": "gradient / trajectory parity vs the CPU restatement (oracle/fastnsf_oracle.py, unpinned): tests/test_fastnsf_gpu.py"}
-            leg = {"frames_per_s": steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warm,
+            leg = {"frames_per_s": steps * per_step / el, "ms_per_step": el / steps * 1e3, "steps": steps, "samples_per_step": per_step, "warmup": warm,
                    "points_per_frame": a.points, "cloud": a.cloud, "workload": workload, "dtype": dtype, "roofline": roof, "parity": parity}
             if name == "train" and side:
-                leg["frames_per_s_without_side_streams"] = 1.0 / el_train_single
+                leg["frames_per_s_without_side_streams"] = per_step / el_train_single
             if name == "fastnsf" and el_single is not None:
                 leg["fits_in_flight"] = len(nsf.engines)
                 leg["frames_per_s_one_fit_at_a_time"] = 1.0 / el_single
@@ -1115,7 +1137,8 @@ def fit_h5_leg(args, device) -> dict:
     reference's extractors write), samples read with ``fields=`` on reader threads, staged in pinned memory, copied and LABELLED
     on the device (two exact nearest-neighbour passes + two DBSCANs per pair) ahead of the optimiser step
     (``feeder.TrainFeeder``), ``--leg-fit-steps`` optimiser steps of 8 samples each, BatchNorm in training mode, Adam, StepLR
-    bookkeeping, the epoch's loss read back.  ``leg_train`` beside it is the bare step on resident samples with pre-made labels."""
+    bookkeeping, the epoch's loss read back.  ``leg_train_b8`` beside it is the bare step (8 samples per pass) on resident samples
+    with pre-made labels."""
     import shutil
     import tempfile
     import warnings
@@ -1143,7 +1166,7 @@ def fit_h5_leg(args, device) -> dict:
         steps_per_epoch = -(-n_trip // bs)
         epochs = max(1, -(-args.leg_fit_steps // steps_per_epoch))
         tr = SeFlowTrainer(spec.init_params(0), device=device, max_points=int(args.points * 1.02), precision=args.train_precision,
-                           batchnorm=args.train_batchnorm)
+                           batchnorm=args.train_batchnorm, batch=bs)      # a step's 8 samples in ONE pass, as `leg_train_b8`
         fit(ds, trainer=tr, epochs=1, batch_size=bs, max_steps=3, log=None, num_workers=args.fit_workers)      # warm-up: tile choices, buffers, page cache
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -445,6 +445,102 @@ def combine_batch_(flat_acc: torch.Tensor, flat_g: torch.Tensor) -> torch.Tensor
     return (flat_acc[n + 1] / count).clone()
 
 
+# The backward pass finishes the gradients in three groups, long before its last kernel: head + decoder first, then the two coarse
+# encoder stages, then the fine stage and the pillar net.  A bucket is the parameters of one group = a few ranges of the flat buffer
+# (the BatchNorm gamma / beta of the encoder layers live at the end of the flat layout, after everything else).
+BUCKETS = (("head + decoder", ("dec", "head.")), ("encoder stages 3 + 2", ("enc3.", "enc2.")), ("encoder stage 1 + pillar net", ("enc1.", "pfn.")))
+
+
+def bucket_ranges(names, offsets) -> list:
+    """[[(lo, hi), ...] per bucket of ``BUCKETS``] over the flat parameter layout (``offsets[name] = (lo, hi)`` in floats, padded):
+    the names of a bucket merged into maximal runs of consecutive names.  Every name falls in exactly one bucket."""
+    which = []
+    for k in names:
+        hit = [i for i, (_, prefixes) in enumerate(BUCKETS) if k.startswith(prefixes)]
+        if len(hit) != 1:
+            raise ValueError(f"parameter {k!r} belongs to {len(hit)} gradient buckets")
+        which.append(hit[0])
+    out = [[] for _ in BUCKETS]
+    for i, k in enumerate(names):
+        lo, hi = offsets[k]
+        runs = out[which[i]]
+        if runs and i > 0 and which[i - 1] == which[i] and runs[-1][1] == lo:
+            runs[-1] = (runs[-1][0], hi)
+        else:
+            runs.append((lo, hi))
+    return out
+
+
+class BucketedAllReduce:
+    """The data-parallel exchange of a step as one SUM all-reduce per range of a bucket, each started as soon as the backward pass
+    has finished that bucket -- on RCCL's own stream, beside the rest of the backward pass -- instead of ONE flat all-reduce after
+    its last kernel (28 MB over xGMI: ~0.3 ms of an 8 ms step at 8 ranks, DESIGN section 6, and the only serial piece of the N > 1
+    path).  ``launch(k, after)``: bucket k of ``flat`` is complete once the events ``after`` have passed; ``words``: a small tensor
+    (sample count, loss sum) that rides along, reduced first.  ``wait()``: every range has been reduced (stream-ordered for RCCL,
+    on the host for gloo).  The sums are those of the flat all-reduce, element by element."""
+
+    def __init__(self, flat: torch.Tensor, buckets, words: torch.Tensor | None = None):
+        import torch.distributed as dist
+        self.flat, self.buckets, self.words = flat, buckets, words
+        self.active = dist.is_available() and dist.is_initialized()
+        self.backend = dist.get_backend() if self.active else None
+        self.works, self.launched = [], set()
+        self.stream = torch.cuda.Stream(device=flat.device) if (flat.is_cuda and self.active) else None
+
+    def _reduce(self, t: torch.Tensor):
+        import torch.distributed as dist
+        if t.is_cuda and self.backend == "gloo":                 # ranks sharing a device (bench.py --share-gpu): through the host, blocking
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            t.copy_(host)
+        else:
+            self.works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+
+    def launch(self, k: int, after=()):
+        if k in self.launched:
+            raise RuntimeError(f"gradient bucket {k} launched twice")
+        self.launched.add(k)
+        if not self.active:
+            return
+        if self.stream is None:                                  # host tensors (tests): nothing to order against
+            if self.words is not None and len(self.launched) == 1:
+                self._reduce(self.words)
+            for lo, hi in self.buckets[k]:
+                self._reduce(self.flat[lo:hi])
+            return
+        with torch.cuda.stream(self.stream):
+            for ev in after:
+                self.stream.wait_event(ev)
+            if self.backend == "gloo":
+                self.stream.synchronize()
+            if self.words is not None and len(self.launched) == 1:
+                self._reduce(self.words)
+            for lo, hi in self.buckets[k]:
+                self._reduce(self.flat[lo:hi])
+
+    def wait(self):
+        if len(self.launched) != len(self.buckets):
+            raise RuntimeError(f"only the gradient buckets {sorted(self.launched)} of {len(self.buckets)} were exchanged")
+        for w in self.works:
+            w.wait()                                             # RCCL: the current stream waits; gloo: the host does
+        self.works = []
+
+
+_SIDE_STREAMS = {}
+
+
+def side_streams(device) -> tuple:
+    """The three side streams of the training step, ONE set per device and process: every trainer of a process shares them.  The HIP
+    runtime multiplexes a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 8 here) and streams that share a queue
+    serialise; a process that builds trainer after trainer (bench.py's legs, a sweep over configurations) would otherwise walk
+    through torch's stream pool until a side stream lands on the queue of the stream it is meant to run beside (measured: the 8-sample
+    step 58 -> 71 ms in the default bench process, 58 ms in a fresh one)."""
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = tuple(torch.cuda.Stream(device=device) for _ in range(3))
+    return _SIDE_STREAMS[key]
+
+
 class SeFlowTrainer:
     """Whole-network training step.  PARITY UNPINNED (``OpenSceneFlow/train.py`` is absent); conventions of this build:
     ``batchnorm="batch"`` (default) is what a from-scratch job runs (assets/slurm/ssl-train-av2.sh:31-34 passes no
@@ -529,13 +625,16 @@ class SeFlowTrainer:
         self.flat_m = torch.zeros_like(self.flat_p)
         self.flat_v = torch.zeros_like(self.flat_p)
         self.p, self.g = {}, {}
-        o = 0
+        o, offsets = 0, {}
         for k, n in zip(self.names, sizes):
             shp = tuple(host[k].shape)
             self.p[k] = self.flat_p[o:o + n].view(shp)
             self.g[k] = self.flat_g[o:o + n].view(shp)
             self.p[k].copy_(torch.from_numpy(np.ascontiguousarray(host[k], dtype=np.float32)))
+            offsets[k] = (o, o + pad(n))
             o += pad(n)
+        self.buckets = bucket_ranges(self.names, offsets)        # the flat ranges the backward pass completes together (BucketedAllReduce)
+        self.overlap_allreduce = os.environ.get("HIMO_TRAIN_OVERLAP_ALLREDUCE", "1") != "0"
         for k in self.names:
             if not k.startswith("head.") or k.startswith("head.offset"):
                 net.p[k] = self.p[k]                              # incl. the BatchNorm gamma / beta views in batch mode
@@ -602,13 +701,11 @@ class SeFlowTrainer:
         if self.tune_tiles and precision != "f32":   # the decoder's forward runs through net._conv: the same restricted candidates
             net.autotune = True
             net._tune = lambda d: self._tune_tile(d) if (d.ksize == 3 and d.w_packed) else 0
-        self.side = torch.cuda.Stream(device=dev)
+        self.side, self.side2, self.side3 = side_streams(dev)
         self.ws_side = torch.empty(ws + 64, dtype=torch.uint8, device=dev)
         # ... and the DECODER's weight gradients on a second side stream (the encoder's ping-pong waits on the first: a backlog of
         # decoder work there would stall the chain).  Their gradient operands get a buffer per block instead of the shared scratch
         self.overlap_decoder = self.overlap_wgrad and os.environ.get("HIMO_TRAIN_SIDE_STREAM_DECODER", "1") != "0"
-        self.side2 = torch.cuda.Stream(device=dev)
-        self.side3 = torch.cuda.Stream(device=dev)
         self._skip_done = []
         self.ws_side2 = torch.empty(ws + 64, dtype=torch.uint8, device=dev) if self.overlap_decoder else None
         for h_ in self.heads:
@@ -1071,9 +1168,22 @@ class SeFlowTrainer:
         """One sample (``backward_batch`` after a ``forward`` of one sample)."""
         return self.backward_batch([dres])
 
-    def backward_batch(self, dres_list):
+    def _bucket_done(self, exchange, k: int, streams):
+        """bucket k of ``flat_g`` is complete once everything enqueued so far on ``streams`` has run: start its exchange there"""
+        if exchange is None:
+            return
+        events = []
+        for st in streams:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            events.append(ev)
+        exchange.launch(k, events)
+
+    def backward_batch(self, dres_list, exchange: BucketedAllReduce | None = None):
         """``dres_list[b]`` [n0_b, 4] = d loss / d res of sample b of the last ``forward_batch``.  The gradients of every trainable
-        tensor -- of the SUM of the samples' losses -- land in ``self.flat_g``."""
+        tensor -- of the SUM of the samples' losses -- land in ``self.flat_g``.  ``exchange``: the step's data-parallel exchange, started
+        bucket by bucket as the pass completes them (head + decoder after the last decoder block, the coarse encoder stages after
+        enc2.0, the rest at the end)."""
         net, lib, s = self.net, self.lib, _lib.stream_handle
         H, W, F, B, nb = net.H, net.W, net.F, self.B, self.nb
         if len(dres_list) != nb:
@@ -1112,6 +1222,8 @@ class SeFlowTrainer:
         dcat = {256: self.dF3, 128: self.dF2, 64: self.dF1, 32: self.dB0}
         dy = None
         main = torch.cuda.current_stream(self.device)
+        # head + decoder: their weight gradients are on the second side stream (or on this one), everything enqueued
+        self._bucket_done(exchange, 0, (main, self.side2))
         while self._skip_done:                                   # the decoder blocks' skip gradients (third side stream) are complete
             main.wait_event(self._skip_done.pop())
         side_done = {}                                           # layer -> event: its side-stream launches have finished reading dp
@@ -1167,6 +1279,8 @@ class SeFlowTrainer:
                 else:
                     self._zero_bn_bias(name)
                 self._wgrad3_batch(NI, x, x_bs, x_pitch, h, w, cin, dp, ho * wo * cout, cout, cout, f"{name}.weight", stride)
+            if name == "enc2.0":                                 # stages 3 and 2: weight gradients on the first side stream, d gamma / d beta on this one
+                self._bucket_done(exchange, 1, (main, self.side))
             wf, wp = self._flip(name, 3, cin, cout)
             if stride == 2:
                 dst = dcat[cin]                                  # fan-in: add to the decoder's skip gradient
@@ -1209,9 +1323,12 @@ class SeFlowTrainer:
                                                  st["ws_slots"][slot].data_ptr(), self.dB0.data_ptr() + 4 * 32 * i, 32 * F * B,
                                                  self.g["pfn.weight"].data_ptr(), 1 if i else 0, self.ws.data_ptr(), self.ws.numel(), s()),
                            "pfn_backward")
+        self._bucket_done(exchange, 2, (main, self.side))
         main.wait_stream(self.side)                             # every gradient is in flat_g when this stream goes on
         main.wait_stream(self.side2)
         main.wait_stream(self.side3)
+        if exchange is not None:
+            exchange.wait()                                      # ... and summed over the ranks
 
     def _pfn_sweep_arrays(self):
         """host arrays of the batch's sweeps (sweep b * F + f) for the pillar-net calls: point counts, transformed points, pillar workspaces"""
@@ -1260,7 +1377,7 @@ class SeFlowTrainer:
         terms, totals = self.loss_and_grad_batch([(pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels)])
         return terms[0], totals[0]
 
-    def loss_and_grad_batch(self, samples):
+    def loss_and_grad_batch(self, samples, exchange=None):
         """forward over the batch + self-supervised loss per sample (himo_amd/ssl_loss.py; the flow it scores is the network's residual
         flow of pc0 in pc1's frame) + backward: the gradient of the SUM of the samples' losses lands in ``flat_g``.  ``samples``: 1 ..
         ``batch`` tuples (pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels).  Returns ([terms per sample], [total per
@@ -1304,7 +1421,10 @@ class SeFlowTrainer:
             dres = torch.zeros((n0, 4), dtype=torch.float32, device=self.device)
             dres[:, :3] = grad
             terms_all.append(terms); totals.append(total); dres_list.append(dres)
-        self.backward_batch(dres_list)
+        if exchange is not None and exchange.words is not None:      # [sample count | loss sum] of this rank ride along with the first bucket
+            exchange.words[0] = float(nb)
+            exchange.words[1] = torch.stack(totals).sum().to(exchange.words.dtype)
+        self.backward_batch(dres_list, exchange=exchange)
         return terms_all, totals
 
     def loss_only(self, pch1, pc0, pc1, pose_h1, pose0, pose1, label0, label1, n_labels: int | None = None):
@@ -1337,8 +1457,25 @@ class SeFlowTrainer:
             self.flat_acc = torch.zeros(n + 2, dtype=self.flat_g.dtype, device=self.flat_g.device)   # [gradient sum | count | loss sum]
         acc = self.flat_acc[:n]
         it, passes = iter(samples), 0
+        import torch.distributed as dist
+        first = list(itertools.islice(it, self.B))
+        more = list(itertools.islice(it, self.B)) if len(first) == self.B else []
+        if first and not more and self.overlap_allreduce and dist.is_available() and dist.is_initialized():
+            # the usual case -- the rank's share of the step is ONE pass: the exchange runs bucket by bucket UNDER the backward pass
+            # (BucketedAllReduce) instead of after it; same sums, element by element, as the flat all-reduce below
+            words = self.flat_acc[n:]
+            exchange = BucketedAllReduce(self.flat_g, self.buckets, words=words)
+            self.loss_and_grad_batch(first, exchange=exchange)
+            count = words[0]
+            if float(count.item()) <= 0.0:
+                raise ValueError("train_batch needs at least one sample on some rank")
+            self.flat_g.div_(count)
+            loss = (words[1] / count).clone()
+            self.adam_step(lr)
+            return loss
+        pending = [first, more] if more else ([first] if first else [])
         while True:
-            chunk = list(itertools.islice(it, self.B))
+            chunk = pending.pop(0) if pending else list(itertools.islice(it, self.B))
             if not chunk:
                 break
             _, totals = self.loss_and_grad_batch(chunk)

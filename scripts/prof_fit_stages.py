@@ -68,7 +68,17 @@ try:
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / 50
     mb = sum(p.numel() * p.element_size() for p in pin) / 1e6
-    print(f"upload alone: {1e3 * el:7.3f} ms per sample ({mb:.1f} MB -> {mb / el / 1e3:.1f} GB/s)")
+    print(f"upload alone: {1e3 * el:7.3f} ms per sample as five copies ({mb:.1f} MB -> {mb / el / 1e3:.1f} GB/s)")
+    for size_mb in (1, 6, 32, 128):
+        block = torch.empty(size_mb << 20, dtype=torch.uint8).pin_memory()
+        block.to(dev, non_blocking=True); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            got = block.to(dev, non_blocking=True)
+        torch.cuda.synchronize()
+        el1 = (time.perf_counter() - t0) / 20
+        print(f"upload alone: one pinned block of {size_mb:3d} MB: {1e3 * el1:7.3f} ms -> {size_mb * 1.048576 / el1 / 1e3:.1f} GB/s" +
+              ("   (what the feeder issues per sample)" if size_mb == 6 else ""))
 
     # ---- labels alone -----------------------------------------------------------------------------------------------
     smp = [make_sample(ds, t, dev, "seflow_auto") for t in trips[:8]]

@@ -363,3 +363,55 @@ def test_rendezvous_waits_for_the_slow_rank_longer_than_the_collective_timeout(t
     guards the data collectives -- a rank that finishes early waits (HIMO_RENDEZVOUS_TIMEOUT_S, hours by default)."""
     mp.spawn(_worker_skewed_rendezvous, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").read_text() == (tmp_path / "ok1").read_text() == "[0, 1]"
+
+
+def _worker_buckets(rank, world, port, out_dir):
+    _init(rank, world, port)
+    from himo_amd.seflow.train import BucketedAllReduce, allreduce_sum_, bucket_ranges
+    names = ["pfn.weight", "enc1.0.weight", "enc1.0.bias", "enc2.0.weight", "enc3.0.weight", "dec1.u1.weight", "dec4.weight", "head.offset.weight",
+             "head.zr.weight", "pfn.bn.gamma", "enc1.0.bn.gamma", "enc2.0.bn.gamma", "enc3.0.bn.beta"]
+    sizes = [288, 18432, 64, 73728, 294912, 196608, 36864, 192, 49152, 32, 64, 128, 256]
+    offsets, o = {}, 0
+    for k, n in zip(names, sizes):
+        offsets[k] = (o, o + n); o += n
+    buckets = bucket_ranges(names, offsets)
+    ok = buckets == [[(offsets["dec1.u1.weight"][0], offsets["head.zr.weight"][1])],
+                     [(offsets["enc2.0.weight"][0], offsets["enc3.0.weight"][1]), (offsets["enc2.0.bn.gamma"][0], offsets["enc3.0.bn.beta"][1])],
+                     [(0, offsets["enc1.0.bias"][1]), (offsets["pfn.bn.gamma"][0], offsets["enc1.0.bn.gamma"][1])]]
+    g = torch.Generator(); g.manual_seed(100 + rank)
+    equal = True
+    for step in range(10):
+        grad = torch.randn(o, generator=g) * 10.0 ** float(torch.randint(-6, 3, (1,), generator=g))
+        words = torch.tensor([float(1 + rank + step % 2), float(torch.rand(1, generator=g))], dtype=torch.float32)
+        flat = torch.cat([grad, words])
+        allreduce_sum_(flat)                                        # the single flat all-reduce
+        mine, w2 = grad.clone(), words.clone()
+        ex = BucketedAllReduce(mine, buckets, words=w2)
+        for k in range(3):
+            ex.launch(k)
+        ex.wait()
+        equal = equal and torch.equal(mine, flat[:o]) and torch.equal(w2, flat[o:])
+    partial = BucketedAllReduce(grad.clone(), buckets)
+    partial.launch(0)
+    try:
+        partial.wait()
+        refused = False
+    except RuntimeError:
+        refused = True
+    for k in (1, 2):                                                # (the other rank entered these collectives too)
+        partial.launch(k)
+    partial.wait()
+    Path(out_dir, f"rank{rank}.json").write_text(json.dumps({"layout": ok, "equal": equal, "refused": refused}))
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_exchange_has_the_bits_of_the_flat_all_reduce(tmp_path):
+    """three buckets of the flat gradient (head + decoder / encoder stages 3 + 2 / stage 1 + pillar net; the BatchNorm
+    gamma / beta at the end of the layout join their stage's bucket), each reduced on its own as the backward pass completes it, with the
+    step's [sample count | loss sum] words riding along -- element by element the sums of the ONE flat all-reduce, over 10 steps of
+    gradients spanning nine decades; an exchange that skipped a bucket refuses to finish."""
+    port = _free_port()
+    mp.spawn(_worker_buckets, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = json.loads(Path(tmp_path, f"rank{r}.json").read_text())
+        assert got == {"layout": True, "equal": True, "refused": True}, (r, got)

@@ -394,6 +394,29 @@ def test_bench_two_ranks_on_this_box(gpu, workload):
     assert line["value"] > 0 and np.isfinite(line["value"])
 
 
+def test_overlapped_gradient_exchange_ends_in_the_flat_exchange_bits_two_ranks(gpu):
+    """the gradient all-reduce bucket by bucket UNDER the backward pass (seflow.train.BucketedAllReduce: head + decoder,
+    encoder stages 3 + 2, stage 1 + pillar net; the sample count and loss ride with the first) against ONE flat all-reduce after it --
+    two ranks with real device work on this box (gloo: RCCL refuses two ranks per device), 2 samples per rank and pass, 10+ optimiser
+    steps: the same parameter bits on both paths."""
+    import json, os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    bits = {}
+    for overlap in ("1", "0"):
+        env = dict(os.environ, HIMO_TRAIN_OVERLAP_ALLREDUCE=overlap)
+        env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+        cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--share-gpu", "--workload", "train", "--train-batch", "2", "--steps", "4",
+               "--warmup", "2", "--points", "20000", "--no-cpu-baseline", "--no-extra-precisions"]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+        assert line["n_gpus"] == 2 and line["config"]["samples_per_pass_and_optimiser_step"] == 2
+        assert ("bucket by bucket" in line["gradient_exchange"]) == (overlap == "1")
+        bits[overlap] = line["param_bits_sum_at_end"]
+    assert bits["1"] == bits["0"], bits
+
+
 def test_cli_programs_as_two_ranks_on_this_box(gpu, tmp_path):
     """The reference's job shape (assets/slurm/ssl-train-av2.sh:3: one process per GPU under a launcher) for the four programs,
     with REAL device work on the one-GPU box: `python -m torch.distributed.run --nproc-per-node 2 -m himo_amd.{save, save_zip,
