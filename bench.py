@@ -740,6 +740,8 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
             extra.update(h5fed_leg(args, overlapped if overlapped is not None else pipe, host_frames, device))
         if world == 1 and not args.no_extra_workloads and args.leg_fit_steps > 0:
             extra.update(fit_h5_leg(args, device))
+        if world == 1 and not args.no_hostfed_leg:
+            extra.update(eval_h5_leg(args, device))
     line = {
         "metric": "lidar_frames_per_sec_120k", "value": total_frames / elapsed, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1107,6 +1109,17 @@ def h5fed_leg(args, pipe, host_frames, device) -> dict:
             for i in range(len(ds)):
                 ds[i]
             loader = len(ds) / (time.perf_counter() - t0)
+            # `loader_views_per_s` above is the rate of CREATING items whose sweeps are views of the file mapping (no byte of a sweep is
+            # touched); the rate with pc0 / pc1 / lidar_dt actually copied out of the mapping -- what a consumer pays once, into its
+            # pinned staging memory -- is this one (the two were reported under one name)
+            sink_buf = [np.empty_like(np.asarray(ds[0][k])) for k in ("pc0", "pc1", "lidar_dt")]
+            t0 = time.perf_counter()
+            for i in range(len(ds)):
+                item = ds[i]
+                for buf, k in zip(sink_buf, ("pc0", "pc1", "lidar_dt")):
+                    if item[k].shape == buf.shape:
+                        np.copyto(buf, item[k])
+            copied = len(ds) / (time.perf_counter() - t0)
             how = None
             for rep in range(2):
                 sink = save.H5ResultSink(root, "seflowpp_bench", before_write=ds.forget)
@@ -1118,13 +1131,90 @@ def h5fed_leg(args, pipe, host_frames, device) -> dict:
                 el = time.perf_counter() - t0
             ds.close()
         leg = {"frames_per_s": done / el, "frames": done, "seconds": el, "scenes": n_scenes, "sweeps_per_scene": per_scene,
-               "points_per_sweep": int(host_frames[0]["pc0"].shape[0]), "loader_items_per_s": loader, "loader_items_per_s_first_pass": cold,
+               "points_per_sweep": int(host_frames[0]["pc0"].shape[0]), "loader_views_per_s": loader, "loader_views_per_s_first_pass": cold, "loader_items_copied_out_per_s": copied,
                "result_writer": how, "scene_file_MB": round((root / "bench00.h5").stat().st_size / 1e6, 1),
                "note": "himo_amd.save.run end to end: read .h5 scenes -> pinned feeder -> network (batches in flight) -> flow written back per sweep; "
                        "second pass over the files (page cache warm)"}
         return {"value_h5fed": leg["frames_per_s"], "leg_h5fed": leg}
     except Exception as e:                                       # a leg must never cost the main line
         return {"leg_h5fed": {"error": f"{type(e).__name__}: {e}"}}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def eval_h5_leg(args, device) -> dict:
+    """N = 1 only, after the timed region: the evaluator as the PROGRAM a user starts -- ``python eval.py --data_dir ... --res_name
+    seflowpp_best`` (eval.py:270-313: ``dataset[i]`` -> ego-motion removal, eval mask, per-instance MPE / Chamfer -> the tables) --
+    END TO END over 120k-point ``.h5`` scene files holding the estimate beside the ground truth: ``himo_amd.eval.main`` reads the
+    scenes (``fields=`` / views of the file mapping, a few reader threads, the next batch's reads in flight), stages the batches in
+    pinned memory (``feeder.EvalFeeder``), scores them on the device and writes ``res-av2.json``.  Beside it the same sweeps as
+    device-RESIDENT batches (``InstanceMetrics.step_batch``: kernels + the pipelined record read-back + the host-side bucket
+    bookkeeping), the figure of profiles/r0x_evaluator_throughput.txt."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    import warnings
+    import torch
+    from himo_amd import eval as ev
+    from himo_amd.synthetic import make_frame, write_h5_scenes
+    n_scenes, per_scene, P = 4, 33, args.points
+    root = Path(tempfile.mkdtemp(prefix="himo_eval_av2_"))
+    try:
+        frames = []
+        for sc in range(n_scenes):
+            fr = [make_frame(9000 + 40 * sc + k, n_points=P, scene_id=f"eval{sc:02d}", cloud=args.cloud) for k in range(per_scene)]
+            frames.append(fr)
+        # (write_h5_scenes writes the reference extractors' datasets; the estimate goes in beside them, as the reference's save.py leaves it)
+        import pickle
+        from himo_amd import h5lite
+        index = []
+        for fr in frames:
+            tree = {}
+            for f in fr:
+                tree[str(f["timestamp"])] = {"lidar": f["pc0"], "lidar_dt": f["lidar_dt"], "lidar_id": f["lidar_id"], "pose": f["pose0"],
+                                             "ground_mask": f["gm0"], "flow": f["flow"], "flow_is_valid": f["flow_is_valid"],
+                                             "flow_category_indices": f["flow_category_indices"], "flow_instance_id": f["flow_instance_id"],
+                                             "seflowpp_best": f["seflowpp_best"]}
+                index.append([f["scene_id"], str(f["timestamp"])])
+            h5lite.write_file(root / f"{fr[0]['scene_id']}.h5", tree)
+        with open(root / "index_total.pkl", "wb") as fh:
+            pickle.dump(index, fh)
+        B = 16
+        sink = io.StringIO()
+        with warnings.catch_warnings(), contextlib.redirect_stdout(sink):
+            warnings.simplefilter("ignore")
+            for rep in range(2):                                   # first pass: page cache, workspaces, pinned arenas
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                m = ev.main(str(root), res_name="seflowpp_best", batch_frames=B, file_name=str(root / "res.json"))
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+            sweeps = m.frame_cnt
+            # the same work on device-resident batches
+            flat = [f for fr in frames for f in fr[:-1]][:4 * B]
+            for f, nxt in zip(flat, [f for fr in frames for f in fr[1:]][:4 * B]):
+                f["pose1"] = nxt["pose0"]
+            ebs = [ev.EvalBatch.from_frames(flat[k * B:(k + 1) * B], "seflowpp_best", device=device) for k in range(4)]
+            res = ev.InstanceMetrics("av2")
+            for eb in ebs:
+                res.step_batch(eb)
+            res.flush(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(12):
+                res.step_batch(ebs[k % 4])
+            res.flush(); torch.cuda.synchronize()
+            resident = 12 * B / (time.perf_counter() - t0)
+        mb = sum(f[k].nbytes for f in frames[0][:1] for k in ("pc0", "lidar_dt", "gm0", "flow", "flow_is_valid", "flow_category_indices",
+                                                              "flow_instance_id", "seflowpp_best")) / 1e6
+        leg = {"sweeps_per_s": sweeps / el, "sweeps": sweeps, "seconds": el, "resident_sweeps_per_s": resident, "fraction_of_resident": sweeps / el / resident,
+               "scenes": n_scenes, "sweeps_per_scene": per_scene, "points_per_sweep": P, "batch_frames": B, "host_MB_read_per_sweep": round(mb, 2),
+               "note": "himo_amd.eval.main end to end: read .h5 scenes (fields=, views of the mapping, 4 reader threads one batch ahead) -> pinned "
+                       "staging + copies on the feeder's stream -> eval mask, per-instance MPE / Chamfer on the device -> tables + res.json; second "
+                       "pass over the files (page cache warm).  resident = the same scoring on batches already in HBM"}
+        return {"value_eval_h5": leg["sweeps_per_s"], "leg_eval_h5": leg}
+    except Exception as e:                                           # a leg must never cost the main line
+        return {"leg_eval_h5": {"error": f"{type(e).__name__}: {e}"}}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 

@@ -112,6 +112,11 @@ def load_index(directory, eval: bool = False) -> list:  # noqa: A002
 SAVE_FIELDS = ("pc0", "pose0", "lidar_dt", "pose1", "pc1")
 
 
+# ... and the ones the evaluator reads (eval.py:282-310: the sweep, its poses and time stamps, the ground truth, the masks and ids -- not
+# the next sweep's points); the estimate's key (``res_name``) joins them
+EVAL_FIELDS = ("pc0", "pose0", "pose1", "lidar_dt", "gm0", "flow", "flow_is_valid", "flow_category_indices", "flow_instance_id")
+
+
 class _OpenFiles:
     """The most recently used scene files, kept OPEN (a walk reads every sweep of a scene in turn, and each sweep three times:
     as next, current and history): re-opening per item meant an mmap, a superblock parse and a group walk each time -- three

@@ -468,7 +468,8 @@ def stream_batches(metrics: "InstanceMetrics", source, res_name: str = ""):
 
 
 def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo", res_name: str = "", comp_dis_zip: str = "",
-         batch_frames: int = 16, dataset=None, file_name: str | None = None, allow_dropped_eval: bool | None = None):
+         batch_frames: int = 16, dataset=None, file_name: str | None = None, allow_dropped_eval: bool | None = None,
+         read_threads: int = 4):
     """eval.py:270-313.  Under ``torchrun`` sweep i is scored by rank i % world on its own GPU, the per-sweep contribution
     logs are all-gathered once at the end and rank 0 alone prints / writes ``res-<data>.json``."""
     from . import distenv
@@ -482,17 +483,34 @@ def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo", res_name: str = 
         err = None
         try:
             if dataset is None:
+                # only what the loop reads (eval.py:282-310): no next-sweep points, no sensor ids; arrays stored as plain runs come
+                # back as views of the file mapping and are copied ONCE, into the feeder's pinned staging memory
+                from .dataset import EVAL_FIELDS
+                want = EVAL_FIELDS + ((res_name,) if (eval_flag == 2 and res_name and res_name != "raw") else ())
                 dataset = open_dataset(data_dir, vis_name=res_name if eval_flag == 2 else "", eval=True,
-                                       allow_dropped_eval=allow_dropped_eval)
+                                       allow_dropped_eval=allow_dropped_eval, fields=want, zero_copy=True)
             mine = list(range(rank, len(dataset), world))
 
             def batches():
-                for lo in range(0, len(mine), batch_frames):
-                    frames = [dataset[i] for i in mine[lo:lo + batch_frames]]
-                    cds = None
-                    if eval_flag == 1:
-                        cds = [read_output_zip(comp_dis_zip, (f["scene_id"], str(f["timestamp"]))) for f in frames]
-                    yield mine[lo:lo + batch_frames], frames, cds
+                # the frames of a batch are read by a few threads (file reads and decompression release the interpreter lock), and
+                # the NEXT batch's reads are in flight while this one is staged and copied
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=max(1, read_threads), thread_name_prefix="himo-eval-read") as pool:
+                    def read(lo):
+                        futs = [pool.submit(dataset.__getitem__, i) for i in mine[lo:lo + batch_frames]]
+                        zips = [pool.submit(lambda i=i: read_output_zip(comp_dis_zip, tuple(map(str, dataset.index[i]))))
+                                for i in mine[lo:lo + batch_frames]] if (eval_flag == 1 and hasattr(dataset, "index")) else None
+                        return futs, zips
+                    nxt = read(0) if mine else None
+                    for lo in range(0, len(mine), batch_frames):
+                        futs, zips = nxt
+                        nxt = read(lo + batch_frames) if lo + batch_frames < len(mine) else None
+                        frames = [f.result() for f in futs]
+                        cds = None
+                        if eval_flag == 1:
+                            cds = ([z.result() for z in zips] if zips is not None else
+                                   [read_output_zip(comp_dis_zip, (f["scene_id"], str(f["timestamp"]))) for f in frames])
+                        yield mine[lo:lo + batch_frames], frames, cds
             stream_batches(metrics, batches(), res_name)
         except Exception as e:
             err = e

@@ -128,8 +128,8 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
     """Train for ``epochs`` passes over ``dataset``; returns {"trainer", "history", "best"}.
 
     ``num_workers`` > 0 (default; the launcher's ``num_workers=16``, ssl-train-av2.sh:32): the samples of an epoch come from
-    ``feeder.TrainFeeder`` -- read on that many threads, staged, copied and labelled ``prefetch`` samples ahead of the optimiser
-    step.  0: every sample is built inside the step loop on the launch thread (``make_sample``) -- same parameter bits, slower.
+    ``feeder.TrainFeeder`` -- read on that many threads, staged, copied and labelled a step's samples + ``prefetch`` ahead of the
+    optimiser step.  0: every sample is built inside the step loop on the launch thread (``make_sample``) -- same parameter bits, slower.
     ``cache_labels``: labels generated for a pair (``ssl_label=seflow_auto``) are kept on the host and uploaded again in the later
     epochs instead of being generated again (the reference's job reads labels an offline pass wrote once); same bits.
 
@@ -167,7 +167,9 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
             return
         import itertools
         from ..feeder import TrainFeeder
-        feed = TrainFeeder(ds, [t for grp in groups for t in grp], device=dev, label_key=ssl_label, depth=prefetch, workers=num_workers,
+        # (a step takes its whole share of the batch at once: the NEXT step's samples, and ``prefetch`` more, are prepared under this one)
+        feed = TrainFeeder(ds, [t for grp in groups for t in grp], device=dev, label_key=ssl_label, depth=prefetch + max(len(g) for g in groups),
+                           workers=num_workers,
                            label_lanes=label_lanes,
                            label_cache=label_caches.setdefault(id(ds), {}) if (cache_labels and ssl_label in AUTO_LABELS) else None)
         try:

@@ -96,7 +96,7 @@ try:
     print(f"labels alone: {1e3 * el:7.3f} ms per pair (resident sweeps; label count read back); sample 0: {smp[0][8] - 1} clusters, {100 * dyn:.1f} % of pc0 dynamic")
 
     # ---- step alone -------------------------------------------------------------------------------------------------
-    tr = SeFlowTrainer(spec.init_params(0), device=dev, max_points=int(P * 1.02), precision="mixed")
+    tr = SeFlowTrainer(spec.init_params(0), device=dev, max_points=int(P * 1.02), precision="mixed", batch=8)      # a step = ONE pass over its 8 samples
     for k in range(3):
         tr.train_batch(smp, lr=6e-5)
     torch.cuda.synchronize()
@@ -105,7 +105,7 @@ try:
         tr.train_batch(smp, lr=6e-5)
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / (6 * len(smp))
-    print(f"step alone  : {1e3 * el:7.3f} ms per sample (train_batch of 8 resident, labelled samples: one Adam step per 8) = {1 / el:6.1f} samples/s")
+    print(f"step alone  : {1e3 * el:7.3f} ms per sample (train_batch of 8 resident, labelled samples in ONE pass: one Adam step per 8) = {1 / el:6.1f} samples/s")
     step_alone = el
     del smp
 
