@@ -1158,7 +1158,7 @@ def eval_h5_leg(args, device) -> dict:
     import torch
     from himo_amd import eval as ev
     from himo_amd.synthetic import make_frame, write_h5_scenes
-    n_scenes, per_scene, P = 4, 33, args.points
+    n_scenes, per_scene, P = 8, 33, args.points              # 256 scored sweeps = 16 batches (the first batches pay for the pinned arenas)
     root = Path(tempfile.mkdtemp(prefix="himo_eval_av2_"))
     try:
         frames = []

@@ -289,6 +289,41 @@ class InstanceMetrics:
         self.flush()
 
     # ---- host bookkeeping: eval.py:75-147 on the per-instance records of ONE sweep ---------------------------
+    # The reference forms a sweep's bucket means with np.average / np.nanmean / np.nanstd on lists of a handful of floats; through
+    # numpy each call costs ~8 us of dispatch, ~0.35 ms per sweep -- as much as the sweep's device work, and it holds the interpreter
+    # lock the feeder threads need.  The three helpers below return numpy's BITS for the short, NaN-free lists that occur (numpy sums
+    # fewer than 8 float64 values left to right; from 8 on it keeps eight partial sums -- those lists go to numpy itself, as does
+    # anything holding a NaN): checked against numpy over random lists in tests/test_host_logic.py and, end to end, by the parity tests
+    # against the reference's own eval.py output (tests/test_eval_gpu.py).
+    @staticmethod
+    def _np_sum(xs):
+        total = xs[0]
+        for v in xs[1:]:
+            total += v
+        return total
+
+    @classmethod
+    def _average(cls, values, weights):
+        """np.average(values, weights=weights) for float values and int weights"""
+        n = len(values)
+        if n > 7 or any(v != v for v in values):
+            return np.average(values, weights=weights)
+        scl = cls._np_sum([float(w) for w in weights])
+        if scl == 0.0:
+            return np.average(values, weights=weights)            # (numpy's ZeroDivisionError)
+        return np.float64(cls._np_sum([v * float(w) for v, w in zip(values, weights)]) / scl)
+
+    @classmethod
+    def _nanmean_nanstd(cls, values):
+        """(float(np.nanmean(values)), float(np.nanstd(values))) for a list of float64 scalars"""
+        n = len(values)
+        if n == 0 or n > 7 or any(v != v for v in values):
+            return float(np.nanmean(values)), float(np.nanstd(values))
+        vals = [float(v) for v in values]
+        mean = cls._np_sum(vals) / n
+        dev = [(v - mean) * (v - mean) for v in vals]
+        return mean, float(np.sqrt(np.float64(cls._np_sum(dev) / n)))
+
     def _accumulate_frame(self, recs, key=0):
         frame_score = self.init_evaluate_data()
         for gid, cats_name in enumerate(EVAL_GROUPS, start=1):
@@ -311,17 +346,18 @@ class InstanceMetrics:
             for name in RANGES:
                 got = frame_score[cats_name]["vel"][name]
                 if got["num_pts"]:
-                    mpes.append(np.average(got["mpe"], weights=got["num_pts"]))
-                    chams.append(np.average(got["cham"], weights=got["num_pts"]))
+                    mpes.append(self._average(got["mpe"], got["num_pts"]))
+                    chams.append(self._average(got["cham"], got["num_pts"]))
                     totals.append(sum(got["num_pts"]))
             if sum(totals) == 0:
                 continue
             mean = frame_score[cats_name]["mean"]
             mean["num_pts"].append(sum(totals))
-            mean["mpe"].append(float(np.nanmean(mpes)))
-            mean["cham"].append(float(np.nanmean(chams)))
-            mean["std_mpe"].append(float(np.nanstd(mpes)))
-            mean["std_cham"].append(float(np.nanstd(chams)))
+            (m_mpe, s_mpe), (m_cham, s_cham) = self._nanmean_nanstd(mpes), self._nanmean_nanstd(chams)
+            mean["mpe"].append(m_mpe)
+            mean["cham"].append(m_cham)
+            mean["std_mpe"].append(s_mpe)
+            mean["std_cham"].append(s_cham)
         self._log.append((key, frame_score))
         self._apply(frame_score)
 

@@ -109,3 +109,24 @@ def test_save_program_takes_the_reference_style_overrides():
     for argv in (["model=nsfp", "dataset_path=/nonexistent"], ["--model", "nsfp", "--dataset_path", "/nonexistent"]):
         r = subprocess.run([sys.executable, "-m", "himo_amd.save", *argv], capture_output=True, text=True, cwd=root)
         assert r.returncode != 0 and "model='nsfp'" in r.stderr and "fastnsf" in r.stderr, r.stderr[-400:]
+
+
+def test_evaluator_bucket_statistics_have_numpys_bits():
+    """the evaluator's per-sweep bucket means (eval.py:113-141: np.average / np.nanmean / np.nanstd on lists of a handful of floats)
+    are formed without numpy's per-call dispatch for short NaN-free lists: the same bits as numpy, over 60k random lists of every
+    length that takes the short path and the lengths / NaNs that fall back to numpy"""
+    from himo_amd.eval import InstanceMetrics as M
+    rng = np.random.default_rng(0)
+    for trial in range(60_000):
+        n = int(rng.integers(1, 11))
+        vals = [float(x) for x in rng.uniform(0, 3, n) * 10.0 ** rng.integers(-3, 2)]
+        if trial % 50 == 0:
+            vals[int(rng.integers(0, n))] = float("nan")
+        w = [int(x) for x in rng.integers(10, 5000, n)]
+        a, b = M._average(vals, w), np.average(vals, weights=w)
+        assert a == b or (a != a and b != b), (vals, w, a, b)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got, want = M._nanmean_nanstd([np.float64(v) for v in vals]), (float(np.nanmean(vals)), float(np.nanstd(vals)))
+        assert got == want or all(g != g and x != x or g == x for g, x in zip(got, want)), (vals, got, want)
