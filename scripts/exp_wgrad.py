@@ -9,11 +9,13 @@ import himo_amd.seflow.train  # noqa: F401  (registers the training entry points
 
 dev = torch.device("cuda", 0)
 lib = _lib.load()
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 1          # samples per pass (SeFlowTrainer(batch=...)): n images x BATCH
 shapes = [("enc1.x", 3, 256, 256, 64, 64, 3), ("enc2.x", 3, 128, 128, 128, 128, 5), ("enc3.x", 3, 64, 64, 256, 256, 5),
           ("dec1.u4", 1, 128, 128, 512, 256, 1), ("dec1.u5", 1, 128, 128, 256, 256, 1), ("dec2.u4", 1, 256, 256, 256, 128, 1),
           ("dec2.u5", 1, 256, 256, 128, 128, 1), ("dec3.u4", 1, 512, 512, 128, 64, 1), ("dec3.u5|dec4", 1, 512, 512, 64, 64, 2)]
 tot = {0: 0.0, 2: 0.0}
 for name, n, h, w, ci, co, reps in shapes:
+    n *= BATCH
     x = torch.randn(n, h, w, ci, device=dev)
     dy = torch.randn(n, h, w, co, device=dev) * 1e-3
     dw = torch.empty(3, 3, ci, co, device=dev)
@@ -36,4 +38,4 @@ for name, n, h, w, ci, co, reps in shapes:
         line += f"  flag {flag}: {ms * 1e3:8.1f} us {2.0 * n * h * w * ci * co * 9 / ms / 1e9:6.1f} TF"
     rel = ((outs[2] - outs[0]).abs().max() / outs[0].abs().max()).item()
     print(line + f"  max rel diff {rel:.2e}", flush=True)
-print(f"sum over a step's stride-1 layers: float32 {tot[0]:.3f} ms, split-bf16 {tot[2]:.3f} ms")
+print(f"sum over a step's stride-1 layers, {BATCH} sample(s) per pass: float32 {tot[0] / BATCH:.3f} ms, split-bf16 {tot[2] / BATCH:.3f} ms per sample")
