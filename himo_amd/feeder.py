@@ -266,7 +266,11 @@ class BatchFeeder:
 
     _END = object()
 
-    def __init__(self, source, build, device=None, depth: int = 2):
+    def __init__(self, source, build, device=None, depth: int = 2, stage_threads: int = 4):
+        """``stage_threads``: threads that copy a batch's arrays into the pinned staging memory; 0 = on the feeder thread itself, one
+        numpy call per tensor -- slower staging (one core), but a consumer whose launch thread is interpreter-bound (the evaluator's
+        bucket bookkeeping) is slowed 2-3x by ANY second thread that wakes often, and a pool's futures are exactly that
+        (scripts/exp_eval_feed.py)"""
         self.device = device if device is not None else _lib.require_gpu()
         self.depth, self._build = depth, build
         self._source = iter(source)
@@ -277,7 +281,7 @@ class BatchFeeder:
         self._error = None
         self._stop = False
         from concurrent.futures import ThreadPoolExecutor
-        self._pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="himo-stage")
+        self._pool = ThreadPoolExecutor(max_workers=stage_threads, thread_name_prefix="himo-stage") if stage_threads > 0 else None
         self._thread = threading.Thread(target=self._work, name="himo-batch-feeder", daemon=True)
         self._thread.start()
 
@@ -302,7 +306,9 @@ class BatchFeeder:
                     # 30 MB) as one job kept one thread busy for 6 ms while the others idled
                     # (small tensors -- masks, labels, time stamps -- stay ONE job: a future costs ~40 us of interpreter time)
                     host, at = pin.numpy(), 0
-                    if pin.numel() * pin.element_size() < (4 << 20) or len(parts) == 1:
+                    if self._pool is None:
+                        np.concatenate(parts, 0, host, casting="unsafe")
+                    elif pin.numel() * pin.element_size() < (4 << 20) or len(parts) == 1:
                         jobs.append((self._pool.submit(np.concatenate, parts, 0, host, casting="unsafe"), None, None))
                     else:
                         for p in parts:
@@ -329,7 +335,8 @@ class BatchFeeder:
             self._error = e
         finally:
             _return_arenas(self._slots, self._slot_done)
-            self._pool.shutdown(wait=False)
+            if self._pool is not None:
+                self._pool.shutdown(wait=False)
             self._offer(self._END)
 
     def _offer(self, item) -> bool:
@@ -601,7 +608,7 @@ class EvalFeeder(BatchFeeder):
     """``eval.EvalBatch`` objects for the evaluator / scorer.  ``source`` yields lists of frame dicts (one list = one batch),
     or ``(frames, comp_dis_list)`` pairs for the zip mode (eval.py:303-304)."""
 
-    def __init__(self, source, res_name: str = "", device=None, depth: int = 2):
+    def __init__(self, source, res_name: str = "", device=None, depth: int = 2, stage_threads: int = 4):
         from .eval import EvalBatch
         dev = device if device is not None else _lib.require_gpu()
 
@@ -610,4 +617,4 @@ class EvalFeeder(BatchFeeder):
             eb = EvalBatch.from_frames(list(frames), res_name, comp_dis, device=dev, upload=upload)
             b = eb.batch
             return eb, [b.offsets, b.pose0, b.pose1, b.pc0, b.lidar_dt, b.gm0, b.flow_is_valid, eb.gt, eb.category, eb.instance, eb.est]
-        super().__init__(source, build, device=dev, depth=depth)
+        super().__init__(source, build, device=dev, depth=depth, stage_threads=stage_threads)

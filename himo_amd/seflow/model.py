@@ -238,8 +238,11 @@ class SeFlowNet:
         # when it writes a NaN / inf flow value (csrc/gruhead.hip).  [1 + k] low-side guard of split-output layer k
         # (himo_conv_desc.d_range_seen): set by the layer when it sees an output of magnitude >= 2^-6; a word still 0 after a
         # forward pass = that layer's activations sit on the split's absolute floor (``range_ok``)
-        self.guard = torch.zeros(1 + self.MAX_RANGE_SLOTS, dtype=torch.int32, device=dev)
+        # [-1]: "a backbone pass ran since the words were cleared" (set by ``backbone``): with no pass in between -- an empty batch --
+        # the low-side words are still 0 and must not read as "underflow" 
+        self.guard = torch.zeros(2 + self.MAX_RANGE_SLOTS, dtype=torch.int32, device=dev)
         self.nonfinite = self.guard[:1]
+        self._ran_word = self.guard[-1:]
         self._range_slots = {}
         self._range = _f32x(spec.POINT_CLOUD_RANGE[:3])
         self._voxel = _f32x(spec.VOXEL_SIZE)
@@ -326,7 +329,7 @@ class SeFlowNet:
         w = [int(v) for v in words]
         if w[0] != 0:
             return "overflow"
-        if any(w[1 + k] == 0 for k in self._range_slots.values()):
+        if w[-1] != 0 and any(w[1 + k] == 0 for k in self._range_slots.values()):
             return "underflow"
         return None
 
@@ -433,6 +436,8 @@ class SeFlowNet:
         if not 1 <= n_samples <= self.max_batch:
             raise ValueError(f"n_samples must be in 1..{self.max_batch}")
         self._nb = n_samples
+        if self.packed_format == 1:
+            self._ran_word.fill_(1)                       # (stream-ordered: the guard words' read-back sees it with this pass's words)
         plan = self._plans.get(n_samples)
         if self.use_plan and plan is not None:
             ops, n = plan

@@ -49,6 +49,13 @@ for n in (4, 12):
         m.step_batch(eb)
     m.flush(); torch.cuda.synchronize()
     print(f"EvalFeeder + step_batch, {n} batches: {1e3 * (time.perf_counter() - t0) / (n * B):.3f} ms per sweep")
+for st in (0, 1, 2):
+    for n in (4, 12):
+        t0 = time.perf_counter()
+        for eb in EvalFeeder((frames[(k % 2) * B:(k % 2 + 1) * B] for k in range(n)), res_name="seflowpp_best", device=dev, stage_threads=st):
+            m.step_batch(eb)
+        m.flush(); torch.cuda.synchronize()
+        print(f"EvalFeeder(stage_threads={st}) + step_batch, {n} batches: {1e3 * (time.perf_counter() - t0) / (n * B):.3f} ms per sweep")
 t0 = time.perf_counter()
 for eb in EvalFeeder((frames[(k % 2) * B:(k % 2 + 1) * B] for k in range(12)), res_name="seflowpp_best", device=dev):
     pass

@@ -259,6 +259,31 @@ def test_flows_never_returns_an_overflowed_batch(gpu):
         HiMoPipeline(device=gpu, max_points=9_000, max_batch=1, params=big, precision="f16x2").flows(samples)
 
 
+def test_an_empty_batch_is_not_an_underflow(gpu):
+    """once the low-side guard words of the fp16 split are registered, a call with NO samples (nothing ran between the
+    clear and the read-back: every word still 0) must not read as "activations on the split's floor": explicit f16x2 does not
+    raise, auto does not leave the fp16 split -- and the next real batch is still checked"""
+    from himo_amd.pipeline import HiMoPipeline, Sample
+    from himo_amd.seflow import spec
+    from himo_amd.synthetic import make_frame
+    frames = [make_frame(60 + i, n_points=6_000) for i in range(3)]
+    samples = [Sample.from_frames(frames[0], frames[1], frames[2], device=gpu)]
+    for precision in ("f16x2", "auto"):
+        pipe = HiMoPipeline(device=gpu, max_points=7_000, max_batch=1, params=spec.init_params(3), precision=precision)
+        first = pipe.flows(samples)[0].clone()
+        assert pipe.net._range_slots                                  # the words exist now
+        assert pipe.flows([]) == []
+        assert pipe.net.precision == "f16x2"
+        assert torch.equal(pipe.flows(samples)[0], first)
+    tiny = dict(spec.init_params(3))
+    tiny["enc1.0.weight"] = tiny["enc1.0.weight"] * 1e-6             # ... and a layer that really sits on the floor is still caught
+    tiny["enc1.0.bias"] = tiny["enc1.0.bias"] * 1e-6
+    tiny["enc1.0.bn.gamma"] = tiny["enc1.0.bn.gamma"] * 1e-6
+    tiny["enc1.0.bn.beta"] = tiny["enc1.0.bn.beta"] * 1e-6
+    with pytest.raises(FloatingPointError):
+        HiMoPipeline(device=gpu, max_points=7_000, max_batch=1, params=tiny, precision="f16x2").flows(samples)
+
+
 @pytest.mark.parametrize("n_points", [2_000, 120_000])
 def test_config2_run_over_the_reference_frame_list(gpu, oracle, tmp_path, monkeypatch, n_points):
     """BASELINE config 2 (the data itself is absent): the reference's own frame lists -- 70 eval frames of 13 scenes
