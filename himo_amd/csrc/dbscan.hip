@@ -43,36 +43,58 @@ __global__ __launch_bounds__(256) void db_count_kernel(int n, const float* __res
     cell_id[i] = c;
 }
 
-// exclusive scan of v[0..n) in place by ONE block, tile by tile (4096 values: every thread loads four NEIGHBOURING values, so a wave
-// reads 1 KB runs -- the round-5 form gave every thread a contiguous chunk of n / 1024 values: 131 us for 120k values, stride-n/1024
-// accesses; this one ~10 us); wave shuffles inside a wave, 16 wave totals through LDS; v[n] = the total
+// exclusive scan of v[0..n) in place, v[n] = the total, as TWO launches over tiles of 4096 values (four NEIGHBOURING values per thread:
+// a wave reads 1 KB runs; wave shuffles inside a wave, 16 wave totals through LDS): (1) every block scans its own tile and leaves the
+// tile's total in tile_sum[block]; (2) every block adds the sum of the tiles before it (a handful of values: one wave sums them).
+// History: round 5 gave every thread of ONE block a contiguous chunk (stride-n/1024 accesses: 131 us for 120k values); ONE block walking
+// the tiles coalesced took 48 us (a load latency per tile, 30 tiles); this takes ~2 x 4.
 constexpr int kDbScanTile = 4096;
-__global__ __launch_bounds__(1024) void db_scan_kernel(int* __restrict__ v, int n) {
+__global__ __launch_bounds__(1024) void db_scan_tiles_kernel(int* __restrict__ v, int n, int* __restrict__ tile_sum) {
     __shared__ int wsum[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int carry = 0;
-    for (int base = 0; base < n; base += kDbScanTile) {
-        const int at = base + threadIdx.x * 4;
-        int x[4];
+    const int at = blockIdx.x * kDbScanTile + threadIdx.x * 4;
+    int x[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = at + k < n ? v[at + k] : 0;
-        const int mine = x[0] + x[1] + x[2] + x[3];
-        int incl = mine;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int y = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += y;
-        }
-        if (lane == 63) wsum[w] = incl;
-        __syncthreads();
-        int run = carry + incl - mine, total = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { const int t = wsum[k]; total += t; if (k < w) run += t; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { if (at + k < n) v[at + k] = run; run += x[k]; }
-        carry += total;
-        __syncthreads();
+    for (int k = 0; k < 4; ++k) x[k] = at + k < n ? v[at + k] : 0;
+    const int mine = x[0] + x[1] + x[2] + x[3];
+    int incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += y;
     }
-    if (threadIdx.x == 0) v[n] = carry;
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int run = incl - mine, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int t = wsum[k]; total += t; if (k < w) run += t; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (at + k < n) v[at + k] = run; run += x[k]; }
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void db_scan_offsets_kernel(int* __restrict__ v, int n, const int* __restrict__ tile_sum) {
+    __shared__ int s_before, s_all;
+    if (threadIdx.x < 64) {                                     // one wave: the tiles before this block's, and all of them (last block)
+        int before = 0, all = 0;
+        for (int t = threadIdx.x; t < (int)gridDim.x; t += 64) {
+            const int x = tile_sum[t];
+            all += x;
+            if (t < (int)blockIdx.x) before += x;
+        }
+        for (int off = 32; off; off >>= 1) { before += __shfl_xor(before, off, 64); all += __shfl_xor(all, off, 64); }
+        if (threadIdx.x == 0) { s_before = before; s_all = all; }
+    }
+    __syncthreads();
+    const int at = blockIdx.x * kDbScanTile + threadIdx.x * 4, add = s_before;
+    if (add) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (at + k < n) v[at + k] += add;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) v[n] = s_all;
+}
+static void db_scan(int* v, int n, int* tile_sum, hipStream_t s) {
+    const int tiles = (n + kDbScanTile - 1) / kDbScanTile;
+    hipLaunchKernelGGL(db_scan_tiles_kernel, dim3(tiles), dim3(1024), 0, s, v, n, tile_sum);
+    hipLaunchKernelGGL(db_scan_offsets_kernel, dim3(tiles), dim3(1024), 0, s, v, n, tile_sum);
 }
 
 __global__ __launch_bounds__(256) void db_scatter_kernel(int n, const float* __restrict__ xyz, int pitch, const int* __restrict__ cell_id,
@@ -98,20 +120,33 @@ __device__ inline void db_neighbours(const DbGrid& g, int cx, int cy, const int*
     }
 }
 
-// one thread per SORTED row: core flag of its point (indexed by original index)
+// one WAVE per sorted row (grid-stride over the rows that take part; the 64 lanes share the walk over the 3 x 3 cells, one row of three
+// cells at a time, and stop as soon as min_pts are counted): core flag of its point (indexed by original index)
 __global__ __launch_bounds__(256) void db_core_kernel(const float4* __restrict__ rows, DbGrid g, const int* __restrict__ offset, float eps2,
                                                       int min_pts, unsigned char* __restrict__ core) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= offset[g.gw * g.gh]) return;                       // the number of points that take part (db_scan_kernel's total)
-    const float4 p = rows[s];
-    const int cx = db_clamp((int)floorf((p.x - g.x0) * g.inv_cell), g.gw - 1), cy = db_clamp((int)floorf((p.y - g.y0) * g.inv_cell), g.gh - 1);
-    int cnt = 0;
-    db_neighbours(g, cx, cy, offset, rows, [&](const float4& q) {
-        const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
-        if (dx * dx + dy * dy + dz * dz <= eps2) ++cnt;
-        return cnt < min_pts;
-    });
-    core[__float_as_int(p.w)] = cnt >= min_pts ? 1 : 0;
+    const int total = offset[g.gw * g.gh];                      // the number of points that take part (the scan's total)
+    const int lane = threadIdx.x & 63, n_waves = gridDim.x * 4;
+    for (int s = blockIdx.x * 4 + (threadIdx.x >> 6); s < total; s += n_waves) {
+        const float4 p = rows[s];
+        const int cx = db_clamp((int)floorf((p.x - g.x0) * g.inv_cell), g.gw - 1), cy = db_clamp((int)floorf((p.y - g.y0) * g.inv_cell), g.gh - 1);
+        int cnt = 0;
+        for (int dy = -1; dy <= 1 && cnt < min_pts; ++dy) {
+            const int y = cy + dy;
+            if (y < 0 || y >= g.gh) continue;
+            const int x_lo = cx > 0 ? cx - 1 : 0, x_hi = cx + 1 < g.gw ? cx + 1 : g.gw - 1;
+            const int lo = offset[y * g.gw + x_lo], hi = offset[y * g.gw + x_hi + 1];      // the three cells of a row are contiguous
+            for (int t0 = lo; t0 < hi && cnt < min_pts; t0 += 64) {
+                bool in = false;
+                if (t0 + lane < hi) {
+                    const float4 q = rows[t0 + lane];
+                    const float dx = q.x - p.x, dy2 = q.y - p.y, dz = q.z - p.z;
+                    in = dx * dx + dy2 * dy2 + dz * dz <= eps2;
+                }
+                cnt += __popcll(__ballot(in));
+            }
+        }
+        if (lane == 0) core[__float_as_int(p.w)] = cnt >= min_pts ? 1 : 0;
+    }
 }
 
 __device__ inline int db_find(const int* __restrict__ parent, int x) {
@@ -150,7 +185,7 @@ __device__ inline void db_union(int* __restrict__ parent, int a, int b) {
 // dense object and chasing un-compressed parent chains for each: 355 us per call.)
 __global__ __launch_bounds__(256) void db_union_kernel(const float4* __restrict__ rows, DbGrid g, const int* __restrict__ offset, float eps2,
                                                        const unsigned char* __restrict__ core, int* __restrict__ parent) {
-    const int total = offset[g.gw * g.gh];                      // the number of points that take part (db_scan_kernel's total)
+    const int total = offset[g.gw * g.gh];                      // the number of points that take part (the scan's total)
     const int lane = threadIdx.x & 63, n_waves = gridDim.x * 4;
     for (int s = blockIdx.x * 4 + (threadIdx.x >> 6); s < total; s += n_waves) {
         const float4 p = rows[s];
@@ -174,33 +209,46 @@ __global__ __launch_bounds__(256) void db_union_kernel(const float4* __restrict_
     }
 }
 
-// root[i] = lowest index of i's cluster, or -1 (noise / skipped); is_root[i] = 1 for the cluster's lowest index
+// root[i] = lowest index of i's cluster, or -1 (noise / skipped); is_root[i] = 1 for the cluster's lowest index.  One WAVE per sorted
+// row: a core point is one find; a border candidate's lanes share the walk over its 3 x 3 cells and the lowest root among its core
+// neighbours is a wave minimum
 __global__ __launch_bounds__(256) void db_root_kernel(const float4* __restrict__ rows, DbGrid g, const int* __restrict__ offset, float eps2,
                                                       const unsigned char* __restrict__ core, const int* __restrict__ parent, int* __restrict__ root,
                                                       int* __restrict__ is_root) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= offset[g.gw * g.gh]) return;                       // the number of points that take part (db_scan_kernel's total)
-    const float4 p = rows[s];
-    const int i = __float_as_int(p.w);
-    int r = -1;
-    if (core[i]) {
-        r = db_find(parent, i);
-    } else {
-        const int cx = db_clamp((int)floorf((p.x - g.x0) * g.inv_cell), g.gw - 1), cy = db_clamp((int)floorf((p.y - g.y0) * g.inv_cell), g.gh - 1);
-        db_neighbours(g, cx, cy, offset, rows, [&](const float4& q) {
-            const int j = __float_as_int(q.w);
-            if (core[j]) {
-                const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
-                if (dx * dx + dy * dy + dz * dz <= eps2) {
-                    const int rj = db_find(parent, j);
-                    r = (r < 0 || rj < r) ? rj : r;
+    const int total = offset[g.gw * g.gh];
+    const int lane = threadIdx.x & 63, n_waves = gridDim.x * 4;
+    for (int s = blockIdx.x * 4 + (threadIdx.x >> 6); s < total; s += n_waves) {
+        const float4 p = rows[s];
+        const int i = __float_as_int(p.w);
+        int r = 0x7fffffff;
+        if (core[i]) {
+            r = db_find(parent, i);
+        } else {
+            const int cx = db_clamp((int)floorf((p.x - g.x0) * g.inv_cell), g.gw - 1), cy = db_clamp((int)floorf((p.y - g.y0) * g.inv_cell), g.gh - 1);
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int y = cy + dy;
+                if (y < 0 || y >= g.gh) continue;
+                const int x_lo = cx > 0 ? cx - 1 : 0, x_hi = cx + 1 < g.gw ? cx + 1 : g.gw - 1;
+                const int lo = offset[y * g.gw + x_lo], hi = offset[y * g.gw + x_hi + 1];
+                for (int t = lo + lane; t < hi; t += 64) {
+                    const float4 q = rows[t];
+                    const int j = __float_as_int(q.w);
+                    if (core[j]) {
+                        const float dx = q.x - p.x, dy2 = q.y - p.y, dz = q.z - p.z;
+                        if (dx * dx + dy2 * dy2 + dz * dz <= eps2) {
+                            const int rj = db_find(parent, j);
+                            r = rj < r ? rj : r;
+                        }
+                    }
                 }
             }
-            return true;
-        });
+            for (int off = 32; off; off >>= 1) { const int o = __shfl_xor(r, off, 64); r = o < r ? o : r; }
+        }
+        if (lane == 0) {
+            root[i] = r == 0x7fffffff ? -1 : r;
+            if (r == i) is_root[i] = 1;
+        }
     }
-    root[i] = r;
-    if (r == i) is_root[i] = 1;
 }
 
 __global__ __launch_bounds__(256) void db_init_kernel(int n, int* __restrict__ parent, int* __restrict__ root, int* __restrict__ is_root,
@@ -220,7 +268,7 @@ __global__ __launch_bounds__(256) void db_label_kernel(int n, const int* __restr
 }
 
 struct DbLayout {
-    size_t count, cursor, cell_id, rows, parent, root, is_root, core, total;
+    size_t count, cursor, cell_id, rows, parent, root, is_root, core, tile_sum, total;
 };
 static DbLayout db_layout(int n, int gw, int gh) {
     DbLayout L{};
@@ -229,6 +277,7 @@ static DbLayout db_layout(int n, int gw, int gh) {
     auto take = [&](size_t bytes) { const size_t at = o; o += round_up(bytes, 256); return at; };
     L.count = take((cells + 1) * 4); L.cursor = take(cells * 4); L.cell_id = take((size_t)n * 4); L.rows = take((size_t)n * 16);
     L.parent = take((size_t)n * 4); L.root = take((size_t)n * 4); L.is_root = take(((size_t)n + 1) * 4); L.core = take((size_t)n);
+    L.tile_sum = take((((size_t)(n > (int)cells ? n : (int)cells) + kDbScanTile - 1) / kDbScanTile + 1) * 4);
     L.total = o;
     return L;
 }
@@ -263,7 +312,9 @@ extern "C" int himo_dbscan(int n, const float* d_xyz, int pitch, const unsigned 
     int* cell_id = reinterpret_cast<int*>(w + L.cell_id); float4* rows = reinterpret_cast<float4*>(w + L.rows);
     int* parent = reinterpret_cast<int*>(w + L.parent); int* root = reinterpret_cast<int*>(w + L.root);
     int* is_root = reinterpret_cast<int*>(w + L.is_root); unsigned char* core = reinterpret_cast<unsigned char*>(w + L.core);
+    int* tile_sum = reinterpret_cast<int*>(w + L.tile_sum);
     const int cells = grid_w * grid_h, nb = (n + 255) / 256;
+    const int nw = nb < 4096 ? nb : 4096;                       // blocks of the wave-per-row kernels (grid-stride over the participating rows)
     const DbGrid g{x0, y0, 1.0f / cell, grid_w, grid_h};
     const float eps2 = eps * eps;
     ProfScope ps("dbscan_kernels", s);
@@ -271,13 +322,13 @@ extern "C" int himo_dbscan(int n, const float* d_xyz, int pitch, const unsigned 
     HIMO_HIP(hipMemsetAsync(cursor, 0, (size_t)cells * 4, s));
     hipLaunchKernelGGL(db_init_kernel, dim3(nb), dim3(256), 0, s, n, parent, root, is_root, core);
     hipLaunchKernelGGL(db_count_kernel, dim3(nb), dim3(256), 0, s, n, d_xyz, pitch, d_skip, g, count, cell_id);
-    hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, s, count, cells);              // count -> offsets; count[cells] = points taking part
+    db_scan(count, cells, tile_sum, s);                                                       // count -> offsets; count[cells] = points taking part
     hipLaunchKernelGGL(db_scatter_kernel, dim3(nb), dim3(256), 0, s, n, d_xyz, pitch, cell_id, count, cursor, rows);
     // (the sorted-row kernels are launched over n slots and stop at the number of participating points, which only the device knows)
-    hipLaunchKernelGGL(db_core_kernel, dim3(nb), dim3(256), 0, s, rows, g, count, eps2, min_pts, core);
-    hipLaunchKernelGGL(db_union_kernel, dim3(nb < 4096 ? nb : 4096), dim3(256), 0, s, rows, g, count, eps2, core, parent);
-    hipLaunchKernelGGL(db_root_kernel, dim3(nb), dim3(256), 0, s, rows, g, count, eps2, core, parent, root, is_root);
-    hipLaunchKernelGGL(db_scan_kernel, dim3(1), dim3(1024), 0, s, is_root, n);                // is_root -> rank of each cluster's lowest index
+    hipLaunchKernelGGL(db_core_kernel, dim3(nw), dim3(256), 0, s, rows, g, count, eps2, min_pts, core);
+    hipLaunchKernelGGL(db_union_kernel, dim3(nw), dim3(256), 0, s, rows, g, count, eps2, core, parent);
+    hipLaunchKernelGGL(db_root_kernel, dim3(nw), dim3(256), 0, s, rows, g, count, eps2, core, parent, root, is_root);
+    db_scan(is_root, n, tile_sum, s);                                                         // is_root -> rank of each cluster's lowest index
     hipLaunchKernelGGL(db_label_kernel, dim3(nb), dim3(256), 0, s, n, root, is_root, d_labels, d_n_clusters);
     HIMO_LAUNCH_CHECK("dbscan kernels");
     return HIMO_OK;

@@ -520,8 +520,7 @@ class TrainFeeder:
                 t.record_stream(tls.stream)
             if "gm0" in dev:
                 from .seflow.ssl_label import auto_labels
-                l0, l1 = auto_labels(dev["pc0"], dev["pc1"], dev["gm0"], dev["gm1"], poses[1], poses[2])
-                top = torch.maximum(l0.max() if l0.numel() else l0.new_zeros(()), l1.max() if l1.numel() else l1.new_zeros(()))
+                l0, l1, top = auto_labels(dev["pc0"], dev["pc1"], dev["gm0"], dev["gm1"], poses[1], poses[2], return_top=True)
                 tls.word.copy_(top.reshape(1), non_blocking=True)
                 keep = self._cache is not None and self._cache_budget > 0
                 if keep:                                       # a host copy for the later epochs, behind the same wait as the count

@@ -111,8 +111,8 @@ def make_sample(dataset, trip, device, label_key: str = "flow_instance_id"):
     p0, p1 = up(h["pc0"]), up(h["pc1"])
     if "gm0" in h:
         from .ssl_label import auto_labels
-        l0, l1 = auto_labels(p0, p1, h["gm0"], h["gm1"], h["pose0"], h["pose1"])
-        n_labels = int(torch.maximum(l0.max() if l0.numel() else l0.new_zeros(()), l1.max() if l1.numel() else l1.new_zeros(())).item()) + 1
+        l0, l1, top = auto_labels(p0, p1, h["gm0"], h["gm1"], h["pose0"], h["pose1"], return_top=True)
+        n_labels = int(top.item()) + 1
     else:
         l0, l1 = lab(h["lab0"]), lab(h["lab1"])
         n_labels = int(max(int(np.max(h["lab0"], initial=0)), int(np.max(h["lab1"], initial=0)))) + 1

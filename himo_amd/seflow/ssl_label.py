@@ -97,9 +97,11 @@ def _compact(pts: torch.Tensor, use: torch.Tensor):
     return buf, dest, pos[-1:]
 
 
-def auto_labels(pc0, pc1, ground0, ground1, pose0, pose1, eps: float = EPS, min_pts: int = MIN_PTS, dyn_dist: float = DYN_DIST):
+def auto_labels(pc0, pc1, ground0, ground1, pose0, pose1, eps: float = EPS, min_pts: int = MIN_PTS, dyn_dist: float = DYN_DIST,
+                return_top: bool = False):
     """(label0 (n0,), label1 (n1,)) int32 device tensors for the sweep pair (module docstring).  ``pc*``: (n, >= 3) float32 in their
-    own sensor frames, ``ground*``: bool masks, ``pose*``: 4x4 world poses.
+    own sensor frames, ``ground*``: bool masks, ``pose*``: 4x4 world poses.  ``return_top``: also the highest label of the pair as a
+    1-element int32 device tensor (= the larger of the two cluster counts the clustering kernels leave: no reduction over the labels).
 
     ONE host wait per pair -- the sizes of the two in-range non-ground subsets, which the nearest-neighbour search takes as host
     integers; they come back through pinned memory behind an event on the current stream.  Everything else is enqueued without
@@ -116,8 +118,8 @@ def auto_labels(pc0, pc1, ground0, ground1, pose0, pose1, eps: float = EPS, min_
         out = []
         for pts, g in ((a, g0), (b, g1)):
             skip = (g | (pts[:, :2].abs().amax(dim=1) > RANGE_NET)) if pts.shape[0] else torch.zeros(0, dtype=torch.bool, device=dev)
-            out.append(dbscan(pts, eps, min_pts, skip)[0])
-        return out[0], out[1]
+            out.append(dbscan(pts, eps, min_pts, skip))
+        return (out[0][0], out[1][0], torch.maximum(out[0][1], out[1][1])) if return_top else (out[0][0], out[1][0])
     far2 = float(dyn_dist) ** 2
     inv_ref2 = 1.0 / (DYN_REF_RANGE * DYN_REF_RANGE)
     use_a = ~(g0 | (a[:, :2].abs().amax(dim=1) > RANGE_NET))   # step 0
@@ -140,5 +142,5 @@ def auto_labels(pc0, pc1, ground0, ground1, pose0, pose1, eps: float = EPS, min_
             x, y = pts[:, 0], pts[:, 1]
             bar2 = far2 * torch.clamp((x * x + y * y) * inv_ref2, min=1.0)       # (dyn_dist * max(1, r / 30 m))^2, float32 as the oracle
             skip = skip | (d2[dest] <= bar2)                    # a close return in the other sweep: static (the dump row holds inf)
-        out.append(dbscan(pts, eps, min_pts, skip)[0])
-    return out[0], out[1]
+        out.append(dbscan(pts, eps, min_pts, skip))
+    return (out[0][0], out[1][0], torch.maximum(out[0][1], out[1][1])) if return_top else (out[0][0], out[1][0])
