@@ -3,14 +3,15 @@
 +optimizer.scheduler.name=StepLR +...step_size=3 +...gamma=0.5``, assets/slurm/ssl-train-av2.sh:31-34, on 4 GPUs :3).
 
 PARITY UNPINNED: ``OpenSceneFlow/train.py`` is absent, so only the launcher's numbers are mirrored: epochs over the
-dataset, ``batch_size`` samples per optimiser step (spread over the ranks: every rank sums the gradients of ITS
-samples, ONE flat all-reduce adds the ranks' sums and sample counts, and the sum is divided by the global count: every
-sample of a batch weighs the same however it splits over the ranks), Adam at ``lr`` with StepLR(step_size, gamma) per epoch, the
+dataset, ``batch_size`` samples per optimiser step (spread over the ranks: a rank's share goes through the network in ONE
+pass, the ranks' gradient sums and sample counts are added -- bucket by bucket under the backward pass, ``train.BucketedAllReduce``
+-- and the sum is divided by the global count: every sample of a batch weighs the same however it splits over the ranks),
+``num_workers`` threads preparing samples ahead of the step (``feeder.TrainFeeder``), Adam at ``lr`` with StepLR(step_size, gamma) per epoch, the
 ``save_top`` best checkpoints kept by the epoch's validation (or mean training) loss, and resuming from a checkpoint.
 Conventions of this build: BatchNorm runs in TRAINING mode by default (``batchnorm="batch"``: batch statistics, trainable
 gamma / beta, running statistics with momentum 0.1 -- the launcher passes no checkpoint, so the reference's job trains from
-scratch; statistics are per forward call = per sample on a rank, un-synchronised across ranks like DDP's default, and rank
-0's running statistics go into the checkpoints); ``batchnorm="frozen"`` is the fine-tuning convention (running statistics
+scratch; statistics are per forward call = over a rank's share of the step's batch, as torch.nn.BatchNorm takes them in a
+per-process batch, un-synchronised across ranks like DDP's default, and rank 0's running statistics go into the checkpoints); ``batchnorm="frozen"`` is the fine-tuning convention (running statistics
 and affine folded into constants); validation always uses the running statistics; the labels (0 static, > 0 dynamic
 cluster id) are GENERATED from the sweep pair on the GPU by default (``ssl_label="seflow_auto"``, the launcher's
 ``+ssl_label=seflow_auto``: seflow/ssl_label.py -- nearest-neighbour dynamic candidates + DBSCAN; the reference's generator

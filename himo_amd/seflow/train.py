@@ -1,14 +1,16 @@
 """Training side of the scene-flow network (stage a11 / BASELINE config 5): forward with saved activations, backward
-pass and optimiser step, one process per GPU with a single flat gradient all-reduce over RCCL.
+pass and optimiser step, one process per GPU, the gradient exchange over RCCL bucket by bucket under the backward pass.
 
 PARITY UNPINNED: the reference trains through ``OpenSceneFlow/train.py`` (assets/slurm/ssl-train-av2.sh:31-34), which
-is absent.  Conventions of this build: BatchNorm statistics frozen (scale / shift are constants), Adam, unit-weight
-SeFlow-style loss (himo_amd/ssl_loss.py).  The oracle is PyTorch CPU autograd through oracle/seflow_oracle.py.
+is absent.  Conventions of this build: BatchNorm in training mode by default (batch statistics over a pass's samples,
+trainable gamma / beta; ``batchnorm="frozen"`` folds them to constants), Adam, unit-weight SeFlow-style loss
+(himo_amd/ssl_loss.py).  The oracle is PyTorch CPU autograd through oracle/seflow_oracle.py.
 
 ``HeadTrainer``: the per-point head (4 GRU iterations -> MLP) with saved states and its BPTT backward pass.
-``SeFlowTrainer``: the whole network -- pillar features, encoder, decoder, head -- forward with saved activations,
-backward (every gradient a fixed-order reduction: no float atomics), one flat parameter / gradient / Adam-moment
-buffer, and a single all-reduce of the flat gradient across ranks.
+``SeFlowTrainer``: the whole network -- pillar features, encoder, decoder, head -- over a per-process BATCH of samples in one
+forward / backward pass (``batch=``), backward (every gradient a fixed-order reduction: no float atomics), one flat parameter /
+gradient / Adam-moment buffer.
+``BucketedAllReduce``: the step's data-parallel exchange, started per bucket as the backward pass completes it.
 """
 from __future__ import annotations
 
