@@ -82,7 +82,7 @@ def parse_args():
     ap.add_argument("--leg-fit-steps", type=int, default=200,
                     help="optimiser steps of the `leg_fit_h5` leg (seflow.fit.fit over .h5 scene files, batch_size 8); 0 skips the leg")
     ap.add_argument("--leg-fastnsf-fits", type=int, default=6, help="timed fits of the `leg_fastnsf` leg (after 1 warm-up)")
-    ap.add_argument("--fit-workers", type=int, default=2, help="`leg_fit_h5`: reader threads of the training feeder (0: samples built inside the step loop)")
+    ap.add_argument("--fit-workers", type=int, default=1, help="`leg_fit_h5`: reader threads of the training feeder (0: samples built inside the step loop)")
     ap.add_argument("--cloud", default="uniform", choices=["uniform", "rings"],
                     help="synthetic sweeps: SURVEY 8(d) uniform cloud with instances (default) or the LiDAR-like ring cloud")
     ap.add_argument("--sample-sets", type=int, default=3, help="distinct input batches rotated through the timed steps")
@@ -952,6 +952,7 @@ def extra_workload_legs(args, device) -> dict:
         per_step = a.train_batch                                   # samples per step of this leg
         result = {}
         try:
+            torch.cuda.reset_peak_memory_stats(device)
             if name == "train":
                 step, obj = make_train_step(a, 0, device, result)
                 dominant, nsf, step_single = TRAIN_DOMINANT, None, None
@@ -1012,6 +1013,8 @@ def extra_workload_legs(args, device) -> dict:
                           "note": "gradient / trajectory parity vs the CPU restatement (oracle/fastnsf_oracle.py, unpinned): tests/test_fastnsf_gpu.py"}
             leg = {"frames_per_s": steps * per_step / el, "ms_per_step": el / steps * 1e3, "steps": steps, "samples_per_step": per_step, "warmup": warm,
                    "points_per_frame": a.points, "cloud": a.cloud, "workload": workload, "dtype": dtype, "roofline": roof, "parity": parity}
+            if name == "train":
+                leg["device_memory_GB_peak"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 1)      # (this leg's trainer, samples and workspaces)
             if name == "train" and side:
                 leg["frames_per_s_without_side_streams"] = per_step / el_train_single
             if name == "fastnsf" and el_single is not None:

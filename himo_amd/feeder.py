@@ -437,8 +437,8 @@ class TrainFeeder:
 
     _END = object()
 
-    def __init__(self, dataset, trips, device=None, label_key: str = "seflow_auto", depth: int = 2, workers: int = 2,
-                 label_lanes: int = 2, label_priority: int = 0, label_cache: dict | None = None, label_cache_bytes: int = 4 << 30):
+    def __init__(self, dataset, trips, device=None, label_key: str = "seflow_auto", depth: int = 2, workers: int = 1,
+                 label_lanes: int = 1, label_priority: int = 0, label_cache: dict | None = None, label_cache_bytes: int = 4 << 30):
         """``label_cache``: a dict the caller keeps between feeders over the SAME dataset (``fit``: one per dataset, for the whole
         run).  Generated labels are a pure function of the sweep pair, and the reference's job reads them from files an offline pass
         wrote once; here the first epoch generates them on the device and leaves a host copy in the dict (up to ``label_cache_bytes``),

@@ -124,7 +124,7 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
         step_size: int = 3, gamma: float = 0.5, save_top: int = 3, val_dataset=None, resume=None, precision: str = "mixed",
         max_points: int = 140_000, device=None, seed: int = 0, max_steps: int | None = None, log=print,
         trainer: SeFlowTrainer | None = None, batchnorm: str = "batch", ssl_label: str = "seflow_auto",
-        num_workers: int = 2, prefetch: int = 2, label_lanes: int = 2,
+        num_workers: int = 1, prefetch: int = 2, label_lanes: int = 1,
         cache_labels: bool = True) -> dict:
     """Train for ``epochs`` passes over ``dataset``; returns {"trainer", "history", "best"}.
 
@@ -241,8 +241,9 @@ def main(argv=None):
                     help="batch: BatchNorm in training mode (from-scratch training, the reference job); frozen: fine-tuning convention")
     ap.add_argument("--ssl_label", default="seflow_auto",
                     help="seflow_auto (the launcher's +ssl_label=seflow_auto): labels generated on the GPU; or the frame key that holds them")
-    ap.add_argument("--num_workers", type=int, default=2,
-                    help="reader threads that prepare samples ahead of the step (the launcher's num_workers=16); 0: inside the step loop")
+    ap.add_argument("--num_workers", type=int, default=1,
+                    help="reader threads that prepare samples ahead of the step (the launcher's num_workers=16; one thread reads ~3.7 k samples/s from "
+                         "warm .h5 files and more of them only contend with the launch thread for the interpreter lock); 0: inside the step loop")
     ap.add_argument("--precision", default="mixed", choices=["mixed", "bf16x3", "f32"])
     a = ap.parse_args(argv)
     with distenv.process_group():
