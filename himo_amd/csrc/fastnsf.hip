@@ -307,6 +307,161 @@ __global__ __launch_bounds__(256, 2) void wgrad_partial_split_kernel(int64_t n, 
                 out[(wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wn * 64 + b * 32 + li] = acc[a][b][r];
 }
 
+// ---- the split-bf16 weight gradient with EVERY operand row read ONCE (round 6; himo_linear_wgrad_ex flag 2 with 128 < cin <= 192 and
+// cout = 128 | 256: the head's gate gradients over the four stacked GRU iterations, 480k rows x 192 -> 128 | 256).  The 128 x 128 block
+// tiles above read each operand tile once per tile of the OTHER operand (X twice, dZ twice for 192 -> 256: 1.7 GB; co-scheduling the tiles
+// of a row chunk on one XCD made the second read an L2 hit, and the kernel still ran at the rate of its operand stream: 347 us, 0.16 of
+// the matrix peak).  Here ONE block of eight waves owns all cin x cout outputs for its run of rows -- wave (wm, wn): input-channel tiles
+// [3 wm, 3 wm + 3) x output tiles [NB wn, NB wn + NB), 3 NB accumulators of 32 x 32 -- so X and dZ leave HBM once (0.86 GB), a stage
+// of 32 rows is (192 + cout) columns of split operands in LDS (72 KB), and a wave issues 9 NB matrix instructions on 2 (3 + NB) fragment
+// reads per 16 rows.  One block per CU (256 blocks: one round), the same partial layout (128 x 128 tiles) and reduce kernels as above;
+// the per-element summation order over the rows of a block is the 128-tile kernel's.
+template <int NB, int STAGE>                               // output tiles per wave: 1 (cout 128) or 2 (cout 256); rows per stage: 32 | 64
+__global__ __launch_bounds__(512, 1) void wgrad_full_split_kernel(int64_t n, const float* __restrict__ X, int x_pitch, int cin,
+                                                                   const float* __restrict__ dZ, int z_pitch, float* __restrict__ partial,
+                                                                   int rows_pb, float* __restrict__ colpart, int n_chunks) {
+    constexpr int CI = 192, CO = NB * 128, kChunks = STAGE / 8, kPad = STAGE + 8;
+    constexpr int kXItems = (CI * kChunks + 511) / 512, kZItems = CO * kChunks / 512;      // staging items per thread: (column, 8-row chunk) pairs
+    __shared__ __attribute__((aligned(16))) unsigned short Xt[2][CI][kPad];
+    __shared__ __attribute__((aligned(16))) unsigned short Zt[2][CO][kPad];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int chunk = (int)blockIdx.x;
+    const int64_t r0 = (int64_t)chunk * rows_pb;
+    const int64_t r1 = r0 + rows_pb < n ? r0 + rows_pb : n;
+    floatx16 acc[3][NB];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // staging item i = thread + 512 k: X items 0 .. 767 = (column i % 192, chunk i / 192), dZ items 0 .. 4 CO - 1 = (column i % CO, chunk
+    // i / CO).  64 divides 192 and CO, so a wave's 64 items share their chunk: row numbers and row bases are scalar, a load is one
+    // global_load_dword with the lane's column as its offset (columns >= cin load column 0 and are staged as zeros)
+    int xcol[kXItems], xch[kXItems], zcol[kZItems], zch[kZItems];
+    bool xlive[kXItems], xok[kXItems];
+#pragma unroll
+    for (int k = 0; k < kXItems; ++k) {
+        const int i = (int)threadIdx.x + 512 * k;
+        xlive[k] = __builtin_amdgcn_readfirstlane((int)(i < kChunks * CI));
+        xch[k] = __builtin_amdgcn_readfirstlane(i / CI);
+        const int c = i % CI;
+        xok[k] = c < cin; xcol[k] = c;
+    }
+#pragma unroll
+    for (int k = 0; k < kZItems; ++k) {
+        const int i = (int)threadIdx.x + 512 * k;
+        zch[k] = __builtin_amdgcn_readfirstlane(i / CO);
+        zcol[k] = i % CO;
+    }
+    float vx[kXItems][8], vz[kZItems][8];
+    const bool want_db = colpart != nullptr;
+    float bsum = 0.f;
+    auto fetch = [&](int64_t base) {
+#pragma unroll
+        for (int k = 0; k < kXItems; ++k) {
+            if (!xlive[k]) continue;
+            const int64_t row0 = base + xch[k] * 8;
+            const float* xr = X + row0 * x_pitch;
+            const int c = xok[k] ? xcol[k] : 0;
+            if (row0 + 8 <= r1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vx[k][j] = xr[(int64_t)j * x_pitch + c];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vx[k][j] = row0 + j < r1 ? xr[(int64_t)j * x_pitch + c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kZItems; ++k) {
+            const int64_t row0 = base + zch[k] * 8;
+            const float* zr = dZ + row0 * z_pitch;
+            if (row0 + 8 <= r1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vz[k][j] = zr[(int64_t)j * z_pitch + zcol[k]];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vz[k][j] = row0 + j < r1 ? zr[(int64_t)j * z_pitch + zcol[k]] : 0.f;
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int k = 0; k < kXItems; ++k) {
+            if (!xlive[k]) continue;
+            if (!xok[k])
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vx[k][j] = 0.f;
+            uint4 h, m;
+            wg_split_pair(vx[k][0], vx[k][1], h.x, m.x); wg_split_pair(vx[k][2], vx[k][3], h.y, m.y);
+            wg_split_pair(vx[k][4], vx[k][5], h.z, m.z); wg_split_pair(vx[k][6], vx[k][7], h.w, m.w);
+            *reinterpret_cast<uint4*>(&Xt[0][xcol[k]][xch[k] * 8]) = h;
+            *reinterpret_cast<uint4*>(&Xt[1][xcol[k]][xch[k] * 8]) = m;
+        }
+#pragma unroll
+        for (int k = 0; k < kZItems; ++k) {
+            if (want_db) bsum += ((vz[k][0] + vz[k][1]) + (vz[k][2] + vz[k][3])) + ((vz[k][4] + vz[k][5]) + (vz[k][6] + vz[k][7]));
+            uint4 h, m;
+            wg_split_pair(vz[k][0], vz[k][1], h.x, m.x); wg_split_pair(vz[k][2], vz[k][3], h.y, m.y);
+            wg_split_pair(vz[k][4], vz[k][5], h.z, m.z); wg_split_pair(vz[k][6], vz[k][7], h.w, m.w);
+            *reinterpret_cast<uint4*>(&Zt[0][zcol[k]][zch[k] * 8]) = h;
+            *reinterpret_cast<uint4*>(&Zt[1][zcol[k]][zch[k] * 8]) = m;
+        }
+    };
+    if (r0 < r1) fetch(r0);
+    for (int64_t base = r0; base < r1; base += STAGE) {
+        __syncthreads();                                   // the previous stage's fragment reads are done
+        stage();
+        __syncthreads();
+        if (base + STAGE < r1) fetch(base + STAGE);
+#pragma unroll
+        for (int ks = 0; ks < STAGE / 16; ++ks) {
+            wg_bf16x8 af[3][2], bf[NB][2];                 // [tile][plane]
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) af[t][pl] = *reinterpret_cast<const wg_bf16x8*>(&Xt[pl][(wm * 3 + t) * 32 + li][ks * 16 + lh * 8]);
+#pragma unroll
+                for (int u = 0; u < NB; ++u) bf[u][pl] = *reinterpret_cast<const wg_bf16x8*>(&Zt[pl][(wn * NB + u) * 32 + li][ks * 16 + lh * 8]);
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], acc[a][b], 0, 0, 0);
+                }
+        }
+    }
+    if (want_db) {                                         // a column's shares (512 / CO threads x their items), fixed order
+        __syncthreads();
+        float* bsh = reinterpret_cast<float*>(&Xt[0][0][0]);
+        bsh[threadIdx.x] = bsum;
+        __syncthreads();
+        if ((int)threadIdx.x < CO) {
+            const int c = threadIdx.x;
+            const float t = NB == 2 ? bsh[c] + bsh[256 + c] : (bsh[c] + bsh[128 + c]) + (bsh[256 + c] + bsh[384 + c]);      // (512 / CO threads per column)
+            colpart[((int64_t)(c / 128) * n_chunks + chunk) * 128 + (c & 127)] = t;
+        }
+    }
+    // partial tiles in the 128 x 128 layout of the kernels above: tile (ci / 128) * (CO / 128) + co / 128
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int ci_t = (wm * 3 + a) * 32, co = (wn * NB + b) * 32 + li;
+            float* out = partial + ((int64_t)((ci_t >> 7) * NB + (co >> 7)) * n_chunks + chunk) * 128 * 128;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci_t + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                out[(ci & 127) * 128 + (co & 127)] = acc[a][b][r];
+            }
+        }
+}
+
 // dW[ci][co] (+)= sum_b partial[tile][b][ci % 128][co % 128], deterministic: a block owns 64 consecutive elements, its
 // four thread groups sum every fourth chunk (four loads in flight per element instead of one serial chain), and the
 // groups are combined in a fixed order
@@ -640,6 +795,21 @@ extern "C" int himo_linear_wgrad_ex(int64_t n, const float* d_x, int x_pitch, in
         ProfScope ps("wgrad_partial_kernel", s);
         const bool vec = !(x_pitch & 3) && !(z_pitch & 3) && !(cin & 3) && !(cout & 3) &&
                          !((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_dz)) & 15);
+        if ((flags & 2u) && cin > 128 && cin <= 192 && (cout == 128 || cout == 256) && n >= 256 * 64) {
+            // every operand row read once: one block of eight waves per run of rows, one block per CU (wgrad_full_split_kernel)
+            int rows_full = (int)(((n + 255) / 256 + 31) / 32 * 32);
+            if (rows_full < kWgRows) rows_full = kWgRows;      // (the workspace is sized for runs of at least kWgRows rows)
+            const int nb_full = (int)((n + rows_full - 1) / rows_full);
+            float* colpart_full = partial + (size_t)ci_tiles * co_tiles * (nb_full + 1) * 128 * 128;
+#define HIMO_WG_FULL(NBV, ST) hipLaunchKernelGGL((wgrad_full_split_kernel<NBV, ST>), dim3(nb_full), dim3(512), 0, s, n, d_x, x_pitch, cin, d_dz, z_pitch, \
+                                                 partial, rows_full, d_db ? colpart_full : nullptr, nb_full)
+            if (cout == 256) HIMO_WG_FULL(2, 32); else HIMO_WG_FULL(1, 32);      // (64-row stages: the same time, 129 instead of 72 KB of LDS)
+#undef HIMO_WG_FULL
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((cin * cout + 63) / 64), dim3(256), 0, s, partial, nb_full, cin, cout, d_dw, acc);
+            if (d_db) hipLaunchKernelGGL(colsum_reduce_kernel, dim3(co_tiles), dim3(1024), 0, s, colpart_full, nb_full, cout, d_db, acc);
+            HIMO_LAUNCH_CHECK("wgrad_full_split kernels");
+            return HIMO_OK;
+        }
         if (flags & 2u)
             hipLaunchKernelGGL(wgrad_partial_split_kernel, dim3((unsigned)((nb + 7) / 8 * 8 * ci_tiles * co_tiles)), dim3(256), 0, s, n, d_x, x_pitch,
                                cin, d_dz, z_pitch, cout, partial, rows_pb, d_db ? colpart : nullptr, nb);

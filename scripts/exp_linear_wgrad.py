@@ -10,6 +10,7 @@ import himo_amd.seflow.train  # noqa: F401  (registers the entry points)
 
 dev = torch.device("cuda", 0)
 lib = _lib.load()
+torch.manual_seed(0)
 shapes = [("head q", 480_000, 192, 128), ("head zr", 480_000, 192, 256), ("head out", 120_000, 192, 32), ("dec u3 512^2", 262_144, 64, 64),
           ("dec u3 256^2", 65_536, 128, 128), ("dec u3 128^2", 16_384, 256, 256), ("dec u1", 16_384, 512, 256)]
 for name, n, ci, co in shapes:
@@ -29,4 +30,8 @@ for name, n, ci, co in shapes:
     b.record(); torch.cuda.synchronize()
     us = a.elapsed_time(b) / 10 * 1e3
     gb = n * (ci + co) * 4 / 1e9
-    print(f"{name:14s} n {n:7d} {ci:3d}->{co:3d}: {us:7.1f} us (whole call)  {2.0 * n * ci * co / us / 1e6:6.1f} TF  operands once {gb:.3f} GB = {gb / us * 1e6:6.0f} GB/s")
+    ref = x.double().T @ dz.double()
+    rel = float(((dw.double() - ref).abs().max() / ref.abs().max()).item())
+    relb = float(((db.double() - dz.double().sum(0)).abs().max() / dz.double().sum(0).abs().max()).item())
+    bits = int(dw.view(torch.int32).to(torch.int64).sum().item()) ^ int(db.view(torch.int32).to(torch.int64).sum().item())
+    print(f"{name:14s} n {n:7d} {ci:3d}->{co:3d}: {us:7.1f} us (whole call)  {2.0 * n * ci * co / us / 1e6:6.1f} TF  operands once {gb:.3f} GB = {gb / us * 1e6:6.0f} GB/s  bits {bits & 0xffffffff:08x}  vs float64: dW {rel:.1e} db {relb:.1e}")
