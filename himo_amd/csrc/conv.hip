@@ -472,7 +472,10 @@ extern "C" int himo_conv2d(const himo_conv_desc* d, void* stream) {
     a.range_seen = (d->act_layout & 2) ? d->d_range_seen : nullptr;
     if (d->act_layout & (8 | 16)) {      // HIMO_ACT_ACCUMULATE (y += result) / HIMO_ACT_STUFFED_2X (compact input read zero-stuffed):
         // the two-term bf16 3x3 stride-1 kernel with the bias epilogue only
-        if ((d->act_layout & ~(8 | 16)) || !d->w_packed || d->packed_format != 2 || d->ksize != 3 || d->stride != 1 || d->epilogue != kEpiBias)
+        // ... or, HIMO_ACT_ACCUMULATE alone, a row GEMM (ksize 1) of either bf16 split with the bias epilogue (csrc/convbf.hip)
+        const bool gemm_acc = d->act_layout == 8 && d->w_packed && d->ksize == 1 && d->epilogue == kEpiBias && (d->packed_format == 0 || d->packed_format == 2);
+        if (!gemm_acc &&
+            ((d->act_layout & ~(8 | 16)) || !d->w_packed || d->packed_format != 2 || d->ksize != 3 || d->stride != 1 || d->epilogue != kEpiBias))
             return HIMO_ERR_UNSUPPORTED;
         if ((d->act_layout & 16) && ((d->h & 1) || (d->w_in & 1) || (int64_t)(d->h / 2) * (d->w_in / 2) * d->x_pitch * 4 >= ((int64_t)1 << 31)))
             return HIMO_ERR_UNSUPPORTED;

@@ -305,17 +305,27 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvArgs a, const unsi
                     if (EPI == kEpiBiasRelu) return fmaxf(v, 0.f);
                     return aux[aoff + col * (unsigned)a.aux_in_pitch] > 0.f ? v : 0.f;      // kEpiReluMask
                 };
+                // HIMO_ACT_ACCUMULATE (row GEMMs with the bias epilogue): y += result -- the fan-in of a gradient with two producers in
+                // the second producer's own epilogue instead of a scratch map and an add pass (the decoder's skip gradient into the
+                // pillar-image gradient the head's scatter wrote: 3.2 GB of traffic -> 1.6 GB per 8-sample pass)
+                const bool accum = EPI == kEpiBias && (a.act_flags & kActAccumulate);
                 if (n_valid == 32) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const unsigned col = (r & 3) + 8 * (r >> 2);
-                        yout[off + col * (unsigned)a.y_pitch] = value(r, col);
+                        float v = value(r, col);
+                        if (accum) v += yout[off + col * (unsigned)a.y_pitch];
+                        yout[off + col * (unsigned)a.y_pitch] = v;
                     }
                 } else if (n_valid > 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const unsigned col = (r & 3) + 8 * (r >> 2);
-                        if ((int)(col + 4 * lh) < n_valid) yout[off + col * (unsigned)a.y_pitch] = value(r, col);
+                        if ((int)(col + 4 * lh) < n_valid) {
+                            float v = value(r, col);
+                            if (accum) v += yout[off + col * (unsigned)a.y_pitch];
+                            yout[off + col * (unsigned)a.y_pitch] = v;
+                        }
                     }
                 }
             }
@@ -396,7 +406,9 @@ int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w
         HIMO_LAUNCH_CHECK("conv3_presplit_kernel");
         return HIMO_OK;
     }
-    if (a.act_flags && !(ksize == 3 && (!tile_hint || (tile_hint & 0x1000) || stride == 2))) return HIMO_ERR_UNSUPPORTED;
+    const bool gemm_accumulate = a.act_flags == kActAccumulate && ksize == 1 && epilogue == kEpiBias &&
+                                 (int64_t)a.Ho * a.Wo * a.y_pitch < (1ll << 30);      // (the row GEMMs' 32-bit-offset epilogue: the one that implements it)
+    if (a.act_flags && !gemm_accumulate && !(ksize == 3 && (!tile_hint || (tile_hint & 0x1000) || stride == 2))) return HIMO_ERR_UNSUPPORTED;
     // 3x3 layers: the weights-from-L2 structure (convsp.hip; tile_hint 0x1000 | rows-per-wave pins its variant) unless the
     // caller pins a tile of this file's kernel
     if (ksize == 3 && (!tile_hint || (tile_hint & 0x1000) || stride == 2) &&
@@ -407,7 +419,7 @@ int launch_conv_bf16x3(const ConvArgs& a, int ksize, int epilogue, const void* w
     if (ksize == 3 && (tile_hint & 0x1000) && (tile_hint & 15) > 4) return HIMO_ERR_UNSUPPORTED;     // a pinned variant this layer does not admit
     if (stride != 1) return HIMO_ERR_UNSUPPORTED;
     if ((int64_t)a.H * a.W * a.x_pitch * 4 >= ((int64_t)1 << 31)) return HIMO_ERR_UNSUPPORTED;          // 32-bit byte offsets into an image (buffer resource)
-    if (format == 2 && (ksize != 1 || (epilogue != kEpiBias && epilogue != kEpiReluMask) || a.act_flags)) return HIMO_ERR_UNSUPPORTED;     // two-term bf16: 3x3 in convsp.hip, row GEMMs here
+    if (format == 2 && (ksize != 1 || (epilogue != kEpiBias && epilogue != kEpiReluMask) || (a.act_flags && !gemm_accumulate))) return HIMO_ERR_UNSUPPORTED;     // two-term bf16: 3x3 in convsp.hip, row GEMMs here
     auto blocks_for = [&](int bn, int mi) -> int64_t {
         const int bm = 64 * mi, th = 2 * mi;
         const int64_t tm = ksize == 1 ? (int64_t)a.N * (((int64_t)a.Ho * a.Wo + bm - 1) / bm)

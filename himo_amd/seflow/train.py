@@ -1135,7 +1135,9 @@ class SeFlowTrainer:
         wt, wp = self._flip(f"{name}.u3", 1, skip_c, lat)                   # [lat][skip_c]
 
         def skip_gradient(tmp):
-            if skip_acc:                                         # (tmp: pixel-major like d_skip)
+            if skip_acc and wp is not None:                      # added to what d_skip holds in the product's own epilogue (HIMO_ACT_ACCUMULATE)
+                self._conv(dcat + 4 * lat, P * 2 * lat, 2 * lat, wt, zb, d_skip, skip_c, skip_c * B, nb, 1, P, lat, skip_c, 1, packed=wp, accumulate=True)
+            elif skip_acc:                                       # (float32 matrix instructions: a scratch map, pixel-major like d_skip, and an add pass)
                 self._conv(dcat + 4 * lat, P * 2 * lat, 2 * lat, wt, zb, tmp, skip_c, skip_c * B, nb, 1, P, lat, skip_c, 1, packed=wp)
                 self._add2d(P, skip_c * nb, tmp, skip_c * B, d_skip, skip_c * B)
             else:

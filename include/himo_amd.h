@@ -296,7 +296,9 @@ typedef struct himo_conv_desc {
 #define HIMO_ACT_SPLIT_IN 1
 #define HIMO_ACT_SPLIT_OUT 2
 #define HIMO_ACT_ACCUMULATE 8   /* alone: y += result instead of y = result -- float32 maps, 3x3 stride 1, packed_format HIMO_PACK_BF16X2,
-                                   bias epilogue (the training step's stride-2 data gradients add into the decoder's skip gradient in place) */
+                                   bias epilogue (the training step's stride-2 data gradients add into the decoder's skip gradient in place);
+                                   also ksize 1 (row GEMM) with packed weights of either bf16 split and the bias epilogue, output map below
+                                   2^30 elements (the decoder's skip gradient added to the pillar-image gradient the head's scatter wrote) */
 #define HIMO_ACT_STUFFED_2X 16  /* alone or with HIMO_ACT_ACCUMULATE, same kernel: d_x is a COMPACT [h / 2][w_in / 2] map that the convolution
                                    reads as its zero-stuffed x2 image (x[2 i][2 j] = map[i][j], zeros elsewhere; h, w_in even = the stuffed
                                    size; x_batch_stride / x_pitch describe the compact map) -- the data gradient of a stride-2 convolution
