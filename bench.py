@@ -457,7 +457,7 @@ def make_train_step(args, rank: int, device, result: dict, n_sets: int = 2):
         turn[0] += 1
         if TB > 1:
             result["loss"] = trainer.train_batch([(smp.pch1, smp.pc0, smp.pc1, smp.pose_h1, smp.pose0, smp.pose1, l0, l1, 31)
-                                                  for smp, (l0, l1) in zip(samples, labels)])
+                                                  for smp, (l0, l1) in zip(samples, labels)], bucketed=True)      # (every rank: TB samples, one pass)
             return
         for smp, (l0, l1) in zip(samples, labels):
             _, total = trainer.train_step(smp.pch1, smp.pc0, smp.pc1, smp.pose_h1, smp.pose0, smp.pose1, l0, l1, n_labels=31)

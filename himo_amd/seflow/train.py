@@ -1447,29 +1447,41 @@ class SeFlowTrainer:
         self.adam_step(lr)
         return terms, total
 
-    def train_batch(self, samples, lr: float = 6e-5):
+    def train_batch(self, samples, lr: float = 6e-5, bucketed: bool = False):
         """One optimisation step on SEVERAL samples per rank (the launcher's ``batch_size=8``): ``samples`` = iterable of (pch1, pc0,
         pc1, pose_h1, pose0, pose1, label0, label1, n_labels).  They go through the network ``batch`` at a time (the constructor's
         capacity: ONE forward / backward pass over up to that many samples, BatchNorm statistics over the pass's samples -- torch's
         semantics for a per-process batch; with ``batch=1`` sample by sample, statistics per sample).  Every sample of the GLOBAL batch
         weighs the same whatever the split over the ranks and passes: each rank sums its passes' gradients (and its sample count and
-        loss) in one flat buffer, ONE all-reduce adds the ranks, and the sum is divided by the global count once.  A rank may hold no
-        sample of a partial last batch -- it still enters the collective with zeros.  Returns the mean loss over the global batch
-        (the same number on every rank)."""
+        loss), the ranks' sums are added, and the sum is divided by the global count once.  A rank may hold no sample of a partial
+        last batch -- it still enters the collectives, with zeros.  Returns the mean loss over the global batch (the same number on
+        every rank).
+
+        ``bucketed``: HOW the ranks' sums are added -- and EVERY rank must pass the same value, since the two forms are different
+        sequences of collectives.  False: ONE flat all-reduce after the last pass.  True: bucket by bucket UNDER the backward pass
+        (``BucketedAllReduce``) -- possible when every rank's share of the step is at most one pass (<= ``batch`` samples; 0 is fine:
+        that rank sends zeros through the same collectives); the caller decides from what all ranks know (``fit``: the global batch
+        size and the world size).  Same sums, element by element."""
         n = self.flat_g.numel()
         if not hasattr(self, "flat_acc") or self.flat_acc.numel() != n + 2:
             self.flat_acc = torch.zeros(n + 2, dtype=self.flat_g.dtype, device=self.flat_g.device)   # [gradient sum | count | loss sum]
         acc = self.flat_acc[:n]
         it, passes = iter(samples), 0
         import torch.distributed as dist
-        first = list(itertools.islice(it, self.B))
-        more = list(itertools.islice(it, self.B)) if len(first) == self.B else []
-        if first and not more and self.overlap_allreduce and dist.is_available() and dist.is_initialized():
-            # the usual case -- the rank's share of the step is ONE pass: the exchange runs bucket by bucket UNDER the backward pass
-            # (BucketedAllReduce) instead of after it; same sums, element by element, as the flat all-reduce below
+        if bucketed and self.overlap_allreduce and dist.is_available() and dist.is_initialized():
+            first = list(itertools.islice(it, self.B + 1))
+            if len(first) > self.B:
+                raise ValueError(f"train_batch(bucketed=True) takes at most batch = {self.B} samples per rank and step")
             words = self.flat_acc[n:]
             exchange = BucketedAllReduce(self.flat_g, self.buckets, words=words)
-            self.loss_and_grad_batch(first, exchange=exchange)
+            if first:
+                self.loss_and_grad_batch(first, exchange=exchange)
+            else:                                                # no sample on this rank: zeros through the same collectives, in the same order
+                self.flat_g.zero_()
+                words.zero_()
+                for k in range(len(self.buckets)):
+                    exchange.launch(k)
+                exchange.wait()
             count = words[0]
             if float(count.item()) <= 0.0:
                 raise ValueError("train_batch needs at least one sample on some rank")
@@ -1477,9 +1489,8 @@ class SeFlowTrainer:
             loss = (words[1] / count).clone()
             self.adam_step(lr)
             return loss
-        pending = [first, more] if more else ([first] if first else [])
         while True:
-            chunk = pending.pop(0) if pending else list(itertools.islice(it, self.B))
+            chunk = list(itertools.islice(it, self.B))
             if not chunk:
                 break
             _, totals = self.loss_and_grad_batch(chunk)

@@ -383,6 +383,8 @@ def _worker_buckets(rank, world, port, out_dir):
     for step in range(10):
         grad = torch.randn(o, generator=g) * 10.0 ** float(torch.randint(-6, 3, (1,), generator=g))
         words = torch.tensor([float(1 + rank + step % 2), float(torch.rand(1, generator=g))], dtype=torch.float32)
+        if rank == 1 and step % 4 == 3:                             # a rank without a sample in a partial last batch: zeros, same collectives
+            grad, words = torch.zeros(o), torch.zeros(2)
         flat = torch.cat([grad, words])
         allreduce_sum_(flat)                                        # the single flat all-reduce
         mine, w2 = grad.clone(), words.clone()

@@ -502,6 +502,11 @@ def test_cli_programs_as_two_ranks_on_this_box(gpu, tmp_path):
     torchrun("himo_amd.seflow.fit", "--dataset_path", str(two), "--out_dir", str(tmp_path / "ckpt"), "--epochs", "1", "--batch_size", "2",
              cwd=tmp_path / "two")
     assert list((tmp_path / "ckpt").glob("*.npz"))
+    # ... and an UNEVEN split: 6 samples in steps of 5 -> shares 3 + 2, then 1 + 0: the rank without a sample sends zeros through the same
+    # bucketed collectives as the rank that runs a pass (a rank choosing another exchange than its peer would hang here)
+    torchrun("himo_amd.seflow.fit", "--dataset_path", str(two), "--out_dir", str(tmp_path / "ckpt5"), "--epochs", "1", "--batch_size", "5",
+             cwd=tmp_path / "two")
+    assert list((tmp_path / "ckpt5").glob("*.npz"))
 
 
 @pytest.mark.parametrize("in_flight", [2, 3])
