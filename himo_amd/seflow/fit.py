@@ -162,6 +162,8 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
     def samples_of(ds, groups):
         """one iterator of device samples per group of triplets, in order; the groups' samples are prepared ahead across group
         boundaries (``TrainFeeder``), or built on the spot (``num_workers=0``)"""
+        if not groups:
+            return
         if num_workers <= 0:
             for grp in groups:
                 yield (make_sample(ds, t, dev, ssl_label) for t in grp)
