@@ -41,9 +41,10 @@ def test_one_full_size_train_step_is_finite_and_reproducible(gpu):
     assert all(v >= 0 for v in t0.values()) and sum(t0.values()) == pytest.approx(l0, rel=1e-9)
 
 
-def test_training_steps_are_bit_reproducible(gpu):
-    """Two fresh trainers, the same four samples, BatchNorm in training mode, the encoder's weight gradients on the side stream:
-    the same parameter bits after four optimiser steps.  Every reduction of the step is a fixed-order tree, and the one scatter-add
+@pytest.mark.parametrize("batch", [1, 3])
+def test_training_steps_are_bit_reproducible(gpu, batch):
+    """Two fresh trainers, the same four samples (``batch`` = 3: three of them per pass and optimiser step, BatchNorm statistics over the
+    pass), BatchNorm in training mode, the encoder's weight gradients on the side stream: the same parameter bits after four optimiser steps.  Every reduction of the step is a fixed-order tree, and the one scatter-add
     (the pc1 -> moved half of the Chamfer gradient, csrc/sslloss.hip) accumulates 64-bit fixed point -- with float atomics the
     last bits of a step depended on the arrival order, and the trained-weights parity case saw different weights on every run."""
     from himo_amd.dataset import ListDataset
@@ -55,8 +56,8 @@ def test_training_steps_are_bit_reproducible(gpu):
     trips = triplets(ds)
     finals, losses = [], []
     for _ in range(2):
-        tr = SeFlowTrainer(spec.init_params(5), device=gpu, max_points=32_000, batchnorm="batch")
-        ls = [float(tr.train_batch([make_sample(ds, trips[k % len(trips)], gpu)], lr=3e-4).item()) for k in range(4)]
+        tr = SeFlowTrainer(spec.init_params(5), device=gpu, max_points=32_000, batchnorm="batch", batch=batch)
+        ls = [float(tr.train_batch([make_sample(ds, trips[(k + j) % len(trips)], gpu) for j in range(batch)], lr=3e-4).item()) for k in range(4)]
         torch.cuda.synchronize()
         finals.append(tr.flat_p.clone())
         losses.append(ls)
