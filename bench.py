@@ -953,6 +953,7 @@ def extra_workload_legs(args, device) -> dict:
         result = {}
         try:
             torch.cuda.reset_peak_memory_stats(device)
+            mem0 = torch.cuda.memory_allocated(device)             # (what the main workload's objects still hold)
             if name == "train":
                 step, obj = make_train_step(a, 0, device, result)
                 dominant, nsf, step_single = TRAIN_DOMINANT, None, None
@@ -1016,7 +1017,7 @@ def extra_workload_legs(args, device) -> dict:
             leg = {"frames_per_s": steps * per_step / el, "ms_per_step": el / steps * 1e3, "steps": steps, "samples_per_step": per_step, "warmup": warm,
                    "points_per_frame": a.points, "cloud": a.cloud, "workload": workload, "dtype": dtype, "roofline": roof, "parity": parity}
             if name == "train":
-                leg["device_memory_GB_peak"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 1)      # (this leg's trainer, samples and workspaces)
+                leg["device_memory_GB"] = round((torch.cuda.max_memory_allocated(device) - mem0) / 1e9, 1)      # this leg's trainer, samples and workspaces (peak)
             if name == "train" and side:
                 leg["frames_per_s_without_side_streams"] = per_step / el_train_single
             if name == "fastnsf" and el_single is not None:

@@ -564,7 +564,7 @@ class SeFlowTrainer:
         assets/slurm/ssl-train-av2.sh:32-34): every encoder layer runs over ``batch`` x F images in ONE launch, every decoder
         layer over ``batch`` images, and training-mode BatchNorm takes its statistics over the whole batch, as torch does
         (``forward_batch`` / ``backward_batch`` / ``train_batch``); saved activations and gradient buffers are ``batch`` times
-        the single-sample ones (~5 GB per sample at 120k points).  Layout: the maps whose frames are channel groups (pillar
+        the single-sample ones (~7 GB per sample at 120k points: 56 GB at batch = 8).  Layout: the maps whose frames are channel groups (pillar
         images, the stage outputs the decoder concatenates) hold ALL the batch's images as channel groups of one pixel-major buffer
         -- image b * F + f at channel offset C * (b * F + f), pitch C * F * batch -- so that every kernel that walks "n images with a
         stride" (convolutions, BatchNorm, weight gradients) sees the batch as n = batch * F images, and the decoder reads sample
