@@ -620,9 +620,13 @@ class TrainFeeder:
             sample, done = got
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(done)                                # after the sample's copies and label kernels: no host wait
-            for t in sample:
-                if isinstance(t, torch.Tensor):
-                    t.record_stream(cur)                        # allocated on the feeder's streams, used on this one
+            seen = set()
+            for t in sample:                                    # allocated on the feeder's streams, used on this one: ONE record per storage
+                if isinstance(t, torch.Tensor):                 # (the sweeps -- and uploaded labels -- are views of one block; a record costs
+                    key = t.untyped_storage().data_ptr()        #  ~0.1 ms of the launch thread)
+                    if key not in seen:
+                        seen.add(key)
+                        t.record_stream(cur)
             yield sample
 
 
