@@ -198,3 +198,30 @@ def test_train_feeder_surfaces_reader_errors_and_stops_early(gpu):
     bad = ListDataset([{k: v for k, v in f.items() if k != "gm0"} for f in frames])
     with pytest.raises(KeyError, match="gm0"):
         list(TrainFeeder(bad, triplets(bad), device=gpu))
+
+
+def test_fit_program_over_h5_scene_files(gpu, tmp_path):
+    """``python -m himo_amd.seflow.fit --dataset_path <dir of .h5 scenes>`` (the reference's ``train.py ... +ssl_label=seflow_auto``,
+    assets/slurm/ssl-train-av2.sh:31-34) as a PROGRAM: scenes opened with the training fields as views of the file mapping, samples fed
+    ahead of the step, labels generated on the device, a batch in one pass, checkpoints written -- and a second run resumes from one."""
+    import subprocess, sys, os
+    from pathlib import Path
+    from himo_amd.seflow.checkpoint import load_params
+    from himo_amd.synthetic import make_scene, write_h5_scenes
+    data = tmp_path / "scenes"
+    data.mkdir()
+    write_h5_scenes(data, [make_scene(70 + sc, 5, n_points=5_000, scene_id=f"h5fit{sc}") for sc in range(2)])
+    repo = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, PYTHONPATH=str(repo))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, "-m", "himo_amd.seflow.fit", "--dataset_path", str(data), "--out_dir", str(tmp_path / "ckpt"), "--epochs", "2",
+           "--batch_size", "3", "--save_top_model", "2"]
+    out = subprocess.run(cmd, env=env, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.count("epoch ") == 2 and "train loss" in out.stdout
+    kept = sorted((tmp_path / "ckpt").glob("*.npz"))
+    assert len(kept) == 2
+    params, extra = load_params(kept[0], with_extra=True)
+    assert int(extra["step"]) in (3, 6) and np.isfinite(params["enc1.0.weight"]).all()      # 8 samples in steps of 3: 3 steps per epoch
+    again = subprocess.run(cmd[:-4] + ["--epochs", "3", "--resume", str(kept[-1])], env=env, cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert again.returncode == 0, again.stderr[-3000:]
