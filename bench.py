@@ -781,7 +781,32 @@ def run_rank(args, rank: int, world: int, device, sync) -> dict | None:
             host_samples = [(host_frames[j], host_frames[j + 1], host_frames[j + 2]) for j in range(min(B, len(host_frames) - 2))]
             line["cpu_baseline"] = cpu_baseline_pipeline(host_samples, params, args.cpu_seconds, args.cpu_frames, args.cpu_threads)
         line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+    line["summary"] = line_summary(line)
     return line
+
+
+def line_summary(line: dict) -> dict:
+    """The line's figures once more, compact, as its LAST key: a reader that keeps only the end of a long line (the driver stores the last
+    2000 characters beside the fields it parses) still sees every leg's number.  Nothing here is new: each entry repeats a value above."""
+    r3 = lambda v: None if v is None else round(float(v), 3)
+    g = lambda leg, key="frames_per_s": r3((line.get(leg) or {}).get(key))
+    out = {"value": r3(line.get("value")), "roofline_frac": r3((line.get("roofline") or {}).get("frac")),
+           "roofline_avg_launch_ms": r3((line.get("roofline") or {}).get("avg_launch_ms")),
+           "value_single_stream": r3(line.get("value_single_stream")), "value_bf16x3": r3(line.get("value_bf16x3")), "value_f32": r3(line.get("value_f32")),
+           "hostfed": g("leg_hostfed"), "h5fed": g("leg_h5fed"),
+           "train": g("leg_train"), "train_b8": g("leg_train_b8"), "train_bf16x3": g("leg_train_bf16x3"), "train_rings": g("leg_train_rings"),
+           "train_wgrad_roofline_frac": r3(((line.get("leg_train") or {}).get("roofline") or {}).get("frac")),
+           "train_b8_wgrad_roofline_frac": r3(((line.get("leg_train_b8") or {}).get("roofline") or {}).get("frac")),
+           "fit_h5": g("leg_fit_h5"), "fit_h5_by_epoch": (line.get("leg_fit_h5") or {}).get("frames_per_s_by_epoch"),
+           "eval_h5_sweeps_per_s": g("leg_eval_h5", "sweeps_per_s"), "eval_resident_sweeps_per_s": g("leg_eval_h5", "resident_sweeps_per_s"),
+           "fastnsf": g("leg_fastnsf"), "fastnsf_one_fit_at_a_time": g("leg_fastnsf", "frames_per_s_one_fit_at_a_time"),
+           "fastnsf_roofline_frac": r3(((line.get("leg_fastnsf") or {}).get("roofline") or {}).get("frac")),
+           "cpu_baseline": r3((line.get("cpu_baseline") or {}).get("value")), "cpu_cores": (line.get("cpu_baseline") or {}).get("cores"),
+           "gpu_over_cpu": r3(line.get("gpu_over_cpu"))}
+    errors = {k: v["error"] for k, v in line.items() if k.startswith("leg_") and isinstance(v, dict) and "error" in v}
+    if errors:
+        out["leg_errors"] = errors
+    return {k: v for k, v in out.items() if v is not None}
 
 
 FASTNSF_DOMINANT = "nsf_"          # nsf_forward / nsf_backward / nsf_update_kernel (csrc/nsffused.hip): substring filter of himo_prof_filter
