@@ -63,6 +63,7 @@ class File:
             self.close()
             raise
         self._objects = {}                    # header address -> parsed Group / Dataset (the file is read-only: parsed once)
+        self._datatypes = {}                  # datatype message image -> (numpy dtype, is_bool)
         self._root = Group(self, self._root_addr, "/")
 
     # -- low-level helpers
@@ -142,6 +143,9 @@ class File:
             pass
 
 
+_HDR_V1 = struct.Struct("<HHB")                                         # version-1 header message prefix: type, size, flags
+
+
 def _messages(f: File, addr: int):
     """(type, flags, offset, size) of every header message of the object at ``addr`` (continuations followed)."""
     b = f._buf
@@ -185,7 +189,7 @@ def _messages(f: File, addr: int):
     while blocks and seen < nmsg:
         p, end = blocks.pop(0)
         while p + 8 <= end and seen < nmsg:
-            mtype, msize, mflags = f._u(p, 2), f._u(p + 2, 2), b[p + 4]
+            mtype, msize, mflags = _HDR_V1.unpack_from(b, p)
             body = p + 8
             seen += 1
             if mtype == 0x10:
@@ -421,9 +425,10 @@ def _dense_links(f: File, heap_addr: int, btree_addr: int, parse_link, links: di
 
 
 def _open_object(f: File, addr: int, name: str):
-    kinds = {m[0] for m in _messages(f, addr)}
+    msgs = _messages(f, addr)
+    kinds = {m[0] for m in msgs}
     if 0x08 in kinds or 0x01 in kinds:
-        return Dataset(f, addr, name)
+        return Dataset(f, addr, name, msgs)                              # (the header is walked once, not once to tell and once to parse)
     return Group(f, addr, name)
 
 
@@ -492,12 +497,12 @@ def _filters(f: File, p: int):
 
 
 class Dataset:
-    def __init__(self, f: File, addr: int, name: str):
+    def __init__(self, f: File, addr: int, name: str, messages=None):
         self._f, self.name = f, name
         b = f._buf
         self.shape, self._dtype, self._bool = None, None, False
         self._layout, self._filters = None, []
-        for mtype, mflags, p, size in _messages(f, addr):
+        for mtype, mflags, p, size in (messages if messages is not None else _messages(f, addr)):
             if mflags & 0x02 and mtype in (0x01, 0x03, 0x08, 0x0B):
                 raise Unsupported("shared object-header messages (committed datatypes)")
             if mtype == 0x01:
@@ -512,7 +517,12 @@ class Dataset:
                     raise Unsupported(f"dataspace message version {ver}")
                 self.shape = tuple(f._u(q + i * f.L, f.L) for i in range(rank))
             elif mtype == 0x03:
-                self._dtype, self._bool, _ = _datatype(f, p)
+                # (a scene file holds a handful of distinct datatype messages, thousands of times: parsed once per message image)
+                key = bytes(b[p:p + size])
+                hit = f._datatypes.get(key)
+                if hit is None:
+                    hit = f._datatypes[key] = _datatype(f, p)[:2]
+                self._dtype, self._bool = hit
             elif mtype == 0x08:
                 self._layout = self._parse_layout(p)
             elif mtype == 0x0B:
