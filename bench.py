@@ -798,7 +798,8 @@ def line_summary(line: dict) -> dict:
            "train_wgrad_roofline_frac": r3(((line.get("leg_train") or {}).get("roofline") or {}).get("frac")),
            "train_b8_wgrad_roofline_frac": r3(((line.get("leg_train_b8") or {}).get("roofline") or {}).get("frac")),
            "fit_h5": g("leg_fit_h5"), "fit_h5_by_epoch": (line.get("leg_fit_h5") or {}).get("frames_per_s_by_epoch"),
-           "eval_h5_sweeps_per_s": g("leg_eval_h5", "sweeps_per_s"), "eval_resident_sweeps_per_s": g("leg_eval_h5", "resident_sweeps_per_s"),
+           "eval_h5_sweeps_per_s": g("leg_eval_h5", "sweeps_per_s"), "eval_h5_whole_loop_sweeps_per_s": g("leg_eval_h5", "whole_loop_sweeps_per_s"),
+           "eval_resident_sweeps_per_s": g("leg_eval_h5", "resident_sweeps_per_s"),
            "fastnsf": g("leg_fastnsf"), "fastnsf_one_fit_at_a_time": g("leg_fastnsf", "frames_per_s_one_fit_at_a_time"),
            "fastnsf_roofline_frac": r3(((line.get("leg_fastnsf") or {}).get("roofline") or {}).get("frac")),
            "cpu_baseline": r3((line.get("cpu_baseline") or {}).get("value")), "cpu_cores": (line.get("cpu_baseline") or {}).get("cores"),
@@ -1176,11 +1177,13 @@ def h5fed_leg(args, pipe, host_frames, device) -> dict:
 def eval_h5_leg(args, device) -> dict:
     """N = 1 only, after the timed region: the evaluator as the PROGRAM a user starts -- ``python eval.py --data_dir ... --res_name
     seflowpp_best`` (eval.py:270-313: ``dataset[i]`` -> ego-motion removal, eval mask, per-instance MPE / Chamfer -> the tables) --
-    END TO END over 120k-point ``.h5`` scene files holding the estimate beside the ground truth: ``himo_amd.eval.main`` reads the
-    scenes (``fields=`` / views of the file mapping, a few reader threads, the next batch's reads in flight), stages the batches in
-    pinned memory (``feeder.EvalFeeder``), scores them on the device and writes ``res-av2.json``.  Beside it the same sweeps as
-    device-RESIDENT batches (``InstanceMetrics.step_batch``: kernels + the pipelined record read-back + the host-side bucket
-    bookkeeping), the figure of profiles/r0x_evaluator_throughput.txt."""
+    END TO END over 120k-point ``.h5`` scene files holding the estimate beside the ground truth, run as ``python -m himo_amd.eval`` in
+    its own interpreter: forked reader processes (the reference loop's ``DataLoader`` workers) read the scenes (``fields=`` / views of
+    the file mapping) and pack the batches into shared slots, the feeder thread issues one DMA per batch, the launch thread scores
+    them on the device and writes ``res-av2.json``.  Beside it the same program on reader threads, ``eval.main`` called inside
+    this process (reader threads: a process that holds device state does not fork), and the same sweeps as device-RESIDENT batches
+    (``InstanceMetrics.step_batch``: kernels + the pipelined record read-back + the host-side bucket bookkeeping), the figure of
+    profiles/r0x_evaluator_throughput.txt."""
     import contextlib
     import io
     import shutil
@@ -1189,12 +1192,17 @@ def eval_h5_leg(args, device) -> dict:
     import torch
     from himo_amd import eval as ev
     from himo_amd.synthetic import make_frame, write_h5_scenes
-    n_scenes, per_scene, P = 8, 33, args.points              # 256 scored sweeps = 16 batches (the first batches pay for the pinned arenas)
+    n_scenes, per_scene, distinct, P = 8, 257, 33, args.points    # 2048 scored sweeps = 128 batches (33 distinct sweeps per scene, repeated under new time stamps)
     root = Path(tempfile.mkdtemp(prefix="himo_eval_av2_"))
     try:
         frames = []
         for sc in range(n_scenes):
-            fr = [make_frame(9000 + 40 * sc + k, n_points=P, scene_id=f"eval{sc:02d}", cloud=args.cloud) for k in range(per_scene)]
+            made = [make_frame(9000 + 40 * sc + k, n_points=P, scene_id=f"eval{sc:02d}", cloud=args.cloud) for k in range(distinct)]
+            fr = []
+            for k in range(per_scene):
+                f = dict(made[k % distinct])
+                f["timestamp"] = int(made[0]["timestamp"]) + k * 100_000_000
+                fr.append(f)
             frames.append(fr)
         # (write_h5_scenes writes the reference extractors' datasets; the estimate goes in beside them, as the reference's save.py leaves it)
         import pickle
@@ -1212,10 +1220,31 @@ def eval_h5_leg(args, device) -> dict:
         with open(root / "index_total.pkl", "wb") as fh:
             pickle.dump(index, fh)
         B = 16
+        # the PROGRAM, in its own interpreter, as a user starts it: reader processes are forked before the HIP runtime starts (a fork from
+        # a process that holds device state -- this one -- is paid for at its next device call: profiles/r06_exp_fork_cost.txt)
+        import re
+        import subprocess
+
+        def program(workers):
+            t0 = time.perf_counter()
+            out = subprocess.run([sys.executable, "-W", "ignore", "-m", "himo_amd.eval", "--data_dir", str(root), "--res_name", "seflowpp_best",
+                                  "--batch_frames", str(B)] + ([] if workers is None else ["--num_workers", str(workers)]),
+                                 cwd=str(root), capture_output=True, text=True, timeout=900, env=dict(os.environ, PYTHONPATH=str(REPO)))
+            wall = time.perf_counter() - t0
+            if out.returncode != 0:
+                raise RuntimeError(out.stderr[-1500:])
+            line = [l for l in out.stdout.splitlines() if l.startswith("Scoring loop")][-1]
+            got = re.match(r"Scoring loop: (\d+) sweeps/s \((\d+) sweeps in ([\d.]+) s, (\d+) reader (\w+)\)(?:; (\d+) sweeps/s after)?", line)
+            return {"sweeps_per_s": float(got.group(1)), "sweeps": int(got.group(2)), "seconds": float(got.group(3)), "readers": int(got.group(4)),
+                    "reader_kind": got.group(5), "sweeps_per_s_after_warm_up": float(got.group(6)) if got.group(6) else None,
+                    "process_wall_s": round(wall, 2)}
+        program(None)                                              # first pass: page cache
+        prog = program(None)                                       # the default: 4 reader processes for an evaluation of this length
+        prog_threads = program(0)
         sink = io.StringIO()
         with warnings.catch_warnings(), contextlib.redirect_stdout(sink):
             warnings.simplefilter("ignore")
-            for rep in range(2):                                   # first pass: page cache, workspaces, pinned arenas
+            for rep in range(2):                                   # ... and inside THIS process (device state: reader threads), as rounds 5-6 timed it
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 m = ev.main(str(root), res_name="seflowpp_best", batch_frames=B, file_name=str(root / "res.json"))
@@ -1238,11 +1267,18 @@ def eval_h5_leg(args, device) -> dict:
             resident = 12 * B / (time.perf_counter() - t0)
         mb = sum(f[k].nbytes for f in frames[0][:1] for k in ("pc0", "lidar_dt", "gm0", "flow", "flow_is_valid", "flow_category_indices",
                                                               "flow_instance_id", "seflowpp_best")) / 1e6
-        leg = {"sweeps_per_s": sweeps / el, "sweeps": sweeps, "seconds": el, "resident_sweeps_per_s": resident, "fraction_of_resident": sweeps / el / resident,
+        steady = prog["sweeps_per_s_after_warm_up"] or prog["sweeps_per_s"]
+        leg = {"sweeps_per_s": steady, "whole_loop_sweeps_per_s": prog["sweeps_per_s"], "sweeps": prog["sweeps"], "seconds": prog["seconds"],
+               "readers": f"{prog['readers']} reader {prog['reader_kind']}", "process_wall_s": prog["process_wall_s"],
+               "reader_threads_program": prog_threads, "in_this_process_reader_threads_sweeps_per_s": sweeps / el,
+               "resident_sweeps_per_s": resident, "fraction_of_resident": steady / resident,
                "scenes": n_scenes, "sweeps_per_scene": per_scene, "points_per_sweep": P, "batch_frames": B, "host_MB_read_per_sweep": round(mb, 2),
-               "note": "himo_amd.eval.main end to end: read .h5 scenes (fields=, views of the mapping, 4 reader threads one batch ahead) -> pinned "
-                       "staging + copies on the feeder's stream -> eval mask, per-instance MPE / Chamfer on the device -> tables + res.json; second "
-                       "pass over the files (page cache warm).  resident = the same scoring on batches already in HBM"}
+               "note": "python -m himo_amd.eval in its own interpreter, end to end: forked reader processes (h5lite views of the scene files, batches "
+                       "packed into shared slots registered with the runtime) -> one DMA per batch on the feeder's stream -> eval mask, per-instance "
+                       "MPE / Chamfer on the device -> tables + res-av2.json; page cache warm.  sweeps_per_s = the scoring loop after its first 8 "
+                       "batches (they pay for the runtime's start, workspaces and slot registration; whole_loop_sweeps_per_s includes them, "
+                       "process_wall_s also the interpreter's start and imports).  reader_threads_program = the same program with --num_workers 0; "
+                       "in_this_process_... = eval.main called here, where it reads on threads.  resident = the same scoring on batches already in HBM"}
         return {"value_eval_h5": leg["sweeps_per_s"], "leg_eval_h5": leg}
     except Exception as e:                                           # a leg must never cost the main line
         return {"leg_eval_h5": {"error": f"{type(e).__name__}: {e}"}}

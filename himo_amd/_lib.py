@@ -126,6 +126,27 @@ def ptr(t) -> int | None:
     return None if t is None else t.data_ptr()
 
 
+_LIBC = None
+
+
+def pinned_empty(numel: int, dtype=None):
+    """``torch.empty(numel, dtype, pin_memory=True)`` whose pages stay OUT of forked children (madvise MADV_DONTFORK).  The runtime maps
+    pinned host memory into the GPU's address space through the pages of an ordinary private mapping; a fork() write-protects such pages
+    for copy-on-write, the driver's notifier then takes the mapping away from the GPU, and the first device operation afterwards pays for
+    putting it back -- 1.5 s per GB of pinned memory the process holds (scripts/exp_fork_cost.py: 3.06 s with 2 GB pinned, 0.22 s with
+    the advice).  Reader processes (feeder.ReaderPool) are forked from processes that hold gigabytes of staging arenas."""
+    import torch
+    global _LIBC
+    t = torch.empty(int(numel), dtype=dtype if dtype is not None else torch.uint8, pin_memory=True)
+    lo = (t.data_ptr() + 4095) & ~4095
+    n = (t.data_ptr() + t.numel() * t.element_size() - lo) & ~4095
+    if n > 0:
+        if _LIBC is None:
+            _LIBC = ctypes.CDLL(None, use_errno=True)
+        _LIBC.madvise(c_void_p(lo), c_size_t(n), 10)          # MADV_DONTFORK; advice only: a refusal changes nothing but fork's cost
+    return t
+
+
 def stream_handle() -> int:
     import torch
     return torch.cuda.current_stream().cuda_stream

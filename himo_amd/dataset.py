@@ -198,6 +198,9 @@ class HDF5Dataset:
     def __init__(self, directory, vis_name="", eval: bool = False, n_frames: int = 2, opener=None,  # noqa: A002
                  allow_dropped_eval: bool | None = None, fields=None, zero_copy: bool = False, keep_open: int = 8):
         self._files = _OpenFiles(opener if opener is not None else _open_h5, keep=keep_open)
+        # reader PROCESSES (feeder.ReaderPool) may inherit this object through fork(): h5lite holds a read-only file mapping and
+        # nothing else; libhdf5's global state under h5py does not survive a fork with files open
+        self.fork_safe = opener is None and h5_reader().__name__.rsplit(".", 1)[-1] == "h5lite"
         self.fields = None if fields is None else frozenset(fields)
         self.zero_copy = zero_copy
         self._result_choice = {}

@@ -130,7 +130,7 @@ class InstanceEvaluator:
         for i, buf in enumerate(self._pin_pool):
             if buf.numel() >= nbytes:
                 return self._pin_pool.pop(i)
-        return torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        return _lib.pinned_empty(nbytes)
 
     def collect(self, ticket) -> np.ndarray:
         """Wait for a ticket's copy and return its records sorted (frame, group, instance); a batch with more instances
@@ -505,6 +505,11 @@ def chamfer_distance(pc1, pc2) -> float:
     return float((np.nanmean(d12) + np.nanmean(d21)) / 2.0)
 
 
+# the first batches of a run pay for the runtime's start, the evaluator's workspaces and the staging memory: ``main`` reports the rate
+# after them beside the whole loop's
+WARM_BATCHES = 8
+
+
 def stream_batches(metrics: "InstanceMetrics", source, res_name: str = ""):
     """``source`` yields (sweep keys, frame dicts, comp_dis list | None) per batch.  The frames are read, staged in pinned
     memory and copied to the device by a background thread two batches ahead (feeder.EvalFeeder); the launch thread only
@@ -516,16 +521,63 @@ def stream_batches(metrics: "InstanceMetrics", source, res_name: str = ""):
         for keys, frames, cds in source:
             keys_q.append(list(keys))
             yield (frames, cds) if cds is not None else frames
-    for eb in EvalFeeder(gen(), res_name=res_name, device=metrics.evaluator.device):
+    metrics.warm_mark = None
+    for k, eb in enumerate(EvalFeeder(gen(), res_name=res_name, device=metrics.evaluator.device)):
+        if k == WARM_BATCHES:
+            metrics.warm_mark = (time.perf_counter(), metrics.frame_cnt + sum(t[1] for t in metrics._pending))
         metrics.step_batch(eb, keys=keys_q.pop(0))
     metrics.flush()
 
 
+def stream_batches_from_processes(metrics: "InstanceMetrics", key_lists, read, res_name: str = "", workers: int = 4):
+    """``stream_batches`` with the reading and packing on forked reader processes (feeder.ProcessBatchFeeder): ``key_lists[k]`` are
+    batch k's sweep keys and ``read(k)`` -- run in a worker -- returns its (frame dicts, comp_dis list | None).  The reference's loop
+    gets its frames from ``DataLoader`` worker processes the same way; here it frees the launch thread's interpreter from the
+    HDF5 parsing and the packing of the batches it scores.  The workers are forked on entry, BEFORE the evaluator starts the HIP
+    runtime when nothing else has (a fork from a process with device state is paid for at its next device call)."""
+    from .feeder import ProcessBatchFeeder
+
+    def build(item, upload):                                          # in a reader process: no device call in here
+        frames, cds = item
+        return EvalBatch.from_frames(list(frames), res_name, cds, device="reader process", upload=upload)
+    t0 = time.perf_counter()
+    feeder = ProcessBatchFeeder(len(key_lists), read, build, workers=workers)
+    metrics.warm_mark = None
+    try:
+        for k, eb in enumerate(feeder):
+            if k == WARM_BATCHES:
+                metrics.warm_mark = (time.perf_counter(), metrics.frame_cnt + sum(t[1] for t in metrics._pending))
+            metrics.step_batch(eb, keys=list(key_lists[k]))
+    finally:
+        feeder.close()
+        metrics.feed_stats = dict(feeder.pool.stage_seconds, restarts=feeder.pool.restarts, workers=workers, slot_bytes=feeder.pool.slot_bytes,
+                                  forked_before_hip=feeder.forked_before_hip, seconds=time.perf_counter() - t0)
+    metrics.flush()
+
+
+def reader_processes_default(n_sweeps: int, dataset) -> int:
+    """How many reader processes ``main`` starts when the caller does not say: env ``HIMO_EVAL_WORKERS``, else 4 -- for a dataset that
+    survives a fork (``HDF5Dataset`` on h5lite), an evaluation long enough to repay their start (~0.3 s against 1.4 k sweeps/s on
+    threads) and a process that holds no device memory yet (the program as started from a shell, a rank under torchrun); otherwise 0:
+    the reader threads of this process."""
+    env = os.environ.get("HIMO_EVAL_WORKERS")
+    if env is not None:
+        return max(0, int(env))
+    if not getattr(dataset, "fork_safe", False) or n_sweeps < 1024:
+        return 0
+    if torch.cuda.is_initialized() and torch.cuda.memory_reserved() > 0:
+        return 0
+    return 4
+
+
 def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo", res_name: str = "", comp_dis_zip: str = "",
          batch_frames: int = 16, dataset=None, file_name: str | None = None, allow_dropped_eval: bool | None = None,
-         read_threads: int = 4):
-    """eval.py:270-313.  Under ``torchrun`` sweep i is scored by rank i % world on its own GPU, the per-sweep contribution
-    logs are all-gathered once at the end and rank 0 alone prints / writes ``res-<data>.json``."""
+         read_threads: int = 4, num_workers: int | None = None):
+    """eval.py:270-313.  Under ``torchrun`` sweep i is scored by rank i % world on its own GPU, the per-sweep records
+    are all-gathered once at the end and rank 0 alone prints / writes ``res-<data>.json``.
+    ``num_workers``: reader PROCESSES (the loop's ``DataLoader`` workers) for a dataset that can be inherited through fork()
+    (``HDF5Dataset`` on h5lite); default: ``reader_processes_default``; 0, or any other dataset: ``read_threads`` threads of this
+    process."""
     from . import distenv
     from .dataset import open_dataset
     from .save_zip import read_output_zip
@@ -565,7 +617,29 @@ def main(data_dir: str = "/home/kin/data/av2/h5py/sensor/himo", res_name: str = 
                             cds = ([z.result() for z in zips] if zips is not None else
                                    [read_output_zip(comp_dis_zip, (f["scene_id"], str(f["timestamp"]))) for f in frames])
                         yield mine[lo:lo + batch_frames], frames, cds
-            stream_batches(metrics, batches(), res_name)
+            if num_workers is None:
+                num_workers = reader_processes_default(len(mine), dataset)
+            t_loop = time.perf_counter()
+            if num_workers > 0 and getattr(dataset, "fork_safe", False) and mine:
+                key_lists = [mine[lo:lo + batch_frames] for lo in range(0, len(mine), batch_frames)]
+
+                def read(k):                                          # in a reader process
+                    frames = [dataset[i] for i in key_lists[k]]
+                    cds = None
+                    if eval_flag == 1:
+                        cds = [read_output_zip(comp_dis_zip, tuple(map(str, dataset.index[i])) if hasattr(dataset, "index") else
+                                               (f["scene_id"], str(f["timestamp"]))) for i, f in zip(key_lists[k], frames)]
+                    return frames, cds
+                stream_batches_from_processes(metrics, key_lists, read, res_name, workers=num_workers)
+            else:
+                num_workers = 0
+                stream_batches(metrics, batches(), res_name)
+            t_end = time.perf_counter()
+            metrics.loop = {"seconds": t_end - t_loop, "sweeps": len(mine), "reader_processes": num_workers,
+                            "reader_threads": 0 if num_workers else max(1, read_threads)}
+            mark = getattr(metrics, "warm_mark", None)
+            if mark is not None and len(mine) > mark[1]:
+                metrics.loop["sweeps_per_s_after_warm_up"] = (len(mine) - mark[1]) / max(t_end - mark[0], 1e-9)
         except Exception as e:
             err = e
         distenv.rendezvous(err, "its sweeps, but no result file was written")
@@ -583,7 +657,15 @@ if __name__ == "__main__":
     ap.add_argument("--comp_dis_zip", default="")
     ap.add_argument("--allow_dropped_eval", action="store_true", default=None,
                     help="skip index_eval.pkl sweeps that have no successor sweep in their h5 scene instead of failing")
+    ap.add_argument("--num_workers", type=int, default=None,
+                    help="reader processes (the reference loop's DataLoader workers); default: 4 for long evaluations of h5 scenes, 0 = reader threads")
+    ap.add_argument("--batch_frames", type=int, default=16)
     a = ap.parse_args()
     start_time = time.time()
-    main(a.data_dir, a.res_name, a.comp_dis_zip, allow_dropped_eval=a.allow_dropped_eval)
+    done = main(a.data_dir, a.res_name, a.comp_dis_zip, batch_frames=a.batch_frames, allow_dropped_eval=a.allow_dropped_eval, num_workers=a.num_workers)
     print(f"Time used: {time.time() - start_time:.2f} s")
+    loop = getattr(done, "loop", None)
+    if loop is not None:                                 # the scoring loop alone (without interpreter start, imports, the runtime's start)
+        fed_by = f"{loop['reader_processes']} reader processes" if loop["reader_processes"] else f"{loop['reader_threads']} reader threads"
+        warm = f"; {loop['sweeps_per_s_after_warm_up']:.0f} sweeps/s after the first {WARM_BATCHES} batches" if "sweeps_per_s_after_warm_up" in loop else ""
+        print(f"Scoring loop: {loop['sweeps'] / max(loop['seconds'], 1e-9):.0f} sweeps/s ({loop['sweeps']} sweeps in {loop['seconds']:.2f} s, {fed_by}){warm}")

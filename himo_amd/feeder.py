@@ -19,6 +19,7 @@ from __future__ import annotations
 import itertools
 import queue
 import threading
+import time
 
 import numpy as np
 import torch
@@ -38,7 +39,7 @@ class _PinnedArena:
 
     def reset(self, need_bytes: int):
         if self._buf.numel() < need_bytes:
-            self._buf = torch.empty(int(need_bytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+            self._buf = _lib.pinned_empty(int(need_bytes * 1.25) + 4096)
         self._used = 0
         self._extra_used = [0] * len(self._extra)
 
@@ -55,7 +56,7 @@ class _PinnedArena:
             if lo + nbytes <= blk.numel():
                 self._extra_used[i] = lo + nbytes
                 return blk[lo:lo + nbytes].view(dtype).view(*shape)
-        blk = torch.empty(max(int(nbytes * 1.25) + 4096, 1 << 24), dtype=torch.uint8, pin_memory=True)
+        blk = _lib.pinned_empty(max(int(nbytes * 1.25) + 4096, 1 << 24))
         self._extra.append(blk)
         self._extra_used.append(nbytes)
         return blk[:nbytes].view(dtype).view(*shape)
@@ -230,7 +231,7 @@ class ResultDrain:
         for buf in rest:
             self._free.put(buf)
         if fit is None:
-            fit = torch.empty(1 << max(int(like.numel()) - 1, 1).bit_length(), dtype=like.dtype, pin_memory=True)
+            fit = _lib.pinned_empty(1 << max(int(like.numel()) - 1, 1).bit_length(), like.dtype)
         return fit
 
     def put(self, key, t: torch.Tensor) -> None:
@@ -397,6 +398,281 @@ class BatchFeeder:
             yield obj
 
 
+class _Ref:
+    """Where a reader process put one array of a batch: byte offset inside its slot, shape, numpy dtype string."""
+    __slots__ = ("off", "shape", "dtype")
+
+    def __init__(self, off, shape, dtype):
+        self.off, self.shape, self.dtype = off, tuple(shape), dtype
+
+    def __reduce__(self):
+        return _Ref, (self.off, self.shape, self.dtype)
+
+
+def _swap_refs(obj, view, depth: int = 0):
+    """Replace the ``_Ref`` attributes of a batch object (and of the himo_amd objects it holds) by ``view(ref)``."""
+    for k, v in list(vars(obj).items()):
+        if isinstance(v, _Ref):
+            setattr(obj, k, view(v))
+        elif depth < 2 and hasattr(v, "__dict__") and type(v).__module__.startswith(__name__.rsplit(".", 1)[0]):
+            _swap_refs(v, view, depth + 1)
+
+
+class ReaderPool:
+    """``build(make(k), upload)`` for k = 0 .. n_items-1 on forked reader PROCESSES, results handed back in order.
+
+    Why processes: parsing an HDF5 sweep is ~0.2 ms of interpreter work and packing a batch a dozen numpy calls; on threads that work
+    holds the interpreter lock the consumer's launch thread needs (the evaluator launches and scores ~5 k sweeps/s from resident
+    batches, 1.4 k fed by threads).  The reference's loops get the same effect from ``DataLoader(num_workers=...)``.
+
+    Each worker writes a batch's arrays end to end into a SLOT -- an anonymous shared mapping made before the fork, so parent and
+    children see the same pages (``slot_bytes`` is address space: only pages a batch touched are ever committed) -- and sends back
+    the batch object with ``_Ref`` placeholders (a few hundred bytes through a pipe).  A batch larger than a slot makes the pool
+    start over from that batch with larger slots.  Workers never touch the GPU; they inherit ``make`` / ``build`` and everything
+    those reference (open, memory-mapped scene files) through the fork.
+
+    WHEN to fork: ``start()`` -- called by the constructor of ``ProcessBatchFeeder`` -- should run BEFORE the process has started
+    the HIP runtime.  A fork write-protects the parent's private pages for copy-on-write; where those pages are mapped into the
+    GPU's address space the driver takes the mappings away and rebuilds them at the next device operation: 0.2 s in a process that
+    has only started the runtime, ~3 s in one that has run the evaluator (scripts/exp_fork_cost.py, profiles/r06_exp_fork_cost.txt).
+    Programs (``python -m himo_amd.eval``) therefore start their readers first thing."""
+
+    def __init__(self, n_items: int, make, build, workers: int = 4, n_slots: int | None = None, slot_bytes: int = 512 << 20,
+                 on_slots=None, off_slots=None):
+        import multiprocessing
+        self.n, self._make, self._build = int(n_items), make, build
+        self.workers = max(1, int(workers))
+        self.n_slots = max(int(n_slots) if n_slots else self.workers + 2, 1)
+        self.slot_bytes = int(slot_bytes)
+        self._on_slots, self._off_slots = on_slots, off_slots
+        self._ctx = multiprocessing.get_context("fork")
+        self._procs, self._tasks, self._results = [], [], None
+        self._maps, self.slots = [], []
+        self.restarts = 0
+        self._stop = False
+        # where the wall time went: slots + fork, shutdown (this process); reading and packing (summed over the workers)
+        self.stage_seconds = {"start": 0.0, "halt": 0.0, "read": 0.0, "pack": 0.0, "batches": 0}
+
+    # ---- the child ---------------------------------------------------------------------------------------------------
+    def _child(self, w):
+        tasks, results, maps = self._tasks[w], self._results, self._maps
+        while True:
+            t = tasks.get()
+            if t is None:
+                return
+            k, s = t
+            try:
+                buf = np.frombuffer(maps[s], dtype=np.uint8)
+                need = [0]
+
+                def upload(parts, dtype):
+                    parts = [np.asarray(p) for p in parts]
+                    dt = np.dtype(dtype)
+                    shape = (sum(p.shape[0] for p in parts),) + tuple(parts[0].shape[1:])
+                    nbytes = int(np.prod(shape)) * dt.itemsize
+                    lo = (need[0] + 63) & ~63
+                    need[0] = lo + nbytes
+                    if nbytes and need[0] <= buf.size:
+                        np.concatenate(parts, 0, buf[lo:lo + nbytes].view(dt).reshape(shape), casting="unsafe")
+                    return _Ref(lo, shape, dt.str)
+                t0 = time.perf_counter()
+                item = self._make(k)
+                t1 = time.perf_counter()
+                obj = self._build(item, upload)
+                t2 = time.perf_counter()
+                results.put(("grow", k, s, need[0]) if need[0] > buf.size else ("ok", k, s, need[0], obj, t1 - t0, t2 - t1))
+            except BaseException as e:
+                try:
+                    results.put(("error", k, s, e))
+                except BaseException:
+                    results.put(("error", k, s, RuntimeError(f"{type(e).__name__}: {e}")))
+
+    # ---- the parent --------------------------------------------------------------------------------------------------
+    def start(self):
+        """make the slots and fork the workers now (idempotent; iteration does it otherwise)"""
+        if not self._procs and self.n > 0:
+            self._start()
+
+    def _start(self):
+        import mmap
+        t0 = time.perf_counter()
+        self._maps = [mmap.mmap(-1, self.slot_bytes) for _ in range(self.n_slots)]           # MAP_SHARED | MAP_ANONYMOUS
+        self.slots = [torch.frombuffer(m, dtype=torch.uint8) for m in self._maps]
+        self._tasks = [self._ctx.SimpleQueue() for _ in range(self.workers)]
+        self._results = self._ctx.SimpleQueue()
+        self._procs = [self._ctx.Process(target=self._child, args=(w,), name=f"himo-reader-{w}", daemon=True) for w in range(self.workers)]
+        for p in self._procs:
+            p.start()
+        if self._on_slots is not None:
+            self._on_slots(self.slots)
+        self.stage_seconds["start"] += time.perf_counter() - t0
+
+    def _halt(self):
+        t0 = time.perf_counter()
+        for p in self._procs:
+            if p.is_alive():
+                p.terminate()                      # readers hold nothing that needs an orderly exit
+        for p in self._procs:
+            p.join(timeout=5)
+        self._procs = []
+        if self.slots and self._off_slots is not None:
+            self._off_slots(self.slots)
+        self.slots = []
+        maps, self._maps = self._maps, []
+        for m in maps:
+            try:
+                m.close()
+            except BufferError:                    # a tensor view is still alive somewhere: the mapping goes with it
+                pass
+        self.stage_seconds["halt"] += time.perf_counter() - t0
+
+    def close(self):
+        self._stop = True
+
+    def _next_message(self):
+        while not self._results._reader.poll(0.2):
+            if self._stop:
+                return None
+            dead = [p.name for p in self._procs if not p.is_alive()]
+            if dead:
+                raise RuntimeError(f"reader process {dead[0]} died")
+        return self._results.get()
+
+    def __iter__(self):
+        """yields (k, slot index, bytes used, batch object with _Ref placeholders); the consumer calls ``release(slot)`` once it has
+        read the slot (copies out of it have completed or are ordered before its next use by ``release``'s caller)."""
+        if self.n == 0:
+            return
+        k_out = k_task = 0
+        done, self._free = {}, list(range(self.n_slots))
+        self.start()
+        try:
+            while k_out < self.n and not self._stop:
+                while self._free and k_task < self.n:
+                    self._tasks[k_task % self.workers].put((k_task, self._free.pop(0)))
+                    k_task += 1
+                if k_out in done:
+                    if done[k_out][0] == "error":          # raised where the serial loop would have met it: after the batches before it
+                        raise done[k_out][3]
+                    _, k, s, used, obj, t_read, t_pack = done.pop(k_out)
+                    st = self.stage_seconds
+                    st["read"] += t_read
+                    st["pack"] += t_pack
+                    st["batches"] += 1
+                    yield k, s, used, obj
+                    k_out += 1
+                    continue
+                msg = self._next_message()
+                if msg is None:
+                    return
+                if msg[0] == "grow":
+                    # start over from the oldest batch not handed out yet, with slots that hold this one
+                    self._halt()
+                    self.slot_bytes = max(int(msg[3] * 1.25) + 4096, self.slot_bytes)
+                    self.restarts += 1
+                    done.clear()
+                    k_task, self._free = k_out, list(range(self.n_slots))
+                    self._start()
+                    continue
+                done[msg[1]] = msg
+        finally:
+            self._halt()
+
+    def release(self, slot: int) -> None:
+        self._free.append(slot)
+
+
+class ProcessBatchFeeder:
+    """``BatchFeeder`` whose batches are read and packed by forked reader processes (``ReaderPool``): iterate device-resident batch
+    objects, ``depth`` ahead of the consumer.  ``make(k)`` reads item k (a list of frame dicts, ...) and ``build(item, upload)`` packs
+    it -- both run in a worker; this process's feeder thread issues ONE host -> device copy per batch out of the worker's slot (the
+    part of a slot that batches have used is registered with the HIP runtime: the copy is a DMA at the link's rate, asynchronous)
+    and turns the placeholders into views of the device block.  The constructor forks the workers BEFORE it touches the device:
+    construct it before anything else starts the HIP runtime (see ``ReaderPool``)."""
+
+    _END = object()
+
+    def __init__(self, n_items: int, make, build, device=None, depth: int = 2, workers: int = 4, slot_bytes: int = 512 << 20):
+        self._registered = {}                          # slot -> bytes of its head registered with the runtime
+        self.pool = ReaderPool(n_items, make, build, workers=workers, n_slots=workers + depth + 1, slot_bytes=slot_bytes,
+                               off_slots=self._unregister)
+        self.forked_before_hip = not torch.cuda.is_initialized()
+        self.pool.start()
+        self.device = device if device is not None else _lib.require_gpu()
+        self.depth = depth
+        self._q = queue.Queue(maxsize=depth)
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._error = None
+        self._stop = False
+        self._thread = threading.Thread(target=self._work, name="himo-process-feeder", daemon=True)
+        self._thread.start()
+
+    def _ensure_registered(self, s: int, used: int) -> None:
+        """the first ``used`` bytes of slot s are pinned and mapped for the GPU (grown in steps: registering commits the pages)"""
+        have = self._registered.get(s, 0)
+        if used <= have:
+            return
+        rt, t = torch.cuda.cudart(), self.pool.slots[s]
+        if have:
+            rt.cudaHostUnregister(t.data_ptr())
+        want = min(t.numel(), ((int(used * 1.25) + (8 << 20)) + 0x1FFFFF) & ~0x1FFFFF)
+        rc = rt.cudaHostRegister(t.data_ptr(), want, 0)
+        if int(rc) != 0:
+            raise RuntimeError(f"hipHostRegister of {want >> 20} MB of a reader slot failed: {rc}")
+        self._registered[s] = want
+
+    def _unregister(self, slots):
+        torch.cuda.synchronize(self.device)                                   # copies out of the slots have completed
+        rt = torch.cuda.cudart()
+        for s, t in enumerate(slots):
+            if self._registered.pop(s, 0):
+                rt.cudaHostUnregister(t.data_ptr())
+
+    def _work(self):
+        try:
+            torch.cuda.set_device(self.device)
+            for k, s, used, obj in self.pool:
+                self._ensure_registered(s, used)
+                with torch.cuda.stream(self._stream):
+                    dev_blk = torch.empty(max(used, 1), dtype=torch.uint8, device=self.device)
+                    if used:
+                        dev_blk[:used].copy_(self.pool.slots[s][:used], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._stream)
+
+                def view(ref, blk=dev_blk):
+                    tdt = torch.from_numpy(np.empty(0, np.dtype(ref.dtype))).dtype
+                    n = int(np.prod(ref.shape)) * np.dtype(ref.dtype).itemsize
+                    if n == 0:
+                        return torch.empty(ref.shape, dtype=tdt, device=self.device)
+                    return blk[ref.off:ref.off + n].view(tdt).view(ref.shape)
+                _swap_refs(obj, view)
+                ev.synchronize()            # the slot goes back to a reader only after the copy out of it (a few ms; this thread idles anyway)
+                self.pool.release(s)
+                if not self._offer((obj, [dev_blk], ev)):
+                    break
+        except BaseException as e:
+            self._error = e
+        finally:
+            self.pool.close()
+            self._offer(self._END)
+
+    _offer = BatchFeeder._offer
+    __iter__ = BatchFeeder.__iter__
+
+    def close(self) -> None:
+        self._stop = True
+        self.pool.close()
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=10)
+        if self.pool._procs and not self._thread.is_alive():      # never iterated: the workers of the constructor are still there
+            self.pool._halt()
+
+
 _TRAIN_STREAMS = {}
 _TRAIN_STREAMS_LOCK = threading.Lock()
 
@@ -525,7 +801,7 @@ class TrainFeeder:
                 keep = self._cache is not None and self._cache_budget > 0
                 if keep:                                       # a host copy for the later epochs, behind the same wait as the count
                     if getattr(tls, "host", None) is None or tls.host.numel() < l0.numel() + l1.numel():
-                        tls.host = torch.empty(int((l0.numel() + l1.numel()) * 1.25) + 16, dtype=torch.int32).pin_memory()
+                        tls.host = _lib.pinned_empty(int((l0.numel() + l1.numel()) * 1.25) + 16, torch.int32)
                     tls.host[:l0.numel()].copy_(l0, non_blocking=True)
                     tls.host[l0.numel():l0.numel() + l1.numel()].copy_(l1, non_blocking=True)
                 counted = torch.cuda.Event()

@@ -69,7 +69,7 @@ class HiMoPipeline:
         slot = self._pin_ring[self._pin_next]
         self._pin_next = (self._pin_next + 1) % len(self._pin_ring)
         if slot[0].numel() < n:
-            slot[0] = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+            slot[0] = _lib.pinned_empty(n)
         elif slot[1] is not None:
             slot[1].synchronize()
         np.copyto(slot[0].numpy()[:n], host_bytes)

@@ -85,6 +85,14 @@ def test_h5_fixture_through_the_three_programs(gpu, oracle, tmp_path, monkeypatc
     direct = ev.main(str(root), res_name=res_name, batch_frames=4, file_name=str(tmp_path / "d.json"))
     via_zip = ev.main(str(root), res_name=res_name, comp_dis_zip=str(z), batch_frames=4, file_name=str(tmp_path / "z.json"))
     assert direct.frame_cnt == via_zip.frame_cnt == 4 and direct.data_name == data_name
+    # the programs above were fed by reader threads (short evaluations, and this process holds device memory); forked reader
+    # PROCESSES -- what a long evaluation started from a shell gets -- give the same lists
+    assert direct.loop["reader_processes"] == 0 and direct.loop["reader_threads"] == 4
+    procs = ev.main(str(root), res_name=res_name, batch_frames=4, file_name=str(tmp_path / "p.json"), num_workers=2)
+    procs_zip = ev.main(str(root), res_name=res_name, comp_dis_zip=str(z), batch_frames=4, file_name=str(tmp_path / "pz.json"), num_workers=2)
+    assert procs.loop["reader_processes"] == 2 and procs.feed_stats["batches"] == 1 and procs.feed_stats["restarts"] == 0
+    assert procs.evaluate_data == direct.evaluate_data and procs_zip.evaluate_data == via_zip.evaluate_data
+    assert [k for k, _ in procs._log] == [k for k, _ in direct._log]
     ref = _check_against_oracle(oracle, data_name, root, res_name,
                                 {"evaluate_data": direct.evaluate_data, "summary": direct.summary()},
                                 {"evaluate_data": via_zip.evaluate_data, "summary": via_zip.summary()}, z, 4)
