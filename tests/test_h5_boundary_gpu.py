@@ -162,7 +162,10 @@ def test_config3_scania_h5_programs_as_two_ranks(gpu, oracle, tmp_path):
     _torchrun("himo_amd.eval", "--data_dir", str(root), "--res_name", res, cwd=tmp_path)
     direct = json.loads((tmp_path / "res-scania.json").read_text())
     (tmp_path / "res-scania.json").rename(tmp_path / "res-scania-direct.json")
-    _torchrun("himo_amd.eval", "--data_dir", str(root), "--res_name", res, "--comp_dis_zip", str(z), cwd=tmp_path)
+    # (the second evaluation is fed by two forked reader processes per rank -- forked inside the process group, before the ranks start
+    # the HIP runtime; the workers read the scene files AND the zip members)
+    out = _torchrun("himo_amd.eval", "--data_dir", str(root), "--res_name", res, "--comp_dis_zip", str(z), "--num_workers", "2", cwd=tmp_path)
+    assert "2 reader processes" in out.stdout
     via_zip = json.loads((tmp_path / "res-scania.json").read_text())
     from himo_amd.save_zip import read_output_zip
     ref_direct, ref_zip = oracle.InstanceMetrics("scania"), oracle.InstanceMetrics("scania")
