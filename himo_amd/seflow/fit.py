@@ -197,7 +197,7 @@ def fit(dataset, params: dict | None = None, out_dir=None, epochs: int = 12, bat
         # know (the step's global sample count and the world size), so that all of them enter the same sequence of collectives
         step_sizes = [len(order[s * batch_size:(s + 1) * batch_size]) for s in range(n_steps)]
         for smp, n_global in zip(samples_of(dataset, mine), step_sizes):
-            losses.append(tr.train_batch(smp, lr=lr_e, bucketed=math.ceil(n_global / world) <= tr.B))
+            losses.append(tr.train_batch(smp, lr=lr_e, bucketed=math.ceil(n_global / world) <= tr.B, global_count=n_global))
             steps_done += 1
         train_feed = dict(feed_stats[0]) if feed_stats else None
         train_loss = float(torch.stack(losses).mean().item()) if losses else float("nan")      # (waits for the epoch's last step)

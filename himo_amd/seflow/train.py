@@ -434,14 +434,32 @@ def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
-def combine_batch_(flat_acc: torch.Tensor, flat_g: torch.Tensor) -> torch.Tensor:
+def global_count_known(local_count: int, global_count: int | None) -> bool:
+    """Does the HOST know the global batch's sample count?  Without a process group it is the local count; with one, only when the
+    caller passed it (``fit`` knows every step's global size).  Raises for a step without any sample.  When the answer is no the count
+    is read back from the device after the exchange -- a host wait for the whole step, every step: the launch thread then starts
+    each step's enqueue only after the previous step has FINISHED (56.4 ms of a 56.6 ms step in ``.item()`` at 8 samples per pass,
+    scripts/exp_train_host.py), and everything the host does between steps -- fetching the next samples from the feeder -- is device
+    idle time."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        global_count = local_count
+    if global_count is None:
+        return False
+    if global_count <= 0:
+        raise ValueError("train_batch needs at least one sample on some rank")
+    return True
+
+
+def combine_batch_(flat_acc: torch.Tensor, flat_g: torch.Tensor, count_known: bool = False) -> torch.Tensor:
     """The data-parallel exchange of ``train_batch``: ``flat_acc`` = [this rank's gradient SUM | its sample count | its loss
     sum] -> ONE all-reduce (sum over ranks) -> ``flat_g`` = global gradient sum / global count.  Returns the global mean loss.
-    Every sample of the global batch gets weight 1 / count whatever the split over the ranks (2,1,1,1 or an empty rank)."""
+    Every sample of the global batch gets weight 1 / count whatever the split over the ranks (2,1,1,1 or an empty rank).
+    ``count_known``: the host has checked that the global count is positive (``global_count_known``): no read-back."""
     n = flat_g.numel()
     allreduce_sum_(flat_acc)
     count = flat_acc[n]
-    if float(count.item()) <= 0.0:
+    if not count_known and float(count.item()) <= 0.0:
         raise ValueError("train_batch needs at least one sample on some rank")
     torch.div(flat_acc[:n], count, out=flat_g)
     return (flat_acc[n + 1] / count).clone()
@@ -1447,7 +1465,7 @@ class SeFlowTrainer:
         self.adam_step(lr)
         return terms, total
 
-    def train_batch(self, samples, lr: float = 6e-5, bucketed: bool = False):
+    def train_batch(self, samples, lr: float = 6e-5, bucketed: bool = False, global_count: int | None = None):
         """One optimisation step on SEVERAL samples per rank (the launcher's ``batch_size=8``): ``samples`` = iterable of (pch1, pc0,
         pc1, pose_h1, pose0, pose1, label0, label1, n_labels).  They go through the network ``batch`` at a time (the constructor's
         capacity: ONE forward / backward pass over up to that many samples, BatchNorm statistics over the pass's samples -- torch's
@@ -1461,11 +1479,17 @@ class SeFlowTrainer:
         sequences of collectives.  False: ONE flat all-reduce after the last pass.  True: bucket by bucket UNDER the backward pass
         (``BucketedAllReduce``) -- possible when every rank's share of the step is at most one pass (<= ``batch`` samples; 0 is fine:
         that rank sends zeros through the same collectives); the caller decides from what all ranks know (``fit``: the global batch
-        size and the world size).  Same sums, element by element."""
+        size and the world size).  Same sums, element by element.
+
+        ``global_count``: the number of samples of the step over ALL ranks when the caller knows it (ignored without a process group:
+        it is ``len(samples)``).  Without it the count is read back from the device after the exchange -- a host wait for the whole
+        step (``global_count_known``)."""
         n = self.flat_g.numel()
         if not hasattr(self, "flat_acc") or self.flat_acc.numel() != n + 2:
             self.flat_acc = torch.zeros(n + 2, dtype=self.flat_g.dtype, device=self.flat_g.device)   # [gradient sum | count | loss sum]
         acc = self.flat_acc[:n]
+        samples = list(samples)
+        known = global_count_known(len(samples), global_count)
         it, passes = iter(samples), 0
         import torch.distributed as dist
         if bucketed and self.overlap_allreduce and dist.is_available() and dist.is_initialized():
@@ -1483,7 +1507,7 @@ class SeFlowTrainer:
                     exchange.launch(k)
                 exchange.wait()
             count = words[0]
-            if float(count.item()) <= 0.0:
+            if not known and float(count.item()) <= 0.0:
                 raise ValueError("train_batch needs at least one sample on some rank")
             self.flat_g.div_(count)
             loss = (words[1] / count).clone()
@@ -1504,7 +1528,7 @@ class SeFlowTrainer:
             self.flat_acc[n + 1] += torch.stack(totals).sum().to(self.flat_acc.dtype)
         if passes == 0:
             self.flat_acc.zero_()
-        loss = combine_batch_(self.flat_acc, self.flat_g)
+        loss = combine_batch_(self.flat_acc, self.flat_g, count_known=known)
         self.adam_step(lr)
         return loss
 

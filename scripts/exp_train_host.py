@@ -1,13 +1,15 @@
 """Is the training step host-bound?  Per step: the wall time of a synchronised step, and the host time spent ENQUEUEING a step (no
 synchronisation until the end of 20 steps).  If the enqueue time is close to the step time the Python / HIP launch path is the limit.
-usage (GPU box): python scripts/exp_train_host.py"""
+usage (GPU box): python scripts/exp_train_host.py [samples per pass = 1]"""
 import sys, time, types
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 import bench
 
-args = types.SimpleNamespace(frames_per_step=1, points=120_000, train_precision="mixed", train_batchnorm="batch", cloud="uniform")
+TB = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+args = types.SimpleNamespace(frames_per_step=TB, points=120_000, train_precision="mixed", train_batchnorm="batch", cloud="uniform", train_batch=TB,
+                             sample_sets=3)
 dev = torch.device("cuda", 0)
 res = {}
 step, trainer = bench.make_train_step(args, 0, dev, res)
@@ -31,4 +33,5 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(10):
     step()
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(24)
+pstats.Stats(pr).sort_stats("cumulative").print_stats("train.py|ssl_loss", 24)
