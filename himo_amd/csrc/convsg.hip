@@ -208,7 +208,8 @@ void conv3_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
                 for (int r = 0; r < 16; ++r) {
                     const float v = epi_activate<EPI>(acc[mi][nt][r], eA[nt], eB[nt]);
                     word[r] = OSPLIT ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
-                    if (OSPLIT && mi == 0 && nt == 0 && r == 0) note_range(a, v);
+                    if (OSPLIT && mi == 0 && nt == 0 && r == 0)          // (a lane's sample counts only where it is a pixel and a channel of the image)
+                        note_range(a, (oy < a.Ho && 4 * lh < n_px && tn * BN + wc * NT * 32 + li < a.Cout) ? v : 0.f);
                 }
                 store_block_vec<OSPLIT>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, oy < a.Ho ? n_px : 0, tn * BN + (wc * NT + nt) * 32);
             }
@@ -350,7 +351,7 @@ void conv1_presplit_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
             for (int r = 0; r < 16; ++r) {
                 const float v = epi_activate<EPI>(acc[mi][r], eA, eB);
                 word[r] = OSPLIT ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
-                if (OSPLIT && mi == 0 && r == 0) note_range(a, v);
+                if (OSPLIT && mi == 0 && r == 0) note_range(a, (4 * lh < left && tn * BN + wc * 32 + li < a.Cout) ? v : 0.f);
             }
             store_block_vec<OSPLIT>(a, yout, stg, word, lane, pix0, left < 0 ? 0 : left > 32 ? 32 : (int)left, tn * BN + wc * 32);
         }

@@ -278,7 +278,7 @@ void conv3_split_kernel(ConvArgs a, const unsigned short* __restrict__ wpk) {
                     v = epilogue_value<EPI>(v + bv, scv, shv);
                 }
                 word[r] = (FMT == 2 && osplit) ? split_word(v, li & 1) : __builtin_bit_cast(unsigned, v);
-                if (FMT == 2 && mi == 0 && r == 0 && osplit) note_range(a, v);
+                if (FMT == 2 && mi == 0 && r == 0 && osplit) note_range(a, (oy < a.Ho && 4 * lh < n_px && tn * BN + wc * 32 + li < a.Cout) ? v : 0.f);
             }
             if (FMT == 2 && osplit) store_block_vec<true>(a, yout, stg, word, lane, (int64_t)oy * a.Wo + ox0, oy < a.Ho ? n_px : 0, tn * BN + wc * 32);
             else if (FMT == 4 && (a.act_flags & kActAccumulate))

@@ -94,6 +94,15 @@ def result_file(directory, res_name: str, scene_id: str) -> Path:
     return Path(directory) / "results_h5" / res_name / f"{scene_id}.h5"
 
 
+def scene_stamp(in_scene) -> np.ndarray:
+    """uint64[2] = (1 if the scene file held the array else 0, CRC-32 of its bytes): what ``save.H5ResultSink`` records beside a result
+    it could not write into the scene file, and what ``HDF5Dataset`` compares the scene file's array with later."""
+    import zlib
+    if in_scene is None:
+        return np.zeros(2, dtype=np.uint64)
+    return np.array([1, zlib.crc32(np.ascontiguousarray(in_scene).view(np.uint8).reshape(-1))], dtype=np.uint64)
+
+
 def allow_dropped_eval_default() -> bool:
     return os.environ.get("HIMO_ALLOW_DROPPED_EVAL", "0") not in ("", "0", "false", "False")
 
@@ -257,9 +266,12 @@ class HDF5Dataset:
 
     def _result_source(self, name: str, scene_id: str):
         """Which file answers for ``<res_name>`` of a scene when BOTH the scene file and a result file beside it
-        (``result_file``) exist: the one modified LAST.  This package's in-place writer removes the side entries it supersedes
+        (``result_file``) exist.  This package's in-place writer removes the side entries it supersedes
         (``save.H5ResultSink._supersede_beside``), but another tool -- the reference's ``save.py``, h5py, h5copy -- that writes
-        ``<res_name>`` into the scene file later knows nothing of the side file: preferring it blindly would score stale flows."""
+        ``<res_name>`` into the scene file later knows nothing of the side file: preferring it blindly would score stale flows.
+        "side": the side file is the newer file.  "scene-newer": the scene file was modified after it -- which says nothing about
+        ``<res_name>`` (a touch, a copy, another result name written in place): ``read`` then decides per sweep from the stamp the
+        side writer left (``scene_stamp``: was the in-scene array there, and with which bytes, when the side result was written)."""
         key = (name, scene_id)
         got = self._result_choice.get(key)
         if got is None:
@@ -303,9 +315,14 @@ class HDF5Dataset:
                     r = self._files.get(result_file(self.directory, name, scene_id))
                     in_side = ts in r and name in r[ts]
                     if in_side and src == "scene-newer" and name in g:
-                        import warnings
-                        warnings.warn(f"{scene_id}.h5 was modified after the result file beside it ({result_file(self.directory, name, scene_id)}) "
-                                      f"and holds '{name}' for sweep {ts} too: using the scene file's; delete or merge the side file", stacklevel=2)
+                        stamp = np.asarray(r[ts][name + "@scene"][:]) if (name + "@scene") in r[ts] else None
+                        if stamp is not None and np.array_equal(stamp, scene_stamp(g[name][:])):
+                            d[name] = self._array(r[ts][name])         # the in-scene array is the one the side result replaced: still older
+                        else:
+                            import warnings
+                            warnings.warn(f"{scene_id}.h5 was modified after the result file beside it ({result_file(self.directory, name, scene_id)}) "
+                                          f"and its '{name}' for sweep {ts} is not the one that file replaced: using the scene file's; delete or "
+                                          f"merge the side file", stacklevel=2)
                     elif in_side:
                         d[name] = self._array(r[ts][name])
                 if name not in d and name in g:

@@ -208,8 +208,21 @@ class H5ResultSink:
         if path.exists():                                          # an earlier run / an earlier part of this scene: keep, then replace
             with h5lite.File(path) as old:
                 tree = {ts: {k: old[ts][k][:] for k in old[ts].keys()} for ts in old.keys()}
+        # provenance, per sweep: what the SCENE file held under <res_name> when this result was written (present?, CRC-32 of its bytes).
+        # The loader uses it when the scene file is later found modified: an unchanged in-scene array is older than this result (the
+        # scene was touched, copied, or given another <res_name>), a changed one was written by another tool afterwards and wins.
+        from .dataset import scene_stamp
+        scene_path = Path(self.directory) / f"{self._scene}.h5"
+        held = {}
+        if scene_path.exists():
+            with h5lite.File(scene_path) as sc:
+                for ts, _ in self._pending:
+                    if ts in sc and self.res_name in sc[ts]:
+                        held[ts] = sc[ts][self.res_name][:]
         for ts, flow in self._pending:
-            tree.setdefault(ts, {})[self.res_name] = flow
+            entry = tree.setdefault(ts, {})
+            entry[self.res_name] = flow
+            entry[self.res_name + "@scene"] = scene_stamp(held.get(ts))
         path.parent.mkdir(parents=True, exist_ok=True)
         h5lite.write_file(path, tree)
         if path not in self.side_files:

@@ -331,28 +331,53 @@ def test_scene_files_stay_open_between_items(tmp_path):
 
 def test_newer_scene_file_wins_over_a_stale_result_file_beside_it(tmp_path, monkeypatch):
     """a result file left beside a scene by a library-less run must not shadow a ``<res_name>`` that
-    another tool wrote INTO the scene file later."""
+    another tool wrote INTO the scene file later.  ADVICE r05 (low): ... and a scene file that was merely touched (or given another
+    result name) afterwards must not bring its OLD ``<res_name>`` back: the side writer stamps what the scene held, per sweep."""
     import os
     import shutil
     import warnings
+    from himo_amd import h5lite
     from himo_amd.dataset import result_file
     shutil.copytree(GOLDEN / "h5", tmp_path / "d")
     root = tmp_path / "d"
     ds = HDF5Dataset(root, vis_name="seflowpp_best")
     in_file = ds[0]["seflowpp_best"].copy()
+    scene = root / f"{ds[0]['scene_id']}.h5"
     monkeypatch.setattr(save, "h5_writer", lambda: (None, "no HDF5 library"))
     sink = save.H5ResultSink(root, "seflowpp_best")
     sink(0, ds[0], np.full_like(in_file, 3.0))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         sink.close()
+    ds.close()
     side = result_file(root, "seflowpp_best", ds[0]["scene_id"])
     assert (HDF5Dataset(root, vis_name="seflowpp_best")[0]["seflowpp_best"] == 3).all()         # the side file is the newer one
     later = side.stat().st_mtime_ns + 5_000_000_000
-    os.utime(root / f"{ds[0]['scene_id']}.h5", ns=(later, later))       # "another tool rewrote the scene file afterwards"
+    os.utime(scene, ns=(later, later))                                  # touched: the in-scene array is still the one the result replaced
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        touched = HDF5Dataset(root, vis_name="seflowpp_best")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                  # (no "modified after the result file" warning)
+        assert (touched[0]["seflowpp_best"] == 3).all()
+    with h5lite.File(scene) as f:                                       # "another tool wrote <res_name> into the scene file afterwards"
+        tree = {ts: {k: f[ts][k].read() for k in f[ts].keys()} for ts in f.keys()}
+    ts0 = str(ds[0]["timestamp"])
+    tree[ts0]["seflowpp_best"] = np.full_like(in_file, 7.0)
+    h5lite.write_file(scene, tree)
+    later += 5_000_000_000
+    os.utime(scene, ns=(later, later))
     with pytest.warns(UserWarning, match="modified after the result file"):
         got = HDF5Dataset(root, vis_name="seflowpp_best")[0]["seflowpp_best"]
-    assert np.array_equal(got, in_file)
+    assert (got == 7).all()
+    # a side file from before the stamps existed: the scene file's copy wins, as it did
+    with h5lite.File(side) as f:
+        old = {ts: {k: f[ts][k][:] for k in f[ts].keys() if not k.endswith("@scene")} for ts in f.keys()}
+    h5lite.write_file(side, old)
+    os.utime(side, ns=(later - 1_000_000_000, later - 1_000_000_000))
+    with pytest.warns(UserWarning, match="modified after the result file"):
+        got = HDF5Dataset(root, vis_name="seflowpp_best")[0]["seflowpp_best"]
+    assert (got == 7).all()
 
 
 def test_prefetching_frame_cache_returns_the_same_frames_in_order(tmp_path):
