@@ -110,7 +110,7 @@ try:
     del smp
 
     # ---- the loop ---------------------------------------------------------------------------------------------------
-    for workers, prefetch, lanes, cache in ((0, 0, 1, False), (1, 2, 1, False), (2, 2, 2, False), (2, 2, 2, True), (1, 2, 1, True)):
+    for workers, prefetch, lanes, cache in ((0, 0, 1, False), (1, 2, 1, False), (1, 2, 2, False), (1, 2, 3, False), (2, 2, 2, False), (1, 4, 2, False), (2, 2, 2, True), (1, 2, 1, True)):
         fit(ds, trainer=tr, epochs=1, batch_size=8, max_steps=2, log=None, num_workers=workers, prefetch=max(prefetch, 1), label_lanes=lanes, cache_labels=cache)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

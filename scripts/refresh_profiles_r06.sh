@@ -20,6 +20,11 @@ timeout 300 python scripts/exp_eval_feed.py > $OUT/${RN}_exp_eval_feed.txt 2>&1
 timeout 300 python scripts/exp_labels.py > $OUT/${RN}_exp_labels.txt 2>&1
 timeout 300 python scripts/exp_fit_feed.py > $OUT/${RN}_exp_fit_feed.txt 2>&1
 timeout 300 bash scripts/diag_legs.sh > $OUT/${RN}_legs_in_the_default_process.txt 2>&1
+timeout 600 python scripts/exp_eval_main.py 257 2>&1 | grep -v "^ \|^$\|amdgpu.ids" > $OUT/${RN}_exp_eval_main_threads_vs_processes.txt
+timeout 300 python scripts/exp_fork_cost.py > $OUT/${RN}_exp_fork_cost.txt 2>&1
+timeout 300 python scripts/exp_train_host.py 8 > $OUT/${RN}_exp_train_host_b8.txt 2>&1
+timeout 300 python scripts/exp_nsf_forward_ablation.py > $OUT/${RN}_exp_nsf_forward_ablation.txt 2>&1      # (after: bash scripts/exp_nsf_forward_ablation.sh on the build host)
+timeout 900 bash scripts/prof_fit_step.sh ${RN}_fit_step_kernels_and_streams > /dev/null 2>&1; cp gpurun_out/${RN}_fit_step_kernels_and_streams.txt $OUT/
 cd /tmp && export TMPDIR=/tmp
 HIMO_EXP_LABELS_ONLY=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_labels -o lab -- python $R/scripts/exp_labels.py > /dev/null 2>&1
 f=$(find $OUT/prof_labels -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${RN}_labels_rocprofv3_kernel_stats.csv; rm -rf $OUT/prof_labels
