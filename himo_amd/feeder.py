@@ -501,6 +501,12 @@ class ReaderPool:
         self._tasks = [self._ctx.SimpleQueue() for _ in range(self.workers)]
         self._results = self._ctx.SimpleQueue()
         self._procs = [self._ctx.Process(target=self._child, args=(w,), name=f"himo-reader-{w}", daemon=True) for w in range(self.workers)]
+        import sys
+        for stream in (sys.stdout, sys.stderr):                   # a child inherits what is buffered here and would write it again if it ever flushed
+            try:
+                stream.flush()
+            except Exception:
+                pass
         for p in self._procs:
             p.start()
         if self._on_slots is not None:
