@@ -306,20 +306,42 @@ class InstanceMetrics:
     def _average(cls, values, weights):
         """np.average(values, weights=weights) for float values and int weights"""
         n = len(values)
-        if n > 7 or any(v != v for v in values):
+        if n == 1:                                                    # (most buckets of a sweep hold one instance)
+            v, w = values[0], float(weights[0])
+            if v == v and w != 0.0:
+                return v * w / w
             return np.average(values, weights=weights)
-        scl = cls._np_sum([float(w) for w in weights])
+        if n > 7:
+            return np.average(values, weights=weights)
+        scl = tot = None
+        for v, w in zip(values, weights):
+            if v != v:
+                return np.average(values, weights=weights)
+            w = float(w)
+            if scl is None:
+                scl, tot = w, v * w
+            else:
+                scl += w
+                tot += v * w
         if scl == 0.0:
             return np.average(values, weights=weights)            # (numpy's ZeroDivisionError)
-        return np.float64(cls._np_sum([v * float(w) for v, w in zip(values, weights)]) / scl)
+        return tot / scl
 
     @classmethod
     def _nanmean_nanstd(cls, values):
         """(float(np.nanmean(values)), float(np.nanstd(values))) for a list of float64 scalars"""
         n = len(values)
-        if n == 0 or n > 7 or any(v != v for v in values):
+        if n == 1:
+            v = float(values[0])
+            if v == v:
+                return v / 1, float(np.sqrt(np.float64((v - v) * (v - v) / 1)))
+        if n == 0 or n > 7:
             return float(np.nanmean(values)), float(np.nanstd(values))
-        vals = [float(v) for v in values]
+        vals = []
+        for v in values:
+            if v != v:
+                return float(np.nanmean(values)), float(np.nanstd(values))
+            vals.append(float(v))
         mean = cls._np_sum(vals) / n
         dev = [(v - mean) * (v - mean) for v in vals]
         return mean, float(np.sqrt(np.float64(cls._np_sum(dev) / n)))
@@ -329,65 +351,56 @@ class InstanceMetrics:
         # contribution: ~125 long-lived dicts and lists per sweep made the interpreter run a full collection -- ~0.3 s with torch
         # imported -- every ~2000 sweeps, 0.15 ms per sweep of the thread that launches the device work
         self._log.append((key, recs))
-        self._apply(self._score(recs))
+        self._accumulate_records(recs)
 
-    def _score(self, recs):
-        """One sweep's contribution to the running lists from its records (eval.py:75-123)."""
-        frame_score = self.init_evaluate_data()
-        # one pass over the sweep's records as Python lists: they come sorted by (group, instance), so appending in this order is
-        # the reference's per-group loop over np.unique's ascending instance ids
+    def _accumulate_records(self, recs):
+        """One sweep's records into the running lists (eval.py:75-147): every qualifying instance into its speed and its distance
+        bucket, then the sweep's mean over its speed buckets.  The records come sorted by (group, instance), so appending in this
+        order is the reference's per-group loop over np.unique's ascending instance ids followed by its bucket-wise ``+=``."""
+        data = self.evaluate_data
         min_vel, n_groups = self.min_vel, len(EVAL_GROUPS)
+        by_speed = {}                                                 # (group id, bucket) -> this sweep's (num_pts, mpe, cham) lists
         for gid, num_pts, vel_ins, dis, mpe, cham in zip(recs["group"].tolist(), recs["num_pts"].tolist(), recs["vel"].tolist(),
                                                          recs["dis"].astype(np.float32).tolist(),     # a float32 mean (eval.py:94)
                                                          recs["mpe"].tolist(), recs["cham"].tolist()):
             if not 1 <= gid <= n_groups or num_pts < 10 or vel_ins < min_vel:
                 continue
-            score = frame_score[EVAL_GROUPS[gid - 1]]
-            for metric, value in (("vel", vel_ins), ("dis", dis)):
-                name = range_name_of(value)
-                if name is None:
-                    print("--- [ERROR]: range_name is None --- the value is:", value, " in ", metric)
-                    continue
-                slot = score[metric][name]
-                slot["num_pts"].append(num_pts)
-                slot["mpe"].append(mpe)
-                slot["cham"].append(cham)
-        for cats_name in EVAL_GROUPS:                                 # per-sweep mean over the speed buckets only
-            totals, mpes, chams = [], [], []
-            by_speed = frame_score[cats_name]["vel"]
-            for name in RANGES:
-                got = by_speed[name]
-                if got["num_pts"]:
-                    mpes.append(self._average(got["mpe"], got["num_pts"]))
-                    chams.append(self._average(got["cham"], got["num_pts"]))
-                    totals.append(sum(got["num_pts"]))
-            if sum(totals) == 0:
-                continue
-            mean = frame_score[cats_name]["mean"]
-            mean["num_pts"].append(sum(totals))
-            (m_mpe, s_mpe), (m_cham, s_cham) = self._nanmean_nanstd(mpes), self._nanmean_nanstd(chams)
-            mean["mpe"].append(m_mpe)
-            mean["cham"].append(m_cham)
-            mean["std_mpe"].append(s_mpe)
-            mean["std_cham"].append(s_cham)
-        return frame_score
-
-    def _apply(self, frame_score):
-        """Append one sweep's contribution to the running lists (eval.py:125-147)."""
-        for c in EVAL_GROUPS:
-            mine, got = self.evaluate_data[c], frame_score[c]
-            for metric in ("vel", "dis"):
+            score = data[EVAL_GROUPS[gid - 1]]
+            name = range_name_of(vel_ins)
+            if name is None:
+                print("--- [ERROR]: range_name is None --- the value is:", vel_ins, " in ", "vel")
+            else:
+                slot = score["vel"][name]
+                slot["num_pts"].append(num_pts); slot["mpe"].append(mpe); slot["cham"].append(cham)
+                mine = by_speed.get((gid, name))
+                if mine is None:
+                    by_speed[(gid, name)] = ([num_pts], [mpe], [cham])
+                else:
+                    mine[0].append(num_pts); mine[1].append(mpe); mine[2].append(cham)
+            name = range_name_of(dis)
+            if name is None:
+                print("--- [ERROR]: range_name is None --- the value is:", dis, " in ", "dis")
+            else:
+                slot = score["dis"][name]
+                slot["num_pts"].append(num_pts); slot["mpe"].append(mpe); slot["cham"].append(cham)
+        if by_speed:
+            for gid, cats_name in enumerate(EVAL_GROUPS, start=1):    # per-sweep mean over the speed buckets only
+                totals, mpes, chams = [], [], []
                 for name in RANGES:
-                    src = got[metric][name]
-                    if src["num_pts"]:
-                        dst = mine[metric][name]
-                        dst["num_pts"] += src["num_pts"]
-                        dst["mpe"] += src["mpe"]
-                        dst["cham"] += src["cham"]
-            src = got["mean"]
-            if src["num_pts"]:
-                for k, dst in mine["mean"].items():
-                    dst += src[k]
+                    got = by_speed.get((gid, name))
+                    if got is not None:
+                        mpes.append(self._average(got[1], got[0]))
+                        chams.append(self._average(got[2], got[0]))
+                        totals.append(sum(got[0]))
+                if sum(totals) == 0:
+                    continue
+                mean = data[cats_name]["mean"]
+                mean["num_pts"].append(sum(totals))
+                (m_mpe, s_mpe), (m_cham, s_cham) = self._nanmean_nanstd(mpes), self._nanmean_nanstd(chams)
+                mean["mpe"].append(m_mpe)
+                mean["cham"].append(m_cham)
+                mean["std_mpe"].append(s_mpe)
+                mean["std_cham"].append(s_cham)
         self.frame_cnt += 1
 
     # ---- multi-GPU: merge the per-sweep contributions of all ranks in sweep order ------------------------------
@@ -406,7 +419,7 @@ class InstanceMetrics:
         self.frame_cnt = 0
         self._log = merged
         for _, recs in merged:
-            self._apply(self._score(recs))
+            self._accumulate_records(recs)
 
     # ---- reporting: eval.py:151-268 ------------------------------------------------------------------------
     def summary(self) -> dict:

@@ -296,8 +296,7 @@ def _worker_eval_cli(rank, world, port, data_dir, out_dir):
                 metrics.frame_cnt += 1
     ev.stream_batches = stream_batches
     ev.InstanceMetrics.flush = lambda self: None
-    ev.InstanceMetrics._score = lambda self, recs: None
-    ev.InstanceMetrics._apply = lambda self, fs: setattr(self, "frame_cnt", self.frame_cnt + 1)
+    ev.InstanceMetrics._accumulate_records = lambda self, recs: setattr(self, "frame_cnt", self.frame_cnt + 1)
     os.chdir(out_dir)
     m = ev.main(data_dir, res_name="seflowpp_best", batch_frames=2, file_name=str(Path(out_dir) / f"res-rank{rank}.json"), num_workers=0)
     Path(out_dir, f"cnt{rank}").write_text(f"{m.frame_cnt} {sorted(k for k, _ in m._log)}")
