@@ -542,7 +542,7 @@ def stream_batches(metrics: "InstanceMetrics", source, res_name: str = ""):
     metrics.flush()
 
 
-def stream_batches_from_processes(metrics: "InstanceMetrics", key_lists, read, res_name: str = "", workers: int = 4):
+def stream_batches_from_processes(metrics: "InstanceMetrics", key_lists, read, res_name: str = "", workers: int = 4, slot_bytes: int | None = None):
     """``stream_batches`` with the reading and packing on forked reader processes (feeder.ProcessBatchFeeder): ``key_lists[k]`` are
     batch k's sweep keys and ``read(k)`` -- run in a worker -- returns its (frame dicts, comp_dis list | None).  The reference's loop
     gets its frames from ``DataLoader`` worker processes the same way; here it frees the launch thread's interpreter from the
@@ -554,7 +554,7 @@ def stream_batches_from_processes(metrics: "InstanceMetrics", key_lists, read, r
         frames, cds = item
         return EvalBatch.from_frames(list(frames), res_name, cds, device="reader process", upload=upload)
     t0 = time.perf_counter()
-    feeder = ProcessBatchFeeder(len(key_lists), read, build, workers=workers)
+    feeder = ProcessBatchFeeder(len(key_lists), read, build, workers=workers, **({} if slot_bytes is None else {"slot_bytes": slot_bytes}))
     metrics.warm_mark = None
     try:
         for k, eb in enumerate(feeder):

@@ -99,6 +99,37 @@ def test_h5_fixture_through_the_three_programs(gpu, oracle, tmp_path, monkeypatc
     assert ref.summary()["Total"]["num_obj"] > 0
 
 
+def test_reader_processes_with_slots_that_have_to_grow(gpu, tmp_path):
+    """feeder.ProcessBatchFeeder on the device: slots far smaller than a batch (the pool starts over with larger ones: registered
+    heads unregistered, workers forked again from a process that holds device state) and a reader's error -- the same result lists as
+    the reader threads, the error where the serial loop would meet it."""
+    import warnings
+    from himo_amd import eval as ev
+    from himo_amd.dataset import EVAL_FIELDS, open_dataset
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ds = open_dataset(H5, vis_name="seflowpp_best", eval=True, fields=EVAL_FIELDS + ("seflowpp_best",), zero_copy=True, allow_dropped_eval=True)
+    assert ds.fork_safe and len(ds) >= 4
+    key_lists = [list(range(lo, min(lo + 2, len(ds)))) for lo in range(0, len(ds), 2)]
+    read = lambda k: ([ds[i] for i in key_lists[k]], None)
+    want = ev.InstanceMetrics("av2")
+    ev.stream_batches(want, ((key_lists[k],) + read(k) for k in range(len(key_lists))), "seflowpp_best")
+    got = ev.InstanceMetrics("av2")
+    ev.stream_batches_from_processes(got, key_lists, read, "seflowpp_best", workers=2, slot_bytes=4096)
+    assert got.feed_stats["restarts"] >= 1 and got.feed_stats["slot_bytes"] > 4096 and got.feed_stats["batches"] == len(key_lists)
+    assert got.evaluate_data == want.evaluate_data and got.frame_cnt == want.frame_cnt == len(ds)
+    assert [k for k, _ in got._log] == [k for k, _ in want._log]
+
+    def failing(k):
+        if k == 1:
+            raise KeyError("seflowpp_missing")
+        return read(k)
+    partial = ev.InstanceMetrics("av2")
+    with pytest.raises(KeyError, match="seflowpp_missing"):
+        ev.stream_batches_from_processes(partial, key_lists, failing, "seflowpp_best", workers=2)
+    assert partial.frame_cnt + sum(t[1] for t in partial._pending) == len(key_lists[0])        # the batch before the failing one was scored
+
+
 def _torchrun(module, *args, cwd, nproc=2):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
