@@ -148,6 +148,30 @@ def test_full_size_sweeps_against_oracle(gpu, oracle):
     assert sum(len(v["num_pts"]) for v in mine.evaluate_data["CAR"]["vel"].values()) > 5
 
 
+def test_many_instances_in_any_point_order_against_oracle(gpu, oracle):
+    """The counting sort by (group, instance) (evalmetrics.hip rank_frames_kernel): points of an instance scattered through the sweep
+    (the fixtures keep them in runs), a few hundred instances per sweep (the hash-table path, several tiles per frame) and more
+    distinct instances than the table admits (the all-pairs path of that frame) -- in one batch, against the numpy + cKDTree oracle."""
+    from himo_amd.eval import InstanceMetrics
+    from himo_amd.synthetic import make_frame
+    frames = []
+    for seed, n_inst in ((60, 400), (61, 3000), (62, 30)):
+        f = make_frame(seed, n_points=120_000, n_instances=n_inst)
+        order = np.random.default_rng(seed).permutation(len(f["pc0"]))
+        for k in ("pc0", "lidar_dt", "lidar_id", "gm0", "flow", "flow_is_valid", "flow_category_indices", "flow_instance_id", RES):
+            f[k] = np.ascontiguousarray(f[k][order])
+        frames.append(f)
+    in_range = np.linalg.norm(frames[1]["pc0"][:, :2], axis=1) < 30.0
+    assert len(np.unique(frames[1]["flow_instance_id"][in_range])) > 1600          # (the table admits 1536 distinct labels)
+    mine, ref = InstanceMetrics("av2"), oracle.InstanceMetrics("av2")
+    mine.step_frames(frames, res_name=RES)
+    for f in frames:
+        oracle.eval_frame(ref, f, res_name=RES)
+    _approx_tree(json.loads(json.dumps(mine.evaluate_data, default=float)),
+                 json.loads(json.dumps(ref.evaluate_data, default=float)))
+    assert sum(len(v["num_pts"]) for v in mine.evaluate_data["CAR"]["vel"].values()) > 500
+
+
 def test_no_evaluated_points_is_a_noop(gpu):
     from himo_amd.eval import InstanceMetrics
     from himo_amd.synthetic import make_frame
