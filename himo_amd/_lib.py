@@ -140,7 +140,7 @@ def pinned_empty(numel: int, dtype=None):
     t = torch.empty(int(numel), dtype=dtype if dtype is not None else torch.uint8, pin_memory=True)
     lo = (t.data_ptr() + 4095) & ~4095
     n = (t.data_ptr() + t.numel() * t.element_size() - lo) & ~4095
-    if n > 0:
+    if n > 0 and os.environ.get("HIMO_PINNED_DONTFORK", "1") != "0":
         if _LIBC is None:
             _LIBC = ctypes.CDLL(None, use_errno=True)
         _LIBC.madvise(c_void_p(lo), c_size_t(n), 10)          # MADV_DONTFORK; advice only: a refusal changes nothing but fork's cost

@@ -435,16 +435,24 @@ class ReaderPool:
     the HIP runtime.  A fork write-protects the parent's private pages for copy-on-write; where those pages are mapped into the
     GPU's address space the driver takes the mappings away and rebuilds them at the next device operation: 0.2 s in a process that
     has only started the runtime, ~3 s in one that has run the evaluator (scripts/exp_fork_cost.py, profiles/r06_exp_fork_cost.txt).
-    Programs (``python -m himo_amd.eval``) therefore start their readers first thing."""
+    Programs (``python -m himo_amd.eval``) therefore start their readers first thing.
+
+    WHO forks matters too: ``os.fork()`` deletes, in the child, the interpreter state of every thread but the forking one -- their
+    frames and thread-local values are released THERE, and releasing a device or pinned tensor that has streams recorded on it calls
+    into a HIP runtime the child must not touch (observed: both children of a second generation segfault inside ``fork()`` when it
+    ran on the feeder thread while the main thread's frames held device tensors).  So: ``start()`` on the thread that owns the
+    process's device objects (the main thread, as ``DataLoader`` does), and ``restart=False`` wherever the pool iterates on another
+    thread of a process with device state -- a batch that does not fit is then an error naming the size to ask for, not a second fork."""
 
     def __init__(self, n_items: int, make, build, workers: int = 4, n_slots: int | None = None, slot_bytes: int = 512 << 20,
-                 on_slots=None, off_slots=None):
+                 on_slots=None, off_slots=None, restart: bool = True):
         import multiprocessing
         self.n, self._make, self._build = int(n_items), make, build
         self.workers = max(1, int(workers))
         self.n_slots = max(int(n_slots) if n_slots else self.workers + 2, 1)
         self.slot_bytes = int(slot_bytes)
         self._on_slots, self._off_slots = on_slots, off_slots
+        self._restart = restart
         self._ctx = multiprocessing.get_context("fork")
         self._procs, self._tasks, self._results = [], [], None
         self._maps, self.slots = [], []
@@ -496,7 +504,8 @@ class ReaderPool:
     def _start(self):
         import mmap
         t0 = time.perf_counter()
-        self._maps = [mmap.mmap(-1, self.slot_bytes) for _ in range(self.n_slots)]           # MAP_SHARED | MAP_ANONYMOUS
+        flags = mmap.MAP_SHARED | mmap.MAP_ANONYMOUS | getattr(mmap, "MAP_NORESERVE", 0)        # address space; pages arrive when touched
+        self._maps = [mmap.mmap(-1, self.slot_bytes, flags=flags) for _ in range(self.n_slots)]
         self.slots = [torch.frombuffer(m, dtype=torch.uint8) for m in self._maps]
         self._tasks = [self._ctx.SimpleQueue() for _ in range(self.workers)]
         self._results = self._ctx.SimpleQueue()
@@ -572,6 +581,9 @@ class ReaderPool:
                 if msg is None:
                     return
                 if msg[0] == "grow":
+                    if not self._restart:
+                        raise RuntimeError(f"batch {msg[1]} needs {msg[3]} bytes, the reader slots hold {self.slot_bytes}: construct the feeder "
+                                           f"with slot_bytes >= {int(msg[3] * 1.25)} (address space only: pages are committed as batches touch them)")
                     # start over from the oldest batch not handed out yet, with slots that hold this one
                     self._halt()
                     self.slot_bytes = max(int(msg[3] * 1.25) + 4096, self.slot_bytes)
@@ -598,10 +610,12 @@ class ProcessBatchFeeder:
 
     _END = object()
 
-    def __init__(self, n_items: int, make, build, device=None, depth: int = 2, workers: int = 4, slot_bytes: int = 512 << 20):
+    def __init__(self, n_items: int, make, build, device=None, depth: int = 2, workers: int = 4, slot_bytes: int = 2 << 30):
         self._registered = {}                          # slot -> bytes of its head registered with the runtime
+        # (no second generation of workers: this pool iterates on the feeder thread of a process with device state -- see ReaderPool;
+        # the slots are 2 GB of ADDRESS SPACE each, of which a batch commits and this process registers only what it uses)
         self.pool = ReaderPool(n_items, make, build, workers=workers, n_slots=workers + depth + 1, slot_bytes=slot_bytes,
-                               off_slots=self._unregister)
+                               off_slots=self._unregister, restart=False)
         self.forked_before_hip = not torch.cuda.is_initialized()
         self.pool.start()
         self.device = device if device is not None else _lib.require_gpu()

@@ -99,10 +99,10 @@ def test_h5_fixture_through_the_three_programs(gpu, oracle, tmp_path, monkeypatc
     assert ref.summary()["Total"]["num_obj"] > 0
 
 
-def test_reader_processes_with_slots_that_have_to_grow(gpu, tmp_path):
-    """feeder.ProcessBatchFeeder on the device: slots far smaller than a batch (the pool starts over with larger ones: registered
-    heads unregistered, workers forked again from a process that holds device state) and a reader's error -- the same result lists as
-    the reader threads, the error where the serial loop would meet it."""
+def test_reader_processes_on_the_device_errors_and_slots(gpu, tmp_path):
+    """feeder.ProcessBatchFeeder on the device, forked from a process that already holds device state: the same result lists as the
+    reader threads; a batch larger than a slot is an error that names the size to ask for (no second generation of workers is
+    forked from the feeder thread); a reader's error arrives where the serial loop would meet it."""
     import warnings
     from himo_amd import eval as ev
     from himo_amd.dataset import EVAL_FIELDS, open_dataset
@@ -115,10 +115,14 @@ def test_reader_processes_with_slots_that_have_to_grow(gpu, tmp_path):
     want = ev.InstanceMetrics("av2")
     ev.stream_batches(want, ((key_lists[k],) + read(k) for k in range(len(key_lists))), "seflowpp_best")
     got = ev.InstanceMetrics("av2")
-    ev.stream_batches_from_processes(got, key_lists, read, "seflowpp_best", workers=2, slot_bytes=4096)
-    assert got.feed_stats["restarts"] >= 1 and got.feed_stats["slot_bytes"] > 4096 and got.feed_stats["batches"] == len(key_lists)
+    ev.stream_batches_from_processes(got, key_lists, read, "seflowpp_best", workers=2, slot_bytes=1 << 20)
+    assert got.feed_stats["restarts"] == 0 and got.feed_stats["batches"] == len(key_lists)
     assert got.evaluate_data == want.evaluate_data and got.frame_cnt == want.frame_cnt == len(ds)
     assert [k for k, _ in got._log] == [k for k, _ in want._log]
+    small = ev.InstanceMetrics("av2")
+    with pytest.raises(RuntimeError, match="slot_bytes >= "):
+        ev.stream_batches_from_processes(small, key_lists, read, "seflowpp_best", workers=2, slot_bytes=4096)
+    assert small.frame_cnt == 0 and small.feed_stats["restarts"] == 0
 
     def failing(k):
         if k == 1:

@@ -72,6 +72,14 @@ def test_a_batch_that_does_not_fit_restarts_with_larger_slots():
     assert registered[0][0] == 4096 and registered[-1][0] == pool.slot_bytes
 
 
+def test_without_restart_a_batch_that_does_not_fit_is_an_error_naming_the_size():
+    pool = ReaderPool(5, _make, _build, workers=2, slot_bytes=4096, restart=False)
+    with pytest.raises(RuntimeError, match=r"slot_bytes >= \d+"):
+        for k, s, used, obj in pool:
+            pool.release(s)
+    assert pool.restarts == 0 and pool._procs == []
+
+
 def test_a_readers_exception_reaches_the_consumer():
     def make(k):
         if k == 4:
