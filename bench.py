@@ -1114,7 +1114,7 @@ def h5fed_leg(args, pipe, host_frames, device) -> dict:
     from himo_amd import h5lite, save
     from himo_amd.dataset import SAVE_FIELDS, HDF5Dataset
     B = args.frames_per_step
-    n_scenes, per_scene = 8, 2 * B + 9                       # 8 x 40 items of 16 = 20 batches (the last scene's results are written after the last batch: a tail the length of a batch or two)
+    n_scenes, per_scene = 8, int(os.environ.get("HIMO_BENCH_H5FED_BATCHES_PER_SCENE", "4")) * B + 9   # 8 x 72 items of 16 = 36 batches (the last scene's results are written after the last batch: a tail the length of a batch or two; 20 batches until round 6)
     root = Path(tempfile.mkdtemp(prefix="himo_h5fed_"))
     try:
         index = []

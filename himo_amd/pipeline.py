@@ -285,6 +285,17 @@ class OverlappedPipeline:
             out = pipe.run(samples, **kw)
             ev = torch.cuda.Event()
             ev.record(st)
+        # the batch's sweeps are read on ``st`` (packing, pillarisation), not on the stream they were allocated or handed over on: tell
+        # the allocator, or a caller that drops its Samples right after this call (a feeder loop) could see their memory handed out
+        # again -- and overwritten by the next upload -- before this batch has read it.  One call per distinct storage (a fed batch: one).
+        seen = set()
+        for smp in samples:
+            for t in (smp.pch1, smp.pc0, smp.pc1, smp.lidar_dt):
+                if t.is_cuda and t.numel():
+                    key = t.untyped_storage().data_ptr()
+                    if key not in seen:
+                        seen.add(key)
+                        t.record_stream(st)
         out["ready"], out["stream"] = ev, st
         return out
 
