@@ -100,6 +100,21 @@ def _return_arenas(arenas: list, events: list) -> None:
         _ARENA_POOL.extend(arenas)
 
 
+_COPY_STREAMS = {}
+_COPY_STREAMS_LOCK = threading.Lock()
+
+
+def copy_stream(device):
+    """The stream the inference / evaluation feeders issue their host -> device copies on: ONE per device and process.  Programs build a
+    feeder per call (per scene list, per bench leg); a stream per feeder would walk through torch's stream pool until one shares a
+    hardware queue with the streams the batches are computed on (``seflow.train.side_streams`` has the measurement)."""
+    key = (device.type, device.index)
+    with _COPY_STREAMS_LOCK:
+        if key not in _COPY_STREAMS:
+            _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
+        return _COPY_STREAMS[key]
+
+
 class SampleFeeder:
     """Iterate batches ``[(index, f0, Sample), ...]`` of up to ``batch`` frames, prepared ``depth`` batches ahead.
 
@@ -124,7 +139,7 @@ class SampleFeeder:
         self._q = queue.Queue(maxsize=depth)
         self._slots = [_PinnedArena() for _ in range(depth + 2)]      # a slot is reused only after its copies completed
         self._slot_done = [None] * (depth + 2)
-        self._stream = torch.cuda.Stream(device=self.device)
+        self._stream = copy_stream(self.device)
         self._error = None
         self._thread = threading.Thread(target=self._work, name="himo-feeder", daemon=True)
         self._thread.start()
@@ -303,7 +318,7 @@ class BatchFeeder:
         self._q = queue.Queue(maxsize=depth)
         self._slots = _borrow_arenas(depth + 2)
         self._slot_done = [None] * (depth + 2)
-        self._stream = torch.cuda.Stream(device=self.device)
+        self._stream = copy_stream(self.device)
         self._error = None
         self._stop = False
         from concurrent.futures import ThreadPoolExecutor
@@ -634,7 +649,7 @@ class ProcessBatchFeeder:
         self.device = device if device is not None else _lib.require_gpu()
         self.depth = depth
         self._q = queue.Queue(maxsize=depth)
-        self._stream = torch.cuda.Stream(device=self.device)
+        self._stream = copy_stream(self.device)
         self._error = None
         self._stop = False
         self._thread = threading.Thread(target=self._work, name="himo-process-feeder", daemon=True)

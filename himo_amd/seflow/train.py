@@ -505,7 +505,9 @@ class BucketedAllReduce:
         self.active = dist.is_available() and dist.is_initialized()
         self.backend = dist.get_backend() if self.active else None
         self.works, self.launched = [], set()
-        self.stream = torch.cuda.Stream(device=flat.device) if (flat.is_cuda and self.active) else None
+        # ONE communication stream per device and process (an exchange object is built every step: a stream per object would walk torch's
+        # stream pool across the hardware queues, side_streams below)
+        self.stream = comm_stream(flat.device) if (flat.is_cuda and self.active) else None
 
     def _reduce(self, t: torch.Tensor):
         import torch.distributed as dist
@@ -547,6 +549,15 @@ class BucketedAllReduce:
 
 
 _SIDE_STREAMS = {}
+_COMM_STREAMS = {}
+
+
+def comm_stream(device):
+    """The stream the gradient exchange runs on: one per device and process (see ``side_streams``)."""
+    key = (device.type, device.index)
+    if key not in _COMM_STREAMS:
+        _COMM_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _COMM_STREAMS[key]
 
 
 def side_streams(device) -> tuple:
