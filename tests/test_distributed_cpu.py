@@ -315,7 +315,14 @@ def test_eval_cli_under_torchrun_env_shards_the_sweeps(tmp_path):
 
 def _worker_combine(rank, world, port, out_dir):
     _init(rank, world, port)
-    from himo_amd.seflow.train import combine_batch_
+    from himo_amd.seflow.train import combine_batch_, global_count_known
+    # under a process group only the caller can know the step's global sample count on the host (fit does); a rank without samples is fine
+    assert global_count_known(2, None) is False and global_count_known(0, 3) is True and global_count_known(2, 3) is True
+    try:
+        global_count_known(0, 0)
+        raise AssertionError("a step without any sample must be refused")
+    except ValueError:
+        pass
     # a partial last batch of 3 samples on 2 ranks: rank 0 holds samples 0 and 2, rank 1 holds sample 1
     grads = [torch.tensor([1.0, 2.0, 3.0]), torch.tensor([10.0, 20.0, 30.0]), torch.tensor([100.0, 200.0, 300.0])]
     losses = [1.0, 2.0, 6.0]
@@ -326,7 +333,10 @@ def _worker_combine(rank, world, port, out_dir):
         for j in mine:
             acc[:3] += grads[j]; acc[3] += 1.0; acc[4] += losses[j]
         g = torch.zeros(3)
-        loss = combine_batch_(acc, g)
+        loss = combine_batch_(acc.clone(), g)
+        g2 = torch.zeros(3)
+        loss2 = combine_batch_(acc, g2, count_known=True)       # (the host has checked the count: no read-back; the same numbers)
+        assert torch.equal(g, g2) and float(loss) == float(loss2)
         out[name] = {"g": g.tolist(), "loss": float(loss)}
     Path(out_dir, f"rank{rank}.json").write_text(json.dumps(out))
     dist.destroy_process_group()

@@ -130,3 +130,14 @@ def test_evaluator_bucket_statistics_have_numpys_bits():
             warnings.simplefilter("ignore")
             got, want = M._nanmean_nanstd([np.float64(v) for v in vals]), (float(np.nanmean(vals)), float(np.nanstd(vals)))
         assert got == want or all(g != g and x != x or g == x for g, x in zip(got, want)), (vals, got, want)
+
+
+def test_the_host_knows_a_steps_sample_count_without_a_process_group():
+    """seflow.train.global_count_known: one process -> the local count decides (no device read-back at the end of a step); a step
+    without any sample is an error either way"""
+    from himo_amd.seflow.train import global_count_known
+    assert global_count_known(8, None) is True and global_count_known(3, 99) is True      # (no group: the caller's figure is ignored)
+    with pytest.raises(ValueError, match="at least one sample"):
+        global_count_known(0, None)
+    with pytest.raises(ValueError, match="at least one sample"):
+        global_count_known(0, 8)
