@@ -486,6 +486,9 @@ class OverlappedFastNSF:
         with torch.cuda.stream(st):
             flow = self.engines[k].fit_async(pc0, pc1, pose0, pose1)
         flow.record_stream(caller)          # ... and the flow is consumed there: its memory must not go back to the engine's stream early
+        for t in (pc0, pc1):                # ... and the sweeps are read on the engine's stream: a caller that drops them right after this call
+            if isinstance(t, torch.Tensor) and t.is_cuda and t.numel():        # (a generator of pairs) must not see their memory handed out again before
+                t.record_stream(st)
         self._busy[k] = True
         return k, flow
 
