@@ -207,7 +207,7 @@ def cpu_baseline_compdis(frames: list[dict], budget_s: float, exact_frames: int 
         legs["one_thread"] = legs["all_cores"]
     a, o = legs["all_cores"], legs["one_thread"]
     return {"value": a["frames_per_s"], "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-            "value_1_thread": o["frames_per_s"], "all_cores": a, "one_thread": o, "host_logical_cores": os.cpu_count(),
+            "value_1_thread": o["frames_per_s"], "all_cores": a, "one_thread": o, "host_logical_cores": os.cpu_count(), "cpu_quota_cores": cpu_quota_cores(),
             "sample": f"median of {a['frames_timed']} x {len(frames[0]['pc0'])}-pt frames (default BLAS threads) and of "
                       f"{o['frames_timed']} (1 thread) after warm-up: numpy oracle/himo_oracle.py comp_dis_frame_f32 "
                       f"(the arithmetic is element-wise numpy: the thread count barely matters)"}
@@ -281,7 +281,7 @@ def cpu_baseline_pipeline(host_samples, params, budget_s: float, exact_frames: i
         torch.set_num_threads(default_threads)
     a, o = legs["all_cores"], legs["one_thread"]
     return {"value": a["frames_per_s"], "unit": "frames/s", "cores": a["threads"], "kind": "port",
-            "value_1_thread": o["frames_per_s"], "all_cores": a, "one_thread": o, "host_logical_cores": os.cpu_count(),
+            "value_1_thread": o["frames_per_s"], "all_cores": a, "one_thread": o, "host_logical_cores": os.cpu_count(), "cpu_quota_cores": cpu_quota_cores(),
             "thread_probe_s_per_frame": {str(k): round(v, 3) for k, v in probe.items()},
             "sample": f"median of {a['frames_timed']} frame(s) after {a['warmup_frames']} warm-up(s) at {a['threads']} torch threads "
                       f"(the fastest of {sorted(probe) or [a['threads']]} on this host) "
@@ -353,6 +353,23 @@ def _dry_run_step(args, rank: int, world: int):
             if abs(float(flat[0]) - want) > 1e-6:
                 raise RuntimeError(f"all-reduce mean {float(flat[0])} != {want}")
     return step
+
+
+def cpu_quota_cores():
+    """CPUs this process may use at once according to its control group (cgroup v2 ``cpu.max`` / v1 ``cpu.cfs_quota_us``): the pool's
+    boxes show 256 logical cores and allow 16 -- which is where the CPU baseline's thread probe peaks and what caps every host-side
+    stage that runs in parallel (reader processes, staging threads).  None when unlimited or unreadable."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else round(int(quota) / int(period), 2)
+    except Exception:
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else round(quota / period, 2)
+    except Exception:
+        return None
 
 
 def main() -> int:
