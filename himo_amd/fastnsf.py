@@ -471,7 +471,8 @@ class OverlappedFastNSF:
     def __init__(self, device=None, engines: int = 2, **kw):
         self.device = device if device is not None else _lib.require_gpu()
         self.engines = [FastNSF(device=self.device, **kw) for _ in range(engines)]
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(engines)]
+        from .pipeline import batch_streams
+        self.streams = batch_streams(self.device, engines)          # (one list per process: pipeline.batch_streams)
         self._turn = 0
         self._busy = [False] * engines
 

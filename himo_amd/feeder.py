@@ -731,7 +731,7 @@ def _train_streams(device, n_label: int, priority: int = 0):
     streams (``seflow.train.side_streams`` has the measurement)."""
     key = (device.type, device.index, priority)
     with _TRAIN_STREAMS_LOCK:
-        copy, labels = _TRAIN_STREAMS.setdefault(key, (torch.cuda.Stream(device=device), []))
+        copy, labels = _TRAIN_STREAMS.setdefault(key, (copy_stream(device), []))            # (the process's one copy stream)
         while len(labels) < n_label:
             labels.append(torch.cuda.Stream(device=device, priority=priority))
         return copy, labels[:n_label]

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import os
+
 import numpy as np
 import torch
 
@@ -239,6 +241,24 @@ class HiMoPipeline:
         return out
 
 
+_BATCH_STREAMS = {}
+
+
+def batch_streams(device, n: int) -> list:
+    """The first ``n`` of the process's streams for batches in flight (``OverlappedPipeline``, ``fastnsf.OverlappedFastNSF``): ONE list per
+    device and process.  The HIP runtime multiplexes a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES: 8) and streams
+    that share a queue serialise; a process that builds pipeline after pipeline (bench.py's precision legs, a sweep over checkpoints)
+    would otherwise walk through torch's stream pool until unrelated streams collide (``seflow.train.side_streams`` has a measurement).
+    Two overlapped objects driven at the same time share these streams -- their batches then take turns instead of overlapping."""
+    if os.environ.get("HIMO_SHARED_BATCH_STREAMS", "1") == "0":          # (A/B knob: a fresh set per object, as before round 6)
+        return [torch.cuda.Stream(device=device) for _ in range(n)]
+    key = (device.type, device.index)
+    have = _BATCH_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:n]
+
+
 class OverlappedPipeline:
     """Several batches in flight (default three; two gave +4.5 %, the third +1 %): ``in_flight`` ``HiMoPipeline``s (own network
     buffers) fed in turn on as many HIP streams, so that one batch's
@@ -265,7 +285,7 @@ class OverlappedPipeline:
         for p in self.pipes[1:]:                                # one tuning table: a layer shape is timed once, by whoever meets it first
             if hasattr(p.net, "tiles") and hasattr(self.pipes[0].net, "tiles"):
                 p.net.tiles = self.pipes[0].net.tiles       # (the tile variants of a layer are bit-identical: tests/test_seflow_gpu.py)
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in self.pipes]
+        self.streams = batch_streams(self.device, len(self.pipes))
         self._turn = 0
 
     @property
