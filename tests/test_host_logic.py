@@ -141,3 +141,26 @@ def test_the_host_knows_a_steps_sample_count_without_a_process_group():
         global_count_known(0, None)
     with pytest.raises(ValueError, match="at least one sample"):
         global_count_known(0, 8)
+
+
+def test_when_the_evaluator_forks_reader_processes(monkeypatch):
+    """eval.reader_processes_default: 4 processes for a long evaluation of a dataset that survives a fork in a process without device
+    memory; reader threads otherwise; the environment overrides"""
+    from himo_amd import eval as ev
+
+    class Ds:
+        fork_safe = True
+    monkeypatch.delenv("HIMO_EVAL_WORKERS", raising=False)
+    assert ev.reader_processes_default(5000, Ds()) == 4
+    assert ev.reader_processes_default(1023, Ds()) == 0                      # too short to repay the start
+    assert ev.reader_processes_default(5000, object()) == 0                  # (an h5py-backed or in-memory dataset)
+    monkeypatch.setenv("HIMO_EVAL_WORKERS", "2")
+    assert ev.reader_processes_default(10, object()) == 2                    # main() still checks fork_safe before it forks
+    monkeypatch.setenv("HIMO_EVAL_WORKERS", "0")
+    assert ev.reader_processes_default(5000, Ds()) == 0
+    monkeypatch.delenv("HIMO_EVAL_WORKERS")
+    monkeypatch.setattr(ev.torch.cuda, "is_initialized", lambda: True)
+    monkeypatch.setattr(ev.torch.cuda, "memory_reserved", lambda *a: 1 << 20)
+    assert ev.reader_processes_default(5000, Ds()) == 0                      # a process that already holds device memory: a fork is paid for
+    monkeypatch.setattr(ev.torch.cuda, "memory_reserved", lambda *a: 0)
+    assert ev.reader_processes_default(5000, Ds()) == 4
