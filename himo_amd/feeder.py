@@ -309,9 +309,9 @@ class BatchFeeder:
 
     def __init__(self, source, build, device=None, depth: int = 2, stage_threads: int = 4):
         """``stage_threads``: threads that copy a batch's arrays into the pinned staging memory; 0 = on the feeder thread itself, one
-        numpy call per tensor -- slower staging (one core), but a consumer whose launch thread is interpreter-bound (the evaluator's
-        bucket bookkeeping) is slowed 2-3x by ANY second thread that wakes often, and a pool's futures are exactly that
-        (scripts/exp_eval_feed.py)"""
+        numpy call per tensor -- slower staging (one core), fewer threads contending with an interpreter-bound consumer (measured for
+        the evaluator, scripts/exp_eval_feed.py: no gain -- what had looked like contention there were the interpreter's full
+        collections, see eval.InstanceMetrics._accumulate_frame; the option stays for hosts with very few cores)"""
         self.device = device if device is not None else _lib.require_gpu()
         self.depth, self._build = depth, build
         self._source = iter(source)
